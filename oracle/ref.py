@@ -1,0 +1,87 @@
+"""Loader for the compiled reference natives in oracle/_ref (TEST INFRASTRUCTURE ONLY).
+
+``stardist2d`` / ``stardist3d`` are the reference's CPython extension modules
+(stardist/lib/stardist2d.cpp:621-646, stardist/lib/stardist3d.cpp:351-392) built by
+oracle/Makefile from /root/reference; ``clipper`` wraps oracle/clipper_shim.cpp, a
+pair-level probe around the vendored Clipper (call pattern of stardist2d.cpp:152-165).
+"""
+import ctypes
+import importlib.machinery
+import importlib.util
+import os
+import sysconfig
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REF = os.path.join(_HERE, "_ref")
+_EXT = sysconfig.get_config_var("EXT_SUFFIX")
+
+
+def available():
+    return os.path.exists(os.path.join(_REF, "stardist2d" + _EXT)) and \
+        os.path.exists(os.path.join(_REF, "stardist3d" + _EXT))
+
+
+def _load_ext(name):
+    path = os.path.join(_REF, name + _EXT)
+    if not os.path.exists(path):
+        raise ImportError("oracle/_ref/%s%s missing: run `make -C oracle ref` where /root/reference exists" % (name, _EXT))
+    loader = importlib.machinery.ExtensionFileLoader(name, path)
+    spec = importlib.util.spec_from_loader(name, loader)
+    mod = importlib.util.module_from_spec(spec)
+    loader.exec_module(mod)
+    return mod
+
+
+_cache = {}
+
+
+def stardist2d():
+    if "2d" not in _cache:
+        _cache["2d"] = _load_ext("stardist2d")
+    return _cache["2d"]
+
+
+def stardist3d():
+    if "3d" not in _cache:
+        _cache["3d"] = _load_ext("stardist3d")
+    return _cache["3d"]
+
+
+def _clipper():
+    if "clip" not in _cache:
+        lib = ctypes.CDLL(os.path.join(_REF, "libclipper_ref.so"))
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        lib.clipper_ref_area.restype = ctypes.c_float
+        lib.clipper_ref_area.argtypes = [i64p, i64p, ctypes.c_int, i64p, i64p, ctypes.c_int]
+        lib.clipper_ref_intersect.restype = ctypes.c_int
+        lib.clipper_ref_intersect.argtypes = [i64p, i64p, ctypes.c_int, i64p, i64p, ctypes.c_int,
+                                              i64p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+        _cache["clip"] = lib
+    return _cache["clip"]
+
+
+def _p64(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+
+
+def clipper_area(xa, ya, xb, yb):
+    """float32 intersection area exactly as stardist2d.cpp:152-165 (A = clip, B = subject)."""
+    xa, ya, xb, yb = (np.ascontiguousarray(v, np.int64) for v in (xa, ya, xb, yb))
+    return float(_clipper().clipper_ref_area(_p64(xa), _p64(ya), len(xa), _p64(xb), _p64(yb), len(xb)))
+
+
+def clipper_paths(xa, ya, xb, yb):
+    """Raw output paths of the vendored Clipper for the same call."""
+    xa, ya, xb, yb = (np.ascontiguousarray(v, np.int64) for v in (xa, ya, xb, yb))
+    out = np.zeros(2 * 1024, np.int64)
+    lens = np.zeros(64, np.int32)
+    n = _clipper().clipper_ref_intersect(_p64(xa), _p64(ya), len(xa), _p64(xb), _p64(yb), len(xb),
+                                         _p64(out), 1024, lens.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), 64)
+    assert n >= 0
+    paths, k = [], 0
+    for r in range(n):
+        paths.append(out[2 * k:2 * (k + lens[r])].reshape(-1, 2).copy())
+        k += lens[r]
+    return paths

@@ -1,0 +1,95 @@
+"""Seeded synthetic inputs of SURVEY.md section 8(d) (TEST INFRASTRUCTURE + bench inputs).
+
+Pure numpy; shared by the oracle and the GPU path so both see identical bytes.
+The generator definitions are normative (SURVEY.md "Generator specifications").
+"""
+import numpy as np
+
+
+def s2d_uniform(H, W, n_rays=32, radius=10, noise=0.1, prob_thresh=0.9, b=2, seed=42, dense=False):
+    """S2D-uniform, after the reference's tests/test_nms2D.py:9-15 (create_random_data).
+
+    Returns (dist (N,R) f32, points (N,2) f32, prob (N,) f32) sorted by prob descending with
+    the reference's ``argsort[::-1]`` (stardist/nms.py:114), or the dense (dist, prob) maps.
+    """
+    rng = np.random.RandomState(seed)
+    dist = (radius * np.ones((H, W, n_rays))).astype(np.float32) * \
+        (1 + noise * rng.uniform(-1, 1, (H, W, n_rays))).astype(np.float32)
+    prob = rng.uniform(0, 1, (H, W)).astype(np.float32)
+    if dense:
+        return dist, prob
+    mask = prob > np.float32(prob_thresh)
+    if b:
+        m2 = np.zeros_like(mask)
+        m2[b:-b, b:-b] = True
+        mask &= m2
+    pts = np.stack(np.where(mask), 1)
+    d = dist[mask]
+    s = prob[mask]
+    ind = np.argsort(s)[::-1]
+    return np.ascontiguousarray(d[ind]), np.ascontiguousarray(pts[ind].astype(np.float32)), np.ascontiguousarray(s[ind])
+
+
+def s3d_nuclei(N, rays_vertices, spacing=24, R=(7, 10), rc=3, seed=0):
+    """S3D-nuclei: spheres on a jittered lattice, candidates within rc voxels of each centre.
+
+    rays_vertices: (n_rays,3) unit vectors (z,y,x) of the ray set (Rays_GoldenSpiral(96)).
+    Returns (dist (N,R) f32, points (N,3) f32, prob (N,) f32) sorted by prob descending.
+    """
+    V = np.asarray(rays_vertices, np.float64)
+    rng = np.random.RandomState(seed)
+    g = np.arange(spacing // 2, N, spacing)
+    C = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
+    C += rng.uniform(-4, 4, C.shape)
+    Rs = rng.uniform(R[0], R[1], len(C))
+    o = np.arange(-rc, rc + 1)
+    off = np.stack(np.meshgrid(o, o, o, indexing="ij"), -1).reshape(-1, 3)
+    off = off[(off ** 2).sum(1) <= rc * rc]
+    P, D, S = [], [], []
+    for c, Rr in zip(C, Rs):
+        p = np.round(c).astype(np.int64) + off
+        p = p[np.all((p >= 2) & (p < N - 2), 1)]
+        q = p - c
+        bq = q @ V.T
+        t = -bq + np.sqrt(bq * bq - ((q * q).sum(1)[:, None] - Rr * Rr))
+        pr = 0.5 * np.clip(1 - np.sqrt((q * q).sum(1)) / Rr, 0, 1) + 0.5 * rng.uniform(0.9, 1, len(p))
+        P.append(p); D.append(t); S.append(pr)
+    P = np.concatenate(P).astype(np.float32)
+    D = np.maximum(np.concatenate(D), 1e-3).astype(np.float32)
+    S = np.concatenate(S).astype(np.float32)
+    ind = np.argsort(S)[::-1]
+    return np.ascontiguousarray(D[ind]), np.ascontiguousarray(P[ind]), np.ascontiguousarray(S[ind]), len(C)
+
+
+def s2d_nuclei_labels(H, W, spacing=32, R=(8, 14), seed=0):
+    """Label image of discs on a jittered lattice (S2D-nuclei). uint16, ids 1..K."""
+    rng = np.random.RandomState(seed)
+    g = np.arange(spacing // 2, max(H, W), spacing)
+    cy, cx = np.meshgrid(g[g < H], g[g < W], indexing="ij")
+    C = np.stack([cy.ravel(), cx.ravel()], 1).astype(np.float64)
+    C += rng.uniform(-6, 6, C.shape)
+    Rs = rng.uniform(R[0], R[1], len(C))
+    lbl = np.zeros((H, W), np.uint16)
+    for k, ((y, x), r) in enumerate(zip(C, Rs)):
+        y0, y1 = max(0, int(y - r - 1)), min(H, int(y + r + 2))
+        x0, x1 = max(0, int(x - r - 1)), min(W, int(x + r + 2))
+        yy, xx = np.mgrid[y0:y1, x0:x1]
+        m = (yy - y) ** 2 + (xx - x) ** 2 <= r * r
+        sub = lbl[y0:y1, x0:x1]
+        sub[m & (sub == 0)] = (k % 65535) + 1
+    return lbl, C, Rs
+
+
+def s2d_nuclei_image(H, W, seed=0, channels=1):
+    """Synthetic 'fluo' image for the U-Net leg: blurred disc mask + gaussian noise, float32 in ~[0,1]."""
+    lbl, _, _ = s2d_nuclei_labels(H, W, seed=seed)
+    rng = np.random.RandomState(seed + 1)
+    img = (lbl > 0).astype(np.float32)
+    # separable 5-tap box blur (no scipy dependency on the GPU box path)
+    k = np.ones(5, np.float32) / 5
+    img = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 0, img)
+    img = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 1, img)
+    img = img + rng.normal(0, 0.05, img.shape).astype(np.float32)
+    if channels > 1:
+        img = np.stack([img * (0.6 + 0.2 * c) for c in range(channels)], -1)
+    return img.astype(np.float32)
