@@ -1,0 +1,140 @@
+/* stardist_hip.h -- C ABI of libstardist_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the native layer of the StarDist prediction path.  Every entry point
+ * replaces one function of the reference's native modules `stardist.lib.stardist2d` /
+ * `stardist.lib.stardist3d` (CPython, positional args) or of its experimental plain-C ABI
+ * `libstardist3d` (stardist/lib/stardist3d_lib.h:52-79) and keeps that function's argument
+ * meaning, array layout (row-major, dense) and ownership rules:
+ *
+ *   - caller owns every buffer; inputs are never modified;
+ *   - `*_host` entry points (and the two `_LIB_*` names kept verbatim from the reference ABI)
+ *     take HOST pointers and do H2D/D2H themselves on the null stream;
+ *   - `*_device` entry points take DEVICE pointers plus a `hipStream_t` (passed as void*) and
+ *     enqueue all work on that stream; they synchronise the stream only where documented
+ *     (the NMS entry points do, because the greedy scan is driven from the host);
+ *   - return value: 0 on success, -1 on error (message via sd_last_error()); the two `_LIB_*`
+ *     functions return void like the reference and report errors on stderr.
+ *
+ * No torch / numpy types appear here.  The reference-side bindings (CPython / ctypes / JNA)
+ * are shown in INTEGRATION.md.
+ */
+#ifndef STARDIST_HIP_H
+#define STARDIST_HIP_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ------------------------------------------------------------------------------ */
+const char* sd_last_error(void);          /* message of the last failed call (thread-unsafe)   */
+int sd_version(void);                     /* ABI version, currently 1                          */
+int sd_device_count(void);                /* number of visible HIP devices (0 without a GPU)   */
+int sd_release_workspace(void);           /* free the cached device workspace                  */
+
+/* ---- 2D non-maximum suppression ------------------------------------------------------------
+ * replaces stardist.lib.stardist2d.c_non_max_suppression_inds
+ *   (stardist/lib/stardist2d.cpp:390-615; caller stardist/nms.py:186-227)
+ * dist   (n_polys, n_rays) float32, points (n_polys, 2) float32 (y, x), both sorted by score
+ * descending.  use_kdtree / use_bbox / verbose / threshold as in the reference ("O!O!iiif").
+ * keep   (n_polys,) bytes: 1 = survivor, 0 = suppressed (the reference returns NPY_BOOL).
+ * stats  optional int64[8] (may be NULL): {pairs evaluated, pairs re-run on the exact-join
+ *        path, greedy rounds, neighbour entries, 0...}.
+ */
+int sd_nms2d_host(const float* dist, const float* points, int n_polys, int n_rays,
+                  int use_kdtree, int use_bbox, int verbose, float threshold,
+                  uint8_t* keep, int64_t* stats);
+int sd_nms2d_device(const float* d_dist, const float* d_points, int n_polys, int n_rays,
+                    int use_kdtree, int use_bbox, int verbose, float threshold,
+                    uint8_t* d_keep, int64_t* stats, void* stream);
+
+/* pair-level probe used by the parity tests: intersection area of integer polygons exactly as
+ * poly_intersection_area (stardist2d.cpp:152-165) computes it.  xa..yb are device int32
+ * arrays of shape (n_pairs, n_verts); out_twice_area int64 (2*area), out_flags int32
+ * (bit0.. see clip_sweep.h status bits, bit8 = pair needed the join path). */
+int sd_clip_pairs_device(const int32_t* d_xa, const int32_t* d_ya, const int32_t* d_xb,
+                         const int32_t* d_yb, int n_pairs, int n_verts,
+                         int64_t* d_out_twice_area, int32_t* d_out_flags, void* stream);
+
+/* ---- star-convex distances (training targets; same native module) --------------------------
+ * replaces stardist.lib.stardist2d.c_star_dist (stardist2d.cpp:55-124)
+ * src (H, W) uint16 labels; dst (ceil(H/gy), ceil(W/gx), n_rays) float32. */
+int sd_star_dist2d_host(const uint16_t* src, int H, int W, int n_rays, int grid_y, int grid_x,
+                        float* dst);
+int sd_star_dist2d_device(const uint16_t* d_src, int H, int W, int n_rays, int grid_y,
+                          int grid_x, float* d_dst, void* stream);
+/* replaces stardist.lib.stardist3d.c_star_dist3d (stardist3d.cpp:245-346)
+ * src (Z, Y, X) uint16; dz/dy/dx (n_rays,) float32 ray unit vectors;
+ * dst (ceil(Z/gz), ceil(Y/gy), ceil(X/gx), n_rays) float32. */
+int sd_star_dist3d_host(const uint16_t* src, int Z, int Y, int X, const float* dz,
+                        const float* dy, const float* dx, int n_rays, int grid_z, int grid_y,
+                        int grid_x, float* dst);
+int sd_star_dist3d_device(const uint16_t* d_src, int Z, int Y, int X, const float* d_dz,
+                          const float* d_dy, const float* d_dx, int n_rays, int grid_z,
+                          int grid_y, int grid_x, float* d_dst, void* stream);
+
+/* ---- 2D label rasteriser --------------------------------------------------------------------
+ * replaces the Python loop stardist.geometry.geom2d.polygons_to_label_coord
+ *   (stardist/geometry/geom2d.py:149-166: skimage.draw.polygon per object, later objects
+ *   overwrite earlier ones).
+ * coord (n_polys, 2, n_rays) float32 (row 0 = y/r, row 1 = x/c), painted in array order;
+ * labels (n_polys,) int32: value written is labels[i]+1 (geom2d.py:164);
+ * result (H, W) int32, fully written (background 0). */
+int sd_polygons_to_label_host(const float* coord, const int32_t* labels, int n_polys, int n_rays,
+                              int H, int W, int32_t* result);
+int sd_polygons_to_label_device(const float* d_coord, const int32_t* d_labels, int n_polys,
+                                int n_rays, int H, int W, int32_t* d_result, void* stream);
+
+/* ---- 3D non-maximum suppression -------------------------------------------------------------
+ * name, signature and semantics of the reference's C ABI
+ *   (stardist/lib/stardist3d_lib.h:52-66 -> _COMMON_non_maximum_suppression_sparse,
+ *    stardist/lib/stardist3d_impl.cpp:956-1385; Python caller stardist/nms.py:327-384)
+ * host pointers; result (n_polys,) bool: true = survivor. */
+void _LIB_non_maximum_suppression_sparse(const float* scores, const float* dist,
+                                         const float* points, const int n_polys,
+                                         const int n_rays, const int n_faces, const float* verts,
+                                         const int* faces, const float threshold,
+                                         const int use_bbox, const int use_kdtree,
+                                         const int verbose, bool* result);
+int sd_nms3d_device(const float* d_scores, const float* d_dist, const float* d_points,
+                    int n_polys, int n_rays, int n_faces, const float* d_verts,
+                    const int* d_faces, float threshold, int use_bbox, int use_kdtree,
+                    int verbose, uint8_t* d_keep, int64_t* stats, void* stream);
+
+/* ---- 3D label rasteriser --------------------------------------------------------------------
+ * name, signature and semantics of the reference's C ABI
+ *   (stardist/lib/stardist3d_lib.h:69-77 -> _COMMON_polyhedron_to_label,
+ *    stardist/lib/stardist3d_impl.cpp:1404-1525; Python caller geom3d.py:100-198)
+ * result (nz, ny, nx) int32 must be zero-initialised by the caller (the reference only writes
+ * inside polyhedra). Polyhedra are given in painting order (first writer keeps the voxel). */
+void _LIB_polyhedron_to_label(const float* dist, const float* points, const float* verts,
+                              const int* faces, const int n_polys, const int n_rays,
+                              const int n_faces, const int* labels, const int nz, const int ny,
+                              const int nx, const int render_mode, const int verbose,
+                              const int use_overlap_label, const int overlap_label, int* result);
+int sd_polyhedron_to_label_device(const float* d_dist, const float* d_points,
+                                  const float* d_verts, const int* d_faces, int n_polys,
+                                  int n_rays, int n_faces, const int* d_labels, int nz, int ny,
+                                  int nx, int render_mode, int verbose, int use_overlap_label,
+                                  int overlap_label, int* d_result, void* stream);
+
+/* ---- candidate selection --------------------------------------------------------------------
+ * replaces the numpy glue stardist.nms._ind_prob_thresh + np.where + gather
+ *   (stardist/nms.py:6-17, stardist/models/base.py:553-610) on device.
+ * prob (n_pix,) float32 and dist (n_pix, n_rays) float32 are the network heads over a grid of
+ * `ndim` (2 or 3) dims `shape`; selects pixels with prob > thresh that are at least b[2*d] /
+ * b[2*d+1] grid cells from the low / high face of dim d, in C order (== np.where order).
+ * Writes out_prob (cap,), out_dist (cap, n_rays) = max(dist, 1e-3f), out_points (cap, ndim)
+ * int32 grid indices (NOT yet multiplied by the grid) and *d_count (int32) = number found
+ * (may exceed cap: then only the first cap are written). */
+int sd_select_candidates_device(const float* d_prob, const float* d_dist, int ndim,
+                                const int* shape, const int* b, int n_rays, float thresh,
+                                int cap, float* d_out_prob, float* d_out_dist,
+                                int32_t* d_out_points, int32_t* d_count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STARDIST_HIP_H */

@@ -1,0 +1,66 @@
+// lib.hip -- library-level entry points of libstardist_hip (error state, workspace arena).
+#include "common.h"
+#include "../../include/stardist_hip.h"
+#include <stdarg.h>
+
+namespace sd {
+
+static char g_err[1024] = "";
+char* err_buf() { return g_err; }
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static Arena g_arena;
+Arena& arena() { return g_arena; }
+
+size_t Arena::capacity() const { size_t t = 0; for (int i = 0; i < n_; ++i) t += cap_[i]; return t; }
+int Arena::begin(hipStream_t stream) {
+  if (n_ > 1) {
+    size_t total = capacity();
+    SD_CHECK(hipStreamSynchronize(stream));
+    for (int i = 0; i < n_; ++i) { (void)hipFree(base_[i]); base_[i] = nullptr; cap_[i] = 0; }
+    n_ = 0;
+    size_t want = total + (total >> 3);
+    SD_CHECK(hipMalloc(&base_[0], want));
+    cap_[0] = want; n_ = 1;
+  }
+  cur_ = 0; off_ = 0;
+  return 0;
+}
+void* Arena::take(size_t bytes) {
+  for (;;) {
+    if (cur_ < n_) {
+      size_t a = (off_ + 255) & ~size_t(255);
+      if (a + bytes <= cap_[cur_]) { off_ = a + bytes; return (char*)base_[cur_] + a; }
+      ++cur_; off_ = 0;
+      continue;
+    }
+    if (n_ >= kMaxChunks) { set_error("workspace arena: too many chunks"); return nullptr; }
+    size_t want = bytes + (bytes >> 2) + (size_t(4) << 20);
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { set_error("workspace arena: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return nullptr; }
+    base_[n_] = p; cap_[n_] = want; cur_ = n_; ++n_; off_ = 0;
+  }
+}
+void Arena::release() {
+  for (int i = 0; i < n_; ++i) { (void)hipFree(base_[i]); base_[i] = nullptr; cap_[i] = 0; }
+  n_ = 0; cur_ = 0; off_ = 0;
+}
+
+}  // namespace sd
+
+extern "C" {
+const char* sd_last_error(void) { return sd::err_buf(); }
+int sd_version(void) { return 1; }
+int sd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+int sd_release_workspace(void) { sd::arena().release(); return 0; }
+}

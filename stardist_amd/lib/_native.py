@@ -1,0 +1,100 @@
+"""ctypes binding of libstardist_hip.so (C ABI declared in include/stardist_hip.h).
+
+This is the only place the shared library is loaded.  There is NO CPU fallback: if the
+library is missing or no HIP device is visible, every compute entry point raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "..", "csrc", "libstardist_hip.so")
+
+_lib = None
+
+_c_f32p = ctypes.POINTER(ctypes.c_float)
+_c_i32p = ctypes.POINTER(ctypes.c_int32)
+_c_i64p = ctypes.POINTER(ctypes.c_int64)
+_c_u8p = ctypes.POINTER(ctypes.c_uint8)
+_c_u16p = ctypes.POINTER(ctypes.c_uint16)
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+
+# name -> (restype, argtypes); must list every symbol include/stardist_hip.h declares
+SIGNATURES = {
+    "sd_last_error": (ctypes.c_char_p, []),
+    "sd_version": (_i, []),
+    "sd_device_count": (_i, []),
+    "sd_release_workspace": (_i, []),
+    "sd_nms2d_host": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "sd_nms2d_device": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "sd_clip_pairs_device": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "sd_star_dist2d_host": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "sd_star_dist2d_device": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sd_star_dist3d_host": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sd_star_dist3d_device": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "sd_polygons_to_label_host": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sd_polygons_to_label_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "_LIB_non_maximum_suppression_sparse": (None, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _i, _i, _i, _vp]),
+    "sd_nms3d_device": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
+    "_LIB_polyhedron_to_label": (None, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sd_polyhedron_to_label_device": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sd_select_candidates_device": (_i, [_vp, _vp, _i, _vp, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the library is not built."""
+    global _lib
+    if _lib is None:
+        path = os.path.abspath(LIB_PATH)
+        if not os.path.exists(path):
+            raise NativeError("libstardist_hip.so not built (%s): run `python -m stardist_amd.build` "
+                              "or __graft_entry__.build(); there is no CPU fallback" % path)
+        l = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def require_device():
+    if lib().sd_device_count() < 1:
+        raise NativeError("no HIP device visible: the stardist_amd natives only run on a GPU "
+                          "(there is no CPU fallback)")
+
+
+def check(rc):
+    if rc != 0:
+        raise NativeError(lib().sd_last_error().decode(errors="replace"))
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def tptr(t):
+    """void* of a contiguous CUDA(=HIP) torch tensor."""
+    assert t.is_cuda and t.is_contiguous()
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

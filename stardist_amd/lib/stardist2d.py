@@ -1,0 +1,97 @@
+"""Mirror of the reference module `stardist.lib.stardist2d` (stardist/lib/stardist2d.cpp:621-646).
+
+Same function names, positional signatures, dtypes and return values; the work runs in
+libstardist_hip.so on the GPU.  numpy in -> numpy out (host entry points);
+torch CUDA tensors in -> torch CUDA tensors out (device entry points, current stream).
+"""
+import numpy as np
+
+from . import _native as N
+
+
+def c_non_max_suppression_inds(dist, points, use_kdtree, use_bbox, verbose, threshold, return_stats=False):
+    """stardist2d.cpp:390-615. dist (n,R) f32, points (n,2) f32 sorted by score desc -> bool (n,)."""
+    N.require_device()
+    stats = np.zeros(8, np.int64)
+    if N.is_torch(dist):
+        import torch
+        assert dist.dtype == torch.float32 and points.dtype == torch.float32
+        dist = dist.contiguous(); points = points.contiguous()
+        n, R = dist.shape
+        keep = torch.empty(n, dtype=torch.uint8, device=dist.device)
+        N.check(N.lib().sd_nms2d_device(N.tptr(dist), N.tptr(points), n, R, int(use_kdtree), int(use_bbox),
+                                        int(verbose), float(threshold), N.tptr(keep), N.ptr(stats), N.current_stream()))
+        keep = keep.bool()
+    else:
+        dist = np.ascontiguousarray(dist, np.float32)
+        points = np.ascontiguousarray(points, np.float32)
+        if dist.ndim != 2 or points.ndim != 2 or points.shape[1] != 2 or len(points) != len(dist):
+            raise ValueError("dist must be (n,n_rays) and points (n,2)")
+        n, R = dist.shape
+        keep = np.zeros(n, np.uint8)
+        N.check(N.lib().sd_nms2d_host(N.ptr(dist), N.ptr(points), n, R, int(use_kdtree), int(use_bbox),
+                                      int(verbose), float(threshold), N.ptr(keep), N.ptr(stats)))
+        keep = keep.astype(bool)
+    return (keep, stats) if return_stats else keep
+
+
+def c_star_dist(src, n_rays, grid_y, grid_x):
+    """stardist2d.cpp:55-124. src (H,W) uint16 -> (ceil(H/gy), ceil(W/gx), n_rays) f32."""
+    N.require_device()
+    n_rays, grid_y, grid_x = int(n_rays), int(grid_y), int(grid_x)
+    if N.is_torch(src):
+        import torch
+        assert src.dtype in (torch.uint16, torch.int16) and src.dim() == 2
+        src = src.contiguous()
+        H, W = src.shape
+        dst = torch.empty(((H - 1) // grid_y + 1, (W - 1) // grid_x + 1, n_rays), dtype=torch.float32, device=src.device)
+        N.check(N.lib().sd_star_dist2d_device(N.tptr(src), H, W, n_rays, grid_y, grid_x, N.tptr(dst), N.current_stream()))
+        return dst
+    src = np.ascontiguousarray(src)
+    if src.dtype != np.uint16:
+        # the reference reads the buffer as unsigned short whatever the dtype (stardist2d.cpp:83);
+        # its Python wrapper always casts (geom2d.py:31) -- do the cast here.
+        src = src.astype(np.uint16)
+    H, W = src.shape
+    dst = np.empty(((H - 1) // grid_y + 1, (W - 1) // grid_x + 1, n_rays), np.float32)
+    N.check(N.lib().sd_star_dist2d_host(N.ptr(src), H, W, n_rays, grid_y, grid_x, N.ptr(dst)))
+    return dst
+
+
+def c_polygons_to_label(coord, labels, shape):
+    """New native for the reference's Python rasteriser loop (geom2d.py:149-166).
+    coord (n,2,R) f32 painted in order, value labels[i]+1; returns int32 (H,W)."""
+    N.require_device()
+    H, W = int(shape[0]), int(shape[1])
+    if N.is_torch(coord):
+        import torch
+        coord = coord.contiguous().float()
+        labels = labels.contiguous().to(torch.int32)
+        n, _, R = coord.shape
+        out = torch.empty((H, W), dtype=torch.int32, device=coord.device)
+        N.check(N.lib().sd_polygons_to_label_device(N.tptr(coord), N.tptr(labels), n, R, H, W, N.tptr(out), N.current_stream()))
+        return out
+    coord = np.ascontiguousarray(coord, np.float32)
+    labels = np.ascontiguousarray(labels, np.int32)
+    n = coord.shape[0]
+    R = coord.shape[2] if coord.ndim == 3 else 0
+    out = np.zeros((H, W), np.int32)
+    if n:
+        N.check(N.lib().sd_polygons_to_label_host(N.ptr(coord), N.ptr(labels), n, R, H, W, N.ptr(out)))
+    return out
+
+
+def clip_pairs(xa, ya, xb, yb):
+    """Pair-level probe (tests): 2*area of A∩B per pair as the reference's Clipper call sums it.
+    xa..yb int32 (n_pairs, n_verts) numpy arrays. Returns (twice_area int64, flags int32)."""
+    import torch
+    N.require_device()
+    dev = torch.device("cuda")
+    t = [torch.from_numpy(np.ascontiguousarray(v, np.int32)).to(dev) for v in (xa, ya, xb, yb)]
+    n, R = t[0].shape
+    out = torch.zeros(n, dtype=torch.int64, device=dev)
+    fl = torch.zeros(n, dtype=torch.int32, device=dev)
+    N.check(N.lib().sd_clip_pairs_device(N.tptr(t[0]), N.tptr(t[1]), N.tptr(t[2]), N.tptr(t[3]), n, R,
+                                         N.tptr(out), N.tptr(fl), N.current_stream()))
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), fl.cpu().numpy()

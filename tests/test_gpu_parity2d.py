@@ -1,0 +1,97 @@
+"""GPU parity tests (2D): the HIP path through the C ABI vs the compiled reference (oracle/_ref)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _star_polys(rng, n, R, radius, noise, spread):
+    """integer star polygons built with the reference's vertex arithmetic (stardist2d.cpp:447-471)"""
+    ang = np.float32(2 * np.pi / R)
+    k = np.arange(R, dtype=np.int32)
+    s = np.sin((ang * k).astype(np.float32)).astype(np.float32)
+    c = np.cos((ang * k).astype(np.float32)).astype(np.float32)
+    d = (radius * (1 + noise * rng.uniform(-1, 1, (n, R)))).astype(np.float32)
+    d = np.maximum(d, np.float32(1e-3))
+    p = np.floor(rng.uniform(50, 50 + spread, (n, 2))).astype(np.float32)
+    y = (p[:, :1] + d * s).astype(np.float32)
+    x = (p[:, 1:] + d * c).astype(np.float32)
+    return x.astype(np.int64).astype(np.int32), y.astype(np.int64).astype(np.int32)
+
+
+@pytest.mark.parametrize("R,radius,noise", [(32, 10, 0.1), (32, 10, 0.9), (32, 3, 0.5), (11, 10, 0.3), (64, 20, 0.3), (100, 30, 0.6)])
+def test_pair_area_matches_clipper(refmods, R, radius, noise):
+    from stardist_amd.lib import stardist2d as sd2
+    rng = np.random.RandomState(R * 1000 + int(radius))
+    n = 4000
+    xa, ya = _star_polys(rng, n, R, radius, noise, 12)
+    xb, yb = _star_polys(rng, n, R, radius * 0.8, noise, 12)
+    twice, flags = sd2.clip_pairs(xa, ya, xb, yb)
+    assert not np.any(flags & 0xFF), "capacity overflow flags set"
+    ref_area = np.array([refmods.clipper_area(xa[i], ya[i], xb[i], yb[i]) for i in range(n)], np.float32)
+    mine = (0.5 * twice.astype(np.float32)).astype(np.float32)
+    bad = np.flatnonzero(mine != ref_area)
+    joins = np.flatnonzero(flags & 256)
+    # every mismatch must be a pair that needed the join path
+    assert set(bad.tolist()) <= set(joins.tolist()), (bad[:10], mine[bad[:10]], ref_area[bad[:10]])
+    assert len(bad) == 0, "join-path mismatches: %d of %d (join pairs %d)" % (len(bad), n, len(joins))
+
+
+@pytest.mark.parametrize("shape,R,thr", [((256, 256), 32, 0.4), ((512, 512), 32, 0.4), ((356, 299), 11, 0.5), ((114, 217), 32, 0.3)])
+def test_nms2d_survivors_bit_exact(refmods, shape, R, thr):
+    from oracle import synth
+    from stardist_amd.lib import stardist2d as sd2
+    d, p, s = synth.s2d_uniform(shape[0], shape[1], n_rays=R)
+    ref_keep = refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(thr))
+    keep, stats = sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(thr), return_stats=True)
+    assert keep.dtype == bool and keep.shape == ref_keep.shape
+    diff = np.flatnonzero(keep != ref_keep)
+    assert len(diff) == 0, "survivor mismatch at %s (pairs=%d joins=%d)" % (diff[:10], stats[0], stats[1])
+
+
+@pytest.mark.parametrize("flags", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_nms2d_flags(refmods, flags):
+    from oracle import synth
+    from stardist_amd.lib import stardist2d as sd2
+    d, p, s = synth.s2d_uniform(128, 160, n_rays=32, prob_thresh=0.8)
+    kd, bb = flags
+    for thr in (0.0, 0.3, 0.7):
+        ref_keep = refmods.stardist2d().c_non_max_suppression_inds(d, p, kd, bb, 0, np.float32(thr))
+        keep = sd2.c_non_max_suppression_inds(d, p, kd, bb, 0, np.float32(thr))
+        assert np.array_equal(keep, ref_keep), (flags, thr)
+
+
+def test_nms2d_edge_cases(refmods):
+    from stardist_amd.lib import stardist2d as sd2
+    assert sd2.c_non_max_suppression_inds(np.zeros((0, 32), np.float32), np.zeros((0, 2), np.float32), 1, 1, 0, 0.4).shape == (0,)
+    d = np.full((1, 32), 5, np.float32); p = np.full((1, 2), 20, np.float32)
+    assert sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, 0.4).tolist() == [True]
+    # identical polygons: the second is suppressed
+    d = np.full((2, 32), 5, np.float32); p = np.full((2, 2), 20, np.float32)
+    assert sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, 0.4).tolist() == refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4)).tolist()
+    # degenerate tiny distances (clamped 1e-3 as base.py:556 does)
+    d = np.full((50, 32), 1e-3, np.float32); p = np.random.RandomState(0).randint(5, 20, (50, 2)).astype(np.float32)
+    assert np.array_equal(sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, 0.4), refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4)))
+
+
+@pytest.mark.parametrize("n_rays,grid", [(32, (1, 1)), (17, (2, 2)), (64, (1, 4)), (4, (3, 1))])
+def test_star_dist2d_bit_exact(refmods, n_rays, grid):
+    from oracle import synth
+    from stardist_amd.lib import stardist2d as sd2
+    lbl, _, _ = synth.s2d_nuclei_labels(200, 231, seed=3)
+    ref_d = refmods.stardist2d().c_star_dist(lbl, n_rays, grid[0], grid[1])
+    d = sd2.c_star_dist(lbl, n_rays, grid[0], grid[1])
+    assert d.shape == ref_d.shape and d.dtype == np.float32
+    assert np.array_equal(d, ref_d), np.abs(d - ref_d).max()
+
+
+def test_raster2d_matches_port(refmods):
+    from oracle import port, synth
+    from stardist_amd.lib import stardist2d as sd2
+    d, p, s = synth.s2d_uniform(96, 128, n_rays=32, prob_thresh=0.97)
+    coord = port.dist_to_coord(d, p)
+    ind = np.argsort(s, kind="stable")
+    ref_lbl = port.polygons_to_label_coord(coord[ind], (96, 128), labels=ind)
+    lbl = sd2.c_polygons_to_label(coord[ind], ind.astype(np.int32), (96, 128))
+    assert lbl.dtype == np.int32
+    assert np.array_equal(lbl, ref_lbl), np.count_nonzero(lbl != ref_lbl)
