@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py -- end-to-end predict_instances() throughput of the MI355X-native StarDist path.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W` prints ONE
+JSON line on rank 0.  One "step" = one full `StarDist2D.predict_instances()` on one synthetic
+2048x2048 image already resident in HBM (BASELINE.json configs[1]): U-Net forward (fp32,
+channels_last) -> threshold/compaction -> score sort -> polygon NMS -> label rasteriser ->
+labels + survivor dict back on the host.  N > 1: one process per GPU (torchrun), each rank owns
+its own image of the same size ("weak" scaling, independent tiles, no data-path collective);
+value = total pixels of all ranks / max-over-ranks time.
+
+Weights are seeded random (no checkpoints offline).  The two 1x1 heads are re-scaled once,
+before timing, so that the network's own outputs have the candidate statistics of the
+reference's NMS test data (tests/test_nms2D.py:9-15: ~10 % of pixels above the probability
+threshold, radius 10 +- 10 %); otherwise a random net yields either zero or millions of
+candidates and the NMS/raster stages would be meaningless.  Nothing is skipped in the timed
+region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def calibrate_heads(model, img, frac=0.10, radius=10.0, noise=0.1):
+    """Re-scale the prob/dist 1x1 heads (weights stay seeded-random directions) so that `frac` of the
+    pixels exceed prob 0.5 and dist ~ radius*(1 +- noise)."""
+    import torch
+    net = model.net
+    feats = {}
+    h = net.features.register_forward_hook(lambda m, i, o: feats.__setitem__("f", o))
+    with torch.no_grad():
+        model.predict(img)
+    h.remove()
+    f = feats["f"].float()
+    with torch.no_grad():
+        z = net.prob(f) - net.prob.bias.reshape(1, -1, *([1] * (f.dim() - 2)))
+        zs = z.flatten()
+        if zs.numel() > 4_000_000:
+            zs = zs[:: zs.numel() // 4_000_000]
+        q = torch.quantile(zs, 1.0 - frac)
+        net.prob.bias.fill_(float(-q))
+        d = net.dist(f) - net.dist.bias.reshape(1, -1, *([1] * (f.dim() - 2)))
+        sd = float(d.std())
+        net.dist.weight.mul_(radius * noise * 0.58 / max(sd, 1e-12))
+        net.dist.bias.fill_(radius)
+
+
+def cpu_baseline(img_np, model, sample, threads):
+    """Reference CPU path on a bounded sample (sample x sample crop of the same image):
+    U-Net = the same PyTorch module on CPU (stand-in for TF-CPU, which is not installed -- flagged
+    deviation), post-processing = the COMPILED REFERENCE natives (oracle/_ref: stardist2d.cpp + Clipper
+    + nanoflann, OpenMP) + the numpy restatement of the Python rasteriser loop."""
+    import copy
+    import torch
+    from oracle import port, ref
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    torch.set_num_threads(threads)
+    x = img_np[:sample, :sample]
+    net_cpu = copy.deepcopy(model.net).to("cpu").float()
+    t0 = time.time()
+    with torch.no_grad():
+        xc = torch.from_numpy(x)[None, None]
+        prob, dist = net_cpu(xc)
+    prob = prob[0, 0].numpy()
+    dist = np.maximum(1e-3, np.moveaxis(dist[0].numpy(), 0, -1))
+    t_net = time.time() - t0
+    t0 = time.time()
+    mask = port.ind_prob_thresh(prob, model.thresholds.prob, b=2)
+    pts = np.stack(np.where(mask), 1)
+    d, s = dist[mask], prob[mask]
+    ind = np.argsort(s)[::-1]
+    d, s, pts = d[ind], s[ind], pts[ind]
+    keep = ref.stardist2d().c_non_max_suppression_inds(np.ascontiguousarray(d, np.float32),
+                                                       np.ascontiguousarray(pts.astype(np.float32)), 1, 1, 0,
+                                                       np.float32(model.thresholds.nms))
+    t_nms = time.time() - t0
+    t0 = time.time()
+    port.polygons_to_label(d[keep], pts[keep], prob=s[keep], shape=x.shape)
+    t_ras = time.time() - t0
+    tot = t_net + t_nms + t_ras
+    return dict(value=round(x.size / tot / 1e6, 4), unit="Mpix/s", cores=threads, kind="reference",
+                sample="%dx%d crop of the bench image: torch-CPU U-Net %.2fs (TF-CPU stand-in) + compiled reference NMS "
+                       "(oracle/_ref, %d candidates -> %d) %.2fs + numpy rasteriser restatement %.2fs"
+                       % (sample, sample, t_net, len(d), int(keep.sum()), t_nms, t_ras))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=2048)
+    ap.add_argument("--dtype", default="float32", choices=["float32", "bfloat16", "float16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist_
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local_rank)
+        dist_.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" IS RCCL on ROCm
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from oracle import synth                       # input generator only (numpy), shared with the tests
+    from stardist_amd.models import Config2D, StarDist2D
+    from stardist_amd.models.unet import conv_macs_per_input_pixel
+
+    H = W = args.size
+    img_np = synth.s2d_nuclei_image(H, W, seed=rank)
+    img = torch.from_numpy(img_np).to(dev)
+    model = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0, compute_dtype=args.dtype)
+    calibrate_heads(model, img)
+    macs = conv_macs_per_input_pixel(model.net, model.config)
+
+    # ---- per-stage instrumentation with HIP events on torch's current stream (the stream every
+    # kernel of the path is launched on: the natives receive torch.cuda.current_stream()).
+    stage_ms = {"net": 0.0, "post": 0.0}
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    orig_forward = model._net_forward
+
+    def timed_forward(x):
+        a, b = ev(), ev()
+        a.record(); r = orig_forward(x); b.record()
+        timed_forward.pairs.append((a, b))
+        return r
+    timed_forward.pairs = []
+    model._net_forward = timed_forward
+
+    def step():
+        return model.predict_instances(img)
+
+    n_cand = n_keep = 0
+    for _ in range(args.warmup):
+        labels, res = step()
+    timed_forward.pairs.clear()
+    if world > 1:
+        dist_.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        labels, res = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist_.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    net_ms = sum(a.elapsed_time(b) for a, b in timed_forward.pairs) / max(1, len(timed_forward.pairs))
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist_.all_reduce(tt, op=dist_.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    n_keep = len(res["prob"])
+
+    if rank == 0:
+        # dense candidate count of the last step (for the record)
+        p, d = model.predict(img)
+        n_cand = int(((p > model.thresholds.prob)[2:-2, 2:-2]).sum())
+        value = world * H * W * args.steps / elapsed / 1e6
+        flops = 2.0 * macs * H * W
+        peak = MFMA_F32_PEAK_TFLOPS if args.dtype == "float32" else MFMA_BF16_PEAK_TFLOPS
+        ach = flops / (net_ms * 1e-3) / 1e12
+        post_ms = ms_per_step - net_ms
+        out = {
+            "metric": "predict_instances() Mpix/s (2D) + Mvox/s (3D) end-to-end at 1/2/4/8 GPU",
+            "value": round(value, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[args.dtype], "data": "synthetic",
+            "config": {"workload": "StarDist2D 32-ray U-Net (depth 3, 32 base filters), %dx%d synthetic fluo tile per GPU, "
+                                   "predict_instances (U-Net + select + 2D NMS + polygon raster), seeded random weights, "
+                                   "heads calibrated to ~10%% candidates radius 10+-10%%" % (H, W),
+                       "candidates": n_cand, "survivors": n_keep, "prob_thresh": model.thresholds.prob,
+                       "nms_thresh": model.thresholds.nms, "parallelism": "tiles-per-gpu x%d" % world},
+            "stages_ms": {"unet_forward": round(net_ms, 3), "select_sort_nms_raster_d2h": round(post_ms, 3)},
+            "roofline": {"bound": "mfma", "kernel": "U-Net conv stack (MIOpen/rocBLAS kernels, fp32 NHWC)",
+                         "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                         "traffic": None, "flops_per_launch": flops, "avg_ms": round(net_ms, 3)},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                threads = args.cpu_threads or min(os.cpu_count() or 1, 32)
+                out["cpu_baseline"] = cpu_baseline(img_np, model, min(args.cpu_sample, H), threads)
+            except Exception as e:   # the oracle is optional at run time (prebuilt oracle/_ref must have travelled)
+                out["cpu_baseline"] = {"value": None, "unit": "Mpix/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist_.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -88,10 +88,15 @@ __global__ void __launch_bounds__(256) k_build(const float* __restrict__ dist, c
     area[i] = (float)(0.5 * (double)fabsf(a));
     radius[i] = rmax;
     bbox[i] = make_int4((int)xmin, (int)xmax, (int)ymin, (int)ymax);   // bbox_intersect takes ints :142-148
-    atomicMax(&gstats[0], __float_as_int(rmax));
+    // contended global atomics only when the running extremum actually improves
+    const int rb = __float_as_int(rmax);
     const int iy = (int)floorf(py), ix = (int)floorf(px);
-    atomicMin(&gstats[1], iy); atomicMax(&gstats[2], iy);
-    atomicMin(&gstats[3], ix); atomicMax(&gstats[4], ix);
+    volatile int* gs = gstats;
+    if (rb > gs[0]) atomicMax(&gstats[0], rb);
+    if (iy < gs[1]) atomicMin(&gstats[1], iy);
+    if (iy > gs[2]) atomicMax(&gstats[2], iy);
+    if (ix < gs[3]) atomicMin(&gstats[3], ix);
+    if (ix > gs[4]) atomicMax(&gstats[4], ix);
   }
 }
 
@@ -178,19 +183,28 @@ __global__ void __launch_bounds__(256) k_neighbours(int N, GridP g, Flags f, con
 // Round kernel A: wave per undecided candidate.
 __global__ void __launch_bounds__(256) k_round_decide(const int* __restrict__ U, int nU, const unsigned char* __restrict__ state,
                                                       const i64* __restrict__ nbrStart, const int* __restrict__ nbr,
-                                                      int* __restrict__ Unext, int* __restrict__ K, int* counters /*0:nUnext 1:nK*/) {
+                                                      int* __restrict__ waitOn, int* __restrict__ Unext, int* __restrict__ K,
+                                                      int* counters /*0:nUnext 1:nK*/) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int w = blockIdx.x * (blockDim.x >> 6) + wave;
   if (w >= nU) return;
   const int i = U[w];
   if (state[i] == ST_SUPPRESSED) return;
-  const i64 beg = nbrStart[i], end = nbrStart[i + 1];
-  bool pending = false;
-  for (i64 t = beg; t < end && !pending; t += 64) {
-    const i64 idx = t + lane;
-    bool p = false;
-    if (idx < end) { const int j = nbr[idx]; p = (j < i) && (state[j] == ST_UNDECIDED); }
-    pending = __any(p);
+  // the undecided higher-scored neighbour found last round is checked first: most waits persist
+  const int wo = waitOn[i];
+  bool pending = (wo >= 0) && (state[wo] == ST_UNDECIDED);
+  if (!pending) {
+    const i64 beg = nbrStart[i], end = nbrStart[i + 1];
+    int found = -1;
+    for (i64 t = beg; t < end && found < 0; t += 64) {
+      const i64 idx = t + lane;
+      int j = -1;
+      if (idx < end) { j = nbr[idx]; if (!(j < i && state[j] == ST_UNDECIDED)) j = -1; }
+      const unsigned long long m = __ballot(j >= 0);
+      if (m) found = __shfl(j, __ffsll((long long)m) - 1);
+    }
+    pending = found >= 0;
+    if (lane == 0 && pending) waitOn[i] = found;
   }
   if (lane == 0) {
     if (pending) Unext[atomicAdd(&counters[0], 1)] = i;
@@ -385,8 +399,8 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   hipLaunchKernelGGL(k_cell_count, dim3(sd::div_up(N, 256)), dim3(256), 0, s, d_points, N, g, cellCount, candCell);
   SD_LAUNCH_CHECK();
   size_t tmpBytes = 0, tmpBytes2 = 0;
-  hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, cellCount, cellStart, nCells + 1, s);
-  hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes2, nbrCount, nbrStart, N + 1, s);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, cellCount, cellStart, nCells + 1, s);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes2, nbrCount, nbrStart, N + 1, s);
   if (tmpBytes2 > tmpBytes) tmpBytes = tmpBytes2;
   void* scanTmp = A.take(tmpBytes + 256);
   if (!scanTmp) return -1;
@@ -416,6 +430,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   const unsigned long long pairCap = (unsigned long long)(totalNbr / 2 + 64);
   int* U0 = A.take_n<int>(N);
   int* U1 = A.take_n<int>(N);
+  int* waitOn = A.take_n<int>(N);
   int* K = A.take_n<int>(N);
   int2* pairs = A.take_n<int2>(pairCap);
   const unsigned int joinCap = (unsigned int)(pairCap < (1ull << 30) ? pairCap : (1ull << 30));
@@ -424,6 +439,8 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   int* joinFlags = A.take_n<int>(joinCap);
   struct Counters { int nU, nK; unsigned long long nPairs; unsigned int nJoin, nErr; };
   Counters* d_cnt = (Counters*)A.take(sizeof(Counters));
+  if (!waitOn) return -1;
+  SD_CHECK(hipMemsetAsync(waitOn, 0xFF, (size_t)N * sizeof(int), s));
   if (!U0 || !U1 || !K || !pairs || !joinPairs || !joinTwice || !joinFlags || !d_cnt) return -1;
   hipLaunchKernelGGL(k_iota, dim3(sd::div_up(N, 256)), dim3(256), 0, s, U0, N);
   int nU = N, rounds = 0;
@@ -433,7 +450,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   while (nU > 0) {
     ++rounds;
     SD_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), s));
-    hipLaunchKernelGGL(k_round_decide, dim3(sd::div_up(nU, 4)), dim3(256), 0, s, Ucur, nU, state, nbrStart, nbr, Unext, K, (int*)d_cnt);
+    hipLaunchKernelGGL(k_round_decide, dim3(sd::div_up(nU, 4)), dim3(256), 0, s, Ucur, nU, state, nbrStart, nbr, waitOn, Unext, K, (int*)d_cnt);
     SD_LAUNCH_CHECK();
     SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
     SD_CHECK(hipStreamSynchronize(s));

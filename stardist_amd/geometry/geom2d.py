@@ -1,0 +1,89 @@
+"""Mirror of stardist/geometry/geom2d.py (hot-path functions) on top of the HIP natives."""
+import numpy as np
+
+from ..lib import _native as N
+from ..utils import _normalize_grid
+
+
+def ray_angles(n_rays=32):
+    """geom2d.py:214-215"""
+    return np.linspace(0, 2 * np.pi, n_rays, endpoint=False)
+
+
+def star_dist(a, n_rays=32, grid=(1, 1), mode="hip"):
+    """geom2d.py:73-85. 'a' is a label image (0 = background). mode 'hip' replaces 'cpp'/'opencl'."""
+    from ..lib.stardist2d import c_star_dist
+    n_rays >= 3 or (_ for _ in ()).throw(ValueError("need 'n_rays' >= 3"))
+    if mode not in ("hip", "cpp", "opencl"):
+        raise ValueError("Unknown mode %s" % mode)
+    grid = _normalize_grid(grid, 2)
+    if N.is_torch(a):
+        import torch
+        return c_star_dist(a.to(torch.uint16) if a.dtype != torch.uint16 else a, np.int32(n_rays), np.int32(grid[0]), np.int32(grid[1]))
+    return c_star_dist(a.astype(np.uint16, copy=False), np.int32(n_rays), np.int32(grid[0]), np.int32(grid[1]))
+
+
+def dist_to_coord(dist, points, scale_dist=(1, 1)):
+    """geom2d.py:130-146: polar -> cartesian, coord (n_polys, 2, n_rays) float32."""
+    assert dist.ndim == 2 and points.ndim == 2 and len(dist) == len(points) and points.shape[1] == 2 and len(scale_dist) == 2
+    n_rays = dist.shape[1]
+    phis = ray_angles(n_rays)
+    sc = np.array([np.sin(phis), np.cos(phis)])           # float64 (2, n_rays)
+    if N.is_torch(dist):
+        import torch
+        sct = torch.as_tensor(sc, device=dist.device)                      # float64
+        coord = (dist[:, None].to(torch.float64) * sct).to(torch.float32)  # f32*f64 product -> f32, as numpy does
+        sd = torch.as_tensor(np.asarray(scale_dist, np.float64).reshape(1, 2, 1), device=dist.device)
+        coord = (coord.to(torch.float64) * sd).to(torch.float32) if tuple(scale_dist) != (1, 1) else coord
+        # in-place float32 += (points cast to float32), as numpy's `coord += points[...,None]`
+        coord = coord + points[..., None].to(torch.float32)
+        return coord
+    dist = np.asarray(dist); points = np.asarray(points)
+    coord = (dist[:, np.newaxis] * sc).astype(np.float32)
+    coord *= np.asarray(scale_dist).reshape(1, 2, 1)
+    coord += points[..., np.newaxis]
+    return coord
+
+
+def polygons_to_label_coord(coord, shape, labels=None):
+    """geom2d.py:149-166: paint polygons in the given order (later overwrite earlier), value labels[i]+1."""
+    from ..lib.stardist2d import c_polygons_to_label
+    assert coord.ndim == 3 and coord.shape[1] == 2
+    n = len(coord)
+    if N.is_torch(coord):
+        import torch
+        if labels is None:
+            labels = torch.arange(n, device=coord.device)
+        assert len(labels) == n
+        return c_polygons_to_label(coord, labels.to(torch.int32), shape)
+    coord = np.asarray(coord)
+    if labels is None:
+        labels = np.arange(n)
+    labels = np.asarray(labels)
+    if not (np.issubdtype(labels.dtype, np.integer) or labels.dtype == bool):
+        raise ValueError("labels must be an array of integers")
+    assert len(labels) == n
+    return c_polygons_to_label(coord, labels.astype(np.int32), shape)
+
+
+def polygons_to_label(dist, points, shape, prob=None, thr=-np.inf, scale_dist=(1, 1)):
+    """geom2d.py:169-197: label ids are consecutive and adhere to the order given."""
+    assert dist.ndim == 2 and points.ndim == 2 and len(dist) == len(points) and points.shape[1] == 2
+    if N.is_torch(dist):
+        import torch
+        prob = torch.full((len(points),), float("inf"), device=dist.device) if prob is None else prob
+        ind = prob > thr
+        points, dist, prob = points[ind], dist[ind], prob[ind]
+        ind = torch.sort(prob, stable=True)[1]
+        points, dist = points[ind], dist[ind]
+        coord = dist_to_coord(dist, points, scale_dist=scale_dist)
+        return polygons_to_label_coord(coord, shape=shape, labels=ind)
+    dist = np.asarray(dist); points = np.asarray(points)
+    prob = np.inf * np.ones(len(points)) if prob is None else np.asarray(prob)
+    assert len(points) == len(prob) and prob.ndim == 1
+    ind = prob > thr
+    points, dist, prob = points[ind], dist[ind], prob[ind]
+    ind = np.argsort(prob, kind="stable")
+    points, dist = points[ind], dist[ind]
+    coord = dist_to_coord(dist, points, scale_dist=scale_dist)
+    return polygons_to_label_coord(coord, shape=shape, labels=ind)

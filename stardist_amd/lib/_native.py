@@ -57,6 +57,12 @@ def lib():
         if not os.path.exists(path):
             raise NativeError("libstardist_hip.so not built (%s): run `python -m stardist_amd.build` "
                               "or __graft_entry__.build(); there is no CPU fallback" % path)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; if it is going to be used
+        # it must be the copy that gets loaded first, our library then binds to the already-loaded SONAME.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         l = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)          # AttributeError if the symbol is missing

@@ -1,0 +1,3 @@
+"""Prediction-side model classes (mirror of stardist/models for predict_instances*)."""
+from .config import Config2D, Config3D
+from .model2d import StarDist2D

@@ -1,0 +1,463 @@
+"""StarDistBase: the prediction API of the reference's model classes, MI355X-native.
+
+Mirrors stardist/models/base.py for the hot path only:
+  predict / predict_sparse / predict_instances (+ the generator variants used by napari),
+  _predict_setup :371-443, _predict_sparse_generator :541-633, _predict_generator :446-529,
+  _predict_instances_generator :645-772, StarDistPadAndCropResizer :1162-1211.
+Device-resident: the image goes to HBM once; network heads, `max(1e-3, dist)`, threshold +
+border mask + compaction (select.hip), score sort, NMS and rasterisation all stay on the GPU;
+only the label image and the survivor dict return to the host.
+Training, threshold optimisation, export are out of scope.
+"""
+import json
+import math
+import numbers
+import os
+import warnings
+from collections import namedtuple
+
+import numpy as np
+
+from ..lib import _native as N
+from ..nms import _ind_prob_thresh
+
+
+def axes_check_and_normalize(axes, length=None):
+    """csbdeep.utils.axes_check_and_normalize (subset)"""
+    allowed = "STCZYX"
+    axes = str(axes).upper()
+    if any(a not in allowed for a in axes) or any(axes.count(a) > 1 for a in axes):
+        raise ValueError("invalid axes '%s'" % axes)
+    if length is not None and len(axes) != length:
+        raise ValueError("axes (%s) must be of length %d." % (axes, length))
+    return axes
+
+
+def axes_dict(axes):
+    axes = axes_check_and_normalize(axes)
+    return {a: (None if axes.find(a) == -1 else axes.find(a)) for a in "STCZYX"}
+
+
+class StarDistPadAndCropResizer(object):
+    """base.py:1162-1211: reflect-pad at the END of each axis to a multiple of div_by."""
+
+    def __init__(self, grid, mode="reflect"):
+        assert isinstance(grid, dict)
+        self.mode, self.grid = mode, grid
+
+    def before(self, x, axes, axes_div_by):
+        """x: torch tensor laid out as `axes`"""
+        import torch
+        assert all(a % g == 0 for g, a in zip((self.grid.get(a, 1) for a in axes), axes_div_by))
+        self.pad = {a: (0, (div_n - s % div_n) % div_n) for a, div_n, s in zip(axes, axes_div_by, x.shape)}
+        pads = [self.pad[a][1] for a in axes]
+        if any(pads):
+            xn = x
+            # np.pad(mode='reflect') one axis at a time (reflect without repeating the edge sample)
+            for d, p in enumerate(pads):
+                if p:
+                    n = xn.shape[d]
+                    if p > n - 1:
+                        raise ValueError("image too small to reflect-pad axis %s by %d" % (axes[d], p))
+                    idx = torch.arange(n - 2, n - 2 - p, -1, device=xn.device)
+                    xn = torch.cat([xn, xn.index_select(d, idx)], dim=d)
+            x = xn
+        self.padded_shape = dict(zip(axes, x.shape))
+        self.padded_shape.pop("C", None)
+        return x
+
+    def after(self, x, axes):
+        crop = tuple(slice(0, -(math.floor(p[1] / g)) if p[1] >= g else None)
+                     for p, g in zip((self.pad.get(a, (0, 0)) for a in axes), (self.grid.get(a, 1) for a in axes)))
+        return x[crop]
+
+    def filter_points(self, ndim, points, axes):
+        """indices of points inside the un-padded region (base.py:1204-1211)"""
+        bounds = tuple(self.padded_shape[a] - self.pad[a][1] for a in axes if a.lower() in ("z", "y", "x"))
+        if N.is_torch(points):
+            import torch
+            b = torch.tensor(bounds, device=points.device, dtype=points.dtype)
+            return torch.where(torch.all(points < b, dim=1))[0]
+        return np.where(np.all(points < np.array(bounds), 1))[0]
+
+
+class StarDistBase(object):
+
+    def __init__(self, config, name=None, basedir=".", device=None, seed=0, compute_dtype="float32"):
+        import torch
+        self.name = name
+        self.basedir = basedir
+        self.logdir = None if basedir is None else os.path.join(str(basedir), name if name is not None else "stardist_amd")
+        if config is None:
+            if self.logdir is None or not os.path.exists(os.path.join(self.logdir, "config.json")):
+                raise FileNotFoundError("config file doesn't exist: %s" % (None if self.logdir is None else os.path.join(self.logdir, "config.json")))
+            config = self._config_class.from_json(os.path.join(self.logdir, "config.json"))
+        self.config = config
+        threshs = dict(prob=None, nms=None)
+        if self.logdir is not None and os.path.exists(os.path.join(self.logdir, "thresholds.json")):
+            threshs = json.load(open(os.path.join(self.logdir, "thresholds.json")))
+            if threshs.get("prob") is None or not (0 < threshs.get("prob") < 1): threshs["prob"] = None
+            if threshs.get("nms") is None or not (0 < threshs.get("nms") < 1): threshs["nms"] = None
+        self.thresholds = dict(prob=0.5 if threshs["prob"] is None else threshs["prob"],
+                               nms=0.4 if threshs["nms"] is None else threshs["nms"])
+        self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        self.compute_dtype = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16}[compute_dtype]
+        self.net = self._build()
+        from .unet import init_he_normal_
+        init_he_normal_(self.net, seed)
+        if self.logdir is not None and os.path.exists(os.path.join(self.logdir, "weights.npz")):
+            self.load_weights_npz(os.path.join(self.logdir, "weights.npz"))
+        self.net = self.net.to(self.device).eval()
+        if self.device.type == "cuda":
+            self.net = self.net.to(memory_format=torch.channels_last if config.n_dim == 2 else torch.channels_last_3d)
+
+    # the seam where the reference calls keras_model.predict (base.py:408-410)
+    @property
+    def keras_model(self):
+        return self.net
+
+    @property
+    def thresholds(self):
+        return self._thresholds
+
+    @thresholds.setter
+    def thresholds(self, d):
+        self._thresholds = namedtuple("Thresholds", d.keys())(*d.values())
+
+    def _is_multiclass(self):
+        return self.config.n_classes is not None
+
+    def load_weights_npz(self, path):
+        """weights exported from Keras as {layer_name/kernel:0, layer_name/bias:0 ...} in graph order."""
+        import torch
+        import torch.nn as nn
+        data = np.load(path)
+        convs = [m for m in self.net.modules() if isinstance(m, (nn.Conv2d, nn.Conv3d))]
+        kernels = [k for k in data.files if "kernel" in k]
+        if len(kernels) != len(convs):
+            raise ValueError("weight file has %d conv kernels, network has %d" % (len(kernels), len(convs)))
+        for m, kn in zip(convs, kernels):
+            w = data[kn]
+            nd = w.ndim - 2
+            wt = np.transpose(w, (nd + 1, nd) + tuple(range(nd)))
+            with torch.no_grad():
+                m.weight.copy_(torch.from_numpy(np.ascontiguousarray(wt)))
+                bn = kn.replace("kernel", "bias")
+                if bn in data.files:
+                    m.bias.copy_(torch.from_numpy(data[bn]))
+
+    # ------------------------------------------------------------------ helpers
+    def _normalize_axes(self, img, axes):
+        if axes is None:
+            axes = self.config.axes
+            assert "C" in axes
+            if img.ndim == len(axes) - 1 and self.config.n_channel_in == 1:
+                axes = axes.replace("C", "")
+        return axes_check_and_normalize(axes, img.ndim)
+
+    def _make_permute_axes(self, img_axes_in, net_axes_in, net_axes_out=None, img_axes_out=None):
+        """csbdeep BaseModel._make_permute_axes (forward direction only)"""
+        if net_axes_out is None: net_axes_out = net_axes_in
+        if img_axes_out is None: img_axes_out = img_axes_in
+        assert "C" in net_axes_in and "C" in net_axes_out
+        if not ("C" in img_axes_in or "C" in img_axes_out):
+            pass
+
+        def _permute_axes(data, undo=False):
+            assert not undo
+            if "C" not in img_axes_in:
+                data = data[..., None] if not N.is_torch(data) else data.unsqueeze(-1)
+                src = img_axes_in + "C"
+            else:
+                src = img_axes_in
+            perm = [src.index(a) for a in net_axes_in]
+            if N.is_torch(data):
+                return data.permute(*perm)
+            return np.transpose(data, perm)
+        return _permute_axes
+
+    def _net_forward(self, x):
+        """x: torch tensor with axes_net semantics (channels last) -> tuple of channels-last outputs"""
+        import torch
+        nd = self.config.n_dim
+        xc = x.permute(*([nd] + list(range(nd)))).unsqueeze(0)      # (1,C,...)
+        xc = xc.contiguous(memory_format=torch.channels_last if nd == 2 else torch.channels_last_3d)
+        with torch.no_grad():
+            if self.compute_dtype != torch.float32:
+                with torch.autocast(device_type=self.device.type, dtype=self.compute_dtype):
+                    ys = self.net(xc)
+                ys = tuple(y.float() for y in ys)
+            else:
+                ys = self.net(xc.float())
+        return tuple(y[0].permute(*(list(range(1, nd + 1)) + [0])) for y in ys)   # (...,C) views
+
+    def _predict_setup(self, img, axes, normalizer, n_tiles):
+        import torch
+        if n_tiles is None:
+            n_tiles = [1] * img.ndim
+        try:
+            n_tiles = tuple(n_tiles)
+            img.ndim == len(n_tiles) or (_ for _ in ()).throw(TypeError())
+        except TypeError:
+            raise ValueError("n_tiles must be an iterable of length %d" % img.ndim)
+        if not all(np.isscalar(t) and 1 <= t and int(t) == t for t in n_tiles):
+            raise ValueError("all values of n_tiles must be integer values >= 1")
+        n_tiles = tuple(map(int, n_tiles))
+        axes = self._normalize_axes(img, axes)
+        axes_net = self.config.axes
+        _permute_axes = self._make_permute_axes(axes, axes_net)
+        if normalizer is not None:
+            # csbdeep Normalizer protocol: .before(x, axes) on the host array
+            x_host = _permute_axes(np.asarray(img))
+            x_host = normalizer.before(x_host, axes_net)
+            x = torch.as_tensor(np.ascontiguousarray(x_host), device=self.device)
+        else:
+            x = img if N.is_torch(img) else torch.as_tensor(np.ascontiguousarray(img), device=self.device)
+            x = _permute_axes(x.to(self.device))
+        channel = axes_dict(axes_net)["C"]
+        if self.config.n_channel_in != x.shape[channel]:
+            raise ValueError("image has %d channels, model expects %d" % (x.shape[channel], self.config.n_channel_in))
+        axes_net_div_by = self._axes_div_by(axes_net)
+        grid = tuple(self.config.grid)
+        grid_dict = dict(zip(axes_net.replace("C", ""), grid))
+        resizer = StarDistPadAndCropResizer(grid=grid_dict)
+        if not x.dtype.is_floating_point:
+            warnings.warn("Predicting on non-float input... ( forgot to normalize? )")
+            x = x.float()
+        x = resizer.before(x.float(), axes_net, axes_net_div_by)
+        return x, axes, axes_net, axes_net_div_by, resizer, n_tiles, grid, grid_dict, channel
+
+    def _tile_slices(self, x, n_tiles, axes_net, axes_net_div_by):
+        """Overlapping tiles (csbdeep tile_iterator role, base.py:412-441): per spatial axis split the padded
+        image into n blocks of div_by-aligned size; each tile carries `overlap` context on both sides."""
+        overlaps = self._axes_tile_overlap(axes_net)
+        per_axis = []
+        for a, n, s, db, ov in zip(axes_net, n_tiles, x.shape, axes_net_div_by, overlaps):
+            if a == "C" or n == 1:
+                per_axis.append([(slice(0, s), slice(0, s), slice(0, s))])
+                continue
+            nblocks = s // db
+            n = min(n, nblocks)
+            ovb = int(np.ceil(ov / db)) * db
+            edges = [int(round(i * nblocks / n)) * db for i in range(n + 1)]
+            lst = []
+            for i in range(n):
+                d0, d1 = edges[i], edges[i + 1]
+                t0, t1 = max(0, d0 - ovb), min(s, d1 + ovb)
+                lst.append((slice(t0, t1), slice(d0 - t0, d1 - t0), slice(d0, d1)))   # tile, src (in tile), dst (in image)
+            per_axis.append(lst)
+        import itertools
+        for combo in itertools.product(*per_axis):
+            yield tuple(c[0] for c in combo), tuple(c[1] for c in combo), tuple(c[2] for c in combo)
+
+    def _axes_tile_overlap(self, query_axes):
+        """base.py:1100-1110 derives this empirically from an impulse response; the analytic receptive field of
+        the conv stack (upper bound of the empirical one) is used instead."""
+        rf = self._receptive_field_radius()
+        d = dict(zip(self.config.axes.replace("C", ""), rf))
+        return tuple(d.get(a, 0) for a in query_axes)
+
+    def _receptive_field_radius(self):
+        cfg = self.config
+        nd = cfg.n_dim
+        if cfg.backbone == "unet":
+            k = cfg.unet_kernel_size; pool = cfg.unet_pool; depth = cfg.unet_n_depth; ncv = cfg.unet_n_conv_per_depth
+            out = []
+            for d in range(nd):
+                r, scale = 0, 1
+                g = cfg.grid[d]
+                while scale < g:                                  # pre-pooling stages
+                    r += ncv * (k[d] // 2) * scale; scale *= 2
+                for n in range(depth):
+                    r += ncv * (k[d] // 2) * scale; scale *= pool[d]
+                r += ncv * (k[d] // 2) * scale
+                for n in reversed(range(depth)):
+                    scale //= pool[d]; r += ncv * (k[d] // 2) * scale + scale
+                r += (k[d] // 2) * scale                          # features conv
+                out.append(int(r))
+            return tuple(out)
+        else:
+            k = cfg.resnet_kernel_size
+            out = []
+            for d in range(nd):
+                r, scale = 3 + 1, 1
+                g = cfg.grid[d]
+                for n in range(cfg.resnet_n_blocks):
+                    if scale < g:
+                        scale *= 2
+                    r += cfg.resnet_n_conv_per_block * (k[d] // 2) * scale
+                r += (k[d] // 2) * scale
+                out.append(int(r))
+            return tuple(out)
+
+    # ------------------------------------------------------------------ predict (dense)   base.py:446-529
+    def _predict_generator(self, img, axes=None, normalizer=None, n_tiles=None, show_tile_progress=True, **predict_kwargs):
+        import torch
+        x, axes, axes_net, axes_net_div_by, resizer, n_tiles, grid, grid_dict, channel = self._predict_setup(img, axes, normalizer, n_tiles)
+        if np.prod(n_tiles) > 1:
+            sh = [s // grid_dict.get(a, 1) for a, s in zip(axes_net, x.shape)]
+            outs = None
+            for s_tile, s_src, s_dst in self._tile_slices(x, n_tiles, axes_net, axes_net_div_by):
+                res = self._net_forward(x[s_tile])
+                g = lambda sl: tuple(slice(None) if a == "C" else slice(s.start // grid_dict.get(a, 1), s.stop // grid_dict.get(a, 1)) for s, a in zip(sl, axes_net))
+                if outs is None:
+                    outs = [torch.empty(tuple(sh[:channel]) + (r.shape[-1],), dtype=torch.float32, device=self.device) for r in res]
+                for o, r in zip(outs, res):
+                    o[g(s_dst)] = r[g(s_src)]
+                yield
+            results = outs
+        else:
+            results = list(self._net_forward(x))
+        prob = results[0][..., 0]
+        dist = torch.clamp_min(results[1], 1e-3)           # base.py:512-513
+        prob = resizer.after(prob, axes_net.replace("C", ""))
+        dist = resizer.after(dist, axes_net)
+        if self._is_multiclass():
+            yield prob, dist, resizer.after(results[2], axes_net)
+        else:
+            yield prob, dist
+
+    def predict(self, *args, **kwargs):
+        """dense prediction -> (prob, dist[, prob_class]) as numpy arrays (base.py:531-538)"""
+        r = None
+        for r in self._predict_generator(*args, **kwargs):
+            pass
+        return tuple(t.cpu().numpy() for t in r)
+
+    # ------------------------------------------------------------------ predict_sparse   base.py:541-633
+    def _select(self, prob, dist, prob_thresh, bs):
+        """threshold + border + ordered compaction on device (select.hip).  prob (...), dist (..., R) contiguous."""
+        import torch
+        prob = prob.contiguous(); dist = dist.contiguous()
+        nd = prob.dim()
+        shape = np.asarray(prob.shape, np.int32)
+        b = np.asarray([v for pair in bs for v in pair], np.int32)
+        cnt = torch.zeros(1, dtype=torch.int32, device=prob.device)
+        R = dist.shape[-1]
+        # first pass with a capacity guess, second pass only if it overflowed
+        cap = max(1024, int(prob.numel() // 64))
+        while True:
+            oprob = torch.empty(cap, dtype=torch.float32, device=prob.device)
+            odist = torch.empty((cap, R), dtype=torch.float32, device=prob.device)
+            opts = torch.empty((cap, nd), dtype=torch.int32, device=prob.device)
+            N.check(N.lib().sd_select_candidates_device(N.tptr(prob), N.tptr(dist), nd, N.ptr(shape), N.ptr(b), R,
+                                                        float(np.float32(prob_thresh)), cap, N.tptr(oprob), N.tptr(odist),
+                                                        N.tptr(opts), N.tptr(cnt), N.current_stream()))
+            n = int(cnt.item())
+            if n <= cap:
+                return oprob[:n], odist[:n], opts[:n].to(torch.int64)
+            cap = n
+
+    def _predict_sparse_generator(self, img, prob_thresh=None, axes=None, normalizer=None, n_tiles=None,
+                                  show_tile_progress=True, b=2, **predict_kwargs):
+        import torch
+        if prob_thresh is None: prob_thresh = self.thresholds.prob
+        x, axes, axes_net, axes_net_div_by, resizer, n_tiles, grid, grid_dict, channel = self._predict_setup(img, axes, normalizer, n_tiles)
+        nd = self.config.n_dim
+        gridt = torch.tensor(self.config.grid, device=self.device, dtype=torch.int64).reshape(1, nd)
+        prob_classa = None
+        if np.prod(n_tiles) > 1:
+            sh = [s // grid_dict.get(a, 1) for a, s in zip(axes_net, x.shape)]
+            pl, dl, ptl, pcl = [], [], [], []
+            for s_tile, s_src, s_dst in self._tile_slices(x, n_tiles, axes_net, axes_net_div_by):
+                res = self._net_forward(x[s_tile])
+                g = lambda sl: [slice(s.start // grid_dict.get(a, 1), s.stop // grid_dict.get(a, 1)) for s, a in zip(sl, axes_net) if a != "C"]
+                gsrc, gdst = g(s_src), g(s_dst)
+                prob_tile = res[0][..., 0][tuple(gsrc)]
+                dist_tile = res[1][tuple(gsrc)]
+                bs = [(b if s.start == 0 else 0, b if s.stop == _sh else 0) for s, _sh in zip(gdst, [v for v, a in zip(sh, axes_net) if a != "C"])]   # base.py:583
+                p_, d_, pt_ = self._select(prob_tile, dist_tile, prob_thresh, bs)
+                off = torch.tensor([s.start for s in gdst], device=self.device, dtype=torch.int64).reshape(1, nd)
+                pl.append(p_); dl.append(d_); ptl.append((pt_ + off) * gridt)
+                if self._is_multiclass():
+                    pc = res[2][tuple(gsrc)].reshape(-1, res[2].shape[-1])
+                    lin = pt_[:, 0]
+                    for d in range(1, nd): lin = lin * prob_tile.shape[d] + pt_[:, d]
+                    pcl.append(pc[lin])
+                yield
+            proba, dista, pointsa = torch.cat(pl), torch.cat(dl), torch.cat(ptl)
+            if self._is_multiclass(): prob_classa = torch.cat(pcl)
+        else:
+            res = self._net_forward(x)
+            prob = res[0][..., 0]
+            bs = [(b, b)] * nd if np.isscalar(b) else list(b)
+            proba, dista, pts = self._select(prob, res[1], prob_thresh, bs)
+            pointsa = pts * gridt
+            if self._is_multiclass():
+                pc = res[2].reshape(-1, res[2].shape[-1])
+                lin = pts[:, 0]
+                for d in range(1, nd): lin = lin * prob.shape[d] + pts[:, d]
+                prob_classa = pc[lin]
+        idx = resizer.filter_points(x.dim(), pointsa, axes_net)
+        proba, dista, pointsa = proba[idx], dista[idx], pointsa[idx]
+        if self._is_multiclass():
+            yield proba, dista, prob_classa[idx], pointsa
+        else:
+            yield proba, dista, pointsa
+
+    def predict_sparse(self, *args, **kwargs):
+        r = None
+        for r in self._predict_sparse_generator(*args, **kwargs):
+            pass
+        return tuple(t.cpu().numpy() for t in r)
+
+    # ------------------------------------------------------------------ predict_instances   base.py:645-790
+    def _predict_instances_generator(self, img, axes=None, normalizer=None, sparse=True, prob_thresh=None, nms_thresh=None,
+                                     scale=None, n_tiles=None, show_tile_progress=True, verbose=False, return_labels=True,
+                                     predict_kwargs=None, nms_kwargs=None, overlap_label=None, return_predict=False):
+        import torch
+        if predict_kwargs is None: predict_kwargs = {}
+        if nms_kwargs is None: nms_kwargs = {}
+        if return_predict and sparse:
+            sparse = False
+            warnings.warn("Setting sparse to False because return_predict is True")
+        nms_kwargs.setdefault("verbose", verbose)
+        _axes = self._normalize_axes(img, axes)
+        _axes_net = self.config.axes
+        _permute = self._make_permute_axes(_axes, _axes_net)
+        _shape_inst = tuple(s for s, a in zip(_permute(np.empty(img.shape, bool) if not N.is_torch(img) else img).shape, _axes_net) if a != "C")
+        if scale is not None:
+            if isinstance(scale, numbers.Number):
+                scale = tuple(scale if a in "XYZ" else 1 for a in _axes)
+            scale = tuple(scale)
+            if len(scale) != len(_axes):
+                raise ValueError("scale %s must be of length %d, i.e. one value for each of the axes %s" % (scale, len(_axes), _axes))
+            for s, a in zip(scale, _axes):
+                if not s > 0: raise ValueError("scale values must be greater than 0")
+            scale = tuple(s if a in "XYZ" else 1 for s, a in zip(scale, _axes))
+            from scipy import ndimage as ndi
+            img = ndi.zoom(np.asarray(img.cpu() if N.is_torch(img) else img), scale, order=1)     # base.py:725-735
+        yield "predict"
+        res = None
+        if sparse:
+            for res in self._predict_sparse_generator(img, axes=axes, normalizer=normalizer, n_tiles=n_tiles,
+                                                      prob_thresh=prob_thresh, show_tile_progress=show_tile_progress, **predict_kwargs):
+                if res is None:
+                    yield "tile"
+        else:
+            for res in self._predict_generator(img, axes=axes, normalizer=normalizer, n_tiles=n_tiles,
+                                               show_tile_progress=show_tile_progress, **predict_kwargs):
+                if res is None:
+                    yield "tile"
+            res = tuple(res) + (None,)
+        if self._is_multiclass():
+            prob, dist, prob_class, points = res
+        else:
+            prob, dist, points = res
+            prob_class = None
+        yield "nms"
+        res_instances = self._instances_from_prediction(_shape_inst, prob, dist, points=points, prob_class=prob_class,
+                                                        prob_thresh=prob_thresh, nms_thresh=nms_thresh,
+                                                        scale=(None if scale is None else dict(zip(_axes, scale))),
+                                                        return_labels=return_labels, overlap_label=overlap_label, **nms_kwargs)
+        if return_predict:
+            yield res_instances, tuple(t.cpu().numpy() for t in res[:-1])
+        else:
+            yield res_instances
+
+    def predict_instances(self, *args, **kwargs):
+        """Predict instance segmentation: returns (labels, dict) exactly like the reference (base.py:775-790)."""
+        r = None
+        for r in self._predict_instances_generator(*args, **kwargs):
+            pass
+        return r

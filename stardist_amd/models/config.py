@@ -1,0 +1,145 @@
+"""Config2D / Config3D: the prediction-relevant part of the reference's configuration schema
+(stardist/models/model2d.py:123-269, model3d.py:129-311), json-compatible with the
+reference's `config.json` (extra training keys are kept verbatim but unused)."""
+import json
+
+import numpy as np
+
+from ..utils import _normalize_grid
+
+
+class BaseConfig(object):
+    """csbdeep.models.BaseConfig surface used by the reference: attribute bag + update_parameters."""
+
+    def __init__(self, axes, n_channel_in, n_channel_out):
+        axes = str(axes).upper()
+        if "C" not in axes:
+            axes = axes + "C"                      # channels_last only (models/__init__.py:8-14)
+        self.n_dim = len(axes) - 1
+        self.axes = axes
+        self.n_channel_in = int(max(1, n_channel_in))
+        self.n_channel_out = int(max(1, n_channel_out))
+
+    def update_parameters(self, allow_new=False, **kwargs):
+        if not allow_new:
+            unknown = [k for k in kwargs if not hasattr(self, k)]
+            # the reference raises AttributeError for unknown keys; json files of other versions may
+            # carry extra training keys, which are accepted silently there too (allow_new on load)
+            if unknown:
+                raise AttributeError("Not allowed to add new parameters (%s)" % ", ".join(unknown))
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    def to_json(self):
+        def conv(v):
+            if isinstance(v, (np.integer,)): return int(v)
+            if isinstance(v, (np.floating,)): return float(v)
+            if isinstance(v, (tuple, list)): return [conv(x) for x in v]
+            return v
+        return json.dumps({k: conv(v) for k, v in vars(self).items()})
+
+    @classmethod
+    def from_json(cls, path_or_dict):
+        d = path_or_dict if isinstance(path_or_dict, dict) else json.load(open(path_or_dict))
+        d = dict(d)
+        init_keys = {k: d.pop(k) for k in list(d) if k in ("axes", "n_rays", "n_channel_in", "grid", "n_classes", "backbone", "rays", "anisotropy")}
+        if "rays_json" in d and "rays" not in init_keys and cls.__name__ == "Config3D":
+            from ..rays3d import rays_from_json
+            init_keys["rays"] = rays_from_json(d["rays_json"])
+        ax = init_keys.get("axes")
+        if ax is not None:
+            init_keys["axes"] = ax.replace("C", "")
+        cfg = cls(**init_keys)
+        for k in ("n_dim", "n_channel_out", "axes"):
+            d.pop(k, None)
+        cfg.update_parameters(True, **d)
+        for k in ("grid", "unet_kernel_size", "unet_pool", "resnet_kernel_size"):
+            if hasattr(cfg, k) and isinstance(getattr(cfg, k), list):
+                setattr(cfg, k, tuple(getattr(cfg, k)))
+        return cfg
+
+
+class Config2D(BaseConfig):
+    """model2d.py:198-269 (prediction-relevant defaults)."""
+
+    def __init__(self, axes="YX", n_rays=32, n_channel_in=1, grid=(1, 1), n_classes=None, backbone="unet", **kwargs):
+        super().__init__(axes=axes, n_channel_in=n_channel_in, n_channel_out=1 + n_rays)
+        self.n_rays = int(n_rays)
+        self.grid = _normalize_grid(grid, 2)
+        self.backbone = str(backbone).lower()
+        self.n_classes = None if n_classes is None else int(n_classes)
+        if self.backbone == "unet":
+            self.unet_n_depth = 3
+            self.unet_kernel_size = 3, 3
+            self.unet_n_filter_base = 32
+            self.unet_n_conv_per_depth = 2
+            self.unet_pool = 2, 2
+            self.unet_activation = "relu"
+            self.unet_last_activation = "relu"
+            self.unet_batch_norm = False
+            self.unet_dropout = 0.0
+            self.unet_prefix = ""
+            self.net_conv_after_unet = 128
+        else:
+            raise ValueError("backbone '%s' not supported." % self.backbone)
+        self.net_input_shape = None, None, self.n_channel_in
+        self.net_mask_shape = None, None, 1
+        self.train_patch_size = 256, 256
+        self.train_batch_size = 4
+        self.use_gpu = False
+        for k in ("n_dim", "n_channel_out"):
+            kwargs.pop(k, None)
+        self.update_parameters(False, **kwargs)
+
+
+class Config3D(BaseConfig):
+    """model3d.py:207-311 (prediction-relevant defaults)."""
+
+    def __init__(self, axes="ZYX", rays=None, n_channel_in=1, grid=(1, 1, 1), n_classes=None, anisotropy=None,
+                 backbone="unet", **kwargs):
+        from ..rays3d import Rays_GoldenSpiral, Rays_Base
+        if rays is None:
+            rays = Rays_GoldenSpiral(96, anisotropy=anisotropy)
+        elif np.isscalar(rays):
+            rays = Rays_GoldenSpiral(rays, anisotropy=anisotropy)
+        super().__init__(axes=axes, n_channel_in=n_channel_in, n_channel_out=1 + len(rays))
+        self.n_rays = len(rays)
+        self.grid = _normalize_grid(grid, 3)
+        self.anisotropy = anisotropy if anisotropy is None else tuple(anisotropy)
+        self.backbone = str(backbone).lower()
+        self.rays_json = rays.to_json()
+        self.n_classes = None if n_classes is None else int(n_classes)
+        if "anisotropy" in self.rays_json["kwargs"]:
+            if self.rays_json["kwargs"]["anisotropy"] is None and self.anisotropy is not None:
+                self.rays_json["kwargs"]["anisotropy"] = self.anisotropy
+        if self.backbone == "unet":
+            self.unet_n_depth = 2
+            self.unet_kernel_size = 3, 3, 3
+            self.unet_n_filter_base = 32
+            self.unet_n_conv_per_depth = 2
+            self.unet_pool = 2, 2, 2
+            self.unet_activation = "relu"
+            self.unet_last_activation = "relu"
+            self.unet_batch_norm = False
+            self.unet_dropout = 0.0
+            self.unet_prefix = ""
+            self.net_conv_after_unet = 128
+        elif self.backbone == "resnet":
+            self.resnet_n_blocks = 4
+            self.resnet_kernel_size = 3, 3, 3
+            self.resnet_kernel_init = "he_normal"
+            self.resnet_n_filter_base = 32
+            self.resnet_n_conv_per_block = 3
+            self.resnet_activation = "relu"
+            self.resnet_batch_norm = False
+            self.net_conv_after_resnet = 128
+        else:
+            raise ValueError("backbone '%s' not supported." % self.backbone)
+        self.net_input_shape = None, None, None, self.n_channel_in
+        self.net_mask_shape = None, None, None, 1
+        self.train_patch_size = 128, 128, 128
+        self.train_batch_size = 1
+        self.use_gpu = False
+        for k in ("n_dim", "n_channel_out"):
+            kwargs.pop(k, None)
+        self.update_parameters(False, **kwargs)

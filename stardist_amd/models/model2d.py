@@ -1,0 +1,75 @@
+"""StarDist2D (prediction API) -- mirror of stardist/models/model2d.py:272-593 for the hot path."""
+import numpy as np
+
+from ..geometry.geom2d import dist_to_coord, polygons_to_label
+from ..lib import _native as N
+from ..nms import non_maximum_suppression, non_maximum_suppression_sparse
+from .base import StarDistBase, axes_check_and_normalize
+from .config import Config2D
+
+
+class StarDist2D(StarDistBase):
+    """StarDist2D model: `predict_instances(img)` -> (labels int32 (H,W), dict(coord, points, prob))."""
+
+    def __init__(self, config=Config2D(), name=None, basedir=".", **kwargs):
+        super().__init__(config, name=name, basedir=basedir, **kwargs)
+
+    def _build(self):
+        from .unet import StarDistNet
+        if self.config.backbone != "unet":
+            raise NotImplementedError()
+        return StarDistNet(self.config)
+
+    def _instances_from_prediction(self, img_shape, prob, dist, points=None, prob_class=None, prob_thresh=None,
+                                   nms_thresh=None, overlap_label=None, return_labels=True, scale=None, **nms_kwargs):
+        """model2d.py:512-563. Works on device tensors (from predict*) or numpy arrays; returns numpy."""
+        if prob_thresh is None: prob_thresh = self.thresholds.prob
+        if nms_thresh is None: nms_thresh = self.thresholds.nms
+        if overlap_label is not None:
+            raise NotImplementedError("overlap_label not supported for 2D yet!")
+        if points is not None:
+            points, probi, disti, indsi = non_maximum_suppression_sparse(dist, prob, points, nms_thresh=nms_thresh, **nms_kwargs)
+            if prob_class is not None:
+                prob_class = prob_class[indsi]
+        else:
+            points, probi, disti = non_maximum_suppression(dist, prob, grid=self.config.grid, prob_thresh=prob_thresh,
+                                                           nms_thresh=nms_thresh, **nms_kwargs)
+            if prob_class is not None:
+                inds = tuple(p // g for p, g in zip(points.T, self.config.grid))
+                prob_class = prob_class[inds]
+        if scale is not None:
+            if not (isinstance(scale, dict) and "X" in scale and "Y" in scale):
+                raise ValueError("scale must be a dictionary with entries for 'X' and 'Y'")
+            rescale = (1 / scale["Y"], 1 / scale["X"])
+            if N.is_torch(points):
+                import torch
+                points = points * torch.tensor(rescale, device=points.device, dtype=torch.float64).reshape(1, 2)
+            else:
+                points = points * np.array(rescale).reshape(1, 2)
+        else:
+            rescale = (1, 1)
+        if return_labels:
+            labels = polygons_to_label(disti, points, prob=probi, shape=img_shape, scale_dist=rescale)
+        else:
+            labels = None
+        coord = dist_to_coord(disti, points, scale_dist=rescale)
+        to_np = (lambda t: t.cpu().numpy()) if N.is_torch(coord) else (lambda t: t)
+        if labels is not None and N.is_torch(labels):
+            labels = labels.cpu().numpy()
+        res_dict = dict(coord=to_np(coord), points=to_np(points), prob=to_np(probi))
+        if prob_class is not None:
+            prob_class = np.asarray(to_np(prob_class))
+            class_id = np.argmax(prob_class, axis=-1)
+            res_dict.update(dict(class_prob=prob_class, class_id=class_id))
+        return labels, res_dict
+
+    def _axes_div_by(self, query_axes):
+        """model2d.py:566-574"""
+        query_axes = axes_check_and_normalize(query_axes)
+        div_by = dict(zip(self.config.axes.replace("C", ""),
+                          tuple(p ** self.config.unet_n_depth * g for p, g in zip(self.config.unet_pool, self.config.grid))))
+        return tuple(div_by.get(a, 1) for a in query_axes)
+
+    @property
+    def _config_class(self):
+        return Config2D

@@ -1,0 +1,228 @@
+"""The StarDist network re-expressed in PyTorch-ROCm (channels_last, convolutions on MFMA).
+
+Topology restated from the reference's Keras graph:
+  StarDist2D._build          stardist/models/model2d.py:310-349
+  StarDist3D._build_unet     stardist/models/model3d.py:360-399
+  StarDist3D._build_resnet   stardist/models/model3d.py:402-447
+  csbdeep.internals.blocks.unet_block / resnet_block (csbdeep>=0.8.0, not vendored; published
+  semantics restated: 'same' zero padding, max-pool 'valid' stride=pool, nearest up-sampling,
+  Concatenate([up, skip]) in that order).
+Keras layer names are kept as module names so a Keras weight file maps 1:1 (kernel
+(k..., cin, cout) -> torch (cout, cin, k...)).
+U-Net parity against TensorFlow is unpinned in this environment (no TF, no weights).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _act(name):
+    if name in (None, "linear"):
+        return nn.Identity()
+    if name == "relu":
+        return nn.ReLU(inplace=True)
+    if name == "elu":
+        return nn.ELU(inplace=True)
+    if name == "sigmoid":
+        return nn.Sigmoid()
+    if name == "tanh":
+        return nn.Tanh()
+    raise ValueError("activation %s not supported" % name)
+
+
+def _conv(nd, cin, cout, k, act="relu", bias=True):
+    k = tuple(k) if isinstance(k, (tuple, list)) else (k,) * nd
+    Conv = nn.Conv2d if nd == 2 else nn.Conv3d
+    assert all(kk % 2 == 1 for kk in k), "Keras 'same' padding restated for odd kernels only"
+    return nn.Sequential(Conv(cin, cout, k, padding=tuple(kk // 2 for kk in k), bias=bias), _act(act))
+
+
+class UNetBlock(nn.Module):
+    """csbdeep unet_block(n_depth, n_filter_base, kernel_size, n_conv_per_depth, activation,
+    last_activation, pool) without batch-norm/dropout (inference)."""
+
+    def __init__(self, nd, cin, n_depth, n_filter_base, kernel_size, n_conv_per_depth, activation, last_activation, pool,
+                 batch_norm=False):
+        super().__init__()
+        if batch_norm:
+            raise NotImplementedError("unet_batch_norm=True is not supported yet")
+        self.nd, self.n_depth, self.pool = nd, n_depth, tuple(pool)
+        self.down = nn.ModuleList()
+        c = cin
+        for n in range(n_depth):
+            convs = []
+            for i in range(n_conv_per_depth):
+                convs.append(_conv(nd, c, n_filter_base * 2 ** n, kernel_size, activation)); c = n_filter_base * 2 ** n
+            self.down.append(nn.Sequential(*convs))
+        mid = []
+        for i in range(n_conv_per_depth - 1):
+            mid.append(_conv(nd, c, n_filter_base * 2 ** n_depth, kernel_size, activation)); c = n_filter_base * 2 ** n_depth
+        mid.append(_conv(nd, c, n_filter_base * 2 ** max(0, n_depth - 1), kernel_size, activation)); c = n_filter_base * 2 ** max(0, n_depth - 1)
+        self.middle = nn.Sequential(*mid)
+        self.up = nn.ModuleList()
+        for n in reversed(range(n_depth)):
+            c = c + n_filter_base * 2 ** n          # concat [up, skip]
+            convs = []
+            for i in range(n_conv_per_depth - 1):
+                convs.append(_conv(nd, c, n_filter_base * 2 ** n, kernel_size, activation)); c = n_filter_base * 2 ** n
+            convs.append(_conv(nd, c, n_filter_base * 2 ** max(0, n - 1), kernel_size, activation if n > 0 else last_activation))
+            c = n_filter_base * 2 ** max(0, n - 1)
+            self.up.append(nn.Sequential(*convs))
+        self.out_channels = c
+
+    def forward(self, x):
+        pool = F.max_pool2d if self.nd == 2 else F.max_pool3d
+        skips = []
+        for blk in self.down:
+            x = blk(x)
+            skips.append(x)
+            x = pool(x, self.pool)
+        x = self.middle(x)
+        for blk, skip in zip(self.up, reversed(skips)):
+            x = F.interpolate(x, scale_factor=tuple(float(p) for p in self.pool), mode="nearest")
+            x = torch.cat([x, skip], dim=1)
+            x = blk(x)
+        return x
+
+
+class ResNetBlock(nn.Module):
+    """csbdeep resnet_block(n_filter, kernel_size, pool, n_conv_per_block, activation): first conv strided by
+    `pool`, last conv linear, 1x1 strided projection on the shortcut when shape changes, add, activation."""
+
+    def __init__(self, nd, cin, n_filter, kernel_size, pool, n_conv_per_block, activation):
+        super().__init__()
+        Conv = nn.Conv2d if nd == 2 else nn.Conv3d
+        k = tuple(kernel_size)
+        pad = tuple(kk // 2 for kk in k)
+        self.pool = tuple(pool)
+        self.k = k
+        self.first = Conv(cin, n_filter, k, stride=self.pool, padding=0)   # Keras 'same' + stride pads asymmetrically
+        layers = [_act(activation)]
+        for _ in range(n_conv_per_block - 2):
+            layers += [Conv(n_filter, n_filter, k, padding=pad), _act(activation)]
+        layers += [Conv(n_filter, n_filter, k, padding=pad)]
+        self.body = nn.Sequential(*layers)
+        self.proj = None
+        if any(p != 1 for p in self.pool) or cin != n_filter:
+            self.proj = Conv(cin, n_filter, (1,) * nd, stride=self.pool)
+        self.act = _act(activation)
+
+    def _same_pad(self, x):
+        # TensorFlow 'SAME': total = max(k - s, 0) if n % s == 0 else max(k - n % s, 0); before = total // 2
+        pads = []
+        for d in reversed(range(len(self.k))):
+            n, k, s = x.shape[2 + d], self.k[d], self.pool[d]
+            total = max(k - s, 0) if n % s == 0 else max(k - n % s, 0)
+            pads += [total // 2, total - total // 2]
+        return F.pad(x, pads)
+
+    def forward(self, x):
+        y = self.body(self.first(self._same_pad(x)))
+        if self.proj is not None:
+            x = self.proj(x)
+        return self.act(x + y)
+
+
+class StarDistNet(nn.Module):
+    """input (N,C,...) -> prob (N,1,...), dist (N,n_rays,...)[, prob_class (N,n_classes+1,...)]"""
+
+    def __init__(self, config):
+        super().__init__()
+        cfg = config
+        nd = cfg.n_dim
+        self.nd = nd
+        self.pre = nn.ModuleList()
+        c = cfg.n_channel_in
+        grid = np.asarray(cfg.grid)
+        if cfg.backbone == "unet":
+            pooled = np.ones(nd, int)
+            while tuple(pooled) != tuple(grid):                       # model2d.py:317-325
+                pool = 1 + (grid > pooled)
+                pooled = pooled * pool
+                convs = []
+                for _ in range(cfg.unet_n_conv_per_depth):
+                    convs.append(_conv(nd, c, cfg.unet_n_filter_base, cfg.unet_kernel_size, cfg.unet_activation)); c = cfg.unet_n_filter_base
+                self.pre.append(nn.ModuleDict(dict(convs=nn.Sequential(*convs))))
+                self.pre[-1].pool = tuple(int(p) for p in pool)
+            self.backbone = UNetBlock(nd, c, cfg.unet_n_depth, cfg.unet_n_filter_base, cfg.unet_kernel_size,
+                                      cfg.unet_n_conv_per_depth, cfg.unet_activation, cfg.unet_last_activation,
+                                      cfg.unet_pool, cfg.unet_batch_norm)
+            c = self.backbone.out_channels
+            n_after, k_after, act_after = cfg.net_conv_after_unet, cfg.unet_kernel_size, cfg.unet_activation
+        elif cfg.backbone == "resnet":                                 # model3d.py:402-447
+            n_filter = cfg.resnet_n_filter_base
+            blocks = [_conv(nd, c, n_filter, (7,) * nd, None),        # linear (no activation) model3d.py:416-417
+                      _conv(nd, n_filter, n_filter, (3,) * nd, None)]
+            c = n_filter
+            pooled = np.ones(nd, int)
+            for n in range(cfg.resnet_n_blocks):
+                pool = 1 + (grid > pooled)
+                pooled = pooled * pool
+                if any(p > 1 for p in pool):
+                    n_filter *= 2
+                blocks.append(ResNetBlock(nd, c, n_filter, cfg.resnet_kernel_size, tuple(int(p) for p in pool),
+                                          cfg.resnet_n_conv_per_block, cfg.resnet_activation))
+                c = n_filter
+            self.backbone = nn.Sequential(*blocks)
+            n_after, k_after, act_after = cfg.net_conv_after_resnet, cfg.resnet_kernel_size, cfg.resnet_activation
+        else:
+            raise ValueError(cfg.backbone)
+        self.features = _conv(nd, c, n_after, k_after, act_after) if n_after > 0 else nn.Identity()
+        cf = n_after if n_after > 0 else c
+        Conv = nn.Conv2d if nd == 2 else nn.Conv3d
+        self.prob = Conv(cf, 1, (1,) * nd)
+        self.dist = Conv(cf, cfg.n_rays, (1,) * nd)
+        self.n_classes = cfg.n_classes
+        if cfg.n_classes is not None:
+            self.features_class = _conv(nd, c, n_after, k_after, act_after) if n_after > 0 else nn.Identity()
+            self.prob_class = Conv(cf, cfg.n_classes + 1, (1,) * nd)
+
+    def forward(self, x):
+        pool = F.max_pool2d if self.nd == 2 else F.max_pool3d
+        for st in self.pre:
+            x = pool(st["convs"](x), st.pool)
+        base = self.backbone(x)
+        f = self.features(base)
+        prob = torch.sigmoid(self.prob(f))
+        dist = self.dist(f)
+        if self.n_classes is not None:
+            pc = torch.softmax(self.prob_class(self.features_class(base)), dim=1)
+            return prob, dist, pc
+        return prob, dist
+
+
+def init_he_normal_(net, seed=0):
+    """Seeded He-normal kernels / small biases: real weights are not available offline
+    (.MISSING_LARGE_BLOBS); throughput is weight independent."""
+    g = torch.Generator().manual_seed(seed)
+    for m in net.modules():
+        if isinstance(m, (nn.Conv2d, nn.Conv3d)):
+            fan_in = m.in_channels * int(np.prod(m.kernel_size))
+            with torch.no_grad():
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * float(np.sqrt(2.0 / fan_in)))
+                if m.bias is not None:
+                    m.bias.zero_()
+    return net
+
+
+def conv_macs_per_input_pixel(net, cfg):
+    """analytic multiply-accumulates per INPUT pixel of the conv stack (for the MFMA roofline)."""
+    nd = cfg.n_dim
+    size = 64 if nd == 2 else 32
+    shape = tuple(size * g for g in cfg.grid)
+    macs = [0.0]
+    hooks = []
+
+    def hook(m, inp, out):
+        k = float(np.prod(m.kernel_size))
+        macs[0] += out.numel() / out.shape[0] * (m.in_channels * k)
+    for m in net.modules():
+        if isinstance(m, (nn.Conv2d, nn.Conv3d)):
+            hooks.append(m.register_forward_hook(hook))
+    dev = next(net.parameters()).device
+    with torch.no_grad():
+        net(torch.zeros((1, cfg.n_channel_in) + shape, device=dev))
+    for h in hooks:
+        h.remove()
+    return macs[0] / float(np.prod(shape))

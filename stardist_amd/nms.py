@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's stardist/nms.py on top of the HIP natives.
+
+Same function names, arguments and return values as the reference (file:line cited per
+function).  Arrays may be numpy (host entry points of the C ABI) or torch CUDA tensors
+(device entry points, nothing leaves HBM); the result type follows the input type.
+"""
+import numpy as np
+
+from .lib import _native as N
+from .utils import _normalize_grid
+
+
+def _is_t(x):
+    return N.is_torch(x)
+
+
+def _ind_prob_thresh(prob, prob_thresh, b=2):
+    """stardist/nms.py:6-17"""
+    if b is not None and np.isscalar(b):
+        b = ((b, b),) * prob.ndim
+    if _is_t(prob):
+        import torch
+        ind_thresh = prob > torch.tensor(prob_thresh, dtype=prob.dtype, device=prob.device)
+        if b is not None:
+            _ind = torch.zeros_like(ind_thresh)
+            ss = tuple(slice(_bs[0] if _bs[0] > 0 else None, -_bs[1] if _bs[1] > 0 else None) for _bs in b)
+            _ind[ss] = True
+            ind_thresh &= _ind
+        return ind_thresh
+    ind_thresh = prob > prob_thresh
+    if b is not None:
+        _ind = np.zeros_like(ind_thresh)
+        ss = tuple(slice(_bs[0] if _bs[0] > 0 else None, -_bs[1] if _bs[1] > 0 else None) for _bs in b)
+        _ind[ss] = True
+        ind_thresh &= _ind
+    return ind_thresh
+
+
+def _argsort_desc(x):
+    """np.argsort(x)[::-1] (nms.py:114,167): ascending order, reversed. Ties: numpy's default sort is
+    unstable, so the reference's tie order is implementation-defined; we use 'stable ascending,
+    then reversed' on both backends (documented in DESIGN.md)."""
+    if _is_t(x):
+        import torch
+        return torch.flip(torch.sort(x, stable=True)[1], dims=(0,))
+    return np.argsort(x, kind="stable")[::-1]
+
+
+def non_maximum_suppression_inds(dist, points, scores, thresh=0.5, use_bbox=True, use_kdtree=True, verbose=1):
+    """stardist/nms.py:186-227. Polygons must be sorted by score (descending). Returns bool survivors."""
+    from .lib.stardist2d import c_non_max_suppression_inds
+    assert dist.ndim == 2 and points.ndim == 2
+    n_poly = dist.shape[0]
+    assert points.shape[0] == n_poly and (scores is None or len(scores) == n_poly)
+    if _is_t(dist):
+        import torch
+        d = dist.to(torch.float32).contiguous()
+        p = points.to(torch.float32).contiguous()
+    else:
+        d = np.ascontiguousarray(dist.astype(np.float32, copy=False))
+        p = np.ascontiguousarray(points.astype(np.float32, copy=False))
+    return c_non_max_suppression_inds(d, p, int(use_kdtree), int(use_bbox), int(verbose), np.float32(thresh))
+
+
+def non_maximum_suppression(dist, prob, grid=(1, 1), b=2, nms_thresh=0.5, prob_thresh=0.5,
+                            use_bbox=True, use_kdtree=True, verbose=False):
+    """stardist/nms.py:77-132: dense (Ny,Nx,n_rays)/(Ny,Nx) maps -> (points, prob, dist) of survivors."""
+    assert prob.ndim == 2 and dist.ndim == 3 and tuple(prob.shape) == tuple(dist.shape[:2])
+    grid = _normalize_grid(grid, 2)
+    mask = _ind_prob_thresh(prob, prob_thresh, b)
+    if _is_t(prob):
+        import torch
+        points = torch.stack(torch.where(mask), dim=1)
+        dist = dist[mask]; scores = prob[mask]
+        ind = _argsort_desc(scores)
+        dist, scores, points = dist[ind], scores[ind], points[ind]
+        points = points * torch.tensor(grid, device=points.device).reshape(1, 2)
+        inds = non_maximum_suppression_inds(dist, points.to(torch.int32), scores=scores, use_bbox=use_bbox,
+                                            use_kdtree=use_kdtree, thresh=nms_thresh, verbose=verbose)
+        return points[inds], scores[inds], dist[inds]
+    dist = np.asarray(dist); prob = np.asarray(prob)
+    points = np.stack(np.where(mask), axis=1)
+    dist = dist[mask]; scores = prob[mask]
+    ind = _argsort_desc(scores)
+    dist, scores, points = dist[ind], scores[ind], points[ind]
+    points = (points * np.array(grid).reshape((1, 2)))
+    inds = non_maximum_suppression_inds(dist, points.astype(np.int32, copy=False), scores=scores, use_bbox=use_bbox,
+                                        use_kdtree=use_kdtree, thresh=nms_thresh, verbose=verbose)
+    return points[inds], scores[inds], dist[inds]
+
+
+def non_maximum_suppression_sparse(dist, prob, points, b=2, nms_thresh=0.5, use_bbox=True, use_kdtree=True, verbose=False):
+    """stardist/nms.py:135-183: candidate lists -> (points, prob, dist, inds) of survivors."""
+    assert dist.ndim == 2 and prob.ndim == 1 and points.ndim == 2 and points.shape[-1] == 2 and \
+        len(prob) == len(dist) == len(points)
+    _sorted = _argsort_desc(prob)
+    if _is_t(prob):
+        import torch
+        inds_original = torch.arange(len(prob), device=prob.device)[_sorted]
+    else:
+        dist = np.asarray(dist); prob = np.asarray(prob); points = np.asarray(points)
+        inds_original = np.arange(len(prob))[_sorted]
+    probi, disti, pointsi = prob[_sorted], dist[_sorted], points[_sorted]
+    inds = non_maximum_suppression_inds(disti, pointsi, scores=probi, thresh=nms_thresh, use_kdtree=use_kdtree, verbose=verbose)
+    return pointsi[inds], probi[inds], disti[inds], inds_original[inds]
+
+
+# ----------------------------------------------------------------------------- 3D
+def non_maximum_suppression_3d_inds(dist, points, rays, scores, thresh=0.5, use_bbox=True, use_kdtree=True, verbose=1):
+    """stardist/nms.py:327-384 (re-sorts by score itself, returns survivors in input order)."""
+    from .lib.stardist3d import c_non_max_suppression_inds
+    assert dist.ndim == 2 and points.ndim == 2 and dist.shape[1] == len(rays)
+    n_poly = dist.shape[0]
+    if _is_t(dist):
+        import torch
+        if scores is None:
+            scores = torch.ones(n_poly, device=dist.device)
+        ind = _argsort_desc(scores)
+        survivors = torch.ones(n_poly, dtype=torch.bool, device=dist.device)
+        verts = torch.as_tensor(np.ascontiguousarray(rays.vertices, np.float32), device=dist.device)
+        faces = torch.as_tensor(np.ascontiguousarray(rays.faces, np.int32), device=dist.device)
+        survivors[ind] = c_non_max_suppression_inds(dist[ind].float().contiguous(), points[ind].float().contiguous(),
+                                                    verts, faces, scores[ind].float().contiguous(),
+                                                    int(use_bbox), int(use_kdtree), int(verbose), np.float32(thresh))
+        return survivors
+    if scores is None:
+        scores = np.ones(n_poly)
+    ind = _argsort_desc(scores)
+    survivors = np.ones(n_poly, bool)
+    dist, points, scores = dist[ind], points[ind], scores[ind]
+
+    def _prep(x, dtype):
+        return np.ascontiguousarray(x.astype(dtype, copy=False))
+    survivors[ind] = c_non_max_suppression_inds(_prep(dist, np.float32), _prep(points, np.float32),
+                                                _prep(rays.vertices, np.float32), _prep(rays.faces, np.int32),
+                                                _prep(scores, np.float32), int(use_bbox), int(use_kdtree), int(verbose),
+                                                np.float32(thresh))
+    return survivors
+
+
+def non_maximum_suppression_3d(dist, prob, rays, grid=(1, 1, 1), b=2, nms_thresh=0.5, prob_thresh=0.5, use_bbox=True,
+                               use_kdtree=True, verbose=False):
+    """stardist/nms.py:233-282"""
+    dist = np.asarray(dist); prob = np.asarray(prob)
+    assert prob.ndim == 3 and dist.ndim == 4 and dist.shape[-1] == len(rays) and prob.shape == dist.shape[:3]
+    grid = _normalize_grid(grid, 3)
+    ind_thresh = _ind_prob_thresh(prob, prob_thresh, b)
+    points = np.stack(np.where(ind_thresh), axis=1)
+    probi = prob[ind_thresh]; disti = dist[ind_thresh]
+    _sorted = _argsort_desc(probi)
+    probi, disti, points = probi[_sorted], disti[_sorted], points[_sorted]
+    points = (points * np.array(grid).reshape((1, 3)))
+    inds = non_maximum_suppression_3d_inds(disti, points, rays=rays, scores=probi, thresh=nms_thresh, use_bbox=use_bbox,
+                                           use_kdtree=use_kdtree, verbose=verbose)
+    return points[inds], probi[inds], disti[inds]
+
+
+def non_maximum_suppression_3d_sparse(dist, prob, points, rays, b=2, nms_thresh=0.5, use_kdtree=True, verbose=False):
+    """stardist/nms.py:285-324"""
+    assert dist.ndim == 2 and prob.ndim == 1 and points.ndim == 2 and dist.shape[-1] == len(rays) and \
+        points.shape[-1] == 3 and len(prob) == len(dist) == len(points)
+    _sorted = _argsort_desc(prob)
+    if _is_t(prob):
+        import torch
+        inds_original = torch.arange(len(prob), device=prob.device)[_sorted]
+    else:
+        dist = np.asarray(dist); prob = np.asarray(prob); points = np.asarray(points)
+        inds_original = np.arange(len(prob))[_sorted]
+    probi, disti, pointsi = prob[_sorted], dist[_sorted], points[_sorted]
+    inds = non_maximum_suppression_3d_inds(disti, pointsi, rays=rays, scores=probi, thresh=nms_thresh, use_kdtree=use_kdtree, verbose=verbose)
+    return pointsi[inds], probi[inds], disti[inds], inds_original[inds]
