@@ -147,11 +147,18 @@ struct StdSort {
 struct LocMin { int y; short left, right; };
 struct INode { int y; int x; short e1, e2; };
 
-// MAXV: max vertices per input polygon; MAXIL: intersection-node capacity per scan-beam;
-// MAXREC: output-ring capacity.
-template <int MAXV, int MAXIL, int MAXREC>
-struct Sweep {
+// SweepCore: everything of the sweep that does not depend on how output rings are stored.
+// D (CRTP) supplies the output side:
+//   int  out_add_pt(e, x, y)          AddOutPt :2463-2499, returns a point handle (or -1)
+//   void out_append(e1, e2)           AppendPolygon :2367-2460
+//   void out_ring_closed(r)           both edges of a local maximum carry ring r (:1888-1892)
+//   void out_add_join(op1, op2, x, y) AddJoin :1942-1949
+//   int  out_last_pt(e), out_pt_x(op) GetLastOutPt :2502-2509
+// MAXV: max vertices per input polygon; MAXIL: intersection-node capacity per scan-beam.
+template <class D, int MAXV, int MAXIL>
+struct SweepCore {
   enum { NE = 2 * MAXV };
+  SD_HD D& self() { return *static_cast<D*>(this); }
   // ---- edges (index = vertex slot; polygon A uses [0,MAXV), polygon B [MAXV,2*MAXV))
   int botx[NE], boty[NE], topx[NE], topy[NE], curx[NE], cury[NE];
   double dx[NE];
@@ -166,15 +173,9 @@ struct Sweep {
   INode il[MAXIL];
   int n_il;
   short ael, sel;            // heads (-1 = empty)
-  // ---- output rings: front/back point + running shoelace sum front->back
-  int rfx[MAXREC], rfy[MAXREC], rlx[MAXREC], rly[MAXREC];
-  i64 rsum[MAXREC];
-  int n_rec;
-  i64 twice_area;            // sum over closed rings of |2*area|
-  i64 sum_abs_terms;         // sum of |cross| terms (exactness bound for the float path)
   int status;
   int n_joins;               // number of AddJoin calls the reference would have made
-  int gjx1[16], gjx2[16];    // ghost joins of the current scan-line: (OutPt1.X, OffPt.X)  :1968-1975
+  int gjop[16], gjx1[16], gjx2[16], gjy2[16];   // ghost joins of the current scan-line: OutPt1, OutPt1.X, OffPt  :1968-1975
   int n_gj;
 
   // ------------------------------------------------------------------ helpers
@@ -203,12 +204,15 @@ struct Sweep {
     if (b1 > b2) { i64 t = b1; b1 = b2; b2 = t; }
     return (a1 < b2) && (b1 < a2);
   }
-  SD_HD void add_ghost_join(int x1, int x2) {
-    if (n_gj < 16) { gjx1[n_gj] = x1; gjx2[n_gj] = x2; ++n_gj; } else ++n_joins;  // overflow: be conservative
+  SD_HD void add_join(int op1, int op2, int offx, int offy) { ++n_joins; self().out_add_join(op1, op2, offx, offy); }
+  SD_HD void add_ghost_join(int op, int x1, int x2, int y2) {
+    if (n_gj < 16) { gjop[n_gj] = op; gjx1[n_gj] = x1; gjx2[n_gj] = x2; gjy2[n_gj] = y2; ++n_gj; }
+    else { ++n_joins; status |= ST_OVERFLOW_REC; }
   }
-  SD_HD void count_horz_joins(int horz) {                                   // :2721-2732, 2774-2785
+  SD_HD void horz_joins(int horz, int op1) {                                // :2721-2732, 2774-2785
     for (int h = sel; h >= 0; h = snext[h])
-      if (outidx[h] >= 0 && horz_segments_overlap(botx[horz], topx[horz], botx[h], topx[h])) ++n_joins;
+      if (outidx[h] >= 0 && horz_segments_overlap(botx[horz], topx[horz], botx[h], topx[h]))
+        add_join(self().out_last_pt(h), op1, topx[h], topy[h]);
   }
   SD_HD void insert_scanbeam(int y) {
     for (int i = 0; i < n_sb; ++i) if (sb[i] == y) return;   // duplicates are popped together (:1341-1348)
@@ -354,80 +358,26 @@ struct Sweep {
     return true;
   }
 
-  // ------------------------------------------------------------------ output rings
-  SD_HD void term(i64 c) { sum_abs_terms += sd_abs64(c); }
-  SD_HD void add_out_pt(int e, int px, int py) {                            // :2463-2499
-    int r = outidx[e];
-    if (r < 0) {
-      if (n_rec >= MAXREC) { status |= ST_OVERFLOW_REC; return; }
-      r = n_rec++;
-      rfx[r] = rlx[r] = px; rfy[r] = rly[r] = py; rsum[r] = 0;
-      outidx[e] = (short)r;
-    } else {
-      if (side[e] == kLeft) {           // to front
-        if (px == rfx[r] && py == rfy[r]) return;
-        i64 c = sd_cross(px, py, rfx[r], rfy[r]); term(c);
-        rsum[r] += c; rfx[r] = px; rfy[r] = py;
-      } else {
-        if (px == rlx[r] && py == rly[r]) return;
-        i64 c = sd_cross(rlx[r], rly[r], px, py); term(c);
-        rsum[r] += c; rlx[r] = px; rly[r] = py;
-      }
-    }
-  }
-  SD_HD void close_ring(int r) {
-    i64 c = sd_cross(rlx[r], rly[r], rfx[r], rfy[r]); term(c);
-    twice_area += sd_abs64(rsum[r] + c);
-  }
-  SD_HD void append_polygon(int e1, int e2) {                               // :2367-2460
-    int r1 = outidx[e1], r2 = outidx[e2];
-    i64 c;
-    if (side[e1] == kLeft) {
-      if (side[e2] == kLeft) {        // reverse(2) + 1
-        c = sd_cross(rfx[r2], rfy[r2], rfx[r1], rfy[r1]);
-        rsum[r1] = -rsum[r2] + c + rsum[r1];
-        rfx[r1] = rlx[r2]; rfy[r1] = rly[r2];
-      } else {                        // 2 + 1
-        c = sd_cross(rlx[r2], rly[r2], rfx[r1], rfy[r1]);
-        rsum[r1] = rsum[r2] + c + rsum[r1];
-        rfx[r1] = rfx[r2]; rfy[r1] = rfy[r2];
-      }
-    } else {
-      if (side[e2] == kRight) {       // 1 + reverse(2)
-        c = sd_cross(rlx[r1], rly[r1], rlx[r2], rly[r2]);
-        rsum[r1] = rsum[r1] + c - rsum[r2];
-        rlx[r1] = rfx[r2]; rly[r1] = rfy[r2];
-      } else {                        // 1 + 2
-        c = sd_cross(rlx[r1], rly[r1], rfx[r2], rfy[r2]);
-        rsum[r1] = rsum[r1] + c + rsum[r2];
-        rlx[r1] = rlx[r2]; rly[r1] = rly[r2];
-      }
-    }
-    term(c);
-    int okIdx = r1, obsolete = r2;
-    outidx[e1] = kUnassigned; outidx[e2] = kUnassigned;
-    for (int e = ael; e >= 0; e = anext[e]) {
-      if (outidx[e] == obsolete) { outidx[e] = (short)okIdx; side[e] = side[e1]; break; }
-    }
-  }
+  // ------------------------------------------------------------------ output (delegated to D)
+  SD_HD int add_out_pt(int e, int px, int py) { return self().out_add_pt(e, px, py); }
   SD_HD void add_local_max_poly(int e1, int e2, int px, int py) {           // :1884-1897
     add_out_pt(e1, px, py);
     if (outidx[e1] == outidx[e2]) {
-      if (outidx[e1] >= 0) close_ring(outidx[e1]);
+      if (outidx[e1] >= 0) self().out_ring_closed(outidx[e1]);
       outidx[e1] = kUnassigned; outidx[e2] = kUnassigned;
-    } else if (outidx[e1] < outidx[e2]) append_polygon(e1, e2);
-    else append_polygon(e2, e1);
+    } else if (outidx[e1] < outidx[e2]) self().out_append(e1, e2);
+    else self().out_append(e2, e1);
   }
-  SD_HD void add_local_min_poly(int e1, int e2, int px, int py) {           // :1841-1881
-    int e, prevE;
+  SD_HD int add_local_min_poly(int e1, int e2, int px, int py) {            // :1841-1881
+    int e, prevE, result;
     if (is_horz(e2) || dx[e1] > dx[e2]) {
-      add_out_pt(e1, px, py);
+      result = add_out_pt(e1, px, py);
       outidx[e2] = outidx[e1];
       side[e1] = kLeft; side[e2] = kRight;
       e = e1;
       prevE = (aprev[e] == e2) ? aprev[e2] : aprev[e];
     } else {
-      add_out_pt(e2, px, py);
+      result = add_out_pt(e2, px, py);
       outidx[e1] = outidx[e2];
       side[e1] = kRight; side[e2] = kLeft;
       e = e2;
@@ -437,10 +387,11 @@ struct Sweep {
       i64 xPrev = top_x(prevE, py), xE = top_x(e, py);
       if (xPrev == xE && wdelta[e] != 0 && wdelta[prevE] != 0 &&
           slopes_equal4(xPrev, py, topx[prevE], topy[prevE], xE, py, topx[e], topy[e])) {
-        add_out_pt(prevE, px, py);
-        ++n_joins;
+        const int outPt = add_out_pt(prevE, px, py);
+        add_join(result, outPt, topx[e], topy[e]);
       }
     }
+    return result;
   }
 
   // ------------------------------------------------------------------ AEL / SEL lists
@@ -614,36 +565,36 @@ struct Sweep {
     while (cur_lm < n_lm && lm[cur_lm].y == botY) {
       int lb = lm[cur_lm].left, rb = lm[cur_lm].right;
       ++cur_lm;
-      bool op1 = false;
+      int op1 = -1; bool have_op1 = false;
       insert_edge_into_ael(lb, -1);
       insert_edge_into_ael(rb, lb);
       set_winding_count(lb);
       wcnt[rb] = wcnt[lb]; wcnt2[rb] = wcnt2[lb];
-      if (is_contributing(lb)) { add_local_min_poly(lb, rb, botx[lb], boty[lb]); op1 = true; }
+      if (is_contributing(lb)) { op1 = add_local_min_poly(lb, rb, botx[lb], boty[lb]); have_op1 = true; }
       insert_scanbeam(topy[lb]);
       if (is_horz(rb)) {
         add_edge_to_sel(rb);
         if (lml[rb] >= 0) insert_scanbeam(topy[lml[rb]]);
       } else insert_scanbeam(topy[rb]);
 
-      if (op1 && is_horz(rb) && n_gj > 0 && wdelta[rb] != 0) {             // :2029-2040
+      if (have_op1 && is_horz(rb) && n_gj > 0 && wdelta[rb] != 0) {       // :2029-2040
         for (int g = 0; g < n_gj; ++g)
-          if (horz_segments_overlap(gjx1[g], gjx2[g], botx[rb], topx[rb])) ++n_joins;
+          if (horz_segments_overlap(gjx1[g], gjx2[g], botx[rb], topx[rb])) add_join(gjop[g], op1, gjx2[g], gjy2[g]);
       }
       int lp = aprev[lb];
       if (outidx[lb] >= 0 && lp >= 0 && curx[lp] == botx[lb] && outidx[lp] >= 0 &&
           slopes_equal4(botx[lp], boty[lp], topx[lp], topy[lp], curx[lb], cury[lb], topx[lb], topy[lb]) &&
           wdelta[lb] != 0 && wdelta[lp] != 0) {
-        add_out_pt(lp, botx[lb], boty[lb]);
-        ++n_joins;
+        const int op2 = add_out_pt(lp, botx[lb], boty[lb]);
+        add_join(op1, op2, topx[lb], topy[lb]);
       }
       if (anext[lb] != rb) {
         int rp = aprev[rb];
         if (outidx[rb] >= 0 && rp >= 0 && outidx[rp] >= 0 &&
             slopes_equal4(curx[rp], cury[rp], topx[rp], topy[rp], curx[rb], cury[rb], topx[rb], topy[rb]) &&
             wdelta[rb] != 0 && wdelta[rp] != 0) {
-          add_out_pt(rp, botx[rb], boty[rb]);
-          ++n_joins;
+          const int op2 = add_out_pt(rp, botx[rb], boty[rb]);
+          add_join(op1, op2, topx[rb], topy[rb]);
         }
         int e = anext[lb];
         int guard = 0;
@@ -653,7 +604,6 @@ struct Sweep {
           if (++guard > NE) { status |= ST_ITER; break; }
         }
       }
-      (void)op1;
     }
   }
 
@@ -676,7 +626,7 @@ struct Sweep {
     int eLast = horz, eMaxPair = -1;
     while (lml[eLast] >= 0 && is_horz(lml[eLast])) eLast = lml[eLast];
     if (lml[eLast] < 0) eMaxPair = get_maxima_pair(eLast);
-    bool op1 = false;
+    int op1 = -1; bool have_op1 = false;
     int guard = 0;
     for (;;) {
       bool isLast = (horz == eLast);
@@ -686,10 +636,10 @@ struct Sweep {
         if ((l2r && curx[e] > hr) || (!l2r && curx[e] < hl)) break;
         if (curx[e] == topx[horz] && lml[horz] >= 0 && dx[e] < dx[lml[horz]]) break;
         if (outidx[horz] >= 0) {
-          add_out_pt(horz, curx[e], cury[e]);
-          op1 = true;
-          count_horz_joins(horz);
-          add_ghost_join(curx[e], botx[horz]);
+          op1 = add_out_pt(horz, curx[e], cury[e]);
+          have_op1 = true;
+          horz_joins(horz, op1);
+          add_ghost_join(op1, curx[e], botx[horz], boty[horz]);
         }
         if (e == eMaxPair && isLast) {
           if (outidx[horz] >= 0) add_local_max_poly(horz, eMaxPair, topx[horz], topy[horz]);
@@ -709,26 +659,25 @@ struct Sweep {
       if (botx[horz] < topx[horz]) { hl = botx[horz]; hr = topx[horz]; l2r = true; }
       else { hl = topx[horz]; hr = botx[horz]; l2r = false; }
     }
-    if (outidx[horz] >= 0 && !op1) {                                        // :2771-2787
-      int r = outidx[horz];
-      int lx = (side[horz] == kLeft) ? rfx[r] : rlx[r];
-      count_horz_joins(horz);
-      add_ghost_join(lx, topx[horz]);
+    if (outidx[horz] >= 0 && !have_op1) {                                   // :2771-2787
+      op1 = self().out_last_pt(horz);
+      horz_joins(horz, op1);
+      add_ghost_join(op1, self().out_last_pt_x(horz), topx[horz], topy[horz]);
     }
     if (lml[horz] >= 0) {
       if (outidx[horz] >= 0) {
-        add_out_pt(horz, topx[horz], topy[horz]);
+        op1 = add_out_pt(horz, topx[horz], topy[horz]);
         horz = update_edge_into_ael(horz);
         if (wdelta[horz] == 0) return;
         int ePrev = aprev[horz], eNext = anext[horz];
         if (ePrev >= 0 && curx[ePrev] == botx[horz] && cury[ePrev] == boty[horz] && wdelta[ePrev] != 0 &&
             (outidx[ePrev] >= 0 && cury[ePrev] > topy[ePrev] && slopes_equal_e(horz, ePrev))) {
-          add_out_pt(ePrev, botx[horz], boty[horz]);
-          ++n_joins;
+          const int op2 = add_out_pt(ePrev, botx[horz], boty[horz]);
+          add_join(op1, op2, topx[horz], topy[horz]);
         } else if (eNext >= 0 && curx[eNext] == botx[horz] && cury[eNext] == boty[horz] && wdelta[eNext] != 0 &&
                    outidx[eNext] >= 0 && cury[eNext] > topy[eNext] && slopes_equal_e(horz, eNext)) {
-          add_out_pt(eNext, botx[horz], boty[horz]);
-          ++n_joins;
+          const int op2 = add_out_pt(eNext, botx[horz], boty[horz]);
+          add_join(op1, op2, topx[horz], topy[horz]);
         }
       } else update_edge_into_ael(horz);
     } else {
@@ -898,22 +847,22 @@ struct Sweep {
     while (e >= 0) {
       if (++guard > 4 * NE) { status |= ST_ITER; break; }
       if (topy[e] == topY && lml[e] >= 0) {
-        bool op = false;
-        if (outidx[e] >= 0) { add_out_pt(e, topx[e], topy[e]); op = true; }
+        bool op = false; int oph = -1;
+        if (outidx[e] >= 0) { oph = add_out_pt(e, topx[e], topy[e]); op = true; }
         e = update_edge_into_ael(e);
         int ePrev = aprev[e], eNext = anext[e];
         if (ePrev >= 0 && curx[ePrev] == botx[e] && cury[ePrev] == boty[e] && op &&
             outidx[ePrev] >= 0 && cury[ePrev] > topy[ePrev] &&
             slopes_equal4(curx[e], cury[e], topx[e], topy[e], curx[ePrev], cury[ePrev], topx[ePrev], topy[ePrev]) &&
             wdelta[e] != 0 && wdelta[ePrev] != 0) {
-          add_out_pt(ePrev, botx[e], boty[e]);
-          ++n_joins;
+          const int op2 = add_out_pt(ePrev, botx[e], boty[e]);
+          add_join(oph, op2, topx[e], topy[e]);
         } else if (eNext >= 0 && curx[eNext] == botx[e] && cury[eNext] == boty[e] && op &&
                    outidx[eNext] >= 0 && cury[eNext] > topy[eNext] &&
                    slopes_equal4(curx[e], cury[e], topx[e], topy[e], curx[eNext], cury[eNext], topx[eNext], topy[eNext]) &&
                    wdelta[e] != 0 && wdelta[eNext] != 0) {
-          add_out_pt(eNext, botx[e], boty[e]);
-          ++n_joins;
+          const int op2 = add_out_pt(eNext, botx[e], boty[e]);
+          add_join(oph, op2, topx[e], topy[e]);
         }
       }
       e = anext[e];
@@ -921,13 +870,14 @@ struct Sweep {
   }
 
   // ------------------------------------------------------------------ Execute  :1560-1621, 1247-1276
-  SD_HD void reset_state() {
-    n_lm = 0; cur_lm = 0; n_sb = 0; n_il = 0; ael = -1; sel = -1; n_rec = 0;
-    twice_area = 0; sum_abs_terms = 0; status = ST_OK; n_joins = 0; n_gj = 0;
+  SD_HD void reset_core() {
+    n_lm = 0; cur_lm = 0; n_sb = 0; n_il = 0; ael = -1; sel = -1;
+    status = ST_OK; n_joins = 0; n_gj = 0;
   }
-  // Returns 2*area of (A ∩ B) as the reference would sum it (0 if Clipper's Execute fails).
-  SD_HD i64 execute() {
-    if (n_lm == 0) return 0;
+  // Runs the sweep (Clipper::ExecuteInternal up to the end of the scan-beam loop). Returns false if
+  // Clipper's Execute would fail (empty solution).
+  SD_HD bool run_sweep() {
+    if (n_lm == 0) return true;
     if (!StdSort<LocMin>::sort(lm, n_lm)) status |= ST_SORT_DEPTH;
     for (int i = 0; i < n_lm; ++i) {
       insert_scanbeam(lm[i].y);
@@ -936,7 +886,7 @@ struct Sweep {
     }
     ael = -1; cur_lm = 0;
     int botY, topY = 0;
-    if (!pop_scanbeam(botY)) return 0;
+    if (!pop_scanbeam(botY)) return false;
     insert_local_minima_into_ael(botY);
     int guard = 0;
     bool ok = true;
@@ -952,9 +902,87 @@ struct Sweep {
       botY = topY;
       insert_local_minima_into_ael(botY);
     }
-    if (!ok || (status & ST_FAIL)) { status |= ST_FAIL; return 0; }
-    return twice_area;
+    if (!ok || (status & ST_FAIL)) { status |= ST_FAIL; return false; }
+    return true;
   }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Sweep: the fast variant.  Output rings are kept as {front point, back point, running shoelace
+// sum}; exact whenever the reference records no joins for the pair (n_joins == 0).
+// MAXREC: output-ring capacity.
+template <int MAXV, int MAXIL, int MAXREC>
+struct Sweep : SweepCore<Sweep<MAXV, MAXIL, MAXREC>, MAXV, MAXIL> {
+  typedef SweepCore<Sweep<MAXV, MAXIL, MAXREC>, MAXV, MAXIL> B;
+  using B::outidx; using B::side; using B::status; using B::ael; using B::anext;
+  int rfx[MAXREC], rfy[MAXREC], rlx[MAXREC], rly[MAXREC];
+  i64 rsum[MAXREC];
+  int n_rec;
+  i64 twice_area;            // sum over closed rings of |2*area|
+  i64 sum_abs_terms;         // sum of |cross| terms (exactness bound for the float path)
+  SD_HD void term(i64 c) { sum_abs_terms += sd_abs64(c); }
+  SD_HD int out_add_pt(int e, int px, int py) {                             // :2463-2499
+    int r = outidx[e];
+    if (r < 0) {
+      if (n_rec >= MAXREC) { status |= ST_OVERFLOW_REC; return -1; }
+      r = n_rec++;
+      rfx[r] = rlx[r] = px; rfy[r] = rly[r] = py; rsum[r] = 0;
+      outidx[e] = (short)r;
+    } else {
+      if (side[e] == kLeft) {           // to front
+        if (px == rfx[r] && py == rfy[r]) return -1;
+        i64 c = sd_cross(px, py, rfx[r], rfy[r]); term(c);
+        rsum[r] += c; rfx[r] = px; rfy[r] = py;
+      } else {
+        if (px == rlx[r] && py == rly[r]) return -1;
+        i64 c = sd_cross(rlx[r], rly[r], px, py); term(c);
+        rsum[r] += c; rlx[r] = px; rly[r] = py;
+      }
+    }
+    return -1;
+  }
+  SD_HD void out_ring_closed(int r) {
+    i64 c = sd_cross(rlx[r], rly[r], rfx[r], rfy[r]); term(c);
+    twice_area += sd_abs64(rsum[r] + c);
+  }
+  SD_HD void out_append(int e1, int e2) {                                   // :2367-2460
+    int r1 = outidx[e1], r2 = outidx[e2];
+    i64 c;
+    if (side[e1] == kLeft) {
+      if (side[e2] == kLeft) {        // reverse(2) + 1
+        c = sd_cross(rfx[r2], rfy[r2], rfx[r1], rfy[r1]);
+        rsum[r1] = -rsum[r2] + c + rsum[r1];
+        rfx[r1] = rlx[r2]; rfy[r1] = rly[r2];
+      } else {                        // 2 + 1
+        c = sd_cross(rlx[r2], rly[r2], rfx[r1], rfy[r1]);
+        rsum[r1] = rsum[r2] + c + rsum[r1];
+        rfx[r1] = rfx[r2]; rfy[r1] = rfy[r2];
+      }
+    } else {
+      if (side[e2] == kRight) {       // 1 + reverse(2)
+        c = sd_cross(rlx[r1], rly[r1], rlx[r2], rly[r2]);
+        rsum[r1] = rsum[r1] + c - rsum[r2];
+        rlx[r1] = rfx[r2]; rly[r1] = rfy[r2];
+      } else {                        // 1 + 2
+        c = sd_cross(rlx[r1], rly[r1], rfx[r2], rfy[r2]);
+        rsum[r1] = rsum[r1] + c + rsum[r2];
+        rlx[r1] = rlx[r2]; rly[r1] = rly[r2];
+      }
+    }
+    term(c);
+    int okIdx = r1, obsolete = r2;
+    outidx[e1] = kUnassigned; outidx[e2] = kUnassigned;
+    for (int e = ael; e >= 0; e = anext[e]) {
+      if (outidx[e] == obsolete) { outidx[e] = (short)okIdx; side[e] = side[e1]; break; }
+    }
+  }
+
+  SD_HD void out_add_join(int, int, int, int) {}
+  SD_HD int out_last_pt(int) { return -1; }
+  SD_HD int out_last_pt_x(int e) { const int r = outidx[e]; return (side[e] == kLeft) ? rfx[r] : rlx[r]; }
+  SD_HD void reset_state() { B::reset_core(); n_rec = 0; twice_area = 0; sum_abs_terms = 0; }
+  // Returns 2*area of (A ∩ B) as the reference would sum it (0 if Clipper's Execute fails).
+  SD_HD i64 execute() { return B::run_sweep() ? twice_area : 0; }
 };
 
 }  // namespace sdclip

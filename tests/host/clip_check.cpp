@@ -3,6 +3,7 @@
 // Clipper (oracle/_ref/libclipper_ref.so) on seeded random star-polygon pairs.
 // Build/run: see tests/test_clip_host.py.
 #include "../../stardist_amd/csrc/clip_sweep.h"
+#include "../../stardist_amd/csrc/clip_sweep_full.h"
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -15,6 +16,7 @@ extern "C" int clipper_ref_intersect(const int64_t*, const int64_t*, int, const 
                                      int64_t*, int, int*, int);
 
 typedef sdclip::Sweep<128, 512, 128> SweepT;
+typedef sdclip::SweepFull<128, 512, 128, 1024, 256> SweepF;
 
 static void make_poly(std::mt19937& rng, int n_rays, float radius, float noise, float cy, float cx,
                       std::vector<int64_t>& xs, std::vector<int64_t>& ys) {
@@ -39,10 +41,13 @@ int main(int argc, char** argv) {
   unsigned seed = argc > 5 ? atoi(argv[5]) : 1;
   float offset = argc > 6 ? atof(argv[6]) : 0.f;      // coordinate offset (large-coordinate regime)
   int verbose = argc > 7 ? atoi(argv[7]) : 0;
+  int all_full = argc > 8 ? atoi(argv[8]) : 0;
   std::mt19937 rng(seed);
   std::uniform_real_distribution<float> U01(0.f, 1.f);
   std::vector<int64_t> xa, ya, xb, yb;
   static SweepT sw;
+  static SweepF sf;
+  long full_runs = 0, mism_fast_nojoin = 0;
   long mism = 0, with_joins = 0, mism_joins = 0, flagged = 0, nonzero = 0, inexact = 0;
   double max_rel = 0;
   for (long p = 0; p < n_pairs; p++) {
@@ -59,8 +64,18 @@ int main(int argc, char** argv) {
     bool okB = sw.add_path(xb.data(), yb.data(), n_rays, sdclip::kSubject, 128);
     (void)okA; (void)okB;
     long long twice = sw.execute();
+    int st = sw.status;
+    if (sw.n_joins == 0 && 0.5f * (float)twice != ref) mism_fast_nojoin++;
+    if (sw.n_joins > 0 || all_full) {
+      sf.reset_state();
+      sf.add_path(xa.data(), ya.data(), n_rays, sdclip::kClip, 0);
+      sf.add_path(xb.data(), yb.data(), n_rays, sdclip::kSubject, 128);
+      twice = sf.execute();
+      st = sf.status;
+      full_runs++;
+    }
     float mine = 0.5f * (float)twice;
-    if (sw.status) flagged++;
+    if (st) flagged++;
     if (sw.n_joins) with_joins++;
     if (ref != 0) nonzero++;
     if (sw.sum_abs_terms >= (1ll << 24)) inexact++;
@@ -82,7 +97,7 @@ int main(int argc, char** argv) {
       }
     }
   }
-  printf("pairs=%ld nonzero=%ld mismatches=%ld (with_joins=%ld, mism_with_joins=%ld) flagged=%ld inexact_risk=%ld max_rel=%.3g\n",
-         n_pairs, nonzero, mism, with_joins, mism_joins, flagged, inexact, max_rel);
+  printf("pairs=%ld nonzero=%ld mismatches=%ld (with_joins=%ld, mism_with_joins=%ld, fast_nojoin_mism=%ld, full_runs=%ld) flagged=%ld inexact_risk=%ld max_rel=%.3g\n",
+         n_pairs, nonzero, mism, with_joins, mism_joins, mism_fast_nojoin, full_runs, flagged, inexact, max_rel);
   return mism ? 1 : 0;
 }
