@@ -66,6 +66,7 @@ def cpu_baseline(img_np, model, sample, threads):
     from oracle import port, ref
     os.environ["OMP_NUM_THREADS"] = str(threads)
     torch.set_num_threads(threads)
+    ref.stardist2d(); ref.set_threads(threads)
     x = img_np[:sample, :sample]
     net_cpu = copy.deepcopy(model.net).to("cpu").float()
     t0 = time.time()

@@ -37,6 +37,20 @@ def _load_ext(name):
 _cache = {}
 
 
+def set_threads(n):
+    """OpenMP threads used by the compiled reference (same libgomp instance as the oracle .so files).
+
+    The reference's 3D NMS accumulates the anisotropy inside an `omp parallel for` without
+    synchronisation (stardist3d_impl.cpp:995-1011), so its result is only DEFINED for one thread;
+    parity tests therefore run it with n=1.  Timing legs (bench.py cpu_baseline) set n=cores."""
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(int(n))
+        return True
+    except OSError:
+        return False
+
+
 def stardist2d():
     if "2d" not in _cache:
         _cache["2d"] = _load_ext("stardist2d")
@@ -46,6 +60,7 @@ def stardist2d():
 def stardist3d():
     if "3d" not in _cache:
         _cache["3d"] = _load_ext("stardist3d")
+        set_threads(int(os.environ.get("ORACLE_OMP_THREADS", "1")))
     return _cache["3d"]
 
 

@@ -1,23 +1,828 @@
-// nms3d.hip -- PLACEHOLDER until the 3D cascade lands (entry points fail loudly).
+// nms3d.hip -- greedy non-maximum suppression of star-convex polyhedra on gfx950.
+//
+// Replaces _COMMON_non_maximum_suppression_sparse (stardist/lib/stardist3d_impl.cpp:956-1385),
+// reached through the reference's C ABI name _LIB_non_maximum_suppression_sparse
+// (stardist3d_lib.h:52-66) and the CPython c_non_max_suppression_inds (stardist3d.cpp:13-62).
+//
+//   P1  per candidate: signed-tetrahedra volume (sequential fp32 sum over faces, :257-291),
+//       integer bbox (lrint, :536-567)
+//   P1b anisotropy = max_k(mean bbox extent) / mean bbox extent_k  (:1008-1023) -- the reference
+//       accumulates it inside an OpenMP loop without synchronisation; the defined value is the
+//       sequential fp32 sum over candidates, which is what is computed here (on the host, from
+//       the device bboxes, n_polys float additions)
+//   P2  per candidate: outer radius, outer/inner isotropic radii (:343-467)
+//   P3  uniform-grid broad phase (replaces nanoflann, :1056-1085, :1167-1171)
+//   greedy rounds (same fixed point as the sequential loop :1121-1338, see nms2d.hip):
+//       emit:  exact neighbour predicate, then the two cheap cascade stages inline
+//              (1) sphere/bbox upper bound  -> keep      :1213-1228
+//              (2) inscribed-sphere lower bound -> suppress :1232-1248
+//       (3) kernel-kernel intersection volume -> suppress   :1261-1277
+//           Qhull's half-space intersection is replaced by an exact-geometry routine: one wave
+//           per pair, one half-space per lane, the face polygon of each plane obtained by
+//           clipping against all other half-spaces in fp64, volume = 1/3 sum(area * height).
+//       (4) hull-hull intersection volume -> keep           :1282-1295
+//           convex hulls by exhaustive facet search (one wave per polyhedron: every vertex triple whose
+//           plane has all other vertices on one side), then the same half-space volume routine.
+//       (5) voxel rendering: count lattice points inside both polyhedra -> suppress :1305-1330
 #include "common.h"
+#include "geom3d.h"
 #include "../../include/stardist_hip.h"
-extern "C" int sd_nms3d_device(const float*, const float*, const float*, int, int, int, const float*, const int*, float, int,
-                               int, int, uint8_t*, int64_t*, void*) {
-  sd::set_error("sd_nms3d_device: not implemented yet");
-  return -1;
+#include <hipcub/hipcub.hpp>
+#include <math.h>
+#include <vector>
+
+namespace {
+
+typedef long long i64;
+enum { ST_UNDECIDED = 0, ST_KEPT = 1, ST_SUPPRESSED = 2 };
+
+// ------------------------------------------------------------------ P1 / P2
+__global__ void k_pre1(const float* __restrict__ dist, const float* __restrict__ pts, const float* __restrict__ verts,
+                       const int* __restrict__ faces, int N, int R, int F, float* __restrict__ volume, int* __restrict__ bbox) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float* d = dist + (size_t)i * R;
+  float vol = 0.f;                                                            // polyhedron_volume :257-291
+  for (int f = 0; f < F; ++f) {
+    const int iA = faces[3 * f], iB = faces[3 * f + 1], iC = faces[3 * f + 2];
+    const float dA = d[iA], dB = d[iB], dC = d[iC];
+    vol += sd3::tetrahedron_volume0(dA * verts[3 * iA], dA * verts[3 * iA + 1], dA * verts[3 * iA + 2],
+                                    dB * verts[3 * iB], dB * verts[3 * iB + 1], dB * verts[3 * iB + 2],
+                                    dC * verts[3 * iC], dC * verts[3 * iC + 1], dC * verts[3 * iC + 2]);
+  }
+  volume[i] = vol;
+  const float cz = pts[3 * i], cy = pts[3 * i + 1], cx = pts[3 * i + 2];
+  int z1 = INT_MAX, z2 = -1, y1 = INT_MAX, y2 = -1, x1 = INT_MAX, x2 = -1;   // polyhedron_bbox :536-567
+  for (int j = 0; j < R; ++j) {
+    const float z = cz + d[j] * verts[3 * j], y = cy + d[j] * verts[3 * j + 1], x = cx + d[j] * verts[3 * j + 2];
+    const int rz = sd3::round_to_int(z), ry = sd3::round_to_int(y), rx = sd3::round_to_int(x);
+    z1 = min(z1, rz); z2 = max(z2, rz); y1 = min(y1, ry); y2 = max(y2, ry); x1 = min(x1, rx); x2 = max(x2, rx);
+  }
+  int* b = bbox + 6 * (size_t)i;
+  b[0] = z1; b[1] = z2; b[2] = y1; b[3] = y2; b[4] = x1; b[5] = x2;
 }
-extern "C" void _LIB_non_maximum_suppression_sparse(const float*, const float*, const float*, const int, const int, const int,
-                                                    const float*, const int*, const float, const int, const int, const int, bool*) {
-  fprintf(stderr, "_LIB_non_maximum_suppression_sparse: not implemented yet\n");
-  abort();
+
+struct Aniso { float a[3]; };
+
+__global__ void k_pre2(const float* __restrict__ dist, const float* __restrict__ verts, const int* __restrict__ faces, int N, int R,
+                       int F, Aniso an, float* __restrict__ r_outer, float* __restrict__ r_outer_iso, float* __restrict__ r_inner_iso,
+                       int* gmax /* max outer radius bits */) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float* d = dist + (size_t)i * R;
+  float r = 0;                                                                // bounding_radius_outer :343-350
+  float r2max = 0;                                                            // bounding_radius_outer_isotropic :401-418
+  for (int k = 0; k < R; ++k) {
+    r = fmaxf(r, d[k]);
+    const float z = an.a[0] * d[k] * verts[3 * k], y = an.a[1] * d[k] * verts[3 * k + 1], x = an.a[2] * d[k] * verts[3 * k + 2];
+    r2max = fmaxf(z * z + y * y + x * x, r2max);
+  }
+  r_outer[i] = r;
+  r_outer_iso[i] = sqrtf(r2max);
+  float rmin = INFINITY;                                                      // bounding_radius_inner_isotropic :420-467
+  for (int f = 0; f < F; ++f) {
+    const int iA = faces[3 * f], iB = faces[3 * f + 1], iC = faces[3 * f + 2];
+    const float Az = an.a[0] * d[iA] * verts[3 * iA], Ay = an.a[1] * d[iA] * verts[3 * iA + 1], Ax = an.a[2] * d[iA] * verts[3 * iA + 2];
+    const float Bz = an.a[0] * d[iB] * verts[3 * iB], By = an.a[1] * d[iB] * verts[3 * iB + 1], Bx = an.a[2] * d[iB] * verts[3 * iB + 2];
+    const float Cz = an.a[0] * d[iC] * verts[3 * iC], Cy = an.a[1] * d[iC] * verts[3 * iC + 1], Cx = an.a[2] * d[iC] * verts[3 * iC + 2];
+    const float pz = Bz - Az, py = By - Ay, px = Bx - Ax;
+    const float qz = Cz - Az, qy = Cy - Ay, qx = Cx - Ax;
+    float Nz = (px * qy - py * qx);
+    float Ny = (pz * qx - px * qz);
+    float Nx = (py * qz - pz * qy);
+    const float normz = (float)(1.f / ((double)sqrtf(Nz * Nz + Ny * Ny + Nx * Nx) + 1.e-10));
+    Nz *= normz; Ny *= normz; Nx *= normz;
+    const float rr = Az * Nz + Ay * Ny + Ax * Nx;
+    rmin = fminf(rmin, rr);
+  }
+  r_inner_iso[i] = rmin;
+  const int rb = __float_as_int(r);
+  volatile int* gm = gmax;
+  if (rb > gm[0]) atomicMax(gmax, rb);
 }
-extern "C" int sd_polyhedron_to_label_device(const float*, const float*, const float*, const int*, int, int, int, const int*, int,
-                                             int, int, int, int, int, int, int*, void*) {
-  sd::set_error("sd_polyhedron_to_label_device: not implemented yet");
-  return -1;
+
+// ------------------------------------------------------------------ grid
+struct Grid3 { float z0, y0, x0, inv_cs; int nz, ny, nx; };
+__device__ __forceinline__ int cell3(const Grid3 g, const float* p, int& cz, int& cy, int& cx) {
+  cz = min(max((int)((p[0] - g.z0) * g.inv_cs), 0), g.nz - 1);
+  cy = min(max((int)((p[1] - g.y0) * g.inv_cs), 0), g.ny - 1);
+  cx = min(max((int)((p[2] - g.x0) * g.inv_cs), 0), g.nx - 1);
+  return (cz * g.ny + cy) * g.nx + cx;
 }
-extern "C" void _LIB_polyhedron_to_label(const float*, const float*, const float*, const int*, const int, const int, const int,
-                                         const int*, const int, const int, const int, const int, const int, const int, const int, int*) {
-  fprintf(stderr, "_LIB_polyhedron_to_label: not implemented yet\n");
-  abort();
+__global__ void k_minmax3(const float* __restrict__ pts, int N, int* mm /* zmin zmax ymin ymax xmin xmax */) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  volatile int* m = mm;
+  for (int d = 0; d < 3; ++d) {
+    const int v = (int)floorf(pts[3 * i + d]);
+    if (v < m[2 * d]) atomicMin(&mm[2 * d], v);
+    if (v > m[2 * d + 1]) atomicMax(&mm[2 * d + 1], v);
+  }
+}
+__global__ void k_cell_count3(const float* __restrict__ pts, int N, Grid3 g, int* __restrict__ cellCount, int* __restrict__ candCell) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int a, b, c;
+  const int cell = cell3(g, pts + 3 * (size_t)i, a, b, c);
+  candCell[i] = cell;
+  atomicAdd(&cellCount[cell], 1);
+}
+__global__ void k_cell_fill3(int N, const int* __restrict__ candCell, const int* __restrict__ cellStart, int* __restrict__ cellFill,
+                             int* __restrict__ cellItems) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int c = candCell[i];
+  cellItems[cellStart[c] + atomicAdd(&cellFill[c], 1)] = i;
+}
+
+struct Flags3 { int use_kdtree, use_bbox, thr_nonneg; float thr, max_dist; };
+
+__device__ __forceinline__ bool bbox_pos_overlap(const int* a, const int* b) {
+  return (min(a[1], b[1]) - max(a[0], b[0]) > 0) && (min(a[3], b[3]) - max(a[2], b[2]) > 0) && (min(a[5], b[5]) - max(a[4], b[4]) > 0);
+}
+
+// symmetric superset of the pairs that can interact
+__device__ __forceinline__ bool may_interact3(const Flags3 f, const float* pi, const float* pj, const int* bi, const int* bj) {
+  const float dz = pi[0] - pj[0], dy = pi[1] - pj[1], dx = pi[2] - pj[2];
+  const float rr = 2.f * f.max_dist + 1.f;
+  if (f.use_kdtree && !(dz * dz + dy * dy + dx * dx < rr * rr)) return false;
+  // with use_bbox and thr >= 0 a pair is dropped at stage 1 unless the boxes overlap with positive extent
+  if (f.use_bbox && f.thr_nonneg && !bbox_pos_overlap(bi, bj)) return false;
+  return true;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_neighbours3(int N, Grid3 g, Flags3 f, const float* __restrict__ pts, const int* __restrict__ bbox,
+                                                     const int* __restrict__ candCell, const int* __restrict__ cellStart,
+                                                     const int* __restrict__ cellItems, int* __restrict__ nbrCount,
+                                                     const i64* __restrict__ nbrStart, int* __restrict__ nbr, int W) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (i >= N) return;
+  const int c = candCell[i];
+  const int cz = c / (g.ny * g.nx), cy = (c / g.nx) % g.ny, cx = c % g.nx;
+  const float* pi = pts + 3 * (size_t)i;
+  const int* bi = bbox + 6 * (size_t)i;
+  int total = 0;
+  const i64 base = MODE ? nbrStart[i] : 0;
+  const int x_lo = max(cx - W, 0), x_hi = min(cx + W, g.nx - 1);
+  for (int zz = max(cz - W, 0); zz <= min(cz + W, g.nz - 1); ++zz)
+    for (int yy = max(cy - W, 0); yy <= min(cy + W, g.ny - 1); ++yy) {
+      const int row = (zz * g.ny + yy) * g.nx;
+      const int beg = cellStart[row + x_lo], end = cellStart[row + x_hi + 1];
+      for (int t = beg; t < end; t += 64) {
+        const int idx = t + lane;
+        bool hit = false;
+        int j = -1;
+        if (idx < end) {
+          j = cellItems[idx];
+          if (j != i) hit = may_interact3(f, pi, pts + 3 * (size_t)j, bi, bbox + 6 * (size_t)j);
+        }
+        const unsigned long long m = __ballot(hit);
+        if (MODE && hit) nbr[base + total + __popcll(m & ((1ull << lane) - 1))] = j;
+        total += __popcll(m);
+      }
+    }
+  if (!MODE && lane == 0) nbrCount[i] = total;
+}
+
+__global__ void __launch_bounds__(256) k_round_decide3(const int* __restrict__ U, int nU, const unsigned char* __restrict__ state,
+                                                       const i64* __restrict__ nbrStart, const int* __restrict__ nbr,
+                                                       int* __restrict__ waitOn, int* __restrict__ Unext, int* __restrict__ K, int* counters) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (w >= nU) return;
+  const int i = U[w];
+  if (state[i] == ST_SUPPRESSED) return;
+  const int wo = waitOn[i];
+  bool pending = (wo >= 0) && (state[wo] == ST_UNDECIDED);
+  if (!pending) {
+    const i64 beg = nbrStart[i], end = nbrStart[i + 1];
+    int found = -1;
+    for (i64 t = beg; t < end && found < 0; t += 64) {
+      const i64 idx = t + lane;
+      int j = -1;
+      if (idx < end) { j = nbr[idx]; if (!(j < i && state[j] == ST_UNDECIDED)) j = -1; }
+      const unsigned long long m = __ballot(j >= 0);
+      if (m) found = __shfl(j, __ffsll((long long)m) - 1);
+    }
+    pending = found >= 0;
+    if (lane == 0 && pending) waitOn[i] = found;
+  }
+  if (lane == 0) {
+    if (pending) Unext[atomicAdd(&counters[0], 1)] = i;
+    else K[atomicAdd(&counters[1], 1)] = i;
+  }
+}
+
+struct Stats { unsigned long long upper, lower, kernel, render, kept_pre, sup_pre, sup_kernel, sup_render, convex, kept_convex, overflow; };
+
+// emit: exact neighbour predicate + cascade stages 1 and 2 (:1199-1248)
+__global__ void __launch_bounds__(256) k_round_emit3(const int* __restrict__ K, int nK, unsigned char* __restrict__ state,
+                                                     const i64* __restrict__ nbrStart, const int* __restrict__ nbr, Flags3 f, Aniso an,
+                                                     const float* __restrict__ pts, const int* __restrict__ bbox,
+                                                     const float* __restrict__ volume, const float* __restrict__ r_outer,
+                                                     const float* __restrict__ r_outer_iso, const float* __restrict__ r_inner_iso,
+                                                     int2* __restrict__ pairs, unsigned int* pairCount, unsigned int pairCap, Stats* st) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (w >= nK) return;
+  const int i = K[w];
+  if (lane == 0) state[i] = ST_KEPT;
+  const i64 beg = nbrStart[i], end = nbrStart[i + 1];
+  const float* pi = pts + 3 * (size_t)i;
+  const float rad = f.max_dist + r_outer[i];
+  const float rad2 = rad * rad;                                                // :1170
+  for (i64 t = beg; t < end; t += 64) {
+    const i64 idx = t + lane;
+    bool emit = false;
+    int j = -1;
+    int c_upper = 0, c_lower = 0, c_keep = 0, c_sup = 0;
+    if (idx < end) {
+      j = nbr[idx];
+      if (j > i && state[j] == ST_UNDECIDED) {
+        const float* pj = pts + 3 * (size_t)j;
+        bool ok = true;
+        if (f.use_kdtree) {                                                    // nanoflann L2_Simple, strict '<'
+          const float d0 = pi[0] - pj[0], d1 = pi[1] - pj[1], d2_ = pi[2] - pj[2];
+          float d2 = d0 * d0; d2 += d1 * d1; d2 += d2_ * d2_;
+          ok = d2 < rad2;
+        }
+        if (ok) {
+          const float A_min = fminf(volume[i], volume[j]);                     // :1206
+          float A_inter = fminf(sd3::intersect_sphere_isotropic(r_outer_iso[i], pi, r_outer_iso[j], pj, an.a),
+                                sd3::intersect_bbox(bbox + 6 * (size_t)i, bbox + 6 * (size_t)j));   // :1213-1219
+          c_upper = 1;
+          float iou = (float)fmin(1.0, (double)A_inter / ((double)A_min + 1e-10));                // :1223
+          if (f.use_bbox && (((double)A_inter < 1.e-10) || (iou <= f.thr))) { c_keep = 1; }
+          else {
+            A_inter = sd3::intersect_sphere_isotropic(r_inner_iso[i], pi, r_inner_iso[j], pj, an.a);   // :1232-1237
+            c_lower = 1;
+            iou = (float)fmax(0.0, (double)A_inter / ((double)A_min + 1e-10));                    // :1241
+            if (iou > f.thr) { c_sup = 1; state[j] = ST_SUPPRESSED; }
+            else emit = true;
+          }
+        }
+      }
+    }
+    const unsigned long long m = __ballot(emit);
+    if (m) {
+      unsigned int base = 0;
+      if (lane == 0) base = atomicAdd(pairCount, (unsigned int)__popcll(m));
+      base = __shfl(base, 0);
+      if (emit) {
+        const unsigned int pos = base + __popcll(m & ((1ull << lane) - 1));
+        if (pos < pairCap) pairs[pos] = make_int2(i, j);
+      }
+    }
+    const int u = __popcll(__ballot(c_upper)), l = __popcll(__ballot(c_lower)), kp = __popcll(__ballot(c_keep)), sp = __popcll(__ballot(c_sup));
+    if (lane == 0 && (u | l | kp | sp)) {
+      if (u) atomicAdd(&st->upper, (unsigned long long)u);
+      if (l) atomicAdd(&st->lower, (unsigned long long)l);
+      if (kp) atomicAdd(&st->kept_pre, (unsigned long long)kp);
+      if (sp) atomicAdd(&st->sup_pre, (unsigned long long)sp);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ stage 3: kernel ∩ kernel volume
+// One wave per pair.  Half-spaces h = (n, d): inside <=> n.p + d <= 0 (build_halfspace :744-764,
+// interleaved poly1/poly2 per face as qhull_overlap_kernel :840-853 does).
+// Qhull's feasibility rule (qh_sethalfspace): the interior point must satisfy offset + n.c <= 0 for
+// every half-space (evaluated in that order in fp64), otherwise the reference gets a QhullError and
+// uses err_value (0).
+#define HIV_MAXP 40
+__device__ double hiv_face_term(const double* __restrict__ hs, int M, int k, const double c[3], double L) {
+  // polygon of plane k clipped by all other half-spaces; returns area * height (height from c)
+  const double nz = hs[4 * k], ny = hs[4 * k + 1], nx = hs[4 * k + 2], d = hs[4 * k + 3];
+  const double nn = sqrt(nz * nz + ny * ny + nx * nx);
+  if (!(nn > 0)) return 0;
+  const double h = -(nz * c[0] + ny * c[1] + nx * c[2] + d) / nn;            // distance from c to the plane (>= 0)
+  // origin on the plane: foot point of c; orthonormal basis (u, v)
+  const double uz0 = nz / nn, uy0 = ny / nn, ux0 = nx / nn;                    // unit normal
+  const double oz = c[0] + h * uz0, oy = c[1] + h * uy0, ox = c[2] + h * ux0;
+  double az = 0, ay = 0, ax = 0;
+  const double fz = fabs(uz0), fy = fabs(uy0), fx = fabs(ux0);
+  if (fz <= fy && fz <= fx) az = 1; else if (fy <= fx) ay = 1; else ax = 1;
+  // u = normalize(a x n), v = n x u
+  double uz = ay * ux0 - ax * uy0, uy = ax * uz0 - az * ux0, ux = az * uy0 - ay * uz0;
+  const double un = sqrt(uz * uz + uy * uy + ux * ux);
+  uz /= un; uy /= un; ux /= un;
+  const double vz = uy0 * ux - ux0 * uy, vy = ux0 * uz - uz0 * ux, vx = uz0 * uy - uy0 * uz;
+  double ps[HIV_MAXP], pt[HIV_MAXP], qs[HIV_MAXP], qt[HIV_MAXP];
+  int n = 4;
+  ps[0] = -L; pt[0] = -L; ps[1] = L; pt[1] = -L; ps[2] = L; pt[2] = L; ps[3] = -L; pt[3] = L;
+  for (int m = 0; m < M && n > 0; ++m) {
+    if (m == k) continue;
+    const double mz = hs[4 * m], my = hs[4 * m + 1], mx = hs[4 * m + 2], md = hs[4 * m + 3];
+    // restriction to the plane: a*s + b*t + e <= 0
+    const double a = mz * uz + my * uy + mx * ux;
+    const double b = mz * vz + my * vy + mx * vx;
+    const double e = mz * oz + my * oy + mx * ox + md;
+    // Sutherland-Hodgman against one half-plane
+    int nq = 0;
+    double s_prev = ps[n - 1], t_prev = pt[n - 1];
+    double f_prev = a * s_prev + b * t_prev + e;
+    for (int v = 0; v < n; ++v) {
+      const double s_cur = ps[v], t_cur = pt[v];
+      const double f_cur = a * s_cur + b * t_cur + e;
+      if ((f_prev <= 0) != (f_cur <= 0)) {
+        const double w = f_prev / (f_prev - f_cur);
+        if (nq < HIV_MAXP) { qs[nq] = s_prev + w * (s_cur - s_prev); qt[nq] = t_prev + w * (t_cur - t_prev); ++nq; } else return NAN;
+      }
+      if (f_cur <= 0) { if (nq < HIV_MAXP) { qs[nq] = s_cur; qt[nq] = t_cur; ++nq; } else return NAN; }
+      s_prev = s_cur; t_prev = t_cur; f_prev = f_cur;
+    }
+    n = nq;
+    for (int v = 0; v < n; ++v) { ps[v] = qs[v]; pt[v] = qt[v]; }
+  }
+  if (n < 3) return 0;
+  double area2 = 0;
+  for (int v = 0; v < n; ++v) { const int w = (v + 1 == n) ? 0 : v + 1; area2 += ps[v] * pt[w] - ps[w] * pt[v]; }
+  return 0.5 * fabs(area2) * h;
+}
+
+__global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, unsigned int nPairs, const float* __restrict__ dist,
+                                               const float* __restrict__ pts, const float* __restrict__ verts,
+                                               const int* __restrict__ faces, int R, int F, const float* __restrict__ volume, float thr,
+                                               unsigned char* __restrict__ state, int2* __restrict__ pairs5, unsigned int* pair5Count,
+                                               Stats* st) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* hs = (double*)smem;                 // 2F * 4
+  float* pv1 = (float*)(hs + 8 * F);          // 3R
+  float* pv2 = pv1 + 3 * R;                   // 3R
+  const int lane = threadIdx.x;
+  for (unsigned int p = blockIdx.x; p < nPairs; p += gridDim.x) {
+    const int2 ij = pairs[p];
+    __syncthreads();
+    const float* c1 = pts + 3 * (size_t)ij.x;
+    const float* c2 = pts + 3 * (size_t)ij.y;
+    for (int k = lane; k < R; k += 64) {
+      const float d1 = dist[(size_t)ij.x * R + k], d2 = dist[(size_t)ij.y * R + k];
+      pv1[3 * k] = c1[0] + d1 * verts[3 * k]; pv1[3 * k + 1] = c1[1] + d1 * verts[3 * k + 1]; pv1[3 * k + 2] = c1[2] + d1 * verts[3 * k + 2];
+      pv2[3 * k] = c2[0] + d2 * verts[3 * k]; pv2[3 * k + 1] = c2[1] + d2 * verts[3 * k + 1]; pv2[3 * k + 2] = c2[2] + d2 * verts[3 * k + 2];
+    }
+    __syncthreads();
+    for (int f = lane; f < F; f += 64) {
+      const int iA = faces[3 * f], iB = faces[3 * f + 1], iC = faces[3 * f + 2];
+      sd3::build_halfspace(&pv1[3 * iA], &pv1[3 * iB], &pv1[3 * iC], &hs[4 * (2 * f)]);
+      sd3::build_halfspace(&pv2[3 * iA], &pv2[3 * iB], &pv2[3 * iC], &hs[4 * (2 * f + 1)]);
+    }
+    __syncthreads();
+    const int M = 2 * F;
+    double c[3];
+    c[0] = .5 * (c1[0] + c2[0]); c[1] = .5 * (c1[1] + c2[1]); c[2] = .5 * (c1[2] + c2[2]);   // :857-859 (float add, then *.5 in double)
+    bool infeasible = false;
+    for (int k = lane; k < M; k += 64) {
+      double dd = hs[4 * k + 3];
+      dd += hs[4 * k] * c[0]; dd += hs[4 * k + 1] * c[1]; dd += hs[4 * k + 2] * c[2];
+      if (dd > 0 || !(dd < 0)) infeasible = true;     // dist > 0 -> error; dist == 0 -> division by zero -> error
+    }
+    infeasible = __any(infeasible);
+    double vol = 0;
+    if (!infeasible) {
+      double ext = 0;
+      for (int k = lane; k < R; k += 64) {
+        const float e1 = dist[(size_t)ij.x * R + k], e2 = dist[(size_t)ij.y * R + k];
+        ext = fmax(ext, (double)fmaxf(e1, e2));
+      }
+      for (int o = 32; o; o >>= 1) ext = fmax(ext, __shfl_xor(ext, o));
+      const double sep = sqrt((double)(c1[0] - c2[0]) * (c1[0] - c2[0]) + (double)(c1[1] - c2[1]) * (c1[1] - c2[1]) + (double)(c1[2] - c2[2]) * (c1[2] - c2[2]));
+      const double L = 4.0 * (2.0 * ext + sep + 1.0);
+      double acc = 0;
+      for (int k = lane; k < M; k += 64) acc += hiv_face_term(hs, M, k, c, L);
+      for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+      vol = acc / 3.0;
+    }
+    if (lane == 0) {
+      atomicAdd(&st->kernel, 1ull);
+      if (vol != vol) atomicAdd(&st->overflow, 1ull);   // polygon capacity overflow (reported as an error by the host)
+      const float A_inter_kernel = (float)vol;                                  // function returns float :679
+      const float A_min = fminf(volume[ij.x], volume[ij.y]);
+      const float iou = (float)((double)A_inter_kernel / ((double)A_min + 1e-10));   // :1269
+      if (iou > thr) { state[ij.y] = ST_SUPPRESSED; atomicAdd(&st->sup_kernel, 1ull); }
+      else pairs5[atomicAdd(pair5Count, 1u)] = ij;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ stage 4: hull ∩ hull volume (:872-939)
+// hull facets of R points by exhaustive search: (a<b<c) is emitted iff every other point lies on one side of its
+// plane and (a,b,c) are the three lowest-indexed points on that plane (one plane per facet).
+__device__ int hull_planes(const float* __restrict__ pv, int R, double* __restrict__ out, int cap, int lane, int* s_n) {
+  if (lane == 0) *s_n = 0;
+  __builtin_amdgcn_wave_barrier();
+  double ext = 0;
+  for (int k = lane; k < R; k += 64) ext = fmax(ext, fmax(fabs((double)pv[3 * k] - pv[0]), fmax(fabs((double)pv[3 * k + 1] - pv[1]), fabs((double)pv[3 * k + 2] - pv[2]))));
+  for (int o = 32; o; o >>= 1) ext = fmax(ext, __shfl_xor(ext, o));
+  for (int a = 0; a < R - 2; ++a) {
+    const double az = pv[3 * a], ay = pv[3 * a + 1], ax = pv[3 * a + 2];
+    for (int b = a + 1; b < R - 1; ++b) {
+      const double ez = pv[3 * b] - az, ey = pv[3 * b + 1] - ay, ex = pv[3 * b + 2] - ax;
+      for (int c0 = b + 1; c0 < R; c0 += 64) {
+        const int c = c0 + lane;
+        bool ok = c < R;
+        double nz = 0, ny = 0, nx = 0;
+        int sign = 0;
+        if (ok) {
+          const double fz = pv[3 * c] - az, fy = pv[3 * c + 1] - ay, fx = pv[3 * c + 2] - ax;
+          nz = ey * fx - ex * fy; ny = ex * fz - ez * fx; nx = ez * fy - ey * fz;
+          const double nn = sqrt(nz * nz + ny * ny + nx * nx);
+          const double eps = 1e-10 * nn * (ext + 1e-30);
+          if (!(nn > 1e-12 * ext * ext)) ok = false;
+          for (int q = 0; q < R && ok; ++q) {
+            if (q == a || q == b || q == c) continue;
+            const double sdist = nz * (pv[3 * q] - az) + ny * (pv[3 * q + 1] - ay) + nx * (pv[3 * q + 2] - ax);
+            if (sdist > eps) { if (sign < 0) ok = false; sign = 1; }
+            else if (sdist < -eps) { if (sign > 0) ok = false; sign = -1; }
+            else if (q < c) ok = false;     // coplanar point with a lower index: not the canonical triple of this facet
+          }
+        }
+        const unsigned long long m = __ballot(ok);
+        if (m) {
+          const int base = *s_n;
+          if (ok) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1));
+            if (pos < cap) {
+              const double sg = (sign > 0) ? -1.0 : 1.0;     // outward normal: all points satisfy n.(p-a) <= 0
+              out[4 * pos] = sg * nz; out[4 * pos + 1] = sg * ny; out[4 * pos + 2] = sg * nx;
+              out[4 * pos + 3] = -(sg * nz * az + sg * ny * ay + sg * nx * ax);
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) *s_n = base + __popcll(m);
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  return *s_n;
+}
+
+__global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, unsigned int nPairs, const float* __restrict__ dist,
+                                               const float* __restrict__ pts, const float* __restrict__ verts, int R,
+                                               const float* __restrict__ volume, float thr, int2* __restrict__ pairs5,
+                                               unsigned int* pair5Count, Stats* st) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int cap = 2 * R;                        // a hull of R points has at most 2R-4 facets
+  double* hs = (double*)smem;                   // 2*cap*4
+  float* pv1 = (float*)(hs + 8 * cap);          // 3R
+  float* pv2 = pv1 + 3 * R;                     // 3R
+  __shared__ int s_n;
+  const int lane = threadIdx.x;
+  for (unsigned int p = blockIdx.x; p < nPairs; p += gridDim.x) {
+    const int2 ij = pairs[p];
+    __syncthreads();
+    const float* c1 = pts + 3 * (size_t)ij.x;
+    const float* c2 = pts + 3 * (size_t)ij.y;
+    for (int k = lane; k < R; k += 64) {
+      const float d1 = dist[(size_t)ij.x * R + k], d2 = dist[(size_t)ij.y * R + k];
+      pv1[3 * k] = c1[0] + d1 * verts[3 * k]; pv1[3 * k + 1] = c1[1] + d1 * verts[3 * k + 1]; pv1[3 * k + 2] = c1[2] + d1 * verts[3 * k + 2];
+      pv2[3 * k] = c2[0] + d2 * verts[3 * k]; pv2[3 * k + 1] = c2[1] + d2 * verts[3 * k + 1]; pv2[3 * k + 2] = c2[2] + d2 * verts[3 * k + 2];
+    }
+    __syncthreads();
+    const int n1 = hull_planes(pv1, R, hs, cap, lane, &s_n);
+    __syncthreads();
+    const int n2 = hull_planes(pv2, R, hs + 4 * (n1 < cap ? n1 : cap), cap, lane, &s_n);
+    __syncthreads();
+    bool failed = (n1 < 4 || n2 < 4 || n1 > cap || n2 > cap);     // Qhull error -> 1e10 (:933-936)
+    const int M = failed ? 0 : n1 + n2;
+    double c[3];
+    c[0] = .5 * ((double)c1[0] + (double)c2[0]); c[1] = .5 * ((double)c1[1] + (double)c2[1]); c[2] = .5 * ((double)c1[2] + (double)c2[2]);   // :890-921 (double)
+    bool infeasible = false;
+    for (int k = lane; k < M; k += 64) {
+      double dd = hs[4 * k + 3];
+      dd += hs[4 * k] * c[0]; dd += hs[4 * k + 1] * c[1]; dd += hs[4 * k + 2] * c[2];
+      if (dd > 0 || !(dd < 0)) infeasible = true;
+    }
+    infeasible = __any(infeasible) || failed;
+    double vol = 1.e10;                                             // err_value :927
+    if (!infeasible) {
+      double ext = 0;
+      for (int k = lane; k < R; k += 64) ext = fmax(ext, (double)fmaxf(dist[(size_t)ij.x * R + k], dist[(size_t)ij.y * R + k]));
+      for (int o = 32; o; o >>= 1) ext = fmax(ext, __shfl_xor(ext, o));
+      const double sep = sqrt((double)(c1[0] - c2[0]) * (c1[0] - c2[0]) + (double)(c1[1] - c2[1]) * (c1[1] - c2[1]) + (double)(c1[2] - c2[2]) * (c1[2] - c2[2]));
+      const double L = 4.0 * (2.0 * ext + sep + 1.0);
+      double acc = 0;
+      for (int k = lane; k < M; k += 64) acc += hiv_face_term(hs, M, k, c, L);
+      for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+      vol = acc / 3.0;
+    }
+    if (lane == 0) {
+      atomicAdd(&st->convex, 1ull);
+      if (vol != vol) atomicAdd(&st->overflow, 1ull);
+      const float A_inter_convex = (float)vol;
+      const float A_min = fminf(volume[ij.x], volume[ij.y]);
+      const float iou = (float)((double)A_inter_convex / ((double)A_min + 1e-10));     // :1289
+      if (iou <= thr) atomicAdd(&st->kept_convex, 1ull);                                // :1291-1295
+      else pairs5[atomicAdd(pair5Count, 1u)] = ij;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ stage 5: voxel rendering (:587-636, 1305-1330)
+__global__ void __launch_bounds__(256) k_stage5(const int2* __restrict__ pairs, unsigned int nPairs, const float* __restrict__ dist,
+                                                const float* __restrict__ pts, const float* __restrict__ verts,
+                                                const int* __restrict__ faces, int R, int F, const int* __restrict__ bbox,
+                                                const float* __restrict__ volume, float thr, unsigned char* __restrict__ state, Stats* st) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* pv1 = (float*)smem;       // 3R
+  float* pv2 = pv1 + 3 * R;        // 3R
+  int* fc = (int*)(pv2 + 3 * R);   // 3F
+  __shared__ unsigned int s_count;
+  for (int k = threadIdx.x; k < 3 * F; k += blockDim.x) fc[k] = faces[k];
+  for (unsigned int p = blockIdx.x; p < nPairs; p += gridDim.x) {
+    const int2 ij = pairs[p];
+    __syncthreads();
+    const float* c1 = pts + 3 * (size_t)ij.x;
+    const float* c2 = pts + 3 * (size_t)ij.y;
+    for (int k = threadIdx.x; k < R; k += blockDim.x) {
+      const float d1 = dist[(size_t)ij.x * R + k], d2 = dist[(size_t)ij.y * R + k];
+      pv1[3 * k] = c1[0] + d1 * verts[3 * k]; pv1[3 * k + 1] = c1[1] + d1 * verts[3 * k + 1]; pv1[3 * k + 2] = c1[2] + d1 * verts[3 * k + 2];
+      pv2[3 * k] = c2[0] + d2 * verts[3 * k]; pv2[3 * k + 1] = c2[1] + d2 * verts[3 * k + 1]; pv2[3 * k + 2] = c2[2] + d2 * verts[3 * k + 2];
+    }
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    // the reference sweeps the whole bbox of i; lattice points outside j's (rounded) bbox cannot be inside j
+    const int* b1 = bbox + 6 * (size_t)ij.x;
+    const int* b2 = bbox + 6 * (size_t)ij.y;
+    const int zlo = max(b1[0], b2[0] - 1), zhi = min(b1[1], b2[1] + 1);
+    const int ylo = max(b1[2], b2[2] - 1), yhi = min(b1[3], b2[3] + 1);
+    const int xlo = max(b1[4], b2[4] - 1), xhi = min(b1[5], b2[5] + 1);
+    unsigned int local = 0;
+    if (zhi >= zlo && yhi >= ylo && xhi >= xlo) {
+      const i64 bz = zhi - zlo + 1, by = yhi - ylo + 1, bx = xhi - xlo + 1;
+      const i64 nvox = bz * by * bx;
+      for (i64 t = threadIdx.x; t < nvox; t += blockDim.x) {
+        const float x = (float)(xlo + (int)(t % bx));
+        const i64 r = t / bx;
+        const float y = (float)(ylo + (int)(r % by)), z = (float)(zlo + (int)(r / by));
+        if (sd3::inside_polyhedron(z, y, x, c1[0], c1[1], c1[2], pv1, fc, F) &&
+            sd3::inside_polyhedron(z, y, x, c2[0], c2[1], c2[2], pv2, fc, F)) ++local;
+      }
+    }
+    for (int o = 32; o; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&s_count, local);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned int C = s_count;
+      const float A_min = fminf(volume[ij.x], volume[ij.y]);
+      const float overlap_maximal = (float)(((double)A_min + 1e-10) * (double)thr);      // :1321
+      // overlap_render_polyhedron returns as soon as res > overlap_maximal (:629-631): the returned value is
+      // the first integer exceeding it, or the full count if that is never reached.
+      unsigned int res = C;
+      if ((float)C > overlap_maximal) {
+        // smallest n in [1, C] with (float)n > overlap_maximal
+        unsigned int lo = 1, hi = C;
+        while (lo < hi) { const unsigned int mid = lo + (hi - lo) / 2; if ((float)mid > overlap_maximal) hi = mid; else lo = mid + 1; }
+        res = lo;
+      }
+      const float A_inter_render = (float)(int)res;
+      const float iou = (float)((double)A_inter_render / ((double)A_min + 1e-10));       // :1325
+      atomicAdd(&st->render, 1ull);
+      if (iou > thr) { state[ij.y] = ST_SUPPRESSED; atomicAdd(&st->sup_render, 1ull); }
+    }
+  }
+}
+
+__global__ void k_iota3(int* a, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = i; }
+__global__ void k_keep3(const unsigned char* __restrict__ state, unsigned char* __restrict__ keep, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keep[i] = (state[i] != ST_SUPPRESSED);
+}
+
+}  // namespace
+
+extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const float* d_points, int n_polys, int n_rays, int n_faces,
+                               const float* d_verts, const int* d_faces, float threshold, int use_bbox, int use_kdtree, int verbose,
+                               uint8_t* d_keep, int64_t* stats, void* stream_) {
+  (void)d_scores;   // unused by the reference's arithmetic as well
+  hipStream_t s = (hipStream_t)stream_;
+  const int N = n_polys, R = n_rays, F = n_faces;
+  if (stats) memset(stats, 0, 8 * sizeof(int64_t));
+  if (verbose) {
+    printf("Non Maximum Suppression (3D) ++++ \n");
+    printf("NMS: n_polys  = %d \nNMS: n_rays   = %d  \nNMS: n_faces  = %d \nNMS: thresh   = %.3f \nNMS: use_bbox = %d \nNMS: use_kdtree = %d \n",
+           N, R, F, threshold, use_bbox, use_kdtree);
+    printf("NMS: using HIP (gfx950)\n");
+    fflush(stdout);
+  }
+  if (N <= 0) return 0;
+  if (R < 4 || F < 4) { sd::set_error("sd_nms3d: need n_rays >= 4 and n_faces >= 4"); return -1; }
+  const size_t lds3 = (size_t)8 * F * sizeof(double) + (size_t)6 * R * sizeof(float);
+  const size_t lds5 = (size_t)6 * R * sizeof(float) + (size_t)3 * F * sizeof(int);
+  const size_t lds4 = (size_t)16 * R * sizeof(double) + (size_t)6 * R * sizeof(float);
+  if (lds3 > 150 * 1024 || lds5 > 150 * 1024 || lds4 > 150 * 1024) { sd::set_error("sd_nms3d: n_rays/n_faces too large for LDS staging"); return -1; }
+  sd::Arena& A = sd::arena();
+  if (A.begin(s)) return -1;
+  if (!use_kdtree && !use_bbox && threshold < 0) {   // every (0, j) passes and iou >= 0 > thr at stage 2
+    SD_CHECK(hipMemsetAsync(d_keep, 0, N, s));
+    SD_CHECK(hipMemsetAsync(d_keep, 1, 1, s));
+    SD_CHECK(hipStreamSynchronize(s));
+    return 0;
+  }
+  float* volume = A.take_n<float>(N);
+  int* bbox = A.take_n<int>((size_t)6 * N);
+  float* r_outer = A.take_n<float>(N);
+  float* r_outer_iso = A.take_n<float>(N);
+  float* r_inner_iso = A.take_n<float>(N);
+  int* gi = A.take_n<int>(8);
+  unsigned char* state = A.take_n<unsigned char>(N);
+  int* candCell = A.take_n<int>(N);
+  if (!volume || !bbox || !r_outer || !r_outer_iso || !r_inner_iso || !gi || !state || !candCell) return -1;
+  const int gi_init[8] = {0, INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN, 0};
+  SD_CHECK(hipMemcpyAsync(gi, gi_init, sizeof(gi_init), hipMemcpyHostToDevice, s));
+  SD_CHECK(hipMemsetAsync(state, 0, N, s));
+  hipLaunchKernelGGL(k_pre1, dim3(sd::div_up(N, 128)), dim3(128), 0, s, d_dist, d_points, d_verts, d_faces, N, R, F, volume, bbox);
+  SD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_minmax3, dim3(sd::div_up(N, 256)), dim3(256), 0, s, d_points, N, gi + 1);
+  // anisotropy: sequential fp32 accumulation over candidates (:1008-1010) on the host
+  std::vector<int> hb((size_t)6 * N);
+  SD_CHECK(hipMemcpyAsync(hb.data(), bbox, (size_t)6 * N * sizeof(int), hipMemcpyDeviceToHost, s));
+  SD_CHECK(hipStreamSynchronize(s));
+  Aniso an;
+  {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = 0; i < N; ++i) {
+      a0 += (float)(hb[6 * (size_t)i + 1] - hb[6 * (size_t)i]) / N;
+      a1 += (float)(hb[6 * (size_t)i + 3] - hb[6 * (size_t)i + 2]) / N;
+      a2 += (float)(hb[6 * (size_t)i + 5] - hb[6 * (size_t)i + 4]) / N;
+    }
+    const float tmp = fmaxf(fmaxf(a0, a1), a2);
+    an.a[0] = tmp / a0; an.a[1] = tmp / a1; an.a[2] = tmp / a2;
+  }
+  if (verbose) { printf("NMS: calculated anisotropy: %.2f \t %.2f \t %.2f \n", an.a[0], an.a[1], an.a[2]); fflush(stdout); }
+  hipLaunchKernelGGL(k_pre2, dim3(sd::div_up(N, 128)), dim3(128), 0, s, d_dist, d_verts, d_faces, N, R, F, an, r_outer, r_outer_iso, r_inner_iso, gi);
+  SD_LAUNCH_CHECK();
+  int g[8];
+  SD_CHECK(hipMemcpyAsync(g, gi, sizeof(g), hipMemcpyDeviceToHost, s));
+  SD_CHECK(hipStreamSynchronize(s));
+  float max_dist;
+  memcpy(&max_dist, &g[0], 4);
+
+  Grid3 gr;
+  float cs = (2.f * max_dist + 1.f) * 0.5f * 1.0001f + 1e-3f;
+  if (!(cs >= 1.f)) cs = 1.f;
+  const int W = 2;
+  if (!use_kdtree) {
+    // the reference then tests every j > i (:1172-1176): one grid cell = all pairs
+    if (N > 16384) { sd::set_error("sd_nms3d: use_kdtree=0 is only supported up to 16384 candidates (all-pairs)"); return -1; }
+    cs = 4.f * (fmaxf(fmaxf((float)g[2] - g[1], (float)g[4] - g[3]), (float)g[6] - g[5]) + 2.f);
+  }
+  for (;;) {
+    gr.nz = (int)(((double)g[2] - g[1]) / cs) + 1;
+    gr.ny = (int)(((double)g[4] - g[3]) / cs) + 1;
+    gr.nx = (int)(((double)g[6] - g[5]) / cs) + 1;
+    if ((i64)gr.nz * gr.ny * gr.nx <= (1ll << 26)) break;
+    cs *= 2.f;
+  }
+  gr.z0 = (float)g[1]; gr.y0 = (float)g[3]; gr.x0 = (float)g[5]; gr.inv_cs = 1.f / cs;
+  const int nCells = gr.nz * gr.ny * gr.nx;
+  int* cellCount = A.take_n<int>(nCells + 1);
+  int* cellStart = A.take_n<int>(nCells + 1);
+  int* cellFill = A.take_n<int>(nCells + 1);
+  int* cellItems = A.take_n<int>(N);
+  int* nbrCount = A.take_n<int>(N + 1);
+  i64* nbrStart = A.take_n<i64>(N + 1);
+  if (!cellCount || !cellStart || !cellFill || !cellItems || !nbrCount || !nbrStart) return -1;
+  SD_CHECK(hipMemsetAsync(cellCount, 0, (nCells + 1) * sizeof(int), s));
+  SD_CHECK(hipMemsetAsync(cellFill, 0, (nCells + 1) * sizeof(int), s));
+  hipLaunchKernelGGL(k_cell_count3, dim3(sd::div_up(N, 256)), dim3(256), 0, s, d_points, N, gr, cellCount, candCell);
+  size_t tb1 = 0, tb2 = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, cellCount, cellStart, nCells + 1, s);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, nbrCount, nbrStart, N + 1, s);
+  if (tb2 > tb1) tb1 = tb2;
+  void* scanTmp = A.take(tb1 + 256);
+  if (!scanTmp) return -1;
+  SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tb1, cellCount, cellStart, nCells + 1, s));
+  hipLaunchKernelGGL(k_cell_fill3, dim3(sd::div_up(N, 256)), dim3(256), 0, s, N, candCell, cellStart, cellFill, cellItems);
+  SD_LAUNCH_CHECK();
+  Flags3 f;
+  f.use_kdtree = use_kdtree; f.use_bbox = use_bbox; f.thr_nonneg = (threshold >= 0.f); f.thr = threshold; f.max_dist = max_dist;
+  Flags3 fs = f;
+  SD_CHECK(hipMemsetAsync(nbrCount, 0, (N + 1) * sizeof(int), s));
+  hipLaunchKernelGGL((k_neighbours3<0>), dim3(sd::div_up(N, 4)), dim3(256), 0, s, N, gr, fs, d_points, bbox, candCell, cellStart, cellItems,
+                     nbrCount, (const i64*)nullptr, (int*)nullptr, W);
+  SD_LAUNCH_CHECK();
+  SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tb1, nbrCount, nbrStart, N + 1, s));
+  i64 totalNbr = 0;
+  SD_CHECK(hipMemcpyAsync(&totalNbr, nbrStart + N, sizeof(i64), hipMemcpyDeviceToHost, s));
+  SD_CHECK(hipStreamSynchronize(s));
+  int* nbr = A.take_n<int>((size_t)totalNbr);
+  if (!nbr) return -1;
+  hipLaunchKernelGGL((k_neighbours3<1>), dim3(sd::div_up(N, 4)), dim3(256), 0, s, N, gr, fs, d_points, bbox, candCell, cellStart, cellItems,
+                     nbrCount, (const i64*)nbrStart, nbr, W);
+  SD_LAUNCH_CHECK();
+
+  const unsigned int pairCap = (unsigned int)((totalNbr / 2 + 64) < (1ll << 31) ? (totalNbr / 2 + 64) : ((1ll << 31) - 1));
+  int* U0 = A.take_n<int>(N);
+  int* U1 = A.take_n<int>(N);
+  int* Kl = A.take_n<int>(N);
+  int* waitOn = A.take_n<int>(N);
+  int2* pairs3 = A.take_n<int2>(pairCap);
+  int2* pairs4 = A.take_n<int2>(pairCap);
+  int2* pairs5 = A.take_n<int2>(pairCap);
+  struct Counters { int nU, nK; unsigned int nP3, nP4, nP5; };
+  Counters* d_cnt = (Counters*)A.take(sizeof(Counters));
+  Stats* d_st = (Stats*)A.take(sizeof(Stats));
+  if (!U0 || !U1 || !Kl || !waitOn || !pairs3 || !pairs4 || !pairs5 || !d_cnt || !d_st) return -1;
+  SD_CHECK(hipMemsetAsync(waitOn, 0xFF, (size_t)N * sizeof(int), s));
+  SD_CHECK(hipMemsetAsync(d_st, 0, sizeof(Stats), s));
+  hipLaunchKernelGGL(k_iota3, dim3(sd::div_up(N, 256)), dim3(256), 0, s, U0, N);
+  int nU = N, rounds = 0;
+  int* Ucur = U0; int* Unext = U1;
+  Counters h;
+  while (nU > 0) {
+    ++rounds;
+    SD_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), s));
+    hipLaunchKernelGGL(k_round_decide3, dim3(sd::div_up(nU, 4)), dim3(256), 0, s, Ucur, nU, state, nbrStart, nbr, waitOn, Unext, Kl, (int*)d_cnt);
+    SD_LAUNCH_CHECK();
+    SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    SD_CHECK(hipStreamSynchronize(s));
+    if (h.nK == 0 && h.nU > 0) { sd::set_error("sd_nms3d: greedy scan made no progress (internal error)"); return -1; }
+    if (h.nK > 0) {
+      hipLaunchKernelGGL(k_round_emit3, dim3(sd::div_up(h.nK, 4)), dim3(256), 0, s, Kl, h.nK, state, nbrStart, nbr, f, an, d_points, bbox, volume,
+                         r_outer, r_outer_iso, r_inner_iso, pairs3, &d_cnt->nP3, pairCap, d_st);
+      SD_LAUNCH_CHECK();
+      SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+      SD_CHECK(hipStreamSynchronize(s));
+      if (h.nP3 > pairCap) { sd::set_error("sd_nms3d: pair queue overflow (internal error)"); return -1; }
+      if (h.nP3 > 0) {
+        const unsigned int b3 = h.nP3 < 16384u ? h.nP3 : 16384u;
+        hipLaunchKernelGGL(k_stage3, dim3(b3), dim3(64), lds3, s, pairs3, h.nP3, d_dist, d_points, d_verts, d_faces, R, F, volume, threshold,
+                           state, pairs4, &d_cnt->nP4, d_st);
+        SD_LAUNCH_CHECK();
+        SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+        SD_CHECK(hipStreamSynchronize(s));
+        if (h.nP4 > 0) {
+          const unsigned int b4 = h.nP4 < 16384u ? h.nP4 : 16384u;
+          hipLaunchKernelGGL(k_stage4, dim3(b4), dim3(64), lds4, s, pairs4, h.nP4, d_dist, d_points, d_verts, R, volume, threshold, pairs5,
+                             &d_cnt->nP5, d_st);
+          SD_LAUNCH_CHECK();
+          SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+          SD_CHECK(hipStreamSynchronize(s));
+        }
+        if (h.nP4 > 0 && h.nP5 > 0) {
+          const unsigned int b5 = h.nP5 < 16384u ? h.nP5 : 16384u;
+          hipLaunchKernelGGL(k_stage5, dim3(b5), dim3(256), lds5, s, pairs5, h.nP5, d_dist, d_points, d_verts, d_faces, R, F, bbox, volume,
+                             threshold, state, d_st);
+          SD_LAUNCH_CHECK();
+        }
+      }
+    }
+    nU = h.nU;
+    int* t = Ucur; Ucur = Unext; Unext = t;
+  }
+  hipLaunchKernelGGL(k_keep3, dim3(sd::div_up(N, 256)), dim3(256), 0, s, state, d_keep, N);
+  SD_LAUNCH_CHECK();
+  Stats hs_;
+  SD_CHECK(hipMemcpyAsync(&hs_, d_st, sizeof(Stats), hipMemcpyDeviceToHost, s));
+  SD_CHECK(hipStreamSynchronize(s));
+  if (hs_.overflow) { sd::set_error("sd_nms3d: half-space intersection capacity exceeded (%llu pairs)", hs_.overflow); return -1; }
+  if (stats) {
+    stats[0] = (int64_t)hs_.upper; stats[1] = (int64_t)hs_.lower; stats[2] = (int64_t)hs_.kernel; stats[3] = (int64_t)hs_.render;
+    stats[4] = rounds; stats[5] = totalNbr; stats[6] = (int64_t)hs_.sup_kernel; stats[7] = (int64_t)hs_.sup_render;
+  }
+  if (verbose) {
+    printf("NMS: Function calls:\nNMS: ~ bbox+out: %8llu\nNMS: ~ inner:    %8llu\nNMS: ~ kernel:   %8llu\nNMS: ~ convex:   %8llu\nNMS: ~ render:   %8llu\n",
+           hs_.upper, hs_.lower, hs_.kernel, hs_.convex, hs_.render);
+    printf("NMS: Excluded intersection:\nNMS: + pretest:  %8llu\nNMS: + convex:   %8llu\n", hs_.kept_pre, hs_.kept_convex);
+    printf("NMS: Suppressed polyhedra:\nNMS: # inner:    %8llu / %d\nNMS: # kernel:   %8llu / %d\nNMS: # render:   %8llu / %d\n", hs_.sup_pre, N,
+           hs_.sup_kernel, N, hs_.sup_render, N);
+    printf("NMS: greedy rounds: %d, neighbour entries: %lld\n", rounds, (long long)totalNbr);
+    fflush(stdout);
+  }
+  return 0;
+}
+
+extern "C" void _LIB_non_maximum_suppression_sparse(const float* scores, const float* dist, const float* points, const int n_polys,
+                                                    const int n_rays, const int n_faces, const float* verts, const int* faces,
+                                                    const float threshold, const int use_bbox, const int use_kdtree, const int verbose,
+                                                    bool* result) {
+  if (n_polys <= 0) return;
+  float *d_dist = nullptr, *d_pts = nullptr, *d_verts = nullptr, *d_scores = nullptr;
+  int* d_faces = nullptr;
+  uint8_t* d_keep = nullptr;
+  bool ok = hipMalloc(&d_dist, (size_t)n_polys * n_rays * 4) == hipSuccess && hipMalloc(&d_pts, (size_t)n_polys * 12) == hipSuccess &&
+            hipMalloc(&d_verts, (size_t)n_rays * 12) == hipSuccess && hipMalloc(&d_faces, (size_t)n_faces * 12) == hipSuccess &&
+            hipMalloc(&d_scores, (size_t)n_polys * 4) == hipSuccess && hipMalloc(&d_keep, n_polys) == hipSuccess;
+  if (ok) {
+    ok = hipMemcpy(d_dist, dist, (size_t)n_polys * n_rays * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(d_pts, points, (size_t)n_polys * 12, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(d_verts, verts, (size_t)n_rays * 12, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(d_faces, faces, (size_t)n_faces * 12, hipMemcpyHostToDevice) == hipSuccess &&
+         (scores == nullptr || hipMemcpy(d_scores, scores, (size_t)n_polys * 4, hipMemcpyHostToDevice) == hipSuccess);
+    if (!ok) sd::set_error("_LIB_non_maximum_suppression_sparse: H2D failed");
+  } else sd::set_error("_LIB_non_maximum_suppression_sparse: hipMalloc failed");
+  std::vector<uint8_t> keep(n_polys);
+  if (ok) ok = sd_nms3d_device(d_scores, d_dist, d_pts, n_polys, n_rays, n_faces, d_verts, d_faces, threshold, use_bbox, use_kdtree, verbose,
+                               d_keep, nullptr, nullptr) == 0;
+  if (ok) ok = hipMemcpy(keep.data(), d_keep, n_polys, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(d_dist); (void)hipFree(d_pts); (void)hipFree(d_verts); (void)hipFree(d_faces); (void)hipFree(d_scores); (void)hipFree(d_keep);
+  if (!ok) {   // the reference ABI has no return code: fail loudly
+    fprintf(stderr, "_LIB_non_maximum_suppression_sparse failed: %s\n", sd::err_buf());
+    abort();
+  }
+  for (int i = 0; i < n_polys; ++i) result[i] = keep[i] != 0;
 }

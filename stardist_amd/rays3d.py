@@ -1,0 +1,195 @@
+"""Ray sets for 3D star-convex polyhedra: unit vectors (z, y, x) + outward-oriented triangles.
+
+Mirror of the reference's stardist/rays3d.py API (Rays_Base :20-152, Rays_Explicit/Cartesian/
+SubDivide/Tetra/Octo :163-327, reorder_faces :330-334, Rays_GoldenSpiral :337-373,
+rays_from_json :156).  The vertex/face arrays feed every 3D kernel, and the FACE ORDER matters
+(sequential fp32 sums over faces), so constructions follow the reference step by step; faces of
+the golden spiral come from scipy.spatial.ConvexHull exactly as there.  Pinned against the
+reference module's output in tests/golden/rays_*.npz.
+"""
+import copy as _copy
+
+import numpy as np
+
+
+class Rays_Base(object):
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+        v, f = self.setup_vertices_faces()
+        self._vertices = np.asarray(v, np.float32)
+        self._faces = np.asanyarray(np.asarray(f, int))
+
+    def setup_vertices_faces(self):
+        """returns (verts ((z,y,x), ...), faces ((i,j,k), ...))"""
+        raise NotImplementedError()
+
+    @property
+    def vertices(self):
+        return self._vertices.copy()
+
+    @property
+    def faces(self):
+        return self._faces.copy()
+
+    def __getitem__(self, i):
+        return self.vertices[i]
+
+    def __len__(self):
+        return len(self._vertices)
+
+    def __repr__(self):
+        def conv(x):
+            if isinstance(x, (tuple, list, np.ndarray)):
+                return "_".join(conv(t) for t in x)
+            if isinstance(x, float):
+                return "%.2f" % x
+            return str(x)
+        return "%s_%s" % (self.__class__.__name__, "_".join("%s_%s" % (k, conv(v)) for k, v in sorted(self.kwargs.items())))
+
+    def to_json(self):
+        return {"name": self.__class__.__name__, "kwargs": self.kwargs}
+
+    def dist_loss_weights(self, anisotropy=(1, 1, 1)):
+        anisotropy = np.array(anisotropy)
+        assert anisotropy.shape == (3,)
+        return np.linalg.norm(self.vertices * anisotropy, axis=-1)
+
+    def volume(self, dist=None):
+        """volume of the polyhedron spanned by dist (last axis = rays); dist=None -> unit distances"""
+        d = np.ones(len(self), np.float64) if dist is None else np.asarray(dist, np.float64)
+        if d.shape[-1] != len(self):
+            raise ValueError("last dimension of dist should have length len(rays.vertices)")
+        p = d[..., None] * self.vertices.astype(np.float64)          # (..., R, 3)
+        a, b, c = (p[..., self._faces[:, k], :] for k in range(3))   # (..., F, 3)
+        det = np.einsum("...i,...i->...", a, np.cross(b, c))
+        return -1. / 6 * det.sum(-1)
+
+    def copy(self, scale=(1, 1, 1)):
+        scale = np.asarray(scale)
+        assert scale.shape == (3,)
+        res = _copy.deepcopy(self)
+        res._vertices *= scale[np.newaxis]
+        return res
+
+
+def rays_from_json(d):
+    cls = {c.__name__: c for c in (Rays_Explicit, Rays_Cartesian, Rays_Tetra, Rays_Octo, Rays_GoldenSpiral)}
+    return cls[d["name"]](**d["kwargs"])
+
+
+class Rays_Explicit(Rays_Base):
+    def __init__(self, vertices0, faces0):
+        self.vertices0, self.faces0 = vertices0, faces0
+        super().__init__(vertices0=list(vertices0), faces0=list(faces0))
+
+    def setup_vertices_faces(self):
+        return self.vertices0, self.faces0
+
+
+class Rays_Cartesian(Rays_Base):
+    def __init__(self, n_rays_x=11, n_rays_z=5):
+        super().__init__(n_rays_x=n_rays_x, n_rays_z=n_rays_z)
+
+    def setup_vertices_faces(self):
+        nx, nz = self.kwargs["n_rays_x"], self.kwargs["n_rays_z"]
+        dphi = np.float32(2. * np.pi / nx)
+        dtheta = np.float32(np.pi / nz)
+        verts = []
+        for mz in range(nz):
+            for mx in range(nx):
+                phi, theta = mx * dphi, mz * dtheta
+                pole = mz in (0, nz - 1)
+                if mz == 0: theta = 1e-12
+                if mz == nz - 1: theta = np.pi - 1e-12
+                dx = np.cos(phi) * np.sin(theta)
+                dy = np.sin(phi) * np.sin(theta)
+                dz = np.cos(theta)
+                if pole:
+                    dx += 1e-12; dy += 1e-12
+                verts.append([dz, dy, dx])
+        ind = lambda mz, mx: mz * nx + mx
+        faces = []
+        for mz in range(nz - 1):
+            for mx in range(nx):
+                faces.append([ind(mz, mx), ind(mz + 1, (mx + 1) % nx), ind(mz, (mx + 1) % nx)])
+                faces.append([ind(mz, mx), ind(mz + 1, mx), ind(mz + 1, (mx + 1) % nx)])
+        return np.array(verts), np.array(faces)
+
+
+class Rays_SubDivide(Rays_Base):
+    """n_level = 1 -> base polyhedron, each further level splits every triangle in four"""
+
+    def __init__(self, n_level=4):
+        super().__init__(n_level=n_level)
+
+    def base_polyhedron(self):
+        raise NotImplementedError()
+
+    def setup_vertices_faces(self):
+        verts, faces = self.base_polyhedron()
+        for _ in range(self.kwargs["n_level"] - 1):
+            verts, faces = Rays_SubDivide.split(verts, faces)
+        return verts, faces
+
+    @classmethod
+    def split(cls, verts0, faces0):
+        mids = dict()
+        verts = list(verts0[:])
+        faces = []
+
+        def mid(a, b):
+            key = tuple(sorted((a, b)))
+            if key not in mids:
+                v = .5 * (verts[a] + verts[b])
+                v *= 1. / np.linalg.norm(v)
+                verts.append(v)
+                mids[key] = len(verts) - 1
+            return mids[key]
+        for v1, v2, v3 in faces0:
+            i1, i2, i3 = mid(v1, v2), mid(v2, v3), mid(v3, v1)
+            faces += [[v1, i1, i3], [v2, i2, i1], [v3, i3, i2], [i1, i2, i3]]
+        return verts, faces
+
+
+class Rays_Tetra(Rays_SubDivide):
+    def base_polyhedron(self):
+        verts = np.array([[np.sqrt(8. / 9), 0., -1. / 3],
+                          [-np.sqrt(2. / 9), np.sqrt(2. / 3), -1. / 3],
+                          [-np.sqrt(2. / 9), -np.sqrt(2. / 3), -1. / 3],
+                          [0., 0., 1.]])
+        return verts, [[0, 1, 2], [0, 3, 1], [0, 2, 3], [1, 3, 2]]
+
+
+class Rays_Octo(Rays_SubDivide):
+    def base_polyhedron(self):
+        verts = np.array([[0, 0, 1], [0, 1, 0], [0, 0, -1], [0, -1, 0], [1, 0, 0], [-1, 0, 0]])
+        faces = [[0, 1, 4], [0, 5, 1], [1, 2, 4], [1, 5, 2], [2, 3, 4], [2, 5, 3], [3, 0, 4], [3, 5, 0]]
+        return verts, faces
+
+
+def reorder_faces(verts, faces):
+    """flip triangles so that their orientation points outward (rays3d.py:330-334)"""
+    return tuple((f[::-1] if np.linalg.det(verts[f]) > 0 else f) for f in faces)
+
+
+class Rays_GoldenSpiral(Rays_Base):
+    def __init__(self, n=70, anisotropy=None):
+        if n < 4:
+            raise ValueError("At least 4 points have to be given!")
+        super().__init__(n=n, anisotropy=anisotropy if anisotropy is None else tuple(anisotropy))
+
+    def setup_vertices_faces(self):
+        from scipy.spatial import ConvexHull
+        n = self.kwargs["n"]
+        anisotropy = self.kwargs["anisotropy"]
+        anisotropy = np.ones(3) if anisotropy is None else np.array(anisotropy)
+        g = (3. - np.sqrt(5.)) * np.pi                 # the smaller golden angle
+        phi = g * np.arange(n)
+        z = np.linspace(-1, 1, n)
+        rho = np.sqrt(1. - z ** 2)
+        verts = np.stack([z, rho * np.sin(phi), rho * np.cos(phi)]).T
+        verts = verts / anisotropy
+        hull = ConvexHull(verts)
+        faces = reorder_faces(verts, hull.simplices)
+        verts /= np.linalg.norm(verts, axis=-1, keepdims=True)
+        return verts, faces

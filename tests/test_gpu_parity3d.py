@@ -1,0 +1,125 @@
+"""GPU parity tests (3D): HIP path through the C ABI vs the compiled reference (oracle/_ref)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rays(n=96, anisotropy=None):
+    from stardist_amd.rays3d import Rays_GoldenSpiral
+    return Rays_GoldenSpiral(n, anisotropy=anisotropy)
+
+
+def _random_candidates(shape, n_rays, noise, seed, prob_thresh=0.9, radius=10):
+    """after the reference's tests/test_nms3D.py:8-14 (create_random_data), seeded"""
+    rng = np.random.RandomState(seed)
+    dist = radius * np.ones(shape + (n_rays,))
+    dist *= (1 + np.clip(noise, 0, 1) * rng.uniform(-1, 1, dist.shape))
+    prob = rng.uniform(0, 1, shape)
+    mask = prob > prob_thresh
+    m2 = np.zeros_like(mask); m2[2:-2, 2:-2, 2:-2] = True
+    mask &= m2
+    pts = np.stack(np.where(mask), 1)
+    d = dist[mask].astype(np.float32); s = prob[mask].astype(np.float32)
+    ind = np.argsort(s)[::-1]
+    return np.ascontiguousarray(d[ind]), np.ascontiguousarray(pts[ind].astype(np.float32)), np.ascontiguousarray(s[ind])
+
+
+@pytest.mark.parametrize("n_rays,grid", [(32, (1, 1, 1)), (96, (1, 2, 2)), (17, (2, 1, 4))])
+def test_star_dist3d_bit_exact(refmods, n_rays, grid):
+    from stardist_amd.lib import stardist3d as sd3
+    rays = _rays(n_rays)
+    rng = np.random.RandomState(1)
+    lbl = np.zeros((40, 50, 46), np.uint16)
+    for k in range(12):
+        c = rng.uniform(8, 36, 3); r = rng.uniform(4, 9)
+        zz, yy, xx = np.mgrid[:40, :50, :46]
+        m = ((zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2) <= r * r
+        lbl[m & (lbl == 0)] = k + 1
+    dz, dy, dx = (np.ascontiguousarray(v, np.float32) for v in rays.vertices.T)
+    ref_d = refmods.stardist3d().c_star_dist3d(lbl, dz, dy, dx, n_rays, *grid)
+    d = sd3.c_star_dist3d(lbl, dz, dy, dx, n_rays, *grid)
+    assert d.shape == ref_d.shape
+    assert np.array_equal(d, ref_d), np.abs(d - ref_d).max()
+
+
+@pytest.mark.parametrize("mode,overlap", [(0, None), (1, None), (3, None), (0, 77), (0, -3)])
+def test_polyhedron_to_label_identical(refmods, mode, overlap):
+    from oracle import synth
+    from stardist_amd.lib import stardist3d as sd3
+    rays = _rays(96)
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    d, p, s, _ = synth.s3d_nuclei(64, V, rc=1)
+    rng = np.random.RandomState(0)
+    sel = rng.choice(len(d), 60, replace=False)
+    d = (d[sel] * (1 + 0.2 * rng.uniform(-1, 1, d[sel].shape))).astype(np.float32); p = p[sel]
+    labels = np.arange(1, len(d) + 1, dtype=np.int32)
+    args = (d, p, V, F, labels, mode, 0, int(overlap is not None), int(0 if overlap is None else overlap), (64, 64, 64))
+    ref_lbl = refmods.stardist3d().c_polyhedron_to_label(*args)
+    lbl = sd3.c_polyhedron_to_label(*args)
+    assert lbl.dtype == np.int32 and lbl.shape == ref_lbl.shape
+    assert np.array_equal(lbl, ref_lbl), np.count_nonzero(lbl != ref_lbl)
+
+
+@pytest.mark.parametrize("shape,n_rays,noise,thr", [((22, 33, 44), 32, 0.1, 0.2), ((22, 33, 44), 32, 0.5, 0.5),
+                                                     ((22, 33, 44), 96, 0.3, 0.3), ((33, 44, 55), 14, 0.0, 0.2),
+                                                     ((33, 44, 55), 22, 0.0, 0.4), ((22, 33, 44), 96, 0.3, 0.6)])
+def test_nms3d_random_survivors(refmods, shape, n_rays, noise, thr):
+    from stardist_amd.lib import stardist3d as sd3
+    rays = _rays(n_rays)
+    d, p, s = _random_candidates(shape, n_rays, noise, seed=n_rays)
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(thr))
+    keep, stats = sd3.c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(thr), return_stats=True)
+    diff = np.flatnonzero(keep != ref_keep)
+    assert len(diff) == 0, "survivor mismatch at %s of %d (stats %s)" % (diff[:10], len(d), stats.tolist())
+
+
+@pytest.mark.parametrize("n,thr,aniso", [(64, 0.3, None), (96, 0.3, None), (64, 0.5, (2, 1, 1))])
+def test_nms3d_nuclei_survivors(refmods, n, thr, aniso):
+    from oracle import synth
+    from stardist_amd.lib import stardist3d as sd3
+    rays = _rays(96, anisotropy=aniso)
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    d, p, s, nobj = synth.s3d_nuclei(n, rays.vertices)
+    ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(thr))
+    keep, stats = sd3.c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(thr), return_stats=True)
+    assert np.array_equal(keep, ref_keep), (int(keep.sum()), int(ref_keep.sum()), stats.tolist())
+
+
+def test_nms3d_flags_and_edges(refmods):
+    from stardist_amd.lib import stardist3d as sd3
+    rays = _rays(32)
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    d, p, s = _random_candidates((20, 30, 28), 32, 0.2, seed=5, prob_thresh=0.85)
+    for bb, kd in [(1, 1), (0, 1), (1, 0)]:
+        ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, bb, kd, 0, np.float32(0.3))
+        keep = sd3.c_non_max_suppression_inds(d, p, V, F, s, bb, kd, 0, np.float32(0.3))
+        assert np.array_equal(keep, ref_keep), (bb, kd)
+    assert sd3.c_non_max_suppression_inds(d[:0], p[:0], V, F, s[:0], 1, 1, 0, 0.3).shape == (0,)
+    assert sd3.c_non_max_suppression_inds(d[:1], p[:1], V, F, s[:1], 1, 1, 0, 0.3).tolist() == [True]
+
+
+@pytest.mark.parametrize("noise", (0, .2, .6, .9))
+@pytest.mark.parametrize("n_rays", (32, 65, 100))
+def test_nms3d_accuracy_like_reference(refmods, noise, n_rays):
+    """the reference's own test (tests/test_nms3D.py:60-83): NMS pinned against the rasteriser's IoU"""
+    from stardist_amd.lib import stardist3d as sd3
+    rays = _rays(n_rays)
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    # NB: the expression yields a Fortran-ordered array; the reference natives read raw C-order memory
+    # (its Python wrapper always passes np.ascontiguousarray, nms.py:365-366)
+    dist = np.ascontiguousarray((10 * (1 + noise * np.sin(2 * np.pi * rays.vertices[:, :2].T))).astype(np.float32))
+    points = np.array([(20, 20, 20), (20, 20, 23)], np.float32)
+    shape = (40, 55, 66)
+    one = np.ones(1, np.int32)
+    m1 = sd3.c_polyhedron_to_label(dist[:1], points[:1], V, F, one, 0, 0, 0, 0, shape)
+    m2 = sd3.c_polyhedron_to_label(dist[1:], points[1:], V, F, one, 0, 0, 0, 0, shape)
+    iou = np.count_nonzero(m1 * m2) / min(np.count_nonzero(m1), np.count_nonzero(m2) + 1e-10)
+    prob = np.array([1, .5], np.float32)
+    k1 = sd3.c_non_max_suppression_inds(dist, points, V, F, prob, 1, 1, 0, np.float32(0.95 * iou))
+    k2 = sd3.c_non_max_suppression_inds(dist, points, V, F, prob, 1, 1, 0, np.float32(1.05 * iou))
+    assert k1.sum() == 1 and k2.sum() == 2
+    r1 = refmods.stardist3d().c_non_max_suppression_inds(dist, points, V, F, prob, 1, 1, 0, np.float32(0.95 * iou))
+    r2 = refmods.stardist3d().c_non_max_suppression_inds(dist, points, V, F, prob, 1, 1, 0, np.float32(1.05 * iou))
+    assert np.array_equal(k1, r1) and np.array_equal(k2, r2)
