@@ -1,0 +1,91 @@
+"""Mirror of stardist/geometry/geom3d.py (hot-path functions) on top of the HIP natives."""
+import numpy as np
+
+from ..lib import _native as N
+from ..utils import _normalize_grid
+
+
+def star_dist3D(lbl, rays, grid=(1, 1, 1), mode="hip"):
+    """geom3d.py:86-97 ('hip' replaces 'cpp' / 'opencl'); lbl: label volume, 0 = background."""
+    from ..lib.stardist3d import c_star_dist3d
+    grid = _normalize_grid(grid, 3)
+    if mode not in ("hip", "cpp", "opencl"):
+        raise ValueError("Unknown mode %s" % mode)
+    dz, dy, dx = rays.vertices.T
+    if N.is_torch(lbl):
+        import torch
+        src = lbl if lbl.dtype == torch.uint16 else lbl.to(torch.uint16)
+    else:
+        src = lbl.astype(np.uint16, copy=False)
+    return c_star_dist3d(src, dz.astype(np.float32, copy=False), dy.astype(np.float32, copy=False),
+                         dx.astype(np.float32, copy=False), int(len(rays)), *tuple(int(a) for a in grid))
+
+
+def polyhedron_to_label(dist, points, rays, shape, prob=None, thr=-np.inf, labels=None, mode="full", verbose=True,
+                        overlap_label=None):
+    """geom3d.py:100-198: filters prob >= thr, sorts by descending prob, paints first-writer-wins."""
+    from ..lib.stardist3d import c_polyhedron_to_label
+    if len(points) == 0:
+        if verbose:
+            print("warning: empty list of points (returning background-only image)")
+        return np.zeros(shape, np.uint16)
+    modes = {"full": 0, "kernel": 1, "hull": 2, "bbox": 3, "debug": 4}
+    if mode not in modes:
+        raise KeyError("Unknown render mode '%s' , allowed:  %s" % (mode, tuple(modes.keys())))
+    if N.is_torch(dist):
+        import torch
+        if dist.dim() == 1: dist = dist.reshape(1, -1)
+        if points.dim() == 1: points = points.reshape(1, -1)
+        dev = dist.device
+        if labels is None: labels = torch.arange(1, len(points) + 1, device=dev)
+        if float(dist.min()) <= 0: raise ValueError("distance array should be positive!")
+        prob = torch.ones(len(points), device=dev) if prob is None else prob
+        if dist.dim() != 2: raise ValueError("dist should be 2 dimensional but has shape %s" % str(tuple(dist.shape)))
+        if dist.shape[1] != len(rays): raise ValueError("inconsistent number of rays!")
+        if len(prob) != len(points): raise ValueError("len(prob) != len(points)")
+        if len(labels) != len(points): raise ValueError("len(labels) != len(points)")
+        ind = torch.where(prob >= thr)[0]
+        if len(ind) == 0:
+            if verbose: print("warning: no points found with probability>= {thr:.4f} (returning background-only image)".format(thr=thr))
+            return np.zeros(shape, np.uint16)
+        prob, points, dist, labels = prob[ind], points[ind], dist[ind], labels[ind]
+        ind = torch.flip(torch.sort(prob, stable=True)[1], dims=(0,))
+        points, dist, labels = points[ind], dist[ind], labels[ind]
+        verts = torch.as_tensor(np.ascontiguousarray(rays.vertices, np.float32), device=dev)
+        faces = torch.as_tensor(np.ascontiguousarray(rays.faces, np.int32), device=dev)
+        return c_polyhedron_to_label(dist.float().contiguous(), points.float().contiguous(), verts, faces, labels.to(torch.int32).contiguous(),
+                                     np.int32(modes[mode]), np.int32(verbose), np.int32(overlap_label is not None),
+                                     np.int32(0 if overlap_label is None else overlap_label), shape)
+    dist = np.asanyarray(dist); points = np.asanyarray(points)
+    if dist.ndim == 1: dist = dist.reshape(1, -1)
+    if points.ndim == 1: points = points.reshape(1, -1)
+    if labels is None: labels = np.arange(1, len(points) + 1)
+    if np.amin(dist) <= 0: raise ValueError("distance array should be positive!")
+    prob = np.ones(len(points)) if prob is None else np.asanyarray(prob)
+    if dist.ndim != 2: raise ValueError("dist should be 2 dimensional but has shape %s" % str(dist.shape))
+    if dist.shape[1] != len(rays): raise ValueError("inconsistent number of rays!")
+    if len(prob) != len(points): raise ValueError("len(prob) != len(points)")
+    if len(labels) != len(points): raise ValueError("len(labels) != len(points)")
+    lbl = np.zeros(shape, np.uint16)
+    ind = np.where(prob >= thr)[0]
+    if len(ind) == 0:
+        if verbose: print("warning: no points found with probability>= {thr:.4f} (returning background-only image)".format(thr=thr))
+        return lbl
+    prob, points, dist, labels = prob[ind], points[ind], dist[ind], np.asarray(labels)[ind]
+    ind = np.argsort(prob, kind="stable")[::-1]
+    points, dist, labels = points[ind], dist[ind], labels[ind]
+
+    def _prep(x, dtype):
+        return np.ascontiguousarray(x.astype(dtype, copy=False))
+    return c_polyhedron_to_label(_prep(dist, np.float32), _prep(points, np.float32), _prep(rays.vertices, np.float32),
+                                 _prep(rays.faces, np.int32), _prep(labels, np.int32), np.int32(modes[mode]), np.int32(verbose),
+                                 np.int32(overlap_label is not None), np.int32(0 if overlap_label is None else overlap_label), shape)
+
+
+def dist_to_coord3D(dist, points, rays_vertices):
+    """geom3d.py:261-274"""
+    dist = np.asarray(dist); points = np.asarray(points); rays_vertices = np.asarray(rays_vertices)
+    if not all((len(dist) == len(points), dist.ndim == 2, points.ndim == 2, points.shape[-1] == 3,
+                rays_vertices.shape[-1] == 3, dist.shape[-1] == len(rays_vertices))):
+        raise ValueError("Wrong shapes! dist -> (m,n) points -> (m,3) rays_vertices -> (m,)")
+    return points[:, np.newaxis] + dist[..., np.newaxis] * rays_vertices

@@ -1,0 +1,134 @@
+"""CPU: host-side logic of the package (no GPU): config, resizer, network graph, tiling, glue vs oracle port."""
+import numpy as np
+import pytest
+
+
+def test_config_json_roundtrip_and_reference_configs():
+    from stardist_amd.models import Config2D, Config3D
+    import json
+    c = Config2D(n_rays=16, grid=(2, 2), n_channel_in=3, unet_n_depth=2)
+    c2 = Config2D.from_json(json.loads(c.to_json()))
+    assert (c2.n_rays, c2.grid, c2.n_channel_in, c2.unet_n_depth, c2.axes) == (16, (2, 2), 3, 2, "YXC")
+    c3 = Config3D(rays=32, grid=(1, 2, 2), backbone="resnet", anisotropy=(2, 1, 1))
+    c4 = Config3D.from_json(json.loads(c3.to_json()))
+    assert c4.n_rays == 32 and c4.backbone == "resnet" and c4.grid == (1, 2, 2)
+    with pytest.raises(ValueError):
+        Config2D(grid=(3, 1))
+    with pytest.raises(AttributeError):
+        Config2D(not_a_parameter=1)
+
+
+def test_glue_matches_oracle_port():
+    from oracle import port
+    from stardist_amd import nms
+    from stardist_amd.geometry import geom2d
+    from stardist_amd.matching import relabel_sequential
+    rng = np.random.RandomState(0)
+    prob = rng.rand(40, 50).astype(np.float32)
+    for b in (2, None, ((1, 0), (0, 3))):
+        assert np.array_equal(nms._ind_prob_thresh(prob, 0.7, b), port.ind_prob_thresh(prob, 0.7, b))
+    d = rng.uniform(3, 9, (17, 32)).astype(np.float32); p = rng.randint(5, 40, (17, 2))
+    assert np.array_equal(geom2d.dist_to_coord(d, p), port.dist_to_coord(d, p))
+    assert np.array_equal(geom2d.dist_to_coord(d, p, (0.5, 2)), port.dist_to_coord(d, p, (0.5, 2)))
+    lab = rng.randint(0, 9, (20, 20)) * 7
+    for off in (1, 5):
+        a, b_ = relabel_sequential(lab, off), port.relabel_sequential(lab, off)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b_))
+
+
+def test_torch_glue_equals_numpy_glue():
+    import torch
+    from stardist_amd import nms
+    from stardist_amd.geometry import geom2d
+    from stardist_amd.matching import relabel_sequential
+    rng = np.random.RandomState(1)
+    prob = rng.rand(30, 31).astype(np.float32)
+    assert np.array_equal(nms._ind_prob_thresh(torch.from_numpy(prob), 0.6, 2).numpy(), nms._ind_prob_thresh(prob, 0.6, 2))
+    d = rng.uniform(3, 9, (9, 32)).astype(np.float32); p = rng.randint(5, 40, (9, 2))
+    assert np.array_equal(geom2d.dist_to_coord(torch.from_numpy(d), torch.from_numpy(p)).numpy(), geom2d.dist_to_coord(d, p))
+    s = rng.rand(100).astype(np.float32); s[10] = s[20]
+    assert np.array_equal(nms._argsort_desc(torch.from_numpy(s)).numpy(), nms._argsort_desc(s))
+    lab = (rng.randint(0, 5, (6, 7, 8)) * 3).astype(np.int32)
+    assert np.array_equal(relabel_sequential(torch.from_numpy(lab))[0].numpy(), relabel_sequential(lab)[0])
+
+
+def test_pad_and_crop_resizer_matches_numpy_reflect():
+    import torch
+    from stardist_amd.models.base import StarDistPadAndCropResizer
+    x = np.random.RandomState(0).rand(37, 50, 1).astype(np.float32)
+    r = StarDistPadAndCropResizer(grid=dict(Y=2, X=2))
+    xp = r.before(torch.from_numpy(x), "YXC", (16, 16, 1)).numpy()
+    assert np.array_equal(xp, np.pad(x, ((0, 11), (0, 14), (0, 0)), mode="reflect"))
+    y = torch.zeros(24, 32)
+    assert tuple(r.after(y, "YX").shape) == (19, 25)
+    pts = torch.tensor([[36, 49], [37, 3], [3, 50]])
+    assert r.filter_points(3, pts, "YXC").tolist() == [0]
+
+
+def _np_conv_same(x, w, b):
+    """Keras Conv 'same' (zero pad, channels_last, cross-correlation): x (H,W,Cin), w (kh,kw,Cin,Cout)"""
+    kh, kw = w.shape[:2]
+    xp = np.pad(x, ((kh // 2, kh // 2), (kw // 2, kw // 2), (0, 0)))
+    out = np.zeros(x.shape[:2] + (w.shape[3],), np.float64)
+    for i in range(kh):
+        for j in range(kw):
+            out += xp[i:i + x.shape[0], j:j + x.shape[1]] @ w[i, j]
+    return out + b
+
+
+def test_unet_graph_matches_keras_semantics_restatement():
+    """PyTorch module vs a numpy restatement of the Keras graph (model2d.py:310-349 + csbdeep unet_block):
+    'same' zero padding, max-pool valid, nearest up-sampling, Concatenate([up, skip])."""
+    import torch
+    from stardist_amd.models import Config2D, StarDist2D
+    cfg = Config2D(n_rays=4, unet_n_depth=1, unet_n_filter_base=3, net_conv_after_unet=5)
+    m = StarDist2D(cfg, basedir=None, device="cpu", seed=3)
+    with torch.no_grad():
+        for prm in m.net.parameters():
+            if prm.dim() == 1:
+                prm.copy_(torch.linspace(-0.1, 0.1, prm.numel()))
+    x = np.random.RandomState(0).rand(8, 10, 1).astype(np.float32)
+    prob, dist = m.predict(x[..., 0])
+    W = lambda conv: (conv.weight.detach().numpy().transpose(2, 3, 1, 0).astype(np.float64), conv.bias.detach().numpy().astype(np.float64))
+    relu = lambda a: np.maximum(a, 0)
+    ub = m.net.backbone
+    h = x.astype(np.float64)
+    for seq in ub.down[0]:
+        h = relu(_np_conv_same(h, *W(seq[0])))
+    skip = h
+    h = h.reshape(4, 2, 5, 2, -1).max((1, 3))
+    for seq in ub.middle:
+        h = relu(_np_conv_same(h, *W(seq[0])))
+    h = np.repeat(np.repeat(h, 2, 0), 2, 1)
+    h = np.concatenate([h, skip], -1)
+    for seq in ub.up[0]:
+        h = relu(_np_conv_same(h, *W(seq[0])))
+    f = relu(_np_conv_same(h, *W(m.net.features[0])))
+    wp, bp = W(m.net.prob); wd, bd = W(m.net.dist)
+    p_ref = 1 / (1 + np.exp(-(f @ wp[0, 0] + bp)))[..., 0]
+    d_ref = np.maximum(f @ wd[0, 0] + bd, 1e-3)
+    assert np.allclose(prob, p_ref, atol=1e-5) and np.allclose(dist, d_ref, atol=1e-5)
+
+
+def test_tiled_prediction_equals_untiled():
+    from stardist_amd.models import Config2D, StarDist2D
+    m = StarDist2D(Config2D(n_rays=8, unet_n_filter_base=4, net_conv_after_unet=8), basedir=None, device="cpu")
+    x = np.random.RandomState(0).rand(150, 170).astype(np.float32)
+    p, d = m.predict(x)
+    p2, d2 = m.predict(x, n_tiles=(2, 3))
+    assert np.allclose(p, p2, atol=1e-5) and np.allclose(d, d2, atol=1e-4)
+    with pytest.raises(ValueError):
+        m.predict(x, n_tiles=(2,))
+    with pytest.raises(ValueError):
+        m.predict(np.zeros((20, 20, 3), np.float32))
+
+
+def test_3d_models_build_and_predict_on_cpu():
+    from stardist_amd.models import Config3D, StarDist3D
+    for cfg in (Config3D(rays=16, unet_n_filter_base=4, net_conv_after_unet=8),
+                Config3D(rays=16, backbone="resnet", grid=(1, 2, 2), resnet_n_filter_base=4, net_conv_after_resnet=8, resnet_n_blocks=2)):
+        m = StarDist3D(cfg, basedir=None, device="cpu")
+        p, d = m.predict(np.random.RandomState(0).rand(12, 20, 24).astype(np.float32))
+        g = cfg.grid
+        assert p.shape == (12 // g[0], 20 // g[1], 24 // g[2]) and d.shape == p.shape + (16,)
+        assert (d >= 1e-3).all() and ((p > 0) & (p < 1)).all()

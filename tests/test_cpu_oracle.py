@@ -1,0 +1,101 @@
+"""CPU: the oracle (compiled reference in oracle/_ref + numpy port) against the committed golden vectors
+(tests/golden/*.npz, produced by tests/golden/make_golden.py from the reference itself)."""
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = np.load(os.path.join(ROOT, "tests", "golden", "reference_outputs.npz"))
+
+
+@pytest.mark.parametrize("H,W,R,thr", [(256, 256, 32, 0.4), (512, 512, 32, 0.4), (356, 299, 11, 0.5), (114, 217, 32, 0.3)])
+def test_ref_nms2d_matches_golden(refmods, H, W, R, thr):
+    from oracle import synth
+    d, p, s = synth.s2d_uniform(H, W, n_rays=R)
+    keep = refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(thr))
+    n, m = G["nms2d_%d_%d_%d_n" % (H, W, R)]
+    assert (len(d), int(keep.sum())) == (n, m)
+    assert np.array_equal(np.packbits(keep), G["nms2d_%d_%d_%d_keep" % (H, W, R)])
+
+
+def test_survey_calibration_counts():
+    """S2D-uniform 512^2 -> 26 010 candidates, 1 622 survivors"""
+    assert tuple(G["nms2d_512_512_32_n"]) == (26010, 1622)
+
+
+def test_ref_old_equals_new_nms(refmods):
+    """the reference's own cross-check tests/test_nms2D.py:78-110 (old grid-search NMS == new kd-tree NMS),
+    restated at the native boundary: same survivors for the same seeded candidates"""
+    from oracle import port, synth
+    m = refmods.stardist2d()
+    for shape, R in (((356, 299), 11), ((114, 217), 32)):
+        dist, prob = synth.s2d_uniform(shape[0], shape[1], n_rays=R, dense=True)
+        mask = port.ind_prob_thresh(prob, 0.9, b=2)
+        pts = np.stack(np.where(mask), 1)
+        d, s = dist[mask], prob[mask]
+        ind = np.argsort(s)[::-1]
+        d, s, pts = d[ind], s[ind], pts[ind]
+        keep_new = m.c_non_max_suppression_inds(np.ascontiguousarray(d), np.ascontiguousarray(pts.astype(np.float32)), 1, 1, 0, np.float32(0.4))
+        coord = port.dist_to_coord(d, pts)                       # (n,2,R)
+        mapping = -np.ones(mask.shape, np.int32)
+        mapping.flat[np.flatnonzero(mask)[ind]] = range(len(ind))
+        keep_old = m.c_non_max_suppression_inds_old(np.ascontiguousarray(coord.astype(np.int32)), mapping, np.float32(0.4),
+                                                    np.int32(1), np.int32(1), np.int32(1), np.int32(0))
+        assert keep_new.sum() == keep_old.sum()
+        assert np.array_equal(keep_new, keep_old)
+
+
+def test_ref_star_dist_matches_golden(refmods):
+    from oracle import synth
+    lbl, _, _ = synth.s2d_nuclei_labels(200, 231, seed=3)
+    m = refmods.stardist2d()
+    assert np.array_equal(m.c_star_dist(lbl, 32, 1, 1)[::7, ::7], G["stardist2d_32_1"])
+    assert np.array_equal(m.c_star_dist(lbl, 17, 2, 2)[::7, ::7], G["stardist2d_17_2"])
+    # the reference's own properties: dtype invariance (tests/test_stardist2D.py:7-17), grid == subsample (:68-80)
+    a = m.c_star_dist(lbl.astype(np.uint16), 32, 1, 1)
+    assert np.array_equal(a[::2, ::2], m.c_star_dist(lbl, 32, 2, 2))
+
+
+def test_ref_3d_matches_golden(refmods):
+    from oracle import synth
+    from stardist_amd.rays3d import Rays_GoldenSpiral
+    rays = Rays_GoldenSpiral(96)
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    d, p, s, nobj = synth.s3d_nuclei(64, V)
+    m = refmods.stardist3d()
+    keep = m.c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(0.3))
+    assert (len(d), int(keep.sum()), nobj) == tuple(G["nms3d_64_n"])
+    assert np.array_equal(np.packbits(keep), G["nms3d_64_keep"])
+    lbl = m.c_polyhedron_to_label(d[keep], p[keep], V, F, np.arange(1, keep.sum() + 1, dtype=np.int32), 0, 0, 0, 0, (64, 64, 64))
+    assert np.array_equal(np.bincount(lbl.ravel()), G["raster3d_64_hist"])
+
+
+def test_clipper_probe_matches_golden(refmods):
+    a = np.array([refmods.clipper_area(G["clip_xa"][i], G["clip_ya"][i], G["clip_xb"][i], G["clip_yb"][i]) for i in range(64)], np.float32)
+    assert np.array_equal(a, G["clip_area"])
+
+
+def test_rays_match_reference_golden():
+    """stardist_amd.rays3d against vertices/faces produced by the reference's own rays3d.py"""
+    from stardist_amd import rays3d as M
+    R = np.load(os.path.join(ROOT, "tests", "golden", "rays_reference.npz"))
+    for name, obj in [("gs96", M.Rays_GoldenSpiral(96)), ("gs32", M.Rays_GoldenSpiral(32)), ("gs65", M.Rays_GoldenSpiral(65)),
+                      ("gs96a", M.Rays_GoldenSpiral(96, anisotropy=(2, 1, 1))), ("cart", M.Rays_Cartesian(11, 5)),
+                      ("tetra3", M.Rays_Tetra(3)), ("octo2", M.Rays_Octo(2))]:
+        assert np.array_equal(obj.vertices, R[name + "_v"]), name
+        assert np.array_equal(obj.faces, R[name + "_f"]), name
+    assert M.rays_from_json(M.Rays_GoldenSpiral(96, anisotropy=(2, 1, 1)).to_json()).vertices.shape == (96, 3)
+
+
+def test_port_polygon_rule():
+    """the restated scikit-image rule: label i == polygon mask (cf. tests/test_big.py:202-213), vertices and
+    edge pixels count as inside, painting order = later overwrites earlier"""
+    from oracle import port
+    r = np.array([2.0, 2.0, 8.0, 8.0]); c = np.array([3.0, 9.0, 9.0, 3.0])
+    rr, cc = port.polygon(r, c, (12, 12))
+    m = np.zeros((12, 12), bool); m[rr, cc] = True
+    assert m[2:9, 3:10].all() and m.sum() == 49          # closed square incl. its edges
+    coord = np.stack([np.stack([r, c]), np.stack([r + 1, c + 1])])
+    lbl = port.polygons_to_label_coord(coord, (12, 12))
+    assert lbl[2, 3] == 1 and lbl[5, 5] == 2 and lbl[9, 10] == 2
