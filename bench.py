@@ -1,20 +1,24 @@
 #!/usr/bin/env python
 """bench.py -- end-to-end predict_instances() throughput of the MI355X-native StarDist path.
 
-Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W` prints ONE
-JSON line on rank 0.  One "step" = one full `StarDist2D.predict_instances()` on one synthetic
-2048x2048 image already resident in HBM (BASELINE.json configs[1]): U-Net forward (fp32,
-channels_last) -> threshold/compaction -> score sort -> polygon NMS -> label rasteriser ->
-labels + survivor dict back on the host.  N > 1: one process per GPU (torchrun), each rank owns
-its own image of the same size ("weak" scaling, independent tiles, no data-path collective);
-value = total pixels of all ranks / max-over-ranks time.
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON
+line on rank 0.  One "step" = one full `predict_instances()` on one synthetic input already
+resident in HBM: network forward (fp32, channels_last) -> threshold/compaction -> score sort ->
+NMS -> label rasteriser -> labels + survivor dict back on the host.
 
-Weights are seeded random (no checkpoints offline).  The two 1x1 heads are re-scaled once,
-before timing, so that the network's own outputs have the candidate statistics of the
-reference's NMS test data (tests/test_nms2D.py:9-15: ~10 % of pixels above the probability
-threshold, radius 10 +- 10 %); otherwise a random net yields either zero or millions of
-candidates and the NMS/raster stages would be meaningless.  Nothing is skipped in the timed
-region.
+  headline (value, Mpix/s): BASELINE.json configs[1], StarDist2D 32-ray U-Net on a 2048x2048 tile;
+  second leg (value_3d, Mvox/s): configs[2], StarDist3D Rays_GoldenSpiral(96) on a 256^3 volume
+  (runs in the same invocation after the 2D leg; `--skip-3d` drops it).
+
+N > 1: one process per GPU (torchrun), every rank owns its own input of the same size ("weak"
+scaling: independent tiles, no data-path collective); value = all ranks' pixels / max-over-ranks time.
+
+Weights are seeded random (no checkpoints offline).  The two 1x1 heads are re-scaled once, before
+timing, so that the network's own outputs have the candidate statistics of the reference's NMS
+workloads (2D: tests/test_nms2D.py:9-15, ~10 % of pixels above threshold, radius 10 +- 10 %;
+3D: SURVEY.md 8d S3D-nuclei, ~0.9 % of voxels, radius ~8.5); otherwise a random net yields either
+no or millions of candidates and the NMS / raster stages would be meaningless.  Nothing is skipped
+in the timed region.
 """
 import argparse
 import json
@@ -44,35 +48,35 @@ def calibrate_heads(model, img, frac=0.10, radius=10.0, noise=0.1):
     h.remove()
     f = feats["f"].float()
     with torch.no_grad():
-        z = net.prob(f) - net.prob.bias.reshape(1, -1, *([1] * (f.dim() - 2)))
+        bshape = (1, -1) + (1,) * (f.dim() - 2)
+        z = net.prob(f) - net.prob.bias.reshape(bshape)
         zs = z.flatten()
         if zs.numel() > 4_000_000:
             zs = zs[:: zs.numel() // 4_000_000]
         q = torch.quantile(zs, 1.0 - frac)
         net.prob.bias.fill_(float(-q))
-        d = net.dist(f) - net.dist.bias.reshape(1, -1, *([1] * (f.dim() - 2)))
-        sd = float(d.std())
+        d = net.dist(f) - net.dist.bias.reshape(bshape)
+        sd = float(d[:, :, ::2].std())
         net.dist.weight.mul_(radius * noise * 0.58 / max(sd, 1e-12))
         net.dist.bias.fill_(radius)
+    del feats, f
 
 
-def cpu_baseline(img_np, model, sample, threads):
-    """Reference CPU path on a bounded sample (sample x sample crop of the same image):
-    U-Net = the same PyTorch module on CPU (stand-in for TF-CPU, which is not installed -- flagged
-    deviation), post-processing = the COMPILED REFERENCE natives (oracle/_ref: stardist2d.cpp + Clipper
-    + nanoflann, OpenMP) + the numpy restatement of the Python rasteriser loop."""
+def cpu_baseline_2d(img_np, model, sample, threads):
+    """Reference CPU path on a bounded sample: U-Net = the same PyTorch module on CPU (stand-in for
+    TF-CPU, which is not installed -- flagged deviation); post-processing = the COMPILED REFERENCE
+    natives (oracle/_ref: stardist2d.cpp + Clipper + nanoflann, OpenMP) + the numpy restatement of
+    the reference's Python rasteriser loop."""
     import copy
     import torch
     from oracle import port, ref
-    os.environ["OMP_NUM_THREADS"] = str(threads)
     torch.set_num_threads(threads)
     ref.stardist2d(); ref.set_threads(threads)
     x = img_np[:sample, :sample]
     net_cpu = copy.deepcopy(model.net).to("cpu").float()
     t0 = time.time()
     with torch.no_grad():
-        xc = torch.from_numpy(x)[None, None]
-        prob, dist = net_cpu(xc)
+        prob, dist = net_cpu(torch.from_numpy(x)[None, None])
     prob = prob[0, 0].numpy()
     dist = np.maximum(1e-3, np.moveaxis(dist[0].numpy(), 0, -1))
     t_net = time.time() - t0
@@ -82,9 +86,8 @@ def cpu_baseline(img_np, model, sample, threads):
     d, s = dist[mask], prob[mask]
     ind = np.argsort(s)[::-1]
     d, s, pts = d[ind], s[ind], pts[ind]
-    keep = ref.stardist2d().c_non_max_suppression_inds(np.ascontiguousarray(d, np.float32),
-                                                       np.ascontiguousarray(pts.astype(np.float32)), 1, 1, 0,
-                                                       np.float32(model.thresholds.nms))
+    keep = ref.stardist2d().c_non_max_suppression_inds(np.ascontiguousarray(d, np.float32), np.ascontiguousarray(pts.astype(np.float32)),
+                                                       1, 1, 0, np.float32(model.thresholds.nms))
     t_nms = time.time() - t0
     t0 = time.time()
     port.polygons_to_label(d[keep], pts[keep], prob=s[keep], shape=x.shape)
@@ -92,8 +95,82 @@ def cpu_baseline(img_np, model, sample, threads):
     tot = t_net + t_nms + t_ras
     return dict(value=round(x.size / tot / 1e6, 4), unit="Mpix/s", cores=threads, kind="reference",
                 sample="%dx%d crop of the bench image: torch-CPU U-Net %.2fs (TF-CPU stand-in) + compiled reference NMS "
-                       "(oracle/_ref, %d candidates -> %d) %.2fs + numpy rasteriser restatement %.2fs"
+                       "(oracle/_ref, %d candidates -> %d) %.2fs + numpy restatement of the Python rasteriser loop %.2fs"
                        % (sample, sample, t_net, len(d), int(keep.sum()), t_nms, t_ras))
+
+
+def cpu_baseline_3d(vol_np, model, sample, threads):
+    import copy
+    import torch
+    from oracle import port, ref
+    from stardist_amd.rays3d import rays_from_json
+    torch.set_num_threads(threads)
+    m3 = ref.stardist3d(); ref.set_threads(threads)
+    rays = rays_from_json(model.config.rays_json)
+    x = vol_np[:sample, :sample, :sample]
+    net_cpu = copy.deepcopy(model.net).to("cpu").float()
+    t0 = time.time()
+    with torch.no_grad():
+        prob, dist = net_cpu(torch.from_numpy(x)[None, None])
+    prob = prob[0, 0].numpy()
+    dist = np.maximum(1e-3, np.moveaxis(dist[0].numpy(), 0, -1))
+    t_net = time.time() - t0
+    t0 = time.time()
+    mask = port.ind_prob_thresh(prob, model.thresholds.prob, b=2)
+    pts = np.stack(np.where(mask), 1)
+    d, s = dist[mask], prob[mask]
+    ind = np.argsort(s)[::-1]
+    d, s, pts = np.ascontiguousarray(d[ind], np.float32), np.ascontiguousarray(s[ind], np.float32), np.ascontiguousarray(pts[ind].astype(np.float32))
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    keep = m3.c_non_max_suppression_inds(d, pts, V, F, s, 1, 1, 0, np.float32(model.thresholds.nms))
+    t_nms = time.time() - t0
+    t0 = time.time()
+    m3.c_polyhedron_to_label(d[keep], pts[keep], V, F, np.arange(1, keep.sum() + 1, dtype=np.int32), 0, 0, 0, 0, x.shape)
+    t_ras = time.time() - t0
+    tot = t_net + t_nms + t_ras
+    return dict(value=round(x.size / tot / 1e6, 4), unit="Mvox/s", cores=threads, kind="reference",
+                sample="%d^3 crop of the bench volume: torch-CPU U-Net %.2fs (TF-CPU stand-in) + compiled reference 3D NMS "
+                       "(oracle/_ref incl. Qhull, %d candidates -> %d) %.2fs + compiled reference rasteriser %.2fs"
+                       % (sample, t_net, len(d), int(keep.sum()), t_nms, t_ras))
+
+
+def run_leg(model, img, steps, warmup, world, dist_):
+    """W untimed + K timed predict_instances, barrier + synchronize on both sides, max over ranks.
+    Returns (elapsed_s, avg net ms, last result, summed native stats)."""
+    import torch
+    from stardist_amd.lib import _native
+    pairs = []
+    orig_forward = model._net_forward
+
+    def timed_forward(x):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); r = orig_forward(x); b.record()
+        pairs.append((a, b))
+        return r
+    model._net_forward = timed_forward
+    for _ in range(warmup):
+        res = model.predict_instances(img)
+    pairs.clear()
+    if world > 1:
+        dist_.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = {}
+    for _ in range(steps):
+        res = model.predict_instances(img)
+        for k, v in _native.last_stats.items():
+            stats[k] = stats.get(k, 0) + v
+    torch.cuda.synchronize()
+    if world > 1:
+        dist_.barrier()
+    elapsed = time.perf_counter() - t0
+    net_ms = sum(a.elapsed_time(b) for a, b in pairs) / max(1, len(pairs))
+    model._net_forward = orig_forward
+    if world > 1:
+        tt = torch.tensor([elapsed], device=img.device, dtype=torch.float64)
+        dist_.all_reduce(tt, op=dist_.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed, net_ms, res, stats
 
 
 def main():
@@ -102,9 +179,12 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=2048)
+    ap.add_argument("--size3d", type=int, default=256)
     ap.add_argument("--dtype", default="float32", choices=["float32", "bfloat16", "float16"])
+    ap.add_argument("--skip-3d", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--cpu-sample3d", type=int, default=96)
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -113,95 +193,107 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local_rank)
         dist_.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" IS RCCL on ROCm
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
+    threads = args.cpu_threads or min(os.cpu_count() or 1, 32)
 
-    from oracle import synth                       # input generator only (numpy), shared with the tests
-    from stardist_amd.models import Config2D, StarDist2D
+    from oracle import synth                       # input generators only (numpy), shared with the tests
+    from stardist_amd.models import Config2D, Config3D, StarDist2D, StarDist3D
     from stardist_amd.models.unet import conv_macs_per_input_pixel
+    peak = MFMA_F32_PEAK_TFLOPS if args.dtype == "float32" else MFMA_BF16_PEAK_TFLOPS
+    dt = {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[args.dtype]
 
+    # ------------------------------------------------------------------ 2D leg (headline)
     H = W = args.size
     img_np = synth.s2d_nuclei_image(H, W, seed=rank)
     img = torch.from_numpy(img_np).to(dev)
     model = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0, compute_dtype=args.dtype)
     calibrate_heads(model, img)
     macs = conv_macs_per_input_pixel(model.net, model.config)
-
-    # ---- per-stage instrumentation with HIP events on torch's current stream (the stream every
-    # kernel of the path is launched on: the natives receive torch.cuda.current_stream()).
-    stage_ms = {"net": 0.0, "post": 0.0}
-    ev = lambda: torch.cuda.Event(enable_timing=True)
-    orig_forward = model._net_forward
-
-    def timed_forward(x):
-        a, b = ev(), ev()
-        a.record(); r = orig_forward(x); b.record()
-        timed_forward.pairs.append((a, b))
-        return r
-    timed_forward.pairs = []
-    model._net_forward = timed_forward
-
-    def step():
-        return model.predict_instances(img)
-
-    n_cand = n_keep = 0
-    for _ in range(args.warmup):
-        labels, res = step()
-    timed_forward.pairs.clear()
-    if world > 1:
-        dist_.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        labels, res = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist_.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    net_ms = sum(a.elapsed_time(b) for a, b in timed_forward.pairs) / max(1, len(timed_forward.pairs))
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist_.all_reduce(tt, op=dist_.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    ms_per_step = 1e3 * elapsed / args.steps
-    n_keep = len(res["prob"])
-
+    elapsed, net_ms, res, st = run_leg(model, img, args.steps, args.warmup, world, dist_)
+    out = None
     if rank == 0:
-        # dense candidate count of the last step (for the record)
+        ms_per_step = 1e3 * elapsed / args.steps
         p, d = model.predict(img)
         n_cand = int(((p > model.thresholds.prob)[2:-2, 2:-2]).sum())
-        value = world * H * W * args.steps / elapsed / 1e6
+        s2 = st.get("nms2d", np.zeros(16, np.int64)) / max(1, args.steps)
         flops = 2.0 * macs * H * W
-        peak = MFMA_F32_PEAK_TFLOPS if args.dtype == "float32" else MFMA_BF16_PEAK_TFLOPS
-        ach = flops / (net_ms * 1e-3) / 1e12
-        post_ms = ms_per_step - net_ms
+        conv_tf = flops / (net_ms * 1e-3) / 1e12
+        pair_ms, pair_launches, n_pairs = s2[4] / 1e6, max(1.0, s2[5]), s2[0]
+        # algorithmic bytes of the pair kernel: SURVEY.md 8(d) pair-traffic model B_pair = 2*(4R+4D) = 272 B per pair (R=32, D=2)
+        pair_bytes_per_launch = 272.0 * n_pairs / pair_launches
+        pair_gbs = pair_bytes_per_launch / max(1e-9, (pair_ms / pair_launches) * 1e-3) / 1e9
+        stages = {"unet_forward": round(net_ms, 3), "nms_pair_kernel": round(float(pair_ms), 3),
+                  "nms_exact_join_kernel": round(float(s2[6] / 1e6), 3), "nms_build_bin_neighbours": round(float(s2[7] / 1e6), 3),
+                  "other(select,sort,greedy-scan,raster,d2h)": round(ms_per_step - net_ms - float(pair_ms + s2[6] / 1e6 + s2[7] / 1e6), 3)}
+        roof_conv = {"bound": "mfma", "kernel": "U-Net conv stack (MIOpen / CK kernels, fp32 NHWC)", "achieved": round(conv_tf, 3), "peak": peak,
+                     "unit": "TFLOP/s", "frac": round(conv_tf / peak, 4), "traffic": None, "flops_per_launch": flops, "avg_ms": round(net_ms, 3)}
+        roof_pair = {"bound": "hbm", "kernel": "k_pairs (scan-beam polygon intersection, one thread per pair)", "achieved": round(pair_gbs, 3),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pair_gbs / HBM_PEAK_GBS, 6), "traffic": None,
+                     "bytes_per_launch": round(pair_bytes_per_launch), "avg_launch_ms": round(float(pair_ms / pair_launches), 4),
+                     "launches_per_step": float(pair_launches), "pairs_per_step": float(n_pairs),
+                     "note": "latency-bound integer sweep; compulsory traffic is tiny (SURVEY.md 8d)"}
+        dominant = roof_pair if pair_ms + s2[6] / 1e6 > net_ms else roof_conv
         out = {
             "metric": "predict_instances() Mpix/s (2D) + Mvox/s (3D) end-to-end at 1/2/4/8 GPU",
-            "value": round(value, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[args.dtype], "data": "synthetic",
-            "config": {"workload": "StarDist2D 32-ray U-Net (depth 3, 32 base filters), %dx%d synthetic fluo tile per GPU, "
-                                   "predict_instances (U-Net + select + 2D NMS + polygon raster), seeded random weights, "
-                                   "heads calibrated to ~10%% candidates radius 10+-10%%" % (H, W),
-                       "candidates": n_cand, "survivors": n_keep, "prob_thresh": model.thresholds.prob,
+            "value": round(world * H * W * args.steps / elapsed / 1e6, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": dt, "data": "synthetic",
+            "config": {"workload": "StarDist2D 32-ray U-Net (depth 3, 32 base filters), %dx%d synthetic fluo tile per GPU, predict_instances "
+                                   "(U-Net + select + 2D NMS + polygon raster), seeded random weights, heads calibrated to ~10%% candidates "
+                                   "radius 10+-10%%" % (H, W),
+                       "candidates": n_cand, "survivors": len(res[1]["prob"]), "prob_thresh": model.thresholds.prob,
                        "nms_thresh": model.thresholds.nms, "parallelism": "tiles-per-gpu x%d" % world},
-            "stages_ms": {"unet_forward": round(net_ms, 3), "select_sort_nms_raster_d2h": round(post_ms, 3)},
-            "roofline": {"bound": "mfma", "kernel": "U-Net conv stack (MIOpen/rocBLAS kernels, fp32 NHWC)",
-                         "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                         "traffic": None, "flops_per_launch": flops, "avg_ms": round(net_ms, 3)},
+            "stages_ms": stages, "roofline": dominant, "roofline_convs": roof_conv, "roofline_pair_kernel": roof_pair,
         }
         if not args.no_cpu_baseline:
             try:
-                threads = args.cpu_threads or min(os.cpu_count() or 1, 32)
-                out["cpu_baseline"] = cpu_baseline(img_np, model, min(args.cpu_sample, H), threads)
-            except Exception as e:   # the oracle is optional at run time (prebuilt oracle/_ref must have travelled)
+                out["cpu_baseline"] = cpu_baseline_2d(img_np, model, min(args.cpu_sample, H), threads)
+            except Exception as e:   # oracle/_ref must have travelled with the tree
                 out["cpu_baseline"] = {"value": None, "unit": "Mpix/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
+    del model, img
+    torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ 3D leg
+    if not args.skip_3d:
+        S = args.size3d
+        vol_np = synth.s3d_nuclei_image(S, seed=rank)
+        vol = torch.from_numpy(vol_np).to(dev)
+        m3 = StarDist3D(Config3D(rays=96), basedir=None, device=dev, seed=0, compute_dtype=args.dtype)
+        m3.thresholds = dict(prob=0.5, nms=0.3)
+        calibrate_heads(m3, vol, frac=0.009, radius=8.5, noise=0.15)
+        macs3 = conv_macs_per_input_pixel(m3.net, m3.config)
+        steps3 = max(1, min(args.steps, 3))
+        elapsed3, net3_ms, res3, st3 = run_leg(m3, vol, steps3, 1, world, dist_)
+        if rank == 0:
+            s3 = st3.get("nms3d", np.zeros(16, np.int64)) / steps3
+            ms3 = 1e3 * elapsed3 / steps3
+            flops3 = 2.0 * macs3 * S ** 3
+            conv3_tf = flops3 / (net3_ms * 1e-3) / 1e12
+            out["value_3d"] = round(world * S ** 3 * steps3 / elapsed3 / 1e6, 3)
+            out["unit_3d"] = "Mvox/s"
+            out["ms_per_step_3d"] = round(ms3, 3)
+            out["config_3d"] = {"workload": "StarDist3D Rays_GoldenSpiral(96) U-Net (depth 2), %d^3 synthetic volume per GPU, predict_instances "
+                                            "(U-Net + select + 3D NMS cascade + polyhedron raster + relabel)" % S,
+                                "survivors": len(res3[1]["prob"]), "steps": steps3, "nms_thresh": 0.3,
+                                "cascade_calls": {"upper": float(s3[0]), "lower": float(s3[1]), "kernel_volume": float(s3[2]),
+                                                  "hull_volume": float(s3[11]), "render": float(s3[3])}}
+            out["stages_ms_3d"] = {"unet_forward": round(net3_ms, 3), "nms_stage3_kernel_volume": round(float(s3[8] / 1e6), 3),
+                                   "nms_stage4_hull_volume": round(float(s3[9] / 1e6), 3), "nms_stage5_render": round(float(s3[10] / 1e6), 3),
+                                   "other": round(ms3 - net3_ms - float((s3[8] + s3[9] + s3[10]) / 1e6), 3)}
+            out["roofline_convs_3d"] = {"bound": "mfma", "achieved": round(conv3_tf, 3), "peak": peak, "unit": "TFLOP/s",
+                                        "frac": round(conv3_tf / peak, 4), "flops_per_launch": flops3, "avg_ms": round(net3_ms, 3)}
+            if not args.no_cpu_baseline:
+                try:
+                    out["cpu_baseline_3d"] = cpu_baseline_3d(vol_np, m3, min(args.cpu_sample3d, S), threads)
+                except Exception as e:
+                    out["cpu_baseline_3d"] = {"value": None, "unit": "Mvox/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist_.destroy_process_group()

@@ -40,8 +40,9 @@ int sd_release_workspace(void);           /* free the cached device workspace   
  * dist   (n_polys, n_rays) float32, points (n_polys, 2) float32 (y, x), both sorted by score
  * descending.  use_kdtree / use_bbox / verbose / threshold as in the reference ("O!O!iiif").
  * keep   (n_polys,) bytes: 1 = survivor, 0 = suppressed (the reference returns NPY_BOOL).
- * stats  optional int64[8] (may be NULL): {pairs evaluated, pairs re-run on the exact-join
- *        path, greedy rounds, neighbour entries, 0...}.
+ * stats  optional int64[16] (may be NULL): {0 pairs evaluated, 1 pairs re-run on the exact-join path,
+ *        2 greedy rounds, 3 neighbour entries, 4 pair-kernel time ns (HIP events on `stream`),
+ *        5 pair-kernel launches, 6 exact-join kernel ns, 7 build+bin+neighbour kernels ns, 8.. 0}.
  */
 int sd_nms2d_host(const float* dist, const float* points, int n_polys, int n_rays,
                   int use_kdtree, int use_bbox, int verbose, float threshold,
@@ -98,6 +99,9 @@ void _LIB_non_maximum_suppression_sparse(const float* scores, const float* dist,
                                          const int* faces, const float threshold,
                                          const int use_bbox, const int use_kdtree,
                                          const int verbose, bool* result);
+/* stats: optional int64[16]: {0 upper-bound tests, 1 lower-bound tests, 2 kernel-volume calls, 3 render calls,
+ * 4 greedy rounds, 5 neighbour entries, 6 suppressed by kernel stage, 7 suppressed by render stage,
+ * 8 stage-3 kernel ns, 9 stage-4 ns, 10 stage-5 ns, 11 hull-volume calls, 12 kept by hull stage, 13.. 0} */
 int sd_nms3d_device(const float* d_scores, const float* d_dist, const float* d_points,
                     int n_polys, int n_rays, int n_faces, const float* d_verts,
                     const int* d_faces, float threshold, int use_bbox, int use_kdtree,

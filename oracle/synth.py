@@ -93,3 +93,20 @@ def s2d_nuclei_image(H, W, seed=0, channels=1):
     if channels > 1:
         img = np.stack([img * (0.6 + 0.2 * c) for c in range(channels)], -1)
     return img.astype(np.float32)
+
+
+def s3d_nuclei_image(N, spacing=24, R=(7, 10), seed=0):
+    """Synthetic 3D 'fluo' volume for the U-Net leg: spheres on a jittered lattice + gaussian noise, float32."""
+    rng = np.random.RandomState(seed)
+    g = np.arange(spacing // 2, N, spacing)
+    C = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
+    C += rng.uniform(-4, 4, C.shape)
+    Rs = rng.uniform(R[0], R[1], len(C))
+    vol = np.zeros((N, N, N), np.float32)
+    for c, r in zip(C, Rs):
+        lo = np.maximum(0, np.floor(c - r - 1).astype(int)); hi = np.minimum(N, np.ceil(c + r + 2).astype(int))
+        zz, yy, xx = np.mgrid[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+        m = (zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2 <= r * r
+        vol[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]][m] = 1.0
+    vol += rng.normal(0, 0.05, vol.shape).astype(np.float32)
+    return vol

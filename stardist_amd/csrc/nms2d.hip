@@ -326,7 +326,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
                                void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   const int N = n_polys, R = n_rays;
-  if (stats) memset(stats, 0, 8 * sizeof(int64_t));
+  if (stats) memset(stats, 0, 16 * sizeof(int64_t));
   if (N <= 0) return 0;
   if (R < 1 || R > 256) { sd::set_error("sd_nms2d: n_rays=%d unsupported (1..256)", R); return -1; }
   if (verbose) {
@@ -337,6 +337,12 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   }
   sd::Arena& A = sd::arena();
   if (A.begin(s)) return -1;
+  // HIP events on the caller's stream: per-kernel durations for the roofline report (bench.py)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (stats) { SD_CHECK(hipEventCreate(&ev0)); SD_CHECK(hipEventCreate(&ev1)); }
+  struct EvGuard { hipEvent_t a, b; ~EvGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evguard{ev0, ev1};
+  double ns_pairs = 0, ns_full = 0, ns_pre = 0;
+  long long n_pair_launches = 0;
 
   // all-pairs configuration with a negative threshold: every pair (0, j) passes the reference's
   // filters and overlap >= 0 > thr, so polygon 0 suppresses everything else.
@@ -365,6 +371,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   const int gs_init[8] = {0, INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN, 0, 0, 0};
   SD_CHECK(hipMemcpyAsync(gstats, gs_init, sizeof(gs_init), hipMemcpyHostToDevice, s));
   SD_CHECK(hipMemsetAsync(state, 0, N, s));
+  if (stats) SD_CHECK(hipEventRecord(ev0, s));
   hipLaunchKernelGGL(k_build, dim3(sd::div_up(N, 4)), dim3(256), 4 * 2 * R * sizeof(int), s, d_dist, d_points, d_sc, N, R,
                      vx, vy, bbox, radius, area, gstats);
   SD_LAUNCH_CHECK();
@@ -426,6 +433,8 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
                      cellItems, nbrCount, (const i64*)nbrStart, nbr, W);
   SD_LAUNCH_CHECK();
 
+  if (stats) { SD_CHECK(hipEventRecord(ev1, s)); SD_CHECK(hipEventSynchronize(ev1)); float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns_pre = ms * 1e6; }
+
   // ---- greedy rounds
   const unsigned long long pairCap = (unsigned long long)(totalNbr / 2 + 64);
   int* U0 = A.take_n<int>(N);
@@ -464,18 +473,23 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
       if (h.nPairs > pairCap) { sd::set_error("sd_nms2d: pair queue overflow (internal error)"); return -1; }
       if (h.nPairs > 0) {
         totalPairs += (i64)h.nPairs;
+        if (stats) SD_CHECK(hipEventRecord(ev0, s));
         if (R <= 32) launch_pairs<32, 64, 32>(pairs, h.nPairs, R, vx, vy, area, threshold, state, joinPairs, &d_cnt->nJoin, joinCap, &d_cnt->nErr, s);
         else if (R <= 64) launch_pairs<64, 96, 48>(pairs, h.nPairs, R, vx, vy, area, threshold, state, joinPairs, &d_cnt->nJoin, joinCap, &d_cnt->nErr, s);
         else if (R <= 128) launch_pairs<128, 128, 64>(pairs, h.nPairs, R, vx, vy, area, threshold, state, joinPairs, &d_cnt->nJoin, joinCap, &d_cnt->nErr, s);
         else launch_pairs<256, 192, 96>(pairs, h.nPairs, R, vx, vy, area, threshold, state, joinPairs, &d_cnt->nJoin, joinCap, &d_cnt->nErr, s);
         SD_LAUNCH_CHECK();
+        if (stats) SD_CHECK(hipEventRecord(ev1, s));
         SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
         SD_CHECK(hipStreamSynchronize(s));
+        if (stats) { float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns_pairs += ms * 1e6; ++n_pair_launches; }
         if (h.nErr) { sd::set_error("sd_nms2d: %u pairs exceeded the scan-beam kernel's fixed capacities", h.nErr); return -1; }
         if (h.nJoin > 0) {
           if (h.nJoin > joinCap) { sd::set_error("sd_nms2d: join queue overflow"); return -1; }
           totalJoin += h.nJoin;
+          if (stats) SD_CHECK(hipEventRecord(ev0, s));
           if (sd::clip_full_pairs(joinPairs, h.nJoin, R, vx, vy, joinTwice, joinFlags, s)) return -1;
+          if (stats) { SD_CHECK(hipEventRecord(ev1, s)); SD_CHECK(hipEventSynchronize(ev1)); float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns_full += ms * 1e6; }
           hipLaunchKernelGGL(k_apply_full, dim3(sd::div_up(h.nJoin, 256)), dim3(256), 0, s, joinPairs, h.nJoin, joinTwice, area, threshold, state);
           SD_LAUNCH_CHECK();
         }
@@ -487,7 +501,8 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   hipLaunchKernelGGL(k_keep, dim3(sd::div_up(N, 256)), dim3(256), 0, s, state, d_keep, N);
   SD_LAUNCH_CHECK();
   SD_CHECK(hipStreamSynchronize(s));
-  if (stats) { stats[0] = totalPairs; stats[1] = totalJoin; stats[2] = rounds; stats[3] = totalNbr; }
+  if (stats) { stats[0] = totalPairs; stats[1] = totalJoin; stats[2] = rounds; stats[3] = totalNbr;
+               stats[4] = (int64_t)ns_pairs; stats[5] = n_pair_launches; stats[6] = (int64_t)ns_full; stats[7] = (int64_t)ns_pre; }
   if (verbose) {
     printf("NMS: %lld pair intersections (%lld on the exact-join path), %d greedy rounds, %lld neighbour entries\n",
            (long long)totalPairs, (long long)totalJoin, rounds, (long long)totalNbr);

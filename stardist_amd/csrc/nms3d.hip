@@ -600,7 +600,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   (void)d_scores;   // unused by the reference's arithmetic as well
   hipStream_t s = (hipStream_t)stream_;
   const int N = n_polys, R = n_rays, F = n_faces;
-  if (stats) memset(stats, 0, 8 * sizeof(int64_t));
+  if (stats) memset(stats, 0, 16 * sizeof(int64_t));
   if (verbose) {
     printf("Non Maximum Suppression (3D) ++++ \n");
     printf("NMS: n_polys  = %d \nNMS: n_rays   = %d  \nNMS: n_faces  = %d \nNMS: thresh   = %.3f \nNMS: use_bbox = %d \nNMS: use_kdtree = %d \n",
@@ -616,6 +616,10 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   if (lds3 > 150 * 1024 || lds5 > 150 * 1024 || lds4 > 150 * 1024) { sd::set_error("sd_nms3d: n_rays/n_faces too large for LDS staging"); return -1; }
   sd::Arena& A = sd::arena();
   if (A.begin(s)) return -1;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (stats) { SD_CHECK(hipEventCreate(&ev0)); SD_CHECK(hipEventCreate(&ev1)); }
+  struct EvGuard { hipEvent_t a, b; ~EvGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evguard{ev0, ev1};
+  double ns3 = 0, ns4 = 0, ns5 = 0;
   if (!use_kdtree && !use_bbox && threshold < 0) {   // every (0, j) passes and iou >= 0 > thr at stage 2
     SD_CHECK(hipMemsetAsync(d_keep, 0, N, s));
     SD_CHECK(hipMemsetAsync(d_keep, 1, 1, s));
@@ -750,24 +754,32 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
       if (h.nP3 > pairCap) { sd::set_error("sd_nms3d: pair queue overflow (internal error)"); return -1; }
       if (h.nP3 > 0) {
         const unsigned int b3 = h.nP3 < 16384u ? h.nP3 : 16384u;
+        if (stats) SD_CHECK(hipEventRecord(ev0, s));
         hipLaunchKernelGGL(k_stage3, dim3(b3), dim3(64), lds3, s, pairs3, h.nP3, d_dist, d_points, d_verts, d_faces, R, F, volume, threshold,
                            state, pairs4, &d_cnt->nP4, d_st);
         SD_LAUNCH_CHECK();
+        if (stats) SD_CHECK(hipEventRecord(ev1, s));
         SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
         SD_CHECK(hipStreamSynchronize(s));
+        if (stats) { float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns3 += ms * 1e6; }
         if (h.nP4 > 0) {
           const unsigned int b4 = h.nP4 < 16384u ? h.nP4 : 16384u;
+          if (stats) SD_CHECK(hipEventRecord(ev0, s));
           hipLaunchKernelGGL(k_stage4, dim3(b4), dim3(64), lds4, s, pairs4, h.nP4, d_dist, d_points, d_verts, R, volume, threshold, pairs5,
                              &d_cnt->nP5, d_st);
           SD_LAUNCH_CHECK();
+          if (stats) SD_CHECK(hipEventRecord(ev1, s));
           SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
           SD_CHECK(hipStreamSynchronize(s));
+          if (stats) { float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns4 += ms * 1e6; }
         }
         if (h.nP4 > 0 && h.nP5 > 0) {
           const unsigned int b5 = h.nP5 < 16384u ? h.nP5 : 16384u;
+          if (stats) SD_CHECK(hipEventRecord(ev0, s));
           hipLaunchKernelGGL(k_stage5, dim3(b5), dim3(256), lds5, s, pairs5, h.nP5, d_dist, d_points, d_verts, d_faces, R, F, bbox, volume,
                              threshold, state, d_st);
           SD_LAUNCH_CHECK();
+          if (stats) { SD_CHECK(hipEventRecord(ev1, s)); SD_CHECK(hipEventSynchronize(ev1)); float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns5 += ms * 1e6; }
         }
       }
     }
@@ -783,6 +795,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   if (stats) {
     stats[0] = (int64_t)hs_.upper; stats[1] = (int64_t)hs_.lower; stats[2] = (int64_t)hs_.kernel; stats[3] = (int64_t)hs_.render;
     stats[4] = rounds; stats[5] = totalNbr; stats[6] = (int64_t)hs_.sup_kernel; stats[7] = (int64_t)hs_.sup_render;
+    stats[8] = (int64_t)ns3; stats[9] = (int64_t)ns4; stats[10] = (int64_t)ns5; stats[11] = (int64_t)hs_.convex; stats[12] = (int64_t)hs_.kept_convex;
   }
   if (verbose) {
     printf("NMS: Function calls:\nNMS: ~ bbox+out: %8llu\nNMS: ~ inner:    %8llu\nNMS: ~ kernel:   %8llu\nNMS: ~ convex:   %8llu\nNMS: ~ render:   %8llu\n",

@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "..", "csrc", "libstardist_hip.so")
 
 _lib = None
+# statistics of the most recent native NMS call (see include/stardist_hip.h): {'nms2d': int64[16], 'nms3d': int64[16]}
+last_stats = {}
 
 _c_f32p = ctypes.POINTER(ctypes.c_float)
 _c_i32p = ctypes.POINTER(ctypes.c_int32)

@@ -12,7 +12,7 @@ from . import _native as N
 def c_non_max_suppression_inds(dist, points, use_kdtree, use_bbox, verbose, threshold, return_stats=False):
     """stardist2d.cpp:390-615. dist (n,R) f32, points (n,2) f32 sorted by score desc -> bool (n,)."""
     N.require_device()
-    stats = np.zeros(8, np.int64)
+    stats = np.zeros(16, np.int64)
     if N.is_torch(dist):
         import torch
         assert dist.dtype == torch.float32 and points.dtype == torch.float32
@@ -32,6 +32,7 @@ def c_non_max_suppression_inds(dist, points, use_kdtree, use_bbox, verbose, thre
         N.check(N.lib().sd_nms2d_host(N.ptr(dist), N.ptr(points), n, R, int(use_kdtree), int(use_bbox),
                                       int(verbose), float(threshold), N.ptr(keep), N.ptr(stats)))
         keep = keep.astype(bool)
+    N.last_stats["nms2d"] = stats
     return (keep, stats) if return_stats else keep
 
 

@@ -15,7 +15,7 @@ from . import _native as N
 def c_non_max_suppression_inds(dist, points, verts, faces, scores, use_bbox, use_kdtree, verbose, threshold, return_stats=False):
     """stardist3d.cpp:13-62 -> stardist3d_impl.cpp:956-1385. Inputs sorted by score descending. Returns bool (n,)."""
     N.require_device()
-    stats = np.zeros(8, np.int64)
+    stats = np.zeros(16, np.int64)
     if N.is_torch(dist):
         import torch
         dist = dist.contiguous().float(); points = points.contiguous().float()
@@ -27,6 +27,7 @@ def c_non_max_suppression_inds(dist, points, verts, faces, scores, use_bbox, use
                                             N.tptr(faces), float(threshold), int(use_bbox), int(use_kdtree), int(verbose),
                                             N.tptr(keep), N.ptr(stats), N.current_stream()))
         keep = keep.bool()
+        N.last_stats["nms3d"] = stats
         return (keep, stats) if return_stats else keep
     dist = np.ascontiguousarray(dist, np.float32); points = np.ascontiguousarray(points, np.float32)
     verts = np.ascontiguousarray(verts, np.float32); faces = np.ascontiguousarray(faces, np.int32)
