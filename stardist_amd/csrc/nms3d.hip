@@ -407,89 +407,136 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
 }
 
 // ------------------------------------------------------------------ stage 4: hull ∩ hull volume (:872-939)
-// hull facets of R points by exhaustive search: (a<b<c) is emitted iff every other point lies on one side of its
-// plane and (a,b,c) are the three lowest-indexed points on that plane (one plane per facet).
-__device__ int hull_planes(const float* __restrict__ pv, int R, double* __restrict__ out, int cap, int lane, int* s_n) {
-  if (lane == 0) *s_n = 0;
-  __builtin_amdgcn_wave_barrier();
-  double ext = 0;
-  for (int k = lane; k < R; k += 64) ext = fmax(ext, fmax(fabs((double)pv[3 * k] - pv[0]), fmax(fabs((double)pv[3 * k + 1] - pv[1]), fabs((double)pv[3 * k + 2] - pv[2]))));
-  for (int o = 32; o; o >>= 1) ext = fmax(ext, __shfl_xor(ext, o));
-  for (int a = 0; a < R - 2; ++a) {
-    const double az = pv[3 * a], ay = pv[3 * a + 1], ax = pv[3 * a + 2];
-    for (int b = a + 1; b < R - 1; ++b) {
-      const double ez = pv[3 * b] - az, ey = pv[3 * b + 1] - ay, ex = pv[3 * b + 2] - ax;
-      for (int c0 = b + 1; c0 < R; c0 += 64) {
-        const int c = c0 + lane;
-        bool ok = c < R;
-        double nz = 0, ny = 0, nx = 0;
-        int sign = 0;
-        if (ok) {
-          const double fz = pv[3 * c] - az, fy = pv[3 * c + 1] - ay, fx = pv[3 * c + 2] - ax;
-          nz = ey * fx - ex * fy; ny = ex * fz - ez * fx; nx = ez * fy - ey * fz;
-          const double nn = sqrt(nz * nz + ny * ny + nx * nx);
-          const double eps = 1e-10 * nn * (ext + 1e-30);
-          if (!(nn > 1e-12 * ext * ext)) ok = false;
-          for (int q = 0; q < R && ok; ++q) {
-            if (q == a || q == b || q == c) continue;
-            const double sdist = nz * (pv[3 * q] - az) + ny * (pv[3 * q + 1] - ay) + nx * (pv[3 * q + 2] - ax);
-            if (sdist > eps) { if (sign < 0) ok = false; sign = 1; }
-            else if (sdist < -eps) { if (sign > 0) ok = false; sign = -1; }
-            else if (q < c) ok = false;     // coplanar point with a lower index: not the canonical triple of this facet
-          }
+// Convex hull facets of the R vertices of one polyhedron by exhaustive search, computed ONCE per candidate that
+// reaches stage 4 and cached in HBM: (a<b<c) is a facet iff every other vertex lies on one side of its plane and
+// (a,b,c) are the three lowest-indexed vertices on that plane (one plane per facet).  One wave per polyhedron:
+// each lane owns a triple, rejects it against 8 extreme "probe" vertices, survivors are verified by the whole wave.
+__global__ void __launch_bounds__(64) k_hull(const int* __restrict__ hullList, unsigned int nList, const float* __restrict__ dist,
+                                             const float* __restrict__ pts, const float* __restrict__ verts, int R, int cap,
+                                             double* __restrict__ hullPlanes, int* __restrict__ hullCount) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* pv = (double*)smem;            // 3R doubles
+  __shared__ int s_probe[8];
+  __shared__ int s_n;
+  const int lane = threadIdx.x;
+  for (unsigned int it = blockIdx.x; it < nList; it += gridDim.x) {
+    const int cand = hullList[it];
+    __syncthreads();
+    const float* c1 = pts + 3 * (size_t)cand;
+    for (int k = lane; k < R; k += 64) {
+      const float d1 = dist[(size_t)cand * R + k];
+      pv[3 * k] = (double)(c1[0] + d1 * verts[3 * k]); pv[3 * k + 1] = (double)(c1[1] + d1 * verts[3 * k + 1]); pv[3 * k + 2] = (double)(c1[2] + d1 * verts[3 * k + 2]);
+    }
+    if (lane == 0) s_n = 0;
+    __syncthreads();
+    // probes: arg-extremes along 8 directions (all are hull vertices)
+    double ext = 0;
+    {
+      const double dirs[8][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}, {1, 1, 1}, {-1, -1, -1}};
+      for (int d = 0; d < 8; ++d) {
+        double best = -1e300; int bi = 0;
+        for (int k = lane; k < R; k += 64) {
+          const double v = dirs[d][0] * pv[3 * k] + dirs[d][1] * pv[3 * k + 1] + dirs[d][2] * pv[3 * k + 2];
+          if (v > best) { best = v; bi = k; }
         }
-        const unsigned long long m = __ballot(ok);
-        if (m) {
-          const int base = *s_n;
+        for (int o = 32; o; o >>= 1) {
+          const double ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+          if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) s_probe[d] = bi;
+      }
+      for (int k = lane; k < R; k += 64) ext = fmax(ext, fmax(fabs(pv[3 * k] - pv[0]), fmax(fabs(pv[3 * k + 1] - pv[1]), fabs(pv[3 * k + 2] - pv[2]))));
+      for (int o = 32; o; o >>= 1) ext = fmax(ext, __shfl_xor(ext, o));
+    }
+    __syncthreads();
+    double* out = hullPlanes + (size_t)cand * cap * 4;
+    for (int a = 0; a < R - 2; ++a) {
+      const double az = pv[3 * a], ay = pv[3 * a + 1], ax = pv[3 * a + 2];
+      for (int b = a + 1; b < R - 1; ++b) {
+        const double ez = pv[3 * b] - az, ey = pv[3 * b + 1] - ay, ex = pv[3 * b + 2] - ax;
+        for (int c0 = b + 1; c0 < R; c0 += 64) {
+          const int c = c0 + lane;
+          bool ok = c < R;
+          double nz = 0, ny = 0, nx = 0, eps = 0;
           if (ok) {
-            const int pos = base + __popcll(m & ((1ull << lane) - 1));
-            if (pos < cap) {
-              const double sg = (sign > 0) ? -1.0 : 1.0;     // outward normal: all points satisfy n.(p-a) <= 0
-              out[4 * pos] = sg * nz; out[4 * pos + 1] = sg * ny; out[4 * pos + 2] = sg * nx;
-              out[4 * pos + 3] = -(sg * nz * az + sg * ny * ay + sg * nx * ax);
+            const double fz = pv[3 * c] - az, fy = pv[3 * c + 1] - ay, fx = pv[3 * c + 2] - ax;
+            nz = ey * fx - ex * fy; ny = ex * fz - ez * fx; nx = ez * fy - ey * fz;
+            const double nn = sqrt(nz * nz + ny * ny + nx * nx);
+            eps = 1e-10 * nn * (ext + 1e-30);
+            if (!(nn > 1e-12 * ext * ext)) ok = false;
+            int sign = 0;
+            for (int d = 0; d < 8 && ok; ++d) {
+              const int q = s_probe[d];
+              const double sd_ = nz * (pv[3 * q] - az) + ny * (pv[3 * q + 1] - ay) + nx * (pv[3 * q + 2] - ax);
+              if (sd_ > eps) { if (sign < 0) ok = false; sign = 1; }
+              else if (sd_ < -eps) { if (sign > 0) ok = false; sign = -1; }
             }
           }
-          __builtin_amdgcn_wave_barrier();
-          if (lane == 0) *s_n = base + __popcll(m);
-          __builtin_amdgcn_wave_barrier();
+          unsigned long long m = __ballot(ok);
+          while (m) {                                   // verify each surviving triple with the whole wave
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int cc = c0 + src;
+            const double tz = __shfl(nz, src), ty = __shfl(ny, src), tx = __shfl(nx, src), te = __shfl(eps, src);
+            bool pos = false, neg = false, low = false;
+            for (int q = lane; q < R; q += 64) {
+              if (q == a || q == b || q == cc) continue;
+              const double sd_ = tz * (pv[3 * q] - az) + ty * (pv[3 * q + 1] - ay) + tx * (pv[3 * q + 2] - ax);
+              if (sd_ > te) pos = true; else if (sd_ < -te) neg = true; else if (q < cc) low = true;
+            }
+            const bool anyp = __any(pos), anyn = __any(neg), anyl = __any(low);
+            if (!(anyp && anyn) && !anyl && lane == 0) {
+              const int pos_i = s_n;
+              if (pos_i < cap) {
+                const double sg = anyp ? -1.0 : 1.0;   // outward normal: every vertex satisfies n.(p-a) <= 0
+                out[4 * pos_i] = sg * tz; out[4 * pos_i + 1] = sg * ty; out[4 * pos_i + 2] = sg * tx;
+                out[4 * pos_i + 3] = -(sg * tz * az + sg * ty * ay + sg * tx * ax);
+              }
+              s_n = pos_i + 1;
+            }
+          }
         }
       }
     }
+    __syncthreads();
+    if (lane == 0) hullCount[cand] = (s_n >= 4 && s_n <= cap) ? s_n : -2;   // -2: failed (Qhull error -> 1e10, :933-936)
   }
-  __builtin_amdgcn_wave_barrier();
-  return *s_n;
+}
+
+// hullState: 0 = not requested, 1 = requested/computed
+__global__ void k_hull_mark(const int2* __restrict__ pairs, unsigned int nPairs, int* __restrict__ hullState, int* __restrict__ hullList,
+                            unsigned int* hullListCount) {
+  const unsigned int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nPairs) return;
+  const int2 ij = pairs[p];
+  if (atomicExch(&hullState[ij.x], 1) == 0) hullList[atomicAdd(hullListCount, 1u)] = ij.x;
+  if (atomicExch(&hullState[ij.y], 1) == 0) hullList[atomicAdd(hullListCount, 1u)] = ij.y;
 }
 
 __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, unsigned int nPairs, const float* __restrict__ dist,
-                                               const float* __restrict__ pts, const float* __restrict__ verts, int R,
-                                               const float* __restrict__ volume, float thr, int2* __restrict__ pairs5,
-                                               unsigned int* pair5Count, Stats* st) {
+                                               const float* __restrict__ pts, int R, int cap, const double* __restrict__ hullPlanes,
+                                               const int* __restrict__ hullCount, const float* __restrict__ volume, float thr,
+                                               int2* __restrict__ pairs5, unsigned int* pair5Count, Stats* st) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int cap = 2 * R;                        // a hull of R points has at most 2R-4 facets
   double* hs = (double*)smem;                   // 2*cap*4
-  float* pv1 = (float*)(hs + 8 * cap);          // 3R
-  float* pv2 = pv1 + 3 * R;                     // 3R
-  __shared__ int s_n;
   const int lane = threadIdx.x;
   for (unsigned int p = blockIdx.x; p < nPairs; p += gridDim.x) {
     const int2 ij = pairs[p];
     __syncthreads();
     const float* c1 = pts + 3 * (size_t)ij.x;
     const float* c2 = pts + 3 * (size_t)ij.y;
-    for (int k = lane; k < R; k += 64) {
-      const float d1 = dist[(size_t)ij.x * R + k], d2 = dist[(size_t)ij.y * R + k];
-      pv1[3 * k] = c1[0] + d1 * verts[3 * k]; pv1[3 * k + 1] = c1[1] + d1 * verts[3 * k + 1]; pv1[3 * k + 2] = c1[2] + d1 * verts[3 * k + 2];
-      pv2[3 * k] = c2[0] + d2 * verts[3 * k]; pv2[3 * k + 1] = c2[1] + d2 * verts[3 * k + 1]; pv2[3 * k + 2] = c2[2] + d2 * verts[3 * k + 2];
+    const int n1 = hullCount[ij.x], n2 = hullCount[ij.y];
+    const bool failed = (n1 < 4 || n2 < 4);
+    const int M = failed ? 0 : n1 + n2;
+    if (!failed) {
+      const double* h1 = hullPlanes + (size_t)ij.x * cap * 4;
+      const double* h2 = hullPlanes + (size_t)ij.y * cap * 4;
+      for (int k = lane; k < 4 * n1; k += 64) hs[k] = h1[k];
+      for (int k = lane; k < 4 * n2; k += 64) hs[4 * n1 + k] = h2[k];
     }
     __syncthreads();
-    const int n1 = hull_planes(pv1, R, hs, cap, lane, &s_n);
-    __syncthreads();
-    const int n2 = hull_planes(pv2, R, hs + 4 * (n1 < cap ? n1 : cap), cap, lane, &s_n);
-    __syncthreads();
-    bool failed = (n1 < 4 || n2 < 4 || n1 > cap || n2 > cap);     // Qhull error -> 1e10 (:933-936)
-    const int M = failed ? 0 : n1 + n2;
     double c[3];
-    c[0] = .5 * ((double)c1[0] + (double)c2[0]); c[1] = .5 * ((double)c1[1] + (double)c2[1]); c[2] = .5 * ((double)c1[2] + (double)c2[2]);   // :890-921 (double)
+    c[0] = .5 * ((double)c1[0] + (double)c2[0]); c[1] = .5 * ((double)c1[1] + (double)c2[1]); c[2] = .5 * ((double)c1[2] + (double)c2[2]);   // :919-921
     bool infeasible = false;
     for (int k = lane; k < M; k += 64) {
       double dd = hs[4 * k + 3];
@@ -612,7 +659,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   if (R < 4 || F < 4) { sd::set_error("sd_nms3d: need n_rays >= 4 and n_faces >= 4"); return -1; }
   const size_t lds3 = (size_t)8 * F * sizeof(double) + (size_t)6 * R * sizeof(float);
   const size_t lds5 = (size_t)6 * R * sizeof(float) + (size_t)3 * F * sizeof(int);
-  const size_t lds4 = (size_t)16 * R * sizeof(double) + (size_t)6 * R * sizeof(float);
+  const size_t lds4 = (size_t)16 * R * sizeof(double);
   if (lds3 > 150 * 1024 || lds5 > 150 * 1024 || lds4 > 150 * 1024) { sd::set_error("sd_nms3d: n_rays/n_faces too large for LDS staging"); return -1; }
   sd::Arena& A = sd::arena();
   if (A.begin(s)) return -1;
@@ -727,10 +774,17 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   int2* pairs3 = A.take_n<int2>(pairCap);
   int2* pairs4 = A.take_n<int2>(pairCap);
   int2* pairs5 = A.take_n<int2>(pairCap);
-  struct Counters { int nU, nK; unsigned int nP3, nP4, nP5; };
+  struct Counters { int nU, nK; unsigned int nP3, nP4, nP5, nHull; };
   Counters* d_cnt = (Counters*)A.take(sizeof(Counters));
   Stats* d_st = (Stats*)A.take(sizeof(Stats));
   if (!U0 || !U1 || !Kl || !waitOn || !pairs3 || !pairs4 || !pairs5 || !d_cnt || !d_st) return -1;
+  const int hullCap = 2 * R;                       // a hull of R points has at most 2R-4 facets
+  int* hullState = A.take_n<int>(N);
+  int* hullCount = A.take_n<int>(N);
+  int* hullList = A.take_n<int>(N);
+  double* hullPlanes = nullptr;                    // N * hullCap * 4 doubles, allocated on first use
+  if (!hullState || !hullCount || !hullList) return -1;
+  SD_CHECK(hipMemsetAsync(hullState, 0, (size_t)N * sizeof(int), s));
   SD_CHECK(hipMemsetAsync(waitOn, 0xFF, (size_t)N * sizeof(int), s));
   SD_CHECK(hipMemsetAsync(d_st, 0, sizeof(Stats), s));
   hipLaunchKernelGGL(k_iota3, dim3(sd::div_up(N, 256)), dim3(256), 0, s, U0, N);
@@ -765,8 +819,19 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
         if (h.nP4 > 0) {
           const unsigned int b4 = h.nP4 < 16384u ? h.nP4 : 16384u;
           if (stats) SD_CHECK(hipEventRecord(ev0, s));
-          hipLaunchKernelGGL(k_stage4, dim3(b4), dim3(64), lds4, s, pairs4, h.nP4, d_dist, d_points, d_verts, R, volume, threshold, pairs5,
-                             &d_cnt->nP5, d_st);
+          if (!hullPlanes) { hullPlanes = A.take_n<double>((size_t)N * hullCap * 4); if (!hullPlanes) return -1; }
+          SD_CHECK(hipMemsetAsync(&d_cnt->nHull, 0, sizeof(unsigned int), s));
+          hipLaunchKernelGGL(k_hull_mark, dim3(sd::div_up(h.nP4, 256)), dim3(256), 0, s, pairs4, h.nP4, hullState, hullList, &d_cnt->nHull);
+          SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+          SD_CHECK(hipStreamSynchronize(s));
+          if (h.nHull > 0) {
+            const unsigned int bh = h.nHull < 32768u ? h.nHull : 32768u;
+            hipLaunchKernelGGL(k_hull, dim3(bh), dim3(64), (size_t)3 * R * sizeof(double), s, hullList, h.nHull, d_dist, d_points, d_verts, R, hullCap,
+                               hullPlanes, hullCount);
+            SD_LAUNCH_CHECK();
+          }
+          hipLaunchKernelGGL(k_stage4, dim3(b4), dim3(64), lds4, s, pairs4, h.nP4, d_dist, d_points, R, hullCap, hullPlanes, hullCount, volume,
+                             threshold, pairs5, &d_cnt->nP5, d_st);
           SD_LAUNCH_CHECK();
           if (stats) SD_CHECK(hipEventRecord(ev1, s));
           SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
