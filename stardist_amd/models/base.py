@@ -455,6 +455,14 @@ class StarDistBase(object):
         else:
             yield res_instances
 
+    def predict_instances_big(self, img, axes, block_size, min_overlap, context=None, labels_out=None, labels_out_dtype=np.int32,
+                              show_progress=True, **kwargs):
+        """Predict instances of very large inputs block by block (base.py:838-983).  When torch.distributed is
+        initialised the blocks are sharded round-robin over the ranks (one process per GPU); see stardist_amd/big.py."""
+        from ..big import predict_instances_big
+        return predict_instances_big(self, img, axes, block_size, min_overlap, context=context, labels_out=labels_out,
+                                     labels_out_dtype=labels_out_dtype, show_progress=show_progress, **kwargs)
+
     def predict_instances(self, *args, **kwargs):
         """Predict instance segmentation: returns (labels, dict) exactly like the reference (base.py:775-790)."""
         r = None

@@ -1,0 +1,112 @@
+"""CPU: block tiling (stardist_amd/big.py) against golden covers from the reference, the reference's own
+cover/filter/reassemble identity test (tests/test_big.py:50-76), and the multi-process (gloo, world_size 2) sharding."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_block_cover_matches_reference_golden():
+    from stardist_amd.big import Block
+    G = np.load(os.path.join(ROOT, "tests", "golden", "big_cover.npz"))
+    k = 0
+    while "case%d" % k in G:
+        size, bs, mo, ctx, grid = (int(v) for v in G["args%d" % k])
+        bl = Block.cover(size, bs, mo, ctx, grid, verbose=False)
+        rows = np.array([[t.start, t.end, t.slice_write.start, t.slice_write.stop, t.context_start, t.context_end, t._r_start] for t in bl])
+        assert np.array_equal(rows, G["case%d" % k]), k
+        k += 1
+    assert k == 10
+
+
+def _gt_labels(shape, seed=0, n=60, r=(3, 6)):
+    rng = np.random.RandomState(seed)
+    lbl = np.zeros(shape, np.int32)
+    grids = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+    k = 0
+    for _ in range(n):
+        c = [rng.uniform(r[1], s - r[1]) for s in shape]; rad = rng.uniform(*r)
+        m = sum((g - ci) ** 2 for g, ci in zip(grids, c)) <= rad * rad
+        if (lbl[m] == 0).all():
+            k += 1; lbl[m] = k
+    return lbl
+
+
+class _FakeModel(object):
+    """predict_instances = ground-truth labels of the block (as the reference's test_cover does with relabelling)"""
+    def __init__(self, ndim, grid):
+        from stardist_amd.models.config import Config2D, Config3D
+        self.config = Config2D() if ndim == 2 else Config3D()
+        self._grid = grid
+
+    def _axes_div_by(self, axes): return tuple(self._grid if a != "C" else 1 for a in axes)
+
+    def _axes_tile_overlap(self, axes): return tuple(0 for a in axes)
+
+    def predict_instances(self, x, **kwargs):
+        from scipy import ndimage as ndi
+        from stardist_amd.matching import relabel_sequential
+        lab = relabel_sequential(np.asarray(x).astype(np.int32))[0]
+        objs = ndi.find_objects(lab)
+        pts = np.array([[0.5 * (s.start + s.stop) for s in o] for o in objs]).reshape(len(objs), x.ndim)
+        return lab, dict(points=pts, prob=np.ones(len(objs)), coord=np.zeros((len(objs), x.ndim, 4)) + pts[:, :, None])
+
+
+@pytest.mark.parametrize("shape,axes,block,overlap,ctx,grid", [((160, 200), "YX", 64, 16, 8, 1), ((150, 131), "YX", (48, 64), 16, (4, 8), 2),
+                                                                 ((40, 80, 72), "ZYX", (32, 40, 40), 12, 2, 1)])
+def test_cover_filter_reassemble_is_identity(shape, axes, block, overlap, ctx, grid):
+    from stardist_amd.big import predict_instances_big
+    from stardist_amd.matching import relabel_sequential
+    gt = _gt_labels(shape, n=80 if len(shape) == 2 else 40)
+    model = _FakeModel(len(shape), grid)
+    labels, polys = predict_instances_big(model, gt, axes, block, overlap, context=ctx, show_progress=False)
+    assert len(polys["prob"]) == gt.max() == labels.max()
+    # same partition into objects (ids may be permuted by block order)
+    assert np.array_equal(labels > 0, gt > 0)
+    pairs = np.unique(np.stack([labels[gt > 0], gt[gt > 0]], 1), axis=0)
+    assert len(pairs) == gt.max()
+    # global coordinates: every reported centre lies inside its object
+    for p in polys["points"]:
+        assert gt[tuple(int(v) for v in p)] > 0
+
+
+def test_object_larger_than_overlap_raises():
+    from stardist_amd.big import predict_instances_big
+    gt = np.zeros((128, 128), np.int32); gt[10:100, 10:100] = 1
+    with pytest.raises(RuntimeError):
+        predict_instances_big(_FakeModel(2, 1), gt, "YX", 64, 16, context=4, show_progress=False)
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stardist_amd.big import predict_instances_big
+    from test_cpu_big import _FakeModel, _gt_labels
+    gt = _gt_labels((160, 200), n=80)
+    labels, polys = predict_instances_big(_FakeModel(2, 1), gt, "YX", 64, 16, context=8, show_progress=False)
+    q.put((rank, labels, polys["points"], polys["prob"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_equals_sequential_gloo_world2():
+    """N>1 path: blocks dealt round-robin to 2 ranks; result identical to the single-process loop on every rank"""
+    import torch.multiprocessing as mp
+    from stardist_amd.big import predict_instances_big
+    gt = _gt_labels((160, 200), n=80)
+    ref_labels, ref_polys = predict_instances_big(_FakeModel(2, 1), gt, "YX", 64, 16, context=8, show_progress=False)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs: p.join(60)
+    for rank, labels, pts, prob in res:
+        assert np.array_equal(labels, ref_labels), rank
+        assert np.array_equal(pts, ref_polys["points"]) and len(prob) == len(ref_polys["prob"])
