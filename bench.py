@@ -16,7 +16,7 @@ scaling: independent tiles, no data-path collective); value = all ranks' pixels 
 Weights are seeded random (no checkpoints offline).  The two 1x1 heads are re-scaled once, before
 timing, so that the network's own outputs have the candidate statistics of the reference's NMS
 workloads (2D: tests/test_nms2D.py:9-15, ~10 % of pixels above threshold, radius 10 +- 10 %;
-3D: SURVEY.md 8d S3D-nuclei, ~0.9 % of voxels, radius ~8.5); otherwise a random net yields either
+3D: SURVEY.md 8d S3D-nuclei, ~0.9 % of voxels, radius 8.5 +- 3 %); otherwise a random net yields either
 no or millions of candidates and the NMS / raster stages would be meaningless.  Nothing is skipped
 in the timed region.
 """
@@ -266,7 +266,7 @@ def main():
         vol = torch.from_numpy(vol_np).to(dev)
         m3 = StarDist3D(Config3D(rays=96), basedir=None, device=dev, seed=0, compute_dtype=args.dtype)
         m3.thresholds = dict(prob=0.5, nms=0.3)
-        calibrate_heads(m3, vol, frac=0.009, radius=8.5, noise=0.15)
+        calibrate_heads(m3, vol, frac=0.009, radius=8.5, noise=0.03)   # near-spherical objects
         macs3 = conv_macs_per_input_pixel(m3.net, m3.config)
         steps3 = max(1, min(args.steps, 3))
         elapsed3, net3_ms, res3, st3 = run_leg(m3, vol, steps3, 1, world, dist_)

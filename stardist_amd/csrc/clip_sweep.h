@@ -39,12 +39,19 @@
 #pragma once
 #include <stdint.h>
 
+// SD_HD : small helpers, always inlined.  SD_HDN: the large building blocks of the sweep are compiled ONCE per kernel
+// (real calls): fully inlined the pair kernel is > 230 KB of code and thrashes the 64 KB instruction cache that two
+// CUs share, which -- not memory latency -- dominated the per-pair latency (rocprof + code-size analysis).
 #if defined(__HIPCC__)
 #define SD_HD __host__ __device__ __forceinline__
+#if defined(SD_SWEEP_INLINE)
+#define SD_HDN __host__ __device__ __forceinline__
+#else
 #define SD_HDN __host__ __device__ __noinline__
+#endif
 #else
 #define SD_HD inline
-#define SD_HDN
+#define SD_HDN inline
 #endif
 
 namespace sdclip {
@@ -114,7 +121,7 @@ struct StdSort {
   }
   static SD_HD int lg(int n) { int k = 0; while (n > 1) { n >>= 1; ++k; } return k; }
   // returns false if the depth limit was hit (heap-sort fallback not restated)
-  static SD_HD bool sort(T* a, int n) {
+  static SD_HDN bool sort(T* a, int n) {
     if (n <= 1) return true;
     bool ok = true;
     if (n > 16) {
@@ -144,6 +151,60 @@ struct StdSort {
   }
 };
 
+
+// ---------------------------------------------------------------------------------------------
+// Storage policies.  The sweep's per-pair state lives in small index arrays; WHERE they live decides the
+// latency of the (inherently serial) sweep:
+//   PlainStorage  : ordinary member arrays -> GPU private (scratch) memory; unlimited threads, ~L2 latency
+//   LdsStorage<S> : arrays interleaved across the S threads of a workgroup in LDS (element i of thread t at
+//                   base[i*S + t], conflict-free), edge slopes recomputed instead of stored; few threads
+//                   per CU but ~5x lower latency per dependent access -- used for the small, latency-bound
+//                   rounds of the greedy NMS scan.
+struct PlainStorage {
+  typedef short idx_t;
+  template <class T, int N> struct Arr {
+    T v[N];
+    SD_HD T& operator[](int i) { return v[i]; }
+    SD_HD const T& operator[](int i) const { return v[i]; }
+  };
+  template <int N> struct DxArr : Arr<double, N> {
+    template <class A> SD_HD void attach(const A*, const A*, const A*, const A*) {}
+  };
+  struct Cursor { template <class A> SD_HD void take(A&) {} };
+};
+
+template <int STRIDE>
+struct LdsStorage {
+  typedef signed char idx_t;
+  template <class T, int N> struct Arr {
+    T* b;
+    SD_HD T& operator[](int i) const { return b[i * STRIDE]; }
+  };
+  template <int N> struct DxArr {     // slope = f(bot, top): recomputed (clipper.cpp:591-596), never stored
+    const Arr<int, N>*bx, *by, *tx, *ty;
+    struct Ref {
+      const DxArr* a; int e;
+      SD_HD operator double() const {
+        const long long dy = (long long)(*a->ty)[e] - (*a->by)[e];
+        if (dy == 0) return SD_HORIZONTAL;
+        return (double)((long long)(*a->tx)[e] - (*a->bx)[e]) / (double)dy;
+      }
+      SD_HD void operator=(double) const {}
+    };
+    SD_HD Ref operator[](int e) const { Ref r; r.a = this; r.e = e; return r; }
+    SD_HD void attach(const Arr<int, N>* bx_, const Arr<int, N>* by_, const Arr<int, N>* tx_, const Arr<int, N>* ty_) { bx = bx_; by = by_; tx = tx_; ty = ty_; }
+  };
+  struct Cursor {                     // carves per-array regions out of the workgroup's LDS block
+    char* base; int tid; unsigned off;
+    template <class T, int N> SD_HD void take(Arr<T, N>& a) {
+      off = (off + 15u) & ~15u;
+      a.b = (T*)(base + off) + tid;
+      off += (unsigned)(N * STRIDE * sizeof(T));
+    }
+    template <int N> SD_HD void take(DxArr<N>&) {}
+  };
+};
+
 struct LocMin { int y; short left, right; };
 struct INode { int y; int x; short e1, e2; };
 
@@ -155,20 +216,28 @@ struct INode { int y; int x; short e1, e2; };
 //   void out_add_join(op1, op2, x, y) AddJoin :1942-1949
 //   int  out_last_pt(e), out_pt_x(op) GetLastOutPt :2502-2509
 // MAXV: max vertices per input polygon; MAXIL: intersection-node capacity per scan-beam.
-template <class D, int MAXV, int MAXIL>
+template <class D, class P, int MAXV, int MAXIL>
 struct SweepCore {
   enum { NE = 2 * MAXV };
   SD_HD D& self() { return *static_cast<D*>(this); }
   // ---- edges (index = vertex slot; polygon A uses [0,MAXV), polygon B [MAXV,2*MAXV))
-  int botx[NE], boty[NE], topx[NE], topy[NE], curx[NE], cury[NE];
-  double dx[NE];
-  short nxt[NE], prv[NE], lml[NE], anext[NE], aprev[NE], snext[NE], sprev[NE];
-  short wcnt[NE], wcnt2[NE], outidx[NE];
-  signed char ptyp[NE], side[NE], wdelta[NE];
+  typedef typename P::idx_t idx_t;
+  typename P::template Arr<int, NE> botx, boty, topx, topy, curx, cury;
+  typename P::template DxArr<NE> dx;
+  typename P::template Arr<idx_t, NE> nxt, prv, lml, anext, aprev, snext, sprev;
+  typename P::template Arr<short, NE> wcnt, wcnt2;
+  typename P::template Arr<idx_t, NE> outidx;
+  typename P::template Arr<signed char, NE> ptyp, side, wdelta;
+  SD_HD void bind_core(typename P::Cursor& c) {
+    c.take(botx); c.take(boty); c.take(topx); c.take(topy); c.take(curx); c.take(cury); c.take(dx);
+    c.take(nxt); c.take(prv); c.take(lml); c.take(anext); c.take(aprev); c.take(snext); c.take(sprev);
+    c.take(wcnt); c.take(wcnt2); c.take(outidx); c.take(ptyp); c.take(side); c.take(wdelta); c.take(sb);
+    dx.attach(&botx, &boty, &topx, &topy);
+  }
   // ---- local minima, scan-beam, intersections
   LocMin lm[NE];
   int n_lm, cur_lm;
-  int sb[NE + 4];
+  typename P::template Arr<int, NE + 4> sb;
   int n_sb;
   INode il[MAXIL];
   int n_il;
@@ -243,7 +312,7 @@ struct SweepCore {
     return E;
   }
 
-  SD_HD int process_bound(int E, bool fwd) {                                // :928-1042 (no skip edges)
+  SD_HDN int process_bound(int E, bool fwd) {                                // :928-1042 (no skip edges)
     int Result = E, Horz;
     if (is_horz(E)) {
       int EStart = fwd ? prv[E] : nxt[E];
@@ -286,7 +355,7 @@ struct SweepCore {
 
   // xs/ys: n integer vertices. base: first edge slot. Returns false if the path is rejected.
   template <typename XT>
-  SD_HD bool add_path(const XT* xs, const XT* ys, int n, int polytype, int base) {
+  SD_HDN bool add_path(const XT* xs, const XT* ys, int n, int polytype, int base) {
     int highI = n - 1;
     while (highI > 0 && xs[highI] == xs[0] && ys[highI] == ys[0]) --highI;
     while (highI > 0 && xs[highI] == xs[highI - 1] && ys[highI] == ys[highI - 1]) --highI;
@@ -360,7 +429,7 @@ struct SweepCore {
 
   // ------------------------------------------------------------------ output (delegated to D)
   SD_HD int add_out_pt(int e, int px, int py) { return self().out_add_pt(e, px, py); }
-  SD_HD void add_local_max_poly(int e1, int e2, int px, int py) {           // :1884-1897
+  SD_HDN void add_local_max_poly(int e1, int e2, int px, int py) {           // :1884-1897
     add_out_pt(e1, px, py);
     if (outidx[e1] == outidx[e2]) {
       if (outidx[e1] >= 0) self().out_ring_closed(outidx[e1]);
@@ -368,7 +437,7 @@ struct SweepCore {
     } else if (outidx[e1] < outidx[e2]) self().out_append(e1, e2);
     else self().out_append(e2, e1);
   }
-  SD_HD int add_local_min_poly(int e1, int e2, int px, int py) {            // :1841-1881
+  SD_HDN int add_local_min_poly(int e1, int e2, int px, int py) {            // :1841-1881
     int e, prevE, result;
     if (is_horz(e2) || dx[e1] > dx[e2]) {
       result = add_out_pt(e1, px, py);
@@ -401,7 +470,7 @@ struct SweepCore {
       else return (i64)topx[e1] > top_x(e2, topy[e1]);
     } else return curx[e2] < curx[e1];
   }
-  SD_HD void insert_edge_into_ael(int edge, int startEdge) {                // :3319-3345
+  SD_HDN void insert_edge_into_ael(int edge, int startEdge) {                // :3319-3345
     if (ael < 0) { aprev[edge] = -1; anext[edge] = -1; ael = (short)edge; }
     else if (startEdge < 0 && e2_inserts_before_e1(ael, edge)) {
       aprev[edge] = -1; anext[edge] = ael; aprev[ael] = (short)edge; ael = (short)edge;
@@ -421,7 +490,7 @@ struct SweepCore {
     if (n >= 0) aprev[n] = (short)p;
     anext[e] = -1; aprev[e] = -1;
   }
-  SD_HD void swap_positions_in_ael(int e1, int e2) {                        // :1395-1439
+  SD_HDN void swap_positions_in_ael(int e1, int e2) {                        // :1395-1439
     if (anext[e1] == aprev[e1] || anext[e2] == aprev[e2]) return;
     if (anext[e1] == e2) {
       int n = anext[e2]; if (n >= 0) aprev[n] = (short)e1;
@@ -440,7 +509,7 @@ struct SweepCore {
     }
     if (aprev[e1] < 0) ael = (short)e1; else if (aprev[e2] < 0) ael = (short)e2;
   }
-  SD_HD void swap_positions_in_sel(int e1, int e2) {                        // :2558-2601
+  SD_HDN void swap_positions_in_sel(int e1, int e2) {                        // :2558-2601
     if (snext[e1] < 0 && sprev[e1] < 0) return;
     if (snext[e2] < 0 && sprev[e2] < 0) return;
     if (snext[e1] == e2) {
@@ -472,7 +541,7 @@ struct SweepCore {
     snext[e] = -1; sprev[e] = -1;
   }
   // UpdateEdgeIntoAEL :1442-1462 ; returns the new edge
-  SD_HD int update_edge_into_ael(int e) {
+  SD_HDN int update_edge_into_ael(int e) {
     int n = lml[e];
     if (n < 0) { status |= ST_FAIL; return e; }
     outidx[n] = outidx[e];
@@ -487,7 +556,7 @@ struct SweepCore {
   }
 
   // ------------------------------------------------------------------ winding  (NonZero both, ctIntersection)
-  SD_HD void set_winding_count(int edge) {                                  // :1624-1722
+  SD_HDN void set_winding_count(int edge) {                                  // :1624-1722
     int e = aprev[edge];
     while (e >= 0 && (ptyp[e] != ptyp[edge] || wdelta[e] == 0)) e = aprev[e];
     if (e < 0) {
@@ -518,7 +587,7 @@ struct SweepCore {
   }
 
   // ------------------------------------------------------------------ IntersectEdges  :2106-2298
-  SD_HD void intersect_edges(int e1, int e2, int px, int py) {
+  SD_HDN void intersect_edges(int e1, int e2, int px, int py) {
     bool c1 = outidx[e1] >= 0, c2 = outidx[e2] >= 0;
     if (ptyp[e1] == ptyp[e2]) {
       if (wcnt[e1] + wdelta[e2] == 0) wcnt[e1] = (short)-wcnt[e1]; else wcnt[e1] = (short)(wcnt[e1] + wdelta[e2]);
@@ -561,7 +630,7 @@ struct SweepCore {
   }
 
   // ------------------------------------------------------------------ InsertLocalMinimaIntoAEL  :1978-2077
-  SD_HD void insert_local_minima_into_ael(int botY) {
+  SD_HDN void insert_local_minima_into_ael(int botY) {
     while (cur_lm < n_lm && lm[cur_lm].y == botY) {
       int lb = lm[cur_lm].left, rb = lm[cur_lm].right;
       ++cur_lm;
@@ -619,7 +688,7 @@ struct SweepCore {
     if (r >= 0 && (anext[r] == aprev[r] && !is_horz(r))) return -1;
     return r;
   }
-  SD_HD void process_horizontal(int horz) {
+  SD_HDN void process_horizontal(int horz) {
     bool l2r; i64 hl, hr;
     if (botx[horz] < topx[horz]) { hl = botx[horz]; hr = topx[horz]; l2r = true; }
     else { hl = topx[horz]; hr = botx[horz]; l2r = false; }
@@ -696,7 +765,7 @@ struct SweepCore {
   }
 
   // ------------------------------------------------------------------ intersections  :2827-2954, 622-689
-  SD_HD void intersect_point(int e1, int e2, i64& ipx, i64& ipy) const {
+  SD_HDN void intersect_point(int e1, int e2, i64& ipx, i64& ipy) const {
     double b1, b2;
     if (dx[e1] == dx[e2]) { ipy = cury[e1]; ipx = top_x(e1, ipy); return; }
     else if (dx[e1] == 0) {
@@ -727,7 +796,7 @@ struct SweepCore {
       if (a1 > a2) ipx = top_x(e2, ipy); else ipx = top_x(e1, ipy);
     }
   }
-  SD_HD void build_intersect_list(int topY) {
+  SD_HDN void build_intersect_list(int topY) {
     if (ael < 0) return;
     int e = ael;
     sel = (short)e;
@@ -759,7 +828,7 @@ struct SweepCore {
     sel = -1;
   }
   SD_HD bool edges_adjacent(const INode& n) const { return snext[n.e1] == n.e2 || sprev[n.e1] == n.e2; }
-  SD_HD bool fixup_intersection_order() {
+  SD_HDN bool fixup_intersection_order() {
     // CopyAELToSEL :1929-1939
     int e = ael; sel = (short)e;
     while (e >= 0) { sprev[e] = aprev[e]; snext[e] = anext[e]; e = anext[e]; }
@@ -792,7 +861,7 @@ struct SweepCore {
   }
 
   // ------------------------------------------------------------------ top of scan-beam  :2957-3113
-  SD_HD void do_maxima(int e) {
+  SD_HDN void do_maxima(int e) {
     int eMaxPair = get_maxima_pair_ex(e);
     if (eMaxPair < 0) {
       if (outidx[e] >= 0) add_out_pt(e, topx[e], topy[e]);
@@ -814,7 +883,7 @@ struct SweepCore {
       delete_from_ael(e); delete_from_ael(eMaxPair);
     } else status |= ST_FAIL;   // "DoMaxima error" -> Execute fails, empty solution
   }
-  SD_HD void process_edges_at_top_of_scanbeam(int topY) {
+  SD_HDN void process_edges_at_top_of_scanbeam(int topY) {
     int e = ael;
     int guard = 0;
     while (e >= 0) {
@@ -876,7 +945,7 @@ struct SweepCore {
   }
   // Runs the sweep (Clipper::ExecuteInternal up to the end of the scan-beam loop). Returns false if
   // Clipper's Execute would fail (empty solution).
-  SD_HD bool run_sweep() {
+  SD_HDN bool run_sweep() {
     if (n_lm == 0) return true;
     if (!StdSort<LocMin>::sort(lm, n_lm)) status |= ST_SORT_DEPTH;
     for (int i = 0; i < n_lm; ++i) {
@@ -911,17 +980,18 @@ struct SweepCore {
 // Sweep: the fast variant.  Output rings are kept as {front point, back point, running shoelace
 // sum}; exact whenever the reference records no joins for the pair (n_joins == 0).
 // MAXREC: output-ring capacity.
-template <int MAXV, int MAXIL, int MAXREC>
-struct Sweep : SweepCore<Sweep<MAXV, MAXIL, MAXREC>, MAXV, MAXIL> {
-  typedef SweepCore<Sweep<MAXV, MAXIL, MAXREC>, MAXV, MAXIL> B;
+template <int MAXV, int MAXIL, int MAXREC, class P = PlainStorage>
+struct Sweep : SweepCore<Sweep<MAXV, MAXIL, MAXREC, P>, P, MAXV, MAXIL> {
+  typedef SweepCore<Sweep<MAXV, MAXIL, MAXREC, P>, P, MAXV, MAXIL> B;
   using B::outidx; using B::side; using B::status; using B::ael; using B::anext;
-  int rfx[MAXREC], rfy[MAXREC], rlx[MAXREC], rly[MAXREC];
-  i64 rsum[MAXREC];
+  typename P::template Arr<int, MAXREC> rfx, rfy, rlx, rly;
+  typename P::template Arr<i64, MAXREC> rsum;
+  SD_HD void bind(typename P::Cursor& c) { B::bind_core(c); c.take(rfx); c.take(rfy); c.take(rlx); c.take(rly); c.take(rsum); }
   int n_rec;
   i64 twice_area;            // sum over closed rings of |2*area|
   i64 sum_abs_terms;         // sum of |cross| terms (exactness bound for the float path)
   SD_HD void term(i64 c) { sum_abs_terms += sd_abs64(c); }
-  SD_HD int out_add_pt(int e, int px, int py) {                             // :2463-2499
+  SD_HDN int out_add_pt(int e, int px, int py) {                             // :2463-2499
     int r = outidx[e];
     if (r < 0) {
       if (n_rec >= MAXREC) { status |= ST_OVERFLOW_REC; return -1; }
@@ -945,7 +1015,7 @@ struct Sweep : SweepCore<Sweep<MAXV, MAXIL, MAXREC>, MAXV, MAXIL> {
     i64 c = sd_cross(rlx[r], rly[r], rfx[r], rfy[r]); term(c);
     twice_area += sd_abs64(rsum[r] + c);
   }
-  SD_HD void out_append(int e1, int e2) {                                   // :2367-2460
+  SD_HDN void out_append(int e1, int e2) {                                   // :2367-2460
     int r1 = outidx[e1], r2 = outidx[e2];
     i64 c;
     if (side[e1] == kLeft) {

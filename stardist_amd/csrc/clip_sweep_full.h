@@ -16,9 +16,10 @@
 
 namespace sdclip {
 
-template <int MAXV, int MAXIL, int MAXREC, int MAXPT, int MAXJ>
-struct SweepFull : SweepCore<SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ>, MAXV, MAXIL> {
-  typedef SweepCore<SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ>, MAXV, MAXIL> B;
+template <int MAXV, int MAXIL, int MAXREC, int MAXPT, int MAXJ, class P = PlainStorage>
+struct SweepFull : SweepCore<SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ, P>, P, MAXV, MAXIL> {
+  typedef SweepCore<SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ, P>, P, MAXV, MAXIL> B;
+  SD_HD void bind(typename P::Cursor& c) { B::bind_core(c); }   // only the core arrays follow the policy; rings stay private
   using B::outidx; using B::side; using B::status; using B::ael; using B::anext; using B::aprev; using B::wdelta;
   // ---- output points (rings)
   int px[MAXPT], py[MAXPT];
@@ -94,7 +95,7 @@ struct SweepFull : SweepCore<SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ>, MAXV, 
   }
 
   // ------------------------------------------------------------------ AddOutPt   :2463-2499
-  SD_HD int out_add_pt(int e, int x, int y) {
+  SD_HDN int out_add_pt(int e, int x, int y) {
     if (outidx[e] < 0) {
       const int r = create_outrec();
       const int op = alloc_pt(x, y, r);
@@ -123,7 +124,7 @@ struct SweepFull : SweepCore<SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ>, MAXV, 
   }
 
   // ------------------------------------------------------------------ bottom point   :798-857
-  SD_HD bool first_is_bottom_pt(int b1, int b2) const {
+  SD_HDN bool first_is_bottom_pt(int b1, int b2) const {
     int p = pp[b1];
     while (pt_eq(p, b1) && p != b1) p = pp[p];
     const double dx1p = dabs(get_dx(px[b1], py[b1], px[p], py[p]));
@@ -142,7 +143,7 @@ struct SweepFull : SweepCore<SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ>, MAXV, 
     if (mx1 == mx2 && mn1 == mn2) return ring_area(b1) > 0;
     else return (dx1p >= dx2p && dx1p >= dx2n) || (dx1n >= dx2p && dx1n >= dx2n);
   }
-  SD_HD int get_bottom_pt(int ppt) {
+  SD_HDN int get_bottom_pt(int ppt) {
     int dups = -1;
     int p = pn[ppt];
     int guard = 0;
@@ -195,7 +196,7 @@ struct SweepFull : SweepCore<SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ>, MAXV, 
   }
 
   // ------------------------------------------------------------------ AppendPolygon   :2367-2460
-  SD_HD void out_append(int e1, int e2) {
+  SD_HDN void out_append(int e1, int e2) {
     const int r1 = outidx[e1], r2 = outidx[e2];
     int holeStateRec;
     if (rec1_right_of_rec2(r1, r2)) holeStateRec = r2;
@@ -239,7 +240,7 @@ struct SweepFull : SweepCore<SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ>, MAXV, 
   }
 
   // ------------------------------------------------------------------ joins   :3348-3783
-  SD_HD int dup_out_pt(int o, bool insertAfter) {                            // :3348-3368
+  SD_HDN int dup_out_pt(int o, bool insertAfter) {                            // :3348-3368
     const int r = alloc_pt(px[o], py[o], pidx[o]);
     if (insertAfter) { pn[r] = pn[o]; pp[r] = (short)o; pp[pn[o]] = (short)r; pn[o] = (short)r; }
     else { pp[r] = pp[o]; pn[r] = (short)o; pn[pp[o]] = (short)r; pp[o] = (short)r; }
@@ -255,7 +256,7 @@ struct SweepFull : SweepCore<SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ>, MAXV, 
     }
     return L < R;
   }
-  SD_HD bool join_horz(int op1, int op1b, int op2, int op2b, int ptx, int pty, bool discardLeft) {   // :3371-3456
+  SD_HDN bool join_horz(int op1, int op1b, int op2, int op2b, int ptx, int pty, bool discardLeft) {   // :3371-3456
     const bool d1_l2r = !(px[op1] > px[op1b]);
     const bool d2_l2r = !(px[op2] > px[op2b]);
     if (d1_l2r == d2_l2r) return false;
@@ -293,7 +294,7 @@ struct SweepFull : SweepCore<SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ>, MAXV, 
   SD_HD bool slopes_eq_pts(int a, int b, int offx, int offy) const {         // SlopesEqual(pt1, pt2, pt3) :554-563
     return ((i64)py[a] - py[b]) * ((i64)px[b] - offx) == ((i64)px[a] - px[b]) * ((i64)py[b] - offy);
   }
-  SD_HD bool join_points(int j, int outRec1, int outRec2) {                  // :3458-3615
+  SD_HDN bool join_points(int j, int outRec1, int outRec2) {                  // :3458-3615
     int op1 = j1[j], op1b;
     int op2 = j2[j], op2b;
     const int offx = jx[j], offy = jy[j];
@@ -366,7 +367,7 @@ struct SweepFull : SweepCore<SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ>, MAXV, 
       return true;
     }
   }
-  SD_HD int point_in_polygon(int ptx_, int pty_, int op) const {             // PointInPolygon(pt, OutPt*) :484-523
+  SD_HDN int point_in_polygon(int ptx_, int pty_, int op) const {             // PointInPolygon(pt, OutPt*) :484-523
     const i64 X = ptx_, Y = pty_;
     int result = 0;
     const int startOp = op;
@@ -412,7 +413,7 @@ struct SweepFull : SweepCore<SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ>, MAXV, 
     int op = r_pts[r], guard = 0;
     do { pidx[op] = r_idx[r]; op = pp[op]; if (++guard > MAXPT) break; } while (op != r_pts[r]);
   }
-  SD_HD void join_common_edges() {                                           // :3679-3783
+  SD_HDN void join_common_edges() {                                           // :3679-3783
     for (int i = 0; i < n_j; ++i) {
       int outRec1 = get_outrec(pidx[j1[i]]);
       int outRec2 = get_outrec(pidx[j2[i]]);
@@ -453,7 +454,7 @@ struct SweepFull : SweepCore<SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ>, MAXV, 
   }
 
   // ------------------------------------------------------------------ Execute   :1560-1621 + stardist2d.cpp:161-164
-  SD_HD i64 execute() {
+  SD_HDN i64 execute() {
     if (!B::run_sweep()) return 0;
     for (int i = 0; i < n_rec; ++i) {                                        // fix orientations :1594-1600
       if (r_pts[i] < 0) continue;

@@ -26,6 +26,7 @@
 #include "../../include/stardist_hip.h"
 #include <hipcub/hipcub.hpp>
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
 
 namespace {
@@ -216,8 +217,9 @@ __global__ void __launch_bounds__(256) k_round_decide(const int* __restrict__ U,
 __global__ void __launch_bounds__(256) k_round_emit(const int* __restrict__ K, int nK, unsigned char* __restrict__ state,
                                                     const i64* __restrict__ nbrStart, const int* __restrict__ nbr, Flags f,
                                                     const float* __restrict__ pts, const int4* __restrict__ bbox,
-                                                    const float* __restrict__ radius, int2* __restrict__ pairs,
-                                                    unsigned long long* pairCount, unsigned long long pairCap) {
+                                                    const float* __restrict__ radius, const float* __restrict__ area,
+                                                    int2* __restrict__ pairs, unsigned long long* pairCount,
+                                                    unsigned long long pairCap) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int w = blockIdx.x * (blockDim.x >> 6) + wave;
   if (w >= nK) return;
@@ -241,7 +243,18 @@ __global__ void __launch_bounds__(256) k_round_emit(const int* __restrict__ K, i
           float d2 = d0 * d0; d2 += d1 * d1;
           ok = d2 < rad2;
         }
-        if (ok && (f.use_bbox || f.thr_nonneg)) ok = bbox_intersect(bi, bbox[j]);   // :576
+        if (ok && (f.use_bbox || f.thr_nonneg)) {
+          const int4 bj = bbox[j];
+          ok = bbox_intersect(bi, bj);                                               // :576
+          if (ok && f.thr_nonneg) {
+            // rigorous upper bound: Clipper's output (input vertices + lattice-rounded crossings) stays inside the
+            // intersection of the two integer bounding boxes, so area_inter <= w*h; if even that cannot exceed
+            // the threshold the reference's  overlap > thr  (:580-581) is false without running the sweep.
+            const double w = (double)(min(bi.y, bj.y) - max(bi.x, bj.x)), hgt = (double)(min(bi.w, bj.w) - max(bi.z, bj.z));
+            const float ub = (float)((w * hgt) / fmin((double)area[i] + 1.e-10, (double)area[j] + 1.e-10));   // monotone in the area
+            if (!(ub > f.thr)) ok = false;
+          }
+        }
         emit = ok;
       }
     }
@@ -283,6 +296,46 @@ __global__ void __launch_bounds__(64) k_pairs(const int2* __restrict__ pairs, un
   const float area_inter = 0.5f * (float)twice;
   const float overlap = (float)((double)area_inter / fmin((double)area[ij.x] + 1.e-10, (double)area[ij.y] + 1.e-10));  // :580
   if (overlap > thr) state[ij.y] = ST_SUPPRESSED;                                           // :581-585
+}
+
+// Round kernel C', latency variant: same sweep, per-pair state in LDS (LdsStorage) instead of scratch.  Used for the
+// small rounds of the greedy scan, where the launch time is one pair's serial latency, not throughput.
+enum { LDS_T = 32 };
+template <int MAXV, int MAXIL, int MAXREC>
+__global__ void __launch_bounds__(LDS_T) k_pairs_lds(const int2* __restrict__ pairs, unsigned long long nPairs, int R,
+                                                     const int* __restrict__ vx, const int* __restrict__ vy,
+                                                     const float* __restrict__ area, float thr, unsigned char* __restrict__ state,
+                                                     int2* __restrict__ joinPairs, unsigned int* joinCount, unsigned int joinCap) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  typedef sdclip::LdsStorage<LDS_T> LP;
+  for (unsigned long long p = (unsigned long long)blockIdx.x * LDS_T + threadIdx.x; p < nPairs; p += (unsigned long long)gridDim.x * LDS_T) {
+    const int2 ij = pairs[p];
+    sdclip::Sweep<MAXV, MAXIL, MAXREC, LP> sw;
+    typename LP::Cursor c; c.base = lds_raw; c.tid = threadIdx.x; c.off = 0;
+    sw.bind(c);
+    sw.reset_state();
+    sw.add_path(vx + (size_t)ij.x * R, vy + (size_t)ij.x * R, R, sdclip::kClip, 0);
+    sw.add_path(vx + (size_t)ij.y * R, vy + (size_t)ij.y * R, R, sdclip::kSubject, MAXV);
+    const i64 twice = sw.execute();
+    if ((sw.status & ~sdclip::ST_FAIL) || sw.n_joins > 0 || sw.sum_abs_terms >= (1ll << 24)) {
+      // capacity of the compact variant exceeded, or joins recorded: the exact path decides
+      const unsigned int q = atomicAdd(joinCount, 1u);
+      if (q < joinCap) joinPairs[q] = ij;
+      continue;
+    }
+    const float area_inter = 0.5f * (float)twice;
+    const float overlap = (float)((double)area_inter / fmin((double)area[ij.x] + 1.e-10, (double)area[ij.y] + 1.e-10));
+    if (overlap > thr) state[ij.y] = ST_SUPPRESSED;
+  }
+}
+
+template <int MAXV, int MAXIL, int MAXREC>
+size_t lds_pairs_bytes() {
+  typedef sdclip::LdsStorage<LDS_T> LP;
+  sdclip::Sweep<MAXV, MAXIL, MAXREC, LP> sw;
+  typename LP::Cursor c; c.base = nullptr; c.tid = 0; c.off = 0;
+  sw.bind(c);
+  return (size_t)c.off + 64;
 }
 
 __global__ void k_iota(int* a, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = i; }
@@ -342,7 +395,8 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   if (stats) { SD_CHECK(hipEventCreate(&ev0)); SD_CHECK(hipEventCreate(&ev1)); }
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evguard{ev0, ev1};
   double ns_pairs = 0, ns_full = 0, ns_pre = 0;
-  long long n_pair_launches = 0;
+  long long n_pair_launches = 0, n_lds_launches = 0;
+  static const long long lds_max_pairs = getenv("SD_LDS_MAX_PAIRS") ? atoll(getenv("SD_LDS_MAX_PAIRS")) : 8192;   // = pairs resident in one pass (256 CUs x 32 threads)
 
   // all-pairs configuration with a negative threshold: every pair (0, j) passes the reference's
   // filters and overlap >= 0 > thr, so polygon 0 suppresses everything else.
@@ -466,7 +520,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
     if (h.nK == 0 && h.nU > 0) { sd::set_error("sd_nms2d: greedy scan made no progress (internal error)"); return -1; }
     if (h.nK > 0) {
       hipLaunchKernelGGL(k_round_emit, dim3(sd::div_up(h.nK, 4)), dim3(256), 0, s, K, h.nK, state, nbrStart, nbr, f, d_points, bbox,
-                         radius, pairs, &d_cnt->nPairs, pairCap);
+                         radius, area, pairs, &d_cnt->nPairs, pairCap);
       SD_LAUNCH_CHECK();
       SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
       SD_CHECK(hipStreamSynchronize(s));
@@ -474,6 +528,19 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
       if (h.nPairs > 0) {
         totalPairs += (i64)h.nPairs;
         if (stats) SD_CHECK(hipEventRecord(ev0, s));
+        if (R <= 32 && h.nPairs <= (unsigned long long)lds_max_pairs) {
+          // latency-bound round: LDS-resident sweep state, one 32-thread workgroup per CU
+          static const size_t ldsBytes = lds_pairs_bytes<32, 48, 16>();
+          static bool attr_set = false;
+          if (!attr_set) {   // > 64 KiB of dynamic LDS needs an explicit opt-in
+            SD_CHECK(hipFuncSetAttribute((const void*)k_pairs_lds<32, 48, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+            attr_set = true;
+          }
+          const unsigned int blocks = (unsigned int)((h.nPairs + LDS_T - 1) / LDS_T);
+          hipLaunchKernelGGL((k_pairs_lds<32, 48, 16>), dim3(blocks < 2048u ? blocks : 2048u), dim3(LDS_T), ldsBytes, s, pairs, h.nPairs, R, vx, vy,
+                             area, threshold, state, joinPairs, &d_cnt->nJoin, joinCap);
+          ++n_lds_launches;
+        } else
         if (R <= 32) launch_pairs<32, 64, 32>(pairs, h.nPairs, R, vx, vy, area, threshold, state, joinPairs, &d_cnt->nJoin, joinCap, &d_cnt->nErr, s);
         else if (R <= 64) launch_pairs<64, 96, 48>(pairs, h.nPairs, R, vx, vy, area, threshold, state, joinPairs, &d_cnt->nJoin, joinCap, &d_cnt->nErr, s);
         else if (R <= 128) launch_pairs<128, 128, 64>(pairs, h.nPairs, R, vx, vy, area, threshold, state, joinPairs, &d_cnt->nJoin, joinCap, &d_cnt->nErr, s);
@@ -482,7 +549,8 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
         if (stats) SD_CHECK(hipEventRecord(ev1, s));
         SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
         SD_CHECK(hipStreamSynchronize(s));
-        if (stats) { float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns_pairs += ms * 1e6; ++n_pair_launches; }
+        if (stats) { float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns_pairs += ms * 1e6; ++n_pair_launches;
+                     if (getenv("SD_TRACE")) printf("round %d: nU=%d nK=%d pairs=%llu joins=%u pair_kernel=%.3f ms\n", rounds, h.nU, h.nK, h.nPairs, h.nJoin, ms); }
         if (h.nErr) { sd::set_error("sd_nms2d: %u pairs exceeded the scan-beam kernel's fixed capacities", h.nErr); return -1; }
         if (h.nJoin > 0) {
           if (h.nJoin > joinCap) { sd::set_error("sd_nms2d: join queue overflow"); return -1; }
@@ -502,7 +570,8 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   SD_LAUNCH_CHECK();
   SD_CHECK(hipStreamSynchronize(s));
   if (stats) { stats[0] = totalPairs; stats[1] = totalJoin; stats[2] = rounds; stats[3] = totalNbr;
-               stats[4] = (int64_t)ns_pairs; stats[5] = n_pair_launches; stats[6] = (int64_t)ns_full; stats[7] = (int64_t)ns_pre; }
+               stats[4] = (int64_t)ns_pairs; stats[5] = n_pair_launches; stats[6] = (int64_t)ns_full; stats[7] = (int64_t)ns_pre;
+               stats[8] = n_lds_launches; }
   if (verbose) {
     printf("NMS: %lld pair intersections (%lld on the exact-join path), %d greedy rounds, %lld neighbour entries\n",
            (long long)totalPairs, (long long)totalJoin, rounds, (long long)totalNbr);

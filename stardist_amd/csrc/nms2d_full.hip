@@ -26,6 +26,35 @@ __global__ void __launch_bounds__(64) k_full_pairs(const int2* __restrict__ pair
   flags[p] = sw.status;
 }
 
+// latency variant of the exact-join kernel: the sweep's core arrays in LDS, the point rings stay private
+enum { LDSF_T = 32 };
+template <int MAXV, int MAXIL, int MAXREC, int MAXPT, int MAXJ>
+__global__ void __launch_bounds__(LDSF_T) k_full_pairs_lds(const int2* __restrict__ pairs, unsigned int n, int R,
+                                                           const int* __restrict__ vx, const int* __restrict__ vy,
+                                                           i64* __restrict__ twice, int* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  typedef sdclip::LdsStorage<LDSF_T> LP;
+  for (unsigned int p = blockIdx.x * LDSF_T + threadIdx.x; p < n; p += gridDim.x * LDSF_T) {
+    const int2 ij = pairs[p];
+    sdclip::SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ, LP> sw;
+    typename LP::Cursor c; c.base = lds_raw; c.tid = threadIdx.x; c.off = 0;
+    sw.bind(c);
+    sw.reset_state();
+    sw.add_path(vx + (size_t)ij.x * R, vy + (size_t)ij.x * R, R, sdclip::kClip, 0);
+    sw.add_path(vx + (size_t)ij.y * R, vy + (size_t)ij.y * R, R, sdclip::kSubject, MAXV);
+    twice[p] = sw.execute();
+    flags[p] = sw.status;
+  }
+}
+template <int MAXV, int MAXIL, int MAXREC, int MAXPT, int MAXJ>
+size_t lds_full_bytes() {
+  typedef sdclip::LdsStorage<LDSF_T> LP;
+  static sdclip::SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ, LP> sw;
+  typename LP::Cursor c; c.base = nullptr; c.tid = 0; c.off = 0;
+  sw.bind(c);
+  return (size_t)c.off + 64;
+}
+
 // probe: explicit vertex arrays per pair; fast sweep first, full sweep when joins were recorded
 template <int MAXV, int MAXIL, int MAXREC, int MAXPT, int MAXJ>
 __global__ void __launch_bounds__(64) k_probe(const int* __restrict__ xa, const int* __restrict__ ya,
@@ -63,6 +92,16 @@ int clip_full_pairs(const int2* d_pairs, unsigned int n, int R, const int* d_vx,
                     int* d_flags, hipStream_t s) {
   if (n == 0) return 0;
   const unsigned int blocks = (n + 63) / 64;
+  if (R <= 32 && n <= 8192u) {   // one resident pass: launch time = one pair's latency (~5x lower than scratch)
+    static const size_t ldsBytes = lds_full_bytes<32, 64, 32, 192, 64>();
+    static bool attr_set = false;
+    if (!attr_set) {
+      SD_CHECK(hipFuncSetAttribute((const void*)k_full_pairs_lds<32, 64, 32, 192, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+      attr_set = true;
+    }
+    const unsigned int bl = (n + LDSF_T - 1) / LDSF_T;
+    hipLaunchKernelGGL((k_full_pairs_lds<32, 64, 32, 192, 64>), dim3(bl < 2048u ? bl : 2048u), dim3(LDSF_T), ldsBytes, s, d_pairs, n, R, d_vx, d_vy, d_twice, d_flags);
+  } else
   if (R <= 32) hipLaunchKernelGGL((k_full_pairs<32, 64, 32, 192, 64>), dim3(blocks), dim3(64), 0, s, d_pairs, n, R, d_vx, d_vy, d_twice, d_flags);
   else if (R <= 64) hipLaunchKernelGGL((k_full_pairs<64, 96, 48, 384, 96>), dim3(blocks), dim3(64), 0, s, d_pairs, n, R, d_vx, d_vy, d_twice, d_flags);
   else if (R <= 128) hipLaunchKernelGGL((k_full_pairs<128, 128, 64, 768, 128>), dim3(blocks), dim3(64), 0, s, d_pairs, n, R, d_vx, d_vy, d_twice, d_flags);

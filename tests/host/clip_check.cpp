@@ -17,6 +17,10 @@ extern "C" int clipper_ref_intersect(const int64_t*, const int64_t*, int, const 
 
 typedef sdclip::Sweep<128, 512, 128> SweepT;
 typedef sdclip::SweepFull<128, 512, 128, 1024, 256> SweepF;
+// LDS-style storage policy exercised on the host (interleaved arrays, recomputed slopes, int8 indices)
+typedef sdclip::LdsStorage<4> LdsP;
+typedef sdclip::Sweep<32, 64, 32, LdsP> SweepL;
+typedef sdclip::SweepFull<32, 64, 32, 192, 64, LdsP> SweepFL;
 
 static void make_poly(std::mt19937& rng, int n_rays, float radius, float noise, float cy, float cx,
                       std::vector<int64_t>& xs, std::vector<int64_t>& ys) {
@@ -42,6 +46,8 @@ int main(int argc, char** argv) {
   float offset = argc > 6 ? atof(argv[6]) : 0.f;      // coordinate offset (large-coordinate regime)
   int verbose = argc > 7 ? atoi(argv[7]) : 0;
   int all_full = argc > 8 ? atoi(argv[8]) : 0;
+  int lds_mode = argc > 9 ? atoi(argv[9]) : 0;   // 1: run the LdsStorage policy variants (n_rays <= 32)
+  static char lds_buf[1 << 16];
   std::mt19937 rng(seed);
   std::uniform_real_distribution<float> U01(0.f, 1.f);
   std::vector<int64_t> xa, ya, xb, yb;
@@ -59,33 +65,50 @@ int main(int argc, char** argv) {
     make_poly(rng, n_rays, radius, noise, cy, cx, xa, ya);
     make_poly(rng, n_rays, r2, noise, cy2, cx2, xb, yb);
     float ref = clipper_ref_area(xa.data(), ya.data(), n_rays, xb.data(), yb.data(), n_rays);
-    sw.reset_state();
-    bool okA = sw.add_path(xa.data(), ya.data(), n_rays, sdclip::kClip, 0);
-    bool okB = sw.add_path(xb.data(), yb.data(), n_rays, sdclip::kSubject, 128);
-    (void)okA; (void)okB;
-    long long twice = sw.execute();
-    int st = sw.status;
-    if (sw.n_joins == 0 && 0.5f * (float)twice != ref) mism_fast_nojoin++;
-    if (sw.n_joins > 0 || all_full) {
-      sf.reset_state();
-      sf.add_path(xa.data(), ya.data(), n_rays, sdclip::kClip, 0);
-      sf.add_path(xb.data(), yb.data(), n_rays, sdclip::kSubject, 128);
-      twice = sf.execute();
-      st = sf.status;
+    long long twice; int st; int nj;
+    if (!lds_mode) {
+      sw.reset_state();
+      sw.add_path(xa.data(), ya.data(), n_rays, sdclip::kClip, 0);
+      sw.add_path(xb.data(), yb.data(), n_rays, sdclip::kSubject, 128);
+      twice = sw.execute(); st = sw.status; nj = sw.n_joins;
+      sw.n_joins = nj;
+    } else {
+      SweepL sl; LdsP::Cursor c; c.base = lds_buf; c.tid = (int)(p & 3); c.off = 0; sl.bind(c);
+      if (c.off > sizeof(lds_buf)) { printf("lds_buf too small: %u\n", c.off); return 2; }
+      sl.reset_state();
+      sl.add_path(xa.data(), ya.data(), n_rays, sdclip::kClip, 0);
+      sl.add_path(xb.data(), yb.data(), n_rays, sdclip::kSubject, 32);
+      twice = sl.execute(); st = sl.status; nj = sl.n_joins;
+      if (p == 0) printf("LdsStorage<4> bytes per 4 threads: %u\n", c.off);
+    }
+    if (nj == 0 && 0.5f * (float)twice != ref) mism_fast_nojoin++;
+    if (nj > 0 || all_full) {
+      if (!lds_mode) {
+        sf.reset_state();
+        sf.add_path(xa.data(), ya.data(), n_rays, sdclip::kClip, 0);
+        sf.add_path(xb.data(), yb.data(), n_rays, sdclip::kSubject, 128);
+        twice = sf.execute(); st = sf.status;
+      } else {
+        static SweepFL sfl; LdsP::Cursor c; c.base = lds_buf; c.tid = (int)(p & 3); c.off = 0; sfl.bind(c);
+        sfl.reset_state();
+        sfl.add_path(xa.data(), ya.data(), n_rays, sdclip::kClip, 0);
+        sfl.add_path(xb.data(), yb.data(), n_rays, sdclip::kSubject, 32);
+        twice = sfl.execute(); st = sfl.status;
+      }
       full_runs++;
     }
     float mine = 0.5f * (float)twice;
     if (st) flagged++;
-    if (sw.n_joins) with_joins++;
+    if (nj) with_joins++;
     if (ref != 0) nonzero++;
     if (sw.sum_abs_terms >= (1ll << 24)) inexact++;
     if (mine != ref) {
       mism++;
-      if (sw.n_joins) mism_joins++;
+      if (nj) mism_joins++;
       double rel = fabs(mine - ref) / (fabs(ref) + 1e-9);
       if (rel > max_rel) max_rel = rel;
       if (verbose && mism <= verbose) {
-        printf("MISMATCH pair %ld: ref=%.1f mine=%.1f status=%d joins=%d\nA:", p, ref, mine, sw.status, sw.n_joins);
+        printf("MISMATCH pair %ld: ref=%.1f mine=%.1f status=%d joins=%d\nA:", p, ref, mine, st, nj);
         for (int k = 0; k < n_rays; k++) printf(" (%ld,%ld)", (long)xa[k], (long)ya[k]);
         printf("\nB:");
         for (int k = 0; k < n_rays; k++) printf(" (%ld,%ld)", (long)xb[k], (long)yb[k]);
