@@ -251,7 +251,7 @@ def main():
                        "nms_thresh": model.thresholds.nms, "parallelism": "tiles-per-gpu x%d" % world},
             "stages_ms": stages, "roofline": dominant, "roofline_convs": roof_conv, "roofline_pair_kernel": roof_pair,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline_2d(img_np, model, min(args.cpu_sample, H), threads)
             except Exception as e:   # oracle/_ref must have travelled with the tree
@@ -288,7 +288,7 @@ def main():
                                    "other": round(ms3 - net3_ms - float((s3[8] + s3[9] + s3[10]) / 1e6), 3)}
             out["roofline_convs_3d"] = {"bound": "mfma", "achieved": round(conv3_tf, 3), "peak": peak, "unit": "TFLOP/s",
                                         "frac": round(conv3_tf / peak, 4), "flops_per_launch": flops3, "avg_ms": round(net3_ms, 3)}
-            if not args.no_cpu_baseline:
+            if not args.no_cpu_baseline and world == 1:
                 try:
                     out["cpu_baseline_3d"] = cpu_baseline_3d(vol_np, m3, min(args.cpu_sample3d, S), threads)
                 except Exception as e:

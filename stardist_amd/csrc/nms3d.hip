@@ -291,54 +291,78 @@ __global__ void __launch_bounds__(256) k_round_emit3(const int* __restrict__ K, 
 // Qhull's feasibility rule (qh_sethalfspace): the interior point must satisfy offset + n.c <= 0 for
 // every half-space (evaluated in that order in fp64), otherwise the reference gets a QhullError and
 // uses err_value (0).
-#define HIV_MAXP 40
+#define HIV_MAXP 64
+struct HivPoly { double ps[HIV_MAXP], pt[HIV_MAXP], qs[HIV_MAXP], qt[HIV_MAXP]; int n; };
+// Sutherland-Hodgman against the half-plane a*s + b*t + e <= 0; returns false on capacity overflow
+__device__ __forceinline__ bool hiv_clip(HivPoly& P, double a, double b, double e) {
+  int nq = 0;
+  const int n = P.n;
+  double s_prev = P.ps[n - 1], t_prev = P.pt[n - 1];
+  double f_prev = a * s_prev + b * t_prev + e;
+  for (int v = 0; v < n; ++v) {
+    const double s_cur = P.ps[v], t_cur = P.pt[v];
+    const double f_cur = a * s_cur + b * t_cur + e;
+    if ((f_prev <= 0) != (f_cur <= 0)) {
+      const double w = f_prev / (f_prev - f_cur);
+      if (nq >= HIV_MAXP) return false;
+      P.qs[nq] = s_prev + w * (s_cur - s_prev); P.qt[nq] = t_prev + w * (t_cur - t_prev); ++nq;
+    }
+    if (f_cur <= 0) { if (nq >= HIV_MAXP) return false; P.qs[nq] = s_cur; P.qt[nq] = t_cur; ++nq; }
+    s_prev = s_cur; t_prev = t_cur; f_prev = f_cur;
+  }
+  P.n = nq;
+  for (int v = 0; v < nq; ++v) { P.ps[v] = P.qs[v]; P.pt[v] = P.qt[v]; }
+  return true;
+}
 __device__ double hiv_face_term(const double* __restrict__ hs, int M, int k, const double c[3], double L) {
-  // polygon of plane k clipped by all other half-spaces; returns area * height (height from c)
+  // polygon of plane k clipped by all other half-spaces; returns area * height (height from c); NaN on overflow
   const double nz = hs[4 * k], ny = hs[4 * k + 1], nx = hs[4 * k + 2], d = hs[4 * k + 3];
   const double nn = sqrt(nz * nz + ny * ny + nx * nx);
   if (!(nn > 0)) return 0;
   const double h = -(nz * c[0] + ny * c[1] + nx * c[2] + d) / nn;            // distance from c to the plane (>= 0)
-  // origin on the plane: foot point of c; orthonormal basis (u, v)
   const double uz0 = nz / nn, uy0 = ny / nn, ux0 = nx / nn;                    // unit normal
-  const double oz = c[0] + h * uz0, oy = c[1] + h * uy0, ox = c[2] + h * ux0;
+  const double oz = c[0] + h * uz0, oy = c[1] + h * uy0, ox = c[2] + h * ux0;  // foot point of c = in-plane origin
   double az = 0, ay = 0, ax = 0;
   const double fz = fabs(uz0), fy = fabs(uy0), fx = fabs(ux0);
   if (fz <= fy && fz <= fx) az = 1; else if (fy <= fx) ay = 1; else ax = 1;
-  // u = normalize(a x n), v = n x u
-  double uz = ay * ux0 - ax * uy0, uy = ax * uz0 - az * ux0, ux = az * uy0 - ay * uz0;
+  double uz = ay * ux0 - ax * uy0, uy = ax * uz0 - az * ux0, ux = az * uy0 - ay * uz0;   // u = normalize(a x n), v = n x u
   const double un = sqrt(uz * uz + uy * uy + ux * ux);
   uz /= un; uy /= un; ux /= un;
   const double vz = uy0 * ux - ux0 * uy, vy = ux0 * uz - uz0 * ux, vx = uz0 * uy - uy0 * uz;
-  double ps[HIV_MAXP], pt[HIV_MAXP], qs[HIV_MAXP], qt[HIV_MAXP];
-  int n = 4;
-  ps[0] = -L; pt[0] = -L; ps[1] = L; pt[1] = -L; ps[2] = L; pt[2] = L; ps[3] = -L; pt[3] = L;
-  for (int m = 0; m < M && n > 0; ++m) {
+  HivPoly P;
+  P.n = 4;
+  P.ps[0] = -L; P.pt[0] = -L; P.ps[1] = L; P.pt[1] = -L; P.ps[2] = L; P.pt[2] = L; P.ps[3] = -L; P.pt[3] = L;
+  // pass 0: distance of every other plane's trace line from the origin; the nearest ones bound the face.
+  // Clipping with the near lines first keeps the intermediate polygons small (the result is order independent).
+  double dmin = 1e300;
+  for (int m = 0; m < M; ++m) {
     if (m == k) continue;
     const double mz = hs[4 * m], my = hs[4 * m + 1], mx = hs[4 * m + 2], md = hs[4 * m + 3];
-    // restriction to the plane: a*s + b*t + e <= 0
-    const double a = mz * uz + my * uy + mx * ux;
-    const double b = mz * vz + my * vy + mx * vx;
-    const double e = mz * oz + my * oy + mx * ox + md;
-    // Sutherland-Hodgman against one half-plane
-    int nq = 0;
-    double s_prev = ps[n - 1], t_prev = pt[n - 1];
-    double f_prev = a * s_prev + b * t_prev + e;
-    for (int v = 0; v < n; ++v) {
-      const double s_cur = ps[v], t_cur = pt[v];
-      const double f_cur = a * s_cur + b * t_cur + e;
-      if ((f_prev <= 0) != (f_cur <= 0)) {
-        const double w = f_prev / (f_prev - f_cur);
-        if (nq < HIV_MAXP) { qs[nq] = s_prev + w * (s_cur - s_prev); qt[nq] = t_prev + w * (t_cur - t_prev); ++nq; } else return NAN;
-      }
-      if (f_cur <= 0) { if (nq < HIV_MAXP) { qs[nq] = s_cur; qt[nq] = t_cur; ++nq; } else return NAN; }
-      s_prev = s_cur; t_prev = t_cur; f_prev = f_cur;
-    }
-    n = nq;
-    for (int v = 0; v < n; ++v) { ps[v] = qs[v]; pt[v] = qt[v]; }
+    const double a = mz * uz + my * uy + mx * ux, b = mz * vz + my * vy + mx * vx, e = mz * oz + my * oy + mx * ox + md;
+    const double nrm = sqrt(a * a + b * b);
+    if (nrm > 0) dmin = fmin(dmin, fabs(e) / nrm);
   }
-  if (n < 3) return 0;
+  const double near_lim = 4.0 * dmin + 1e-9 * L;
+  double rad2 = 2.0 * L * L;                      // squared circum-radius of the current polygon about the origin
+  for (int pass = 0; pass < 2 && P.n > 0; ++pass) {
+    for (int m = 0; m < M && P.n > 0; ++m) {
+      if (m == k) continue;
+      const double mz = hs[4 * m], my = hs[4 * m + 1], mx = hs[4 * m + 2], md = hs[4 * m + 3];
+      const double a = mz * uz + my * uy + mx * ux, b = mz * vz + my * vy + mx * vx, e = mz * oz + my * oy + mx * ox + md;
+      const double n2 = a * a + b * b;
+      const bool is_near = (n2 > 0) && (e * e <= near_lim * near_lim * n2);
+      if (is_near != (pass == 0)) continue;
+      // the origin is inside (e <= 0) and the whole polygon is closer to the origin than the line: nothing to cut
+      if (e <= 0 && e * e >= rad2 * n2 * (1.0 + 1e-12)) continue;
+      if (!hiv_clip(P, a, b, e)) return NAN;
+      double r2 = 0;
+      for (int v = 0; v < P.n; ++v) r2 = fmax(r2, P.ps[v] * P.ps[v] + P.pt[v] * P.pt[v]);
+      rad2 = r2;
+    }
+  }
+  if (P.n < 3) return 0;
   double area2 = 0;
-  for (int v = 0; v < n; ++v) { const int w = (v + 1 == n) ? 0 : v + 1; area2 += ps[v] * pt[w] - ps[w] * pt[v]; }
+  for (int v = 0; v < P.n; ++v) { const int w = (v + 1 == P.n) ? 0 : v + 1; area2 += P.ps[v] * P.pt[w] - P.ps[w] * P.pt[v]; }
   return 0.5 * fabs(area2) * h;
 }
 
@@ -380,17 +404,44 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
     }
     infeasible = __any(infeasible);
     double vol = 0;
+    int Mc = M;
     if (!infeasible) {
-      double ext = 0;
+      double ext = 0, ext1 = 0, ext2 = 0;
       for (int k = lane; k < R; k += 64) {
         const float e1 = dist[(size_t)ij.x * R + k], e2 = dist[(size_t)ij.y * R + k];
-        ext = fmax(ext, (double)fmaxf(e1, e2));
+        ext1 = fmax(ext1, (double)e1); ext2 = fmax(ext2, (double)e2);
       }
-      for (int o = 32; o; o >>= 1) ext = fmax(ext, __shfl_xor(ext, o));
+      for (int o = 32; o; o >>= 1) { ext1 = fmax(ext1, __shfl_xor(ext1, o)); ext2 = fmax(ext2, __shfl_xor(ext2, o)); }
+      ext = fmax(ext1, ext2);
+      // cull: the intersection lies inside both polyhedra, hence inside the outer ball of the OTHER polyhedron; a
+      // half-space that contains that whole ball cannot bound the intersection (exact, 1e-9 safety margin).
+      __syncthreads();
+      {
+        const double b1[4] = {(double)c1[0], (double)c1[1], (double)c1[2], ext1 * (1.0 + 1e-6) + 1e-6};
+        const double b2[4] = {(double)c2[0], (double)c2[1], (double)c2[2], ext2 * (1.0 + 1e-6) + 1e-6};
+        int kept = 0;
+        for (int k0 = 0; k0 < M; k0 += 64) {
+          const int k = k0 + lane;
+          bool keep = false;
+          double h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+          if (k < M) {
+            h0 = hs[4 * k]; h1 = hs[4 * k + 1]; h2 = hs[4 * k + 2]; h3 = hs[4 * k + 3];
+            const double* ob = (k & 1) ? b1 : b2;      // plane of polyhedron 2 (odd index) vs ball of polyhedron 1 and vice versa
+            const double nn = sqrt(h0 * h0 + h1 * h1 + h2 * h2);
+            keep = !(h0 * ob[0] + h1 * ob[1] + h2 * ob[2] + h3 + nn * ob[3] <= 0);
+          }
+          const unsigned long long mk = __ballot(keep);
+          __syncthreads();                               // all reads of this chunk done before compacted writes land
+          if (keep) { const int pos = kept + __popcll(mk & ((1ull << lane) - 1)); hs[4 * pos] = h0; hs[4 * pos + 1] = h1; hs[4 * pos + 2] = h2; hs[4 * pos + 3] = h3; }
+          kept += __popcll(mk);
+          __syncthreads();
+        }
+        Mc = kept;
+      }
       const double sep = sqrt((double)(c1[0] - c2[0]) * (c1[0] - c2[0]) + (double)(c1[1] - c2[1]) * (c1[1] - c2[1]) + (double)(c1[2] - c2[2]) * (c1[2] - c2[2]));
       const double L = 4.0 * (2.0 * ext + sep + 1.0);
       double acc = 0;
-      for (int k = lane; k < M; k += 64) acc += hiv_face_term(hs, M, k, c, L);
+      for (int k = lane; k < Mc; k += 64) acc += hiv_face_term(hs, Mc, k, c, L);
       for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
       vol = acc / 3.0;
     }
@@ -546,13 +597,36 @@ __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, u
     infeasible = __any(infeasible) || failed;
     double vol = 1.e10;                                             // err_value :927
     if (!infeasible) {
-      double ext = 0;
-      for (int k = lane; k < R; k += 64) ext = fmax(ext, (double)fmaxf(dist[(size_t)ij.x * R + k], dist[(size_t)ij.y * R + k]));
-      for (int o = 32; o; o >>= 1) ext = fmax(ext, __shfl_xor(ext, o));
+      double ext = 0, ext1 = 0, ext2 = 0;
+      for (int k = lane; k < R; k += 64) { ext1 = fmax(ext1, (double)dist[(size_t)ij.x * R + k]); ext2 = fmax(ext2, (double)dist[(size_t)ij.y * R + k]); }
+      for (int o = 32; o; o >>= 1) { ext1 = fmax(ext1, __shfl_xor(ext1, o)); ext2 = fmax(ext2, __shfl_xor(ext2, o)); }
+      ext = fmax(ext1, ext2);
       const double sep = sqrt((double)(c1[0] - c2[0]) * (c1[0] - c2[0]) + (double)(c1[1] - c2[1]) * (c1[1] - c2[1]) + (double)(c1[2] - c2[2]) * (c1[2] - c2[2]));
       const double L = 4.0 * (2.0 * ext + sep + 1.0);
+      // cull half-spaces of one hull that contain the other polyhedron's outer ball (which contains its hull)
+      int Mc = 0;
+      {
+        const double b1[4] = {(double)c1[0], (double)c1[1], (double)c1[2], ext1 * (1.0 + 1e-6) + 1e-6};
+        const double b2[4] = {(double)c2[0], (double)c2[1], (double)c2[2], ext2 * (1.0 + 1e-6) + 1e-6};
+        for (int k0 = 0; k0 < M; k0 += 64) {
+          const int k = k0 + lane;
+          bool keep = false;
+          double h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+          if (k < M) {
+            h0 = hs[4 * k]; h1 = hs[4 * k + 1]; h2 = hs[4 * k + 2]; h3 = hs[4 * k + 3];
+            const double* ob = (k >= n1) ? b1 : b2;
+            const double nn = sqrt(h0 * h0 + h1 * h1 + h2 * h2);
+            keep = !(h0 * ob[0] + h1 * ob[1] + h2 * ob[2] + h3 + nn * ob[3] <= 0);
+          }
+          const unsigned long long mk = __ballot(keep);
+          __syncthreads();
+          if (keep) { const int pos = Mc + __popcll(mk & ((1ull << lane) - 1)); hs[4 * pos] = h0; hs[4 * pos + 1] = h1; hs[4 * pos + 2] = h2; hs[4 * pos + 3] = h3; }
+          Mc += __popcll(mk);
+          __syncthreads();
+        }
+      }
       double acc = 0;
-      for (int k = lane; k < M; k += 64) acc += hiv_face_term(hs, M, k, c, L);
+      for (int k = lane; k < Mc; k += 64) acc += hiv_face_term(hs, Mc, k, c, L);
       for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
       vol = acc / 3.0;
     }
