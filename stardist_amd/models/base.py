@@ -177,19 +177,57 @@ class StarDistBase(object):
         return _permute_axes
 
     def _net_forward(self, x):
-        """x: torch tensor with axes_net semantics (channels last) -> tuple of channels-last outputs"""
+        """x: torch tensor with axes_net semantics (channels last) -> tuple of channels-last outputs.
+
+        On the GPU the forward pass is captured once per input shape into a HIP graph (torch.cuda.CUDAGraph) and
+        replayed: the network is ~60 small conv launches whose host-side dispatch (MIOpen solver lookup + launch)
+        otherwise leaves the device idle for several ms per call.  Outputs of a replay are valid until the next call."""
         import torch
         nd = self.config.n_dim
         xc = x.permute(*([nd] + list(range(nd)))).unsqueeze(0)      # (1,C,...)
-        xc = xc.contiguous(memory_format=torch.channels_last if nd == 2 else torch.channels_last_3d)
+        mf = torch.channels_last if nd == 2 else torch.channels_last_3d
+        use_graph = (self.device.type == "cuda") and getattr(self, "use_hip_graph", True)
+        if not use_graph:
+            ys = self._net_eager(xc.contiguous(memory_format=mf))
+        else:
+            key = (tuple(xc.shape), xc.dtype)
+            cache = self.__dict__.setdefault("_graphs", {})
+            if key not in cache:
+                if len(cache) >= 8:                                  # bounded: tiles of a big image share few shapes
+                    cache.pop(next(iter(cache)))
+                static_in = torch.empty(xc.shape, dtype=torch.float32, device=self.device).contiguous(memory_format=mf)
+                static_in.copy_(xc)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):                        # warm-up outside capture (MIOpen find, workspaces)
+                    for _ in range(2):
+                        self._net_eager(static_in)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        static_out = self._net_eager(static_in)
+                    cache[key] = (g, static_in, static_out)
+                except Exception as e:                               # capture unsupported for some solver: stay eager
+                    import warnings
+                    warnings.warn("HIP graph capture of the network failed (%r); running eagerly" % (e,))
+                    self.use_hip_graph = False
+                    return self._net_forward(x)
+            g, static_in, static_out = cache[key]
+            static_in.copy_(xc)
+            g.replay()
+            ys = static_out
+        return tuple(y[0].permute(*(list(range(1, nd + 1)) + [0])) for y in ys)   # (...,C) views
+
+    def _net_eager(self, xc):
+        import torch
         with torch.no_grad():
             if self.compute_dtype != torch.float32:
                 with torch.autocast(device_type=self.device.type, dtype=self.compute_dtype):
                     ys = self.net(xc)
-                ys = tuple(y.float() for y in ys)
-            else:
-                ys = self.net(xc.float())
-        return tuple(y[0].permute(*(list(range(1, nd + 1)) + [0])) for y in ys)   # (...,C) views
+                return tuple(y.float() for y in ys)
+            return tuple(self.net(xc.float()))
 
     def _predict_setup(self, img, axes, normalizer, n_tiles):
         import torch
