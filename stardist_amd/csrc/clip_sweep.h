@@ -162,46 +162,45 @@ struct StdSort {
 //                   rounds of the greedy NMS scan.
 struct PlainStorage {
   typedef short idx_t;
-  template <class T, int N> struct Arr {
+  template <class T, int N> static constexpr unsigned region() { return 0; }
+  template <class T, int N, unsigned OFF> struct Arr {
     T v[N];
     SD_HD T& operator[](int i) { return v[i]; }
     SD_HD const T& operator[](int i) const { return v[i]; }
   };
-  template <int N> struct DxArr : Arr<double, N> {
-    template <class A> SD_HD void attach(const A*, const A*, const A*, const A*) {}
-  };
-  struct Cursor { template <class A> SD_HD void take(A&) {} };
+  template <int N, unsigned OBX, unsigned OBY, unsigned OTX, unsigned OTY> struct DxArr : Arr<double, N, 0> {};
 };
 
+// LDS-interleaved storage: element i of thread t of array A lives at  lds_base + OFF_A + (i*STRIDE + t)*sizeof(T).
+// The arrays are STATELESS (offset = template constant, t = threadIdx.x, base = start of dynamic LDS), so an access
+// never needs a pointer fetched from the (scratch-resident) sweep object.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ char* sd_lds_base() { extern __shared__ __attribute__((aligned(16))) char sd_lds_dyn[]; return sd_lds_dyn; }
+__device__ __forceinline__ int sd_lds_tid() { return (int)threadIdx.x; }
+#else
+struct HostLds { static char*& base() { static thread_local char* b = nullptr; return b; } static int& tid() { static thread_local int t = 0; return t; } };
+inline char* sd_lds_base() { return HostLds::base(); }
+inline int sd_lds_tid() { return HostLds::tid(); }
+#endif
 template <int STRIDE>
 struct LdsStorage {
   typedef signed char idx_t;
-  template <class T, int N> struct Arr {
-    T* b;
-    SD_HD T& operator[](int i) const { return b[i * STRIDE]; }
+  template <class T, int N> static constexpr unsigned region() { return (unsigned)((N * STRIDE * sizeof(T) + 15u) & ~15u); }
+  template <class T, int N, unsigned OFF> struct Arr {
+    SD_HD T& operator[](int i) const { return *(T*)(sd_lds_base() + OFF + (unsigned)(i * STRIDE + sd_lds_tid()) * (unsigned)sizeof(T)); }
   };
-  template <int N> struct DxArr {     // slope = f(bot, top): recomputed (clipper.cpp:591-596), never stored
-    const Arr<int, N>*bx, *by, *tx, *ty;
+  template <int N, unsigned OBX, unsigned OBY, unsigned OTX, unsigned OTY> struct DxArr {   // slope = f(bot, top): recomputed, never stored
     struct Ref {
-      const DxArr* a; int e;
+      int e;
       SD_HD operator double() const {
-        const long long dy = (long long)(*a->ty)[e] - (*a->by)[e];
+        const Arr<int, N, OBX> bx; const Arr<int, N, OBY> by; const Arr<int, N, OTX> tx; const Arr<int, N, OTY> ty;
+        const long long dy = (long long)ty[e] - by[e];
         if (dy == 0) return SD_HORIZONTAL;
-        return (double)((long long)(*a->tx)[e] - (*a->bx)[e]) / (double)dy;
+        return (double)((long long)tx[e] - bx[e]) / (double)dy;
       }
       SD_HD void operator=(double) const {}
     };
-    SD_HD Ref operator[](int e) const { Ref r; r.a = this; r.e = e; return r; }
-    SD_HD void attach(const Arr<int, N>* bx_, const Arr<int, N>* by_, const Arr<int, N>* tx_, const Arr<int, N>* ty_) { bx = bx_; by = by_; tx = tx_; ty = ty_; }
-  };
-  struct Cursor {                     // carves per-array regions out of the workgroup's LDS block
-    char* base; int tid; unsigned off;
-    template <class T, int N> SD_HD void take(Arr<T, N>& a) {
-      off = (off + 15u) & ~15u;
-      a.b = (T*)(base + off) + tid;
-      off += (unsigned)(N * STRIDE * sizeof(T));
-    }
-    template <int N> SD_HD void take(DxArr<N>&) {}
+    SD_HD Ref operator[](int e) const { Ref r; r.e = e; return r; }
   };
 };
 
@@ -222,22 +221,29 @@ struct SweepCore {
   SD_HD D& self() { return *static_cast<D*>(this); }
   // ---- edges (index = vertex slot; polygon A uses [0,MAXV), polygon B [MAXV,2*MAXV))
   typedef typename P::idx_t idx_t;
-  typename P::template Arr<int, NE> botx, boty, topx, topy, curx, cury;
-  typename P::template DxArr<NE> dx;
-  typename P::template Arr<idx_t, NE> nxt, prv, lml, anext, aprev, snext, sprev;
-  typename P::template Arr<short, NE> wcnt, wcnt2;
-  typename P::template Arr<idx_t, NE> outidx;
-  typename P::template Arr<signed char, NE> ptyp, side, wdelta;
-  SD_HD void bind_core(typename P::Cursor& c) {
-    c.take(botx); c.take(boty); c.take(topx); c.take(topy); c.take(curx); c.take(cury); c.take(dx);
-    c.take(nxt); c.take(prv); c.take(lml); c.take(anext); c.take(aprev); c.take(snext); c.take(sprev);
-    c.take(wcnt); c.take(wcnt2); c.take(outidx); c.take(ptyp); c.take(side); c.take(wdelta); c.take(sb);
-    dx.attach(&botx, &boty, &topx, &topy);
-  }
+  // storage offsets (only meaningful for LdsStorage; all zero-sized for PlainStorage)
+  static constexpr unsigned RI = P::template region<int, NE>(), RX = P::template region<idx_t, NE>(),
+                            RS = P::template region<short, NE>(), RB = P::template region<signed char, NE>();
+  static constexpr unsigned O_BOTX = 0, O_BOTY = O_BOTX + RI, O_TOPX = O_BOTY + RI, O_TOPY = O_TOPX + RI, O_CURX = O_TOPY + RI,
+                            O_CURY = O_CURX + RI, O_NXT = O_CURY + RI, O_PRV = O_NXT + RX, O_LML = O_PRV + RX, O_ANEXT = O_LML + RX,
+                            O_APREV = O_ANEXT + RX, O_SNEXT = O_APREV + RX, O_SPREV = O_SNEXT + RX, O_WCNT = O_SPREV + RX,
+                            O_WCNT2 = O_WCNT + RS, O_OUTIDX = O_WCNT2 + RS, O_PTYP = O_OUTIDX + RX, O_SIDE = O_PTYP + RB,
+                            O_WDELTA = O_SIDE + RB, O_SB = O_WDELTA + RB, O_CORE_END = O_SB + P::template region<int, NE + 4>();
+  typename P::template Arr<int, NE, O_BOTX> botx; typename P::template Arr<int, NE, O_BOTY> boty;
+  typename P::template Arr<int, NE, O_TOPX> topx; typename P::template Arr<int, NE, O_TOPY> topy;
+  typename P::template Arr<int, NE, O_CURX> curx; typename P::template Arr<int, NE, O_CURY> cury;
+  typename P::template DxArr<NE, O_BOTX, O_BOTY, O_TOPX, O_TOPY> dx;
+  typename P::template Arr<idx_t, NE, O_NXT> nxt; typename P::template Arr<idx_t, NE, O_PRV> prv; typename P::template Arr<idx_t, NE, O_LML> lml;
+  typename P::template Arr<idx_t, NE, O_ANEXT> anext; typename P::template Arr<idx_t, NE, O_APREV> aprev;
+  typename P::template Arr<idx_t, NE, O_SNEXT> snext; typename P::template Arr<idx_t, NE, O_SPREV> sprev;
+  typename P::template Arr<short, NE, O_WCNT> wcnt; typename P::template Arr<short, NE, O_WCNT2> wcnt2;
+  typename P::template Arr<idx_t, NE, O_OUTIDX> outidx;
+  typename P::template Arr<signed char, NE, O_PTYP> ptyp; typename P::template Arr<signed char, NE, O_SIDE> side;
+  typename P::template Arr<signed char, NE, O_WDELTA> wdelta;
   // ---- local minima, scan-beam, intersections
   LocMin lm[NE];
   int n_lm, cur_lm;
-  typename P::template Arr<int, NE + 4> sb;
+  typename P::template Arr<int, NE + 4, O_SB> sb;
   int n_sb;
   INode il[MAXIL];
   int n_il;
@@ -984,9 +990,13 @@ template <int MAXV, int MAXIL, int MAXREC, class P = PlainStorage>
 struct Sweep : SweepCore<Sweep<MAXV, MAXIL, MAXREC, P>, P, MAXV, MAXIL> {
   typedef SweepCore<Sweep<MAXV, MAXIL, MAXREC, P>, P, MAXV, MAXIL> B;
   using B::outidx; using B::side; using B::status; using B::ael; using B::anext;
-  typename P::template Arr<int, MAXREC> rfx, rfy, rlx, rly;
-  typename P::template Arr<i64, MAXREC> rsum;
-  SD_HD void bind(typename P::Cursor& c) { B::bind_core(c); c.take(rfx); c.take(rfy); c.take(rlx); c.take(rly); c.take(rsum); }
+  static constexpr unsigned RR = P::template region<int, MAXREC>();
+  static constexpr unsigned O_RFX = B::O_CORE_END, O_RFY = O_RFX + RR, O_RLX = O_RFY + RR, O_RLY = O_RLX + RR, O_RSUM = O_RLY + RR,
+                            O_END = O_RSUM + P::template region<i64, MAXREC>();
+  typename P::template Arr<int, MAXREC, O_RFX> rfx; typename P::template Arr<int, MAXREC, O_RFY> rfy;
+  typename P::template Arr<int, MAXREC, O_RLX> rlx; typename P::template Arr<int, MAXREC, O_RLY> rly;
+  typename P::template Arr<i64, MAXREC, O_RSUM> rsum;
+  static constexpr unsigned lds_bytes() { return O_END; }
   int n_rec;
   i64 twice_area;            // sum over closed rings of |2*area|
   i64 sum_abs_terms;         // sum of |cross| terms (exactness bound for the float path)

@@ -19,7 +19,7 @@ namespace sdclip {
 template <int MAXV, int MAXIL, int MAXREC, int MAXPT, int MAXJ, class P = PlainStorage>
 struct SweepFull : SweepCore<SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ, P>, P, MAXV, MAXIL> {
   typedef SweepCore<SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ, P>, P, MAXV, MAXIL> B;
-  SD_HD void bind(typename P::Cursor& c) { B::bind_core(c); }   // only the core arrays follow the policy; rings stay private
+  static constexpr unsigned lds_bytes() { return B::O_CORE_END; }   // only the core arrays follow the policy; rings stay private
   using B::outidx; using B::side; using B::status; using B::ael; using B::anext; using B::aprev; using B::wdelta;
   // ---- output points (rings)
   int px[MAXPT], py[MAXPT];

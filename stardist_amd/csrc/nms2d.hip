@@ -306,13 +306,10 @@ __global__ void __launch_bounds__(LDS_T) k_pairs_lds(const int2* __restrict__ pa
                                                      const int* __restrict__ vx, const int* __restrict__ vy,
                                                      const float* __restrict__ area, float thr, unsigned char* __restrict__ state,
                                                      int2* __restrict__ joinPairs, unsigned int* joinCount, unsigned int joinCap) {
-  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   typedef sdclip::LdsStorage<LDS_T> LP;
   for (unsigned long long p = (unsigned long long)blockIdx.x * LDS_T + threadIdx.x; p < nPairs; p += (unsigned long long)gridDim.x * LDS_T) {
     const int2 ij = pairs[p];
-    sdclip::Sweep<MAXV, MAXIL, MAXREC, LP> sw;
-    typename LP::Cursor c; c.base = lds_raw; c.tid = threadIdx.x; c.off = 0;
-    sw.bind(c);
+    sdclip::Sweep<MAXV, MAXIL, MAXREC, LP> sw;       // arrays live in dynamic LDS (stateless, see LdsStorage)
     sw.reset_state();
     sw.add_path(vx + (size_t)ij.x * R, vy + (size_t)ij.x * R, R, sdclip::kClip, 0);
     sw.add_path(vx + (size_t)ij.y * R, vy + (size_t)ij.y * R, R, sdclip::kSubject, MAXV);
@@ -332,10 +329,7 @@ __global__ void __launch_bounds__(LDS_T) k_pairs_lds(const int2* __restrict__ pa
 template <int MAXV, int MAXIL, int MAXREC>
 size_t lds_pairs_bytes() {
   typedef sdclip::LdsStorage<LDS_T> LP;
-  sdclip::Sweep<MAXV, MAXIL, MAXREC, LP> sw;
-  typename LP::Cursor c; c.base = nullptr; c.tid = 0; c.off = 0;
-  sw.bind(c);
-  return (size_t)c.off + 64;
+  return (size_t)sdclip::Sweep<MAXV, MAXIL, MAXREC, LP>::lds_bytes() + 64;
 }
 
 __global__ void k_iota(int* a, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = i; }

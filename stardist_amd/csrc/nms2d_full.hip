@@ -32,13 +32,10 @@ template <int MAXV, int MAXIL, int MAXREC, int MAXPT, int MAXJ>
 __global__ void __launch_bounds__(LDSF_T) k_full_pairs_lds(const int2* __restrict__ pairs, unsigned int n, int R,
                                                            const int* __restrict__ vx, const int* __restrict__ vy,
                                                            i64* __restrict__ twice, int* __restrict__ flags) {
-  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   typedef sdclip::LdsStorage<LDSF_T> LP;
   for (unsigned int p = blockIdx.x * LDSF_T + threadIdx.x; p < n; p += gridDim.x * LDSF_T) {
     const int2 ij = pairs[p];
     sdclip::SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ, LP> sw;
-    typename LP::Cursor c; c.base = lds_raw; c.tid = threadIdx.x; c.off = 0;
-    sw.bind(c);
     sw.reset_state();
     sw.add_path(vx + (size_t)ij.x * R, vy + (size_t)ij.x * R, R, sdclip::kClip, 0);
     sw.add_path(vx + (size_t)ij.y * R, vy + (size_t)ij.y * R, R, sdclip::kSubject, MAXV);
@@ -49,10 +46,7 @@ __global__ void __launch_bounds__(LDSF_T) k_full_pairs_lds(const int2* __restric
 template <int MAXV, int MAXIL, int MAXREC, int MAXPT, int MAXJ>
 size_t lds_full_bytes() {
   typedef sdclip::LdsStorage<LDSF_T> LP;
-  static sdclip::SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ, LP> sw;
-  typename LP::Cursor c; c.base = nullptr; c.tid = 0; c.off = 0;
-  sw.bind(c);
-  return (size_t)c.off + 64;
+  return (size_t)sdclip::SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ, LP>::lds_bytes() + 64;
 }
 
 // probe: explicit vertex arrays per pair; fast sweep first, full sweep when joins were recorded

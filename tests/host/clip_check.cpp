@@ -73,13 +73,13 @@ int main(int argc, char** argv) {
       twice = sw.execute(); st = sw.status; nj = sw.n_joins;
       sw.n_joins = nj;
     } else {
-      SweepL sl; LdsP::Cursor c; c.base = lds_buf; c.tid = (int)(p & 3); c.off = 0; sl.bind(c);
-      if (c.off > sizeof(lds_buf)) { printf("lds_buf too small: %u\n", c.off); return 2; }
+      SweepL sl; sdclip::HostLds::base() = lds_buf; sdclip::HostLds::tid() = (int)(p & 3);
+      if (SweepL::lds_bytes() > sizeof(lds_buf)) { printf("lds_buf too small\n"); return 2; }
       sl.reset_state();
       sl.add_path(xa.data(), ya.data(), n_rays, sdclip::kClip, 0);
       sl.add_path(xb.data(), yb.data(), n_rays, sdclip::kSubject, 32);
       twice = sl.execute(); st = sl.status; nj = sl.n_joins;
-      if (p == 0) printf("LdsStorage<4> bytes per 4 threads: %u\n", c.off);
+      if (p == 0) printf("LdsStorage<4> bytes per 4 threads: %u\n", SweepL::lds_bytes());
     }
     if (nj == 0 && 0.5f * (float)twice != ref) mism_fast_nojoin++;
     if (nj > 0 || all_full) {
@@ -89,7 +89,7 @@ int main(int argc, char** argv) {
         sf.add_path(xb.data(), yb.data(), n_rays, sdclip::kSubject, 128);
         twice = sf.execute(); st = sf.status;
       } else {
-        static SweepFL sfl; LdsP::Cursor c; c.base = lds_buf; c.tid = (int)(p & 3); c.off = 0; sfl.bind(c);
+        static SweepFL sfl; sdclip::HostLds::base() = lds_buf; sdclip::HostLds::tid() = (int)(p & 3);
         sfl.reset_state();
         sfl.add_path(xa.data(), ya.data(), n_rays, sdclip::kClip, 0);
         sfl.add_path(xb.data(), yb.data(), n_rays, sdclip::kSubject, 32);
