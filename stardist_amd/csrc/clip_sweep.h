@@ -169,6 +169,7 @@ struct PlainStorage {
     SD_HD const T& operator[](int i) const { return v[i]; }
   };
   template <int N, unsigned OBX, unsigned OBY, unsigned OTX, unsigned OTY> struct DxArr : Arr<double, N, 0> {};
+  template <class T, unsigned OFF> using Scalar = T;
 };
 
 // LDS-interleaved storage: element i of thread t of array A lives at  lds_base + OFF_A + (i*STRIDE + t)*sizeof(T).
@@ -202,6 +203,21 @@ struct LdsStorage {
     };
     SD_HD Ref operator[](int e) const { Ref r; r.e = e; return r; }
   };
+  // scalar sweep state in LDS as well: inside the (non-inlined) building blocks a plain member would be a load
+  // from the scratch-resident object on every use
+  template <class T, unsigned OFF> struct Scalar {
+    SD_HD T& ref() const { return *(T*)(sd_lds_base() + OFF + (unsigned)sd_lds_tid() * (unsigned)sizeof(T)); }
+    SD_HD operator T() const { return ref(); }
+    SD_HD T operator=(T v) const { ref() = v; return v; }
+    SD_HD T operator=(const Scalar& o) const { const T v = o.ref(); ref() = v; return v; }
+    SD_HD T operator+=(T v) const { return ref() += v; }
+    SD_HD T operator-=(T v) const { return ref() -= v; }
+    SD_HD T operator|=(T v) const { return ref() |= v; }
+    SD_HD T operator++() const { return ++ref(); }
+    SD_HD T operator++(int) const { return ref()++; }
+    SD_HD T operator--() const { return --ref(); }
+    SD_HD T operator--(int) const { return ref()--; }
+  };
 };
 
 struct LocMin { int y; short left, right; };
@@ -228,7 +244,10 @@ struct SweepCore {
                             O_CURY = O_CURX + RI, O_NXT = O_CURY + RI, O_PRV = O_NXT + RX, O_LML = O_PRV + RX, O_ANEXT = O_LML + RX,
                             O_APREV = O_ANEXT + RX, O_SNEXT = O_APREV + RX, O_SPREV = O_SNEXT + RX, O_WCNT = O_SPREV + RX,
                             O_WCNT2 = O_WCNT + RS, O_OUTIDX = O_WCNT2 + RS, O_PTYP = O_OUTIDX + RX, O_SIDE = O_PTYP + RB,
-                            O_WDELTA = O_SIDE + RB, O_SB = O_WDELTA + RB, O_CORE_END = O_SB + P::template region<int, NE + 4>();
+                            O_WDELTA = O_SIDE + RB, O_SB = O_WDELTA + RB, O_SC = O_SB + P::template region<int, NE + 4>();
+  static constexpr unsigned R1 = P::template region<int, 1>();
+  static constexpr unsigned O_NLM = O_SC, O_CURLM = O_NLM + R1, O_NSB = O_CURLM + R1, O_NIL = O_NSB + R1, O_AEL = O_NIL + R1, O_SEL = O_AEL + R1,
+                            O_STATUS = O_SEL + R1, O_NJOINS = O_STATUS + R1, O_NGJ = O_NJOINS + R1, O_CORE_END = O_NGJ + R1;
   typename P::template Arr<int, NE, O_BOTX> botx; typename P::template Arr<int, NE, O_BOTY> boty;
   typename P::template Arr<int, NE, O_TOPX> topx; typename P::template Arr<int, NE, O_TOPY> topy;
   typename P::template Arr<int, NE, O_CURX> curx; typename P::template Arr<int, NE, O_CURY> cury;
@@ -242,16 +261,16 @@ struct SweepCore {
   typename P::template Arr<signed char, NE, O_WDELTA> wdelta;
   // ---- local minima, scan-beam, intersections
   LocMin lm[NE];
-  int n_lm, cur_lm;
+  typename P::template Scalar<int, O_NLM> n_lm; typename P::template Scalar<int, O_CURLM> cur_lm;
   typename P::template Arr<int, NE + 4, O_SB> sb;
-  int n_sb;
+  typename P::template Scalar<int, O_NSB> n_sb;
   INode il[MAXIL];
-  int n_il;
-  short ael, sel;            // heads (-1 = empty)
-  int status;
-  int n_joins;               // number of AddJoin calls the reference would have made
+  typename P::template Scalar<int, O_NIL> n_il;
+  typename P::template Scalar<int, O_AEL> ael; typename P::template Scalar<int, O_SEL> sel;   // heads (-1 = empty)
+  typename P::template Scalar<int, O_STATUS> status;
+  typename P::template Scalar<int, O_NJOINS> n_joins;   // number of AddJoin calls the reference would have made
   int gjop[16], gjx1[16], gjx2[16], gjy2[16];   // ghost joins of the current scan-line: OutPt1, OutPt1.X, OffPt  :1968-1975
-  int n_gj;
+  typename P::template Scalar<int, O_NGJ> n_gj;
 
   // ------------------------------------------------------------------ helpers
   SD_HD bool is_horz(int e) const { return dx[e] == SD_HORIZONTAL; }
@@ -903,7 +922,7 @@ struct SweepCore {
         int ePrev = aprev[e];
         do_maxima(e);
         if (status & ST_FAIL) return;
-        e = (ePrev < 0) ? ael : anext[ePrev];
+        e = (ePrev < 0) ? (int)ael : (int)anext[ePrev];
       } else {
         if (topy[e] == topY && lml[e] >= 0 && is_horz(lml[e])) {
           e = update_edge_into_ael(e);
@@ -992,14 +1011,15 @@ struct Sweep : SweepCore<Sweep<MAXV, MAXIL, MAXREC, P>, P, MAXV, MAXIL> {
   using B::outidx; using B::side; using B::status; using B::ael; using B::anext;
   static constexpr unsigned RR = P::template region<int, MAXREC>();
   static constexpr unsigned O_RFX = B::O_CORE_END, O_RFY = O_RFX + RR, O_RLX = O_RFY + RR, O_RLY = O_RLX + RR, O_RSUM = O_RLY + RR,
-                            O_END = O_RSUM + P::template region<i64, MAXREC>();
+                            O_NREC = O_RSUM + P::template region<i64, MAXREC>(), O_TWICE = O_NREC + P::template region<i64, 1>(),
+                            O_SABS = O_TWICE + P::template region<i64, 1>(), O_END = O_SABS + P::template region<i64, 1>();
   typename P::template Arr<int, MAXREC, O_RFX> rfx; typename P::template Arr<int, MAXREC, O_RFY> rfy;
   typename P::template Arr<int, MAXREC, O_RLX> rlx; typename P::template Arr<int, MAXREC, O_RLY> rly;
   typename P::template Arr<i64, MAXREC, O_RSUM> rsum;
   static constexpr unsigned lds_bytes() { return O_END; }
-  int n_rec;
-  i64 twice_area;            // sum over closed rings of |2*area|
-  i64 sum_abs_terms;         // sum of |cross| terms (exactness bound for the float path)
+  typename P::template Scalar<int, O_NREC> n_rec;
+  typename P::template Scalar<i64, O_TWICE> twice_area;      // sum over closed rings of |2*area|
+  typename P::template Scalar<i64, O_SABS> sum_abs_terms;    // sum of |cross| terms (exactness bound for the float path)
   SD_HD void term(i64 c) { sum_abs_terms += sd_abs64(c); }
   SD_HDN int out_add_pt(int e, int px, int py) {                             // :2463-2499
     int r = outidx[e];
