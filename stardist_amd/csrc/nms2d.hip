@@ -133,8 +133,16 @@ __device__ __forceinline__ bool bbox_intersect(const int4 a, const int4 b) {   /
 struct Flags { int use_kdtree, use_bbox, thr_nonneg; float thr; float max_dist; };
 
 // symmetric "may interact" predicate used for the dependency lists
-__device__ __forceinline__ bool may_interact(const Flags f, const int4 bi, const int4 bj, float pyi, float pxi, float pyj, float pxj) {
-  if (f.thr_nonneg) return bbox_intersect(bi, bj);   // disjoint integer bboxes => area 0 => overlap 0 <= thr
+__device__ __forceinline__ bool may_interact(const Flags f, const int4 bi, const int4 bj, float pyi, float pxi, float pyj, float pxj,
+                                             float ai, float aj) {
+  if (f.thr_nonneg) {
+    // disjoint integer bboxes => area 0 => overlap 0 <= thr; more generally area_inter <= area(bbox_i ∩ bbox_j), so a pair
+    // whose bbox-intersection area cannot exceed thr * min(area) can never suppress (same bound as in k_round_emit)
+    if (!bbox_intersect(bi, bj)) return false;
+    const double w = (double)(min(bi.y, bj.y) - max(bi.x, bj.x)), hgt = (double)(min(bi.w, bj.w) - max(bi.z, bj.z));
+    const float ub = (float)((w * hgt) / fmin((double)ai + 1.e-10, (double)aj + 1.e-10));
+    return ub > f.thr;
+  }
   bool ok = true;
   if (f.use_bbox) ok = ok && bbox_intersect(bi, bj);
   if (f.use_kdtree) {
@@ -148,7 +156,7 @@ __device__ __forceinline__ bool may_interact(const Flags f, const int4 bi, const
 // MODE 0: count neighbours, MODE 1: fill CSR
 template <int MODE>
 __global__ void __launch_bounds__(256) k_neighbours(int N, GridP g, Flags f, const float* __restrict__ pts, const int4* __restrict__ bbox,
-                                                    const int* __restrict__ candCell, const int* __restrict__ cellStart,
+                                                    const float* __restrict__ area, const int* __restrict__ candCell, const int* __restrict__ cellStart,
                                                     const int* __restrict__ cellItems, int* __restrict__ nbrCount,
                                                     const i64* __restrict__ nbrStart, int* __restrict__ nbr, int W) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -158,6 +166,7 @@ __global__ void __launch_bounds__(256) k_neighbours(int N, GridP g, Flags f, con
   const int cy = c / g.nx, cx = c - cy * g.nx;
   const int4 bi = bbox[i];
   const float pyi = pts[2 * i], pxi = pts[2 * i + 1];
+  const float ai = area[i];
   int total = 0;
   i64 base = MODE ? nbrStart[i] : 0;
   const int x_lo = max(cx - W, 0), x_hi = min(cx + W, g.nx - 1);
@@ -169,7 +178,7 @@ __global__ void __launch_bounds__(256) k_neighbours(int N, GridP g, Flags f, con
       int j = -1;
       if (idx < end) {
         j = cellItems[idx];
-        if (j != i) hit = may_interact(f, bi, bbox[j], pyi, pxi, pts[2 * j], pts[2 * j + 1]);
+        if (j != i) hit = may_interact(f, bi, bbox[j], pyi, pxi, pts[2 * j], pts[2 * j + 1], ai, area[j]);
       }
       const unsigned long long m = __ballot(hit);
       if (MODE) {
@@ -468,7 +477,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
 
   // ---- neighbour CSR
   SD_CHECK(hipMemsetAsync(nbrCount, 0, (N + 1) * sizeof(int), s));
-  hipLaunchKernelGGL((k_neighbours<0>), dim3(sd::div_up(N, 4)), dim3(256), 0, s, N, g, f, d_points, bbox, candCell, cellStart,
+  hipLaunchKernelGGL((k_neighbours<0>), dim3(sd::div_up(N, 4)), dim3(256), 0, s, N, g, f, d_points, bbox, area, candCell, cellStart,
                      cellItems, nbrCount, (const i64*)nullptr, (int*)nullptr, W);
   SD_LAUNCH_CHECK();
   SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tmpBytes, nbrCount, nbrStart, N + 1, s));
@@ -477,7 +486,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   SD_CHECK(hipStreamSynchronize(s));
   int* nbr = A.take_n<int>((size_t)totalNbr);
   if (!nbr) return -1;
-  hipLaunchKernelGGL((k_neighbours<1>), dim3(sd::div_up(N, 4)), dim3(256), 0, s, N, g, f, d_points, bbox, candCell, cellStart,
+  hipLaunchKernelGGL((k_neighbours<1>), dim3(sd::div_up(N, 4)), dim3(256), 0, s, N, g, f, d_points, bbox, area, candCell, cellStart,
                      cellItems, nbrCount, (const i64*)nbrStart, nbr, W);
   SD_LAUNCH_CHECK();
 
