@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256) k_round_emit(const int* __restrict__ K, i
 
 // Round kernel C: one thread per pair.
 template <int MAXV, int MAXIL, int MAXREC>
-__global__ void __launch_bounds__(64) k_pairs(const int2* __restrict__ pairs, unsigned long long nPairs, int R,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_pairs(const int2* __restrict__ pairs, unsigned long long nPairs, int R,
                                               const int* __restrict__ vx, const int* __restrict__ vy,
                                               const float* __restrict__ area, float thr, unsigned char* __restrict__ state,
                                               int2* __restrict__ joinPairs, unsigned int* joinCount, unsigned int joinCap,

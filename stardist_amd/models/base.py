@@ -109,6 +109,9 @@ class StarDistBase(object):
             self.load_weights_npz(os.path.join(self.logdir, "weights.npz"))
         self.net = self.net.to(self.device).eval()
         if self.device.type == "cuda":
+            # let MIOpen time its solvers per conv shape once (find mode) instead of the immediate-mode heuristic:
+            # 2D net 20.9 -> 18.2 ms, 3D net 267 -> 205 ms on MI355X; the search runs during the first call per shape
+            torch.backends.cudnn.benchmark = True
             self.net = self.net.to(memory_format=torch.channels_last if config.n_dim == 2 else torch.channels_last_3d)
 
     # the seam where the reference calls keras_model.predict (base.py:408-410)
