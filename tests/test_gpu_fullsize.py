@@ -1,0 +1,107 @@
+"""GPU: BASELINE.json full-size workloads checked through size-independent properties and the calibration counts the
+survey measured with the compiled reference (SURVEY.md section 8d generator specification)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_nms2d_2048_count_idempotence_and_order():
+    """S2D-uniform 2048^2: 416 700 candidates -> 25 628 survivors with the reference;
+    NMS of the survivors keeps all of them (idempotence); survivors are pairwise below the threshold by construction."""
+    from oracle import synth
+    from stardist_amd.lib import stardist2d as sd2
+    d, p, s = synth.s2d_uniform(2048, 2048)
+    assert len(d) == 416700
+    keep = sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4))
+    assert int(keep.sum()) == 25628
+    assert keep[0]                                   # the best candidate always survives
+    keep2 = sd2.c_non_max_suppression_inds(d[keep], p[keep], 1, 1, 0, np.float32(0.4))
+    assert keep2.all()
+    # appending suppressed candidates at the end (lowest rank) cannot change who survives among the first ones
+    sup = np.flatnonzero(~keep)[:5000]
+    d3 = np.concatenate([d[keep], d[sup]]); p3 = np.concatenate([p[keep], p[sup]])
+    keep3 = sd2.c_non_max_suppression_inds(d3, p3, 1, 1, 0, np.float32(0.4))
+    assert keep3[:int(keep.sum())].all() and not keep3[int(keep.sum()):].any()
+
+
+def test_nms2d_1024_bit_exact_vs_reference(refmods):
+    from oracle import synth
+    from stardist_amd.lib import stardist2d as sd2
+    d, p, s = synth.s2d_uniform(1024, 1024)
+    ref_keep = refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4))
+    keep = sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4))
+    assert (len(d), int(ref_keep.sum())) == (104580, 6439)
+    assert np.array_equal(keep, ref_keep)
+
+
+@pytest.mark.parametrize("R", [64, 100])
+def test_nms2d_many_rays_vs_reference(refmods, R):
+    """n_rays > 32 goes through the larger-capacity kernel instantiations"""
+    from oracle import synth
+    from stardist_amd.lib import stardist2d as sd2
+    d, p, s = synth.s2d_uniform(200, 220, n_rays=R, radius=14, noise=0.3)
+    ref_keep = refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4))
+    keep = sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4))
+    assert np.array_equal(keep, ref_keep)
+
+
+def test_raster2d_label_equals_polygon_mask():
+    """the reference's tests/test_big.py:202-213 property: with non-overlapping painting order, label i is exactly the
+    mask of polygon i where no later polygon covers it; checked via the oracle port on the NMS survivors of a 512^2 tile"""
+    from oracle import port, synth
+    from stardist_amd.lib import stardist2d as sd2
+    d, p, s = synth.s2d_uniform(512, 512)
+    keep = sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4))
+    d, p, s = d[keep], p[keep], s[keep]
+    coord = port.dist_to_coord(d, p)
+    ind = np.argsort(s, kind="stable")
+    lbl = sd2.c_polygons_to_label(coord[ind], ind.astype(np.int32), (512, 512))
+    assert np.array_equal(lbl, port.polygons_to_label(d, p, (512, 512), prob=s))
+    top = int(np.argmax(s))                          # the best polygon is painted last: its label is its full mask
+    rr, cc = port.polygon(coord[top, 0], coord[top, 1], (512, 512))
+    m = np.zeros((512, 512), bool); m[rr, cc] = True
+    assert np.array_equal(lbl == top + 1, m)
+
+
+def test_nms3d_256_calibration_count_and_raster():
+    """S3D-nuclei 256^3: 150 606 candidates -> 1 328 survivors with the reference"""
+    from oracle import synth
+    from stardist_amd.lib import stardist3d as sd3
+    from stardist_amd.rays3d import Rays_GoldenSpiral
+    rays = Rays_GoldenSpiral(96)
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    d, p, s, nobj = synth.s3d_nuclei(256, V)
+    assert (len(d), nobj) == (150606, 1331)
+    keep = sd3.c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(0.3))
+    assert int(keep.sum()) == 1328
+    keep2 = sd3.c_non_max_suppression_inds(d[keep], p[keep], V, F, s[keep], 1, 1, 0, np.float32(0.3))
+    assert keep2.all()
+    lbl = sd3.c_polyhedron_to_label(d[keep], p[keep], V, F, np.arange(1, keep.sum() + 1, dtype=np.int32), 0, 0, 0, 0, (256, 256, 256))
+    assert lbl.shape == (256, 256, 256) and lbl.max() == keep.sum()
+    # every surviving centre is labelled with its own id unless an earlier (higher-scored) polyhedron covers it
+    own = lbl[tuple(p[keep].astype(int).T)]
+    assert (own > 0).all() and (own <= np.arange(1, keep.sum() + 1)).all()
+
+
+def test_predict_instances_dense_equals_sparse_and_big_equals_whole():
+    """reference properties tests/test_model2D.py:442-450 (dense == sparse) and tests/test_big.py:86-117 (big == whole image:
+    same objects), on the network's own output"""
+    import torch
+    import bench
+    from oracle import synth
+    from stardist_amd.models import Config2D, StarDist2D
+    dev = torch.device("cuda:0")
+    img = synth.s2d_nuclei_image(512, 512, seed=5)
+    model = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
+    bench.calibrate_heads(model, torch.from_numpy(img).to(dev), frac=0.03)
+    l1, r1 = model.predict_instances(img, sparse=True)
+    l2, r2 = model.predict_instances(img, sparse=False)
+    assert np.array_equal(l1, l2) and np.array_equal(r1["points"], r2["points"]) and np.allclose(r1["coord"], r2["coord"])
+    l3, r3 = model.predict_instances(img, n_tiles=(2, 2))
+    assert len(r3["prob"]) == len(r1["prob"]) and (l3 > 0).sum() == pytest.approx((l1 > 0).sum(), rel=1e-3)
+    lb, rb = model.predict_instances_big(img, axes="YX", block_size=256, min_overlap=64, context=64, show_progress=False)
+    assert lb.shape == l1.shape
+    a = np.array(sorted(map(tuple, r1["points"]))); b = np.array(sorted(map(tuple, rb["points"])))
+    assert np.array_equal(a, b)
+    assert np.array_equal(lb > 0, l1 > 0)
