@@ -101,7 +101,8 @@ void _LIB_non_maximum_suppression_sparse(const float* scores, const float* dist,
                                          const int verbose, bool* result);
 /* stats: optional int64[16]: {0 upper-bound tests, 1 lower-bound tests, 2 kernel-volume calls, 3 render calls,
  * 4 greedy rounds, 5 neighbour entries, 6 suppressed by kernel stage, 7 suppressed by render stage,
- * 8 stage-3 kernel ns, 9 stage-4 ns, 10 stage-5 ns, 11 hull-volume calls, 12 kept by hull stage, 13.. 0} */
+ * 8 stage-3 kernel ns, 9 stage-4 ns, 10 stage-5 ns, 11 hull-volume calls, 12 kept by hull stage,
+ * 13 half-space faces evaluated, 14 faces that needed the large-capacity fallback, 15 0} */
 int sd_nms3d_device(const float* d_scores, const float* d_dist, const float* d_points,
                     int n_polys, int n_rays, int n_faces, const float* d_verts,
                     const int* d_faces, float threshold, int use_bbox, int use_kdtree,

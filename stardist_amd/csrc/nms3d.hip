@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(256) k_round_decide3(const int* __restrict__ U
   }
 }
 
-struct Stats { unsigned long long upper, lower, kernel, render, kept_pre, sup_pre, sup_kernel, sup_render, convex, kept_convex, overflow; };
+struct Stats { unsigned long long upper, lower, kernel, render, kept_pre, sup_pre, sup_kernel, sup_render, convex, kept_convex, overflow, hiv_faces, hiv_fallback, hiv_list, hiv_clips, hiv_rest, lb_decided; };
 
 // emit: exact neighbour predicate + cascade stages 1 and 2 (:1199-1248)
 __global__ void __launch_bounds__(256) k_round_emit3(const int* __restrict__ K, int nK, unsigned char* __restrict__ state,
@@ -314,21 +314,37 @@ __device__ __forceinline__ bool hiv_clip(HivPoly& P, double a, double b, double 
   for (int v = 0; v < nq; ++v) { P.ps[v] = P.qs[v]; P.pt[v] = P.qt[v]; }
   return true;
 }
-__device__ double hiv_face_term(const double* __restrict__ hs, int M, int k, const double c[3], double L) {
-  // polygon of plane k clipped by all other half-spaces; returns area * height (height from c); NaN on overflow
+struct HivFrame { double uz, uy, ux, vz, vy, vx, oz, oy, ox, h; bool ok; };
+// in-plane frame of half-space k: origin = foot point of c, (u, v) orthonormal in the plane
+__device__ __forceinline__ HivFrame hiv_frame(const double* __restrict__ hs, int k, const double c[3]) {
+  HivFrame fr;
   const double nz = hs[4 * k], ny = hs[4 * k + 1], nx = hs[4 * k + 2], d = hs[4 * k + 3];
   const double nn = sqrt(nz * nz + ny * ny + nx * nx);
-  if (!(nn > 0)) return 0;
-  const double h = -(nz * c[0] + ny * c[1] + nx * c[2] + d) / nn;            // distance from c to the plane (>= 0)
+  fr.ok = nn > 0;
+  if (!fr.ok) { fr.uz = fr.uy = fr.ux = fr.vz = fr.vy = fr.vx = fr.oz = fr.oy = fr.ox = fr.h = 0; return fr; }
+  fr.h = -(nz * c[0] + ny * c[1] + nx * c[2] + d) / nn;                        // distance from c to the plane (>= 0)
   const double uz0 = nz / nn, uy0 = ny / nn, ux0 = nx / nn;                    // unit normal
-  const double oz = c[0] + h * uz0, oy = c[1] + h * uy0, ox = c[2] + h * ux0;  // foot point of c = in-plane origin
+  fr.oz = c[0] + fr.h * uz0; fr.oy = c[1] + fr.h * uy0; fr.ox = c[2] + fr.h * ux0;
   double az = 0, ay = 0, ax = 0;
   const double fz = fabs(uz0), fy = fabs(uy0), fx = fabs(ux0);
   if (fz <= fy && fz <= fx) az = 1; else if (fy <= fx) ay = 1; else ax = 1;
   double uz = ay * ux0 - ax * uy0, uy = ax * uz0 - az * ux0, ux = az * uy0 - ay * uz0;   // u = normalize(a x n), v = n x u
   const double un = sqrt(uz * uz + uy * uy + ux * ux);
   uz /= un; uy /= un; ux /= un;
-  const double vz = uy0 * ux - ux0 * uy, vy = ux0 * uz - uz0 * ux, vx = uz0 * uy - uy0 * uz;
+  fr.uz = uz; fr.uy = uy; fr.ux = ux;
+  fr.vz = uy0 * ux - ux0 * uy; fr.vy = ux0 * uz - uz0 * ux; fr.vx = uz0 * uy - uy0 * uz;
+  return fr;
+}
+#define HIV_LINE(fr, hs, m, a, b, e)                                                                         \
+  const double mz_ = hs[4 * (m)], my_ = hs[4 * (m) + 1], mx_ = hs[4 * (m) + 2], md_ = hs[4 * (m) + 3];       \
+  const double a = mz_ * fr.uz + my_ * fr.uy + mx_ * fr.ux, b = mz_ * fr.vz + my_ * fr.vy + mx_ * fr.vx,     \
+               e = mz_ * fr.oz + my_ * fr.oy + mx_ * fr.ox + md_;
+
+// Scratch-resident fallback (arbitrary polygons up to HIV_MAXP vertices); only used for the rare faces that exceed
+// the LDS capacities below.  Returns area * height (height from c); NaN on overflow.
+__device__ __noinline__ double hiv_face_term(const double* __restrict__ hs, int M, int k, const double c[3], double L) {
+  const HivFrame fr = hiv_frame(hs, k, c);
+  if (!fr.ok) return 0;
   HivPoly P;
   P.n = 4;
   P.ps[0] = -L; P.pt[0] = -L; P.ps[1] = L; P.pt[1] = -L; P.ps[2] = L; P.pt[2] = L; P.ps[3] = -L; P.pt[3] = L;
@@ -337,8 +353,7 @@ __device__ double hiv_face_term(const double* __restrict__ hs, int M, int k, con
   double dmin = 1e300;
   for (int m = 0; m < M; ++m) {
     if (m == k) continue;
-    const double mz = hs[4 * m], my = hs[4 * m + 1], mx = hs[4 * m + 2], md = hs[4 * m + 3];
-    const double a = mz * uz + my * uy + mx * ux, b = mz * vz + my * vy + mx * vx, e = mz * oz + my * oy + mx * ox + md;
+    HIV_LINE(fr, hs, m, a, b, e)
     const double nrm = sqrt(a * a + b * b);
     if (nrm > 0) dmin = fmin(dmin, fabs(e) / nrm);
   }
@@ -347,8 +362,7 @@ __device__ double hiv_face_term(const double* __restrict__ hs, int M, int k, con
   for (int pass = 0; pass < 2 && P.n > 0; ++pass) {
     for (int m = 0; m < M && P.n > 0; ++m) {
       if (m == k) continue;
-      const double mz = hs[4 * m], my = hs[4 * m + 1], mx = hs[4 * m + 2], md = hs[4 * m + 3];
-      const double a = mz * uz + my * uy + mx * ux, b = mz * vz + my * vy + mx * vx, e = mz * oz + my * oy + mx * ox + md;
+      HIV_LINE(fr, hs, m, a, b, e)
       const double n2 = a * a + b * b;
       const bool is_near = (n2 > 0) && (e * e <= near_lim * near_lim * n2);
       if (is_near != (pass == 0)) continue;
@@ -363,19 +377,299 @@ __device__ double hiv_face_term(const double* __restrict__ hs, int M, int k, con
   if (P.n < 3) return 0;
   double area2 = 0;
   for (int v = 0; v < P.n; ++v) { const int w = (v + 1 == P.n) ? 0 : v + 1; area2 += P.ps[v] * P.pt[w] - P.ps[w] * P.pt[v]; }
-  return 0.5 * fabs(area2) * h;
+  return 0.5 * fabs(area2) * fr.h;
+}
+
+// LDS-resident fast path.  Each lane owns one face; its polygon (<= HIV_CAPL vertices, lane-interleaved doubles) lives
+// in LDS, nothing in scratch.  Half-spaces are expected with UNIT normals (zero normals stay zero).  The polygon is
+// seeded by the (up to three) half-spaces of the faces that share an edge with this face -- known from the mesh topology
+// (kernels) or from the cached hull adjacency -- which localises it immediately; it is then re-centred and every other
+// half-space is rejected with one dot product (polygon inside the ball around its centre inside the half-space) before
+// the exact in-plane test.  A convex polygon cut by a line loses ONE cyclic run of vertices and gains two, which is
+// done in place.  Anything unusual (capacity, more than one run because of rounding) sets `fallback` and the caller
+// recomputes this face with the routine above.  The result does not depend on the clipping order (up to rounding).
+#define HIV_CAPL 16
+#define HIV_LCAP 40
+#define HIV_NONE 0xFFFFu
+struct HivLds {
+  double* S; double* T;                 // polygon vertices [HIV_CAPL][64]
+  unsigned short* list;                 // [HIV_LCAP][64] per-lane list of half-spaces that may cut the polygon
+  const unsigned short* seed;           // [M_orig][3]: original indices of the edge-adjacent half-spaces (HIV_NONE: unknown)
+  const unsigned short* pos;            // [M_orig]: original index -> index after culling (HIV_NONE: culled)
+  const unsigned short* orig;           // [M]: index after culling -> original index
+};
+static inline size_t hiv_poly_bytes() { return (size_t)2 * HIV_CAPL * 64 * sizeof(double) + (size_t)HIV_LCAP * 64 * sizeof(unsigned short); }
+__device__ __forceinline__ size_t hiv_poly_bytes_dev() { return (size_t)2 * HIV_CAPL * 64 * sizeof(double) + (size_t)HIV_LCAP * 64 * sizeof(unsigned short); }
+
+// returns false when the fallback is needed
+__device__ __forceinline__ bool hiv_clip_lds(const HivLds& W, int lane, int& n, double a, double b, double e) {
+  unsigned int in_mask = 0;
+  for (int v = 0; v < n; ++v) {
+    const double f = a * W.S[v * 64 + lane] + b * W.T[v * 64 + lane] + e;
+    if (f <= 0) in_mask |= 1u << v;
+  }
+  const unsigned int full = (1u << n) - 1u;
+  if (in_mask == full) return true;
+  if (in_mask == 0) { n = 0; return true; }
+  const unsigned int out = ~in_mask & full;
+  const unsigned int prev_out = ((out << 1) | (out >> (n - 1))) & full;     // bit i = out[i-1 cyclic]
+  const unsigned int starts = out & ~prev_out;
+  if (__popc(starts) != 1) return false;
+  const int i = __ffs((int)starts) - 1;        // first vertex of the outside run
+  const int k = __popc(out);                   // its length
+  const int nn = n - k + 2;
+  if (nn > HIV_CAPL) return false;
+  const int im1 = (i == 0) ? n - 1 : i - 1;
+  int j1 = i + k - 1; if (j1 >= n) j1 -= n;
+  int j2 = i + k; if (j2 >= n) j2 -= n;
+  double As, At, Bs, Bt;
+  {
+    const double sp = W.S[im1 * 64 + lane], tp = W.T[im1 * 64 + lane], sc = W.S[i * 64 + lane], tc = W.T[i * 64 + lane];
+    const double fp = a * sp + b * tp + e, fc = a * sc + b * tc + e;
+    const double w = fp / (fp - fc);
+    As = sp + w * (sc - sp); At = tp + w * (tc - tp);
+  }
+  {
+    const double sp = W.S[j1 * 64 + lane], tp = W.T[j1 * 64 + lane], sc = W.S[j2 * 64 + lane], tc = W.T[j2 * 64 + lane];
+    const double fp = a * sp + b * tp + e, fc = a * sc + b * tc + e;
+    const double w = fp / (fp - fc);
+    Bs = sp + w * (sc - sp); Bt = tp + w * (tc - tp);
+  }
+  if (i + k <= n) {                             // run does not wrap: [0,i) stays, A, B, then the tail [i+k, n)
+    const int shift = 2 - k;
+    if (shift < 0) { for (int v = i + k; v < n; ++v) { W.S[(v + shift) * 64 + lane] = W.S[v * 64 + lane]; W.T[(v + shift) * 64 + lane] = W.T[v * 64 + lane]; } }
+    else if (shift > 0) { for (int v = n - 1; v >= i + k; --v) { W.S[(v + 1) * 64 + lane] = W.S[v * 64 + lane]; W.T[(v + 1) * 64 + lane] = W.T[v * 64 + lane]; } }
+    W.S[i * 64 + lane] = As; W.T[i * 64 + lane] = At; W.S[(i + 1) * 64 + lane] = Bs; W.T[(i + 1) * 64 + lane] = Bt;
+  } else {                                      // run wraps: inside vertices are [w0, i)
+    const int w0 = i + k - n;
+    if (w0 > 0) for (int v = w0; v < i; ++v) { W.S[(v - w0) * 64 + lane] = W.S[v * 64 + lane]; W.T[(v - w0) * 64 + lane] = W.T[v * 64 + lane]; }
+    W.S[(n - k) * 64 + lane] = As; W.T[(n - k) * 64 + lane] = At; W.S[(n - k + 1) * 64 + lane] = Bs; W.T[(n - k + 1) * 64 + lane] = Bt;
+  }
+  n = nn;
+  return true;
+}
+
+__device__ __forceinline__ double hiv_rad2(const HivLds& W, int lane, int n) {
+  double r2 = 0;
+  for (int v = 0; v < n; ++v) { const double s = W.S[v * 64 + lane], t = W.T[v * 64 + lane]; r2 = fmax(r2, s * s + t * t); }
+  return r2;
+}
+
+__device__ __forceinline__ double hiv_face_term_lds(const double* __restrict__ hs, int M, int k, const double c[3], double L, const HivLds& W,
+                                                    int lane, bool& fallback, int* dbg) {
+#pragma clang fp contract(fast)
+  fallback = false;
+  HivFrame fr = hiv_frame(hs, k, c);
+  if (!fr.ok) return 0;
+  int sd[3];
+  {
+    const int o_ = W.orig[k];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const unsigned int t = W.seed[3 * o_ + q];
+      const unsigned int pp = (t == HIV_NONE) ? HIV_NONE : (unsigned int)W.pos[t];
+      sd[q] = (pp == HIV_NONE) ? -1 : (int)pp;
+    }
+  }
+  int n = 4;
+  W.S[0 * 64 + lane] = -L; W.T[0 * 64 + lane] = -L; W.S[1 * 64 + lane] = L; W.T[1 * 64 + lane] = -L;
+  W.S[2 * 64 + lane] = L; W.T[2 * 64 + lane] = L; W.S[3 * 64 + lane] = -L; W.T[3 * 64 + lane] = L;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    if (sd[q] < 0 || n == 0) continue;
+    HIV_LINE(fr, hs, sd[q], a, b, e)
+    if (!hiv_clip_lds(W, lane, n, a, b, e)) { fallback = true; return 0; }
+  }
+  if (n < 3) return 0;
+  {                                              // re-centre the in-plane frame on the polygon
+    double ms = 0, mt = 0;
+    for (int v = 0; v < n; ++v) { ms += W.S[v * 64 + lane]; mt += W.T[v * 64 + lane]; }
+    ms /= n; mt /= n;
+    for (int v = 0; v < n; ++v) { W.S[v * 64 + lane] -= ms; W.T[v * 64 + lane] -= mt; }
+    fr.oz += ms * fr.uz + mt * fr.vz; fr.oy += ms * fr.uy + mt * fr.vy; fr.ox += ms * fr.ux + mt * fr.vx;
+  }
+  double rad2 = hiv_rad2(W, lane, n);
+  const double radm = sqrt(rad2) * (1.0 + 1e-12);
+  // phase 1 (no divergence): half-spaces that do not contain the ball around the polygon go to this lane's list
+  int nl = 0, m_rest = M;
+  for (int m0 = 0; m0 < M; m0 += 4) {
+    double e4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = (m0 + q < M) ? m0 + q : M - 1;
+      e4[q] = hs[4 * m] * fr.oz + hs[4 * m + 1] * fr.oy + hs[4 * m + 2] * fr.ox + hs[4 * m + 3];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = m0 + q;
+      const bool cand = (m < M) && !(e4[q] + radm <= 0) && m != k && m != sd[0] && m != sd[1] && m != sd[2];
+      if (cand) {
+        if (nl < HIV_LCAP) { W.list[nl * 64 + lane] = (unsigned short)m; ++nl; }
+        else if (m < m_rest) m_rest = m;
+      }
+    }
+  }
+  dbg[0] += nl; if (m_rest < M) dbg[2] += 1;
+  // phase 2: every lane walks its own short list
+  for (int t = 0; t < nl && n > 0; ++t) {
+    const int m = W.list[t * 64 + lane];
+    HIV_LINE(fr, hs, m, a, b, e)
+    const double n2 = a * a + b * b;
+    if (e <= 0 && e * e >= rad2 * n2 * (1.0 + 1e-12)) continue;      // the trace line does not reach the polygon
+    dbg[1] += 1;
+    if (!hiv_clip_lds(W, lane, n, a, b, e)) { fallback = true; return 0; }
+    rad2 = hiv_rad2(W, lane, n);
+  }
+  // list overflow (rare): the remaining half-spaces one by one
+  for (int m = m_rest; m < M && n > 0; ++m) {
+    if (m == k || m == sd[0] || m == sd[1] || m == sd[2]) continue;
+    HIV_LINE(fr, hs, m, a, b, e)
+    const double n2 = a * a + b * b;
+    if (e <= 0 && e * e >= rad2 * n2 * (1.0 + 1e-12)) continue;
+    if (!hiv_clip_lds(W, lane, n, a, b, e)) { fallback = true; return 0; }
+    rad2 = hiv_rad2(W, lane, n);
+  }
+  if (n < 3) return 0;
+  double area2 = 0;
+  const double s0 = W.S[lane], t0 = W.T[lane];
+  double sp = s0, tp = t0;
+  for (int v = 1; v < n; ++v) { const double sc = W.S[v * 64 + lane], tc = W.T[v * 64 + lane]; area2 += sp * tc - sc * tp; sp = sc; tp = tc; }
+  area2 += sp * t0 - s0 * tp;
+  return 0.5 * fabs(area2) * fr.h;
+}
+
+// sum of the face terms of the M half-spaces in hs (one wave); NaN when a face exceeded even the fallback capacity
+__device__ __forceinline__ double hiv_volume_wave(const double* __restrict__ hs, int M, const double c[3], double L, const HivLds& W, int lane,
+                                                  Stats* st) {
+  double acc = 0;
+  int nfb = 0;
+  int dbg[3] = {0, 0, 0};
+  for (int k0 = 0; k0 < M; k0 += 64) {
+    const int k = k0 + lane;
+    if (k < M) {
+      bool fb;
+      double term = hiv_face_term_lds(hs, M, k, c, L, W, lane, fb, dbg);
+      if (fb) { term = hiv_face_term(hs, M, k, c, L); ++nfb; }
+      acc += term;
+    }
+  }
+  for (int o = 32; o; o >>= 1) {
+    acc += __shfl_xor(acc, o); nfb += __shfl_xor(nfb, o);
+    dbg[0] += __shfl_xor(dbg[0], o); dbg[1] += __shfl_xor(dbg[1], o); dbg[2] += __shfl_xor(dbg[2], o);
+  }
+  if (lane == 0) {
+    atomicAdd(&st->hiv_faces, (unsigned long long)M); if (nfb) atomicAdd(&st->hiv_fallback, (unsigned long long)nfb);
+    atomicAdd(&st->hiv_list, (unsigned long long)dbg[0]); atomicAdd(&st->hiv_clips, (unsigned long long)dbg[1]);
+    if (dbg[2]) atomicAdd(&st->hiv_rest, (unsigned long long)dbg[2]);
+  }
+  return acc / 3.0;
+}
+
+// Cull + compact + normalise the M half-spaces in hs (one wave, in place).  A half-space of one polyhedron that contains
+// the whole outer ball of the OTHER polyhedron cannot bound the intersection (exact, 1e-6 safety margin).
+// `second(k)` tells whether original half-space k belongs to polyhedron 2.  Fills pos/orig; returns the kept count.
+// The kept half-spaces are also translated so that the interior point c becomes the origin (offset = n.c + d < 0).
+template <class Second>
+__device__ __forceinline__ int hiv_cull_wave(double* hs, int M, const double b1[4], const double b2[4], const double c[3], unsigned short* pos,
+                                             unsigned short* orig, int lane, Second second) {
+  int kept = 0;
+  for (int k0 = 0; k0 < M; k0 += 64) {
+    const int k = k0 + lane;
+    bool keep = false;
+    double h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+    if (k < M) {
+      h0 = hs[4 * k]; h1 = hs[4 * k + 1]; h2 = hs[4 * k + 2]; h3 = hs[4 * k + 3];
+      const double* ob = second(k) ? b1 : b2;      // plane of polyhedron 2 vs ball of polyhedron 1 and vice versa
+      const double nn = sqrt(h0 * h0 + h1 * h1 + h2 * h2);
+      keep = !(h0 * ob[0] + h1 * ob[1] + h2 * ob[2] + h3 + nn * ob[3] <= 0);
+      h3 += h0 * c[0] + h1 * c[1] + h2 * c[2];
+      if (nn > 0) { h0 /= nn; h1 /= nn; h2 /= nn; h3 /= nn; }
+    }
+    const unsigned long long mk = __ballot(keep);
+    __syncthreads();                               // all reads of this chunk done before compacted writes land
+    if (k < M) {
+      if (keep) {
+        const int p_ = kept + __popcll(mk & ((1ull << lane) - 1));
+        hs[4 * p_] = h0; hs[4 * p_ + 1] = h1; hs[4 * p_ + 2] = h2; hs[4 * p_ + 3] = h3;
+        pos[k] = (unsigned short)p_; orig[p_] = (unsigned short)k;
+      } else pos[k] = (unsigned short)HIV_NONE;
+    }
+    kept += __popcll(mk);
+    __syncthreads();
+  }
+  return kept;
+}
+
+// Rigorous lower bound of the volume of the convex region K = {x : n_m.x + d_m <= 0 for all m} (origin strictly inside):
+// the boundary point of K along every ray direction is in K, K is convex, hence every tetrahedron (0, w_a, w_b, w_c)
+// over a triangle of the ray mesh lies in K; these tetrahedra are cones over a triangulation of the sphere of directions
+// and do not overlap (the ray mesh is the hull of the ray directions and contains the origin, rays.py).  ~100x cheaper
+// than the exact volume and decisive for the typical near-duplicate pair.  wv: LDS, 3R doubles.
+__device__ __forceinline__ double hiv_lower_bound_wave(const double* __restrict__ hs, int M, const float* __restrict__ verts,
+                                                       const int* __restrict__ faces, int R, int F, double* wv, int lane) {
+#pragma clang fp contract(fast)
+  for (int k = lane; k < R; k += 64) {
+    const double dz = (double)verts[3 * k], dy = (double)verts[3 * k + 1], dx = (double)verts[3 * k + 2];
+    double ne_b = 1.0, q_b = 0.0;                      // boundary distance t = ne_b / q_b, kept as a fraction
+    for (int m = 0; m < M; ++m) {
+      const double q = hs[4 * m] * dz + hs[4 * m + 1] * dy + hs[4 * m + 2] * dx;
+      const double ne = -hs[4 * m + 3];
+      if (q > 0 && ne * q_b < ne_b * q) { ne_b = ne; q_b = q; }
+    }
+    const double t = (q_b > 0) ? ne_b / q_b : 0.0;
+    wv[3 * k] = t * dz; wv[3 * k + 1] = t * dy; wv[3 * k + 2] = t * dx;
+  }
+  __syncthreads();
+  double acc = 0;
+  for (int f = lane; f < F; f += 64) {
+    const int ia = faces[3 * f], ib = faces[3 * f + 1], ic = faces[3 * f + 2];
+    const double az = wv[3 * ia], ay = wv[3 * ia + 1], ax = wv[3 * ia + 2];
+    const double bz = wv[3 * ib], by = wv[3 * ib + 1], bx = wv[3 * ib + 2];
+    const double cz = wv[3 * ic], cy = wv[3 * ic + 1], cx = wv[3 * ic + 2];
+    acc += fabs(az * (by * cx - bx * cy) + ay * (bx * cz - bz * cx) + ax * (bz * cy - by * cz));
+  }
+  for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+  __syncthreads();
+  return acc / 6.0;
+}
+
+// edge adjacency of the ray mesh: adj[3f + e] = face sharing edge e = (v_e, v_{e+1}) of face f, or -1
+__global__ void k_face_adj(const int* __restrict__ faces, int F, int* __restrict__ adj) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const int v[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
+  for (int e = 0; e < 3; ++e) {
+    const int x = v[e], y = v[(e + 1) % 3];
+    int found = -1;
+    for (int g = 0; g < F && found < 0; ++g) {
+      if (g == f) continue;
+      const int a = faces[3 * g], b = faces[3 * g + 1], c = faces[3 * g + 2];
+      if ((a == x || b == x || c == x) && (a == y || b == y || c == y)) found = g;
+    }
+    adj[3 * f + e] = found;
+  }
 }
 
 __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, unsigned int nPairs, const float* __restrict__ dist,
                                                const float* __restrict__ pts, const float* __restrict__ verts,
-                                               const int* __restrict__ faces, int R, int F, const float* __restrict__ volume, float thr,
-                                               unsigned char* __restrict__ state, int2* __restrict__ pairs5, unsigned int* pair5Count,
-                                               Stats* st) {
+                                               const int* __restrict__ faces, const int* __restrict__ faceAdj, int R, int F,
+                                               const float* __restrict__ volume, float thr, unsigned char* __restrict__ state,
+                                               int2* __restrict__ pairs5, unsigned int* pair5Count, Stats* st, unsigned int wsBytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* hs = (double*)smem;                 // 2F * 4
-  float* pv1 = (float*)(hs + 8 * F);          // 3R
+  float* pv1 = (float*)(hs + 8 * F);          // 3R   (dead once hs is built: aliased by the polygon workspace)
   float* pv2 = pv1 + 3 * R;                   // 3R
+  unsigned short* seed = (unsigned short*)(smem + (size_t)8 * F * sizeof(double) + (wsBytes & 0x7FFFFFFFu));   // 2F * 3
+  unsigned short* pos = seed + 6 * F;         // 2F
+  unsigned short* orig = pos + 2 * F;         // 2F
+  HivLds W;
+  W.S = hs + 8 * F; W.T = W.S + HIV_CAPL * 64; W.list = (unsigned short*)(W.T + HIV_CAPL * 64); W.seed = seed; W.pos = pos; W.orig = orig;
   const int lane = threadIdx.x;
+  for (int idx = lane; idx < 6 * F; idx += 64) {            // half-space 2f+w belongs to face f of polyhedron w (interleaved)
+    const int o_ = idx / 3, e_ = idx - 3 * o_;
+    const int a_ = faceAdj[3 * (o_ >> 1) + e_];
+    seed[idx] = (unsigned short)(a_ < 0 ? HIV_NONE : (unsigned int)(2 * a_ + (o_ & 1)));
+  }
   for (unsigned int p = blockIdx.x; p < nPairs; p += gridDim.x) {
     const int2 ij = pairs[p];
     __syncthreads();
@@ -413,37 +707,24 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
       }
       for (int o = 32; o; o >>= 1) { ext1 = fmax(ext1, __shfl_xor(ext1, o)); ext2 = fmax(ext2, __shfl_xor(ext2, o)); }
       ext = fmax(ext1, ext2);
-      // cull: the intersection lies inside both polyhedra, hence inside the outer ball of the OTHER polyhedron; a
-      // half-space that contains that whole ball cannot bound the intersection (exact, 1e-9 safety margin).
       __syncthreads();
       {
         const double b1[4] = {(double)c1[0], (double)c1[1], (double)c1[2], ext1 * (1.0 + 1e-6) + 1e-6};
         const double b2[4] = {(double)c2[0], (double)c2[1], (double)c2[2], ext2 * (1.0 + 1e-6) + 1e-6};
-        int kept = 0;
-        for (int k0 = 0; k0 < M; k0 += 64) {
-          const int k = k0 + lane;
-          bool keep = false;
-          double h0 = 0, h1 = 0, h2 = 0, h3 = 0;
-          if (k < M) {
-            h0 = hs[4 * k]; h1 = hs[4 * k + 1]; h2 = hs[4 * k + 2]; h3 = hs[4 * k + 3];
-            const double* ob = (k & 1) ? b1 : b2;      // plane of polyhedron 2 (odd index) vs ball of polyhedron 1 and vice versa
-            const double nn = sqrt(h0 * h0 + h1 * h1 + h2 * h2);
-            keep = !(h0 * ob[0] + h1 * ob[1] + h2 * ob[2] + h3 + nn * ob[3] <= 0);
-          }
-          const unsigned long long mk = __ballot(keep);
-          __syncthreads();                               // all reads of this chunk done before compacted writes land
-          if (keep) { const int pos = kept + __popcll(mk & ((1ull << lane) - 1)); hs[4 * pos] = h0; hs[4 * pos + 1] = h1; hs[4 * pos + 2] = h2; hs[4 * pos + 3] = h3; }
-          kept += __popcll(mk);
-          __syncthreads();
-        }
-        Mc = kept;
+        Mc = hiv_cull_wave(hs, M, b1, b2, c, pos, orig, lane, [](int k) { return (k & 1) != 0; });
       }
-      const double sep = sqrt((double)(c1[0] - c2[0]) * (c1[0] - c2[0]) + (double)(c1[1] - c2[1]) * (c1[1] - c2[1]) + (double)(c1[2] - c2[2]) * (c1[2] - c2[2]));
-      const double L = 4.0 * (2.0 * ext + sep + 1.0);
-      double acc = 0;
-      for (int k = lane; k < Mc; k += 64) acc += hiv_face_term(hs, Mc, k, c, L);
-      for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
-      vol = acc / 3.0;
+      const double A_min_d = (double)fminf(volume[ij.x], volume[ij.y]) + 1e-10;
+      const double thr_hi = (double)thr + 1e-5 * fabs((double)thr) + 1e-7;
+      const double zero3[3] = {0, 0, 0};
+      const double lb = hiv_lower_bound_wave(hs, Mc, verts, faces, R, F, W.S, lane);
+      if (lb * (1.0 - 1e-9) / A_min_d > thr_hi && !(wsBytes >> 31)) {
+        vol = lb;                                       // certainly above the threshold: same decision as the exact volume
+        if (lane == 0) atomicAdd(&st->lb_decided, 1ull);
+      } else {
+        const double sep = sqrt((double)(c1[0] - c2[0]) * (c1[0] - c2[0]) + (double)(c1[1] - c2[1]) * (c1[1] - c2[1]) + (double)(c1[2] - c2[2]) * (c1[2] - c2[2]));
+        const double L = 4.0 * (2.0 * ext + sep + 1.0);
+        vol = hiv_volume_wave(hs, Mc, zero3, L, W, lane, st);
+      }
     }
     if (lane == 0) {
       atomicAdd(&st->kernel, 1ull);
@@ -464,9 +745,10 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
 // each lane owns a triple, rejects it against 8 extreme "probe" vertices, survivors are verified by the whole wave.
 __global__ void __launch_bounds__(64) k_hull(const int* __restrict__ hullList, unsigned int nList, const float* __restrict__ dist,
                                              const float* __restrict__ pts, const float* __restrict__ verts, int R, int cap,
-                                             double* __restrict__ hullPlanes, int* __restrict__ hullCount) {
+                                             double* __restrict__ hullPlanes, unsigned short* __restrict__ hullAdj, int* __restrict__ hullCount) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* pv = (double*)smem;            // 3R doubles
+  unsigned int* tri = (unsigned int*)(pv + 3 * R);   // cap packed facets a | b << 10 | c << 20
   __shared__ int s_probe[8];
   __shared__ int s_n;
   const int lane = threadIdx.x;
@@ -542,10 +824,32 @@ __global__ void __launch_bounds__(64) k_hull(const int* __restrict__ hullList, u
                 const double sg = anyp ? -1.0 : 1.0;   // outward normal: every vertex satisfies n.(p-a) <= 0
                 out[4 * pos_i] = sg * tz; out[4 * pos_i + 1] = sg * ty; out[4 * pos_i + 2] = sg * tx;
                 out[4 * pos_i + 3] = -(sg * tz * az + sg * ty * ay + sg * tx * ax);
+                tri[pos_i] = (unsigned int)a | ((unsigned int)b << 10) | ((unsigned int)cc << 20);
               }
               s_n = pos_i + 1;
             }
           }
+        }
+      }
+    }
+    __syncthreads();
+    // edge adjacency of the facets (seeds of the intersection-volume routine; a hint, not needed for correctness)
+    if (s_n >= 4 && s_n <= cap) {
+      const int nf = s_n;
+      unsigned short* adj = hullAdj + (size_t)cand * cap * 3;
+      for (int t = lane; t < nf; t += 64) {
+        const unsigned int tt = tri[t];
+        const unsigned int v[3] = {tt & 1023u, (tt >> 10) & 1023u, (tt >> 20) & 1023u};
+        for (int e = 0; e < 3; ++e) {
+          const unsigned int x = v[e], y = v[(e + 1) % 3];
+          unsigned int found = HIV_NONE;
+          for (int u = 0; u < nf && found == HIV_NONE; ++u) {
+            if (u == t) continue;
+            const unsigned int uu = tri[u];
+            const unsigned int a_ = uu & 1023u, b_ = (uu >> 10) & 1023u, c_ = (uu >> 20) & 1023u;
+            if ((a_ == x || b_ == x || c_ == x) && (a_ == y || b_ == y || c_ == y)) found = (unsigned int)u;
+          }
+          adj[3 * t + e] = (unsigned short)found;
         }
       }
     }
@@ -565,11 +869,18 @@ __global__ void k_hull_mark(const int2* __restrict__ pairs, unsigned int nPairs,
 }
 
 __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, unsigned int nPairs, const float* __restrict__ dist,
-                                               const float* __restrict__ pts, int R, int cap, const double* __restrict__ hullPlanes,
-                                               const int* __restrict__ hullCount, const float* __restrict__ volume, float thr,
-                                               int2* __restrict__ pairs5, unsigned int* pair5Count, Stats* st) {
+                                               const float* __restrict__ pts, const float* __restrict__ verts,
+                                               const int* __restrict__ faces, int R, int F, int cap, const double* __restrict__ hullPlanes,
+                                               const unsigned short* __restrict__ hullAdj, const int* __restrict__ hullCount,
+                                               const float* __restrict__ volume, float thr,
+                                               int2* __restrict__ pairs5, unsigned int* pair5Count, Stats* st, int no_lb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* hs = (double*)smem;                   // 2*cap*4
+  unsigned short* seed = (unsigned short*)(smem + (size_t)8 * cap * sizeof(double) + hiv_poly_bytes_dev());   // 2*cap*3
+  unsigned short* pos = seed + 6 * cap;         // 2*cap
+  unsigned short* orig = pos + 2 * cap;         // 2*cap
+  HivLds W;
+  W.S = hs + 8 * cap; W.T = W.S + HIV_CAPL * 64; W.list = (unsigned short*)(W.T + HIV_CAPL * 64); W.seed = seed; W.pos = pos; W.orig = orig;
   const int lane = threadIdx.x;
   for (unsigned int p = blockIdx.x; p < nPairs; p += gridDim.x) {
     const int2 ij = pairs[p];
@@ -584,6 +895,10 @@ __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, u
       const double* h2 = hullPlanes + (size_t)ij.y * cap * 4;
       for (int k = lane; k < 4 * n1; k += 64) hs[k] = h1[k];
       for (int k = lane; k < 4 * n2; k += 64) hs[4 * n1 + k] = h2[k];
+      const unsigned short* a1 = hullAdj + (size_t)ij.x * cap * 3;
+      const unsigned short* a2 = hullAdj + (size_t)ij.y * cap * 3;
+      for (int k = lane; k < 3 * n1; k += 64) seed[k] = a1[k];
+      for (int k = lane; k < 3 * n2; k += 64) { const unsigned int t = a2[k]; seed[3 * n1 + k] = (unsigned short)(t == HIV_NONE ? HIV_NONE : t + n1); }
     }
     __syncthreads();
     double c[3];
@@ -604,31 +919,20 @@ __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, u
       const double sep = sqrt((double)(c1[0] - c2[0]) * (c1[0] - c2[0]) + (double)(c1[1] - c2[1]) * (c1[1] - c2[1]) + (double)(c1[2] - c2[2]) * (c1[2] - c2[2]));
       const double L = 4.0 * (2.0 * ext + sep + 1.0);
       // cull half-spaces of one hull that contain the other polyhedron's outer ball (which contains its hull)
-      int Mc = 0;
+      int Mc;
       {
         const double b1[4] = {(double)c1[0], (double)c1[1], (double)c1[2], ext1 * (1.0 + 1e-6) + 1e-6};
         const double b2[4] = {(double)c2[0], (double)c2[1], (double)c2[2], ext2 * (1.0 + 1e-6) + 1e-6};
-        for (int k0 = 0; k0 < M; k0 += 64) {
-          const int k = k0 + lane;
-          bool keep = false;
-          double h0 = 0, h1 = 0, h2 = 0, h3 = 0;
-          if (k < M) {
-            h0 = hs[4 * k]; h1 = hs[4 * k + 1]; h2 = hs[4 * k + 2]; h3 = hs[4 * k + 3];
-            const double* ob = (k >= n1) ? b1 : b2;
-            const double nn = sqrt(h0 * h0 + h1 * h1 + h2 * h2);
-            keep = !(h0 * ob[0] + h1 * ob[1] + h2 * ob[2] + h3 + nn * ob[3] <= 0);
-          }
-          const unsigned long long mk = __ballot(keep);
-          __syncthreads();
-          if (keep) { const int pos = Mc + __popcll(mk & ((1ull << lane) - 1)); hs[4 * pos] = h0; hs[4 * pos + 1] = h1; hs[4 * pos + 2] = h2; hs[4 * pos + 3] = h3; }
-          Mc += __popcll(mk);
-          __syncthreads();
-        }
+        Mc = hiv_cull_wave(hs, M, b1, b2, c, pos, orig, lane, [n1](int k) { return k >= n1; });
       }
-      double acc = 0;
-      for (int k = lane; k < Mc; k += 64) acc += hiv_face_term(hs, Mc, k, c, L);
-      for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
-      vol = acc / 3.0;
+      const double A_min_d = (double)fminf(volume[ij.x], volume[ij.y]) + 1e-10;
+      const double thr_hi = (double)thr + 1e-5 * fabs((double)thr) + 1e-7;
+      const double zero3[3] = {0, 0, 0};
+      const double lb = hiv_lower_bound_wave(hs, Mc, verts, faces, R, F, W.S, lane);
+      if (lb * (1.0 - 1e-9) / A_min_d > thr_hi && !no_lb) {
+        vol = lb;                                       // certainly above the threshold -> render stage, as with the exact volume
+        if (lane == 0) atomicAdd(&st->lb_decided, 1ull);
+      } else vol = hiv_volume_wave(hs, Mc, zero3, L, W, lane, st);
     }
     if (lane == 0) {
       atomicAdd(&st->convex, 1ull);
@@ -731,9 +1035,12 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   }
   if (N <= 0) return 0;
   if (R < 4 || F < 4) { sd::set_error("sd_nms3d: need n_rays >= 4 and n_faces >= 4"); return -1; }
-  const size_t lds3 = (size_t)8 * F * sizeof(double) + (size_t)6 * R * sizeof(float);
+  if (R > 896) { sd::set_error("sd_nms3d: n_rays must be <= 896"); return -1; }
+  const size_t hivBytes = hiv_poly_bytes();
+  const size_t ws3 = ((size_t)3 * R * sizeof(double) > hivBytes ? (((size_t)3 * R * sizeof(double) + 15) & ~(size_t)15) : hivBytes);   // >= 6R floats
+  const size_t lds3 = (size_t)8 * F * sizeof(double) + ws3 + (size_t)10 * F * sizeof(unsigned short);
   const size_t lds5 = (size_t)6 * R * sizeof(float) + (size_t)3 * F * sizeof(int);
-  const size_t lds4 = (size_t)16 * R * sizeof(double);
+  const size_t lds4 = (size_t)16 * R * sizeof(double) + hivBytes + (size_t)20 * R * sizeof(unsigned short);   // cap = 2R
   if (lds3 > 150 * 1024 || lds5 > 150 * 1024 || lds4 > 150 * 1024) { sd::set_error("sd_nms3d: n_rays/n_faces too large for LDS staging"); return -1; }
   sd::Arena& A = sd::arena();
   if (A.begin(s)) return -1;
@@ -741,6 +1048,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   if (stats) { SD_CHECK(hipEventCreate(&ev0)); SD_CHECK(hipEventCreate(&ev1)); }
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evguard{ev0, ev1};
   double ns3 = 0, ns4 = 0, ns5 = 0;
+  const bool trace = getenv("SD_TRACE") != nullptr;
   if (!use_kdtree && !use_bbox && threshold < 0) {   // every (0, j) passes and iou >= 0 > thr at stage 2
     SD_CHECK(hipMemsetAsync(d_keep, 0, N, s));
     SD_CHECK(hipMemsetAsync(d_keep, 1, 1, s));
@@ -857,6 +1165,11 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   int* hullCount = A.take_n<int>(N);
   int* hullList = A.take_n<int>(N);
   double* hullPlanes = nullptr;                    // N * hullCap * 4 doubles, allocated on first use
+  unsigned short* hullAdj = nullptr;               // N * hullCap * 3
+  int* faceAdj = A.take_n<int>((size_t)3 * F);
+  if (!faceAdj) return -1;
+  hipLaunchKernelGGL(k_face_adj, dim3(sd::div_up(F, 64)), dim3(64), 0, s, d_faces, F, faceAdj);
+  SD_LAUNCH_CHECK();
   if (!hullState || !hullCount || !hullList) return -1;
   SD_CHECK(hipMemsetAsync(hullState, 0, (size_t)N * sizeof(int), s));
   SD_CHECK(hipMemsetAsync(waitOn, 0xFF, (size_t)N * sizeof(int), s));
@@ -883,34 +1196,40 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
       if (h.nP3 > 0) {
         const unsigned int b3 = h.nP3 < 16384u ? h.nP3 : 16384u;
         if (stats) SD_CHECK(hipEventRecord(ev0, s));
-        hipLaunchKernelGGL(k_stage3, dim3(b3), dim3(64), lds3, s, pairs3, h.nP3, d_dist, d_points, d_verts, d_faces, R, F, volume, threshold,
-                           state, pairs4, &d_cnt->nP4, d_st);
+        hipLaunchKernelGGL(k_stage3, dim3(b3), dim3(64), lds3, s, pairs3, h.nP3, d_dist, d_points, d_verts, d_faces, faceAdj, R, F, volume,
+                           threshold, state, pairs4, &d_cnt->nP4, d_st, (unsigned int)ws3 | (getenv("SD_NMS3D_NO_LB") ? 0x80000000u : 0u));
         SD_LAUNCH_CHECK();
         if (stats) SD_CHECK(hipEventRecord(ev1, s));
         SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
         SD_CHECK(hipStreamSynchronize(s));
-        if (stats) { float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns3 += ms * 1e6; }
+        if (stats) { float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns3 += ms * 1e6;
+                     if (trace) printf("round %d: nU=%d nK=%d stage3 pairs=%u %.3f ms -> stage4 pairs=%u\n", rounds, h.nU, h.nK, h.nP3, ms, h.nP4); }
         if (h.nP4 > 0) {
           const unsigned int b4 = h.nP4 < 16384u ? h.nP4 : 16384u;
           if (stats) SD_CHECK(hipEventRecord(ev0, s));
-          if (!hullPlanes) { hullPlanes = A.take_n<double>((size_t)N * hullCap * 4); if (!hullPlanes) return -1; }
+          if (!hullPlanes) {
+            hullPlanes = A.take_n<double>((size_t)N * hullCap * 4);
+            hullAdj = A.take_n<unsigned short>((size_t)N * hullCap * 3);
+            if (!hullPlanes || !hullAdj) return -1;
+          }
           SD_CHECK(hipMemsetAsync(&d_cnt->nHull, 0, sizeof(unsigned int), s));
           hipLaunchKernelGGL(k_hull_mark, dim3(sd::div_up(h.nP4, 256)), dim3(256), 0, s, pairs4, h.nP4, hullState, hullList, &d_cnt->nHull);
           SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
           SD_CHECK(hipStreamSynchronize(s));
           if (h.nHull > 0) {
             const unsigned int bh = h.nHull < 32768u ? h.nHull : 32768u;
-            hipLaunchKernelGGL(k_hull, dim3(bh), dim3(64), (size_t)3 * R * sizeof(double), s, hullList, h.nHull, d_dist, d_points, d_verts, R, hullCap,
-                               hullPlanes, hullCount);
+            hipLaunchKernelGGL(k_hull, dim3(bh), dim3(64), (size_t)3 * R * sizeof(double) + (size_t)hullCap * sizeof(unsigned int), s, hullList,
+                               h.nHull, d_dist, d_points, d_verts, R, hullCap, hullPlanes, hullAdj, hullCount);
             SD_LAUNCH_CHECK();
           }
-          hipLaunchKernelGGL(k_stage4, dim3(b4), dim3(64), lds4, s, pairs4, h.nP4, d_dist, d_points, R, hullCap, hullPlanes, hullCount, volume,
-                             threshold, pairs5, &d_cnt->nP5, d_st);
+          hipLaunchKernelGGL(k_stage4, dim3(b4), dim3(64), lds4, s, pairs4, h.nP4, d_dist, d_points, d_verts, d_faces, R, F, hullCap, hullPlanes, hullAdj, hullCount,
+                             volume, threshold, pairs5, &d_cnt->nP5, d_st, getenv("SD_NMS3D_NO_LB") ? 1 : 0);
           SD_LAUNCH_CHECK();
           if (stats) SD_CHECK(hipEventRecord(ev1, s));
           SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
           SD_CHECK(hipStreamSynchronize(s));
-          if (stats) { float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns4 += ms * 1e6; }
+          if (stats) { float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns4 += ms * 1e6;
+                       if (trace) printf("         stage4 pairs=%u hulls=%u %.3f ms -> stage5 pairs=%u\n", h.nP4, h.nHull, ms, h.nP5); }
         }
         if (h.nP4 > 0 && h.nP5 > 0) {
           const unsigned int b5 = h.nP5 < 16384u ? h.nP5 : 16384u;
@@ -935,6 +1254,9 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
     stats[0] = (int64_t)hs_.upper; stats[1] = (int64_t)hs_.lower; stats[2] = (int64_t)hs_.kernel; stats[3] = (int64_t)hs_.render;
     stats[4] = rounds; stats[5] = totalNbr; stats[6] = (int64_t)hs_.sup_kernel; stats[7] = (int64_t)hs_.sup_render;
     stats[8] = (int64_t)ns3; stats[9] = (int64_t)ns4; stats[10] = (int64_t)ns5; stats[11] = (int64_t)hs_.convex; stats[12] = (int64_t)hs_.kept_convex;
+    stats[13] = (int64_t)hs_.hiv_faces; stats[14] = (int64_t)hs_.hiv_fallback;
+    if (trace) printf("hiv: faces %llu list entries %llu clips %llu list overflows %llu fallbacks %llu\n", hs_.hiv_faces, hs_.hiv_list, hs_.hiv_clips, hs_.hiv_rest, hs_.hiv_fallback);
+    if (trace) printf("hiv: pairs decided by the lower bound %llu of %llu\n", hs_.lb_decided, hs_.kernel + hs_.convex);
   }
   if (verbose) {
     printf("NMS: Function calls:\nNMS: ~ bbox+out: %8llu\nNMS: ~ inner:    %8llu\nNMS: ~ kernel:   %8llu\nNMS: ~ convex:   %8llu\nNMS: ~ render:   %8llu\n",
