@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(256) k_round_decide3(const int* __restrict__ U
   }
 }
 
-struct Stats { unsigned long long upper, lower, kernel, render, kept_pre, sup_pre, sup_kernel, sup_render, convex, kept_convex, overflow, hiv_faces, hiv_fallback, hiv_list, hiv_clips, hiv_rest, lb_decided; };
+struct Stats { unsigned long long upper, lower, kernel, render, kept_pre, sup_pre, sup_kernel, sup_render, convex, kept_convex, overflow, hiv_faces, hiv_fallback, hiv_list, hiv_clips, hiv_rest, lb_decided, ub_decided; };
 
 // emit: exact neighbour predicate + cascade stages 1 and 2 (:1199-1248)
 __global__ void __launch_bounds__(256) k_round_emit3(const int* __restrict__ K, int nK, unsigned char* __restrict__ state,
@@ -600,37 +600,68 @@ __device__ __forceinline__ int hiv_cull_wave(double* hs, int M, const double b1[
   return kept;
 }
 
-// Rigorous lower bound of the volume of the convex region K = {x : n_m.x + d_m <= 0 for all m} (origin strictly inside):
-// the boundary point of K along every ray direction is in K, K is convex, hence every tetrahedron (0, w_a, w_b, w_c)
-// over a triangle of the ray mesh lies in K; these tetrahedra are cones over a triangulation of the sphere of directions
-// and do not overlap (the ray mesh is the hull of the ray directions and contains the origin, rays.py).  ~100x cheaper
-// than the exact volume and decisive for the typical near-duplicate pair.  wv: LDS, 3R doubles.
-__device__ __forceinline__ double hiv_lower_bound_wave(const double* __restrict__ hs, int M, const float* __restrict__ verts,
-                                                       const int* __restrict__ faces, int R, int F, double* wv, int lane) {
+// Rigorous lower AND upper bound of the volume of the convex region K = {x : n_m.x + d_m <= 0 for all m} (origin strictly
+// inside) from one ray cast per ray direction u_y (boundary point w_y = t_y u_y on half-space m_y):
+//   lower: K is convex, so every tetrahedron (0, w_a, w_b, w_c) over a triangle of the ray mesh lies in K; these are cones
+//          over a triangulation of the sphere of directions and do not overlap (the ray mesh is the hull of the ray
+//          directions and contains the origin, rays.py);
+//   upper: K lies inside each of its half-spaces, so (cone over the triangle) n K is inside (cone) n half-space m_x for each
+//          corner x, a tetrahedron with volume |det(w_a,w_b,w_c)|/6 * prod_y s_y, s_y = -d_x / (n_x.w_y) >= 1; take the
+//          smallest of the three.
+// ~100x cheaper than the exact volume and decisive unless the ratio to the threshold is within the gap between the two
+// (a few percent).  wv: LDS 3R doubles, hit: LDS R shorts.  ub = +inf when no bound could be formed.
+__device__ __forceinline__ void hiv_bounds_wave(const double* __restrict__ hs, int M, const float* __restrict__ verts,
+                                                const int* __restrict__ faces, int R, int F, double* wv, unsigned short* hit, int lane,
+                                                double& lb, double& ub) {
 #pragma clang fp contract(fast)
   for (int k = lane; k < R; k += 64) {
     const double dz = (double)verts[3 * k], dy = (double)verts[3 * k + 1], dx = (double)verts[3 * k + 2];
     double ne_b = 1.0, q_b = 0.0;                      // boundary distance t = ne_b / q_b, kept as a fraction
+    int m_b = 0;
     for (int m = 0; m < M; ++m) {
       const double q = hs[4 * m] * dz + hs[4 * m + 1] * dy + hs[4 * m + 2] * dx;
       const double ne = -hs[4 * m + 3];
-      if (q > 0 && ne * q_b < ne_b * q) { ne_b = ne; q_b = q; }
+      if (q > 0 && ne * q_b < ne_b * q) { ne_b = ne; q_b = q; m_b = m; }
     }
     const double t = (q_b > 0) ? ne_b / q_b : 0.0;
     wv[3 * k] = t * dz; wv[3 * k + 1] = t * dy; wv[3 * k + 2] = t * dx;
+    hit[k] = (unsigned short)((q_b > 0) ? m_b : HIV_NONE);
   }
   __syncthreads();
-  double acc = 0;
+  double accl = 0, accu = 0;
+  bool bad = false;
   for (int f = lane; f < F; f += 64) {
-    const int ia = faces[3 * f], ib = faces[3 * f + 1], ic = faces[3 * f + 2];
-    const double az = wv[3 * ia], ay = wv[3 * ia + 1], ax = wv[3 * ia + 2];
-    const double bz = wv[3 * ib], by = wv[3 * ib + 1], bx = wv[3 * ib + 2];
-    const double cz = wv[3 * ic], cy = wv[3 * ic + 1], cx = wv[3 * ic + 2];
-    acc += fabs(az * (by * cx - bx * cy) + ay * (bx * cz - bz * cx) + ax * (bz * cy - by * cz));
+    const int iv[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
+    double w[3][3];
+#pragma unroll
+    for (int y = 0; y < 3; ++y) { w[y][0] = wv[3 * iv[y]]; w[y][1] = wv[3 * iv[y] + 1]; w[y][2] = wv[3 * iv[y] + 2]; }
+    const double det = fabs(w[0][0] * (w[1][1] * w[2][2] - w[1][2] * w[2][1]) + w[0][1] * (w[1][2] * w[2][0] - w[1][0] * w[2][2]) +
+                            w[0][2] * (w[1][0] * w[2][1] - w[1][1] * w[2][0]));
+    accl += det;
+    double best = 1e300;
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      const unsigned int m = hit[iv[x]];
+      if (m == HIV_NONE) continue;
+      const double nz = hs[4 * m], ny = hs[4 * m + 1], nx = hs[4 * m + 2], ne = -hs[4 * m + 3];
+      double prod = 1.0;
+      bool ok = true;
+#pragma unroll
+      for (int y = 0; y < 3; ++y) {
+        const double q = nz * w[y][0] + ny * w[y][1] + nx * w[y][2];
+        if (!(q > 0)) ok = false;
+        prod *= ne / q;
+      }
+      if (ok) best = fmin(best, prod);
+    }
+    if (best >= 1e300) bad = true;
+    accu += det * fmax(best, 1.0);
   }
-  for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+  for (int o = 32; o; o >>= 1) { accl += __shfl_xor(accl, o); accu += __shfl_xor(accu, o); }
+  bad = __any(bad);
   __syncthreads();
-  return acc / 6.0;
+  lb = accl / 6.0;
+  ub = bad ? 1e300 : accu / 6.0;
 }
 
 // edge adjacency of the ray mesh: adj[3f + e] = face sharing edge e = (v_e, v_{e+1}) of face f, or -1
@@ -648,6 +679,35 @@ __global__ void k_face_adj(const int* __restrict__ faces, int F, int* __restrict
     }
     adj[3 * f + e] = found;
   }
+}
+
+// The volume bounds above need the ray mesh to be a closed surface that is star-shaped about the origin (cones over its
+// triangles tile the sphere of directions exactly once).  mesh[0] |= 1: an edge without a partner, |= 2: degenerate or
+// degenerate face; mesh_sa = sum of the absolute solid angles (Van Oosterom & Strackee): exactly 4 pi iff the radial
+// projection of the closed mesh covers the sphere once without folds.
+__global__ void k_mesh_check(const float* __restrict__ verts, const int* __restrict__ faces, const int* __restrict__ adj, int F, int* mesh,
+                             double* mesh_sa) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  double u[3][3];
+  for (int y = 0; y < 3; ++y) {
+    const int v = faces[3 * f + y];
+    const double z = verts[3 * v], yy = verts[3 * v + 1], x = verts[3 * v + 2];
+    const double nn = sqrt(z * z + yy * yy + x * x);
+    u[y][0] = z / nn; u[y][1] = yy / nn; u[y][2] = x / nn;
+  }
+  const double det = u[0][0] * (u[1][1] * u[2][2] - u[1][2] * u[2][1]) + u[0][1] * (u[1][2] * u[2][0] - u[1][0] * u[2][2]) +
+                     u[0][2] * (u[1][0] * u[2][1] - u[1][1] * u[2][0]);
+  const double d01 = u[0][0] * u[1][0] + u[0][1] * u[1][1] + u[0][2] * u[1][2];
+  const double d12 = u[1][0] * u[2][0] + u[1][1] * u[2][1] + u[1][2] * u[2][2];
+  const double d20 = u[2][0] * u[0][0] + u[2][1] * u[0][1] + u[2][2] * u[0][2];
+  const double sa = 2.0 * atan2(det, 1.0 + d01 + d12 + d20);
+  int bad = 0;
+  if (adj[3 * f] < 0 || adj[3 * f + 1] < 0 || adj[3 * f + 2] < 0) bad |= 1;
+  if (!(fabs(det) > 1e-12)) bad |= 2;
+  if (bad) atomicOr(&mesh[0], bad);
+  atomicAdd(&mesh[det > 0 ? 1 : 2], 1);
+  atomicAdd(mesh_sa, fabs(sa));
 }
 
 __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, unsigned int nPairs, const float* __restrict__ dist,
@@ -716,10 +776,15 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
       const double A_min_d = (double)fminf(volume[ij.x], volume[ij.y]) + 1e-10;
       const double thr_hi = (double)thr + 1e-5 * fabs((double)thr) + 1e-7;
       const double zero3[3] = {0, 0, 0};
-      const double lb = hiv_lower_bound_wave(hs, Mc, verts, faces, R, F, W.S, lane);
+      const double thr_lo = (double)thr - 1e-5 * fabs((double)thr) - 1e-7;
+      double lb, ub;
+      hiv_bounds_wave(hs, Mc, verts, faces, R, F, W.S, (unsigned short*)(W.S + 3 * R), lane, lb, ub);
       if (lb * (1.0 - 1e-9) / A_min_d > thr_hi && !(wsBytes >> 31)) {
         vol = lb;                                       // certainly above the threshold: same decision as the exact volume
         if (lane == 0) atomicAdd(&st->lb_decided, 1ull);
+      } else if (ub * (1.0 + 1e-9) / A_min_d < thr_lo && !(wsBytes >> 31)) {
+        vol = ub;                                       // certainly not above the threshold
+        if (lane == 0) atomicAdd(&st->ub_decided, 1ull);
       } else {
         const double sep = sqrt((double)(c1[0] - c2[0]) * (c1[0] - c2[0]) + (double)(c1[1] - c2[1]) * (c1[1] - c2[1]) + (double)(c1[2] - c2[2]) * (c1[2] - c2[2]));
         const double L = 4.0 * (2.0 * ext + sep + 1.0);
@@ -928,10 +993,15 @@ __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, u
       const double A_min_d = (double)fminf(volume[ij.x], volume[ij.y]) + 1e-10;
       const double thr_hi = (double)thr + 1e-5 * fabs((double)thr) + 1e-7;
       const double zero3[3] = {0, 0, 0};
-      const double lb = hiv_lower_bound_wave(hs, Mc, verts, faces, R, F, W.S, lane);
+      const double thr_lo = (double)thr - 1e-5 * fabs((double)thr) - 1e-7;
+      double lb, ub;
+      hiv_bounds_wave(hs, Mc, verts, faces, R, F, W.S, (unsigned short*)(W.S + 3 * R), lane, lb, ub);
       if (lb * (1.0 - 1e-9) / A_min_d > thr_hi && !no_lb) {
         vol = lb;                                       // certainly above the threshold -> render stage, as with the exact volume
         if (lane == 0) atomicAdd(&st->lb_decided, 1ull);
+      } else if (ub * (1.0 + 1e-9) / A_min_d < thr_lo && !no_lb) {
+        vol = ub;                                       // certainly not above the threshold -> pair kept
+        if (lane == 0) atomicAdd(&st->ub_decided, 1ull);
       } else vol = hiv_volume_wave(hs, Mc, zero3, L, W, lane, st);
     }
     if (lane == 0) {
@@ -1035,9 +1105,9 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   }
   if (N <= 0) return 0;
   if (R < 4 || F < 4) { sd::set_error("sd_nms3d: need n_rays >= 4 and n_faces >= 4"); return -1; }
-  if (R > 896) { sd::set_error("sd_nms3d: n_rays must be <= 896"); return -1; }
+  if (R > 800) { sd::set_error("sd_nms3d: n_rays must be <= 800"); return -1; }
   const size_t hivBytes = hiv_poly_bytes();
-  const size_t ws3 = ((size_t)3 * R * sizeof(double) > hivBytes ? (((size_t)3 * R * sizeof(double) + 15) & ~(size_t)15) : hivBytes);   // >= 6R floats
+  const size_t ws3 = ((size_t)3 * R * sizeof(double) + 2 * R > hivBytes ? (((size_t)3 * R * sizeof(double) + 2 * R + 15) & ~(size_t)15) : hivBytes);   // >= 6R floats
   const size_t lds3 = (size_t)8 * F * sizeof(double) + ws3 + (size_t)10 * F * sizeof(unsigned short);
   const size_t lds5 = (size_t)6 * R * sizeof(float) + (size_t)3 * F * sizeof(int);
   const size_t lds4 = (size_t)16 * R * sizeof(double) + hivBytes + (size_t)20 * R * sizeof(unsigned short);   // cap = 2R
@@ -1141,7 +1211,24 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tb1, nbrCount, nbrStart, N + 1, s));
   i64 totalNbr = 0;
   SD_CHECK(hipMemcpyAsync(&totalNbr, nbrStart + N, sizeof(i64), hipMemcpyDeviceToHost, s));
+  // ray mesh: edge adjacency (seeds of the exact volume routine) and validity (precondition of the volume bounds)
+  int* faceAdj = A.take_n<int>((size_t)3 * F);
+  int* d_mesh = A.take_n<int>(4);
+  double* d_mesh_sa = A.take_n<double>(1);
+  if (!faceAdj || !d_mesh || !d_mesh_sa) return -1;
+  SD_CHECK(hipMemsetAsync(d_mesh, 0, 4 * sizeof(int), s));
+  SD_CHECK(hipMemsetAsync(d_mesh_sa, 0, sizeof(double), s));
+  hipLaunchKernelGGL(k_face_adj, dim3(sd::div_up(F, 64)), dim3(64), 0, s, d_faces, F, faceAdj);
+  hipLaunchKernelGGL(k_mesh_check, dim3(sd::div_up(F, 64)), dim3(64), 0, s, d_verts, d_faces, faceAdj, F, d_mesh, d_mesh_sa);
+  SD_LAUNCH_CHECK();
+  int h_mesh[4]; double h_mesh_sa = 0;
+  SD_CHECK(hipMemcpyAsync(h_mesh, d_mesh, sizeof(h_mesh), hipMemcpyDeviceToHost, s));
+  SD_CHECK(hipMemcpyAsync(&h_mesh_sa, d_mesh_sa, sizeof(double), hipMemcpyDeviceToHost, s));
   SD_CHECK(hipStreamSynchronize(s));
+  const bool mesh_ok = h_mesh[0] == 0 && fabs(h_mesh_sa - 4.0 * M_PI) < 1e-6;
+  const bool use_bounds = mesh_ok && getenv("SD_NMS3D_NO_LB") == nullptr;
+  if (trace) printf("ray mesh: open/degenerate flags %d, orientation +%d/-%d, solid angle %.9f -> volume bounds %s\n", h_mesh[0], h_mesh[1], h_mesh[2],
+                    h_mesh_sa, use_bounds ? "on" : "off");
   int* nbr = A.take_n<int>((size_t)totalNbr);
   if (!nbr) return -1;
   hipLaunchKernelGGL((k_neighbours3<1>), dim3(sd::div_up(N, 4)), dim3(256), 0, s, N, gr, fs, d_points, bbox, candCell, cellStart, cellItems,
@@ -1166,10 +1253,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   int* hullList = A.take_n<int>(N);
   double* hullPlanes = nullptr;                    // N * hullCap * 4 doubles, allocated on first use
   unsigned short* hullAdj = nullptr;               // N * hullCap * 3
-  int* faceAdj = A.take_n<int>((size_t)3 * F);
-  if (!faceAdj) return -1;
-  hipLaunchKernelGGL(k_face_adj, dim3(sd::div_up(F, 64)), dim3(64), 0, s, d_faces, F, faceAdj);
-  SD_LAUNCH_CHECK();
+
   if (!hullState || !hullCount || !hullList) return -1;
   SD_CHECK(hipMemsetAsync(hullState, 0, (size_t)N * sizeof(int), s));
   SD_CHECK(hipMemsetAsync(waitOn, 0xFF, (size_t)N * sizeof(int), s));
@@ -1197,7 +1281,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
         const unsigned int b3 = h.nP3 < 16384u ? h.nP3 : 16384u;
         if (stats) SD_CHECK(hipEventRecord(ev0, s));
         hipLaunchKernelGGL(k_stage3, dim3(b3), dim3(64), lds3, s, pairs3, h.nP3, d_dist, d_points, d_verts, d_faces, faceAdj, R, F, volume,
-                           threshold, state, pairs4, &d_cnt->nP4, d_st, (unsigned int)ws3 | (getenv("SD_NMS3D_NO_LB") ? 0x80000000u : 0u));
+                           threshold, state, pairs4, &d_cnt->nP4, d_st, (unsigned int)ws3 | (use_bounds ? 0u : 0x80000000u));
         SD_LAUNCH_CHECK();
         if (stats) SD_CHECK(hipEventRecord(ev1, s));
         SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -1223,7 +1307,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
             SD_LAUNCH_CHECK();
           }
           hipLaunchKernelGGL(k_stage4, dim3(b4), dim3(64), lds4, s, pairs4, h.nP4, d_dist, d_points, d_verts, d_faces, R, F, hullCap, hullPlanes, hullAdj, hullCount,
-                             volume, threshold, pairs5, &d_cnt->nP5, d_st, getenv("SD_NMS3D_NO_LB") ? 1 : 0);
+                             volume, threshold, pairs5, &d_cnt->nP5, d_st, use_bounds ? 0 : 1);
           SD_LAUNCH_CHECK();
           if (stats) SD_CHECK(hipEventRecord(ev1, s));
           SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -1256,7 +1340,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
     stats[8] = (int64_t)ns3; stats[9] = (int64_t)ns4; stats[10] = (int64_t)ns5; stats[11] = (int64_t)hs_.convex; stats[12] = (int64_t)hs_.kept_convex;
     stats[13] = (int64_t)hs_.hiv_faces; stats[14] = (int64_t)hs_.hiv_fallback;
     if (trace) printf("hiv: faces %llu list entries %llu clips %llu list overflows %llu fallbacks %llu\n", hs_.hiv_faces, hs_.hiv_list, hs_.hiv_clips, hs_.hiv_rest, hs_.hiv_fallback);
-    if (trace) printf("hiv: pairs decided by the lower bound %llu of %llu\n", hs_.lb_decided, hs_.kernel + hs_.convex);
+    if (trace) printf("hiv: pairs decided by the lower bound %llu, by the upper bound %llu, of %llu\n", hs_.lb_decided, hs_.ub_decided, hs_.kernel + hs_.convex);
   }
   if (verbose) {
     printf("NMS: Function calls:\nNMS: ~ bbox+out: %8llu\nNMS: ~ inner:    %8llu\nNMS: ~ kernel:   %8llu\nNMS: ~ convex:   %8llu\nNMS: ~ render:   %8llu\n",
