@@ -808,14 +808,167 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
 // reaches stage 4 and cached in HBM: (a<b<c) is a facet iff every other vertex lies on one side of its plane and
 // (a,b,c) are the three lowest-indexed vertices on that plane (one plane per facet).  One wave per polyhedron:
 // each lane owns a triple, rejects it against 8 extreme "probe" vertices, survivors are verified by the whole wave.
+// ---- fast hull: gift wrapping, breadth first (one lane per open edge), for non-degenerate point sets.
+// Each open edge (u,v) of a known facet (u,v,t) is pivoted: the neighbouring facet's third vertex w is the point that is
+// angularly extreme about the edge (all points lie in a wedge < pi; 2D cross-product order in the plane normal to the edge).
+// Every facet is verified by the whole wave with the criterion of the exhaustive search below; anything unusual (more than
+// three points on a supporting plane, an edge used three times, a facet that is not supporting) returns false and the caller
+// runs the exhaustive search, so both paths emit the same facet set; the facets are sorted so that they are also emitted
+// in the same order.
+#define HULL_FAST_MAXR 192
+__device__ __forceinline__ int hull_pivot(const double* __restrict__ pv, int R, int iu, int iv, int it, const double u[3], const double e[3],
+                                          const double dref[3], const double g[3]) {
+  const double en = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+  if (!(en > 0)) return -1;
+  const double e0 = e[0] / en, e1 = e[1] / en, e2 = e[2] / en;
+  const double dr = dref[0] * e0 + dref[1] * e1 + dref[2] * e2;
+  double x0 = dref[0] - dr * e0, x1 = dref[1] - dr * e1, x2 = dref[2] - dr * e2;
+  const double xn = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+  if (!(xn > 0)) return -1;
+  x0 /= xn; x1 /= xn; x2 /= xn;
+  double y0 = e1 * x2 - e2 * x1, y1 = e2 * x0 - e0 * x2, y2 = e0 * x1 - e1 * x0;
+  if ((g[0] - u[0]) * y0 + (g[1] - u[1]) * y1 + (g[2] - u[2]) * y2 < 0) { y0 = -y0; y1 = -y1; y2 = -y2; }
+  int best = -1;
+  double bx = 0, by = 0;
+  for (int q = 0; q < R; ++q) {
+    if (q == iu || q == iv || q == it) continue;
+    const double d0 = pv[3 * q] - u[0], d1 = pv[3 * q + 1] - u[1], d2 = pv[3 * q + 2] - u[2];
+    const double xq = d0 * x0 + d1 * x1 + d2 * x2, yq = d0 * y0 + d1 * y1 + d2 * y2;
+    if (best < 0) { best = q; bx = xq; by = yq; }
+    else if (bx * yq - by * xq > 0) { best = q; bx = xq; by = yq; }     // q is counter-clockwise of the current extreme
+  }
+  return best;
+}
+
+// tri: facets packed a << 20 | b << 10 | c with a < b < c, bit 30 = flip the normal; returns the facet count or -1
+__device__ int hull_giftwrap(const double* __restrict__ pv, int R, int cap, int p0, double ext, unsigned int* tri, unsigned char* cnt,
+                             unsigned int* frA, unsigned int* frB, int* s_cnt, int lane) {
+  for (int k = lane; k < (R * R + 3) / 4; k += 64) ((unsigned int*)cnt)[k] = 0u;
+  double g[3] = {0, 0, 0};
+  for (int k = lane; k < R; k += 64) { g[0] += pv[3 * k]; g[1] += pv[3 * k + 1]; g[2] += pv[3 * k + 2]; }
+  for (int o = 32; o; o >>= 1) { g[0] += __shfl_xor(g[0], o); g[1] += __shfl_xor(g[1], o); g[2] += __shfl_xor(g[2], o); }
+  g[0] /= R; g[1] /= R; g[2] /= R;
+  if (lane == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; }
+  __syncthreads();
+  // first facet: p0 has the lowest z, so the plane z = z(p0) supports the hull; pivot about the line through p0 parallel
+  // to y, then about the edge (p0, p1).  Every lane computes the same thing.
+  int p1, p2;
+  {
+    const double u[3] = {pv[3 * p0], pv[3 * p0 + 1], pv[3 * p0 + 2]};
+    const double ey[3] = {0, 1, 0}, ex[3] = {0, 0, 1};
+    p1 = hull_pivot(pv, R, p0, -1, -1, u, ey, ex, g);
+    if (p1 < 0) return -1;
+    const double e[3] = {pv[3 * p1] - u[0], pv[3 * p1 + 1] - u[1], pv[3 * p1 + 2] - u[2]};
+    p2 = hull_pivot(pv, R, p0, p1, -1, u, e, ey, g);
+    if (p2 < 0) return -1;
+  }
+  int nfr = 0;            // entries in the current frontier (uniform)
+  unsigned int* frCur = frA; unsigned int* frNext = frB;
+  int nf = 0;             // facets so far (uniform, mirrored in s_cnt[0])
+  bool failed = false;
+  // the insertion routine is used for the first facet as well: a "batch" with one proposal
+  int prop_u = p0, prop_v = p1, prop_w = (lane == 0) ? p2 : -1;
+  int round_start = 0;
+  for (int round = 0; round < 8 * R && !failed; ++round) {
+    for (int base = 0; (round == 0 ? base == 0 : base < nfr) && !failed; base += 64) {
+      if (round > 0) {
+        prop_w = -1;
+        if (base + lane < nfr) {
+          const unsigned int item = frCur[base + lane];
+          prop_u = (int)(item & 1023u); prop_v = (int)((item >> 10) & 1023u);
+          const int t = (int)((item >> 20) & 1023u);
+          const int lo = prop_u < prop_v ? prop_u : prop_v, hi = prop_u < prop_v ? prop_v : prop_u;
+          if (cnt[lo * R + hi] == 1) {
+            const double u[3] = {pv[3 * prop_u], pv[3 * prop_u + 1], pv[3 * prop_u + 2]};
+            const double e[3] = {pv[3 * prop_v] - u[0], pv[3 * prop_v + 1] - u[1], pv[3 * prop_v + 2] - u[2]};
+            const double dref[3] = {pv[3 * t] - u[0], pv[3 * t + 1] - u[1], pv[3 * t + 2] - u[2]};
+            prop_w = hull_pivot(pv, R, prop_u, prop_v, t, u, e, dref, g);
+            if (prop_w < 0) failed = true;
+          }
+        }
+      }
+      failed = __any(failed);
+      unsigned long long mask = __ballot(prop_w >= 0);
+      while (mask && !failed) {
+        const int src = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        int a = __shfl(prop_u, src), b = __shfl(prop_v, src), c = __shfl(prop_w, src);
+        { const int lo = a < b ? a : b, hi = a < b ? b : a; if (round > 0 && cnt[lo * R + hi] != 1) continue; }   // closed meanwhile
+        if (a > b) { const int t_ = a; a = b; b = t_; }
+        if (b > c) { const int t_ = b; b = c; c = t_; }
+        if (a > b) { const int t_ = a; a = b; b = t_; }
+        if (a == b || b == c) { failed = true; break; }
+        // verification (same arithmetic and tolerance as the exhaustive search)
+        const double az = pv[3 * a], ay = pv[3 * a + 1], ax = pv[3 * a + 2];
+        const double ez = pv[3 * b] - az, ey_ = pv[3 * b + 1] - ay, ex_ = pv[3 * b + 2] - ax;
+        const double fz = pv[3 * c] - az, fy = pv[3 * c + 1] - ay, fx = pv[3 * c + 2] - ax;
+        const double nz = ey_ * fx - ex_ * fy, ny = ex_ * fz - ez * fx, nx = ez * fy - ey_ * fz;
+        const double nn = sqrt(nz * nz + ny * ny + nx * nx);
+        const double te = 1e-10 * nn * (ext + 1e-30);
+        if (!(nn > 1e-12 * ext * ext)) { failed = true; break; }
+        bool pos = false, neg = false, flat = false;
+        for (int q = lane; q < R; q += 64) {
+          if (q == a || q == b || q == c) continue;
+          const double sd_ = nz * (pv[3 * q] - az) + ny * (pv[3 * q + 1] - ay) + nx * (pv[3 * q + 2] - ax);
+          if (sd_ > te) pos = true; else if (sd_ < -te) neg = true; else flat = true;
+        }
+        const bool anyp = __any(pos), anyn = __any(neg), anyf = __any(flat);
+        if ((anyp && anyn) || anyf || nf >= cap) { failed = true; break; }
+        if (lane == 0) {
+          tri[nf] = ((unsigned int)a << 20) | ((unsigned int)b << 10) | (unsigned int)c | (anyp ? (1u << 30) : 0u);
+          const unsigned char c0 = ++cnt[a * R + b], c1 = ++cnt[b * R + c], c2 = ++cnt[a * R + c];
+          if (c0 > 2 || c1 > 2 || c2 > 2) s_cnt[2] = 1;
+        }
+        ++nf;
+        __syncthreads();
+        if (s_cnt[2]) failed = true;
+      }
+    }
+    if (failed) break;
+    // next frontier: edges of this round's facets that are still used once
+    if (lane == 0) s_cnt[1] = 0;
+    __syncthreads();
+    for (int t = round_start + lane; t < nf; t += 64) {
+      const unsigned int key = tri[t];
+      const int a = (int)((key >> 20) & 1023u), b = (int)((key >> 10) & 1023u), c = (int)(key & 1023u);
+      if (cnt[a * R + b] == 1) frNext[atomicAdd(&s_cnt[1], 1)] = (unsigned int)a | ((unsigned int)b << 10) | ((unsigned int)c << 20);
+      if (cnt[b * R + c] == 1) frNext[atomicAdd(&s_cnt[1], 1)] = (unsigned int)b | ((unsigned int)c << 10) | ((unsigned int)a << 20);
+      if (cnt[a * R + c] == 1) frNext[atomicAdd(&s_cnt[1], 1)] = (unsigned int)a | ((unsigned int)c << 10) | ((unsigned int)b << 20);
+    }
+    __syncthreads();
+    nfr = s_cnt[1];
+    round_start = nf;
+    { unsigned int* t_ = frCur; frCur = frNext; frNext = t_; }
+    if (nfr == 0) break;
+    if (nfr > 6 * R) { failed = true; break; }
+  }
+  __syncthreads();
+  if (failed || nfr != 0 || nf < 4) return -1;
+  // sort the facets lexicographically by (a, b, c) (rank sort; keys are distinct)
+  for (int t = lane; t < nf; t += 64) {
+    const unsigned int key = tri[t] & 0x3FFFFFFFu;
+    int rank = 0;
+    for (int q = 0; q < nf; ++q) rank += ((tri[q] & 0x3FFFFFFFu) < key) ? 1 : 0;
+    frCur[rank] = tri[t];
+  }
+  __syncthreads();
+  for (int t = lane; t < nf; t += 64) tri[t] = frCur[t];
+  __syncthreads();
+  return nf;
+}
+
 __global__ void __launch_bounds__(64) k_hull(const int* __restrict__ hullList, unsigned int nList, const float* __restrict__ dist,
                                              const float* __restrict__ pts, const float* __restrict__ verts, int R, int cap,
                                              double* __restrict__ hullPlanes, unsigned short* __restrict__ hullAdj, int* __restrict__ hullCount) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* pv = (double*)smem;            // 3R doubles
   unsigned int* tri = (unsigned int*)(pv + 3 * R);   // cap packed facets a | b << 10 | c << 20
+  unsigned int* frA = tri + cap;                     // fast path only: 6R + 6R open edges, R*R edge use counts
+  unsigned int* frB = frA + 6 * R;
+  unsigned char* cnt = (unsigned char*)(frB + 6 * R);
   __shared__ int s_probe[8];
   __shared__ int s_n;
+  __shared__ int s_cnt[3];
   const int lane = threadIdx.x;
   for (unsigned int it = blockIdx.x; it < nList; it += gridDim.x) {
     const int cand = hullList[it];
@@ -848,6 +1001,27 @@ __global__ void __launch_bounds__(64) k_hull(const int* __restrict__ hullList, u
     }
     __syncthreads();
     double* out = hullPlanes + (size_t)cand * cap * 4;
+    int nfast = -1;
+    if (R <= HULL_FAST_MAXR) nfast = hull_giftwrap(pv, R, cap, s_probe[1], ext, tri, cnt, frA, frB, s_cnt, lane);
+    if (nfast > 0) {
+      for (int t = lane; t < nfast; t += 64) {
+        const unsigned int key = tri[t];
+        const int a = (int)((key >> 20) & 1023u), b = (int)((key >> 10) & 1023u), c = (int)(key & 1023u);
+        const double az = pv[3 * a], ay = pv[3 * a + 1], ax = pv[3 * a + 2];
+        const double ez = pv[3 * b] - az, ey = pv[3 * b + 1] - ay, ex = pv[3 * b + 2] - ax;
+        const double fz = pv[3 * c] - az, fy = pv[3 * c + 1] - ay, fx = pv[3 * c + 2] - ax;
+        const double tz = ey * fx - ex * fy, ty = ex * fz - ez * fx, tx = ez * fy - ey * fz;
+        const double sg = (key >> 30) & 1u ? -1.0 : 1.0;
+        out[4 * t] = sg * tz; out[4 * t + 1] = sg * ty; out[4 * t + 2] = sg * tx;
+        out[4 * t + 3] = -(sg * tz * az + sg * ty * ay + sg * tx * ax);
+      }
+      __syncthreads();
+      for (int t = lane; t < nfast; t += 64) {          // repack as the adjacency code below expects
+        const unsigned int key = tri[t];
+        tri[t] = ((key >> 20) & 1023u) | (((key >> 10) & 1023u) << 10) | ((key & 1023u) << 20);
+      }
+      if (lane == 0) s_n = nfast;
+    } else
     for (int a = 0; a < R - 2; ++a) {
       const double az = pv[3 * a], ay = pv[3 * a + 1], ax = pv[3 * a + 2];
       for (int b = a + 1; b < R - 1; ++b) {
@@ -1302,7 +1476,8 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
           SD_CHECK(hipStreamSynchronize(s));
           if (h.nHull > 0) {
             const unsigned int bh = h.nHull < 32768u ? h.nHull : 32768u;
-            hipLaunchKernelGGL(k_hull, dim3(bh), dim3(64), (size_t)3 * R * sizeof(double) + (size_t)hullCap * sizeof(unsigned int), s, hullList,
+            hipLaunchKernelGGL(k_hull, dim3(bh), dim3(64), (size_t)3 * R * sizeof(double) + (size_t)hullCap * sizeof(unsigned int) +
+                                   (R <= HULL_FAST_MAXR ? (size_t)12 * R * sizeof(unsigned int) + (size_t)R * R + 4 : 0), s, hullList,
                                h.nHull, d_dist, d_points, d_verts, R, hullCap, hullPlanes, hullAdj, hullCount);
             SD_LAUNCH_CHECK();
           }
