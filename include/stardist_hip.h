@@ -139,6 +139,14 @@ int sd_select_candidates_device(const float* d_prob, const float* d_dist, int nd
                                 int cap, float* d_out_prob, float* d_out_dist,
                                 int32_t* d_out_points, int32_t* d_count, void* stream);
 
+/* ---- network epilogue ------------------------------------------------------------------------
+ * bias + activation of a convolution output in one in-place pass (the reference's Keras Conv layers do both inside the
+ * layer: csbdeep unet_block / resnet_block as called from stardist/models/model2d.py:310-349, model3d.py:360-447).
+ * x is viewed as [n_outer][n_channels][inner] float32 (channels-last tensors: inner = 1, n_outer = pixels);
+ * act: 0 = linear, 1 = relu. */
+int sd_bias_act_device(float* d_x, const float* d_bias, long long n_outer, int n_channels,
+                       long long inner, int act, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

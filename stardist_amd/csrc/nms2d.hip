@@ -154,11 +154,13 @@ __device__ __forceinline__ bool may_interact(const Flags f, const int4 bi, const
 }
 
 // MODE 0: count neighbours, MODE 1: fill CSR
+#define WAIT_NONE (-2)
+#define WAIT_SCAN (-1)
 template <int MODE>
 __global__ void __launch_bounds__(256) k_neighbours(int N, GridP g, Flags f, const float* __restrict__ pts, const int4* __restrict__ bbox,
                                                     const float* __restrict__ area, const int* __restrict__ candCell, const int* __restrict__ cellStart,
                                                     const int* __restrict__ cellItems, int* __restrict__ nbrCount,
-                                                    const i64* __restrict__ nbrStart, int* __restrict__ nbr, int W) {
+                                                    const i64* __restrict__ nbrStart, int* __restrict__ nbr, int* __restrict__ waitOn, int W) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * (blockDim.x >> 6) + wave;
   if (i >= N) return;
@@ -168,6 +170,7 @@ __global__ void __launch_bounds__(256) k_neighbours(int N, GridP g, Flags f, con
   const float pyi = pts[2 * i], pxi = pts[2 * i + 1];
   const float ai = area[i];
   int total = 0;
+  int minj = INT32_MAX;                      // MODE 1: best-scored neighbour above i (first wait target of the greedy scan)
   i64 base = MODE ? nbrStart[i] : 0;
   const int x_lo = max(cx - W, 0), x_hi = min(cx + W, g.nx - 1);
   for (int yy = max(cy - W, 0); yy <= min(cy + W, g.ny - 1); ++yy) {
@@ -182,28 +185,57 @@ __global__ void __launch_bounds__(256) k_neighbours(int N, GridP g, Flags f, con
       }
       const unsigned long long m = __ballot(hit);
       if (MODE) {
-        if (hit) nbr[base + total + __popcll(m & ((1ull << lane) - 1))] = j;
+        if (hit) { nbr[base + total + __popcll(m & ((1ull << lane) - 1))] = j; if (j < minj) minj = j; }
       }
       total += __popcll(m);
     }
   }
   if (!MODE && lane == 0) nbrCount[i] = total;
+  if (MODE) {
+    for (int o = 32; o; o >>= 1) minj = min(minj, __shfl_xor(minj, o));
+    if (lane == 0) waitOn[i] = (minj < i) ? minj : WAIT_NONE;
+  }
 }
 
-// Round kernel A: wave per undecided candidate.
-__global__ void __launch_bounds__(256) k_round_decide(const int* __restrict__ U, int nU, const unsigned char* __restrict__ state,
-                                                      const i64* __restrict__ nbrStart, const int* __restrict__ nbr,
-                                                      int* __restrict__ waitOn, int* __restrict__ Unext, int* __restrict__ K,
-                                                      int* counters /*0:nUnext 1:nK*/) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int w = blockIdx.x * (blockDim.x >> 6) + wave;
-  if (w >= nU) return;
-  const int i = U[w];
-  if (state[i] == ST_SUPPRESSED) return;
-  // the undecided higher-scored neighbour found last round is checked first: most waits persist
-  const int wo = waitOn[i];
-  bool pending = (wo >= 0) && (state[wo] == ST_UNDECIDED);
-  if (!pending) {
+// Round kernel A1: thread per undecided candidate, O(1): waitOn[i] is the higher-scored neighbour i was last seen waiting
+// for (k_neighbours seeds it with the best-scored one; WAIT_NONE = there is none, WAIT_SCAN = unknown).  Most waits persist
+// from round to round, so only the candidates whose wait target has just been decided go to the list scan (A2).
+__global__ void __launch_bounds__(256) k_round_triage(const int* __restrict__ U, int nU, const unsigned char* __restrict__ state,
+                                                      const int* __restrict__ waitOn, int* __restrict__ Unext, int* __restrict__ K,
+                                                      int* __restrict__ S, int* counters /*0:nUnext 1:nK 2:nS*/) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int kind = 0, i = -1;                       // 0 drop, 1 still waiting, 2 becomes a survivor, 3 needs the list scan
+  if (t < nU) {
+    i = U[t];
+    if (state[i] != ST_SUPPRESSED) {
+      const int wo = waitOn[i];
+      if (wo == WAIT_NONE) kind = 2;
+      else if (wo >= 0 && state[wo] == ST_UNDECIDED) kind = 1;
+      else kind = 3;
+    }
+  }
+#pragma unroll
+  for (int q = 1; q <= 3; ++q) {
+    const unsigned long long m = __ballot(kind == q);
+    if (!m) continue;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&counters[q - 1], __popcll(m));
+    base = __shfl(base, 0);
+    if (kind == q) (q == 1 ? Unext : (q == 2 ? K : S))[base + __popcll(m & ((1ull << lane) - 1))] = i;
+  }
+}
+
+// Round kernel A2: wave per candidate of the scan list (persistent grid; the list length is read on the device).
+__global__ void __launch_bounds__(256) k_round_scan(const int* __restrict__ S, const unsigned char* __restrict__ state,
+                                                    const i64* __restrict__ nbrStart, const int* __restrict__ nbr,
+                                                    int* __restrict__ waitOn, int* __restrict__ Unext, int* __restrict__ K,
+                                                    int* counters /*0:nUnext 1:nK 2:nS*/) {
+  const int lane = threadIdx.x & 63;
+  const int nS = counters[2];
+  const int nWaves = gridDim.x * (blockDim.x >> 6);
+  for (int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); w < nS; w += nWaves) {
+    const int i = S[w];
     const i64 beg = nbrStart[i], end = nbrStart[i + 1];
     int found = -1;
     for (i64 t = beg; t < end && found < 0; t += 64) {
@@ -213,12 +245,10 @@ __global__ void __launch_bounds__(256) k_round_decide(const int* __restrict__ U,
       const unsigned long long m = __ballot(j >= 0);
       if (m) found = __shfl(j, __ffsll((long long)m) - 1);
     }
-    pending = found >= 0;
-    if (lane == 0 && pending) waitOn[i] = found;
-  }
-  if (lane == 0) {
-    if (pending) Unext[atomicAdd(&counters[0], 1)] = i;
-    else K[atomicAdd(&counters[1], 1)] = i;
+    if (lane == 0) {
+      if (found >= 0) { waitOn[i] = found; Unext[atomicAdd(&counters[0], 1)] = i; }
+      else { waitOn[i] = WAIT_NONE; K[atomicAdd(&counters[1], 1)] = i; }
+    }
   }
 }
 
@@ -478,16 +508,17 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   // ---- neighbour CSR
   SD_CHECK(hipMemsetAsync(nbrCount, 0, (N + 1) * sizeof(int), s));
   hipLaunchKernelGGL((k_neighbours<0>), dim3(sd::div_up(N, 4)), dim3(256), 0, s, N, g, f, d_points, bbox, area, candCell, cellStart,
-                     cellItems, nbrCount, (const i64*)nullptr, (int*)nullptr, W);
+                     cellItems, nbrCount, (const i64*)nullptr, (int*)nullptr, (int*)nullptr, W);
   SD_LAUNCH_CHECK();
   SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tmpBytes, nbrCount, nbrStart, N + 1, s));
   i64 totalNbr = 0;
   SD_CHECK(hipMemcpyAsync(&totalNbr, nbrStart + N, sizeof(i64), hipMemcpyDeviceToHost, s));
   SD_CHECK(hipStreamSynchronize(s));
   int* nbr = A.take_n<int>((size_t)totalNbr);
-  if (!nbr) return -1;
+  int* waitOn = A.take_n<int>(N);
+  if (!nbr || !waitOn) return -1;
   hipLaunchKernelGGL((k_neighbours<1>), dim3(sd::div_up(N, 4)), dim3(256), 0, s, N, g, f, d_points, bbox, area, candCell, cellStart,
-                     cellItems, nbrCount, (const i64*)nbrStart, nbr, W);
+                     cellItems, nbrCount, (const i64*)nbrStart, nbr, waitOn, W);
   SD_LAUNCH_CHECK();
 
   if (stats) { SD_CHECK(hipEventRecord(ev1, s)); SD_CHECK(hipEventSynchronize(ev1)); float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns_pre = ms * 1e6; }
@@ -496,17 +527,16 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   const unsigned long long pairCap = (unsigned long long)(totalNbr / 2 + 64);
   int* U0 = A.take_n<int>(N);
   int* U1 = A.take_n<int>(N);
-  int* waitOn = A.take_n<int>(N);
   int* K = A.take_n<int>(N);
   int2* pairs = A.take_n<int2>(pairCap);
   const unsigned int joinCap = (unsigned int)(pairCap < (1ull << 30) ? pairCap : (1ull << 30));
   int2* joinPairs = A.take_n<int2>(joinCap);
   i64* joinTwice = A.take_n<i64>(joinCap);
   int* joinFlags = A.take_n<int>(joinCap);
-  struct Counters { int nU, nK; unsigned long long nPairs; unsigned int nJoin, nErr; };
+  struct Counters { int nU, nK, nS, pad; unsigned long long nPairs; unsigned int nJoin, nErr; };
+  int* Sl = A.take_n<int>(N);
+  if (!Sl) return -1;
   Counters* d_cnt = (Counters*)A.take(sizeof(Counters));
-  if (!waitOn) return -1;
-  SD_CHECK(hipMemsetAsync(waitOn, 0xFF, (size_t)N * sizeof(int), s));
   if (!U0 || !U1 || !K || !pairs || !joinPairs || !joinTwice || !joinFlags || !d_cnt) return -1;
   hipLaunchKernelGGL(k_iota, dim3(sd::div_up(N, 256)), dim3(256), 0, s, U0, N);
   int nU = N, rounds = 0;
@@ -516,7 +546,11 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   while (nU > 0) {
     ++rounds;
     SD_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), s));
-    hipLaunchKernelGGL(k_round_decide, dim3(sd::div_up(nU, 4)), dim3(256), 0, s, Ucur, nU, state, nbrStart, nbr, waitOn, Unext, K, (int*)d_cnt);
+    hipLaunchKernelGGL(k_round_triage, dim3(sd::div_up(nU, 256)), dim3(256), 0, s, Ucur, nU, state, waitOn, Unext, K, Sl, (int*)d_cnt);
+    {
+      const int scanBlocks = sd::div_up(nU, 4) < 2048 ? sd::div_up(nU, 4) : 2048;
+      hipLaunchKernelGGL(k_round_scan, dim3(scanBlocks), dim3(256), 0, s, Sl, state, nbrStart, nbr, waitOn, Unext, K, (int*)d_cnt);
+    }
     SD_LAUNCH_CHECK();
     SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
     SD_CHECK(hipStreamSynchronize(s));

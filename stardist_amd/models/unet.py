@@ -11,6 +11,8 @@ Keras layer names are kept as module names so a Keras weight file maps 1:1 (kern
 (k..., cin, cout) -> torch (cout, cin, k...)).
 U-Net parity against TensorFlow is unpinned in this environment (no TF, no weights).
 """
+import ctypes
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -31,11 +33,36 @@ def _act(name):
     raise ValueError("activation %s not supported" % name)
 
 
+class ConvAct(nn.Sequential):
+    """[conv, activation] with the Keras layer's parameter names.  On a HIP device in inference the bias add and the
+    (linear / relu) activation are done by one in-place pass of the native library (sd_bias_act_device) instead of two
+    framework element-wise kernels; everywhere else (CPU, training, other activations) it is the plain Sequential."""
+
+    def forward(self, x):
+        conv, act = self[0], self[1]
+        kind = 0 if isinstance(act, nn.Identity) else (1 if isinstance(act, nn.ReLU) else -1)
+        if not (x.is_cuda and kind >= 0 and conv.bias is not None and x.dtype == torch.float32 and not torch.is_grad_enabled()):
+            return super().forward(x)
+        from ..lib import _native as N
+        y = conv._conv_forward(x, conv.weight, None)
+        C = y.shape[1]
+        cl = torch.channels_last if y.dim() == 4 else torch.channels_last_3d
+        if y.is_contiguous(memory_format=cl):
+            n_outer, inner = y.numel() // C, 1
+        elif y.is_contiguous():
+            n_outer, inner = y.shape[0], y.numel() // (y.shape[0] * C)
+        else:
+            return act(y + conv.bias.view((1, C) + (1,) * (y.dim() - 2)))
+        N.check(N.lib().sd_bias_act_device(ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(conv.bias.data_ptr()), n_outer, C, inner, kind,
+                                           N.current_stream()))
+        return y
+
+
 def _conv(nd, cin, cout, k, act="relu", bias=True):
     k = tuple(k) if isinstance(k, (tuple, list)) else (k,) * nd
     Conv = nn.Conv2d if nd == 2 else nn.Conv3d
     assert all(kk % 2 == 1 for kk in k), "Keras 'same' padding restated for odd kernels only"
-    return nn.Sequential(Conv(cin, cout, k, padding=tuple(kk // 2 for kk in k), bias=bias), _act(act))
+    return ConvAct(Conv(cin, cout, k, padding=tuple(kk // 2 for kk in k), bias=bias), _act(act))
 
 
 class UNetBlock(nn.Module):

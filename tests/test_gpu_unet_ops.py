@@ -1,0 +1,37 @@
+"""GPU: the fused bias+activation epilogue equals the framework's two element-wise passes (fp32, exact: one add, one max)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("nd,act,cl", [(2, "relu", True), (2, None, True), (2, "relu", False), (3, "relu", True), (3, None, False)])
+def test_conv_bias_act_fused_equals_plain(nd, act, cl):
+    import torch
+    import torch.nn as nn
+    from stardist_amd.models.unet import _conv
+    dev = torch.device("cuda:0")
+    torch.manual_seed(nd * 7 + (1 if cl else 0))
+    m = _conv(nd, 5, 12, 3, act).to(dev)
+    with torch.no_grad():
+        m[0].bias.normal_()
+        x = torch.randn((2, 5, 33, 47) if nd == 2 else (1, 5, 9, 17, 21), device=dev)
+        if cl:
+            fmt = torch.channels_last if nd == 2 else torch.channels_last_3d
+            x = x.contiguous(memory_format=fmt); m = m.to(memory_format=fmt)
+        y_fused = m(x)
+        y_plain = nn.Sequential.forward(m, x)
+    assert y_fused.shape == y_plain.shape
+    assert torch.equal(y_fused, y_plain)
+
+
+def test_bias_act_odd_channels_and_error():
+    import ctypes
+    import torch
+    from stardist_amd.lib import _native as N
+    dev = torch.device("cuda:0")
+    x = torch.randn(1000, 7, device=dev); b = torch.randn(7, device=dev)
+    ref = torch.relu(x + b)
+    N.check(N.lib().sd_bias_act_device(N.tptr(x), N.tptr(b), 1000, 7, 1, 1, N.current_stream()))
+    assert torch.equal(x, ref)
+    assert N.lib().sd_bias_act_device(N.tptr(x), N.tptr(b), 1000, 7, 1, 5, N.current_stream()) != 0
