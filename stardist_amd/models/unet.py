@@ -205,18 +205,45 @@ class StarDistNet(nn.Module):
             self.features_class = _conv(nd, c, n_after, k_after, act_after) if n_after > 0 else nn.Identity()
             self.prob_class = Conv(cf, cfg.n_classes + 1, (1,) * nd)
 
-    def forward(self, x):
-        pool = F.max_pool2d if self.nd == 2 else F.max_pool3d
-        for st in self.pre:
-            x = pool(st["convs"](x), st.pool)
-        base = self.backbone(x)
+    def _heads(self, base):
         f = self.features(base)
         prob = torch.sigmoid(self.prob(f))
         dist = self.dist(f)
         if self.n_classes is not None:
-            pc = torch.softmax(self.prob_class(self.features_class(base)), dim=1)
-            return prob, dist, pc
+            return prob, dist, torch.softmax(self.prob_class(self.features_class(base)), dim=1)
         return prob, dist
+
+    # MIOpen convolutions index with int32: a tensor of >= 2**31 elements (e.g. 128 feature channels on a 256^3 volume)
+    # silently drops PyTorch to its im2col+GEMM fallback, ~3x slower.  The head (features conv + 1x1 output convs) is
+    # therefore run on slabs along the first spatial axis, with a halo of the features kernel's radius.
+    _INDEX_LIMIT = 2 ** 31 - 1
+    _slab_on_cpu = False                      # tests only
+
+    def _heads_slabbed(self, base):
+        widest = max([base.shape[1], self.prob.in_channels, self.dist.out_channels] +
+                     ([self.prob_class.out_channels] if self.n_classes is not None else []))
+        per_plane = base.shape[0] * widest * int(np.prod(base.shape[3:]))
+        D = base.shape[2]
+        if not (base.is_cuda or self._slab_on_cpu) or per_plane * D <= self._INDEX_LIMIT:
+            return self._heads(base)
+        halo = self.features[0].kernel_size[0] // 2 if isinstance(self.features, nn.Sequential) else 0
+        cz = max(1, (self._INDEX_LIMIT // per_plane) - 2 * halo)
+        outs = None
+        for z0 in range(0, D, cz):
+            z1 = min(D, z0 + cz)
+            a, b = max(0, z0 - halo), min(D, z1 + halo)
+            part = self._heads(base[:, :, a:b])
+            if outs is None:
+                outs = [torch.empty(p.shape[:2] + (D,) + p.shape[3:], dtype=p.dtype, device=p.device) for p in part]
+            for o, p in zip(outs, part):
+                o[:, :, z0:z1] = p[:, :, z0 - a:z0 - a + (z1 - z0)]
+        return tuple(outs)
+
+    def forward(self, x):
+        pool = F.max_pool2d if self.nd == 2 else F.max_pool3d
+        for st in self.pre:
+            x = pool(st["convs"](x), st.pool)
+        return self._heads_slabbed(self.backbone(x))
 
 
 def init_he_normal_(net, seed=0):

@@ -132,3 +132,22 @@ def test_3d_models_build_and_predict_on_cpu():
         g = cfg.grid
         assert p.shape == (12 // g[0], 20 // g[1], 24 // g[2]) and d.shape == p.shape + (16,)
         assert (d >= 1e-3).all() and ((p > 0) & (p < 1)).all()
+
+
+def test_network_head_slabs_equal_whole_volume():
+    """the head is run on z-slabs with a halo when a tensor would exceed MIOpen's int32 indexing: same result"""
+    import torch
+    from stardist_amd.models.config import Config3D
+    from stardist_amd.models.unet import StarDistNet, init_he_normal_
+    from stardist_amd.rays3d import Rays_GoldenSpiral
+    cfg = Config3D(rays=Rays_GoldenSpiral(16), n_channel_in=1, unet_n_depth=1, unet_n_filter_base=4, net_conv_after_unet=8)
+    net = StarDistNet(cfg); init_he_normal_(net, 0); net.eval()
+    x = torch.randn(1, 1, 24, 16, 16)
+    with torch.no_grad():
+        ref = net(x)
+        net._slab_on_cpu = True
+        net._INDEX_LIMIT = 16 * 16 * 16 * 5          # forces 5 slabs of 3 planes + halo
+        out = net(x)
+    assert len(ref) == len(out)
+    for a, b in zip(ref, out):
+        assert a.shape == b.shape and torch.equal(a, b)
