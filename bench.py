@@ -43,8 +43,12 @@ def calibrate_heads(model, img, frac=0.10, radius=10.0, noise=0.1):
     net = model.net
     feats = {}
     h = net.features.register_forward_hook(lambda m, i, o: feats.__setitem__("f", o))
+    limit = net._INDEX_LIMIT
+    net._INDEX_LIMIT = 2 ** 62          # whole-volume head for the statistics (the timed path runs it in slabs)
     with torch.no_grad():
         model.predict(img)
+    net._INDEX_LIMIT = limit
+    model.__dict__.pop("_graphs", None)   # the captured HIP graph of this pass has the whole-volume head baked in
     h.remove()
     f = feats["f"].float()
     with torch.no_grad():

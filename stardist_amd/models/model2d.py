@@ -1,6 +1,8 @@
 """StarDist2D (prediction API) -- mirror of stardist/models/model2d.py:272-593 for the hot path."""
 import numpy as np
 
+from ..utils import to_host
+
 from ..geometry.geom2d import dist_to_coord, polygons_to_label
 from ..lib import _native as N
 from ..nms import non_maximum_suppression, non_maximum_suppression_sparse
@@ -55,7 +57,7 @@ class StarDist2D(StarDistBase):
         coord = dist_to_coord(disti, points, scale_dist=rescale)
         to_np = (lambda t: t.cpu().numpy()) if N.is_torch(coord) else (lambda t: t)
         if labels is not None and N.is_torch(labels):
-            labels = labels.cpu().numpy()
+            labels = to_host(labels)
         res_dict = dict(coord=to_np(coord), points=to_np(points), prob=to_np(probi))
         if prob_class is not None:
             prob_class = np.asarray(to_np(prob_class))

@@ -1,6 +1,8 @@
 """StarDist3D (prediction API) -- mirror of stardist/models/model3d.py:314-695 for the hot path."""
 import numpy as np
 
+from ..utils import to_host
+
 from ..geometry.geom3d import polyhedron_to_label
 from ..lib import _native as N
 from ..matching import relabel_sequential
@@ -64,7 +66,7 @@ class StarDist3D(StarDistBase):
                     labels[labels == fwd[overlap_label2]] = overlap_label
                 else:
                     labels, _, _ = relabel_sequential(labels)
-                labels = labels.cpu().numpy()
+                labels = to_host(labels)
             else:
                 if overlap_label is not None and overlap_label < 0 and (overlap_label in labels):
                     overlap_mask = (labels == overlap_label)

@@ -33,6 +33,26 @@ def _act(name):
     raise ValueError("activation %s not supported" % name)
 
 
+def _conv_bias_act(conv, x, kind):
+    """conv + bias + (0 linear | 1 relu) with the element-wise part done by the native one-pass kernel; None if not applicable"""
+    if not (x.is_cuda and conv.bias is not None and x.dtype == torch.float32 and not torch.is_grad_enabled()):
+        return None
+    from ..lib import _native as N
+    y = conv._conv_forward(x, conv.weight, None)
+    C = y.shape[1]
+    cl = torch.channels_last if y.dim() == 4 else torch.channels_last_3d
+    if y.is_contiguous(memory_format=cl):
+        n_outer, inner = y.numel() // C, 1
+    elif y.is_contiguous():
+        n_outer, inner = y.shape[0], y.numel() // (y.shape[0] * C)
+    else:
+        y = y + conv.bias.view((1, C) + (1,) * (y.dim() - 2))
+        return torch.relu_(y) if kind == 1 else y
+    N.check(N.lib().sd_bias_act_device(ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(conv.bias.data_ptr()), n_outer, C, inner, kind,
+                                       N.current_stream()))
+    return y
+
+
 class ConvAct(nn.Sequential):
     """[conv, activation] with the Keras layer's parameter names.  On a HIP device in inference the bias add and the
     (linear / relu) activation are done by one in-place pass of the native library (sd_bias_act_device) instead of two
@@ -41,21 +61,8 @@ class ConvAct(nn.Sequential):
     def forward(self, x):
         conv, act = self[0], self[1]
         kind = 0 if isinstance(act, nn.Identity) else (1 if isinstance(act, nn.ReLU) else -1)
-        if not (x.is_cuda and kind >= 0 and conv.bias is not None and x.dtype == torch.float32 and not torch.is_grad_enabled()):
-            return super().forward(x)
-        from ..lib import _native as N
-        y = conv._conv_forward(x, conv.weight, None)
-        C = y.shape[1]
-        cl = torch.channels_last if y.dim() == 4 else torch.channels_last_3d
-        if y.is_contiguous(memory_format=cl):
-            n_outer, inner = y.numel() // C, 1
-        elif y.is_contiguous():
-            n_outer, inner = y.shape[0], y.numel() // (y.shape[0] * C)
-        else:
-            return act(y + conv.bias.view((1, C) + (1,) * (y.dim() - 2)))
-        N.check(N.lib().sd_bias_act_device(ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(conv.bias.data_ptr()), n_outer, C, inner, kind,
-                                           N.current_stream()))
-        return y
+        y = _conv_bias_act(conv, x, kind) if kind >= 0 else None
+        return super().forward(x) if y is None else y
 
 
 def _conv(nd, cin, cout, k, act="relu", bias=True):
@@ -207,8 +214,11 @@ class StarDistNet(nn.Module):
 
     def _heads(self, base):
         f = self.features(base)
-        prob = torch.sigmoid(self.prob(f))
-        dist = self.dist(f)
+        p = _conv_bias_act(self.prob, f, 0)
+        prob = torch.sigmoid_(p) if p is not None else torch.sigmoid(self.prob(f))
+        dist = _conv_bias_act(self.dist, f, 0)
+        if dist is None:
+            dist = self.dist(f)
         if self.n_classes is not None:
             return prob, dist, torch.softmax(self.prob_class(self.features_class(base)), dim=1)
         return prob, dist
@@ -233,8 +243,10 @@ class StarDistNet(nn.Module):
             z1 = min(D, z0 + cz)
             a, b = max(0, z0 - halo), min(D, z1 + halo)
             part = self._heads(base[:, :, a:b])
-            if outs is None:
-                outs = [torch.empty(p.shape[:2] + (D,) + p.shape[3:], dtype=p.dtype, device=p.device) for p in part]
+            if outs is None:       # same memory format as the slabs, so that every slab lands as one contiguous block
+                cl = torch.channels_last_3d if base.dim() == 5 else torch.channels_last
+                outs = [torch.empty(p.shape[:2] + (D,) + p.shape[3:], dtype=p.dtype, device=p.device,
+                                    memory_format=cl if p.is_contiguous(memory_format=cl) else torch.contiguous_format) for p in part]
             for o, p in zip(outs, part):
                 o[:, :, z0:z1] = p[:, :, z0 - a:z0 - a + (z1 - z0)]
         return tuple(outs)
@@ -275,7 +287,7 @@ def conv_macs_per_input_pixel(net, cfg):
         if isinstance(m, (nn.Conv2d, nn.Conv3d)):
             hooks.append(m.register_forward_hook(hook))
     dev = next(net.parameters()).device
-    with torch.no_grad():
+    with torch.enable_grad():      # the plain module path (the fused inference epilogue bypasses the Conv modules' hooks)
         net(torch.zeros((1, cfg.n_channel_in) + shape, device=dev))
     for h in hooks:
         h.remove()

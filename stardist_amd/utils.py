@@ -40,3 +40,15 @@ def normalize(x, pmin=3, pmax=99.8, axis=None, clip=False, eps=1e-20, dtype=np.f
     mi = np.percentile(x, pmin, axis=axis, keepdims=True)
     ma = np.percentile(x, pmax, axis=axis, keepdims=True)
     return normalize_mi_ma(x, mi, ma, clip=clip, eps=eps, dtype=dtype)
+
+
+def to_host(t):
+    """device tensor -> numpy array through a page-locked staging tensor (PyTorch's caching host allocator re-uses the
+    pinned block once the returned array is dropped): ~50 GB/s over PCIe instead of the pageable path's ~5 GB/s."""
+    import torch
+    if not t.is_cuda:
+        return t.numpy()
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return h.numpy()
