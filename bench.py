@@ -241,7 +241,7 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pair_gbs / HBM_PEAK_GBS, 6), "traffic": None,
                      "bytes_per_launch": round(pair_bytes_per_launch), "avg_launch_ms": round(float(pair_ms / pair_launches), 4),
                      "launches_per_step": float(pair_launches), "pairs_per_step": float(n_pairs),
-                     "note": "latency-bound integer sweep; compulsory traffic is tiny (SURVEY.md 8d)"}
+                     "note": "integer scan-beam sweep, one pair per lane: bound by instruction issue under lane divergence, not by HBM; compulsory traffic is tiny (SURVEY.md 8d); measured HBM traffic: profiles/"}
         dominant = roof_pair if pair_ms + s2[6] / 1e6 > net_ms else roof_conv
         out = {
             "metric": "predict_instances() Mpix/s (2D) + Mvox/s (3D) end-to-end at 1/2/4/8 GPU",
