@@ -117,13 +117,19 @@ __global__ void k_cell_count(const float* __restrict__ pts, int N, GridP g, int*
   candCell[i] = c;
   atomicAdd(&cellCount[c], 1);
 }
+// candidates re-packed in cell order: the broad phase streams these 32-byte records (coalesced) instead of gathering
+// bbox / centre / area of every cell item by candidate index
+struct __attribute__((aligned(16))) CellRec { int4 bb; float py, px, area; int j; };
 __global__ void k_cell_fill(int N, const int* __restrict__ candCell, const int* __restrict__ cellStart,
-                            int* __restrict__ cellFill, int* __restrict__ cellItems) {
+                            int* __restrict__ cellFill, const float* __restrict__ pts, const int4* __restrict__ bbox,
+                            const float* __restrict__ area, CellRec* __restrict__ rec) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int c = candCell[i];
   const int pos = atomicAdd(&cellFill[c], 1);
-  cellItems[cellStart[c] + pos] = i;
+  CellRec r;
+  r.bb = bbox[i]; r.py = pts[2 * i]; r.px = pts[2 * i + 1]; r.area = area[i]; r.j = i;
+  rec[cellStart[c] + pos] = r;
 }
 
 __device__ __forceinline__ bool bbox_intersect(const int4 a, const int4 b) {   // stardist2d.cpp:142-148
@@ -157,18 +163,22 @@ __device__ __forceinline__ bool may_interact(const Flags f, const int4 bi, const
 #define WAIT_NONE (-2)
 #define WAIT_SCAN (-1)
 template <int MODE>
-__global__ void __launch_bounds__(256) k_neighbours(int N, GridP g, Flags f, const float* __restrict__ pts, const int4* __restrict__ bbox,
-                                                    const float* __restrict__ area, const int* __restrict__ candCell, const int* __restrict__ cellStart,
-                                                    const int* __restrict__ cellItems, int* __restrict__ nbrCount,
-                                                    const i64* __restrict__ nbrStart, int* __restrict__ nbr, int* __restrict__ waitOn, int W) {
+__global__ void __launch_bounds__(256) k_neighbours(int N, GridP g, Flags f, const CellRec* __restrict__ rec, const int* __restrict__ cellStart,
+                                                    int* __restrict__ nbrCount, const i64* __restrict__ nbrStart, int* __restrict__ nbr,
+                                                    int* __restrict__ waitOn, int W) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * (blockDim.x >> 6) + wave;
-  if (i >= N) return;
-  const int c = candCell[i];
-  const int cy = c / g.nx, cx = c - cy * g.nx;
-  const int4 bi = bbox[i];
-  const float pyi = pts[2 * i], pxi = pts[2 * i + 1];
-  const float ai = area[i];
+  // wave w handles the w-th candidate IN CELL ORDER, and consecutive workgroups of one XCD (blockIdx % 8) get consecutive
+  // cells: the 5x5 cell neighbourhoods of successive waves overlap almost completely and stay in that XCD's L2
+  const int per = gridDim.x >> 3;                                   // grid is a multiple of 8
+  const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int w = blk * (blockDim.x >> 6) + wave;
+  if (w >= N) return;
+  const CellRec me = rec[w];
+  const int i = me.j;
+  int cy, cx;
+  cell_of(g, me.py, me.px, cy, cx);
+  const int4 bi = me.bb;
+  const float pyi = me.py, pxi = me.px, ai = me.area;
   int total = 0;
   int minj = INT32_MAX;                      // MODE 1: best-scored neighbour above i (first wait target of the greedy scan)
   i64 base = MODE ? nbrStart[i] : 0;
@@ -180,8 +190,9 @@ __global__ void __launch_bounds__(256) k_neighbours(int N, GridP g, Flags f, con
       bool hit = false;
       int j = -1;
       if (idx < end) {
-        j = cellItems[idx];
-        if (j != i) hit = may_interact(f, bi, bbox[j], pyi, pxi, pts[2 * j], pts[2 * j + 1], ai, area[j]);
+        const CellRec r = rec[idx];
+        j = r.j;
+        if (j != i) hit = may_interact(f, bi, r.bb, pyi, pxi, r.py, r.px, ai, r.area);
       }
       const unsigned long long m = __ballot(hit);
       if (MODE) {
@@ -484,10 +495,10 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   int* cellCount = A.take_n<int>(nCells + 1);
   int* cellStart = A.take_n<int>(nCells + 1);
   int* cellFill = A.take_n<int>(nCells + 1);
-  int* cellItems = A.take_n<int>(N);
+  CellRec* cellRec = (CellRec*)A.take((size_t)N * sizeof(CellRec));
   int* nbrCount = A.take_n<int>(N + 1);
   i64* nbrStart = A.take_n<i64>(N + 1);
-  if (!cellCount || !cellStart || !cellFill || !cellItems || !nbrCount || !nbrStart) return -1;
+  if (!cellCount || !cellStart || !cellFill || !cellRec || !nbrCount || !nbrStart) return -1;
   SD_CHECK(hipMemsetAsync(cellCount, 0, (nCells + 1) * sizeof(int), s));
   SD_CHECK(hipMemsetAsync(cellFill, 0, (nCells + 1) * sizeof(int), s));
   hipLaunchKernelGGL(k_cell_count, dim3(sd::div_up(N, 256)), dim3(256), 0, s, d_points, N, g, cellCount, candCell);
@@ -499,7 +510,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   void* scanTmp = A.take(tmpBytes + 256);
   if (!scanTmp) return -1;
   SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tmpBytes, cellCount, cellStart, nCells + 1, s));
-  hipLaunchKernelGGL(k_cell_fill, dim3(sd::div_up(N, 256)), dim3(256), 0, s, N, candCell, cellStart, cellFill, cellItems);
+  hipLaunchKernelGGL(k_cell_fill, dim3(sd::div_up(N, 256)), dim3(256), 0, s, N, candCell, cellStart, cellFill, d_points, bbox, area, cellRec);
   SD_LAUNCH_CHECK();
 
   Flags f;
@@ -507,8 +518,9 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
 
   // ---- neighbour CSR
   SD_CHECK(hipMemsetAsync(nbrCount, 0, (N + 1) * sizeof(int), s));
-  hipLaunchKernelGGL((k_neighbours<0>), dim3(sd::div_up(N, 4)), dim3(256), 0, s, N, g, f, d_points, bbox, area, candCell, cellStart,
-                     cellItems, nbrCount, (const i64*)nullptr, (int*)nullptr, (int*)nullptr, W);
+  const int nbBlocks = (sd::div_up(N, 4) + 7) & ~7;
+  hipLaunchKernelGGL((k_neighbours<0>), dim3(nbBlocks), dim3(256), 0, s, N, g, f, cellRec, cellStart, nbrCount, (const i64*)nullptr, (int*)nullptr,
+                     (int*)nullptr, W);
   SD_LAUNCH_CHECK();
   SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tmpBytes, nbrCount, nbrStart, N + 1, s));
   i64 totalNbr = 0;
@@ -517,8 +529,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   int* nbr = A.take_n<int>((size_t)totalNbr);
   int* waitOn = A.take_n<int>(N);
   if (!nbr || !waitOn) return -1;
-  hipLaunchKernelGGL((k_neighbours<1>), dim3(sd::div_up(N, 4)), dim3(256), 0, s, N, g, f, d_points, bbox, area, candCell, cellStart,
-                     cellItems, nbrCount, (const i64*)nbrStart, nbr, waitOn, W);
+  hipLaunchKernelGGL((k_neighbours<1>), dim3(nbBlocks), dim3(256), 0, s, N, g, f, cellRec, cellStart, nbrCount, (const i64*)nbrStart, nbr, waitOn, W);
   SD_LAUNCH_CHECK();
 
   if (stats) { SD_CHECK(hipEventRecord(ev1, s)); SD_CHECK(hipEventSynchronize(ev1)); float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns_pre = ms * 1e6; }
