@@ -34,6 +34,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0
+# HBM bytes per pair-kernel launch measured with rocprofv3 PMC in separate passes (profiles/r01_pmc_hbm_traffic.md: raw
+# FETCH_SIZE + WRITE_SIZE, mean over the 7 launches of one step = 3 x (6864.6 + 5061.6) MiB scratch kernel + 4 x 0.8 MiB LDS
+# kernel).  Only valid for the default 2048^2 workload (checked against the pair count below).
+PAIR_TRAFFIC_BYTES_PER_LAUNCH_2048 = 5.36e9
+PAIR_TRAFFIC_PAIRS_2048 = 521706
 
 
 def calibrate_heads(model, img, frac=0.10, radius=10.0, noise=0.1):
@@ -242,6 +247,9 @@ def main():
                      "bytes_per_launch": round(pair_bytes_per_launch), "avg_launch_ms": round(float(pair_ms / pair_launches), 4),
                      "launches_per_step": float(pair_launches), "pairs_per_step": float(n_pairs),
                      "note": "integer scan-beam sweep, one pair per lane: bound by instruction issue under lane divergence, not by HBM; compulsory traffic is tiny (SURVEY.md 8d); measured HBM traffic: profiles/"}
+        if H == 2048 and W == 2048 and abs(float(n_pairs) - PAIR_TRAFFIC_PAIRS_2048) < 0.02 * PAIR_TRAFFIC_PAIRS_2048 and int(pair_launches) == 7:
+            roof_pair["traffic"] = PAIR_TRAFFIC_BYTES_PER_LAUNCH_2048
+            roof_pair["traffic_source"] = "profiles/r01_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, raw)"
         dominant = roof_pair if pair_ms + s2[6] / 1e6 > net_ms else roof_conv
         out = {
             "metric": "predict_instances() Mpix/s (2D) + Mvox/s (3D) end-to-end at 1/2/4/8 GPU",
