@@ -1286,6 +1286,13 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   const size_t lds5 = (size_t)6 * R * sizeof(float) + (size_t)3 * F * sizeof(int);
   const size_t lds4 = (size_t)16 * R * sizeof(double) + hivBytes + (size_t)20 * R * sizeof(unsigned short);   // cap = 2R
   if (lds3 > 150 * 1024 || lds5 > 150 * 1024 || lds4 > 150 * 1024) { sd::set_error("sd_nms3d: n_rays/n_faces too large for LDS staging"); return -1; }
+  const size_t ldsH = (size_t)3 * R * sizeof(double) + (size_t)2 * R * sizeof(unsigned int) +
+                      (R <= HULL_FAST_MAXR ? (size_t)12 * R * sizeof(unsigned int) + (size_t)R * R + 4 : 0);
+  // more than 64 KiB of dynamic LDS needs an explicit opt-in (only reached with several hundred rays)
+  if (lds3 > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_stage3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+  if (lds4 > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_stage4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+  if (lds5 > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_stage5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5));
+  if (ldsH > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_hull, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsH));
   sd::Arena& A = sd::arena();
   if (A.begin(s)) return -1;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1476,8 +1483,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
           SD_CHECK(hipStreamSynchronize(s));
           if (h.nHull > 0) {
             const unsigned int bh = h.nHull < 32768u ? h.nHull : 32768u;
-            hipLaunchKernelGGL(k_hull, dim3(bh), dim3(64), (size_t)3 * R * sizeof(double) + (size_t)hullCap * sizeof(unsigned int) +
-                                   (R <= HULL_FAST_MAXR ? (size_t)12 * R * sizeof(unsigned int) + (size_t)R * R + 4 : 0), s, hullList,
+            hipLaunchKernelGGL(k_hull, dim3(bh), dim3(64), ldsH, s, hullList,
                                h.nHull, d_dist, d_points, d_verts, R, hullCap, hullPlanes, hullAdj, hullCount);
             SD_LAUNCH_CHECK();
           }
