@@ -338,3 +338,117 @@ def predict_instances_big(model, img, axes, block_size, min_overlap, context=Non
             polys_all.setdefault(k, []).append(v)
     polys_all = {k: (np.concatenate(v) if k in OBJECT_KEYS else v[0]) for k, v in polys_all.items()}
     return (labels_out if labels_out is not None else False), polys_all
+
+
+def predict_instances_sharded(model, img, axes, block_size, min_overlap, context=None, prob_thresh=None, nms_thresh=None,
+                              return_labels=True, show_progress=False, distributed=None, predict_kwargs=None, nms_kwargs=None):
+    """Block-sharded prediction with a final cross-tile NMS (SURVEY.md 8e design A, the north-star's multi-GPU path).
+
+    The blocks of `BlockND.cover` (big.py:426-450) are dealt round-robin to the ranks of the default torch.distributed group
+    (one process per GPU; RCCL when the backend is "nccl").  Per block: network + candidate selection (`predict_sparse`) +
+    LOCAL NMS on the block incl. its context; of the local survivors a block keeps those whose centre lies in its write region
+    (= block minus context; neighbouring write regions overlap by >= min_overlap, so an object in an overlap band is seen
+    with full context by both blocks).  The kept survivors of all ranks -- 141 B (2D) / 401 B (3D) each -- are exchanged
+    with one all_gather of the counts and one padded all_gather per array; exact duplicates (same pixel reported by two
+    blocks) are dropped, then rank 0 runs the SAME NMS once more over the union in global score order (cross-tile conflicts
+    in the overlap bands) and rasterises the final instances.  Unlike `predict_instances_big` (design B, the reference's own semantics: per-block NMS +
+    bbox responsibility rule, no cross-tile NMS) label ids follow the global score order, as in `predict_instances`.
+
+    Returns (labels, dict) on rank 0 and (None, dict) on the other ranks (the label image is not broadcast)."""
+    from .models.base import axes_check_and_normalize, axes_dict
+    predict_kwargs = dict(predict_kwargs or {})
+    nms_kwargs = dict(nms_kwargs or {})
+    if getattr(model.config, "n_classes", None) is not None:
+        raise NotImplementedError("predict_instances_sharded: multi-class heads are not supported yet")
+    n = img.ndim
+    axes = axes_check_and_normalize(axes, length=n)
+    grid = model._axes_div_by(axes)
+    axes_out = model.config.axes.replace("C", "")
+    shape_dict = dict(zip(axes, img.shape))
+    shape_out = tuple(shape_dict[a] for a in axes_out)
+    if context is None:
+        context = model._axes_tile_overlap(axes)
+    if np.isscalar(block_size): block_size = n * [block_size]
+    if np.isscalar(min_overlap): min_overlap = n * [min_overlap]
+    if np.isscalar(context): context = n * [context]
+    block_size, min_overlap, context = list(block_size), list(min_overlap), list(context)
+    if "C" in axes:
+        i = axes_dict(axes)["C"]
+        block_size[i] = img.shape[i]
+        min_overlap[i] = context[i] = 0
+    block_size = tuple(_grid_divisible(g, v, name="block_size", verbose=False) for v, g in zip(block_size, grid))
+    min_overlap = tuple(_grid_divisible(g, v, name="min_overlap", verbose=False) for v, g in zip(min_overlap, grid))
+    context = tuple(_grid_divisible(g, v, name="context", verbose=False) for v, g in zip(context, grid))
+    blocks = BlockND.cover(img.shape, axes, block_size, min_overlap, context, grid)
+    if show_progress:
+        print("sharded: %d blocks, block_size=%s, min_overlap=%s, context=%s" % (len(blocks), block_size, min_overlap, context), flush=True)
+
+    dist_, rank, world = None, 0, 1
+    try:
+        import torch.distributed as td
+        if (distributed is None and td.is_available() and td.is_initialized()) or distributed:
+            dist_, rank, world = td, td.get_rank(), td.get_world_size()
+    except ImportError:
+        pass
+
+    # ---- phase 1: my blocks -> local survivors inside the block's write region, global coordinates
+    nd = len(axes_out)
+    k_pts, k_prob, k_dist, k_blk = [], [], [], []
+    for bi, block in enumerate(blocks):
+        if bi % world != rank:
+            continue
+        res = model.predict_sparse(block.read(img, axes=axes), axes=axes, prob_thresh=prob_thresh, **predict_kwargs)
+        prob, dist, points = np.asarray(res[0]), np.asarray(res[1]), np.asarray(res[-1])
+        if len(prob) == 0:
+            continue
+        keep = np.asarray(model._nms_sparse(dist, prob, points, nms_thresh=nms_thresh, **nms_kwargs)).astype(np.int64)
+        bl = block.blocks_for_axes(axes_out)
+        start = np.array([t.start for t in bl]).reshape(1, nd)
+        lo = np.array([t.start + t.context_start for t in bl]).reshape(1, nd)
+        hi = np.array([t.end - t.context_end for t in bl]).reshape(1, nd)
+        gp = points[keep].astype(np.int64) + start
+        inside = np.all((gp >= lo) & (gp < hi), axis=1)
+        k_pts.append(gp[inside]); k_prob.append(prob[keep][inside]); k_dist.append(dist[keep][inside])
+        k_blk.append(np.full(int(inside.sum()), bi, np.int64))
+    n_rays = model.config.n_rays
+    pts = np.concatenate(k_pts) if k_pts else np.zeros((0, nd), np.int64)
+    prob = np.concatenate(k_prob).astype(np.float32) if k_prob else np.zeros((0,), np.float32)
+    dst = np.concatenate(k_dist).astype(np.float32) if k_dist else np.zeros((0, n_rays), np.float32)
+    blk = np.concatenate(k_blk) if k_blk else np.zeros((0,), np.int64)
+
+    # ---- phase 2: exchange (counts, then padded arrays); every rank ends up with the union
+    if dist_ is not None and world > 1:
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist_.get_backend() == "nccl" else torch.device("cpu")
+        cnt = torch.tensor([len(prob)], dtype=torch.int64, device=dev)
+        cnts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist_.all_gather(cnts, cnt)
+        cnts = [int(c.item()) for c in cnts]
+        cap = max(max(cnts), 1)
+
+        def exchange(a, dtype):
+            t = torch.zeros((cap,) + a.shape[1:], dtype=dtype, device=dev)
+            if len(a):
+                t[:len(a)] = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist_.all_gather(out, t)
+            return np.concatenate([o[:c].cpu().numpy() for o, c in zip(out, cnts)])
+        pts, prob, dst, blk = exchange(pts, torch.int64), exchange(prob, torch.float32), exchange(dst, torch.float32), exchange(blk, torch.int64)
+    # canonical order (block index, then the block's score order): the result does not depend on the number of ranks
+    order = np.argsort(blk, kind="stable")
+    pts, prob, dst = pts[order], prob[order], dst[order]
+    if len(pts):                                     # same pixel reported by two overlapping blocks: keep the first
+        _, first = np.unique(pts, axis=0, return_index=True)
+        first.sort()
+        pts, prob, dst = pts[first], prob[first], dst[first]
+
+    # ---- phase 3: rank 0: final NMS over the union + rasterisation
+    labels, res_dict = None, None
+    if rank == 0:
+        labels, res_dict = model._instances_from_prediction(shape_out, prob, dst, points=pts, prob_thresh=prob_thresh, nms_thresh=nms_thresh,
+                                                            return_labels=return_labels, **nms_kwargs)
+    if dist_ is not None and world > 1:
+        box = [res_dict]
+        dist_.broadcast_object_list(box, src=0)
+        res_dict = box[0]
+    return labels, res_dict

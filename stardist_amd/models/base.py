@@ -504,6 +504,12 @@ class StarDistBase(object):
         return predict_instances_big(self, img, axes, block_size, min_overlap, context=context, labels_out=labels_out,
                                      labels_out_dtype=labels_out_dtype, show_progress=show_progress, **kwargs)
 
+    def predict_instances_sharded(self, img, axes, block_size, min_overlap, context=None, **kwargs):
+        """Block-sharded prediction over the ranks of torch.distributed with a final cross-tile NMS on rank 0
+        (SURVEY.md 8e design A); see stardist_amd/big.py::predict_instances_sharded."""
+        from ..big import predict_instances_sharded
+        return predict_instances_sharded(self, img, axes, block_size, min_overlap, context=context, **kwargs)
+
     def predict_instances(self, *args, **kwargs):
         """Predict instance segmentation: returns (labels, dict) exactly like the reference (base.py:775-790)."""
         r = None

@@ -65,6 +65,12 @@ class StarDist2D(StarDistBase):
             res_dict.update(dict(class_prob=prob_class, class_id=class_id))
         return labels, res_dict
 
+    def _nms_sparse(self, dist, prob, points, nms_thresh=None, **nms_kwargs):
+        """indices (into the given candidates) of the NMS survivors, best score first (used by the sharded predictor)"""
+        if nms_thresh is None: nms_thresh = self.thresholds.nms
+        inds = non_maximum_suppression_sparse(dist, prob, points, nms_thresh=nms_thresh, **nms_kwargs)[3]
+        return inds.cpu().numpy() if N.is_torch(inds) else np.asarray(inds)
+
     def _axes_div_by(self, query_axes):
         """model2d.py:566-574"""
         query_axes = axes_check_and_normalize(query_axes)

@@ -86,6 +86,13 @@ class StarDist3D(StarDistBase):
             res_dict.update(dict(class_prob=prob_class, class_id=np.argmax(prob_class, axis=-1)))
         return labels, res_dict
 
+    def _nms_sparse(self, dist, prob, points, nms_thresh=None, **nms_kwargs):
+        """indices (into the given candidates) of the NMS survivors, best score first (used by the sharded predictor)"""
+        if nms_thresh is None: nms_thresh = self.thresholds.nms
+        rays = rays_from_json(self.config.rays_json)
+        inds = non_maximum_suppression_3d_sparse(dist, prob, points, rays, nms_thresh=nms_thresh, **nms_kwargs)[3]
+        return inds.cpu().numpy() if N.is_torch(inds) else np.asarray(inds)
+
     def _axes_div_by(self, query_axes):
         """model3d.py:677-690"""
         if self.config.backbone == "unet":

@@ -110,3 +110,96 @@ def test_sharded_equals_sequential_gloo_world2():
     for rank, labels, pts, prob in res:
         assert np.array_equal(labels, ref_labels), rank
         assert np.array_equal(pts, ref_polys["points"]) and len(prob) == len(ref_polys["prob"])
+
+
+# ---------------------------------------------------------------- design A: sharded prediction + final cross-tile NMS
+class _FieldModel(object):
+    """'Network' = identity on a (H, W, 1 + n_rays) field holding prob and dist; NMS / rasteriser = the oracle (compiled
+    reference NMS + numpy port of the Python rasteriser), i.e. exactly what the product calls on the GPU."""
+    n_rays = 32
+
+    def __init__(self):
+        from stardist_amd.models.config import Config2D
+        self.config = Config2D(n_rays=self.n_rays, n_channel_in=1 + self.n_rays)
+
+        class T: prob, nms = 0.5, 0.4
+        self.thresholds = T()
+
+    def _axes_div_by(self, axes): return tuple(1 for a in axes)
+
+    def _axes_tile_overlap(self, axes): return tuple(0 for a in axes)
+
+    def predict_sparse(self, x, axes=None, prob_thresh=None, **kw):
+        from oracle import port
+        prob, dist = x[..., 0], x[..., 1:]
+        mask = port.ind_prob_thresh(prob, self.thresholds.prob if prob_thresh is None else prob_thresh, b=2)
+        return prob[mask], dist[mask], np.stack(np.where(mask), 1)
+
+    def _order(self, prob): return np.argsort(prob, kind="stable")[::-1]
+
+    def _nms_sparse(self, dist, prob, points, nms_thresh=None, **kw):
+        from oracle import ref
+        ind = self._order(prob)
+        keep = ref.stardist2d().c_non_max_suppression_inds(np.ascontiguousarray(dist[ind], np.float32), np.ascontiguousarray(points[ind], np.float32),
+                                                           1, 1, 0, np.float32(self.thresholds.nms if nms_thresh is None else nms_thresh))
+        return ind[keep]
+
+    def _instances_from_prediction(self, shape, prob, dist, points=None, prob_thresh=None, nms_thresh=None, return_labels=True, **kw):
+        from oracle import port
+        s = self._nms_sparse(dist, prob, points, nms_thresh)
+        d, p, pr = dist[s], points[s], prob[s]
+        labels = port.polygons_to_label(d, p, shape, prob=pr) if return_labels else None
+        return labels, dict(coord=port.dist_to_coord(d, p), points=p, prob=pr)
+
+
+def _field(shape=(192, 224), seed=3):
+    """StarDist-style targets of a synthetic nuclei image: prob = normalised distance transform, dist = reference c_star_dist"""
+    from scipy import ndimage as ndi
+    from oracle import ref, synth
+    lbl = synth.s2d_nuclei_labels(shape[0], shape[1], seed=seed)[0].astype(np.uint16)
+    dist = ref.stardist2d().c_star_dist(lbl, _FieldModel.n_rays, 1, 1)
+    edt = ndi.distance_transform_edt(lbl > 0)
+    mx = ndi.maximum(edt, lbl, index=np.arange(0, lbl.max() + 1)); mx[0] = 1
+    prob = (edt / np.maximum(mx[lbl], 1e-6)).astype(np.float32)
+    prob += np.random.RandomState(seed).uniform(0, 1e-3, prob.shape).astype(np.float32)   # break exact ties
+    return np.concatenate([prob[..., None], dist.astype(np.float32)], -1), lbl
+
+
+def _sharded_worker(rank, world, port_, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port_)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stardist_amd.big import predict_instances_sharded
+    from test_cpu_big import _FieldModel, _field
+    x, _ = _field()
+    labels, res = predict_instances_sharded(_FieldModel(), x, "YXC", 96, 32, context=16)
+    q.put((rank, labels, res["points"], res["prob"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_cross_tile_nms_equals_whole_image(refmods):
+    """design A: per-block local NMS + survivor exchange + final NMS on rank 0 == predict_instances on the whole image"""
+    from stardist_amd.big import predict_instances_sharded
+    m = _FieldModel()
+    x, lbl = _field()
+    p, d, pts = m.predict_sparse(x)
+    ref_labels, ref_res = m._instances_from_prediction(x.shape[:2], p, d, points=pts)
+    assert len(ref_res["prob"]) >= 0.9 * lbl.max() > 10
+    labels, res = predict_instances_sharded(m, x, "YXC", 96, 32, context=16)              # single process, 9 blocks
+    assert np.array_equal(res["points"], ref_res["points"]) and np.array_equal(labels, ref_labels)
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port_ = 29950 + os.getpid() % 40
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port_, q)) for r in range(2)]
+    for pr in procs: pr.start()
+    out = [q.get(timeout=240) for _ in range(2)]
+    for pr in procs: pr.join(60)
+    for rank, lab, pts2, prob2 in out:
+        assert np.array_equal(pts2, ref_res["points"]) and np.allclose(prob2, ref_res["prob"]), rank
+        if rank == 0:
+            assert np.array_equal(lab, ref_labels)
+        else:
+            assert lab is None
