@@ -87,6 +87,21 @@ def test_nms3d_nuclei_survivors(refmods, n, thr, aniso):
     assert np.array_equal(keep, ref_keep), (int(keep.sum()), int(ref_keep.sum()), stats.tolist())
 
 
+def test_nms3d_volume_bounds_do_not_change_decisions(refmods, monkeypatch):
+    """the inscribed / circumscribed polytope shortcut vs exact volumes for every pair: same survivors"""
+    from oracle import synth
+    from stardist_amd.lib import stardist3d as sd3
+    rays = _rays(96)
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    d, p, s, nobj = synth.s3d_nuclei(96, rays.vertices)
+    keep_bounds = sd3.c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(0.3))
+    monkeypatch.setenv("SD_NMS3D_NO_LB", "1")
+    keep_exact = sd3.c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(0.3))
+    monkeypatch.delenv("SD_NMS3D_NO_LB")
+    ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(0.3))
+    assert np.array_equal(keep_bounds, keep_exact) and np.array_equal(keep_exact, ref_keep)
+
+
 def test_nms3d_flags_and_edges(refmods):
     from stardist_amd.lib import stardist3d as sd3
     rays = _rays(32)
