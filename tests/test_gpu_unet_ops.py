@@ -1,4 +1,5 @@
-"""GPU: the fused bias+activation epilogue equals the framework's two element-wise passes (fp32, exact: one add, one max)."""
+"""GPU: the fused bias+activation epilogue equals the framework's two element-wise passes (the epilogue itself is exact: one
+add, one max -- checked bit for bit on a plain tensor below)."""
 import numpy as np
 import pytest
 
@@ -22,7 +23,10 @@ def test_conv_bias_act_fused_equals_plain(nd, act, cl):
         y_fused = m(x)
         y_plain = nn.Sequential.forward(m, x)
     assert y_fused.shape == y_plain.shape
-    assert torch.equal(y_fused, y_plain)
+    # two separate convolution launches (MIOpen may pick an atomics-based solver): identical up to float summation order
+    assert torch.allclose(y_fused, y_plain, rtol=1e-5, atol=1e-5)
+    if act == "relu":
+        assert float(y_fused.min()) >= 0.0
 
 
 def test_bias_act_odd_channels_and_error():
