@@ -89,3 +89,25 @@ def dist_to_coord3D(dist, points, rays_vertices):
                 rays_vertices.shape[-1] == 3, dist.shape[-1] == len(rays_vertices))):
         raise ValueError("Wrong shapes! dist -> (m,n) points -> (m,3) rays_vertices -> (m,)")
     return points[:, np.newaxis] + dist[..., np.newaxis] * rays_vertices
+
+
+def dist_to_volume(dist, rays):
+    """volumes of the polyhedra, dist.shape = (nz, ny, nx, n_rays) (geom3d.py:220-235)"""
+    from ..lib.stardist3d import c_dist_to_volume
+    if dist.ndim != 4:
+        raise ValueError("dist.ndim = %d but should be 4" % dist.ndim)
+    if dist.shape[-1] != len(rays):
+        raise ValueError("dist.shape[-1] = %d but should be %d" % (dist.shape[-1], len(rays)))
+    return c_dist_to_volume(dist, rays.vertices.astype(np.float32), rays.faces.astype(np.int32))
+
+
+def dist_to_centroid(dist, rays, mode="absolute"):
+    """centroids of the polyhedra, mode = 'absolute' or 'relative' (geom3d.py:238-257)"""
+    from ..lib.stardist3d import c_dist_to_centroid
+    if dist.ndim != 4:
+        raise ValueError("dist.ndim = %d but should be 4" % dist.ndim)
+    if dist.shape[-1] != len(rays):
+        raise ValueError("dist.shape[-1] = %d but should be %d" % (dist.shape[-1], len(rays)))
+    if mode not in ("absolute", "relative"):
+        raise ValueError("mode should be either 'absolute' or 'relative'")
+    return c_dist_to_centroid(dist, rays.vertices.astype(np.float32), rays.faces.astype(np.int32), int(mode == "absolute"))

@@ -91,3 +91,66 @@ def c_star_dist3d(src, pdz, pdy, pdx, n_rays, grid_z, grid_y, grid_x):
     dst = np.empty(((Z - 1) // gz + 1, (Y - 1) // gy + 1, (X - 1) // gx + 1, n_rays), np.float32)
     N.check(N.lib().sd_star_dist3d_host(N.ptr(src), Z, Y, X, N.ptr(pdz), N.ptr(pdy), N.ptr(pdx), n_rays, gz, gy, gx, N.ptr(dst)))
     return dst
+
+
+# ---- analysis helpers of the same native module (not on the prediction path): tensor formulation on the device
+def _tet_terms(dist, verts, faces):
+    """signed volumes of the tetrahedra (origin, A, B, C) of every face and the vertex sums A+B+C; dist (..., R) float32 tensor.
+    tetrahedron_volume / polyhedron_volume, stardist3d_impl.cpp:234-291 (fp32; the face sum is a tree sum here, sequential there)."""
+    P = dist[..., None] * verts                                   # (..., R, 3) in (z, y, x)
+    A, B, C = P[..., faces[:, 0], :], P[..., faces[:, 1], :], P[..., faces[:, 2], :]
+    M0, M1, M2 = B - A, C - A, -A
+    det = (M0[..., 0] * (M1[..., 1] * M2[..., 2] - M2[..., 1] * M1[..., 2])
+           - M0[..., 1] * (M1[..., 0] * M2[..., 2] - M1[..., 2] * M2[..., 0])
+           + M0[..., 2] * (M1[..., 0] * M2[..., 1] - M1[..., 1] * M2[..., 0]))
+    return det / 6.0, A + B + C
+
+
+def _dist_to_volume_t(dist, verts, faces, chunk=8):
+    import torch
+    out = torch.empty(dist.shape[:-1], dtype=torch.float32, device=dist.device)
+    for z in range(0, dist.shape[0], chunk):
+        out[z:z + chunk] = _tet_terms(dist[z:z + chunk], verts, faces)[0].sum(-1)
+    return out
+
+
+def _dist_to_centroid_t(dist, verts, faces, absolute, chunk=8):
+    import torch
+    out = torch.empty(dist.shape[:-1] + (3,), dtype=torch.float32, device=dist.device)
+    for z in range(0, dist.shape[0], chunk):
+        vol_f, s = _tet_terms(dist[z:z + chunk], verts, faces)
+        vol = vol_f.sum(-1)
+        R = (0.25 * s * vol_f[..., None]).sum(-2)                  # stardist3d_impl.cpp:327-329
+        c = torch.where((vol > 1e-10)[..., None], R / vol[..., None].clamp_min(1e-30), torch.zeros_like(R))   # :335-337
+        out[z:z + chunk] = c
+    if absolute:                                                   # :1581-1583
+        Z, Y, X = dist.shape[:3]
+        grid = torch.stack(torch.meshgrid(torch.arange(Z, device=dist.device), torch.arange(Y, device=dist.device),
+                                          torch.arange(X, device=dist.device), indexing="ij"), -1).to(torch.float32)
+        out = out + grid
+    return out
+
+
+def _analysis_call(fn, dist, verts, faces, *extra):
+    import torch
+    N.require_device()
+    as_np = not N.is_torch(dist)
+    dev = torch.device("cuda") if as_np else dist.device
+    d = (torch.from_numpy(np.ascontiguousarray(dist, np.float32)) if as_np else dist.float()).to(dev)
+    if d.dim() != 4:
+        raise ValueError("dist.ndim = %d but should be 4" % d.dim())
+    v = torch.as_tensor(np.asarray(verts.cpu() if N.is_torch(verts) else verts), dtype=torch.float32, device=dev)
+    f = torch.as_tensor(np.asarray(faces.cpu() if N.is_torch(faces) else faces), dtype=torch.int64, device=dev)
+    out = fn(d, v, f, *extra)
+    return out.cpu().numpy() if as_np else out
+
+
+def c_dist_to_volume(dist, verts, faces):
+    """stardist3d.cpp:148-194 -> _COMMON_dist_to_volume (stardist3d_impl.cpp:1529-1556): dist (Z,Y,X,R) -> volumes (Z,Y,X) float32."""
+    return _analysis_call(_dist_to_volume_t, dist, verts, faces)
+
+
+def c_dist_to_centroid(dist, verts, faces, absolute):
+    """stardist3d.cpp:196-243 -> _COMMON_dist_to_centroid (:1558-1589): dist (Z,Y,X,R) -> centroids (Z,Y,X,3) float32 (z,y,x),
+    relative to the voxel or (absolute=1) in volume coordinates."""
+    return _analysis_call(_dist_to_centroid_t, dist, verts, faces, int(absolute))

@@ -99,3 +99,25 @@ def test_port_polygon_rule():
     coord = np.stack([np.stack([r, c]), np.stack([r + 1, c + 1])])
     lbl = port.polygons_to_label_coord(coord, (12, 12))
     assert lbl[2, 3] == 1 and lbl[5, 5] == 2 and lbl[9, 10] == 2
+
+
+def test_dist_to_volume_and_centroid_tensor_formulation_vs_reference(refmods):
+    """the tensor formulation used by stardist_amd.lib.stardist3d.c_dist_to_volume / c_dist_to_centroid (run here on CPU
+    tensors; the public wrappers only run on a HIP device) against the compiled reference, within the 1e-5 float tolerance"""
+    import torch
+    from stardist_amd.lib import stardist3d as sd3
+    from stardist_amd.rays3d import Rays_GoldenSpiral
+    rays = Rays_GoldenSpiral(33, anisotropy=(2, 1, 1))
+    V, F = rays.vertices.astype(np.float32), rays.faces.astype(np.int32)
+    rng = np.random.RandomState(0)
+    dist = (5 + 3 * rng.rand(5, 6, 7, 33)).astype(np.float32)
+    dist[0, 0, 0] = 0
+    m3 = refmods.stardist3d()
+    ref_vol = m3.c_dist_to_volume(dist, V, F)
+    tv, tf = torch.from_numpy(V), torch.from_numpy(F.astype(np.int64))
+    vol = sd3._dist_to_volume_t(torch.from_numpy(dist), tv, tf, chunk=2).numpy()
+    assert vol.shape == ref_vol.shape and np.allclose(vol, ref_vol, rtol=1e-5, atol=1e-4)
+    for absolute in (0, 1):
+        ref_c = m3.c_dist_to_centroid(dist, V, F, absolute)
+        c = sd3._dist_to_centroid_t(torch.from_numpy(dist), tv, tf, absolute, chunk=3).numpy()
+        assert c.shape == ref_c.shape and np.allclose(c, ref_c, rtol=1e-5, atol=1e-4)

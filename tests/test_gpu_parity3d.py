@@ -138,3 +138,16 @@ def test_nms3d_accuracy_like_reference(refmods, noise, n_rays):
     r1 = refmods.stardist3d().c_non_max_suppression_inds(dist, points, V, F, prob, 1, 1, 0, np.float32(0.95 * iou))
     r2 = refmods.stardist3d().c_non_max_suppression_inds(dist, points, V, F, prob, 1, 1, 0, np.float32(1.05 * iou))
     assert np.array_equal(k1, r1) and np.array_equal(k2, r2)
+
+
+def test_dist_to_volume_and_centroid_vs_reference(refmods):
+    """analysis helpers of the native module (stardist3d.cpp:148-243), float tolerance 1e-5"""
+    from stardist_amd.geometry.geom3d import dist_to_centroid, dist_to_volume
+    rays = _rays(48)
+    V, F = rays.vertices.astype(np.float32), rays.faces.astype(np.int32)
+    rng = np.random.RandomState(1)
+    dist = (4 + 4 * rng.rand(9, 10, 11, 48)).astype(np.float32)
+    m3 = refmods.stardist3d()
+    assert np.allclose(dist_to_volume(dist, rays), m3.c_dist_to_volume(dist, V, F), rtol=1e-5, atol=1e-4)
+    for mode in ("absolute", "relative"):
+        assert np.allclose(dist_to_centroid(dist, rays, mode), m3.c_dist_to_centroid(dist, V, F, int(mode == "absolute")), rtol=1e-5, atol=1e-4)
