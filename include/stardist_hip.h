@@ -139,6 +139,24 @@ int sd_select_candidates_device(const float* d_prob, const float* d_dist, int nd
                                 int cap, float* d_out_prob, float* d_out_dist,
                                 int32_t* d_out_points, int32_t* d_count, void* stream);
 
+/* ---- reference-style C ABI for the natives that have none in the reference --------------------
+ * (stardist/lib/stardist3d_lib.h:52-79 covers only the two 3D functions above).  Same conventions: host pointers, caller
+ * owns all buffers, no return code (errors abort with a message on stderr).  Argument meaning as the CPython functions:
+ *   _LIB_non_maximum_suppression_2d  <- c_non_max_suppression_inds      stardist2d.cpp:390-615  (dist, points sorted by score)
+ *   _LIB_polygon_to_label            <- polygons_to_label_coord         geom2d.py:149-166       (coord (n,2,n_rays); result (ny,nx))
+ *   _LIB_star_dist                   <- c_star_dist                     stardist2d.cpp:55-124
+ *   _LIB_star_dist3d                 <- c_star_dist3d                   stardist3d.cpp:245-346 */
+void _LIB_non_maximum_suppression_2d(const float* dist, const float* points, const int n_polys,
+                                     const int n_rays, const float threshold, const int use_bbox,
+                                     const int use_kdtree, const int verbose, bool* result);
+void _LIB_polygon_to_label(const float* coord, const int* labels, const int n_polys,
+                           const int n_rays, const int ny, const int nx, int* result);
+void _LIB_star_dist(const unsigned short* src, const int ny, const int nx, const int n_rays,
+                    const int grid_y, const int grid_x, float* dst);
+void _LIB_star_dist3d(const unsigned short* src, const int nz, const int ny, const int nx,
+                      const float* pdz, const float* pdy, const float* pdx, const int n_rays,
+                      const int grid_z, const int grid_y, const int grid_x, float* dst);
+
 /* ---- network epilogue ------------------------------------------------------------------------
  * bias + activation of a convolution output in one in-place pass (the reference's Keras Conv layers do both inside the
  * layer: csbdeep unet_block / resnet_block as called from stardist/models/model2d.py:310-349, model3d.py:360-447).

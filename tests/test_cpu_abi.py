@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     txt = open(os.path.join(ROOT, "include", "stardist_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    names = re.findall(r"\b(sd_[a-z0-9_]+|_LIB_[a-z_]+)\s*\(", txt)
+    names = re.findall(r"\b(sd_[a-z0-9_]+|_LIB_[a-z0-9_]+)\s*\(", txt)
     return sorted(set(names))
 
 
