@@ -95,3 +95,24 @@ def test_raster2d_matches_port(refmods):
     lbl = sd2.c_polygons_to_label(coord[ind], ind.astype(np.int32), (96, 128))
     assert lbl.dtype == np.int32
     assert np.array_equal(lbl, ref_lbl), np.count_nonzero(lbl != ref_lbl)
+
+
+def test_reference_style_c_abi_2d(refmods):
+    """_LIB_non_maximum_suppression_2d / _LIB_star_dist / _LIB_polygon_to_label (plain C ABI, host pointers) == the sd_* entry points"""
+    import ctypes
+    from oracle import port, synth
+    from stardist_amd.lib import _native as N, stardist2d as sd2
+    d, p, s = synth.s2d_uniform(96, 128)
+    keep = sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4))
+    res = np.zeros(len(d), np.bool_)
+    N.lib()._LIB_non_maximum_suppression_2d(N.ptr(d), N.ptr(p), len(d), d.shape[1], ctypes.c_float(0.4), 1, 1, 0, res.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(res, keep)
+    lbl = synth.s2d_nuclei_labels(64, 80, seed=2)[0].astype(np.uint16)
+    dst = np.zeros((64, 80, 16), np.float32)
+    N.lib()._LIB_star_dist(N.ptr(lbl), 64, 80, 16, 1, 1, N.ptr(dst))
+    assert np.array_equal(dst, refmods.stardist2d().c_star_dist(lbl, 16, 1, 1))
+    coord = np.ascontiguousarray(port.dist_to_coord(d[keep], p[keep]), np.float32)
+    ids = np.arange(len(coord), dtype=np.int32)
+    out = np.zeros((96, 128), np.int32)
+    N.lib()._LIB_polygon_to_label(N.ptr(coord), N.ptr(ids), len(coord), coord.shape[2], 96, 128, N.ptr(out))
+    assert np.array_equal(out, sd2.c_polygons_to_label(coord, ids, (96, 128)))
