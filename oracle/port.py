@@ -5,10 +5,12 @@ installed), so the pure-Python pieces between the network 
 natives are restated, each function citing the reference lines it follows.  The natives
 themselves are NOT restated: they are the compiled reference in oracle/_ref (oracle.ref).
 
-Parity status: `polygon` restates scikit-image's published rule (skimage/draw/_draw.pyx
-`_polygon` + skimage/_shared/geometry.pyx `point_in_polygon`, the OUTSIDE/INSIDE/VERTEX/EDGE
-version); scikit-image is absent from /root/reference and from this image, so this one
-function is "parity unpinned" (no golden vector available).
+Parity status: `polygon` restates scikit-image's rule (skimage/draw/_draw.pyx `_polygon` +
+skimage/_shared/geometry.pyx `point_in_polygon`, the OUTSIDE/INSIDE/VERTEX/EDGE version).
+scikit-image is absent from /root/reference and from the default interpreter, but the image's
+Anaconda python has scikit-image 0.18.3: tests/golden/make_raster2d_golden.py runs the
+reference's geom2d functions on it, and `polygon` / `polygons_to_label*` reproduce those golden
+label images bit for bit (tests/test_cpu_oracle.py) -- pinned.
 """
 import numpy as np
 

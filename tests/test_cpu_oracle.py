@@ -121,3 +121,32 @@ def test_dist_to_volume_and_centroid_tensor_formulation_vs_reference(refmods):
         ref_c = m3.c_dist_to_centroid(dist, V, F, absolute)
         c = sd3._dist_to_centroid_t(torch.from_numpy(dist), tv, tf, absolute, chunk=3).numpy()
         assert c.shape == ref_c.shape and np.allclose(c, ref_c, rtol=1e-5, atol=1e-4)
+
+
+RASTER_CASES = ("stars32", "stars8_small", "stars64_big", "stars5_int")
+
+
+def _raster_golden():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raster2d_reference.npz"))
+
+
+@pytest.mark.parametrize("name", RASTER_CASES)
+def test_port_rasteriser_equals_reference_with_real_skimage(name):
+    """oracle/port.py's restatement of skimage.draw.polygon + geom2d.polygons_to_label against golden label images made by the
+    reference's own code running on the real scikit-image (tests/golden/make_raster2d_golden.py): bit-identical"""
+    from oracle import port
+    g = _raster_golden()
+    lbl = port.polygons_to_label(g[name + "_dist"], g[name + "_points"], tuple(g[name + "_shape"]), prob=g[name + "_prob"], thr=0.2)
+    assert lbl.dtype == np.int32 and np.array_equal(lbl, g[name + "_labels"])
+
+
+def test_port_polygon_rule_on_lattice_and_degenerate_cases():
+    """vertices / edges exactly on pixel centres, half-integer rectangles, zero-area, bow-tie, clipped polygons"""
+    from oracle import port
+    g = _raster_golden()
+    coord, shape = g["explicit_coord"], tuple(g["explicit_shape"])
+    assert np.array_equal(port.polygons_to_label_coord(coord, shape), g["explicit_labels"])
+    for i, c in enumerate(coord):
+        rr, cc = port.polygon(c[0], c[1], shape)
+        m = np.zeros(shape, bool); m[rr, cc] = True
+        assert np.array_equal(m, g["explicit_mask%d" % i]), i

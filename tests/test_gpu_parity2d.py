@@ -116,3 +116,26 @@ def test_reference_style_c_abi_2d(refmods):
     out = np.zeros((96, 128), np.int32)
     N.lib()._LIB_polygon_to_label(N.ptr(coord), N.ptr(ids), len(coord), coord.shape[2], 96, 128, N.ptr(out))
     assert np.array_equal(out, sd2.c_polygons_to_label(coord, ids, (96, 128)))
+
+
+@pytest.mark.parametrize("name", ("stars32", "stars8_small", "stars64_big", "stars5_int"))
+def test_raster2d_equals_reference_with_real_skimage(name):
+    """HIP rasteriser against golden label images made by the reference's own geom2d code on the real scikit-image
+    (tests/golden/make_raster2d_golden.py): bit-identical"""
+    import os
+    from stardist_amd.geometry.geom2d import polygons_to_label
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raster2d_reference.npz"))
+    lbl = polygons_to_label(g[name + "_dist"], g[name + "_points"], tuple(g[name + "_shape"]), prob=g[name + "_prob"], thr=0.2)
+    assert np.array_equal(np.asarray(lbl), g[name + "_labels"])
+
+
+def test_raster2d_lattice_and_degenerate_cases_vs_skimage():
+    import os
+    from stardist_amd.lib import stardist2d as sd2
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raster2d_reference.npz"))
+    coord, shape = np.ascontiguousarray(g["explicit_coord"], np.float32), tuple(int(v) for v in g["explicit_shape"])
+    lbl = sd2.c_polygons_to_label(coord, np.arange(len(coord), dtype=np.int32), shape)
+    assert np.array_equal(lbl, g["explicit_labels"])
+    for i in range(len(coord)):
+        one = sd2.c_polygons_to_label(coord[i:i + 1], np.zeros(1, np.int32), shape)
+        assert np.array_equal(one > 0, g["explicit_mask%d" % i]), i
