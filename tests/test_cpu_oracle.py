@@ -150,3 +150,23 @@ def test_port_polygon_rule_on_lattice_and_degenerate_cases():
         rr, cc = port.polygon(c[0], c[1], shape)
         m = np.zeros(shape, bool); m[rr, cc] = True
         assert np.array_equal(m, g["explicit_mask%d" % i]), i
+
+
+def test_glue_functions_equal_reference_golden():
+    """relabel_sequential (matching.py:319-408) and _ind_prob_thresh (nms.py:6-17): product mirror and oracle port against outputs
+    of the reference's own functions (tests/golden/make_glue_golden.py)"""
+    from oracle import port
+    from stardist_amd.matching import relabel_sequential
+    from stardist_amd.nms import _ind_prob_thresh
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glue_reference.npz"))
+    for k in "abcde":
+        lab, off = g["relabel_%s_in" % k], int(g["relabel_%s_offset" % k])
+        for fn in (relabel_sequential, port.relabel_sequential):
+            r, fw, inv = fn(lab.copy(), off)
+            assert r.dtype == g["relabel_%s_out" % k].dtype and np.array_equal(r, g["relabel_%s_out" % k]), (k, fn.__module__)
+            assert np.array_equal(np.asarray(fw), g["relabel_%s_fw" % k]) and np.array_equal(np.asarray(inv), g["relabel_%s_inv" % k])
+    for k in ("2d", "3d", "b0", "bt"):
+        prob, thr, b = g["thresh_%s_prob" % k], float(g["thresh_%s_args" % k][0]), g["thresh_%s_b" % k]
+        b = None if (b.ndim == 0 and int(b) == -1) else (int(b) if b.ndim == 0 else tuple(map(tuple, b)))
+        assert np.array_equal(np.asarray(_ind_prob_thresh(prob, thr, b=b)), g["thresh_%s_mask" % k])
+        assert np.array_equal(port.ind_prob_thresh(prob, thr, b=b), g["thresh_%s_mask" % k])
