@@ -1,6 +1,6 @@
 """Convert a StarDist Keras weight file (weights_best.h5 / weights_last.h5 of a csbdeep model folder) into the .npz consumed by
-`StarDistBase.load_weights_npz` -- to be run on a machine that has h5py (this build image has neither h5py nor TensorFlow,
-so this script is UNTESTED here).
+`StarDistBase.load_weights_npz` -- to be run with an interpreter that has h5py (in the build image: /opt/conda/bin/python3.9;
+checked there on a synthetic Keras-style file only, real StarDist weight files are not available offline).
 
 usage: python tools/keras_to_npz.py <model_dir or weights.h5> <out.npz>
 
