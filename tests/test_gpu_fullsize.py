@@ -111,3 +111,23 @@ def test_predict_instances_dense_equals_sparse_and_big_equals_whole():
     d = np.sqrt(((a[:, None] - b[None]) ** 2).sum(-1)).min(1)
     assert (d <= 1.5).mean() >= 0.99
     assert np.count_nonzero((lb > 0) != (l1 > 0)) <= 1e-3 * l1.size
+
+
+def test_predict_instances_sharded_single_rank_equals_whole_image():
+    """design A (block-wise local NMS + final cross-tile NMS; here one rank, no process group) on the network's own output:
+    same objects as predict_instances on the whole image (up to float noise between differently shaped forward passes)"""
+    import torch
+    import bench
+    from oracle import synth
+    from stardist_amd.models import Config2D, StarDist2D
+    dev = torch.device("cuda:0")
+    img = synth.s2d_nuclei_image(512, 512, seed=7)
+    model = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
+    bench.calibrate_heads(model, torch.from_numpy(img).to(dev), frac=0.03)
+    l1, r1 = model.predict_instances(img)
+    ls, rs = model.predict_instances_sharded(img, "YX", block_size=256, min_overlap=64, context=64)
+    assert ls.shape == l1.shape and abs(len(rs["prob"]) - len(r1["prob"])) <= max(2, 0.01 * len(r1["prob"]))
+    a = np.asarray(r1["points"], np.float64); b = np.asarray(rs["points"], np.float64)
+    d = np.sqrt(((a[:, None] - b[None]) ** 2).sum(-1)).min(1)
+    assert (d <= 1.5).mean() >= 0.98
+    assert np.count_nonzero((ls > 0) != (l1 > 0)) <= 2e-3 * l1.size
