@@ -111,3 +111,44 @@ def dist_to_centroid(dist, rays, mode="absolute"):
     if mode not in ("absolute", "relative"):
         raise ValueError("mode should be either 'absolute' or 'relative'")
     return c_dist_to_centroid(dist, rays.vertices.astype(np.float32), rays.faces.astype(np.int32), int(mode == "absolute"))
+
+
+def export_to_obj_file3D(polys, fname=None, scale=1, single_mesh=True, uv_map=False, name="poly"):
+    """Wavefront .obj text of the predicted polyhedra (geom3d.py:277-347): one `o` block (or one per polyhedron), vertices as
+    `v x y z` with the reference's precision rule, optional spherical `vt` coordinates of the rays, faces `f a/a b/b c/c` with
+    running 1-based vertex indices.  polys = the dict returned by StarDist3D.predict_instances."""
+    try:
+        dist, points = np.asarray(polys["dist"]), np.asarray(polys["points"])
+        rays_vertices, rays_faces = np.asarray(polys["rays_vertices"]), np.asarray(polys["rays_faces"])
+    except KeyError as e:
+        raise ValueError("polys should be a dict with keys 'dist', 'points', 'rays_vertices', 'rays_faces' "
+                         "(such as generated by StarDist3D.predict_instances)") from e
+    coord = dist_to_coord3D(dist, points, rays_vertices)
+    if not (coord.ndim == 3 and coord.shape[-1] == 3 and rays_faces.shape[-1] == 3):
+        raise ValueError("Wrong shapes! coord -> (m,n,3) rays_faces -> (k,3)")
+    scale = np.asarray((scale,) * 3 if np.isscalar(scale) else scale)
+    assert len(scale) == 3
+    coord = coord * scale
+    decimals = int(max(1, 1 - np.log10(np.min(scale))))
+    vfmt = "v %%.%df %%.%df %%.%df\n" % (decimals, decimals, decimals)
+    uv_lines = ""
+    if uv_map:
+        sv = scale * rays_vertices
+        sv = sv / np.linalg.norm(sv, axis=1, keepdims=True)
+        u = 1 - (.5 + .5 * np.arctan2(sv[:, 0], sv[:, 2]) / np.pi)
+        v = 1 - (.5 - np.arcsin(sv[:, 1]) / np.pi)
+        uv_lines = "".join("vt %.4f %.4f\n" % (a, b) for a, b in zip(u, v))
+    faces1 = rays_faces.astype(np.int64) + 1
+    parts = []
+    for i, xs in enumerate(coord):
+        if i == 0 or not single_mesh:
+            parts.append("o %s_%d\n" % (name, i))
+        parts.append("".join(vfmt % (p[2], p[1], p[0]) for p in xs))           # (z, y, x) -> x y z
+        parts.append(uv_lines)
+        f = faces1 + i * len(xs)
+        parts.append("".join("f %d/%d %d/%d %d/%d\n" % (a, a, b, b, c, c) for a, b, c in f))
+    obj_str = "".join(parts)
+    if fname is not None:
+        with open(fname, "w") as fh:
+            fh.write(obj_str)
+    return obj_str

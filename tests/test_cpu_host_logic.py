@@ -151,3 +151,18 @@ def test_network_head_slabs_equal_whole_volume():
     assert len(ref) == len(out)
     for a, b in zip(ref, out):
         assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_export_to_obj_file3D_equals_reference_text(tmp_path):
+    """geom3d.export_to_obj_file3D against the text produced by the reference's own function (tests/golden/make_export_golden.py)"""
+    import os
+    from stardist_amd.geometry.geom3d import export_to_obj_file3D
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "export_obj_reference.npz"))
+    polys = {k: g[k] for k in ("dist", "points", "rays_vertices", "rays_faces")}
+    for tag, kw in {"default": {}, "multi_uv": dict(single_mesh=False, uv_map=True, name="cell"), "scaled": dict(scale=(0.05, 0.2, 0.2))}.items():
+        assert export_to_obj_file3D(dict(polys), **kw) == str(g["obj_" + tag]), tag
+    f = tmp_path / "a.obj"
+    s = export_to_obj_file3D(dict(polys), fname=str(f))
+    assert f.read_text() == s
+    with pytest.raises(ValueError):
+        export_to_obj_file3D(dict(dist=polys["dist"]))
