@@ -203,3 +203,25 @@ def test_sharded_cross_tile_nms_equals_whole_image(refmods):
             assert np.array_equal(lab, ref_labels)
         else:
             assert lab is None
+
+
+@pytest.mark.parametrize("name,axes", [("2d", "YX"), ("2dg", "YX"), ("3d", "ZYX")])
+def test_cover_crop_filter_objects_equal_reference_golden(name, axes):
+    """BlockND.cover + read + crop_context + filter_objects (responsibility rule, coordinate translation) against outputs of the
+    reference's own classes with the real skimage regionprops (tests/golden/make_big_filter_golden.py)"""
+    from stardist_amd.big import BlockND
+    g = np.load(os.path.join(ROOT, "tests", "golden", "big_filter.npz"))
+    gt = g[name + "_gt"]
+    bs, mo, ctx, grid = [tuple(int(v) for v in r) for r in g[name + "_args"]]
+    blocks = BlockND.cover(gt.shape, axes, bs, mo, ctx, grid)
+    assert len(blocks) == int(g[name + "_nblocks"])
+    for bi, block in enumerate(blocks):
+        sub = block.read(gt, axes=axes)
+        ids = np.unique(sub); ids = ids[ids > 0]
+        lab = np.zeros_like(sub)
+        for j, v in enumerate(ids, 1):
+            lab[sub == v] = j
+        pts = np.array([np.mean(np.nonzero(lab == j), axis=1) for j in range(1, len(ids) + 1)]).reshape(len(ids), gt.ndim)
+        lf, pf = block.filter_objects(block.crop_context(lab, axes=axes), dict(points=pts, prob=np.linspace(1, 0.5, len(ids))), axes=axes)
+        assert np.array_equal(lf, g["%s_b%d_labels" % (name, bi)]), (name, bi)
+        assert np.allclose(pf["points"], g["%s_b%d_points" % (name, bi)]) and np.allclose(pf["prob"], g["%s_b%d_prob" % (name, bi)])
