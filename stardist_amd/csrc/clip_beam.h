@@ -1,0 +1,1101 @@
+// clip_beam.h -- the scan-beam polygon intersection re-laid-out for the GPU ("bound slots").
+//
+// Same arithmetic as clip_sweep.h (the restated Vatti/Clipper 6.4.2 sweep behind
+// stardist/lib/stardist2d.cpp:152-165, reference clipper.cpp line numbers are cited there and
+// repeated here per function), different data layout -- chosen so that one pair's whole dynamic
+// state is a few hundred bytes and can live in LDS at real occupancy:
+//
+//   * PREPARED POLYGONS.  Everything Clipper::AddPath does (clipper.cpp:1045-1221: duplicate /
+//     collinear vertex removal, InitEdge2, local minima, ProcessBound incl. horizontal reversal) depends
+//     on ONE polygon only.  It is done once per candidate (prepare_polygon) and stored as a compact
+//     record: cleaned vertex ring + one code byte per edge {successor in its bound, bot/top swap} +
+//     the local-minima list, stable-sorted by Y.  The pair sweep never touches per-edge arrays of size
+//     2*n_rays again.
+//   * BOUND SLOTS.  An edge in the active edge list is always "the current edge of a bound": when it
+//     ends, UpdateEdgeIntoAEL (:1442-1462) replaces it IN PLACE by its successor, which inherits
+//     position, winding counts, output ring and side.  So the dynamic per-edge state is kept per
+//     bound in K slots (K = 8 for 32 rays); a slot caches the static data of its current edge.
+//   * AEL = ONE 64-BIT WORD.  The active edge list is the sequence of slot numbers, one nibble per
+//     position (unused nibbles = 0xF).  next/prev/insert/delete/swap are shifts and masks in
+//     registers instead of dependent memory loads along a linked list; the same for the sorted copy
+//     used by BuildIntersectList / FixupIntersectionOrder and for the stack of pending horizontals.
+//   * NO SCAN-BEAM QUEUE.  Clipper's queue holds exactly {Y of pending local minima} + {top Y of every
+//     non-horizontal edge currently in the AEL} + {top Y of the successor of a horizontal right bound
+//     inserted at a local minimum (:2018-2021)}; the next scan-beam is the maximum of those, computed
+//     from the slots.
+//   * std::sort of local minima / intersections is a stable sort for n <= 16 (libstdc++ insertion
+//     sort); more than 16 of either is flagged (ST_OVERFLOW_*) and the pair is re-run on the general
+//     path (clip_sweep_full.h).
+//
+// The CPU harness tests/host/beam_check.cpp compares this against clip_sweep.h (itself checked against
+// the compiled reference Clipper on millions of pairs) and against the reference Clipper directly.
+#pragma once
+#include "clip_sweep.h"
+#include <limits.h>
+
+namespace sdclip {
+
+typedef unsigned long long u64;
+
+enum {
+  ST_OVERFLOW_AEL = 32,   // more than K bounds active at once
+  ST_OVERFLOW_LM = 64,    // more than 8 local minima in one polygon / 16 in the pair
+  ST_OVERFLOW_GJ = 128    // ghost-join / extra scan-beam capacity
+};
+enum { BEAM_MAXLM = 8 };
+
+// ---------------------------------------------------------------------------------------------
+// Prepared polygon (one per candidate).  n == 0: the path is rejected by AddPath (fewer than 3
+// distinct vertices, or flat) and contributes no edges.
+template <int MAXV>
+struct PolyPrep {
+  int n;                              // edges (= vertices) of the cleaned ring
+  int n_lm;                           // local minima, stable-sorted by Y descending
+  int status;                         // ST_* flags raised while preparing
+  int pad;
+  int vx[MAXV], vy[MAXV];             // cleaned ring; edge e runs from vertex e to vertex e+1 (mod n)
+  unsigned char ecode[MAXV];          // bits 0-1: NextInLML (0 none, 1 ring-next, 2 ring-prev); bit 2: Bot is vertex e+1
+  unsigned char lm_left[BEAM_MAXLM], lm_right[BEAM_MAXLM];
+};
+
+// Working storage + routine of the preparation.  P = storage policy (PlainStorage / LdsStorage<S>).
+template <class P, int MAXV>
+struct PrepWork {
+  static constexpr unsigned RI = P::template region<int, MAXV>(), RS = P::template region<short, MAXV>(),
+                            RB = P::template region<unsigned char, MAXV>();
+  static constexpr unsigned O_CX = 0, O_CY = O_CX + RI, O_NXT = O_CY + RI, O_PRV = O_NXT + RS, O_CODE = O_PRV + RS,
+                            O_N = O_CODE + RB, O_END = O_N + P::template region<int, 1>();
+  static constexpr unsigned lds_bytes() { return O_END; }
+  typename P::template Arr<int, MAXV, O_CX> cx; typename P::template Arr<int, MAXV, O_CY> cy;
+  typename P::template Arr<short, MAXV, O_NXT> nxt; typename P::template Arr<short, MAXV, O_PRV> prv;
+  typename P::template Arr<unsigned char, MAXV, O_CODE> code;
+  typename P::template Scalar<int, O_N> n;
+
+  // ---- accessors on the COMPACT ring (after cleaning): edge e = vertex e -> vertex e+1
+  SD_HD int nx(int e) const { return e + 1 == n ? 0 : e + 1; }
+  SD_HD int pv(int e) const { return e == 0 ? n - 1 : e - 1; }
+  SD_HD bool sw(int e) const { return (code[e] & 4) != 0; }
+  SD_HD int botx(int e) const { return sw(e) ? cx[nx(e)] : cx[e]; }
+  SD_HD int boty(int e) const { return sw(e) ? cy[nx(e)] : cy[e]; }
+  SD_HD int topx(int e) const { return sw(e) ? cx[e] : cx[nx(e)]; }
+  SD_HD int topy(int e) const { return sw(e) ? cy[e] : cy[nx(e)]; }
+  SD_HD bool is_horz(int e) const { return cy[e] == cy[nx(e)]; }
+  SD_HD double dx(int e) const {                                              // clipper.cpp:591-596
+    const i64 dy = (i64)topy(e) - boty(e);
+    if (dy == 0) return SD_HORIZONTAL;
+    return (double)((i64)topx(e) - botx(e)) / (double)dy;
+  }
+  SD_HD void reverse_horizontal(int e) { code[e] = (unsigned char)(code[e] ^ 4); }
+  SD_HD void set_lml(int e, int c) { code[e] = (unsigned char)((code[e] & ~3) | c); }
+
+  SD_HD int find_next_loc_min(int E) const {                                  // :911-925
+    for (;;) {
+      while (botx(E) != botx(pv(E)) || boty(E) != boty(pv(E)) || (cx[E] == topx(E) && cy[E] == topy(E))) E = nx(E);
+      if (!is_horz(E) && !is_horz(pv(E))) break;
+      while (is_horz(pv(E))) E = pv(E);
+      int E2 = E;
+      while (is_horz(E)) E = nx(E);
+      if (topy(E) == boty(pv(E))) continue;   // just an intermediate horizontal
+      if (botx(pv(E2)) < botx(E)) E = E2;
+      break;
+    }
+    return E;
+  }
+  SD_HD int process_bound(int E, bool fwd) {                                  // :928-1042 (no skip edges)
+    int Result = E, Horz;
+    if (is_horz(E)) {
+      int EStart = fwd ? pv(E) : nx(E);
+      if (is_horz(EStart)) {
+        if (botx(EStart) != botx(E) && topx(EStart) != botx(E)) reverse_horizontal(E);
+      } else if (botx(EStart) != botx(E)) reverse_horizontal(E);
+    }
+    int EStart = E;
+    if (fwd) {
+      while (topy(Result) == boty(nx(Result))) Result = nx(Result);
+      if (is_horz(Result)) {
+        Horz = Result;
+        while (is_horz(pv(Horz))) Horz = pv(Horz);
+        if (topx(pv(Horz)) > topx(nx(Result))) Result = pv(Horz);
+      }
+      while (E != Result) {
+        set_lml(E, 1);
+        if (is_horz(E) && E != EStart && botx(E) != topx(pv(E))) reverse_horizontal(E);
+        E = nx(E);
+      }
+      if (is_horz(E) && E != EStart && botx(E) != topx(pv(E))) reverse_horizontal(E);
+      Result = nx(Result);
+    } else {
+      while (topy(Result) == boty(pv(Result))) Result = pv(Result);
+      if (is_horz(Result)) {
+        Horz = Result;
+        while (is_horz(nx(Horz))) Horz = nx(Horz);
+        if (topx(nx(Horz)) == topx(pv(Result)) || topx(nx(Horz)) > topx(pv(Result))) Result = nx(Horz);
+      }
+      while (E != Result) {
+        set_lml(E, 2);
+        if (is_horz(E) && E != EStart && botx(E) != topx(nx(E))) reverse_horizontal(E);
+        E = pv(E);
+      }
+      if (is_horz(E) && E != EStart && botx(E) != topx(nx(E))) reverse_horizontal(E);
+      Result = pv(Result);
+    }
+    return Result;
+  }
+
+  // Clipper::AddPath for one closed path (:1045-1221).  xs/ys: the n_in integer vertices.
+  template <typename XT>
+  SD_HDN void prepare(const XT* xs, const XT* ys, int n_in, PolyPrep<MAXV>* out) {
+    out->n = 0; out->n_lm = 0; out->status = 0; out->pad = 0;
+    int highI = n_in - 1;
+    while (highI > 0 && xs[highI] == xs[0] && ys[highI] == ys[0]) --highI;
+    while (highI > 0 && xs[highI] == xs[highI - 1] && ys[highI] == ys[highI - 1]) --highI;
+    if (highI < 2) return;
+    for (int i = 0; i <= highI; ++i) {
+      cx[i] = (int)xs[i]; cy[i] = (int)ys[i];
+      nxt[i] = (short)(i == highI ? 0 : i + 1);
+      prv[i] = (short)(i == 0 ? highI : i - 1);
+    }
+    int eStart = 0, E = 0, eLoopStop = 0;
+    for (;;) {   // remove duplicate vertices and collinear edges (:1098-1122)
+      if (cx[E] == cx[nxt[E]] && cy[E] == cy[nxt[E]]) {
+        if (E == nxt[E]) break;
+        if (E == eStart) eStart = nxt[E];
+        const int en = nxt[E]; nxt[prv[E]] = (short)en; prv[en] = prv[E]; E = en;
+        eLoopStop = E;
+        continue;
+      }
+      if (prv[E] == nxt[E]) break;
+      const int ep0 = prv[E], en0 = nxt[E];
+      if (((i64)cy[ep0] - cy[E]) * ((i64)cx[E] - cx[en0]) == ((i64)cx[ep0] - cx[E]) * ((i64)cy[E] - cy[en0])) {   // SlopesEqual :554-563
+        if (E == eStart) eStart = nxt[E];
+        nxt[ep0] = (short)en0; prv[en0] = (short)ep0;
+        E = ep0;
+        eLoopStop = E;
+        continue;
+      }
+      E = nxt[E];
+      if (E == eLoopStop) break;
+    }
+    if (prv[E] == nxt[E]) return;
+    // compact the surviving ring, starting at eStart (ring order preserved, so every later traversal
+    // visits the edges in the order the reference does)
+    int m = 0;
+    {
+      // two passes through out->vx/vy as staging (the linked ring is read-only now)
+      int e = eStart;
+      do { out->vx[m] = cx[e]; out->vy[m] = cy[e]; ++m; e = nxt[e]; } while (e != eStart && m < MAXV);
+      for (int i = 0; i < m; ++i) { cx[i] = out->vx[i]; cy[i] = out->vy[i]; }
+    }
+    n = m;
+    bool isFlat = true;
+    for (int e = 0; e < m; ++e) {   // InitEdge2 :729-742
+      const int en = nx(e);
+      code[e] = (unsigned char)((cy[e] >= cy[en]) ? 0 : 4);
+      if (cy[en] != cy[0]) isFlat = false;
+    }
+    if (isFlat) return;
+    E = 0;
+    if (botx(pv(E)) == topx(pv(E)) && boty(pv(E)) == topy(pv(E))) E = nx(E);
+    int EMin = -1, guard = 0, n_lm = 0;
+    int lmy[BEAM_MAXLM];
+    unsigned char lml_[BEAM_MAXLM], lmr_[BEAM_MAXLM];
+    int st = 0;
+    for (;;) {
+      E = find_next_loc_min(E);
+      if (E == EMin) break;
+      else if (EMin < 0) EMin = E;
+      if (++guard > 2 * MAXV + 2) { st |= ST_ITER; break; }
+      int left, right; bool leftFwd;
+      if (dx(E) < dx(pv(E))) { left = pv(E); right = E; leftFwd = false; }
+      else { left = E; right = pv(E); leftFwd = true; }
+      const int y = boty(E);
+      E = process_bound(left, leftFwd);
+      const int E2 = process_bound(right, !leftFwd);
+      if (n_lm < BEAM_MAXLM) {
+        // stable insertion by Y descending (== libstdc++ std::sort for n <= 16, LocMinSorter :125-131)
+        int k = n_lm;
+        while (k > 0 && lmy[k - 1] < y) { lmy[k] = lmy[k - 1]; lml_[k] = lml_[k - 1]; lmr_[k] = lmr_[k - 1]; --k; }
+        lmy[k] = y; lml_[k] = (unsigned char)left; lmr_[k] = (unsigned char)right;
+        ++n_lm;
+      } else st |= ST_OVERFLOW_LM;
+      if (!leftFwd) E = E2;
+    }
+    for (int i = 0; i < m; ++i) out->ecode[i] = code[i];
+    for (int i = 0; i < n_lm; ++i) { out->lm_left[i] = lml_[i]; out->lm_right[i] = lmr_[i]; }
+    out->n = m; out->n_lm = n_lm; out->status = st;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// BeamCore: the sweep over two prepared polygons.  D (CRTP) supplies the output side exactly as for
+// SweepCore (out_add_pt, out_append, out_ring_closed, out_add_join, out_last_pt, out_last_pt_x).
+// Handles are slot numbers (0..K-1), -1 = none.  K <= 15.
+template <class D, class P, int MAXV, int K, int MAXIL>
+struct BeamCore {
+  typedef PolyPrep<MAXV> Prep;
+  enum { GJ = 4, NX = 4, EID_POLY = 4096 };
+  SD_HD D& self() { return *static_cast<D*>(this); }
+  static constexpr unsigned RI = P::template region<int, K>(), RD = P::template region<double, K>(),
+                            RS = P::template region<short, K>(), RB = P::template region<signed char, K>(),
+                            RIL = P::template region<int, MAXIL>(), RILB = P::template region<signed char, MAXIL>(),
+                            RG = P::template region<int, GJ>(), R1 = P::template region<int, 1>(), R8 = P::template region<u64, 1>();
+  static constexpr unsigned O_BOTX = 0, O_BOTY = O_BOTX + RI, O_TOPX = O_BOTY + RI, O_TOPY = O_TOPX + RI, O_CURX = O_TOPY + RI,
+                            O_CURY = O_CURX + RI, O_DX = O_CURY + RI, O_EID = O_DX + RD, O_WCNT = O_EID + RS, O_WCNT2 = O_WCNT + RS,
+                            O_OUTIDX = O_WCNT2 + RS, O_LMLC = O_OUTIDX + RB, O_WDELTA = O_LMLC + RB, O_PTYP = O_WDELTA + RB,
+                            O_SIDE = O_PTYP + RB, O_ILX = O_SIDE + RB, O_ILY = O_ILX + RIL, O_ILE1 = O_ILY + RIL, O_ILE2 = O_ILE1 + RILB,
+                            O_GJOP = O_ILE2 + RILB, O_GJX1 = O_GJOP + RG, O_GJX2 = O_GJX1 + RG, O_GJY2 = O_GJX2 + RG,
+                            O_XTRA = O_GJY2 + RG, O_MLM = O_XTRA + P::template region<int, NX>(),
+                            O_ORD = O_MLM + P::template region<unsigned char, 16>(), O_SORD = O_ORD + R8, O_HSEL = O_SORD + R8,
+                            O_PA = O_HSEL + R8, O_PB = O_PA + R8, O_NAEL = O_PB + R8, O_FREE = O_NAEL + R1, O_NLM = O_FREE + R1,
+                            O_CURLM = O_NLM + R1, O_NIL = O_CURLM + R1, O_STATUS = O_NIL + R1, O_NJOINS = O_STATUS + R1,
+                            O_NGJ = O_NJOINS + R1, O_NXTRA = O_NGJ + R1, O_CORE_END = O_NXTRA + R1;
+  // ---- bound slots
+  typename P::template Arr<int, K, O_BOTX> botx; typename P::template Arr<int, K, O_BOTY> boty;
+  typename P::template Arr<int, K, O_TOPX> topx; typename P::template Arr<int, K, O_TOPY> topy;
+  typename P::template Arr<int, K, O_CURX> curx; typename P::template Arr<int, K, O_CURY> cury;
+  typename P::template Arr<double, K, O_DX> dx;
+  typename P::template Arr<short, K, O_EID> eid;                 // current edge: poly * EID_POLY + index in that polygon's ring
+  typename P::template Arr<short, K, O_WCNT> wcnt; typename P::template Arr<short, K, O_WCNT2> wcnt2;
+  typename P::template Arr<signed char, K, O_OUTIDX> outidx;
+  typename P::template Arr<signed char, K, O_LMLC> lmlc;        // NextInLML code of the current edge (0 none, 1 next, 2 prev)
+  typename P::template Arr<signed char, K, O_WDELTA> wdelta; typename P::template Arr<signed char, K, O_PTYP> ptyp;
+  typename P::template Arr<signed char, K, O_SIDE> side;
+  // ---- intersections of the current scan-beam
+  typename P::template Arr<int, MAXIL, O_ILX> ilx; typename P::template Arr<int, MAXIL, O_ILY> ily;
+  typename P::template Arr<signed char, MAXIL, O_ILE1> ile1; typename P::template Arr<signed char, MAXIL, O_ILE2> ile2;
+  // ---- ghost joins of the current scan-line (:1968-1975), extra scan-beam Ys, merged local minima
+  typename P::template Arr<int, GJ, O_GJOP> gjop; typename P::template Arr<int, GJ, O_GJX1> gjx1;
+  typename P::template Arr<int, GJ, O_GJX2> gjx2; typename P::template Arr<int, GJ, O_GJY2> gjy2;
+  typename P::template Arr<int, NX, O_XTRA> xtra;
+  typename P::template Arr<unsigned char, 16, O_MLM> mlm;       // poly * 128 + index into that polygon's lm list
+  // ---- scalars
+  typename P::template Scalar<u64, O_ORD> ord;                   // AEL: nibble p = slot at position p; unused = 0xF
+  typename P::template Scalar<u64, O_SORD> sord;                 // SEL copy used for the intersection sort
+  typename P::template Scalar<u64, O_HSEL> hsel;                 // SEL as the stack of pending horizontals (nibble 0 = head)
+  typename P::template Scalar<const Prep*, O_PA> prepA; typename P::template Scalar<const Prep*, O_PB> prepB;
+  typename P::template Scalar<int, O_NAEL> n_ael; typename P::template Scalar<int, O_FREE> freemask;
+  typename P::template Scalar<int, O_NLM> n_lm; typename P::template Scalar<int, O_CURLM> cur_lm;
+  typename P::template Scalar<int, O_NIL> n_il; typename P::template Scalar<int, O_STATUS> status;
+  typename P::template Scalar<int, O_NJOINS> n_joins; typename P::template Scalar<int, O_NGJ> n_gj;
+  typename P::template Scalar<int, O_NXTRA> n_xtra;
+
+  static constexpr u64 ALLF = ~0ull;
+  // ------------------------------------------------------------------ nibble lists
+  static SD_HD int nib(u64 w, int p) { return (int)((w >> (4 * p)) & 15ull); }
+  static SD_HD int nib_find(u64 w, int h) {                       // position of slot h (unused nibbles are 0xF, h < 15), or -1
+    const u64 x = w ^ ((u64)h * 0x1111111111111111ull);
+    const u64 t = (x - 0x1111111111111111ull) & ~x & 0x8888888888888888ull;
+    if (!t) return -1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (__ffsll((long long)t) - 1) >> 2;
+#else
+    return __builtin_ctzll(t) >> 2;
+#endif
+  }
+  static SD_HD u64 nib_insert(u64 w, int p, int h) {
+    const u64 lowmask = (p == 0) ? 0ull : (ALLF >> (64 - 4 * p));
+    return (w & lowmask) | ((u64)h << (4 * p)) | ((w & ~lowmask) << 4);
+  }
+  static SD_HD u64 nib_remove(u64 w, int p) {
+    const u64 lowmask = (p == 0) ? 0ull : (ALLF >> (64 - 4 * p));
+    return (w & lowmask) | (((w >> 4) & ~lowmask)) | (0xFull << 60);
+  }
+  static SD_HD u64 nib_swap(u64 w, int p, int q) {
+    const u64 d = (u64)(nib(w, p) ^ nib(w, q));
+    return w ^ (d << (4 * p)) ^ (d << (4 * q));
+  }
+  SD_HD int ael_head() const { return n_ael > 0 ? nib(ord, 0) : -1; }
+  SD_HD int anext(int h) const { const u64 w = ord; const int p = nib_find(w, h); if (p < 0 || p + 1 >= n_ael) return -1; return nib(w, p + 1); }
+  SD_HD int aprev(int h) const { const u64 w = ord; const int p = nib_find(w, h); if (p <= 0) return -1; return nib(w, p - 1); }
+  SD_HD bool in_ael(int h) const { return nib_find(ord, h) >= 0; }
+  SD_HD int alloc_slot() {
+    const int f = freemask;
+    if (!f) { status |= ST_OVERFLOW_AEL; return 0; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int h = __ffs(f) - 1;
+#else
+    const int h = __builtin_ctz((unsigned)f);
+#endif
+    freemask = f & (f - 1);
+    return h;
+  }
+
+  // ------------------------------------------------------------------ static edge data
+  SD_HD const Prep* prep_of(int id) const { return (id >= EID_POLY) ? (const Prep*)prepB : (const Prep*)prepA; }
+  static SD_HD int ring_nx(const Prep* q, int i) { return i + 1 == q->n ? 0 : i + 1; }
+  static SD_HD int ring_pv(const Prep* q, int i) { return i == 0 ? q->n - 1 : i - 1; }
+  struct ES { int bx, by, tx, ty, code; };
+  static SD_HD ES edge_static(const Prep* q, int i) {
+    ES s;
+    const int j = ring_nx(q, i);
+    s.code = q->ecode[i];
+    const int x0 = q->vx[i], y0 = q->vy[i], x1 = q->vx[j], y1 = q->vy[j];
+    if (s.code & 4) { s.bx = x1; s.by = y1; s.tx = x0; s.ty = y0; }
+    else { s.bx = x0; s.by = y0; s.tx = x1; s.ty = y1; }
+    return s;
+  }
+  // NextInLML of edge id (or -1)
+  SD_HD int lml_id(int id, int code) const {
+    const int c = code & 3;
+    if (!c) return -1;
+    const Prep* q = prep_of(id);
+    const int base = id & ~(EID_POLY - 1), i = id & (EID_POLY - 1);
+    return base + (c == 1 ? ring_nx(q, i) : ring_pv(q, i));
+  }
+  SD_HD ES es_of(int id) const { return edge_static(prep_of(id), id & (EID_POLY - 1)); }
+  static SD_HD double es_dx(const ES& s) {
+    const i64 dy = (i64)s.ty - s.by;
+    if (dy == 0) return SD_HORIZONTAL;
+    return (double)((i64)s.tx - s.bx) / (double)dy;
+  }
+  SD_HD void load_slot(int h, int id) {
+    const ES s = es_of(id);
+    botx[h] = s.bx; boty[h] = s.by; topx[h] = s.tx; topy[h] = s.ty;
+    dx[h] = es_dx(s);
+    eid[h] = (short)id; lmlc[h] = (signed char)(s.code & 3);
+  }
+
+  // ------------------------------------------------------------------ helpers (as SweepCore)
+  SD_HD bool is_horz(int h) const { return topy[h] == boty[h]; }
+  SD_HD i64 top_x(int h, i64 y) const {                                      // clipper.cpp:615-619
+    return (y == topy[h]) ? (i64)topx[h] : (i64)botx[h] + sd_round(dx[h] * (double)(y - boty[h]));
+  }
+  static SD_HD bool slopes_equal4(i64 x1, i64 y1, i64 x2, i64 y2, i64 x3, i64 y3, i64 x4, i64 y4) {  // :566-575
+    return (y1 - y2) * (x3 - x4) == (x1 - x2) * (y3 - y4);
+  }
+  SD_HD bool slopes_equal_e(int e1, int e2) const {                          // :541-551
+    return ((i64)topy[e1] - boty[e1]) * ((i64)topx[e2] - botx[e2]) ==
+           ((i64)topx[e1] - botx[e1]) * ((i64)topy[e2] - boty[e2]);
+  }
+  static SD_HD bool horz_segments_overlap(i64 a1, i64 a2, i64 b1, i64 b2) {  // :872-877
+    if (a1 > a2) { i64 t = a1; a1 = a2; a2 = t; }
+    if (b1 > b2) { i64 t = b1; b1 = b2; b2 = t; }
+    return (a1 < b2) && (b1 < a2);
+  }
+  SD_HD void add_join(int op1, int op2, int offx, int offy) { ++n_joins; self().out_add_join(op1, op2, offx, offy); }
+  SD_HD void add_ghost_join(int op, int x1, int x2, int y2) {
+    const int g = n_gj;
+    if (g < GJ) { gjop[g] = op; gjx1[g] = x1; gjx2[g] = x2; gjy2[g] = y2; n_gj = g + 1; }
+    else { ++n_joins; status |= ST_OVERFLOW_GJ; }
+  }
+  SD_HD void horz_joins(int horz, int op1) {                                  // :2721-2732, 2774-2785
+    u64 w = hsel;
+    for (int h = (int)(w & 15ull); h != 15; w >>= 4, h = (int)(w & 15ull))
+      if (outidx[h] >= 0 && horz_segments_overlap(botx[horz], topx[horz], botx[h], topx[h]))
+        add_join(self().out_last_pt(h), op1, topx[h], topy[h]);
+  }
+  SD_HD void push_xtra(int y) {
+    const int k = n_xtra;
+    for (int i = 0; i < k; ++i) if (xtra[i] == y) return;
+    if (k < NX) { xtra[k] = y; n_xtra = k + 1; } else status |= ST_OVERFLOW_GJ;
+  }
+  SD_HD int lm_y(int i) const {
+    const int m = mlm[i];
+    const Prep* q = (m & 128) ? (const Prep*)prepB : (const Prep*)prepA;
+    const int l = q->lm_left[m & 127];
+    const ES s = edge_static(q, l);
+    return s.by;
+  }
+  // PopScanbeam :1341-1348 on the implicit queue (see header).  curY: the scan-line just processed.
+  SD_HD bool pop_scanbeam(int curY, int& y) {
+    bool have = false; int best = 0;
+    if (cur_lm < n_lm) { best = lm_y(cur_lm); have = true; }
+    const int k = n_xtra;
+    for (int i = 0; i < k; ++i) { const int v = xtra[i]; if (!have || v > best) { best = v; have = true; } }
+    const u64 w = ord; const int n = n_ael;
+    for (int p = 0; p < n; ++p) {
+      const int h = nib(w, p);
+      const int t = topy[h];
+      if (t != boty[h] && t < curY && (!have || t > best)) { best = t; have = true; }
+    }
+    if (!have) return false;
+    int kk = 0;
+    for (int i = 0; i < k; ++i) { const int v = xtra[i]; if (v != best) { xtra[kk] = v; ++kk; } }
+    n_xtra = kk;
+    y = best;
+    return true;
+  }
+
+  // ------------------------------------------------------------------ output (delegated to D)
+  SD_HD int add_out_pt(int e, int px, int py) { return self().out_add_pt(e, px, py); }
+  SD_HDN void add_local_max_poly(int e1, int e2, int px, int py) {           // :1884-1897
+    add_out_pt(e1, px, py);
+    if (outidx[e1] == outidx[e2]) {
+      if (outidx[e1] >= 0) self().out_ring_closed(outidx[e1]);
+      outidx[e1] = kUnassigned; outidx[e2] = kUnassigned;
+    } else if (outidx[e1] < outidx[e2]) self().out_append(e1, e2);
+    else self().out_append(e2, e1);
+  }
+  SD_HDN int add_local_min_poly(int e1, int e2, int px, int py) {            // :1841-1881
+    int e, prevE, result;
+    if (is_horz(e2) || dx[e1] > dx[e2]) {
+      result = add_out_pt(e1, px, py);
+      outidx[e2] = outidx[e1];
+      side[e1] = kLeft; side[e2] = kRight;
+      e = e1;
+      prevE = (aprev(e) == e2) ? aprev(e2) : aprev(e);
+    } else {
+      result = add_out_pt(e2, px, py);
+      outidx[e1] = outidx[e2];
+      side[e1] = kRight; side[e2] = kLeft;
+      e = e2;
+      prevE = (aprev(e) == e1) ? aprev(e1) : aprev(e);
+    }
+    if (prevE >= 0 && outidx[prevE] >= 0 && topy[prevE] < py && topy[e] < py) {
+      i64 xPrev = top_x(prevE, py), xE = top_x(e, py);
+      if (xPrev == xE && wdelta[e] != 0 && wdelta[prevE] != 0 &&
+          slopes_equal4(xPrev, py, topx[prevE], topy[prevE], xE, py, topx[e], topy[e])) {
+        const int outPt = add_out_pt(prevE, px, py);
+        add_join(result, outPt, topx[e], topy[e]);
+      }
+    }
+    return result;
+  }
+
+  // ------------------------------------------------------------------ AEL
+  SD_HD bool e2_inserts_before_e1(int e1, int e2) const {                   // :3278-3287
+    if (curx[e2] == curx[e1]) {
+      if (topy[e2] > topy[e1]) return (i64)topx[e2] < top_x(e1, topy[e2]);
+      else return (i64)topx[e1] > top_x(e2, topy[e1]);
+    } else return curx[e2] < curx[e1];
+  }
+  SD_HDN void insert_edge_into_ael(int edge, int startEdge) {                // :3319-3345
+    const int n = n_ael;
+    u64 w = ord;
+    int at;
+    if (n == 0) at = 0;
+    else if (startEdge < 0 && e2_inserts_before_e1(nib(w, 0), edge)) at = 0;
+    else {
+      int p = (startEdge < 0) ? 0 : nib_find(w, startEdge);
+      if (p < 0) p = 0;
+      while (p + 1 < n && !e2_inserts_before_e1(nib(w, p + 1), edge)) ++p;
+      at = p + 1;
+    }
+    ord = nib_insert(w, at, edge);
+    n_ael = n + 1;
+  }
+  SD_HD void delete_from_ael(int e) {                                       // :1367-1377
+    const u64 w = ord;
+    const int p = nib_find(w, e);
+    if (p < 0) return;
+    ord = nib_remove(w, p);
+    n_ael = n_ael - 1;
+    freemask = freemask | (1 << e);
+  }
+  SD_HD void swap_positions_in_ael(int e1, int e2) {                        // :1395-1439
+    const u64 w = ord;
+    const int p = nib_find(w, e1), q = nib_find(w, e2);
+    if (p < 0 || q < 0) return;
+    ord = nib_swap(w, p, q);
+  }
+  SD_HD void add_edge_to_sel(int edge) { hsel = (hsel << 4) | (u64)edge; }   // :1900-1917 (push at the head)
+  // UpdateEdgeIntoAEL :1442-1462 ; the successor takes over the slot
+  SD_HDN int update_edge_into_ael(int e) {
+    const int id = eid[e];
+    const int n = lml_id(id, lmlc[e]);
+    if (n < 0) { status |= ST_FAIL; return e; }
+    load_slot(e, n);
+    curx[e] = botx[e]; cury[e] = boty[e];
+    return e;
+  }
+
+  // ------------------------------------------------------------------ winding  (NonZero both, ctIntersection)
+  SD_HDN void set_winding_count(int edge) {                                  // :1624-1722
+    const u64 w = ord;
+    const int pe = nib_find(w, edge);
+    int p = pe - 1;
+    while (p >= 0 && (ptyp[nib(w, p)] != ptyp[edge] || wdelta[nib(w, p)] == 0)) --p;
+    if (p < 0) {
+      wcnt[edge] = wdelta[edge];
+      wcnt2[edge] = 0;
+      p = 0;
+    } else {
+      const int e = nib(w, p);
+      if (wcnt[e] * wdelta[e] < 0) {
+        int a = wcnt[e] < 0 ? -wcnt[e] : wcnt[e];
+        if (a > 1) {
+          if (wdelta[e] * wdelta[edge] < 0) wcnt[edge] = wcnt[e];
+          else wcnt[edge] = (short)(wcnt[e] + wdelta[edge]);
+        } else wcnt[edge] = (wdelta[edge] == 0 ? 1 : wdelta[edge]);
+      } else {
+        if (wdelta[edge] == 0) wcnt[edge] = (short)(wcnt[e] < 0 ? wcnt[e] - 1 : wcnt[e] + 1);
+        else if (wdelta[e] * wdelta[edge] < 0) wcnt[edge] = wcnt[e];
+        else wcnt[edge] = (short)(wcnt[e] + wdelta[edge]);
+      }
+      wcnt2[edge] = wcnt2[e];
+      ++p;
+    }
+    for (; p < pe; ++p) wcnt2[edge] = (short)(wcnt2[edge] + wdelta[nib(w, p)]);
+  }
+  SD_HD bool is_contributing(int e) const {                                 // :1741-1838
+    int a = wcnt[e] < 0 ? -wcnt[e] : wcnt[e];
+    if (a != 1) return false;
+    return wcnt2[e] != 0;
+  }
+
+  // ------------------------------------------------------------------ IntersectEdges  :2106-2298
+  SD_HDN void intersect_edges(int e1, int e2, int px, int py) {
+    bool c1 = outidx[e1] >= 0, c2 = outidx[e2] >= 0;
+    if (ptyp[e1] == ptyp[e2]) {
+      if (wcnt[e1] + wdelta[e2] == 0) wcnt[e1] = (short)-wcnt[e1]; else wcnt[e1] = (short)(wcnt[e1] + wdelta[e2]);
+      if (wcnt[e2] - wdelta[e1] == 0) wcnt[e2] = (short)-wcnt[e2]; else wcnt[e2] = (short)(wcnt[e2] - wdelta[e1]);
+    } else {
+      wcnt2[e1] = (short)(wcnt2[e1] + wdelta[e2]);
+      wcnt2[e2] = (short)(wcnt2[e2] - wdelta[e1]);
+    }
+    int e1Wc = wcnt[e1] < 0 ? -wcnt[e1] : wcnt[e1];
+    int e2Wc = wcnt[e2] < 0 ? -wcnt[e2] : wcnt[e2];
+    if (c1 && c2) {
+      if ((e1Wc != 0 && e1Wc != 1) || (e2Wc != 0 && e2Wc != 1) || (ptyp[e1] != ptyp[e2])) {
+        add_local_max_poly(e1, e2, px, py);
+      } else {
+        add_out_pt(e1, px, py);
+        add_out_pt(e2, px, py);
+        signed char s = side[e1]; side[e1] = side[e2]; side[e2] = s;
+        signed char o = outidx[e1]; outidx[e1] = outidx[e2]; outidx[e2] = o;
+      }
+    } else if (c1) {
+      if (e2Wc == 0 || e2Wc == 1) {
+        add_out_pt(e1, px, py);
+        signed char s = side[e1]; side[e1] = side[e2]; side[e2] = s;
+        signed char o = outidx[e1]; outidx[e1] = outidx[e2]; outidx[e2] = o;
+      }
+    } else if (c2) {
+      if (e1Wc == 0 || e1Wc == 1) {
+        add_out_pt(e2, px, py);
+        signed char s = side[e1]; side[e1] = side[e2]; side[e2] = s;
+        signed char o = outidx[e1]; outidx[e1] = outidx[e2]; outidx[e2] = o;
+      }
+    } else if ((e1Wc == 0 || e1Wc == 1) && (e2Wc == 0 || e2Wc == 1)) {
+      int e1Wc2 = wcnt2[e1] < 0 ? -wcnt2[e1] : wcnt2[e1];
+      int e2Wc2 = wcnt2[e2] < 0 ? -wcnt2[e2] : wcnt2[e2];
+      if (ptyp[e1] != ptyp[e2]) add_local_min_poly(e1, e2, px, py);
+      else if (e1Wc == 1 && e2Wc == 1) {
+        if (e1Wc2 > 0 && e2Wc2 > 0) add_local_min_poly(e1, e2, px, py);
+      } else { signed char s = side[e1]; side[e1] = side[e2]; side[e2] = s; }
+    }
+  }
+
+  // ------------------------------------------------------------------ InsertLocalMinimaIntoAEL  :1978-2077
+  SD_HDN void insert_local_minima_into_ael(int botY) {
+    while (cur_lm < n_lm && lm_y(cur_lm) == botY) {
+      const int m = mlm[cur_lm];
+      ++cur_lm;
+      const int poly = (m & 128) ? 1 : 0;
+      const Prep* q = poly ? (const Prep*)prepB : (const Prep*)prepA;
+      const int li = q->lm_left[m & 127], ri = q->lm_right[m & 127];
+      const int lb = alloc_slot();
+      const int rb = alloc_slot();
+      if (status & ST_OVERFLOW_AEL) return;
+      load_slot(lb, poly * EID_POLY + li);
+      load_slot(rb, poly * EID_POLY + ri);
+      // AddPath :1185-1189 + Reset :1260-1273
+      const signed char wl = (ring_nx(q, li) == ri) ? -1 : 1;
+      wdelta[lb] = wl; wdelta[rb] = (signed char)-wl;
+      const signed char pt = poly ? (signed char)kSubject : (signed char)kClip;
+      ptyp[lb] = pt; ptyp[rb] = pt;
+      curx[lb] = botx[lb]; cury[lb] = boty[lb]; side[lb] = kLeft; outidx[lb] = kUnassigned; wcnt[lb] = 0; wcnt2[lb] = 0;
+      curx[rb] = botx[rb]; cury[rb] = boty[rb]; side[rb] = kRight; outidx[rb] = kUnassigned; wcnt[rb] = 0; wcnt2[rb] = 0;
+
+      int op1 = -1; bool have_op1 = false;
+      insert_edge_into_ael(lb, -1);
+      insert_edge_into_ael(rb, lb);
+      set_winding_count(lb);
+      wcnt[rb] = wcnt[lb]; wcnt2[rb] = wcnt2[lb];
+      if (is_contributing(lb)) { op1 = add_local_min_poly(lb, rb, botx[lb], boty[lb]); have_op1 = true; }
+      // InsertScanbeam(lb->Top.Y) is implicit (lb is never horizontal: AddPath puts a horizontal at a minimum on the right bound)
+      if (is_horz(rb)) {
+        add_edge_to_sel(rb);
+        const int nid = lml_id(eid[rb], lmlc[rb]);
+        if (nid >= 0) push_xtra(es_of(nid).ty);                              // :2020
+      }
+      if (is_horz(lb)) status |= ST_ITER;                                    // cannot happen (see above); flagged, never silently wrong
+
+      if (have_op1 && is_horz(rb) && n_gj > 0 && wdelta[rb] != 0) {       // :2029-2040
+        const int ng = n_gj;
+        for (int g = 0; g < ng; ++g)
+          if (horz_segments_overlap(gjx1[g], gjx2[g], botx[rb], topx[rb])) add_join(gjop[g], op1, gjx2[g], gjy2[g]);
+      }
+      const int lp = aprev(lb);
+      if (outidx[lb] >= 0 && lp >= 0 && curx[lp] == botx[lb] && outidx[lp] >= 0 &&
+          slopes_equal4(botx[lp], boty[lp], topx[lp], topy[lp], curx[lb], cury[lb], topx[lb], topy[lb]) &&
+          wdelta[lb] != 0 && wdelta[lp] != 0) {
+        const int op2 = add_out_pt(lp, botx[lb], boty[lb]);
+        add_join(op1, op2, topx[lb], topy[lb]);
+      }
+      if (anext(lb) != rb) {
+        const int rp = aprev(rb);
+        if (outidx[rb] >= 0 && rp >= 0 && outidx[rp] >= 0 &&
+            slopes_equal4(curx[rp], cury[rp], topx[rp], topy[rp], curx[rb], cury[rb], topx[rb], topy[rb]) &&
+            wdelta[rb] != 0 && wdelta[rp] != 0) {
+          const int op2 = add_out_pt(rp, botx[rb], boty[rb]);
+          add_join(op1, op2, topx[rb], topy[rb]);
+        }
+        int e = anext(lb);
+        int guard = 0;
+        while (e >= 0 && e != rb) {
+          intersect_edges(rb, e, curx[lb], cury[lb]);
+          e = anext(e);
+          if (++guard > K) { status |= ST_ITER; break; }
+        }
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ horizontals  :2512-2824
+  // GetMaximaPair :2538-2545 for edge id `id` whose Top is (tx, ty); returns an edge id or -1
+  SD_HD int get_maxima_pair_id(int id, int tx, int ty) const {
+    const Prep* q = prep_of(id);
+    const int base = id & ~(EID_POLY - 1), i = id & (EID_POLY - 1);
+    const int n = ring_nx(q, i), p = ring_pv(q, i);
+    const ES sn = edge_static(q, n);
+    if (sn.tx == tx && sn.ty == ty && (sn.code & 3) == 0) return base + n;
+    const ES sp = edge_static(q, p);
+    if (sp.tx == tx && sp.ty == ty && (sp.code & 3) == 0) return base + p;
+    return -1;
+  }
+  // slot holding edge id (or -1)
+  SD_HD int slot_of(int id) const {
+    const u64 w = ord; const int n = n_ael;
+    for (int p = 0; p < n; ++p) { const int h = nib(w, p); if (eid[h] == id) return h; }
+    return -1;
+  }
+  // GetMaximaPairEx :2548-2555 for the edge in slot e.  Returns: -1 none; otherwise the pair's edge id, with
+  // `slot` = its slot if it is in the AEL (else -1: the pair is a horizontal that has not entered the AEL yet).
+  SD_HD int get_maxima_pair_ex(int e, int& slot) const {
+    slot = -1;
+    const int r = get_maxima_pair_id(eid[e], topx[e], topy[e]);
+    if (r < 0) return -1;
+    slot = slot_of(r);
+    if (slot < 0) {
+      const ES s = es_of(r);
+      if (s.ty != s.by) return -1;            // not in the AEL and not horizontal
+    }
+    return r;
+  }
+  SD_HDN void process_horizontal(int horz) {
+    bool l2r; i64 hl, hr;
+    if (botx[horz] < topx[horz]) { hl = botx[horz]; hr = topx[horz]; l2r = true; }
+    else { hl = topx[horz]; hr = botx[horz]; l2r = false; }
+    // eLast: last horizontal of the run in this bound; eMaxPair only if the run ends the bound
+    int eLast = eid[horz], lastCode = lmlc[horz], lastTx = topx[horz], lastTy = topy[horz];
+    {
+      int guard0 = 0;
+      for (;;) {
+        const int nid = lml_id(eLast, lastCode);
+        if (nid < 0) break;
+        const ES s = es_of(nid);
+        if (s.ty != s.by) break;
+        eLast = nid; lastCode = s.code; lastTx = s.tx; lastTy = s.ty;
+        if (++guard0 > MAXV) { status |= ST_ITER; return; }
+      }
+    }
+    int eMaxPair = -1;
+    if ((lastCode & 3) == 0) eMaxPair = get_maxima_pair_id(eLast, lastTx, lastTy);
+    int op1 = -1; bool have_op1 = false;
+    int guard = 0;
+    for (;;) {
+      const bool isLast = (eid[horz] == eLast);
+      int e = l2r ? anext(horz) : aprev(horz);
+      while (e >= 0) {
+        if (++guard > 4 * K * K + 4 * MAXV) { status |= ST_ITER; return; }
+        if ((l2r && curx[e] > hr) || (!l2r && curx[e] < hl)) break;
+        if (curx[e] == topx[horz] && lmlc[horz] != 0) {
+          const ES s = es_of(lml_id(eid[horz], lmlc[horz]));
+          if (dx[e] < es_dx(s)) break;
+        }
+        if (outidx[horz] >= 0) {
+          op1 = add_out_pt(horz, curx[e], cury[e]);
+          have_op1 = true;
+          horz_joins(horz, op1);
+          add_ghost_join(op1, curx[e], botx[horz], boty[horz]);
+        }
+        if (eid[e] == eMaxPair && isLast) {
+          if (outidx[horz] >= 0) add_local_max_poly(horz, e, topx[horz], topy[horz]);
+          delete_from_ael(horz);
+          delete_from_ael(e);
+          return;
+        }
+        if (l2r) intersect_edges(horz, e, curx[e], cury[horz]);
+        else intersect_edges(e, horz, curx[e], cury[horz]);
+        const int eNext = l2r ? anext(e) : aprev(e);
+        swap_positions_in_ael(horz, e);
+        e = eNext;
+      }
+      if (lmlc[horz] == 0) break;
+      {
+        const ES s = es_of(lml_id(eid[horz], lmlc[horz]));
+        if (s.ty != s.by) break;
+      }
+      horz = update_edge_into_ael(horz);
+      if (outidx[horz] >= 0) add_out_pt(horz, botx[horz], boty[horz]);
+      if (botx[horz] < topx[horz]) { hl = botx[horz]; hr = topx[horz]; l2r = true; }
+      else { hl = topx[horz]; hr = botx[horz]; l2r = false; }
+    }
+    if (outidx[horz] >= 0 && !have_op1) {                                   // :2771-2787
+      op1 = self().out_last_pt(horz);
+      horz_joins(horz, op1);
+      add_ghost_join(op1, self().out_last_pt_x(horz), topx[horz], topy[horz]);
+    }
+    if (lmlc[horz] != 0) {
+      if (outidx[horz] >= 0) {
+        op1 = add_out_pt(horz, topx[horz], topy[horz]);
+        horz = update_edge_into_ael(horz);
+        if (wdelta[horz] == 0) return;
+        const int ePrev = aprev(horz), eNext = anext(horz);
+        if (ePrev >= 0 && curx[ePrev] == botx[horz] && cury[ePrev] == boty[horz] && wdelta[ePrev] != 0 &&
+            (outidx[ePrev] >= 0 && cury[ePrev] > topy[ePrev] && slopes_equal_e(horz, ePrev))) {
+          const int op2 = add_out_pt(ePrev, botx[horz], boty[horz]);
+          add_join(op1, op2, topx[horz], topy[horz]);
+        } else if (eNext >= 0 && curx[eNext] == botx[horz] && cury[eNext] == boty[horz] && wdelta[eNext] != 0 &&
+                   outidx[eNext] >= 0 && cury[eNext] > topy[eNext] && slopes_equal_e(horz, eNext)) {
+          const int op2 = add_out_pt(eNext, botx[horz], boty[horz]);
+          add_join(op1, op2, topx[horz], topy[horz]);
+        }
+      } else update_edge_into_ael(horz);
+    } else {
+      if (outidx[horz] >= 0) add_out_pt(horz, topx[horz], topy[horz]);
+      delete_from_ael(horz);
+    }
+  }
+  SD_HD void process_horizontals() {
+    int guard = 0;
+    for (;;) {
+      const u64 w = hsel;
+      const int h = (int)(w & 15ull);
+      if (h == 15) break;
+      hsel = (w >> 4) | (0xFull << 60);                                     // DeleteFromSEL (head)
+      process_horizontal(h);
+      if (++guard > 4 * MAXV) { status |= ST_ITER; break; }
+    }
+  }
+
+  // ------------------------------------------------------------------ intersections  :2827-2954, 622-689
+  SD_HDN void intersect_point(int e1, int e2, i64& ipx, i64& ipy) const {
+    double b1, b2;
+    const double d1 = dx[e1], d2 = dx[e2];
+    if (d1 == d2) { ipy = cury[e1]; ipx = top_x(e1, ipy); return; }
+    else if (d1 == 0) {
+      ipx = botx[e1];
+      if (is_horz(e2)) ipy = boty[e2];
+      else { b2 = (double)boty[e2] - ((double)botx[e2] / d2); ipy = sd_round((double)ipx / d2 + b2); }
+    } else if (d2 == 0) {
+      ipx = botx[e2];
+      if (is_horz(e1)) ipy = boty[e1];
+      else { b1 = (double)boty[e1] - ((double)botx[e1] / d1); ipy = sd_round((double)ipx / d1 + b1); }
+    } else {
+      b1 = (double)botx[e1] - (double)boty[e1] * d1;
+      b2 = (double)botx[e2] - (double)boty[e2] * d2;
+      double q = (b2 - b1) / (d1 - d2);
+      ipy = sd_round(q);
+      double a1 = d1 < 0 ? -d1 : d1, a2 = d2 < 0 ? -d2 : d2;
+      if (a1 < a2) ipx = sd_round(d1 * q + b1);
+      else ipx = sd_round(d2 * q + b2);
+    }
+    if (ipy < topy[e1] || ipy < topy[e2]) {
+      if (topy[e1] > topy[e2]) ipy = topy[e1]; else ipy = topy[e2];
+      double a1 = d1 < 0 ? -d1 : d1, a2 = d2 < 0 ? -d2 : d2;
+      if (a1 < a2) ipx = top_x(e1, ipy); else ipx = top_x(e2, ipy);
+    }
+    if (ipy > cury[e1]) {
+      ipy = cury[e1];
+      double a1 = d1 < 0 ? -d1 : d1, a2 = d2 < 0 ? -d2 : d2;
+      if (a1 > a2) ipx = top_x(e2, ipy); else ipx = top_x(e1, ipy);
+    }
+  }
+  SD_HDN void build_intersect_list(int topY) {
+    const int n = n_ael;
+    if (n == 0) return;
+    u64 w = ord;
+    for (int p = 0; p < n; ++p) { const int h = nib(w, p); curx[h] = (int)top_x(h, topY); }
+    // bubble sort of the SEL copy (:2837-2862): a pass carries the largest element to the end, which is then cut off
+    int m = n, guard = 0;
+    bool isModified;
+    do {
+      isModified = false;
+      int p = 0;
+      while (p + 1 < m) {
+        const int e = nib(w, p), eNext = nib(w, p + 1);
+        if (curx[e] > curx[eNext]) {
+          i64 px, py;
+          intersect_point(e, eNext, px, py);
+          if (py < topY) { px = top_x(e, topY); py = topY; }
+          const int k = n_il;
+          if (k < MAXIL) { ile1[k] = (signed char)e; ile2[k] = (signed char)eNext; ilx[k] = (int)px; ily[k] = (int)py; n_il = k + 1; }
+          else status |= ST_OVERFLOW_IL;
+          w = nib_swap(w, p, p + 1);
+          isModified = true;
+        }
+        ++p;
+        if (++guard > K * K * 2 + 8) { status |= ST_ITER; return; }
+      }
+      if (m > 1) --m; else break;
+    } while (isModified);
+  }
+  SD_HDN bool fixup_intersection_order() {
+    // CopyAELToSEL :1929-1939
+    u64 w = ord;
+    const int n = n_il;
+    // std::sort(IntersectListSort :2921-2924): n <= 16 -> insertion sort == stable sort by Y descending
+    for (int i = 1; i < n; ++i) {
+      const int y = ily[i], x = ilx[i]; const signed char a = ile1[i], b = ile2[i];
+      int k = i;
+      while (k > 0 && ily[k - 1] < y) { ily[k] = ily[k - 1]; ilx[k] = ilx[k - 1]; ile1[k] = ile1[k - 1]; ile2[k] = ile2[k - 1]; --k; }
+      if (k != i) { ily[k] = y; ilx[k] = x; ile1[k] = a; ile2[k] = b; }
+    }
+    for (int i = 0; i < n; ++i) {
+      int p = nib_find(w, ile1[i]), q = nib_find(w, ile2[i]);
+      if (!(p - q == 1 || q - p == 1)) {
+        int j = i + 1;
+        while (j < n) {
+          const int pj = nib_find(w, ile1[j]), qj = nib_find(w, ile2[j]);
+          if (pj - qj == 1 || qj - pj == 1) break;
+          j++;
+        }
+        if (j == n) return false;
+        const int y = ily[i], x = ilx[i]; const signed char a = ile1[i], b = ile2[i];
+        ily[i] = ily[j]; ilx[i] = ilx[j]; ile1[i] = ile1[j]; ile2[i] = ile2[j];
+        ily[j] = y; ilx[j] = x; ile1[j] = a; ile2[j] = b;
+        p = nib_find(w, ile1[i]); q = nib_find(w, ile2[i]);
+      }
+      w = nib_swap(w, p, q);
+    }
+    return true;
+  }
+  SD_HD bool process_intersections(int topY) {
+    if (n_ael == 0) return true;
+    n_il = 0;
+    build_intersect_list(topY);
+    const int n = n_il;
+    if (n == 0) return true;
+    if (n == 1 || fixup_intersection_order()) {
+      for (int i = 0; i < n; ++i) {
+        const int e1 = ile1[i], e2 = ile2[i];
+        intersect_edges(e1, e2, ilx[i], ily[i]);
+        swap_positions_in_ael(e1, e2);
+      }
+      n_il = 0;
+    } else return false;
+    return true;
+  }
+
+  // ------------------------------------------------------------------ top of scan-beam  :2957-3113
+  SD_HDN void do_maxima(int e) {
+    int mp;
+    const int mpid = get_maxima_pair_ex(e, mp);
+    if (mpid < 0) {
+      if (outidx[e] >= 0) add_out_pt(e, topx[e], topy[e]);
+      delete_from_ael(e);
+      return;
+    }
+    if (mp < 0) { status |= ST_FAIL; return; }      // unreachable: do_maxima is only entered with the pair in the AEL
+    int eNext = anext(e);
+    int guard = 0;
+    while (eNext >= 0 && eNext != mp) {
+      intersect_edges(e, eNext, topx[e], topy[e]);
+      swap_positions_in_ael(e, eNext);
+      eNext = anext(e);
+      if (++guard > K) { status |= ST_ITER; break; }
+    }
+    if (outidx[e] == kUnassigned && outidx[mp] == kUnassigned) {
+      delete_from_ael(e); delete_from_ael(mp);
+    } else if (outidx[e] >= 0 && outidx[mp] >= 0) {
+      add_local_max_poly(e, mp, topx[e], topy[e]);
+      delete_from_ael(e); delete_from_ael(mp);
+    } else status |= ST_FAIL;   // "DoMaxima error" -> Execute fails, empty solution
+  }
+  SD_HDN void process_edges_at_top_of_scanbeam(int topY) {
+    int e = ael_head();
+    int guard = 0;
+    while (e >= 0) {
+      if (++guard > 4 * MAXV) { status |= ST_ITER; break; }
+      bool isMax = (topy[e] == topY && lmlc[e] == 0);
+      if (isMax) {
+        int mps;
+        const int mp = get_maxima_pair_ex(e, mps);
+        bool mpHorz = false;
+        if (mp >= 0) { if (mps >= 0) mpHorz = is_horz(mps); else mpHorz = true; }
+        isMax = (mp < 0 || !mpHorz);
+      }
+      if (isMax) {
+        const int ePrev = aprev(e);
+        do_maxima(e);
+        if (status & ST_FAIL) return;
+        e = (ePrev < 0) ? ael_head() : anext(ePrev);
+      } else {
+        bool nextHorz = false;
+        if (topy[e] == topY && lmlc[e] != 0) { const ES s = es_of(lml_id(eid[e], lmlc[e])); nextHorz = (s.ty == s.by); }
+        if (nextHorz) {
+          e = update_edge_into_ael(e);
+          if (outidx[e] >= 0) add_out_pt(e, botx[e], boty[e]);
+          add_edge_to_sel(e);
+        } else {
+          curx[e] = (int)top_x(e, topY);
+          cury[e] = topY;
+        }
+        e = anext(e);
+      }
+    }
+    process_horizontals();
+    e = ael_head();
+    guard = 0;
+    while (e >= 0) {
+      if (++guard > 4 * MAXV) { status |= ST_ITER; break; }
+      if (topy[e] == topY && lmlc[e] != 0) {
+        bool op = false; int oph = -1;
+        if (outidx[e] >= 0) { oph = add_out_pt(e, topx[e], topy[e]); op = true; }
+        e = update_edge_into_ael(e);
+        const int ePrev = aprev(e), eNext = anext(e);
+        if (ePrev >= 0 && curx[ePrev] == botx[e] && cury[ePrev] == boty[e] && op &&
+            outidx[ePrev] >= 0 && cury[ePrev] > topy[ePrev] &&
+            slopes_equal4(curx[e], cury[e], topx[e], topy[e], curx[ePrev], cury[ePrev], topx[ePrev], topy[ePrev]) &&
+            wdelta[e] != 0 && wdelta[ePrev] != 0) {
+          const int op2 = add_out_pt(ePrev, botx[e], boty[e]);
+          add_join(oph, op2, topx[e], topy[e]);
+        } else if (eNext >= 0 && curx[eNext] == botx[e] && cury[eNext] == boty[e] && op &&
+                   outidx[eNext] >= 0 && cury[eNext] > topy[eNext] &&
+                   slopes_equal4(curx[e], cury[e], topx[e], topy[e], curx[eNext], cury[eNext], topx[eNext], topy[eNext]) &&
+                   wdelta[e] != 0 && wdelta[eNext] != 0) {
+          const int op2 = add_out_pt(eNext, botx[e], boty[e]);
+          add_join(oph, op2, topx[e], topy[e]);
+        }
+      }
+      e = anext(e);
+    }
+  }
+
+  // ------------------------------------------------------------------ Execute  :1560-1621, 1247-1276
+  SD_HD void reset_core(const Prep* a, const Prep* b) {
+    prepA = a; prepB = b;
+    ord = ALLF; sord = ALLF; hsel = ALLF; n_ael = 0; freemask = (1 << K) - 1;
+    n_lm = 0; cur_lm = 0; n_il = 0; status = ST_OK; n_joins = 0; n_gj = 0; n_xtra = 0;
+  }
+  // Runs the sweep.  Returns false if Clipper's Execute would fail (empty solution).
+  SD_HDN bool run_sweep() {
+    const Prep* a = prepA; const Prep* b = prepB;
+    status |= (a->status | b->status);
+    // merged local-minima list: stable by Y descending, polygon A (added first, :157) before B on ties
+    {
+      const int na = a->n ? a->n_lm : 0, nb = b->n ? b->n_lm : 0;
+      if (na + nb > 16) { status |= ST_OVERFLOW_LM; return false; }
+      int ia = 0, ib = 0, k = 0;
+      while (ia < na || ib < nb) {
+        bool takeA;
+        if (ia >= na) takeA = false;
+        else if (ib >= nb) takeA = true;
+        else takeA = edge_static(a, a->lm_left[ia]).by >= edge_static(b, b->lm_left[ib]).by;
+        if (takeA) { mlm[k] = (unsigned char)ia; ++ia; } else { mlm[k] = (unsigned char)(128 + ib); ++ib; }
+        ++k;
+      }
+      n_lm = k;
+    }
+    if (n_lm == 0) return true;
+    cur_lm = 0;
+    int botY = lm_y(0), topY = 0;
+    insert_local_minima_into_ael(botY);
+    int guard = 0;
+    bool ok = true;
+    for (;;) {
+      if (status & (ST_OVERFLOW_AEL | ST_ITER)) { ok = false; break; }
+      const bool popped = pop_scanbeam(botY, topY);
+      if (!popped) break;
+      if (++guard > 4 * MAXV + 8) { status |= ST_ITER; break; }
+      process_horizontals();
+      n_gj = 0;                                                             // ClearGhostJoins :1575
+      if (!process_intersections(topY)) { ok = false; break; }
+      process_edges_at_top_of_scanbeam(topY);
+      if (status & ST_FAIL) { ok = false; break; }
+      botY = topY;
+      insert_local_minima_into_ael(botY);
+    }
+    if (!ok || (status & ST_FAIL)) { status |= ST_FAIL; return false; }
+    return true;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Beam: the fast variant (rings as {front, back, running shoelace sum}), exact whenever the reference
+// records no joins for the pair (n_joins == 0) -- same contract as Sweep in clip_sweep.h.
+template <int MAXV, int K, int MAXIL, int MAXREC, class P = PlainStorage>
+struct Beam : BeamCore<Beam<MAXV, K, MAXIL, MAXREC, P>, P, MAXV, K, MAXIL> {
+  typedef BeamCore<Beam<MAXV, K, MAXIL, MAXREC, P>, P, MAXV, K, MAXIL> B;
+  using B::outidx; using B::side; using B::status; using B::ord; using B::n_ael;
+  static constexpr unsigned RR = P::template region<int, MAXREC>();
+  static constexpr unsigned O_RFX = B::O_CORE_END, O_RFY = O_RFX + RR, O_RLX = O_RFY + RR, O_RLY = O_RLX + RR, O_RSUM = O_RLY + RR,
+                            O_NREC = O_RSUM + P::template region<i64, MAXREC>(), O_TWICE = O_NREC + P::template region<i64, 1>(),
+                            O_SABS = O_TWICE + P::template region<i64, 1>(), O_END = O_SABS + P::template region<i64, 1>();
+  typename P::template Arr<int, MAXREC, O_RFX> rfx; typename P::template Arr<int, MAXREC, O_RFY> rfy;
+  typename P::template Arr<int, MAXREC, O_RLX> rlx; typename P::template Arr<int, MAXREC, O_RLY> rly;
+  typename P::template Arr<i64, MAXREC, O_RSUM> rsum;
+  static constexpr unsigned lds_bytes() { return O_END; }
+  typename P::template Scalar<int, O_NREC> n_rec;
+  typename P::template Scalar<i64, O_TWICE> twice_area;      // sum over closed rings of |2*area|
+  typename P::template Scalar<i64, O_SABS> sum_abs_terms;    // sum of |cross| terms (exactness bound for the float path)
+  SD_HD void term(i64 c) { sum_abs_terms += sd_abs64(c); }
+  SD_HDN int out_add_pt(int e, int px, int py) {                             // :2463-2499
+    int r = outidx[e];
+    if (r < 0) {
+      if (n_rec >= MAXREC) { status |= ST_OVERFLOW_REC; return -1; }
+      r = n_rec++;
+      rfx[r] = rlx[r] = px; rfy[r] = rly[r] = py; rsum[r] = 0;
+      outidx[e] = (signed char)r;
+    } else {
+      if (side[e] == kLeft) {           // to front
+        if (px == rfx[r] && py == rfy[r]) return -1;
+        i64 c = sd_cross(px, py, rfx[r], rfy[r]); term(c);
+        rsum[r] += c; rfx[r] = px; rfy[r] = py;
+      } else {
+        if (px == rlx[r] && py == rly[r]) return -1;
+        i64 c = sd_cross(rlx[r], rly[r], px, py); term(c);
+        rsum[r] += c; rlx[r] = px; rly[r] = py;
+      }
+    }
+    return -1;
+  }
+  SD_HD void out_ring_closed(int r) {
+    i64 c = sd_cross(rlx[r], rly[r], rfx[r], rfy[r]); term(c);
+    twice_area += sd_abs64(rsum[r] + c);
+  }
+  SD_HDN void out_append(int e1, int e2) {                                   // :2367-2460
+    int r1 = outidx[e1], r2 = outidx[e2];
+    i64 c;
+    if (side[e1] == kLeft) {
+      if (side[e2] == kLeft) {        // reverse(2) + 1
+        c = sd_cross(rfx[r2], rfy[r2], rfx[r1], rfy[r1]);
+        rsum[r1] = -rsum[r2] + c + rsum[r1];
+        rfx[r1] = rlx[r2]; rfy[r1] = rly[r2];
+      } else {                        // 2 + 1
+        c = sd_cross(rlx[r2], rly[r2], rfx[r1], rfy[r1]);
+        rsum[r1] = rsum[r2] + c + rsum[r1];
+        rfx[r1] = rfx[r2]; rfy[r1] = rfy[r2];
+      }
+    } else {
+      if (side[e2] == kRight) {       // 1 + reverse(2)
+        c = sd_cross(rlx[r1], rly[r1], rlx[r2], rly[r2]);
+        rsum[r1] = rsum[r1] + c - rsum[r2];
+        rlx[r1] = rfx[r2]; rly[r1] = rfy[r2];
+      } else {                        // 1 + 2
+        c = sd_cross(rlx[r1], rly[r1], rfx[r2], rfy[r2]);
+        rsum[r1] = rsum[r1] + c + rsum[r2];
+        rlx[r1] = rlx[r2]; rly[r1] = rly[r2];
+      }
+    }
+    term(c);
+    const int okIdx = r1, obsolete = r2;
+    const signed char s1 = side[e1];
+    outidx[e1] = kUnassigned; outidx[e2] = kUnassigned;
+    const u64 w = ord; const int n = n_ael;
+    for (int p = 0; p < n; ++p) {
+      const int e = B::nib(w, p);
+      if (outidx[e] == obsolete) { outidx[e] = (signed char)okIdx; side[e] = s1; break; }
+    }
+  }
+  SD_HD void out_add_join(int, int, int, int) {}
+  SD_HD int out_last_pt(int) { return -1; }
+  SD_HD int out_last_pt_x(int e) { const int r = outidx[e]; return (side[e] == kLeft) ? rfx[r] : rlx[r]; }
+  SD_HD void reset_state(const PolyPrep<MAXV>* a, const PolyPrep<MAXV>* b) { B::reset_core(a, b); n_rec = 0; twice_area = 0; sum_abs_terms = 0; }
+  // Returns 2*area of (A ∩ B) as the reference would sum it (0 if Clipper's Execute fails).
+  SD_HD i64 execute() { return B::run_sweep() ? (i64)twice_area : 0; }
+};
+
+}  // namespace sdclip
