@@ -51,6 +51,11 @@ int sd_nms2d_device(const float* d_dist, const float* d_points, int n_polys, int
                     int use_kdtree, int use_bbox, int verbose, float threshold,
                     uint8_t* d_keep, int64_t* stats, void* stream);
 
+/* Test probe: Clipper::AddPath (clipper.cpp:1045-1221) once per polygon -- the prepared-polygon records the 2D NMS
+ * builds per candidate (stardist_amd/csrc/clip_beam.h, PolyPrep<MAXV>, MAXV = 32/64/128/256 for n_verts). */
+int sd_prepare_polys_device(const int32_t* d_x, const int32_t* d_y, int n_polys, int n_verts, void* d_out,
+                            int64_t out_bytes, void* stream);
+
 /* pair-level probe used by the parity tests: intersection area of integer polygons exactly as
  * poly_intersection_area (stardist2d.cpp:152-165) computes it.  xa..yb are device int32
  * arrays of shape (n_pairs, n_verts); out_twice_area int64 (2*area), out_flags int32

@@ -33,6 +33,14 @@
 #include "clip_sweep.h"
 #include <limits.h>
 
+#if defined(BEAM_COUNT) && !defined(__HIP_DEVICE_COMPILE__)
+struct BeamCounters { long beams, topx, isect_pt, isect_edges, outpt, update, maxima, lm, horz, ael_sum, il_beams, es_loads; };
+inline BeamCounters& beam_counters() { static BeamCounters c = {}; return c; }
+#define BEAM_CNT(f, v) (beam_counters().f += (v))
+#else
+#define BEAM_CNT(f, v) ((void)0)
+#endif
+
 namespace sdclip {
 
 typedef unsigned long long u64;
@@ -47,15 +55,23 @@ enum { BEAM_MAXLM = 8 };
 // ---------------------------------------------------------------------------------------------
 // Prepared polygon (one per candidate).  n == 0: the path is rejected by AddPath (fewer than 3
 // distinct vertices, or flat) and contributes no edges.
+struct PrepPt { int x, y; };
+template <bool WIDE> struct PrepIdx { typedef unsigned char type; enum { NONE = 255 }; };
+template <> struct PrepIdx<true> { typedef unsigned short type; enum { NONE = 65535 }; };
 template <int MAXV>
 struct PolyPrep {
+  typedef typename PrepIdx<(MAXV > 128)>::type pidx;
+  enum { NONE = PrepIdx<(MAXV > 128)>::NONE };
   int n;                              // edges (= vertices) of the cleaned ring
   int n_lm;                           // local minima, stable-sorted by Y descending
   int status;                         // ST_* flags raised while preparing
   int pad;
-  int vx[MAXV], vy[MAXV];             // cleaned ring; edge e runs from vertex e to vertex e+1 (mod n)
-  unsigned char ecode[MAXV];          // bits 0-1: NextInLML (0 none, 1 ring-next, 2 ring-prev); bit 2: Bot is vertex e+1
-  unsigned char lm_left[BEAM_MAXLM], lm_right[BEAM_MAXLM];
+  PrepPt v[MAXV + 1];                 // cleaned ring, v[n] = v[0]; edge e runs from vertex e to vertex e+1
+  unsigned char ecode[MAXV];          // bits 0-1: NextInLML (0 none, 1 ring-next, 2 ring-prev); bit 2: Bot is vertex e+1;
+                                      // bit 3: NextInLML exists and is horizontal
+  pidx mpair[MAXV];                   // GetMaximaPair(e) (:2538-2545) as a ring index, NONE = no pair
+  pidx hlast[MAXV];                   // horizontal e: last edge of the run of horizontals that starts at e in its bound (:2519-2521)
+  pidx lm_left[BEAM_MAXLM], lm_right[BEAM_MAXLM];
 };
 
 // Working storage + routine of the preparation.  P = storage policy (PlainStorage / LdsStorage<S>).
@@ -64,12 +80,15 @@ struct PrepWork {
   static constexpr unsigned RI = P::template region<int, MAXV>(), RS = P::template region<short, MAXV>(),
                             RB = P::template region<unsigned char, MAXV>();
   static constexpr unsigned O_CX = 0, O_CY = O_CX + RI, O_NXT = O_CY + RI, O_PRV = O_NXT + RS, O_CODE = O_PRV + RS,
-                            O_N = O_CODE + RB, O_END = O_N + P::template region<int, 1>();
+                            O_N = O_CODE + RB, O_LMY = O_N + P::template region<int, 1>(), O_LML = O_LMY + P::template region<int, BEAM_MAXLM>(),
+                            O_LMR = O_LML + P::template region<short, BEAM_MAXLM>(), O_END = O_LMR + P::template region<short, BEAM_MAXLM>();
   static constexpr unsigned lds_bytes() { return O_END; }
   typename P::template Arr<int, MAXV, O_CX> cx; typename P::template Arr<int, MAXV, O_CY> cy;
   typename P::template Arr<short, MAXV, O_NXT> nxt; typename P::template Arr<short, MAXV, O_PRV> prv;
   typename P::template Arr<unsigned char, MAXV, O_CODE> code;
   typename P::template Scalar<int, O_N> n;
+  typename P::template Arr<int, BEAM_MAXLM, O_LMY> lmy;
+  typename P::template Arr<short, BEAM_MAXLM, O_LML> lml_; typename P::template Arr<short, BEAM_MAXLM, O_LMR> lmr_;
 
   // ---- accessors on the COMPACT ring (after cleaning): edge e = vertex e -> vertex e+1
   SD_HD int nx(int e) const { return e + 1 == n ? 0 : e + 1; }
@@ -177,14 +196,19 @@ struct PrepWork {
       if (E == eLoopStop) break;
     }
     if (prv[E] == nxt[E]) return;
-    // compact the surviving ring, starting at eStart (ring order preserved, so every later traversal
-    // visits the edges in the order the reference does)
-    int m = 0;
+    // compact the surviving ring in place (ring order = increasing original index, cyclically; the traversal below starts
+    // at the image of eStart, so every later step visits the edges in the order the reference does)
+    int m = 0, E0 = 0;
     {
-      // two passes through out->vx/vy as staging (the linked ring is read-only now)
-      int e = eStart;
-      do { out->vx[m] = cx[e]; out->vy[m] = cy[e]; ++m; e = nxt[e]; } while (e != eStart && m < MAXV);
-      for (int i = 0; i < m; ++i) { cx[i] = out->vx[i]; cy[i] = out->vy[i]; }
+      for (int i = 0; i <= highI; ++i) code[i] = 0;
+      int e = eStart, g0 = 0;
+      do { code[e] = 1; e = nxt[e]; } while (e != eStart && ++g0 <= MAXV);
+      for (int i = 0; i <= highI; ++i) {
+        if (!code[i]) continue;
+        if (i == eStart) E0 = m;
+        if (m != i) { cx[m] = cx[i]; cy[m] = cy[i]; }
+        ++m;
+      }
     }
     n = m;
     bool isFlat = true;
@@ -194,11 +218,9 @@ struct PrepWork {
       if (cy[en] != cy[0]) isFlat = false;
     }
     if (isFlat) return;
-    E = 0;
+    E = E0;
     if (botx(pv(E)) == topx(pv(E)) && boty(pv(E)) == topy(pv(E))) E = nx(E);
     int EMin = -1, guard = 0, n_lm = 0;
-    int lmy[BEAM_MAXLM];
-    unsigned char lml_[BEAM_MAXLM], lmr_[BEAM_MAXLM];
     int st = 0;
     for (;;) {
       E = find_next_loc_min(E);
@@ -215,13 +237,39 @@ struct PrepWork {
         // stable insertion by Y descending (== libstdc++ std::sort for n <= 16, LocMinSorter :125-131)
         int k = n_lm;
         while (k > 0 && lmy[k - 1] < y) { lmy[k] = lmy[k - 1]; lml_[k] = lml_[k - 1]; lmr_[k] = lmr_[k - 1]; --k; }
-        lmy[k] = y; lml_[k] = (unsigned char)left; lmr_[k] = (unsigned char)right;
+        lmy[k] = y; lml_[k] = (short)left; lmr_[k] = (short)right;
         ++n_lm;
       } else st |= ST_OVERFLOW_LM;
       if (!leftFwd) E = E2;
     }
-    for (int i = 0; i < m; ++i) out->ecode[i] = code[i];
-    for (int i = 0; i < n_lm; ++i) { out->lm_left[i] = lml_[i]; out->lm_right[i] = lmr_[i]; }
+    for (int i = 0; i < m; ++i) { out->v[i].x = cx[i]; out->v[i].y = cy[i]; }
+    out->v[m].x = cx[0]; out->v[m].y = cy[0];
+    for (int i = 0; i < m; ++i) {
+      const int c = code[i] & 3;
+      const int nl = (c == 1) ? nx(i) : (c == 2 ? pv(i) : -1);
+      int cc = code[i] & 7;
+      if (nl >= 0 && is_horz(nl)) cc |= 8;
+      out->ecode[i] = (unsigned char)cc;
+      // GetMaximaPair :2538-2545
+      const int a = nx(i), b = pv(i);
+      int mp = PolyPrep<MAXV>::NONE;
+      if (topx(a) == topx(i) && topy(a) == topy(i) && (code[a] & 3) == 0) mp = a;
+      else if (topx(b) == topx(i) && topy(b) == topy(i) && (code[b] & 3) == 0) mp = b;
+      out->mpair[i] = (typename PolyPrep<MAXV>::pidx)mp;
+      // last horizontal of the run (:2519-2521)
+      int last = i, g2 = 0;
+      if (is_horz(i)) {
+        for (;;) {
+          const int c2 = code[last] & 3;
+          const int n2 = (c2 == 1) ? nx(last) : (c2 == 2 ? pv(last) : -1);
+          if (n2 < 0 || !is_horz(n2)) break;
+          last = n2;
+          if (++g2 > MAXV) { st |= ST_ITER; break; }
+        }
+      }
+      out->hlast[i] = (typename PolyPrep<MAXV>::pidx)last;
+    }
+    for (int i = 0; i < n_lm; ++i) { out->lm_left[i] = (typename PolyPrep<MAXV>::pidx)lml_[i]; out->lm_right[i] = (typename PolyPrep<MAXV>::pidx)lmr_[i]; }
     out->n = m; out->n_lm = n_lm; out->status = st;
   }
 };
@@ -230,83 +278,89 @@ struct PrepWork {
 // BeamCore: the sweep over two prepared polygons.  D (CRTP) supplies the output side exactly as for
 // SweepCore (out_add_pt, out_append, out_ring_closed, out_add_join, out_last_pt, out_last_pt_x).
 // Handles are slot numbers (0..K-1), -1 = none.  K <= 15.
-template <class D, class P, int MAXV, int K, int MAXIL>
+template <class D, class P, int MAXV, int K, int MAXIL, bool FULLGJ = false>
 struct BeamCore {
   typedef PolyPrep<MAXV> Prep;
-  enum { GJ = 4, NX = 4, EID_POLY = 4096 };
+  // nibble lists: one 32-bit word holds 8 positions (K <= 8), a 64-bit word 15
+  template <bool W, int = 0> struct OrdT { typedef unsigned int type; };
+  template <int D0> struct OrdT<true, D0> { typedef u64 type; };
+  typedef typename OrdT<(K > 8)>::type ord_t;
+  enum { ORD_BITS = (K > 8) ? 64 : 32 };
+  enum { GJ = (K <= 8 ? 3 : 4), NX = (K <= 8 ? 2 : 4), EID_POLY = 4096 };
   SD_HD D& self() { return *static_cast<D*>(this); }
   static constexpr unsigned RI = P::template region<int, K>(), RD = P::template region<double, K>(),
                             RS = P::template region<short, K>(), RB = P::template region<signed char, K>(),
                             RIL = P::template region<int, MAXIL>(), RILB = P::template region<signed char, MAXIL>(),
-                            RG = P::template region<int, GJ>(), R1 = P::template region<int, 1>(), R8 = P::template region<u64, 1>();
+                            RG = P::template region<int, GJ>(), RGF = P::template region<int, (FULLGJ ? GJ : 1)>(), R1 = P::template region<int, 1>(), R8 = P::template region<u64, 1>(), RO = P::template region<ord_t, 1>();
   static constexpr unsigned O_BOTX = 0, O_BOTY = O_BOTX + RI, O_TOPX = O_BOTY + RI, O_TOPY = O_TOPX + RI, O_CURX = O_TOPY + RI,
-                            O_CURY = O_CURX + RI, O_DX = O_CURY + RI, O_EID = O_DX + RD, O_WCNT = O_EID + RS, O_WCNT2 = O_WCNT + RS,
-                            O_OUTIDX = O_WCNT2 + RS, O_LMLC = O_OUTIDX + RB, O_WDELTA = O_LMLC + RB, O_PTYP = O_WDELTA + RB,
+                            O_CURY = O_CURX + RI, O_DX = O_CURY + RI, O_EID = O_DX + RD, O_WCNT = O_EID + RS, O_WCNT2 = O_WCNT + RB,
+                            O_OUTIDX = O_WCNT2 + RB, O_LMLC = O_OUTIDX + RB, O_WDELTA = O_LMLC + RB, O_PTYP = O_WDELTA + RB,
                             O_SIDE = O_PTYP + RB, O_ILX = O_SIDE + RB, O_ILY = O_ILX + RIL, O_ILE1 = O_ILY + RIL, O_ILE2 = O_ILE1 + RILB,
-                            O_GJOP = O_ILE2 + RILB, O_GJX1 = O_GJOP + RG, O_GJX2 = O_GJX1 + RG, O_GJY2 = O_GJX2 + RG,
-                            O_XTRA = O_GJY2 + RG, O_MLM = O_XTRA + P::template region<int, NX>(),
-                            O_ORD = O_MLM + P::template region<unsigned char, 16>(), O_SORD = O_ORD + R8, O_HSEL = O_SORD + R8,
-                            O_PA = O_HSEL + R8, O_PB = O_PA + R8, O_NAEL = O_PB + R8, O_FREE = O_NAEL + R1, O_NLM = O_FREE + R1,
+                            O_GJOP = O_ILE2 + RILB, O_GJX1 = O_GJOP + RGF, O_GJX2 = O_GJX1 + RG, O_GJY2 = O_GJX2 + RG,
+                            O_XTRA = O_GJY2 + RGF, O_MLM = O_XTRA + P::template region<int, NX>(),
+                            O_PA = O_MLM + P::template region<unsigned char, 16>(),
+                            O_ORD = O_PA + 2 * R8, O_HSEL = O_ORD + RO, O_AFTER_ORD = O_HSEL + RO, O_PB = O_PA + R8, O_NAEL = O_AFTER_ORD, O_FREE = O_NAEL + R1, O_NLM = O_FREE + R1,
                             O_CURLM = O_NLM + R1, O_NIL = O_CURLM + R1, O_STATUS = O_NIL + R1, O_NJOINS = O_STATUS + R1,
-                            O_NGJ = O_NJOINS + R1, O_NXTRA = O_NGJ + R1, O_CORE_END = O_NXTRA + R1;
+                            O_NGJ = O_NJOINS + R1, O_NXTRA = O_NGJ + R1, O_LMY = O_NXTRA + R1, O_CORE_END = O_LMY + R1;
   // ---- bound slots
   typename P::template Arr<int, K, O_BOTX> botx; typename P::template Arr<int, K, O_BOTY> boty;
   typename P::template Arr<int, K, O_TOPX> topx; typename P::template Arr<int, K, O_TOPY> topy;
   typename P::template Arr<int, K, O_CURX> curx; typename P::template Arr<int, K, O_CURY> cury;
   typename P::template Arr<double, K, O_DX> dx;
   typename P::template Arr<short, K, O_EID> eid;                 // current edge: poly * EID_POLY + index in that polygon's ring
-  typename P::template Arr<short, K, O_WCNT> wcnt; typename P::template Arr<short, K, O_WCNT2> wcnt2;
+  typename P::template Arr<signed char, K, O_WCNT> wcnt; typename P::template Arr<signed char, K, O_WCNT2> wcnt2;   // |winding| <= n_lm <= 16
   typename P::template Arr<signed char, K, O_OUTIDX> outidx;
-  typename P::template Arr<signed char, K, O_LMLC> lmlc;        // NextInLML code of the current edge (0 none, 1 next, 2 prev)
+  typename P::template Arr<signed char, K, O_LMLC> lmlc;        // current edge: bits 0-1 NextInLML (0 none, 1 next, 2 prev), bit 3 NextInLML is horizontal
   typename P::template Arr<signed char, K, O_WDELTA> wdelta; typename P::template Arr<signed char, K, O_PTYP> ptyp;
   typename P::template Arr<signed char, K, O_SIDE> side;
   // ---- intersections of the current scan-beam
   typename P::template Arr<int, MAXIL, O_ILX> ilx; typename P::template Arr<int, MAXIL, O_ILY> ily;
   typename P::template Arr<signed char, MAXIL, O_ILE1> ile1; typename P::template Arr<signed char, MAXIL, O_ILE2> ile2;
   // ---- ghost joins of the current scan-line (:1968-1975), extra scan-beam Ys, merged local minima
-  typename P::template Arr<int, GJ, O_GJOP> gjop; typename P::template Arr<int, GJ, O_GJX1> gjx1;
-  typename P::template Arr<int, GJ, O_GJX2> gjx2; typename P::template Arr<int, GJ, O_GJY2> gjy2;
+  typename P::template Arr<int, (FULLGJ ? GJ : 1), O_GJOP> gjop; typename P::template Arr<int, GJ, O_GJX1> gjx1;
+  typename P::template Arr<int, GJ, O_GJX2> gjx2; typename P::template Arr<int, (FULLGJ ? GJ : 1), O_GJY2> gjy2;
   typename P::template Arr<int, NX, O_XTRA> xtra;
   typename P::template Arr<unsigned char, 16, O_MLM> mlm;       // poly * 128 + index into that polygon's lm list
   // ---- scalars
-  typename P::template Scalar<u64, O_ORD> ord;                   // AEL: nibble p = slot at position p; unused = 0xF
-  typename P::template Scalar<u64, O_SORD> sord;                 // SEL copy used for the intersection sort
-  typename P::template Scalar<u64, O_HSEL> hsel;                 // SEL as the stack of pending horizontals (nibble 0 = head)
+  typename P::template Scalar<ord_t, O_ORD> ord;                 // AEL: nibble p = slot at position p; unused = 0xF
+  typename P::template Scalar<ord_t, O_HSEL> hsel;                // SEL as the stack of pending horizontals (nibble 0 = head)
   typename P::template Scalar<const Prep*, O_PA> prepA; typename P::template Scalar<const Prep*, O_PB> prepB;
   typename P::template Scalar<int, O_NAEL> n_ael; typename P::template Scalar<int, O_FREE> freemask;
   typename P::template Scalar<int, O_NLM> n_lm; typename P::template Scalar<int, O_CURLM> cur_lm;
   typename P::template Scalar<int, O_NIL> n_il; typename P::template Scalar<int, O_STATUS> status;
   typename P::template Scalar<int, O_NJOINS> n_joins; typename P::template Scalar<int, O_NGJ> n_gj;
   typename P::template Scalar<int, O_NXTRA> n_xtra;
+  typename P::template Scalar<int, O_LMY> next_lm_y;             // Y of local minimum cur_lm (valid while cur_lm < n_lm)
 
-  static constexpr u64 ALLF = ~0ull;
+  static constexpr ord_t ALLF = (ord_t)~(ord_t)0;
+  static constexpr ord_t ONES = (ord_t)0x1111111111111111ull, HIGHS = (ord_t)0x8888888888888888ull;
   // ------------------------------------------------------------------ nibble lists
-  static SD_HD int nib(u64 w, int p) { return (int)((w >> (4 * p)) & 15ull); }
-  static SD_HD int nib_find(u64 w, int h) {                       // position of slot h (unused nibbles are 0xF, h < 15), or -1
-    const u64 x = w ^ ((u64)h * 0x1111111111111111ull);
-    const u64 t = (x - 0x1111111111111111ull) & ~x & 0x8888888888888888ull;
+  static SD_HD int nib(ord_t w, int p) { return (int)((w >> (4 * p)) & (ord_t)15); }
+  static SD_HD int nib_find(ord_t w, int h) {                       // position of slot h (unused nibbles are 0xF, h < 15), or -1
+    const ord_t x = w ^ ((ord_t)h * ONES);
+    const ord_t t = (ord_t)(x - ONES) & ~x & HIGHS;                  // lowest set bit marks the first zero nibble (exact)
     if (!t) return -1;
 #if defined(__HIP_DEVICE_COMPILE__)
-    return (__ffsll((long long)t) - 1) >> 2;
+    return (ORD_BITS == 64) ? ((__ffsll((long long)t) - 1) >> 2) : ((__ffs((int)t) - 1) >> 2);
 #else
-    return __builtin_ctzll(t) >> 2;
+    return (ORD_BITS == 64) ? (__builtin_ctzll((u64)t) >> 2) : (__builtin_ctz((unsigned)t) >> 2);
 #endif
   }
-  static SD_HD u64 nib_insert(u64 w, int p, int h) {
-    const u64 lowmask = (p == 0) ? 0ull : (ALLF >> (64 - 4 * p));
-    return (w & lowmask) | ((u64)h << (4 * p)) | ((w & ~lowmask) << 4);
+  static SD_HD ord_t nib_insert(ord_t w, int p, int h) {
+    const ord_t lowmask = (p == 0) ? (ord_t)0 : (ord_t)(ALLF >> (ORD_BITS - 4 * p));
+    return (ord_t)((w & lowmask) | ((ord_t)h << (4 * p)) | ((ord_t)(w & ~lowmask) << 4));
   }
-  static SD_HD u64 nib_remove(u64 w, int p) {
-    const u64 lowmask = (p == 0) ? 0ull : (ALLF >> (64 - 4 * p));
-    return (w & lowmask) | (((w >> 4) & ~lowmask)) | (0xFull << 60);
+  static SD_HD ord_t nib_remove(ord_t w, int p) {
+    const ord_t lowmask = (p == 0) ? (ord_t)0 : (ord_t)(ALLF >> (ORD_BITS - 4 * p));
+    return (ord_t)((w & lowmask) | (((w >> 4) & ~lowmask)) | ((ord_t)0xF << (ORD_BITS - 4)));
   }
-  static SD_HD u64 nib_swap(u64 w, int p, int q) {
-    const u64 d = (u64)(nib(w, p) ^ nib(w, q));
-    return w ^ (d << (4 * p)) ^ (d << (4 * q));
+  static SD_HD ord_t nib_swap(ord_t w, int p, int q) {
+    const ord_t d = (ord_t)(nib(w, p) ^ nib(w, q));
+    return (ord_t)(w ^ (d << (4 * p)) ^ (d << (4 * q)));
   }
   SD_HD int ael_head() const { return n_ael > 0 ? nib(ord, 0) : -1; }
-  SD_HD int anext(int h) const { const u64 w = ord; const int p = nib_find(w, h); if (p < 0 || p + 1 >= n_ael) return -1; return nib(w, p + 1); }
-  SD_HD int aprev(int h) const { const u64 w = ord; const int p = nib_find(w, h); if (p <= 0) return -1; return nib(w, p - 1); }
+  SD_HD int anext(int h) const { const ord_t w = ord; const int p = nib_find(w, h); if (p < 0 || p + 1 >= n_ael) return -1; return nib(w, p + 1); }
+  SD_HD int aprev(int h) const { const ord_t w = ord; const int p = nib_find(w, h); if (p <= 0) return -1; return nib(w, p - 1); }
   SD_HD bool in_ael(int h) const { return nib_find(ord, h) >= 0; }
   SD_HD int alloc_slot() {
     const int f = freemask;
@@ -326,10 +380,11 @@ struct BeamCore {
   static SD_HD int ring_pv(const Prep* q, int i) { return i == 0 ? q->n - 1 : i - 1; }
   struct ES { int bx, by, tx, ty, code; };
   static SD_HD ES edge_static(const Prep* q, int i) {
+    BEAM_CNT(es_loads, 1);
     ES s;
-    const int j = ring_nx(q, i);
     s.code = q->ecode[i];
-    const int x0 = q->vx[i], y0 = q->vy[i], x1 = q->vx[j], y1 = q->vy[j];
+    const PrepPt p0 = q->v[i], p1 = q->v[i + 1];
+    const int x0 = p0.x, y0 = p0.y, x1 = p1.x, y1 = p1.y;
     if (s.code & 4) { s.bx = x1; s.by = y1; s.tx = x0; s.ty = y0; }
     else { s.bx = x0; s.by = y0; s.tx = x1; s.ty = y1; }
     return s;
@@ -352,12 +407,13 @@ struct BeamCore {
     const ES s = es_of(id);
     botx[h] = s.bx; boty[h] = s.by; topx[h] = s.tx; topy[h] = s.ty;
     dx[h] = es_dx(s);
-    eid[h] = (short)id; lmlc[h] = (signed char)(s.code & 3);
+    eid[h] = (short)id; lmlc[h] = (signed char)(s.code & 11);
   }
 
   // ------------------------------------------------------------------ helpers (as SweepCore)
   SD_HD bool is_horz(int h) const { return topy[h] == boty[h]; }
   SD_HD i64 top_x(int h, i64 y) const {                                      // clipper.cpp:615-619
+    BEAM_CNT(topx, 1);
     return (y == topy[h]) ? (i64)topx[h] : (i64)botx[h] + sd_round(dx[h] * (double)(y - boty[h]));
   }
   static SD_HD bool slopes_equal4(i64 x1, i64 y1, i64 x2, i64 y2, i64 x3, i64 y3, i64 x4, i64 y4) {  // :566-575
@@ -375,12 +431,12 @@ struct BeamCore {
   SD_HD void add_join(int op1, int op2, int offx, int offy) { ++n_joins; self().out_add_join(op1, op2, offx, offy); }
   SD_HD void add_ghost_join(int op, int x1, int x2, int y2) {
     const int g = n_gj;
-    if (g < GJ) { gjop[g] = op; gjx1[g] = x1; gjx2[g] = x2; gjy2[g] = y2; n_gj = g + 1; }
+    if (g < GJ) { gjop[FULLGJ ? g : 0] = op; gjx1[g] = x1; gjx2[g] = x2; gjy2[FULLGJ ? g : 0] = y2; n_gj = g + 1; }
     else { ++n_joins; status |= ST_OVERFLOW_GJ; }
   }
   SD_HD void horz_joins(int horz, int op1) {                                  // :2721-2732, 2774-2785
-    u64 w = hsel;
-    for (int h = (int)(w & 15ull); h != 15; w >>= 4, h = (int)(w & 15ull))
+    ord_t w = hsel;
+    for (int h = (int)(w & 15u); h != 15; w = (ord_t)((w >> 4) | ((ord_t)0xF << (ORD_BITS - 4))), h = (int)(w & 15u))
       if (outidx[h] >= 0 && horz_segments_overlap(botx[horz], topx[horz], botx[h], topx[h]))
         add_join(self().out_last_pt(h), op1, topx[h], topy[h]);
   }
@@ -399,10 +455,10 @@ struct BeamCore {
   // PopScanbeam :1341-1348 on the implicit queue (see header).  curY: the scan-line just processed.
   SD_HD bool pop_scanbeam(int curY, int& y) {
     bool have = false; int best = 0;
-    if (cur_lm < n_lm) { best = lm_y(cur_lm); have = true; }
+    if (cur_lm < n_lm) { best = next_lm_y; have = true; }
     const int k = n_xtra;
     for (int i = 0; i < k; ++i) { const int v = xtra[i]; if (!have || v > best) { best = v; have = true; } }
-    const u64 w = ord; const int n = n_ael;
+    const ord_t w = ord; const int n = n_ael;
     for (int p = 0; p < n; ++p) {
       const int h = nib(w, p);
       const int t = topy[h];
@@ -417,13 +473,13 @@ struct BeamCore {
   }
 
   // ------------------------------------------------------------------ output (delegated to D)
-  SD_HD int add_out_pt(int e, int px, int py) { return self().out_add_pt(e, px, py); }
+  SD_HD int add_out_pt(int e, int px, int py) { BEAM_CNT(outpt, 1); return self().out_add_pt(e, px, py); }
   SD_HDN void add_local_max_poly(int e1, int e2, int px, int py) {           // :1884-1897
     add_out_pt(e1, px, py);
     if (outidx[e1] == outidx[e2]) {
       if (outidx[e1] >= 0) self().out_ring_closed(outidx[e1]);
       outidx[e1] = kUnassigned; outidx[e2] = kUnassigned;
-    } else if (outidx[e1] < outidx[e2]) self().out_append(e1, e2);
+    } else if (self().out_ring_before(outidx[e1], outidx[e2])) self().out_append(e1, e2);   // OutRec index order (:1893)
     else self().out_append(e2, e1);
   }
   SD_HDN int add_local_min_poly(int e1, int e2, int px, int py) {            // :1841-1881
@@ -461,7 +517,7 @@ struct BeamCore {
   }
   SD_HDN void insert_edge_into_ael(int edge, int startEdge) {                // :3319-3345
     const int n = n_ael;
-    u64 w = ord;
+    ord_t w = ord;
     int at;
     if (n == 0) at = 0;
     else if (startEdge < 0 && e2_inserts_before_e1(nib(w, 0), edge)) at = 0;
@@ -475,7 +531,7 @@ struct BeamCore {
     n_ael = n + 1;
   }
   SD_HD void delete_from_ael(int e) {                                       // :1367-1377
-    const u64 w = ord;
+    const ord_t w = ord;
     const int p = nib_find(w, e);
     if (p < 0) return;
     ord = nib_remove(w, p);
@@ -483,14 +539,15 @@ struct BeamCore {
     freemask = freemask | (1 << e);
   }
   SD_HD void swap_positions_in_ael(int e1, int e2) {                        // :1395-1439
-    const u64 w = ord;
+    const ord_t w = ord;
     const int p = nib_find(w, e1), q = nib_find(w, e2);
     if (p < 0 || q < 0) return;
     ord = nib_swap(w, p, q);
   }
-  SD_HD void add_edge_to_sel(int edge) { hsel = (hsel << 4) | (u64)edge; }   // :1900-1917 (push at the head)
+  SD_HD void add_edge_to_sel(int edge) { hsel = (ord_t)(((ord_t)hsel << 4) | (ord_t)edge); }   // :1900-1917 (push at the head)
   // UpdateEdgeIntoAEL :1442-1462 ; the successor takes over the slot
   SD_HDN int update_edge_into_ael(int e) {
+    BEAM_CNT(update, 1);
     const int id = eid[e];
     const int n = lml_id(id, lmlc[e]);
     if (n < 0) { status |= ST_FAIL; return e; }
@@ -501,7 +558,7 @@ struct BeamCore {
 
   // ------------------------------------------------------------------ winding  (NonZero both, ctIntersection)
   SD_HDN void set_winding_count(int edge) {                                  // :1624-1722
-    const u64 w = ord;
+    const ord_t w = ord;
     const int pe = nib_find(w, edge);
     int p = pe - 1;
     while (p >= 0 && (ptyp[nib(w, p)] != ptyp[edge] || wdelta[nib(w, p)] == 0)) --p;
@@ -515,17 +572,17 @@ struct BeamCore {
         int a = wcnt[e] < 0 ? -wcnt[e] : wcnt[e];
         if (a > 1) {
           if (wdelta[e] * wdelta[edge] < 0) wcnt[edge] = wcnt[e];
-          else wcnt[edge] = (short)(wcnt[e] + wdelta[edge]);
+          else wcnt[edge] = (signed char)(wcnt[e] + wdelta[edge]);
         } else wcnt[edge] = (wdelta[edge] == 0 ? 1 : wdelta[edge]);
       } else {
-        if (wdelta[edge] == 0) wcnt[edge] = (short)(wcnt[e] < 0 ? wcnt[e] - 1 : wcnt[e] + 1);
+        if (wdelta[edge] == 0) wcnt[edge] = (signed char)(wcnt[e] < 0 ? wcnt[e] - 1 : wcnt[e] + 1);
         else if (wdelta[e] * wdelta[edge] < 0) wcnt[edge] = wcnt[e];
-        else wcnt[edge] = (short)(wcnt[e] + wdelta[edge]);
+        else wcnt[edge] = (signed char)(wcnt[e] + wdelta[edge]);
       }
       wcnt2[edge] = wcnt2[e];
       ++p;
     }
-    for (; p < pe; ++p) wcnt2[edge] = (short)(wcnt2[edge] + wdelta[nib(w, p)]);
+    for (; p < pe; ++p) wcnt2[edge] = (signed char)(wcnt2[edge] + wdelta[nib(w, p)]);
   }
   SD_HD bool is_contributing(int e) const {                                 // :1741-1838
     int a = wcnt[e] < 0 ? -wcnt[e] : wcnt[e];
@@ -535,13 +592,14 @@ struct BeamCore {
 
   // ------------------------------------------------------------------ IntersectEdges  :2106-2298
   SD_HDN void intersect_edges(int e1, int e2, int px, int py) {
+    BEAM_CNT(isect_edges, 1);
     bool c1 = outidx[e1] >= 0, c2 = outidx[e2] >= 0;
     if (ptyp[e1] == ptyp[e2]) {
-      if (wcnt[e1] + wdelta[e2] == 0) wcnt[e1] = (short)-wcnt[e1]; else wcnt[e1] = (short)(wcnt[e1] + wdelta[e2]);
-      if (wcnt[e2] - wdelta[e1] == 0) wcnt[e2] = (short)-wcnt[e2]; else wcnt[e2] = (short)(wcnt[e2] - wdelta[e1]);
+      if (wcnt[e1] + wdelta[e2] == 0) wcnt[e1] = (signed char)-wcnt[e1]; else wcnt[e1] = (signed char)(wcnt[e1] + wdelta[e2]);
+      if (wcnt[e2] - wdelta[e1] == 0) wcnt[e2] = (signed char)-wcnt[e2]; else wcnt[e2] = (signed char)(wcnt[e2] - wdelta[e1]);
     } else {
-      wcnt2[e1] = (short)(wcnt2[e1] + wdelta[e2]);
-      wcnt2[e2] = (short)(wcnt2[e2] - wdelta[e1]);
+      wcnt2[e1] = (signed char)(wcnt2[e1] + wdelta[e2]);
+      wcnt2[e2] = (signed char)(wcnt2[e2] - wdelta[e1]);
     }
     int e1Wc = wcnt[e1] < 0 ? -wcnt[e1] : wcnt[e1];
     int e2Wc = wcnt[e2] < 0 ? -wcnt[e2] : wcnt[e2];
@@ -578,9 +636,11 @@ struct BeamCore {
 
   // ------------------------------------------------------------------ InsertLocalMinimaIntoAEL  :1978-2077
   SD_HDN void insert_local_minima_into_ael(int botY) {
-    while (cur_lm < n_lm && lm_y(cur_lm) == botY) {
+    while (cur_lm < n_lm && next_lm_y == botY) {
       const int m = mlm[cur_lm];
       ++cur_lm;
+      if (cur_lm < n_lm) next_lm_y = lm_y(cur_lm);
+      BEAM_CNT(lm, 1);
       const int poly = (m & 128) ? 1 : 0;
       const Prep* q = poly ? (const Prep*)prepB : (const Prep*)prepA;
       const int li = q->lm_left[m & 127], ri = q->lm_right[m & 127];
@@ -614,7 +674,7 @@ struct BeamCore {
       if (have_op1 && is_horz(rb) && n_gj > 0 && wdelta[rb] != 0) {       // :2029-2040
         const int ng = n_gj;
         for (int g = 0; g < ng; ++g)
-          if (horz_segments_overlap(gjx1[g], gjx2[g], botx[rb], topx[rb])) add_join(gjop[g], op1, gjx2[g], gjy2[g]);
+          if (horz_segments_overlap(gjx1[g], gjx2[g], botx[rb], topx[rb])) add_join(gjop[FULLGJ ? g : 0], op1, gjx2[g], gjy2[FULLGJ ? g : 0]);
       }
       const int lp = aprev(lb);
       if (outidx[lb] >= 0 && lp >= 0 && curx[lp] == botx[lb] && outidx[lp] >= 0 &&
@@ -643,20 +703,15 @@ struct BeamCore {
   }
 
   // ------------------------------------------------------------------ horizontals  :2512-2824
-  // GetMaximaPair :2538-2545 for edge id `id` whose Top is (tx, ty); returns an edge id or -1
-  SD_HD int get_maxima_pair_id(int id, int tx, int ty) const {
+  // GetMaximaPair :2538-2545 for edge id `id` (prepared per edge); returns an edge id or -1
+  SD_HD int get_maxima_pair_id(int id) const {
     const Prep* q = prep_of(id);
-    const int base = id & ~(EID_POLY - 1), i = id & (EID_POLY - 1);
-    const int n = ring_nx(q, i), p = ring_pv(q, i);
-    const ES sn = edge_static(q, n);
-    if (sn.tx == tx && sn.ty == ty && (sn.code & 3) == 0) return base + n;
-    const ES sp = edge_static(q, p);
-    if (sp.tx == tx && sp.ty == ty && (sp.code & 3) == 0) return base + p;
-    return -1;
+    const int mp = q->mpair[id & (EID_POLY - 1)];
+    return (mp == Prep::NONE) ? -1 : (id & ~(EID_POLY - 1)) + mp;
   }
   // slot holding edge id (or -1)
   SD_HD int slot_of(int id) const {
-    const u64 w = ord; const int n = n_ael;
+    const ord_t w = ord; const int n = n_ael;
     for (int p = 0; p < n; ++p) { const int h = nib(w, p); if (eid[h] == id) return h; }
     return -1;
   }
@@ -664,7 +719,7 @@ struct BeamCore {
   // `slot` = its slot if it is in the AEL (else -1: the pair is a horizontal that has not entered the AEL yet).
   SD_HD int get_maxima_pair_ex(int e, int& slot) const {
     slot = -1;
-    const int r = get_maxima_pair_id(eid[e], topx[e], topy[e]);
+    const int r = get_maxima_pair_id(eid[e]);
     if (r < 0) return -1;
     slot = slot_of(r);
     if (slot < 0) {
@@ -674,24 +729,20 @@ struct BeamCore {
     return r;
   }
   SD_HDN void process_horizontal(int horz) {
+    BEAM_CNT(horz, 1);
     bool l2r; i64 hl, hr;
     if (botx[horz] < topx[horz]) { hl = botx[horz]; hr = topx[horz]; l2r = true; }
     else { hl = topx[horz]; hr = botx[horz]; l2r = false; }
-    // eLast: last horizontal of the run in this bound; eMaxPair only if the run ends the bound
-    int eLast = eid[horz], lastCode = lmlc[horz], lastTx = topx[horz], lastTy = topy[horz];
+    // eLast: last horizontal of the run in this bound; eMaxPair only if the run ends the bound (both prepared per edge)
+    int eLast, eMaxPair = -1;
     {
-      int guard0 = 0;
-      for (;;) {
-        const int nid = lml_id(eLast, lastCode);
-        if (nid < 0) break;
-        const ES s = es_of(nid);
-        if (s.ty != s.by) break;
-        eLast = nid; lastCode = s.code; lastTx = s.tx; lastTy = s.ty;
-        if (++guard0 > MAXV) { status |= ST_ITER; return; }
-      }
+      const int id = eid[horz];
+      const Prep* q = prep_of(id);
+      const int base = id & ~(EID_POLY - 1);
+      const int li = q->hlast[id & (EID_POLY - 1)];
+      eLast = base + li;
+      if ((q->ecode[li] & 3) == 0) { const int mp = q->mpair[li]; if (mp != Prep::NONE) eMaxPair = base + mp; }
     }
-    int eMaxPair = -1;
-    if ((lastCode & 3) == 0) eMaxPair = get_maxima_pair_id(eLast, lastTx, lastTy);
     int op1 = -1; bool have_op1 = false;
     int guard = 0;
     for (;;) {
@@ -700,7 +751,7 @@ struct BeamCore {
       while (e >= 0) {
         if (++guard > 4 * K * K + 4 * MAXV) { status |= ST_ITER; return; }
         if ((l2r && curx[e] > hr) || (!l2r && curx[e] < hl)) break;
-        if (curx[e] == topx[horz] && lmlc[horz] != 0) {
+        if (curx[e] == topx[horz] && (lmlc[horz] & 3) != 0) {
           const ES s = es_of(lml_id(eid[horz], lmlc[horz]));
           if (dx[e] < es_dx(s)) break;
         }
@@ -722,11 +773,7 @@ struct BeamCore {
         swap_positions_in_ael(horz, e);
         e = eNext;
       }
-      if (lmlc[horz] == 0) break;
-      {
-        const ES s = es_of(lml_id(eid[horz], lmlc[horz]));
-        if (s.ty != s.by) break;
-      }
+      if ((lmlc[horz] & 8) == 0) break;                                      // no successor, or it is not horizontal
       horz = update_edge_into_ael(horz);
       if (outidx[horz] >= 0) add_out_pt(horz, botx[horz], boty[horz]);
       if (botx[horz] < topx[horz]) { hl = botx[horz]; hr = topx[horz]; l2r = true; }
@@ -737,7 +784,7 @@ struct BeamCore {
       horz_joins(horz, op1);
       add_ghost_join(op1, self().out_last_pt_x(horz), topx[horz], topy[horz]);
     }
-    if (lmlc[horz] != 0) {
+    if ((lmlc[horz] & 3) != 0) {
       if (outidx[horz] >= 0) {
         op1 = add_out_pt(horz, topx[horz], topy[horz]);
         horz = update_edge_into_ael(horz);
@@ -761,10 +808,10 @@ struct BeamCore {
   SD_HD void process_horizontals() {
     int guard = 0;
     for (;;) {
-      const u64 w = hsel;
-      const int h = (int)(w & 15ull);
+      const ord_t w = hsel;
+      const int h = (int)(w & 15u);
       if (h == 15) break;
-      hsel = (w >> 4) | (0xFull << 60);                                     // DeleteFromSEL (head)
+      hsel = (ord_t)((w >> 4) | ((ord_t)0xF << (ORD_BITS - 4)));                                   // DeleteFromSEL (head)
       process_horizontal(h);
       if (++guard > 4 * MAXV) { status |= ST_ITER; break; }
     }
@@ -806,7 +853,7 @@ struct BeamCore {
   SD_HDN void build_intersect_list(int topY) {
     const int n = n_ael;
     if (n == 0) return;
-    u64 w = ord;
+    ord_t w = ord;
     for (int p = 0; p < n; ++p) { const int h = nib(w, p); curx[h] = (int)top_x(h, topY); }
     // bubble sort of the SEL copy (:2837-2862): a pass carries the largest element to the end, which is then cut off
     int m = n, guard = 0;
@@ -834,7 +881,7 @@ struct BeamCore {
   }
   SD_HDN bool fixup_intersection_order() {
     // CopyAELToSEL :1929-1939
-    u64 w = ord;
+    ord_t w = ord;
     const int n = n_il;
     // std::sort(IntersectListSort :2921-2924): n <= 16 -> insertion sort == stable sort by Y descending
     for (int i = 1; i < n; ++i) {
@@ -868,6 +915,7 @@ struct BeamCore {
     build_intersect_list(topY);
     const int n = n_il;
     if (n == 0) return true;
+    BEAM_CNT(il_beams, 1); BEAM_CNT(isect_pt, n);
     if (n == 1 || fixup_intersection_order()) {
       for (int i = 0; i < n; ++i) {
         const int e1 = ile1[i], e2 = ile2[i];
@@ -881,6 +929,7 @@ struct BeamCore {
 
   // ------------------------------------------------------------------ top of scan-beam  :2957-3113
   SD_HDN void do_maxima(int e) {
+    BEAM_CNT(maxima, 1);
     int mp;
     const int mpid = get_maxima_pair_ex(e, mp);
     if (mpid < 0) {
@@ -909,7 +958,7 @@ struct BeamCore {
     int guard = 0;
     while (e >= 0) {
       if (++guard > 4 * MAXV) { status |= ST_ITER; break; }
-      bool isMax = (topy[e] == topY && lmlc[e] == 0);
+      bool isMax = (topy[e] == topY && (lmlc[e] & 3) == 0);
       if (isMax) {
         int mps;
         const int mp = get_maxima_pair_ex(e, mps);
@@ -923,9 +972,7 @@ struct BeamCore {
         if (status & ST_FAIL) return;
         e = (ePrev < 0) ? ael_head() : anext(ePrev);
       } else {
-        bool nextHorz = false;
-        if (topy[e] == topY && lmlc[e] != 0) { const ES s = es_of(lml_id(eid[e], lmlc[e])); nextHorz = (s.ty == s.by); }
-        if (nextHorz) {
+        if (topy[e] == topY && (lmlc[e] & 8) != 0) {
           e = update_edge_into_ael(e);
           if (outidx[e] >= 0) add_out_pt(e, botx[e], boty[e]);
           add_edge_to_sel(e);
@@ -941,7 +988,7 @@ struct BeamCore {
     guard = 0;
     while (e >= 0) {
       if (++guard > 4 * MAXV) { status |= ST_ITER; break; }
-      if (topy[e] == topY && lmlc[e] != 0) {
+      if (topy[e] == topY && (lmlc[e] & 3) != 0) {
         bool op = false; int oph = -1;
         if (outidx[e] >= 0) { oph = add_out_pt(e, topx[e], topy[e]); op = true; }
         e = update_edge_into_ael(e);
@@ -967,7 +1014,7 @@ struct BeamCore {
   // ------------------------------------------------------------------ Execute  :1560-1621, 1247-1276
   SD_HD void reset_core(const Prep* a, const Prep* b) {
     prepA = a; prepB = b;
-    ord = ALLF; sord = ALLF; hsel = ALLF; n_ael = 0; freemask = (1 << K) - 1;
+    ord = ALLF; hsel = ALLF; n_ael = 0; freemask = (1 << K) - 1;
     n_lm = 0; cur_lm = 0; n_il = 0; status = ST_OK; n_joins = 0; n_gj = 0; n_xtra = 0;
   }
   // Runs the sweep.  Returns false if Clipper's Execute would fail (empty solution).
@@ -991,15 +1038,17 @@ struct BeamCore {
     }
     if (n_lm == 0) return true;
     cur_lm = 0;
-    int botY = lm_y(0), topY = 0;
+    next_lm_y = lm_y(0);
+    int botY = next_lm_y, topY = 0;
     insert_local_minima_into_ael(botY);
     int guard = 0;
     bool ok = true;
     for (;;) {
-      if (status & (ST_OVERFLOW_AEL | ST_ITER)) { ok = false; break; }
+      if (status & (ST_OVERFLOW_AEL | ST_OVERFLOW_REC | ST_OVERFLOW_IL | ST_ITER)) { ok = false; break; }
       const bool popped = pop_scanbeam(botY, topY);
       if (!popped) break;
       if (++guard > 4 * MAXV + 8) { status |= ST_ITER; break; }
+      BEAM_CNT(beams, 1); BEAM_CNT(ael_sum, n_ael);
       process_horizontals();
       n_gj = 0;                                                             // ClearGhostJoins :1575
       if (!process_intersections(topY)) { ok = false; break; }
@@ -1022,21 +1071,31 @@ struct Beam : BeamCore<Beam<MAXV, K, MAXIL, MAXREC, P>, P, MAXV, K, MAXIL> {
   using B::outidx; using B::side; using B::status; using B::ord; using B::n_ael;
   static constexpr unsigned RR = P::template region<int, MAXREC>();
   static constexpr unsigned O_RFX = B::O_CORE_END, O_RFY = O_RFX + RR, O_RLX = O_RFY + RR, O_RLY = O_RLX + RR, O_RSUM = O_RLY + RR,
-                            O_NREC = O_RSUM + P::template region<i64, MAXREC>(), O_TWICE = O_NREC + P::template region<i64, 1>(),
+                            O_RSER = O_RSUM + P::template region<i64, MAXREC>(), O_NREC = O_RSER + P::template region<unsigned char, MAXREC>(),
+                            O_RFREE = O_NREC + P::template region<int, 1>(), O_TWICE = O_RFREE + P::template region<int, 1>(),
                             O_SABS = O_TWICE + P::template region<i64, 1>(), O_END = O_SABS + P::template region<i64, 1>();
   typename P::template Arr<int, MAXREC, O_RFX> rfx; typename P::template Arr<int, MAXREC, O_RFY> rfy;
   typename P::template Arr<int, MAXREC, O_RLX> rlx; typename P::template Arr<int, MAXREC, O_RLY> rly;
   typename P::template Arr<i64, MAXREC, O_RSUM> rsum;
   static constexpr unsigned lds_bytes() { return O_END; }
-  typename P::template Scalar<int, O_NREC> n_rec;
+  typename P::template Arr<unsigned char, MAXREC, O_RSER> rser;   // creation order of the ring held in a slot (Clipper's OutRec index)
+  typename P::template Scalar<int, O_NREC> n_rec;            // rings created so far
+  typename P::template Scalar<int, O_RFREE> rfree;           // free ring slots (closed / appended rings are never referenced again)
   typename P::template Scalar<i64, O_TWICE> twice_area;      // sum over closed rings of |2*area|
   typename P::template Scalar<i64, O_SABS> sum_abs_terms;    // sum of |cross| terms (exactness bound for the float path)
   SD_HD void term(i64 c) { sum_abs_terms += sd_abs64(c); }
   SD_HDN int out_add_pt(int e, int px, int py) {                             // :2463-2499
     int r = outidx[e];
     if (r < 0) {
-      if (n_rec >= MAXREC) { status |= ST_OVERFLOW_REC; return -1; }
-      r = n_rec++;
+      const int f = rfree;
+      if (!f || n_rec >= 255) { status |= ST_OVERFLOW_REC; return -1; }
+#if defined(__HIP_DEVICE_COMPILE__)
+      r = __ffs(f) - 1;
+#else
+      r = __builtin_ctz((unsigned)f);
+#endif
+      rfree = f & (f - 1);
+      rser[r] = (unsigned char)n_rec; n_rec = n_rec + 1;
       rfx[r] = rlx[r] = px; rfy[r] = rly[r] = py; rsum[r] = 0;
       outidx[e] = (signed char)r;
     } else {
@@ -1053,11 +1112,18 @@ struct Beam : BeamCore<Beam<MAXV, K, MAXIL, MAXREC, P>, P, MAXV, K, MAXIL> {
     return -1;
   }
   SD_HD void out_ring_closed(int r) {
+    if (r < 0 || r >= MAXREC) { status |= ST_OVERFLOW_REC; return; }
     i64 c = sd_cross(rlx[r], rly[r], rfx[r], rfy[r]); term(c);
     twice_area += sd_abs64(rsum[r] + c);
+    rfree = rfree | (1 << r);
+  }
+  SD_HD bool out_ring_before(int r1, int r2) const {
+    if (r1 < 0 || r2 < 0) return r1 < r2;
+    return rser[r1] < rser[r2];
   }
   SD_HDN void out_append(int e1, int e2) {                                   // :2367-2460
     int r1 = outidx[e1], r2 = outidx[e2];
+    if (r1 < 0 || r2 < 0) { status |= ST_OVERFLOW_REC; return; }          // only after a ring-capacity overflow
     i64 c;
     if (side[e1] == kLeft) {
       if (side[e2] == kLeft) {        // reverse(2) + 1
@@ -1084,7 +1150,8 @@ struct Beam : BeamCore<Beam<MAXV, K, MAXIL, MAXREC, P>, P, MAXV, K, MAXIL> {
     const int okIdx = r1, obsolete = r2;
     const signed char s1 = side[e1];
     outidx[e1] = kUnassigned; outidx[e2] = kUnassigned;
-    const u64 w = ord; const int n = n_ael;
+    rfree = rfree | (1 << obsolete);
+    const typename B::ord_t w = ord; const int n = n_ael;
     for (int p = 0; p < n; ++p) {
       const int e = B::nib(w, p);
       if (outidx[e] == obsolete) { outidx[e] = (signed char)okIdx; side[e] = s1; break; }
@@ -1092,8 +1159,8 @@ struct Beam : BeamCore<Beam<MAXV, K, MAXIL, MAXREC, P>, P, MAXV, K, MAXIL> {
   }
   SD_HD void out_add_join(int, int, int, int) {}
   SD_HD int out_last_pt(int) { return -1; }
-  SD_HD int out_last_pt_x(int e) { const int r = outidx[e]; return (side[e] == kLeft) ? rfx[r] : rlx[r]; }
-  SD_HD void reset_state(const PolyPrep<MAXV>* a, const PolyPrep<MAXV>* b) { B::reset_core(a, b); n_rec = 0; twice_area = 0; sum_abs_terms = 0; }
+  SD_HD int out_last_pt_x(int e) { const int r = outidx[e]; if (r < 0) return 0; return (side[e] == kLeft) ? rfx[r] : rlx[r]; }
+  SD_HD void reset_state(const PolyPrep<MAXV>* a, const PolyPrep<MAXV>* b) { B::reset_core(a, b); n_rec = 0; rfree = (1 << MAXREC) - 1; twice_area = 0; sum_abs_terms = 0; }
   // Returns 2*area of (A ∩ B) as the reference would sum it (0 if Clipper's Execute fails).
   SD_HD i64 execute() { return B::run_sweep() ? (i64)twice_area : 0; }
 };

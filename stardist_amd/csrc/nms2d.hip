@@ -23,6 +23,7 @@
 //   promoted to survivor after all of its possible suppressors are final.
 #include "common.h"
 #include "clip_sweep.h"
+#include "clip_beam.h"
 #include "../../include/stardist_hip.h"
 #include <hipcub/hipcub.hpp>
 #include <math.h>
@@ -264,15 +265,15 @@ __global__ void __launch_bounds__(256) k_round_scan(const int* __restrict__ S, c
 }
 
 // Round kernel B: wave per new survivor: mark it, emit the pairs the reference would evaluate.
-__global__ void __launch_bounds__(256) k_round_emit(const int* __restrict__ K, int nK, unsigned char* __restrict__ state,
+__global__ void __launch_bounds__(256) k_round_emit(const int* __restrict__ K, const int* __restrict__ nKPtr, unsigned char* __restrict__ state,
                                                     const i64* __restrict__ nbrStart, const int* __restrict__ nbr, Flags f,
                                                     const float* __restrict__ pts, const int4* __restrict__ bbox,
                                                     const float* __restrict__ radius, const float* __restrict__ area,
                                                     int2* __restrict__ pairs, unsigned long long* pairCount,
                                                     unsigned long long pairCap) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int w = blockIdx.x * (blockDim.x >> 6) + wave;
-  if (w >= nK) return;
+  const int nK = *nKPtr;                               // persistent grid: the survivor count of this round is read on the device
+  for (int w = blockIdx.x * (blockDim.x >> 6) + wave; w < nK; w += gridDim.x * (blockDim.x >> 6)) {
   const int i = K[w];
   if (lane == 0) state[i] = ST_KEPT;
   const i64 beg = nbrStart[i], end = nbrStart[i + 1];
@@ -319,68 +320,56 @@ __global__ void __launch_bounds__(256) k_round_emit(const int* __restrict__ K, i
       }
     }
   }
-}
-
-// Round kernel C: one thread per pair.
-template <int MAXV, int MAXIL, int MAXREC>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_pairs(const int2* __restrict__ pairs, unsigned long long nPairs, int R,
-                                              const int* __restrict__ vx, const int* __restrict__ vy,
-                                              const float* __restrict__ area, float thr, unsigned char* __restrict__ state,
-                                              int2* __restrict__ joinPairs, unsigned int* joinCount, unsigned int joinCap,
-                                              unsigned int* errCount) {
-  const unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= nPairs) return;
-  const int2 ij = pairs[p];
-  sdclip::Sweep<MAXV, MAXIL, MAXREC> sw;
-  sw.reset_state();
-  sw.add_path(vx + (size_t)ij.x * R, vy + (size_t)ij.x * R, R, sdclip::kClip, 0);        // :157
-  sw.add_path(vx + (size_t)ij.y * R, vy + (size_t)ij.y * R, R, sdclip::kSubject, MAXV);  // :158
-  const i64 twice = sw.execute();
-  if (sw.status & ~sdclip::ST_FAIL) { atomicAdd(errCount, 1u); }
-  if (sw.n_joins > 0 || sw.sum_abs_terms >= (1ll << 24)) {
-    // shared-edge joins (or float-order sensitivity) can change the reference's area: re-run on the exact path
-    const unsigned int q = atomicAdd(joinCount, 1u);
-    if (q < joinCap) joinPairs[q] = ij;
-    return;
   }
-  const float area_inter = 0.5f * (float)twice;
-  const float overlap = (float)((double)area_inter / fmin((double)area[ij.x] + 1.e-10, (double)area[ij.y] + 1.e-10));  // :580
-  if (overlap > thr) state[ij.y] = ST_SUPPRESSED;                                           // :581-585
 }
 
-// Round kernel C', latency variant: same sweep, per-pair state in LDS (LdsStorage) instead of scratch.  Used for the
-// small rounds of the greedy scan, where the launch time is one pair's serial latency, not throughput.
-enum { LDS_T = 32 };
-template <int MAXV, int MAXIL, int MAXREC>
-__global__ void __launch_bounds__(LDS_T) k_pairs_lds(const int2* __restrict__ pairs, unsigned long long nPairs, int R,
-                                                     const int* __restrict__ vx, const int* __restrict__ vy,
-                                                     const float* __restrict__ area, float thr, unsigned char* __restrict__ state,
-                                                     int2* __restrict__ joinPairs, unsigned int* joinCount, unsigned int joinCap) {
-  typedef sdclip::LdsStorage<LDS_T> LP;
-  for (unsigned long long p = (unsigned long long)blockIdx.x * LDS_T + threadIdx.x; p < nPairs; p += (unsigned long long)gridDim.x * LDS_T) {
+// ---- prepared polygons: Clipper::AddPath once per candidate (clip_beam.h), one thread per candidate, working arrays
+// lane-interleaved in LDS
+template <int MAXV, int S>
+__global__ void __launch_bounds__(S) k_prepare(const int* __restrict__ vx, const int* __restrict__ vy, int N, int R,
+                                               sdclip::PolyPrep<MAXV>* __restrict__ prep) {
+  const int i = blockIdx.x * S + threadIdx.x;
+  if (i >= N) return;
+  sdclip::PrepWork<sdclip::LdsStorage<S>, MAXV> w;
+  w.prepare(vx + (size_t)i * R, vy + (size_t)i * R, R, prep + i);
+}
+
+// Round kernel C: one thread per pair, bound-slot sweep with the whole per-pair state lane-interleaved in LDS.
+// Persistent grid: the pair count is read on the device (no host round trip between emit and this kernel).
+//   result 'capacity exceeded'  -> spill queue (next tier with larger K / list capacities, finally the general path)
+//   joins recorded / float-order risk / any other flag -> exact queue (clip_sweep_full.h restates JoinCommonEdges)
+struct PairQueues { int2* spill; unsigned int* spillCount; int2* exact; unsigned int* exactCount; unsigned int cap; };
+enum { BEAM_CAPFLAGS = sdclip::ST_OVERFLOW_IL | sdclip::ST_OVERFLOW_REC | sdclip::ST_OVERFLOW_AEL | sdclip::ST_OVERFLOW_LM | sdclip::ST_OVERFLOW_GJ };
+template <int MAXV, int K, int MAXIL, int MAXREC, int S, typename CNT>
+__global__ void __launch_bounds__(S) k_pairs_beam(const int2* __restrict__ pairs, const CNT* __restrict__ nPairsPtr,
+                                                  const sdclip::PolyPrep<MAXV>* __restrict__ prep,
+                                                  const float* __restrict__ area, float thr, unsigned char* __restrict__ state,
+                                                  PairQueues q) {
+  typedef sdclip::Beam<MAXV, K, MAXIL, MAXREC, sdclip::LdsStorage<S>> BeamT;
+  const unsigned long long nPairs = (unsigned long long)*nPairsPtr;
+  for (unsigned long long p = (unsigned long long)blockIdx.x * S + threadIdx.x; p < nPairs; p += (unsigned long long)gridDim.x * S) {
     const int2 ij = pairs[p];
-    sdclip::Sweep<MAXV, MAXIL, MAXREC, LP> sw;       // arrays live in dynamic LDS (stateless, see LdsStorage)
-    sw.reset_state();
-    sw.add_path(vx + (size_t)ij.x * R, vy + (size_t)ij.x * R, R, sdclip::kClip, 0);
-    sw.add_path(vx + (size_t)ij.y * R, vy + (size_t)ij.y * R, R, sdclip::kSubject, MAXV);
-    const i64 twice = sw.execute();
-    if ((sw.status & ~sdclip::ST_FAIL) || sw.n_joins > 0 || sw.sum_abs_terms >= (1ll << 24)) {
-      // capacity of the compact variant exceeded, or joins recorded: the exact path decides
-      const unsigned int q = atomicAdd(joinCount, 1u);
-      if (q < joinCap) joinPairs[q] = ij;
+    BeamT bm;
+    bm.reset_state(prep + ij.x, prep + ij.y);                                  // clip = i (:157), subject = j (:158)
+    const i64 twice = bm.execute();
+    const int st = bm.status;
+    if (st & BEAM_CAPFLAGS) {
+      const unsigned int k = atomicAdd(q.spillCount, 1u);
+      if (k < q.cap) q.spill[k] = ij;
+      continue;
+    }
+    if ((st & ~sdclip::ST_FAIL) || bm.n_joins > 0 || bm.sum_abs_terms >= (1ll << 24)) {
+      const unsigned int k = atomicAdd(q.exactCount, 1u);
+      if (k < q.cap) q.exact[k] = ij;
       continue;
     }
     const float area_inter = 0.5f * (float)twice;
-    const float overlap = (float)((double)area_inter / fmin((double)area[ij.x] + 1.e-10, (double)area[ij.y] + 1.e-10));
-    if (overlap > thr) state[ij.y] = ST_SUPPRESSED;
+    const float overlap = (float)((double)area_inter / fmin((double)area[ij.x] + 1.e-10, (double)area[ij.y] + 1.e-10));  // :580
+    if (overlap > thr) state[ij.y] = ST_SUPPRESSED;                                           // :581-585
   }
 }
-
-template <int MAXV, int MAXIL, int MAXREC>
-size_t lds_pairs_bytes() {
-  typedef sdclip::LdsStorage<LDS_T> LP;
-  return (size_t)sdclip::Sweep<MAXV, MAXIL, MAXREC, LP>::lds_bytes() + 64;
-}
+template <int MAXV, int K, int MAXIL, int MAXREC, int S>
+size_t beam_lds_bytes() { return (size_t)sdclip::Beam<MAXV, K, MAXIL, MAXREC, sdclip::LdsStorage<S>>::lds_bytes() + 64; }
 
 __global__ void k_iota(int* a, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = i; }
 __global__ void k_keep(const unsigned char* __restrict__ state, unsigned char* __restrict__ keep, int n) {
@@ -391,31 +380,43 @@ __global__ void k_keep(const unsigned char* __restrict__ state, unsigned char* _
 }  // namespace
 
 namespace sd {
-// exact-join path (nms2d_full.hip): evaluates pairs whose result depends on Clipper's
-// JoinCommonEdges; returns per pair 2*area as the reference sums it.
-int clip_full_pairs(const int2* d_pairs, unsigned int n, int R, const int* d_vx, const int* d_vy, i64* d_twice,
-                    int* d_flags, hipStream_t stream);
+// general path (nms2d_full.hip): pairs whose result depends on Clipper's JoinCommonEdges, or that exceed the
+// capacities of the bound-slot kernels; device-side queue, result applied directly.
+int clip_full_pairs(const int2* d_pairs, const unsigned int* d_n, unsigned int cap, int R, const int* d_vx, const int* d_vy,
+                    const float* d_area, float thr, unsigned char* d_state, unsigned int* d_errCount, hipStream_t stream);
 }
 
 namespace {
-__global__ void k_apply_full(const int2* __restrict__ pairs, unsigned int n, const i64* __restrict__ twice,
-                             const float* __restrict__ area, float thr, unsigned char* __restrict__ state) {
-  const unsigned int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const int2 ij = pairs[p];
-  const float area_inter = 0.5f * (float)twice[p];
-  const float overlap = (float)((double)area_inter / fmin((double)area[ij.x] + 1.e-10, (double)area[ij.y] + 1.e-10));
-  if (overlap > thr) state[ij.y] = ST_SUPPRESSED;
-}
+struct Counters { int nU, nK, nS, pad; unsigned long long nPairs; unsigned int nSpill, nExact, nErr, pad2; };
 
-template <int MAXV, int MAXIL, int MAXREC>
-void launch_pairs(const int2* pairs, unsigned long long nPairs, int R, const int* vx, const int* vy, const float* area,
-                  float thr, unsigned char* state, int2* joinPairs, unsigned int* joinCount, unsigned int joinCap,
-                  unsigned int* errCount, hipStream_t s) {
-  const unsigned int blocks = (unsigned int)((nPairs + 63) / 64);
-  hipLaunchKernelGGL((k_pairs<MAXV, MAXIL, MAXREC>), dim3(blocks), dim3(64), 0, s, pairs, nPairs, R, vx, vy, area, thr,
-                     state, joinPairs, joinCount, joinCap, errCount);
-}
+// prepared polygons + the two tiers of the bound-slot pair kernel for one vertex capacity
+template <int MAXV, int SPREP>
+struct BeamPath {
+  typedef sdclip::PolyPrep<MAXV> Prep;
+  static int prepare(const int* vx, const int* vy, int N, int R, void* prep, hipStream_t s) {
+    const size_t lds = sdclip::PrepWork<sdclip::LdsStorage<SPREP>, MAXV>::lds_bytes() + 64;
+    hipLaunchKernelGGL((k_prepare<MAXV, SPREP>), dim3(sd::div_up(N, SPREP)), dim3(SPREP), lds, s, vx, vy, N, R, (Prep*)prep);
+    SD_LAUNCH_CHECK();
+    return 0;
+  }
+  // tier 1 (K = 8): all pairs of the round; capacity spills -> q.spill
+  static int tier1(const int2* pairs, const unsigned long long* nPairs, const void* prep, const float* area, float thr,
+                   unsigned char* state, PairQueues q, hipStream_t s) {
+    static const size_t lds = beam_lds_bytes<MAXV, 8, 6, 4, 64>();
+    hipLaunchKernelGGL((k_pairs_beam<MAXV, 8, 6, 4, 64, unsigned long long>), dim3(256 * 4), dim3(64), lds, s, pairs, nPairs, (const Prep*)prep, area, thr, state, q);
+    SD_LAUNCH_CHECK();
+    return 0;
+  }
+  // tier 2 (K = 15, larger lists): the spills of tier 1 (or, for n_rays > 32, all pairs); its spills -> general path
+  template <typename CNT>
+  static int tier2(const int2* pairs, const CNT* nPairs, const void* prep, const float* area, float thr,
+                   unsigned char* state, PairQueues q, hipStream_t s) {
+    static const size_t lds = beam_lds_bytes<MAXV, 15, 16, 8, 32>();
+    hipLaunchKernelGGL((k_pairs_beam<MAXV, 15, 16, 8, 32, CNT>), dim3(256 * 3), dim3(32), lds, s, pairs, nPairs, (const Prep*)prep, area, thr, state, q);
+    SD_LAUNCH_CHECK();
+    return 0;
+  }
+};
 }  // namespace
 
 extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n_polys, int n_rays, int use_kdtree,
@@ -439,8 +440,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   if (stats) { SD_CHECK(hipEventCreate(&ev0)); SD_CHECK(hipEventCreate(&ev1)); }
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evguard{ev0, ev1};
   double ns_pairs = 0, ns_full = 0, ns_pre = 0;
-  long long n_pair_launches = 0, n_lds_launches = 0;
-  static const long long lds_max_pairs = getenv("SD_LDS_MAX_PAIRS") ? atoll(getenv("SD_LDS_MAX_PAIRS")) : 8192;   // = pairs resident in one pass (256 CUs x 32 threads)
+  long long n_pair_launches = 0;
 
   // all-pairs configuration with a negative threshold: every pair (0, j) passes the reference's
   // filters and overlap >= 0 > thr, so polygon 0 suppresses everything else.
@@ -532,84 +532,82 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   hipLaunchKernelGGL((k_neighbours<1>), dim3(nbBlocks), dim3(256), 0, s, N, g, f, cellRec, cellStart, nbrCount, (const i64*)nbrStart, nbr, waitOn, W);
   SD_LAUNCH_CHECK();
 
+  // ---- prepared polygons (Clipper::AddPath once per candidate)
+  size_t prepStride;
+  if (R <= 32) prepStride = sizeof(sdclip::PolyPrep<32>); else if (R <= 64) prepStride = sizeof(sdclip::PolyPrep<64>);
+  else if (R <= 128) prepStride = sizeof(sdclip::PolyPrep<128>); else prepStride = sizeof(sdclip::PolyPrep<256>);
+  void* prep = A.take((size_t)N * prepStride);
+  if (!prep) return -1;
+  {
+    int rc;
+    if (R <= 32) rc = BeamPath<32, 64>::prepare(vx, vy, N, R, prep, s);
+    else if (R <= 64) rc = BeamPath<64, 64>::prepare(vx, vy, N, R, prep, s);
+    else if (R <= 128) rc = BeamPath<128, 32>::prepare(vx, vy, N, R, prep, s);
+    else rc = BeamPath<256, 16>::prepare(vx, vy, N, R, prep, s);
+    if (rc) return -1;
+  }
   if (stats) { SD_CHECK(hipEventRecord(ev1, s)); SD_CHECK(hipEventSynchronize(ev1)); float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns_pre = ms * 1e6; }
 
-  // ---- greedy rounds
+  // ---- greedy rounds: every kernel of a round takes its work-list length from device memory; ONE host round trip per
+  // round (the undecided / survivor counts that end the loop)
   const unsigned long long pairCap = (unsigned long long)(totalNbr / 2 + 64);
   int* U0 = A.take_n<int>(N);
   int* U1 = A.take_n<int>(N);
   int* K = A.take_n<int>(N);
   int2* pairs = A.take_n<int2>(pairCap);
-  const unsigned int joinCap = (unsigned int)(pairCap < (1ull << 30) ? pairCap : (1ull << 30));
-  int2* joinPairs = A.take_n<int2>(joinCap);
-  i64* joinTwice = A.take_n<i64>(joinCap);
-  int* joinFlags = A.take_n<int>(joinCap);
-  struct Counters { int nU, nK, nS, pad; unsigned long long nPairs; unsigned int nJoin, nErr; };
+  const unsigned int qCap = (unsigned int)(pairCap < (1ull << 30) ? pairCap : (1ull << 30));
+  int2* spillPairs = A.take_n<int2>(qCap);
+  int2* exactPairs = A.take_n<int2>(qCap);
   int* Sl = A.take_n<int>(N);
-  if (!Sl) return -1;
   Counters* d_cnt = (Counters*)A.take(sizeof(Counters));
-  if (!U0 || !U1 || !K || !pairs || !joinPairs || !joinTwice || !joinFlags || !d_cnt) return -1;
+  if (!U0 || !U1 || !K || !pairs || !spillPairs || !exactPairs || !Sl || !d_cnt) return -1;
   hipLaunchKernelGGL(k_iota, dim3(sd::div_up(N, 256)), dim3(256), 0, s, U0, N);
   int nU = N, rounds = 0;
-  i64 totalPairs = 0, totalJoin = 0;
+  i64 totalPairs = 0, totalExact = 0, totalSpill = 0;
   int* Ucur = U0; int* Unext = U1;
   Counters h;
+  hipEvent_t ev2 = nullptr, ev3 = nullptr;
+  if (stats) { SD_CHECK(hipEventCreate(&ev2)); SD_CHECK(hipEventCreate(&ev3)); }
+  EvGuard evguard2{ev2, ev3};
   while (nU > 0) {
     ++rounds;
     SD_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), s));
     hipLaunchKernelGGL(k_round_triage, dim3(sd::div_up(nU, 256)), dim3(256), 0, s, Ucur, nU, state, waitOn, Unext, K, Sl, (int*)d_cnt);
-    {
-      const int scanBlocks = sd::div_up(nU, 4) < 2048 ? sd::div_up(nU, 4) : 2048;
-      hipLaunchKernelGGL(k_round_scan, dim3(scanBlocks), dim3(256), 0, s, Sl, state, nbrStart, nbr, waitOn, Unext, K, (int*)d_cnt);
-    }
+    const int wgrid = sd::div_up(nU, 4) < 2048 ? sd::div_up(nU, 4) : 2048;
+    hipLaunchKernelGGL(k_round_scan, dim3(wgrid), dim3(256), 0, s, Sl, state, nbrStart, nbr, waitOn, Unext, K, (int*)d_cnt);
+    hipLaunchKernelGGL(k_round_emit, dim3(wgrid), dim3(256), 0, s, K, &d_cnt->nK, state, nbrStart, nbr, f, d_points, bbox,
+                       radius, area, pairs, &d_cnt->nPairs, pairCap);
     SD_LAUNCH_CHECK();
+    if (stats) SD_CHECK(hipEventRecord(ev0, s));
+    PairQueues q1{spillPairs, &d_cnt->nSpill, exactPairs, &d_cnt->nExact, qCap};
+    PairQueues q2{exactPairs, &d_cnt->nExact, exactPairs, &d_cnt->nExact, qCap};   // what tier 2 cannot hold goes to the general path
+    int rc;
+    if (R <= 32) {
+      rc = BeamPath<32, 64>::tier1(pairs, &d_cnt->nPairs, prep, area, threshold, state, q1, s);
+      if (stats) SD_CHECK(hipEventRecord(ev1, s));
+      if (!rc) rc = BeamPath<32, 64>::tier2(spillPairs, &d_cnt->nSpill, prep, area, threshold, state, q2, s);
+    } else {
+      if (R <= 64) rc = BeamPath<64, 64>::tier2(pairs, &d_cnt->nPairs, prep, area, threshold, state, q2, s);
+      else if (R <= 128) rc = BeamPath<128, 32>::tier2(pairs, &d_cnt->nPairs, prep, area, threshold, state, q2, s);
+      else rc = BeamPath<256, 16>::tier2(pairs, &d_cnt->nPairs, prep, area, threshold, state, q2, s);
+      if (stats) SD_CHECK(hipEventRecord(ev1, s));
+    }
+    if (rc) return -1;
+    if (stats) SD_CHECK(hipEventRecord(ev2, s));
+    if (sd::clip_full_pairs(exactPairs, &d_cnt->nExact, qCap, R, vx, vy, area, threshold, state, &d_cnt->nErr, s)) return -1;
+    if (stats) SD_CHECK(hipEventRecord(ev3, s));
     SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
     SD_CHECK(hipStreamSynchronize(s));
     if (h.nK == 0 && h.nU > 0) { sd::set_error("sd_nms2d: greedy scan made no progress (internal error)"); return -1; }
-    if (h.nK > 0) {
-      hipLaunchKernelGGL(k_round_emit, dim3(sd::div_up(h.nK, 4)), dim3(256), 0, s, K, h.nK, state, nbrStart, nbr, f, d_points, bbox,
-                         radius, area, pairs, &d_cnt->nPairs, pairCap);
-      SD_LAUNCH_CHECK();
-      SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
-      SD_CHECK(hipStreamSynchronize(s));
-      if (h.nPairs > pairCap) { sd::set_error("sd_nms2d: pair queue overflow (internal error)"); return -1; }
-      if (h.nPairs > 0) {
-        totalPairs += (i64)h.nPairs;
-        if (stats) SD_CHECK(hipEventRecord(ev0, s));
-        if (R <= 32 && h.nPairs <= (unsigned long long)lds_max_pairs) {
-          // latency-bound round: LDS-resident sweep state, one 32-thread workgroup per CU
-          static const size_t ldsBytes = lds_pairs_bytes<32, 48, 16>();
-          static bool attr_set = false;
-          if (!attr_set) {   // > 64 KiB of dynamic LDS needs an explicit opt-in
-            SD_CHECK(hipFuncSetAttribute((const void*)k_pairs_lds<32, 48, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-            attr_set = true;
-          }
-          const unsigned int blocks = (unsigned int)((h.nPairs + LDS_T - 1) / LDS_T);
-          hipLaunchKernelGGL((k_pairs_lds<32, 48, 16>), dim3(blocks < 2048u ? blocks : 2048u), dim3(LDS_T), ldsBytes, s, pairs, h.nPairs, R, vx, vy,
-                             area, threshold, state, joinPairs, &d_cnt->nJoin, joinCap);
-          ++n_lds_launches;
-        } else
-        if (R <= 32) launch_pairs<32, 64, 32>(pairs, h.nPairs, R, vx, vy, area, threshold, state, joinPairs, &d_cnt->nJoin, joinCap, &d_cnt->nErr, s);
-        else if (R <= 64) launch_pairs<64, 96, 48>(pairs, h.nPairs, R, vx, vy, area, threshold, state, joinPairs, &d_cnt->nJoin, joinCap, &d_cnt->nErr, s);
-        else if (R <= 128) launch_pairs<128, 128, 64>(pairs, h.nPairs, R, vx, vy, area, threshold, state, joinPairs, &d_cnt->nJoin, joinCap, &d_cnt->nErr, s);
-        else launch_pairs<256, 192, 96>(pairs, h.nPairs, R, vx, vy, area, threshold, state, joinPairs, &d_cnt->nJoin, joinCap, &d_cnt->nErr, s);
-        SD_LAUNCH_CHECK();
-        if (stats) SD_CHECK(hipEventRecord(ev1, s));
-        SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
-        SD_CHECK(hipStreamSynchronize(s));
-        if (stats) { float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns_pairs += ms * 1e6; ++n_pair_launches;
-                     if (getenv("SD_TRACE")) printf("round %d: nU=%d nK=%d pairs=%llu joins=%u pair_kernel=%.3f ms\n", rounds, h.nU, h.nK, h.nPairs, h.nJoin, ms); }
-        if (h.nErr) { sd::set_error("sd_nms2d: %u pairs exceeded the scan-beam kernel's fixed capacities", h.nErr); return -1; }
-        if (h.nJoin > 0) {
-          if (h.nJoin > joinCap) { sd::set_error("sd_nms2d: join queue overflow"); return -1; }
-          totalJoin += h.nJoin;
-          if (stats) SD_CHECK(hipEventRecord(ev0, s));
-          if (sd::clip_full_pairs(joinPairs, h.nJoin, R, vx, vy, joinTwice, joinFlags, s)) return -1;
-          if (stats) { SD_CHECK(hipEventRecord(ev1, s)); SD_CHECK(hipEventSynchronize(ev1)); float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns_full += ms * 1e6; }
-          hipLaunchKernelGGL(k_apply_full, dim3(sd::div_up(h.nJoin, 256)), dim3(256), 0, s, joinPairs, h.nJoin, joinTwice, area, threshold, state);
-          SD_LAUNCH_CHECK();
-        }
-      }
+    if (h.nPairs > pairCap || h.nSpill > qCap || h.nExact > qCap) { sd::set_error("sd_nms2d: pair queue overflow (internal error)"); return -1; }
+    if (h.nErr) { sd::set_error("sd_nms2d: %u pairs exceeded the general path's fixed capacities", h.nErr); return -1; }
+    totalPairs += (i64)h.nPairs; totalExact += h.nExact; totalSpill += h.nSpill;
+    if (stats) {
+      float ms = 0, ms2 = 0;
+      SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); SD_CHECK(hipEventElapsedTime(&ms2, ev2, ev3));
+      if (h.nPairs) { ns_pairs += ms * 1e6; ++n_pair_launches; }
+      ns_full += ms2 * 1e6;
+      if (getenv("SD_TRACE")) printf("round %d: nU=%d nK=%d pairs=%llu spill=%u exact=%u pair_kernel=%.3f ms exact_path=%.3f ms\n", rounds, h.nU, h.nK, h.nPairs, h.nSpill, h.nExact, ms, ms2);
     }
     nU = h.nU;
     int* t = Ucur; Ucur = Unext; Unext = t;
@@ -617,12 +615,12 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   hipLaunchKernelGGL(k_keep, dim3(sd::div_up(N, 256)), dim3(256), 0, s, state, d_keep, N);
   SD_LAUNCH_CHECK();
   SD_CHECK(hipStreamSynchronize(s));
-  if (stats) { stats[0] = totalPairs; stats[1] = totalJoin; stats[2] = rounds; stats[3] = totalNbr;
+  if (stats) { stats[0] = totalPairs; stats[1] = totalExact; stats[2] = rounds; stats[3] = totalNbr;
                stats[4] = (int64_t)ns_pairs; stats[5] = n_pair_launches; stats[6] = (int64_t)ns_full; stats[7] = (int64_t)ns_pre;
-               stats[8] = n_lds_launches; }
+               stats[8] = totalSpill; }
   if (verbose) {
     printf("NMS: %lld pair intersections (%lld on the exact-join path), %d greedy rounds, %lld neighbour entries\n",
-           (long long)totalPairs, (long long)totalJoin, rounds, (long long)totalNbr);
+           (long long)totalPairs, (long long)totalExact, rounds, (long long)totalNbr);
     fflush(stdout);
   }
   return 0;

@@ -71,7 +71,14 @@ int main(int argc, char** argv) {
   static Prep pa, pb;
   long mism_old = 0, mism_ref = 0, flagged_cap = 0, flagged_other = 0, with_joins = 0, nonzero = 0, join_mism = 0, fail_mism = 0;
   long max_ael = 0; long capbits[8] = {0};
+  FILE* fin = getenv("BEAM_PAIRS_FILE") ? fopen(getenv("BEAM_PAIRS_FILE"), "r") : nullptr;   // rows: xa[R] ya[R] xb[R] yb[R]
   for (long p = 0; p < n_pairs; p++) {
+    if (fin) {
+      xa.resize(n_rays); ya.resize(n_rays); xb.resize(n_rays); yb.resize(n_rays);
+      bool ok = true;
+      for (auto* v : {&xa, &ya, &xb, &yb}) for (int k = 0; k < n_rays; k++) { long t; if (fscanf(fin, "%ld", &t) != 1) ok = false; (*v)[k] = t; }
+      if (!ok) { n_pairs = p; break; }
+    } else {
     float cy = offset + 50 + (int)(U01(rng) * 20), cx = offset + 50 + (int)(U01(rng) * 20);
     float sep = U01(rng) * 2.2f * radius;
     float ang = U01(rng) * 6.2831853f;
@@ -79,6 +86,7 @@ int main(int argc, char** argv) {
     float r2 = radius * (0.5f + U01(rng));
     make_poly(rng, n_rays, radius, noise, cy, cx, xa, ya);
     make_poly(rng, n_rays, r2, noise, cy2, cx2, xb, yb);
+    }
     const float ref = clipper_ref_area(xa.data(), ya.data(), n_rays, xb.data(), yb.data(), n_rays);
     sw.reset_state();
     sw.add_path(xa.data(), ya.data(), n_rays, sdclip::kClip, 0);
@@ -127,6 +135,11 @@ int main(int argc, char** argv) {
   printf("pairs=%ld nonzero=%ld with_joins=%ld mism_vs_sweep=%ld join_flag_mism=%ld fail_mism=%ld mism_vs_clipper=%ld capacity_flagged=%ld other_flagged=%ld\n",
          n_pairs, nonzero, with_joins, mism_old, join_mism, fail_mism, mism_ref, flagged_cap, flagged_other);
   printf("  capacity flags: IL=%ld REC=%ld AEL=%ld LM=%ld GJ=%ld\n", capbits[0], capbits[1], capbits[5], capbits[6], capbits[7]);
+#ifdef BEAM_COUNT
+  { const BeamCounters& c = beam_counters(); const double n = (double)n_pairs;
+    printf("  per pair: scanbeams %.1f  mean AEL %.2f  top_x %.1f  beams-with-intersections %.2f  intersections %.2f  intersect_edges %.2f  out pts %.1f  edge updates %.1f  maxima %.2f  lm %.2f  horizontals %.2f  static edge loads %.1f\n",
+           c.beams / n, (double)c.ael_sum / c.beams, c.topx / n, c.il_beams / n, c.isect_pt / n, c.isect_edges / n, c.outpt / n, c.update / n, c.maxima / n, c.lm / n, c.horz / n, c.es_loads / n); }
+#endif
   (void)max_ael;
   return (mism_old || join_mism || fail_mism || mism_ref || flagged_other) ? 1 : 0;
 }

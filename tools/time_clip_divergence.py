@@ -30,7 +30,8 @@ def run(tag, arrs):
         torch.cuda.synchronize(); t0 = time.time()
         N.check(N.lib().sd_clip_pairs_device(N.tptr(t[0]), N.tptr(t[1]), N.tptr(t[2]), N.tptr(t[3]), n, R, N.tptr(out), N.tptr(fl), N.current_stream()))
         torch.cuda.synchronize(); dt = time.time() - t0
-    print(f"{tag}: {dt*1e3:.2f} ms for {n} pairs = {dt/n*1e9:.1f} ns/pair, joins flagged {int((fl.cpu().numpy() & 256 != 0).sum())}", flush=True)
+    f = fl.cpu().numpy()
+    print(f"{tag}: {dt*1e3:.2f} ms for {n} pairs = {dt/n*1e9:.1f} ns/pair, general path {int((f & 256 != 0).sum())}, capacity flags {int(((f & 512 != 0) & (f & (1|2|32|64|128) != 0)).sum())}", flush=True)
 
 
 run("different pairs per lane", (xa, ya, xb, yb))
