@@ -75,16 +75,20 @@ struct PolyPrep {
 };
 
 // Working storage + routine of the preparation.  P = storage policy (PlainStorage / LdsStorage<S>).
+#ifndef BEAM_PREP_IDX
+#define BEAM_PREP_IDX short
+#endif
 template <class P, int MAXV>
 struct PrepWork {
-  static constexpr unsigned RI = P::template region<int, MAXV>(), RS = P::template region<short, MAXV>(),
+  typedef BEAM_PREP_IDX ridx;
+  static constexpr unsigned RI = P::template region<int, MAXV>(), RS = P::template region<ridx, MAXV>(),
                             RB = P::template region<unsigned char, MAXV>();
   static constexpr unsigned O_CX = 0, O_CY = O_CX + RI, O_NXT = O_CY + RI, O_PRV = O_NXT + RS, O_CODE = O_PRV + RS,
                             O_N = O_CODE + RB, O_LMY = O_N + P::template region<int, 1>(), O_LML = O_LMY + P::template region<int, BEAM_MAXLM>(),
                             O_LMR = O_LML + P::template region<short, BEAM_MAXLM>(), O_END = O_LMR + P::template region<short, BEAM_MAXLM>();
   static constexpr unsigned lds_bytes() { return O_END; }
   typename P::template Arr<int, MAXV, O_CX> cx; typename P::template Arr<int, MAXV, O_CY> cy;
-  typename P::template Arr<short, MAXV, O_NXT> nxt; typename P::template Arr<short, MAXV, O_PRV> prv;
+  typename P::template Arr<ridx, MAXV, O_NXT> nxt; typename P::template Arr<ridx, MAXV, O_PRV> prv;
   typename P::template Arr<unsigned char, MAXV, O_CODE> code;
   typename P::template Scalar<int, O_N> n;
   typename P::template Arr<int, BEAM_MAXLM, O_LMY> lmy;
@@ -107,20 +111,30 @@ struct PrepWork {
   SD_HD void reverse_horizontal(int e) { code[e] = (unsigned char)(code[e] ^ 4); }
   SD_HD void set_lml(int e, int c) { code[e] = (unsigned char)((code[e] & ~3) | c); }
 
-  SD_HD int find_next_loc_min(int E) const {                                  // :911-925
-    for (;;) {
+#ifndef BEAM_PREP_FN
+#define BEAM_PREP_FN SD_HD
+#endif
+  BEAM_PREP_FN int find_next_loc_min(int E) const {                                  // :911-925
+    // (the reference's for(;;) / continue / break nest, written with one exit flag)
+    bool done = false;
+    int guard = 0;
+    while (!done) {
       while (botx(E) != botx(pv(E)) || boty(E) != boty(pv(E)) || (cx[E] == topx(E) && cy[E] == topy(E))) E = nx(E);
-      if (!is_horz(E) && !is_horz(pv(E))) break;
-      while (is_horz(pv(E))) E = pv(E);
-      int E2 = E;
-      while (is_horz(E)) E = nx(E);
-      if (topy(E) == boty(pv(E))) continue;   // just an intermediate horizontal
-      if (botx(pv(E2)) < botx(E)) E = E2;
-      break;
+      if (!is_horz(E) && !is_horz(pv(E))) done = true;
+      else {
+        while (is_horz(pv(E))) E = pv(E);
+        const int E2 = E;
+        while (is_horz(E)) E = nx(E);
+        if (topy(E) != boty(pv(E))) {            // otherwise: just an intermediate horizontal, keep looking
+          if (botx(pv(E2)) < botx(E)) E = E2;
+          done = true;
+        }
+      }
+      if (++guard > 4 * MAXV) done = true;
     }
     return E;
   }
-  SD_HD int process_bound(int E, bool fwd) {                                  // :928-1042 (no skip edges)
+  BEAM_PREP_FN int process_bound(int E, bool fwd) {                                  // :928-1042 (no skip edges)
     int Result = E, Horz;
     if (is_horz(E)) {
       int EStart = fwd ? pv(E) : nx(E);
@@ -171,15 +185,15 @@ struct PrepWork {
     if (highI < 2) return;
     for (int i = 0; i <= highI; ++i) {
       cx[i] = (int)xs[i]; cy[i] = (int)ys[i];
-      nxt[i] = (short)(i == highI ? 0 : i + 1);
-      prv[i] = (short)(i == 0 ? highI : i - 1);
+      nxt[i] = (ridx)(i == highI ? 0 : i + 1);
+      prv[i] = (ridx)(i == 0 ? highI : i - 1);
     }
     int eStart = 0, E = 0, eLoopStop = 0;
     for (;;) {   // remove duplicate vertices and collinear edges (:1098-1122)
       if (cx[E] == cx[nxt[E]] && cy[E] == cy[nxt[E]]) {
         if (E == nxt[E]) break;
         if (E == eStart) eStart = nxt[E];
-        const int en = nxt[E]; nxt[prv[E]] = (short)en; prv[en] = prv[E]; E = en;
+        const int en = nxt[E]; nxt[prv[E]] = (ridx)en; prv[en] = prv[E]; E = en;
         eLoopStop = E;
         continue;
       }
@@ -187,7 +201,7 @@ struct PrepWork {
       const int ep0 = prv[E], en0 = nxt[E];
       if (((i64)cy[ep0] - cy[E]) * ((i64)cx[E] - cx[en0]) == ((i64)cx[ep0] - cx[E]) * ((i64)cy[E] - cy[en0])) {   // SlopesEqual :554-563
         if (E == eStart) eStart = nxt[E];
-        nxt[ep0] = (short)en0; prv[en0] = (short)ep0;
+        nxt[ep0] = (ridx)en0; prv[en0] = (ridx)ep0;
         E = ep0;
         eLoopStop = E;
         continue;
