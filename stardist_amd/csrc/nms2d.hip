@@ -338,16 +338,20 @@ __global__ void __launch_bounds__(S) k_prepare(const int* __restrict__ vx, const
 // Persistent grid: the pair count is read on the device (no host round trip between emit and this kernel).
 //   result 'capacity exceeded'  -> spill queue (next tier with larger K / list capacities, finally the general path)
 //   joins recorded / float-order risk / any other flag -> exact queue (clip_sweep_full.h restates JoinCommonEdges)
-struct PairQueues { int2* spill; unsigned int* spillCount; int2* exact; unsigned int* exactCount; unsigned int cap; };
+// queues hold PAIR INDICES (into the round's pair list), so a result can be written per pair (tail batch) as well as applied
+struct PairQueues { unsigned int* spill; unsigned int* spillCount; unsigned int* exact; unsigned int* exactCount; unsigned int cap; };
 enum { BEAM_CAPFLAGS = sdclip::ST_OVERFLOW_IL | sdclip::ST_OVERFLOW_REC | sdclip::ST_OVERFLOW_AEL | sdclip::ST_OVERFLOW_LM | sdclip::ST_OVERFLOW_GJ };
+// idx == nullptr: pairs[0 .. *nPtr);  else pairs[idx[0 .. *nPtr)].   supp == nullptr: a suppressing pair marks state[j]
+// (greedy round, i is a survivor); else supp[pair index] = 1 (tail batch: i is still undecided, the result is kept per edge).
 template <int MAXV, int K, int MAXIL, int MAXREC, int S, typename CNT>
-__global__ void __launch_bounds__(S) k_pairs_beam(const int2* __restrict__ pairs, const CNT* __restrict__ nPairsPtr,
+__global__ void __launch_bounds__(S) k_pairs_beam(const int2* __restrict__ pairs, const unsigned int* __restrict__ idx, const CNT* __restrict__ nPtr,
                                                   const sdclip::PolyPrep<MAXV>* __restrict__ prep,
                                                   const float* __restrict__ area, float thr, unsigned char* __restrict__ state,
-                                                  PairQueues q) {
+                                                  unsigned char* __restrict__ supp, PairQueues q) {
   typedef sdclip::Beam<MAXV, K, MAXIL, MAXREC, sdclip::LdsStorage<S>> BeamT;
-  const unsigned long long nPairs = (unsigned long long)*nPairsPtr;
-  for (unsigned long long p = (unsigned long long)blockIdx.x * S + threadIdx.x; p < nPairs; p += (unsigned long long)gridDim.x * S) {
+  const unsigned long long n = (unsigned long long)*nPtr;
+  for (unsigned long long t = (unsigned long long)blockIdx.x * S + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * S) {
+    const unsigned int p = idx ? idx[t] : (unsigned int)t;
     const int2 ij = pairs[p];
     BeamT bm;
     bm.reset_state(prep + ij.x, prep + ij.y);                                  // clip = i (:157), subject = j (:158)
@@ -355,21 +359,120 @@ __global__ void __launch_bounds__(S) k_pairs_beam(const int2* __restrict__ pairs
     const int st = bm.status;
     if (st & BEAM_CAPFLAGS) {
       const unsigned int k = atomicAdd(q.spillCount, 1u);
-      if (k < q.cap) q.spill[k] = ij;
+      if (k < q.cap) q.spill[k] = p;
       continue;
     }
     if ((st & ~sdclip::ST_FAIL) || bm.n_joins > 0 || bm.sum_abs_terms >= (1ll << 24)) {
       const unsigned int k = atomicAdd(q.exactCount, 1u);
-      if (k < q.cap) q.exact[k] = ij;
+      if (k < q.cap) q.exact[k] = p;
       continue;
     }
     const float area_inter = 0.5f * (float)twice;
     const float overlap = (float)((double)area_inter / fmin((double)area[ij.x] + 1.e-10, (double)area[ij.y] + 1.e-10));  // :580
-    if (overlap > thr) state[ij.y] = ST_SUPPRESSED;                                           // :581-585
+    if (overlap > thr) { if (supp) supp[p] = 1; else state[ij.y] = ST_SUPPRESSED; }                // :581-585
   }
 }
 template <int MAXV, int K, int MAXIL, int MAXREC, int S>
 size_t beam_lds_bytes() { return (size_t)sdclip::Beam<MAXV, K, MAXIL, MAXREC, sdclip::LdsStorage<S>>::lds_bytes() + 64; }
+
+// ---- tail batch.  Late greedy rounds hold few pairs but each costs one sweep's serial latency; once few candidates are
+// undecided, ALL pairs (i < j, both undecided) the reference could still evaluate are emitted at once, their overlap decisions
+// are computed speculatively (supp[edge]), and one workgroup then replays the remaining greedy rounds on the device:
+// j is suppressed iff some KEPT i < j has supp(i, j); it is kept once every such i is decided and none suppresses it.
+__global__ void __launch_bounds__(256) k_tail_emit(const int* __restrict__ U, int nU, const unsigned char* __restrict__ state,
+                                                   const i64* __restrict__ nbrStart, const int* __restrict__ nbr, Flags f,
+                                                   const float* __restrict__ pts, const int4* __restrict__ bbox,
+                                                   const float* __restrict__ radius, const float* __restrict__ area,
+                                                   int2* __restrict__ pairs, unsigned long long* pairCount, unsigned long long pairCap,
+                                                   unsigned int* __restrict__ segStart, int* __restrict__ segCnt) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int w = blockIdx.x * (blockDim.x >> 6) + wave; w < nU; w += gridDim.x * (blockDim.x >> 6)) {
+    const int j = U[w];
+    int cnt = 0;
+    unsigned long long base = 0;
+    if (state[j] == ST_UNDECIDED) {
+      const i64 beg = nbrStart[j], end = nbrStart[j + 1];
+      const int4 bj = bbox[j];
+      const float pyj = pts[2 * j], pxj = pts[2 * j + 1];
+      const float aj = area[j];
+      for (int pass = 0; pass < 2; ++pass) {
+        int k = 0;
+        for (i64 t = beg; t < end; t += 64) {
+          const i64 id = t + lane;
+          bool emit = false;
+          int i = -1;
+          if (id < end) {
+            i = nbr[id];
+            if (i < j && state[i] == ST_UNDECIDED) {          // i may become a survivor before j is decided (:572 seen from i)
+              bool ok = true;
+              if (f.use_kdtree) {                             // nanoflann radius search around i (:546-550)
+                const float rad = f.max_dist + radius[i];
+                const float d0 = pts[2 * i] - pyj, d1 = pts[2 * i + 1] - pxj;
+                float d2 = d0 * d0; d2 += d1 * d1;
+                ok = d2 < rad * rad;
+              }
+              if (ok && (f.use_bbox || f.thr_nonneg)) {
+                const int4 bi = bbox[i];
+                ok = bbox_intersect(bi, bj);                                             // :576
+                if (ok && f.thr_nonneg) {                     // same rigorous bbox-area bound as k_round_emit
+                  const double w2 = (double)(min(bi.y, bj.y) - max(bi.x, bj.x)), hgt = (double)(min(bi.w, bj.w) - max(bi.z, bj.z));
+                  const float ub = (float)((w2 * hgt) / fmin((double)area[i] + 1.e-10, (double)aj + 1.e-10));
+                  if (!(ub > f.thr)) ok = false;
+                }
+              }
+              emit = ok;
+            }
+          }
+          const unsigned long long m = __ballot(emit);
+          if (pass == 1 && emit) {
+            const unsigned long long pos = base + k + __popcll(m & ((1ull << lane) - 1));
+            if (pos < pairCap) pairs[pos] = make_int2(i, j);
+          }
+          k += __popcll(m);
+        }
+        if (pass == 0) {
+          cnt = k;
+          if (cnt == 0) break;
+          if (lane == 0) base = atomicAdd(pairCount, (unsigned long long)cnt);
+          base = __shfl(base, 0);
+        }
+      }
+    }
+    if (lane == 0) { segStart[w] = (unsigned int)base; segCnt[w] = cnt; }
+  }
+}
+// one workgroup; 'left' receives the number of candidates still undecided (0 unless something is inconsistent)
+__global__ void __launch_bounds__(1024) k_tail_resolve(const int* __restrict__ U, int nU, volatile unsigned char* state,
+                                                       const int2* __restrict__ pairs, const unsigned char* __restrict__ supp,
+                                                       const unsigned int* __restrict__ segStart, const int* __restrict__ segCnt,
+                                                       unsigned long long pairCap, int* left) {
+  __shared__ int changed, undecided;
+  for (int iter = 0; iter <= nU; ++iter) {
+    if (threadIdx.x == 0) { changed = 0; undecided = 0; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nU; t += blockDim.x) {
+      const int j = U[t];
+      if (state[j] != ST_UNDECIDED) continue;
+      bool wait = false, sup = false;
+      const unsigned int e0 = segStart[t];
+      const int c = segCnt[t];
+      for (int e = 0; e < c && !sup; ++e) {
+        if ((unsigned long long)e0 + e >= pairCap) { wait = true; break; }
+        const unsigned char si = state[pairs[e0 + e].x];
+        if (si == ST_UNDECIDED) wait = true;
+        else if (si == ST_KEPT && supp[e0 + e]) sup = true;
+      }
+      if (sup) { state[j] = ST_SUPPRESSED; changed = 1; }
+      else if (!wait) { state[j] = ST_KEPT; changed = 1; }
+      else undecided = 1;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int ch = changed, un = undecided;
+    __syncthreads();
+    if (!un || !ch) { if (threadIdx.x == 0) *left = un; break; }
+  }
+}
 
 __global__ void k_iota(int* a, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = i; }
 __global__ void k_keep(const unsigned char* __restrict__ state, unsigned char* __restrict__ keep, int n) {
@@ -382,12 +485,12 @@ __global__ void k_keep(const unsigned char* __restrict__ state, unsigned char* _
 namespace sd {
 // general path (nms2d_full.hip): pairs whose result depends on Clipper's JoinCommonEdges, or that exceed the
 // capacities of the bound-slot kernels; device-side queue, result applied directly.
-int clip_full_pairs(const int2* d_pairs, const unsigned int* d_n, unsigned int cap, int R, const int* d_vx, const int* d_vy,
-                    const float* d_area, float thr, unsigned char* d_state, unsigned int* d_errCount, hipStream_t stream);
+int clip_full_pairs(const int2* d_pairs, const unsigned int* d_idx, const unsigned int* d_n, unsigned int cap, int R, const int* d_vx, const int* d_vy,
+                    const float* d_area, float thr, unsigned char* d_state, unsigned char* d_supp, unsigned int* d_errCount, hipStream_t stream);
 }
 
 namespace {
-struct Counters { int nU, nK, nS, pad; unsigned long long nPairs; unsigned int nSpill, nExact, nErr, pad2; };
+struct Counters { int nU, nK, nS, left; unsigned long long nPairs; unsigned int nSpill, nExact, nErr, pad2; };
 
 // prepared polygons + the two tiers of the bound-slot pair kernel for one vertex capacity
 template <int MAXV, int SPREP>
@@ -401,18 +504,18 @@ struct BeamPath {
   }
   // tier 1 (K = 8): all pairs of the round; capacity spills -> q.spill
   static int tier1(const int2* pairs, const unsigned long long* nPairs, const void* prep, const float* area, float thr,
-                   unsigned char* state, PairQueues q, hipStream_t s) {
+                   unsigned char* state, unsigned char* supp, PairQueues q, hipStream_t s) {
     static const size_t lds = beam_lds_bytes<MAXV, 8, 6, 4, 64>();
-    hipLaunchKernelGGL((k_pairs_beam<MAXV, 8, 6, 4, 64, unsigned long long>), dim3(256 * 4), dim3(64), lds, s, pairs, nPairs, (const Prep*)prep, area, thr, state, q);
+    hipLaunchKernelGGL((k_pairs_beam<MAXV, 8, 6, 4, 64, unsigned long long>), dim3(256 * 4), dim3(64), lds, s, pairs, (const unsigned int*)nullptr, nPairs, (const Prep*)prep, area, thr, state, supp, q);
     SD_LAUNCH_CHECK();
     return 0;
   }
   // tier 2 (K = 15, larger lists): the spills of tier 1 (or, for n_rays > 32, all pairs); its spills -> general path
   template <typename CNT>
-  static int tier2(const int2* pairs, const CNT* nPairs, const void* prep, const float* area, float thr,
-                   unsigned char* state, PairQueues q, hipStream_t s) {
+  static int tier2(const int2* pairs, const unsigned int* idx, const CNT* nPairs, const void* prep, const float* area, float thr,
+                   unsigned char* state, unsigned char* supp, PairQueues q, hipStream_t s) {
     static const size_t lds = beam_lds_bytes<MAXV, 15, 16, 8, 32>();
-    hipLaunchKernelGGL((k_pairs_beam<MAXV, 15, 16, 8, 32, CNT>), dim3(256 * 3), dim3(32), lds, s, pairs, nPairs, (const Prep*)prep, area, thr, state, q);
+    hipLaunchKernelGGL((k_pairs_beam<MAXV, 15, 16, 8, 32, CNT>), dim3(256 * 3), dim3(32), lds, s, pairs, idx, nPairs, (const Prep*)prep, area, thr, state, supp, q);
     SD_LAUNCH_CHECK();
     return 0;
   }
@@ -556,8 +659,8 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   int* K = A.take_n<int>(N);
   int2* pairs = A.take_n<int2>(pairCap);
   const unsigned int qCap = (unsigned int)(pairCap < (1ull << 30) ? pairCap : (1ull << 30));
-  int2* spillPairs = A.take_n<int2>(qCap);
-  int2* exactPairs = A.take_n<int2>(qCap);
+  unsigned int* spillPairs = A.take_n<unsigned int>(qCap);
+  unsigned int* exactPairs = A.take_n<unsigned int>(qCap);
   int* Sl = A.take_n<int>(N);
   Counters* d_cnt = (Counters*)A.take(sizeof(Counters));
   if (!U0 || !U1 || !K || !pairs || !spillPairs || !exactPairs || !Sl || !d_cnt) return -1;
@@ -569,36 +672,34 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   hipEvent_t ev2 = nullptr, ev3 = nullptr;
   if (stats) { SD_CHECK(hipEventCreate(&ev2)); SD_CHECK(hipEventCreate(&ev3)); }
   EvGuard evguard2{ev2, ev3};
-  while (nU > 0) {
-    ++rounds;
-    SD_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), s));
-    hipLaunchKernelGGL(k_round_triage, dim3(sd::div_up(nU, 256)), dim3(256), 0, s, Ucur, nU, state, waitOn, Unext, K, Sl, (int*)d_cnt);
-    const int wgrid = sd::div_up(nU, 4) < 2048 ? sd::div_up(nU, 4) : 2048;
-    hipLaunchKernelGGL(k_round_scan, dim3(wgrid), dim3(256), 0, s, Sl, state, nbrStart, nbr, waitOn, Unext, K, (int*)d_cnt);
-    hipLaunchKernelGGL(k_round_emit, dim3(wgrid), dim3(256), 0, s, K, &d_cnt->nK, state, nbrStart, nbr, f, d_points, bbox,
-                       radius, area, pairs, &d_cnt->nPairs, pairCap);
-    SD_LAUNCH_CHECK();
+  // tail batch threshold: undecided candidates at or below which the remaining rounds are replayed on the device
+  static const int tailDiv = getenv("SD_NMS_TAIL_DIV") ? atoi(getenv("SD_NMS_TAIL_DIV")) : 6;
+  static const int tailMax = getenv("SD_NMS_TAIL_MAX") ? atoi(getenv("SD_NMS_TAIL_MAX")) : 65536;
+  const int tailT = tailDiv > 0 ? ((N / tailDiv) < tailMax ? (N / tailDiv) : tailMax) : -1;
+  unsigned char* supp = nullptr; unsigned int* segStart = nullptr; int* segCnt = nullptr;
+  // one beam-path pass over the current pair list (tier 1, tier 2, general path); suppOut == nullptr applies to state
+  auto run_pairs = [&](unsigned char* suppOut) -> int {
     if (stats) SD_CHECK(hipEventRecord(ev0, s));
     PairQueues q1{spillPairs, &d_cnt->nSpill, exactPairs, &d_cnt->nExact, qCap};
     PairQueues q2{exactPairs, &d_cnt->nExact, exactPairs, &d_cnt->nExact, qCap};   // what tier 2 cannot hold goes to the general path
     int rc;
     if (R <= 32) {
-      rc = BeamPath<32, 64>::tier1(pairs, &d_cnt->nPairs, prep, area, threshold, state, q1, s);
+      rc = BeamPath<32, 64>::tier1(pairs, &d_cnt->nPairs, prep, area, threshold, state, suppOut, q1, s);
       if (stats) SD_CHECK(hipEventRecord(ev1, s));
-      if (!rc) rc = BeamPath<32, 64>::tier2(spillPairs, &d_cnt->nSpill, prep, area, threshold, state, q2, s);
+      if (!rc) rc = BeamPath<32, 64>::tier2(pairs, spillPairs, &d_cnt->nSpill, prep, area, threshold, state, suppOut, q2, s);
     } else {
-      if (R <= 64) rc = BeamPath<64, 64>::tier2(pairs, &d_cnt->nPairs, prep, area, threshold, state, q2, s);
-      else if (R <= 128) rc = BeamPath<128, 32>::tier2(pairs, &d_cnt->nPairs, prep, area, threshold, state, q2, s);
-      else rc = BeamPath<256, 16>::tier2(pairs, &d_cnt->nPairs, prep, area, threshold, state, q2, s);
+      if (R <= 64) rc = BeamPath<64, 64>::tier2(pairs, (const unsigned int*)nullptr, &d_cnt->nPairs, prep, area, threshold, state, suppOut, q2, s);
+      else if (R <= 128) rc = BeamPath<128, 32>::tier2(pairs, (const unsigned int*)nullptr, &d_cnt->nPairs, prep, area, threshold, state, suppOut, q2, s);
+      else rc = BeamPath<256, 16>::tier2(pairs, (const unsigned int*)nullptr, &d_cnt->nPairs, prep, area, threshold, state, suppOut, q2, s);
       if (stats) SD_CHECK(hipEventRecord(ev1, s));
     }
     if (rc) return -1;
     if (stats) SD_CHECK(hipEventRecord(ev2, s));
-    if (sd::clip_full_pairs(exactPairs, &d_cnt->nExact, qCap, R, vx, vy, area, threshold, state, &d_cnt->nErr, s)) return -1;
+    if (sd::clip_full_pairs(pairs, exactPairs, &d_cnt->nExact, qCap, R, vx, vy, area, threshold, state, suppOut, &d_cnt->nErr, s)) return -1;
     if (stats) SD_CHECK(hipEventRecord(ev3, s));
-    SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
-    SD_CHECK(hipStreamSynchronize(s));
-    if (h.nK == 0 && h.nU > 0) { sd::set_error("sd_nms2d: greedy scan made no progress (internal error)"); return -1; }
+    return 0;
+  };
+  auto account = [&](const char* what) -> int {
     if (h.nPairs > pairCap || h.nSpill > qCap || h.nExact > qCap) { sd::set_error("sd_nms2d: pair queue overflow (internal error)"); return -1; }
     if (h.nErr) { sd::set_error("sd_nms2d: %u pairs exceeded the general path's fixed capacities", h.nErr); return -1; }
     totalPairs += (i64)h.nPairs; totalExact += h.nExact; totalSpill += h.nSpill;
@@ -607,8 +708,45 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
       SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); SD_CHECK(hipEventElapsedTime(&ms2, ev2, ev3));
       if (h.nPairs) { ns_pairs += ms * 1e6; ++n_pair_launches; }
       ns_full += ms2 * 1e6;
-      if (getenv("SD_TRACE")) printf("round %d: nU=%d nK=%d pairs=%llu spill=%u exact=%u pair_kernel=%.3f ms exact_path=%.3f ms\n", rounds, h.nU, h.nK, h.nPairs, h.nSpill, h.nExact, ms, ms2);
+      if (getenv("SD_TRACE")) printf("%s %d: nU=%d nK=%d pairs=%llu spill=%u exact=%u pair_kernel=%.3f ms general_path=%.3f ms\n", what, rounds, h.nU, h.nK, h.nPairs, h.nSpill, h.nExact, ms, ms2);
     }
+    return 0;
+  };
+  while (nU > 0) {
+    ++rounds;
+    if (nU <= tailT && rounds > 1) {
+      // ---- tail batch: every remaining (undecided, undecided) pair at once, then the greedy rounds replayed on the device
+      if (!supp) { supp = A.take_n<unsigned char>(pairCap); segStart = A.take_n<unsigned int>(N); segCnt = A.take_n<int>(N); }
+      if (!supp || !segStart || !segCnt) return -1;
+      SD_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), s));
+      SD_CHECK(hipMemsetAsync(supp, 0, pairCap, s));
+      const int wg = sd::div_up(nU, 4) < 2048 ? sd::div_up(nU, 4) : 2048;
+      hipLaunchKernelGGL(k_tail_emit, dim3(wg), dim3(256), 0, s, Ucur, nU, state, nbrStart, nbr, f, d_points, bbox, radius, area, pairs,
+                         &d_cnt->nPairs, pairCap, segStart, segCnt);
+      SD_LAUNCH_CHECK();
+      if (run_pairs(supp)) return -1;
+      hipLaunchKernelGGL(k_tail_resolve, dim3(1), dim3(1024), 0, s, Ucur, nU, state, pairs, supp, segStart, segCnt, pairCap, &d_cnt->left);
+      SD_LAUNCH_CHECK();
+      SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+      SD_CHECK(hipStreamSynchronize(s));
+      h.nU = nU; h.nK = 0;
+      if (account("tail batch after round")) return -1;
+      if (h.left) { sd::set_error("sd_nms2d: tail batch left candidates undecided (internal error)"); return -1; }
+      nU = 0;
+      break;
+    }
+    SD_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), s));
+    hipLaunchKernelGGL(k_round_triage, dim3(sd::div_up(nU, 256)), dim3(256), 0, s, Ucur, nU, state, waitOn, Unext, K, Sl, (int*)d_cnt);
+    const int wgrid = sd::div_up(nU, 4) < 2048 ? sd::div_up(nU, 4) : 2048;
+    hipLaunchKernelGGL(k_round_scan, dim3(wgrid), dim3(256), 0, s, Sl, state, nbrStart, nbr, waitOn, Unext, K, (int*)d_cnt);
+    hipLaunchKernelGGL(k_round_emit, dim3(wgrid), dim3(256), 0, s, K, &d_cnt->nK, state, nbrStart, nbr, f, d_points, bbox,
+                       radius, area, pairs, &d_cnt->nPairs, pairCap);
+    SD_LAUNCH_CHECK();
+    if (run_pairs(nullptr)) return -1;
+    SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    SD_CHECK(hipStreamSynchronize(s));
+    if (h.nK == 0 && h.nU > 0) { sd::set_error("sd_nms2d: greedy scan made no progress (internal error)"); return -1; }
+    if (account("round")) return -1;
     nU = h.nU;
     int* t = Ucur; Ucur = Unext; Unext = t;
   }

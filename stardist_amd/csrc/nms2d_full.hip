@@ -17,12 +17,13 @@ using sdclip::i64;
 // (stardist2d.cpp:579-585): no intermediate area array, no host round trip.
 enum { ST_SUPPRESSED_ = 2 };
 template <int MAXV, int MAXIL, int MAXREC, int MAXPT, int MAXJ>
-__global__ void __launch_bounds__(64) k_full_pairs(const int2* __restrict__ pairs, const unsigned int* __restrict__ nPtr, unsigned int cap, int R,
+__global__ void __launch_bounds__(64) k_full_pairs(const int2* __restrict__ pairs, const unsigned int* __restrict__ idx, const unsigned int* __restrict__ nPtr, unsigned int cap, int R,
                                                    const int* __restrict__ vx, const int* __restrict__ vy,
-                                                   const float* __restrict__ area, float thr, unsigned char* __restrict__ state,
+                                                   const float* __restrict__ area, float thr, unsigned char* __restrict__ state, unsigned char* __restrict__ supp,
                                                    unsigned int* errCount) {
   unsigned int n = *nPtr; if (n > cap) n = cap;
-  for (unsigned int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+  for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const unsigned int p = idx ? idx[t] : t;
     const int2 ij = pairs[p];
     sdclip::SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ> sw;
     sw.reset_state();
@@ -32,20 +33,21 @@ __global__ void __launch_bounds__(64) k_full_pairs(const int2* __restrict__ pair
     if (sw.status & ~sdclip::ST_FAIL) atomicAdd(errCount, 1u);
     const float area_inter = 0.5f * (float)twice;
     const float overlap = (float)((double)area_inter / fmin((double)area[ij.x] + 1.e-10, (double)area[ij.y] + 1.e-10));
-    if (overlap > thr) state[ij.y] = ST_SUPPRESSED_;
+    if (overlap > thr) { if (supp) supp[p] = 1; else state[ij.y] = ST_SUPPRESSED_; }
   }
 }
 
 // latency variant of the general kernel: the sweep's core arrays in LDS, the point rings stay private
 enum { LDSF_T = 32 };
 template <int MAXV, int MAXIL, int MAXREC, int MAXPT, int MAXJ>
-__global__ void __launch_bounds__(LDSF_T) k_full_pairs_lds(const int2* __restrict__ pairs, const unsigned int* __restrict__ nPtr, unsigned int cap, int R,
+__global__ void __launch_bounds__(LDSF_T) k_full_pairs_lds(const int2* __restrict__ pairs, const unsigned int* __restrict__ idx, const unsigned int* __restrict__ nPtr, unsigned int cap, int R,
                                                            const int* __restrict__ vx, const int* __restrict__ vy,
-                                                           const float* __restrict__ area, float thr, unsigned char* __restrict__ state,
+                                                           const float* __restrict__ area, float thr, unsigned char* __restrict__ state, unsigned char* __restrict__ supp,
                                                            unsigned int* errCount) {
   typedef sdclip::LdsStorage<LDSF_T> LP;
   unsigned int n = *nPtr; if (n > cap) n = cap;
-  for (unsigned int p = blockIdx.x * LDSF_T + threadIdx.x; p < n; p += gridDim.x * LDSF_T) {
+  for (unsigned int t = blockIdx.x * LDSF_T + threadIdx.x; t < n; t += gridDim.x * LDSF_T) {
+    const unsigned int p = idx ? idx[t] : t;
     const int2 ij = pairs[p];
     sdclip::SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ, LP> sw;
     sw.reset_state();
@@ -55,7 +57,7 @@ __global__ void __launch_bounds__(LDSF_T) k_full_pairs_lds(const int2* __restric
     if (sw.status & ~sdclip::ST_FAIL) atomicAdd(errCount, 1u);
     const float area_inter = 0.5f * (float)twice;
     const float overlap = (float)((double)area_inter / fmin((double)area[ij.x] + 1.e-10, (double)area[ij.y] + 1.e-10));
-    if (overlap > thr) state[ij.y] = ST_SUPPRESSED_;
+    if (overlap > thr) { if (supp) supp[p] = 1; else state[ij.y] = ST_SUPPRESSED_; }
   }
 }
 template <int MAXV, int MAXIL, int MAXREC, int MAXPT, int MAXJ>
@@ -138,9 +140,10 @@ int launch_prepare_probe(const int* x, const int* y, int n, int R, void* out, hi
 }  // namespace
 
 namespace sd {
-// general (exact-join) path over a device-side queue: evaluates pairs[0 .. min(*d_n, cap)) and applies the suppression
-int clip_full_pairs(const int2* d_pairs, const unsigned int* d_n, unsigned int cap, int R, const int* d_vx, const int* d_vy,
-                    const float* d_area, float thr, unsigned char* d_state, unsigned int* d_errCount, hipStream_t s) {
+// general (exact-join) path over a device-side queue of pair indices: evaluates pairs[idx[0 .. min(*d_n, cap))] and either
+// applies the suppression to state[j] or records it per pair in supp[] (tail batch)
+int clip_full_pairs(const int2* d_pairs, const unsigned int* d_idx, const unsigned int* d_n, unsigned int cap, int R, const int* d_vx, const int* d_vy,
+                    const float* d_area, float thr, unsigned char* d_state, unsigned char* d_supp, unsigned int* d_errCount, hipStream_t s) {
   if (R <= 32) {
     static const size_t ldsBytes = lds_full_bytes<32, 64, 32, 192, 64>();
     static bool attr_set = false;
@@ -148,10 +151,10 @@ int clip_full_pairs(const int2* d_pairs, const unsigned int* d_n, unsigned int c
       SD_CHECK(hipFuncSetAttribute((const void*)k_full_pairs_lds<32, 64, 32, 192, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
       attr_set = true;
     }
-    hipLaunchKernelGGL((k_full_pairs_lds<32, 64, 32, 192, 64>), dim3(1024), dim3(LDSF_T), ldsBytes, s, d_pairs, d_n, cap, R, d_vx, d_vy, d_area, thr, d_state, d_errCount);
-  } else if (R <= 64) hipLaunchKernelGGL((k_full_pairs<64, 96, 48, 384, 96>), dim3(2048), dim3(64), 0, s, d_pairs, d_n, cap, R, d_vx, d_vy, d_area, thr, d_state, d_errCount);
-  else if (R <= 128) hipLaunchKernelGGL((k_full_pairs<128, 128, 64, 768, 128>), dim3(2048), dim3(64), 0, s, d_pairs, d_n, cap, R, d_vx, d_vy, d_area, thr, d_state, d_errCount);
-  else hipLaunchKernelGGL((k_full_pairs<256, 192, 96, 1536, 192>), dim3(2048), dim3(64), 0, s, d_pairs, d_n, cap, R, d_vx, d_vy, d_area, thr, d_state, d_errCount);
+    hipLaunchKernelGGL((k_full_pairs_lds<32, 64, 32, 192, 64>), dim3(1024), dim3(LDSF_T), ldsBytes, s, d_pairs, d_idx, d_n, cap, R, d_vx, d_vy, d_area, thr, d_state, d_supp, d_errCount);
+  } else if (R <= 64) hipLaunchKernelGGL((k_full_pairs<64, 96, 48, 384, 96>), dim3(2048), dim3(64), 0, s, d_pairs, d_idx, d_n, cap, R, d_vx, d_vy, d_area, thr, d_state, d_supp, d_errCount);
+  else if (R <= 128) hipLaunchKernelGGL((k_full_pairs<128, 128, 64, 768, 128>), dim3(2048), dim3(64), 0, s, d_pairs, d_idx, d_n, cap, R, d_vx, d_vy, d_area, thr, d_state, d_supp, d_errCount);
+  else hipLaunchKernelGGL((k_full_pairs<256, 192, 96, 1536, 192>), dim3(2048), dim3(64), 0, s, d_pairs, d_idx, d_n, cap, R, d_vx, d_vy, d_area, thr, d_state, d_supp, d_errCount);
   SD_LAUNCH_CHECK();
   return 0;
 }
