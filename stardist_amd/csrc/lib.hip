@@ -14,8 +14,15 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-static Arena g_arena;
-Arena& arena() { return g_arena; }
+// one workspace arena per HIP device: a call carves its slices from the arena of the device that is current when it runs
+// (the Python wrappers make the tensors' device current, stardist_amd/lib/_native.py dcall)
+enum { kMaxDevices = 64 };
+static Arena g_arena[kMaxDevices];
+Arena& arena() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+  return g_arena[d];
+}
 
 size_t Arena::capacity() const { size_t t = 0; for (int i = 0; i < n_; ++i) t += cap_[i]; return t; }
 int Arena::begin(hipStream_t stream) {
@@ -62,5 +69,5 @@ int sd_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
-int sd_release_workspace(void) { sd::arena().release(); return 0; }
+int sd_release_workspace(void) { sd::arena().release(); return 0; }   /* the current device's arena */
 }

@@ -35,8 +35,9 @@ def dist_to_coord(dist, points, scale_dist=(1, 1)):
         coord = (dist[:, None].to(torch.float64) * sct).to(torch.float32)  # f32*f64 product -> f32, as numpy does
         sd = torch.as_tensor(np.asarray(scale_dist, np.float64).reshape(1, 2, 1), device=dist.device)
         coord = (coord.to(torch.float64) * sd).to(torch.float32) if tuple(scale_dist) != (1, 1) else coord
-        # in-place float32 += (points cast to float32), as numpy's `coord += points[...,None]`
-        coord = coord + points[..., None].to(torch.float32)
+        # numpy's in-place `coord += points[..., None]` adds in the common type of both operands and rounds ONCE to float32
+        # (points may be int64 / float64): add in float64, cast once
+        coord = (coord.to(torch.float64) + points[..., None].to(torch.float64)).to(torch.float32)
         return coord
     dist = np.asarray(dist); points = np.asarray(points)
     coord = (dist[:, np.newaxis] * sc).astype(np.float32)

@@ -109,6 +109,23 @@ def tptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def current_stream():
+def current_stream(device=None):
+    """torch's current stream ON THE GIVEN DEVICE (default: torch's current device)"""
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dcall(t, name, *args):
+    """Call the device entry point `name` for tensors living on t.device: that device is made current for the call (the
+    kernels and the per-device workspace arena follow the current HIP device) and ITS current torch stream is passed as the
+    trailing stream argument."""
+    import torch
+    with torch.cuda.device(t.device):
+        check(getattr(lib(), name)(*args, current_stream(t.device)))
+
+
+def on_device_of(t):
+    """context manager: make the tensor's device the current HIP device for the duration of a native call (the workspace
+    arena and the kernels of a call live on the current device)"""
+    import torch
+    return torch.cuda.device(t.device)

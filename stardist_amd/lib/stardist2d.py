@@ -19,8 +19,8 @@ def c_non_max_suppression_inds(dist, points, use_kdtree, use_bbox, verbose, thre
         dist = dist.contiguous(); points = points.contiguous()
         n, R = dist.shape
         keep = torch.empty(n, dtype=torch.uint8, device=dist.device)
-        N.check(N.lib().sd_nms2d_device(N.tptr(dist), N.tptr(points), n, R, int(use_kdtree), int(use_bbox),
-                                        int(verbose), float(threshold), N.tptr(keep), N.ptr(stats), N.current_stream()))
+        N.dcall(dist, "sd_nms2d_device", N.tptr(dist), N.tptr(points), n, R, int(use_kdtree), int(use_bbox),
+                                        int(verbose), float(threshold), N.tptr(keep), N.ptr(stats))
         keep = keep.bool()
     else:
         dist = np.ascontiguousarray(dist, np.float32)
@@ -46,7 +46,7 @@ def c_star_dist(src, n_rays, grid_y, grid_x):
         src = src.contiguous()
         H, W = src.shape
         dst = torch.empty(((H - 1) // grid_y + 1, (W - 1) // grid_x + 1, n_rays), dtype=torch.float32, device=src.device)
-        N.check(N.lib().sd_star_dist2d_device(N.tptr(src), H, W, n_rays, grid_y, grid_x, N.tptr(dst), N.current_stream()))
+        N.dcall(src, "sd_star_dist2d_device", N.tptr(src), H, W, n_rays, grid_y, grid_x, N.tptr(dst))
         return dst
     src = np.ascontiguousarray(src)
     if src.dtype != np.uint16:
@@ -70,7 +70,7 @@ def c_polygons_to_label(coord, labels, shape):
         labels = labels.contiguous().to(torch.int32)
         n, _, R = coord.shape
         out = torch.empty((H, W), dtype=torch.int32, device=coord.device)
-        N.check(N.lib().sd_polygons_to_label_device(N.tptr(coord), N.tptr(labels), n, R, H, W, N.tptr(out), N.current_stream()))
+        N.dcall(coord, "sd_polygons_to_label_device", N.tptr(coord), N.tptr(labels), n, R, H, W, N.tptr(out))
         return out
     coord = np.ascontiguousarray(coord, np.float32)
     labels = np.ascontiguousarray(labels, np.int32)
@@ -92,7 +92,7 @@ def clip_pairs(xa, ya, xb, yb):
     n, R = t[0].shape
     out = torch.zeros(n, dtype=torch.int64, device=dev)
     fl = torch.zeros(n, dtype=torch.int32, device=dev)
-    N.check(N.lib().sd_clip_pairs_device(N.tptr(t[0]), N.tptr(t[1]), N.tptr(t[2]), N.tptr(t[3]), n, R,
-                                         N.tptr(out), N.tptr(fl), N.current_stream()))
+    N.dcall(t[0], "sd_clip_pairs_device", N.tptr(t[0]), N.tptr(t[1]), N.tptr(t[2]), N.tptr(t[3]), n, R,
+                                         N.tptr(out), N.tptr(fl))
     torch.cuda.synchronize()
     return out.cpu().numpy(), fl.cpu().numpy()

@@ -23,9 +23,9 @@ def c_non_max_suppression_inds(dist, points, verts, faces, scores, use_bbox, use
         n, R = dist.shape
         keep = torch.empty(n, dtype=torch.uint8, device=dist.device)
         if n:
-            N.check(N.lib().sd_nms3d_device(N.tptr(scores), N.tptr(dist), N.tptr(points), n, R, faces.shape[0], N.tptr(verts),
+            N.dcall(scores, "sd_nms3d_device", N.tptr(scores), N.tptr(dist), N.tptr(points), n, R, faces.shape[0], N.tptr(verts),
                                             N.tptr(faces), float(threshold), int(use_bbox), int(use_kdtree), int(verbose),
-                                            N.tptr(keep), N.ptr(stats), N.current_stream()))
+                                            N.tptr(keep), N.ptr(stats))
         keep = keep.bool()
         N.last_stats["nms3d"] = stats
         return (keep, stats) if return_stats else keep
@@ -51,10 +51,9 @@ def c_polyhedron_to_label(dist, points, verts, faces, labels, render_mode, verbo
         verts = verts.contiguous().float(); faces = faces.contiguous().to(torch.int32); labels = labels.contiguous().to(torch.int32)
         out = torch.zeros((nz, ny, nx), dtype=torch.int32, device=dist.device)
         if dist.shape[0]:
-            N.check(N.lib().sd_polyhedron_to_label_device(N.tptr(dist), N.tptr(points), N.tptr(verts), N.tptr(faces), dist.shape[0],
+            N.dcall(dist, "sd_polyhedron_to_label_device", N.tptr(dist), N.tptr(points), N.tptr(verts), N.tptr(faces), dist.shape[0],
                                                           dist.shape[1], faces.shape[0], N.tptr(labels), nz, ny, nx, int(render_mode),
-                                                          int(verbose), int(use_overlap_label), int(overlap_label), N.tptr(out),
-                                                          N.current_stream()))
+                                                          int(verbose), int(use_overlap_label), int(overlap_label), N.tptr(out))
         return out
     dist = np.ascontiguousarray(dist, np.float32); points = np.ascontiguousarray(points, np.float32)
     verts = np.ascontiguousarray(verts, np.float32); faces = np.ascontiguousarray(faces, np.int32)
@@ -80,8 +79,8 @@ def c_star_dist3d(src, pdz, pdy, pdx, n_rays, grid_z, grid_y, grid_x):
         dev = src.device
         pdz, pdy, pdx = (torch.as_tensor(v, dtype=torch.float32, device=dev).contiguous() for v in (pdz, pdy, pdx))
         dst = torch.empty(((Z - 1) // gz + 1, (Y - 1) // gy + 1, (X - 1) // gx + 1, n_rays), dtype=torch.float32, device=dev)
-        N.check(N.lib().sd_star_dist3d_device(N.tptr(src), Z, Y, X, N.tptr(pdz), N.tptr(pdy), N.tptr(pdx), n_rays, gz, gy, gx,
-                                              N.tptr(dst), N.current_stream()))
+        N.dcall(src, "sd_star_dist3d_device", N.tptr(src), Z, Y, X, N.tptr(pdz), N.tptr(pdy), N.tptr(pdx), n_rays, gz, gy, gx,
+                                              N.tptr(dst))
         return dst
     src = np.ascontiguousarray(src)
     if src.dtype != np.uint16:

@@ -57,9 +57,11 @@ class StarDistPadAndCropResizer(object):
             for d, p in enumerate(pads):
                 if p:
                     n = xn.shape[d]
-                    if p > n - 1:
-                        raise ValueError("image too small to reflect-pad axis %s by %d" % (axes[d], p))
-                    idx = torch.arange(n - 2, n - 2 - p, -1, device=xn.device)
+                    if n == 1:                                    # numpy: a length-1 axis is repeated
+                        idx = torch.zeros(p, dtype=torch.long, device=xn.device)
+                    else:                                         # periodic reflection (period 2n-2), as np.pad does for p > n-1
+                        k = torch.arange(n, n + p, device=xn.device) % (2 * n - 2)
+                        idx = torch.where(k < n, k, 2 * n - 2 - k)
                     xn = torch.cat([xn, xn.index_select(d, idx)], dim=d)
             x = xn
         self.padded_shape = dict(zip(axes, x.shape))
@@ -131,23 +133,51 @@ class StarDistBase(object):
         return self.config.n_classes is not None
 
     def load_weights_npz(self, path):
-        """weights exported from Keras as {layer_name/kernel:0, layer_name/bias:0 ...} in graph order."""
+        """weights exported from Keras (tools/keras_to_npz.py) as {layer_name/kernel:0, layer_name/bias:0, ...}.
+        The output heads and the feature convolutions are matched BY NAME (prob, dist, features, features_class, prob_class:
+        Keras orders layers by graph depth, which for a multi-class model differs from this module's order); the backbone
+        convolutions (csbdeep block names vary between versions) are matched in graph order.  Every kernel's shape is checked."""
         import torch
         import torch.nn as nn
         data = np.load(path)
-        convs = [m for m in self.net.modules() if isinstance(m, (nn.Conv2d, nn.Conv3d))]
         kernels = [k for k in data.files if "kernel" in k]
-        if len(kernels) != len(convs):
-            raise ValueError("weight file has %d conv kernels, network has %d" % (len(kernels), len(convs)))
-        for m, kn in zip(convs, kernels):
+
+        def lname(k):
+            return k.split("/")[0]
+        named = {"prob": self.net.prob, "dist": self.net.dist}
+        if isinstance(self.net.features, nn.Sequential):
+            named["features"] = self.net.features[0]
+        if self.net.n_classes is not None:
+            named["prob_class"] = self.net.prob_class
+            if isinstance(self.net.features_class, nn.Sequential):
+                named["features_class"] = self.net.features_class[0]
+        head_ids = {id(m) for m in named.values()}
+        backbone = [m for m in self.net.modules() if isinstance(m, (nn.Conv2d, nn.Conv3d)) and id(m) not in head_ids]
+        by_name = {lname(k): k for k in kernels if lname(k) in named}
+        missing = [n for n in named if n not in by_name]
+        if missing:
+            raise ValueError("weight file has no kernels for layer(s) %s" % ", ".join(missing))
+        rest = [k for k in kernels if lname(k) not in named]
+        if len(rest) != len(backbone):
+            raise ValueError("weight file has %d backbone conv kernels, network has %d" % (len(rest), len(backbone)))
+
+        def put(m, kn):
             w = data[kn]
             nd = w.ndim - 2
-            wt = np.transpose(w, (nd + 1, nd) + tuple(range(nd)))
+            wt = np.ascontiguousarray(np.transpose(w, (nd + 1, nd) + tuple(range(nd))))
+            if tuple(wt.shape) != tuple(m.weight.shape):
+                raise ValueError("kernel %s has shape %s (torch layout %s), layer expects %s" % (kn, w.shape, wt.shape, tuple(m.weight.shape)))
             with torch.no_grad():
-                m.weight.copy_(torch.from_numpy(np.ascontiguousarray(wt)))
+                m.weight.copy_(torch.from_numpy(wt))
                 bn = kn.replace("kernel", "bias")
                 if bn in data.files:
+                    if m.bias is None or tuple(data[bn].shape) != tuple(m.bias.shape):
+                        raise ValueError("bias %s does not fit its layer" % bn)
                     m.bias.copy_(torch.from_numpy(data[bn]))
+        for n, m in named.items():
+            put(m, by_name[n])
+        for m, kn in zip(backbone, rest):
+            put(m, kn)
 
     # ------------------------------------------------------------------ helpers
     def _normalize_axes(self, img, axes):
@@ -246,6 +276,11 @@ class StarDistBase(object):
         n_tiles = tuple(map(int, n_tiles))
         axes = self._normalize_axes(img, axes)
         axes_net = self.config.axes
+        # n_tiles is given per IMAGE axis (base.py:418 permutes it like the data): re-order to the net's axes, 1 for an added C
+        nt = dict(zip(axes, n_tiles))
+        if nt.get("C", 1) != 1:
+            raise ValueError("entry of n_tiles > 1 only allowed for axes '%s'" % axes_net.replace("C", ""))
+        n_tiles = tuple(nt.get(a, 1) for a in axes_net)
         _permute_axes = self._make_permute_axes(axes, axes_net)
         if normalizer is not None:
             # csbdeep Normalizer protocol: .before(x, axes) on the host array
@@ -381,9 +416,9 @@ class StarDistBase(object):
             oprob = torch.empty(cap, dtype=torch.float32, device=prob.device)
             odist = torch.empty((cap, R), dtype=torch.float32, device=prob.device)
             opts = torch.empty((cap, nd), dtype=torch.int32, device=prob.device)
-            N.check(N.lib().sd_select_candidates_device(N.tptr(prob), N.tptr(dist), nd, N.ptr(shape), N.ptr(b), R,
+            N.dcall(prob, "sd_select_candidates_device", N.tptr(prob), N.tptr(dist), nd, N.ptr(shape), N.ptr(b), R,
                                                         float(np.float32(prob_thresh)), cap, N.tptr(oprob), N.tptr(odist),
-                                                        N.tptr(opts), N.tptr(cnt), N.current_stream()))
+                                                        N.tptr(opts), N.tptr(cnt))
             n = int(cnt.item())
             if n <= cap:
                 return oprob[:n], odist[:n], opts[:n].to(torch.int64)

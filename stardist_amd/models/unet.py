@@ -37,8 +37,13 @@ def _conv_bias_act(conv, x, kind):
     """conv + bias + (0 linear | 1 relu) with the element-wise part done by the native one-pass kernel; None if not applicable"""
     if not (x.is_cuda and conv.bias is not None and x.dtype == torch.float32 and not torch.is_grad_enabled()):
         return None
+    if torch.is_autocast_enabled():
+        return None                      # reduced-precision autocast: the native epilogue is float32 only -> plain Sequential
     from ..lib import _native as N
     y = conv._conv_forward(x, conv.weight, None)
+    if y.dtype != torch.float32:         # gate on the convolution OUTPUT (the kernel reads/writes 4 bytes per element)
+        y = y + conv.bias.to(y.dtype).view((1, y.shape[1]) + (1,) * (y.dim() - 2))
+        return torch.relu_(y) if kind == 1 else y
     C = y.shape[1]
     cl = torch.channels_last if y.dim() == 4 else torch.channels_last_3d
     if y.is_contiguous(memory_format=cl):
@@ -48,8 +53,9 @@ def _conv_bias_act(conv, x, kind):
     else:
         y = y + conv.bias.view((1, C) + (1,) * (y.dim() - 2))
         return torch.relu_(y) if kind == 1 else y
-    N.check(N.lib().sd_bias_act_device(ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(conv.bias.data_ptr()), n_outer, C, inner, kind,
-                                       N.current_stream()))
+    with torch.cuda.device(y.device):
+        N.check(N.lib().sd_bias_act_device(ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(conv.bias.data_ptr()), n_outer, C, inner, kind,
+                                           N.current_stream(y.device)))
     return y
 
 

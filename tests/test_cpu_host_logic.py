@@ -166,3 +166,68 @@ def test_export_to_obj_file3D_equals_reference_text(tmp_path):
     assert f.read_text() == s
     with pytest.raises(ValueError):
         export_to_obj_file3D(dict(dist=polys["dist"]))
+
+
+def test_resizer_reflects_tiny_axes_like_numpy():
+    """np.pad(mode='reflect') reflects periodically when the pad exceeds n-1 (base.py:1180 relies on it)"""
+    import torch
+    from stardist_amd.models.base import StarDistPadAndCropResizer
+    rng = np.random.RandomState(3)
+    for shape, div in (((3, 5, 1), (8, 8, 1)), ((1, 7, 1), (4, 16, 1)), ((2, 2, 1), (16, 16, 1))):
+        x = rng.rand(*shape).astype(np.float32)
+        r = StarDistPadAndCropResizer(grid=dict(Y=1, X=1))
+        xp = r.before(torch.from_numpy(x), "YXC", div).numpy()
+        pads = [(0, (d - s % d) % d) for s, d in zip(shape, div)]
+        assert np.array_equal(xp, np.pad(x, pads, mode="reflect")), shape
+
+
+def test_n_tiles_follows_image_axes():
+    """n_tiles is given per IMAGE axis (base.py:418 permutes it with the data): 'CYX' + (1,4,2) must tile Y by 4 and X by 2"""
+    import torch
+    from stardist_amd.models import Config2D, StarDist2D
+    m = StarDist2D(Config2D(n_rays=8, unet_n_depth=1, unet_n_filter_base=4, n_channel_in=2), basedir=None, device="cpu", seed=0)
+    img = np.random.RandomState(0).rand(2, 64, 48).astype(np.float32)
+    x, axes, axes_net, div_by, resizer, n_tiles, *_ = m._predict_setup(img, "CYX", None, (1, 4, 2))
+    assert axes_net == "YXC" and n_tiles == (4, 2, 1)
+    with pytest.raises(ValueError):
+        m._predict_setup(img, "CYX", None, (2, 1, 1))
+    a = m.predict(img, axes="CYX")
+    b = m.predict(img, axes="CYX", n_tiles=(1, 4, 2))
+    assert all(np.allclose(u, v, atol=1e-5) for u, v in zip(a, b))
+
+
+def test_load_weights_npz_matches_heads_by_name(tmp_path):
+    """Keras stores layers by graph depth: a multi-class model has [.., features, features_class, prob, dist, prob_class];
+    the loader must not pair them with the module order [features, prob, dist, features_class, prob_class]."""
+    import torch
+    from stardist_amd.models import Config2D, StarDist2D
+    cfg = dict(n_rays=8, unet_n_depth=1, unet_n_filter_base=4, net_conv_after_unet=6, n_classes=3)
+    src = StarDist2D(Config2D(**cfg), basedir=None, device="cpu", seed=1)
+    import torch.nn as nn
+    heads = {"features": src.net.features[0], "features_class": src.net.features_class[0], "prob": src.net.prob,
+             "dist": src.net.dist, "prob_class": src.net.prob_class}
+    head_ids = {id(m) for m in heads.values()}
+    data = {}
+
+    def put(name, m):
+        w = m.weight.detach().numpy()
+        nd = w.ndim - 2
+        data[name + "/kernel:0"] = np.transpose(w, tuple(range(2, 2 + nd)) + (1, 0))
+        data[name + "/bias:0"] = m.bias.detach().numpy()
+    k = 0
+    for m in src.net.modules():
+        if isinstance(m, nn.Conv2d) and id(m) not in head_ids:
+            put("conv2d_%d" % k, m); k += 1
+    for name in ("features", "features_class", "prob", "dist", "prob_class"):      # Keras (depth) order
+        put(name, heads[name])
+    path = str(tmp_path / "w.npz")
+    np.savez(path, **data)
+    dst = StarDist2D(Config2D(**cfg), basedir=None, device="cpu", seed=2)
+    dst.load_weights_npz(path)
+    for (n1, p1), (n2, p2) in zip(src.net.state_dict().items(), dst.net.state_dict().items()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+    # a kernel of the wrong shape is rejected instead of being broadcast
+    bad = dict(data); bad["prob/kernel:0"] = np.zeros((1, 1, 6, 5), np.float32)
+    np.savez(path, **bad)
+    with pytest.raises(ValueError):
+        dst.load_weights_npz(path)
