@@ -33,6 +33,42 @@ def _act(name):
     raise ValueError("activation %s not supported" % name)
 
 
+# MIOpen's find mode picks split-K kernels (partial sums combined with atomics, run-to-run different in the last bits) for
+# convolutions with few output pixels and a long reduction -- the deep levels of the U-Net on small inputs (measured:
+# 256->128 channels at 64^2: not repeatable; the same layer at 256^2 and every full-resolution layer: repeatable).
+# Below this many output pixels the convolution is done as ONE rocBLAS GEMM over explicitly shifted views instead
+# (repeatable; 0.05-0.1 ms per layer, tools/conv_det_probe2.py), so that predict() is deterministic and the dense and the
+# sparse prediction path agree bit for bit.
+_GEMM_CONV_MAX_PIXELS = 128 * 128
+
+
+def _gemm_conv(x, w):
+    """stride-1 'same' convolution of x (N, C, *S) with w (Cout, C, *k), odd k, as one matrix product"""
+    nd = x.dim() - 2
+    k = w.shape[2:]
+    pads = []
+    for kk in reversed(k):
+        pads += [kk // 2, kk // 2]
+    xp = F.pad(x, pads)
+    S = x.shape[2:]
+    import itertools
+    cols = [xp[(slice(None), slice(None)) + tuple(slice(o, o + s) for o, s in zip(off, S))] for off in itertools.product(*[range(kk) for kk in k])]
+    cols = torch.stack(cols, dim=2).reshape(x.shape[0], x.shape[1] * len(cols), -1)      # (N, C*K, prod S), K fastest like w
+    y = torch.matmul(w.reshape(w.shape[0], -1), cols)
+    y = y.reshape((x.shape[0], w.shape[0]) + tuple(S))
+    return y.contiguous(memory_format=torch.channels_last if nd == 2 else torch.channels_last_3d)
+
+
+def _conv_nobias(conv, x):
+    """the convolution without its bias: MIOpen/CK kernel, or the repeatable GEMM form for small deep layers"""
+    S = x.shape[2:]
+    if (x.is_cuda and int(np.prod(S)) <= _GEMM_CONV_MAX_PIXELS and conv.in_channels * int(np.prod(conv.kernel_size)) >= 256
+            and all(s == 1 for s in conv.stride) and all(d == 1 for d in conv.dilation) and conv.groups == 1
+            and all(kk % 2 == 1 and p == kk // 2 for kk, p in zip(conv.kernel_size, conv.padding)) and not torch.is_grad_enabled()):
+        return _gemm_conv(x, conv.weight)
+    return conv._conv_forward(x, conv.weight, None)
+
+
 def _conv_bias_act(conv, x, kind):
     """conv + bias + (0 linear | 1 relu) with the element-wise part done by the native one-pass kernel; None if not applicable"""
     if not (x.is_cuda and conv.bias is not None and x.dtype == torch.float32 and not torch.is_grad_enabled()):
@@ -40,7 +76,7 @@ def _conv_bias_act(conv, x, kind):
     if torch.is_autocast_enabled():
         return None                      # reduced-precision autocast: the native epilogue is float32 only -> plain Sequential
     from ..lib import _native as N
-    y = conv._conv_forward(x, conv.weight, None)
+    y = _conv_nobias(conv, x)
     if y.dtype != torch.float32:         # gate on the convolution OUTPUT (the kernel reads/writes 4 bytes per element)
         y = y + conv.bias.to(y.dtype).view((1, y.shape[1]) + (1,) * (y.dim() - 2))
         return torch.relu_(y) if kind == 1 else y

@@ -231,3 +231,16 @@ def test_load_weights_npz_matches_heads_by_name(tmp_path):
     np.savez(path, **bad)
     with pytest.raises(ValueError):
         dst.load_weights_npz(path)
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_gemm_form_of_small_convolutions_equals_conv(nd):
+    """the repeatable GEMM form used for the small deep layers on the GPU (unet.py _gemm_conv) is the same convolution"""
+    import torch
+    import torch.nn.functional as F
+    from stardist_amd.models.unet import _gemm_conv
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((2, 5) + (7, 9, 6)[:nd], generator=g)
+    w = torch.randn((4, 5) + (3, 3, 3)[:nd], generator=g)
+    ref = (F.conv2d if nd == 2 else F.conv3d)(x, w, padding=1)
+    assert torch.allclose(_gemm_conv(x, w), ref, atol=1e-5)

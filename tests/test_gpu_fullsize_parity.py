@@ -1,0 +1,116 @@
+"""GPU: survivor parity (keep ARRAYS, not counts) at the sizes BASELINE.json's metric is quoted on, and the 3D end-to-end
+composition (NMS -> polyhedron raster -> relabel incl. negative overlap_label, stardist/models/model3d.py:589-674)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "fullsize_keep.npz"))
+
+
+def test_nms2d_2048_keep_array_equals_reference(refmods):
+    """config 2 (S2D-uniform 2048^2, 416 700 candidates): survivors bit-identical to the compiled reference, run live, and to
+    the committed golden bits (tests/golden/make_fullsize_golden.py)"""
+    from oracle import synth
+    from stardist_amd.lib import stardist2d as sd2
+    d, p, s = synth.s2d_uniform(2048, 2048)
+    refmods.set_threads(os.cpu_count() or 1)          # the 2D reference is thread-count independent
+    ref_keep = refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4))
+    keep = sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4))
+    assert np.array_equal(keep, ref_keep), "mismatching candidates: %s" % np.flatnonzero(keep != ref_keep)[:10]
+    g = _golden()
+    assert int(g["nms2d_2048_n"]) == len(d)
+    assert np.array_equal(np.packbits(keep), g["nms2d_2048_keep"])
+
+
+def test_nms2d_bench_candidate_set_keep_array_equals_reference(refmods):
+    """the bench's own workload: the calibrated U-Net's candidates on the 2048^2 synthetic fluo tile (~4.2e5), NMS on the GPU vs the
+    compiled reference on the very same sorted candidate arrays"""
+    import torch
+    import bench
+    from oracle import synth
+    from stardist_amd import nms
+    from stardist_amd.lib import stardist2d as sd2
+    from stardist_amd.models import Config2D, StarDist2D
+    dev = torch.device("cuda:0")
+    img = torch.from_numpy(synth.s2d_nuclei_image(2048, 2048, seed=0)).to(dev)
+    model = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
+    model.thresholds = dict(prob=0.5, nms=0.4)
+    bench.calibrate_heads(model, img)
+    prob, dist, points = model.predict_sparse(img)
+    assert len(prob) > 300000
+    order = nms._argsort_desc(prob)
+    d = np.ascontiguousarray(dist[order], np.float32); p = np.ascontiguousarray(points[order], np.float32)
+    refmods.set_threads(os.cpu_count() or 1)
+    ref_keep = refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4))
+    keep, stats = sd2.c_non_max_suppression_inds(torch.from_numpy(d).to(dev), torch.from_numpy(p).to(dev), 1, 1, 0, np.float32(0.4), return_stats=True)
+    keep = keep.cpu().numpy()
+    assert np.array_equal(keep, ref_keep), "mismatching candidates: %s (pairs %d, general path %d)" % (np.flatnonzero(keep != ref_keep)[:10], stats[0], stats[1])
+
+
+def test_nms3d_256_keep_array_equals_reference_golden():
+    """config 3 (S3D-nuclei 256^3, 150 606 candidates, Rays_GoldenSpiral(96)): survivors bit-identical to the compiled reference
+    run with ONE OpenMP thread (minutes of Qhull, hence the committed golden bits)"""
+    from oracle import synth
+    from stardist_amd.lib import stardist3d as sd3
+    from stardist_amd.rays3d import Rays_GoldenSpiral
+    rays = Rays_GoldenSpiral(96)
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    d, p, s, nobj = synth.s3d_nuclei(256, V)
+    g = _golden()
+    assert int(g["nms3d_256_n"]) == len(d)
+    keep = sd3.c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(0.3))
+    ref_keep = np.unpackbits(g["nms3d_256_keep"])[:len(d)].astype(bool)
+    assert int(ref_keep.sum()) == 1328
+    assert np.array_equal(keep, ref_keep), "mismatching candidates: %s" % np.flatnonzero(keep != ref_keep)[:10]
+
+
+@pytest.mark.parametrize("overlap_label", [None, -1])
+def test_predict_instances_3d_end_to_end_equals_oracle_composition(refmods, overlap_label):
+    """StarDist3D.predict_instances (dense path, so that both sides see ONE forward pass) vs the reference composition on the same
+    prob/dist maps: _ind_prob_thresh -> sort -> c_non_max_suppression_inds (1 thread) -> c_polyhedron_to_label -> relabel_sequential
+    with the negative-overlap-label remapping of model3d.py:634-645"""
+    import torch
+    import bench
+    from oracle import port, synth
+    from stardist_amd import nms
+    from stardist_amd.models import Config3D, StarDist3D
+    dev = torch.device("cuda:0")
+    vol = synth.s3d_nuclei_image(64, seed=3)
+    model = StarDist3D(Config3D(rays=96), basedir=None, device=dev, seed=0)
+    model.thresholds = dict(prob=0.5, nms=0.3)
+    bench.calibrate_heads(model, torch.from_numpy(vol).to(dev), frac=0.02, radius=8.5, noise=0.03)
+    (labels, res), (prob, dist) = model.predict_instances(vol, return_predict=True, overlap_label=overlap_label)
+    prob = np.asarray(prob); dist = np.asarray(dist)
+    rays = res["rays"]
+    V, F = np.asarray(rays.vertices, np.float32), np.asarray(rays.faces, np.int32)
+    # ---- reference composition (stardist/nms.py:233-282, model3d.py:589-674)
+    mask = port.ind_prob_thresh(prob, 0.5, b=2)
+    pts = np.stack(np.where(mask), 1)
+    pr = prob[mask]; di = dist[mask]
+    order = nms._argsort_desc(pr)                       # ties: stable order on both sides (DESIGN.md deviation 6)
+    pr, di, pts = pr[order], di[order], pts[order]
+    refmods.stardist3d(); refmods.set_threads(1)
+    keep = refmods.stardist3d().c_non_max_suppression_inds(np.ascontiguousarray(di, np.float32), np.ascontiguousarray(pts, np.float32), V, F,
+                                                           np.ascontiguousarray(pr, np.float32), 1, 1, 0, np.float32(0.3))
+    keep = keep.astype(bool)
+    assert 10 < keep.sum() < len(keep)
+    pts_s, pr_s, di_s = pts[keep], pr[keep], di[keep]
+    lab_ref = port.polyhedron_to_label(di_s, pts_s, V, F, vol.shape, prob=pr_s, overlap_label=overlap_label)
+    if overlap_label is not None and overlap_label < 0 and (overlap_label in lab_ref):
+        m = lab_ref == overlap_label
+        ol2 = max(set(np.unique(lab_ref)) - {overlap_label}) + 1
+        lab_ref[m] = ol2
+        lab_ref, fwd, bwd = port.relabel_sequential(lab_ref)
+        lab_ref[lab_ref == fwd[ol2]] = overlap_label
+    else:
+        lab_ref, _, _ = port.relabel_sequential(lab_ref)
+    assert np.array_equal(res["points"], pts_s) and np.array_equal(res["prob"], pr_s) and np.array_equal(res["dist"], di_s)
+    assert labels.shape == lab_ref.shape and np.array_equal(labels, lab_ref)
+    if overlap_label is not None:
+        assert (labels == overlap_label).any()           # the synthetic spheres do overlap: the branch is exercised
