@@ -97,10 +97,9 @@ def test_predict_instances_dense_equals_sparse_and_big_equals_whole():
     bench.calibrate_heads(model, torch.from_numpy(img).to(dev), frac=0.03)
     l1, r1 = model.predict_instances(img, sparse=True)
     l2, r2 = model.predict_instances(img, sparse=False)
-    # two forward passes: MIOpen may use split-K kernels with atomics, so network outputs agree to ~1e-5 relative only;
-    # a handful of border pixels may then fall on the other side of a polygon edge
-    assert np.array_equal(r1["points"], r2["points"]) and np.allclose(r1["coord"], r2["coord"], atol=2e-2)
-    assert np.count_nonzero(l1 != l2) <= 1e-4 * l1.size
+    # two forward passes: the network is run-to-run deterministic (small deep layers as one GEMM, models/unet.py), so both agree exactly
+    assert np.array_equal(r1["points"], r2["points"]) and np.array_equal(r1["coord"], r2["coord"])
+    assert np.array_equal(l1, l2)
     l3, r3 = model.predict_instances(img, n_tiles=(2, 2))
     assert len(r3["prob"]) == len(r1["prob"]) and (l3 > 0).sum() == pytest.approx((l1 > 0).sum(), rel=1e-3)
     lb, rb = model.predict_instances_big(img, axes="YX", block_size=256, min_overlap=64, context=64, show_progress=False)

@@ -19,7 +19,7 @@ def test_nms2d_2048_keep_array_equals_reference(refmods):
     from oracle import synth
     from stardist_amd.lib import stardist2d as sd2
     d, p, s = synth.s2d_uniform(2048, 2048)
-    refmods.set_threads(os.cpu_count() or 1)          # the 2D reference is thread-count independent
+    refmods.set_threads(min(os.cpu_count() or 1, 16))          # the 2D reference is thread-count independent
     ref_keep = refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4))
     keep = sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4))
     assert np.array_equal(keep, ref_keep), "mismatching candidates: %s" % np.flatnonzero(keep != ref_keep)[:10]
@@ -46,7 +46,7 @@ def test_nms2d_bench_candidate_set_keep_array_equals_reference(refmods):
     assert len(prob) > 300000
     order = nms._argsort_desc(prob)
     d = np.ascontiguousarray(dist[order], np.float32); p = np.ascontiguousarray(points[order], np.float32)
-    refmods.set_threads(os.cpu_count() or 1)
+    refmods.set_threads(min(os.cpu_count() or 1, 16))
     ref_keep = refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4))
     keep, stats = sd2.c_non_max_suppression_inds(torch.from_numpy(d).to(dev), torch.from_numpy(p).to(dev), 1, 1, 0, np.float32(0.4), return_stats=True)
     keep = keep.cpu().numpy()
