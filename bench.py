@@ -34,11 +34,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0
-# HBM bytes per pair-kernel launch measured with rocprofv3 PMC in separate passes (profiles/r01_pmc_hbm_traffic.md: raw
-# FETCH_SIZE + WRITE_SIZE, mean over the 7 launches of one step = 3 x (6864.6 + 5061.6) MiB scratch kernel + 4 x 0.8 MiB LDS
-# kernel).  Only valid for the default 2048^2 workload (checked against the pair count below).
-PAIR_TRAFFIC_BYTES_PER_LAUNCH_2048 = 5.36e9
-PAIR_TRAFFIC_PAIRS_2048 = 521706
+# HBM bytes per pair-kernel launch are NOT a constant in this file: tools/profile_traffic.py (run under rocprofv3 --pmc FETCH_SIZE /
+# WRITE_SIZE in separate passes) writes them, together with the pair count of the profiled workload, to this json; bench.py
+# reports them as roofline.traffic only when its own pair count matches the profiled one.
+PAIR_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pair_kernel_traffic.json")
 
 
 def calibrate_heads(model, img, frac=0.10, radius=10.0, noise=0.1):
@@ -102,7 +101,18 @@ def cpu_baseline_2d(img_np, model, sample, threads):
     port.polygons_to_label(d[keep], pts[keep], prob=s[keep], shape=x.shape)
     t_ras = time.time() - t0
     tot = t_net + t_nms + t_ras
+    # BASELINE.md 3.1 asks for the native post-processing at cpu_count AND at one thread: the first quarter of the candidates
+    # (bounded sample) through the compiled reference NMS with a single OpenMP thread
+    n1 = max(1, len(d) // 4)
+    ref.set_threads(1)
+    t0 = time.time()
+    k1 = ref.stardist2d().c_non_max_suppression_inds(np.ascontiguousarray(d[:n1], np.float32), np.ascontiguousarray(pts[:n1].astype(np.float32)),
+                                                     1, 1, 0, np.float32(model.thresholds.nms))
+    t_nms1 = time.time() - t0
+    ref.set_threads(threads)
     return dict(value=round(x.size / tot / 1e6, 4), unit="Mpix/s", cores=threads, kind="reference",
+                nms_only={"threads_%d" % threads: {"candidates": int(len(d)), "seconds": round(t_nms, 3), "cand_per_s": round(len(d) / t_nms)},
+                          "threads_1": {"candidates": int(n1), "seconds": round(t_nms1, 3), "cand_per_s": round(n1 / t_nms1), "survivors": int(k1.sum())}},
                 sample="%dx%d crop of the bench image: torch-CPU U-Net %.2fs (TF-CPU stand-in) + compiled reference NMS "
                        "(oracle/_ref, %d candidates -> %d) %.2fs + numpy restatement of the Python rasteriser loop %.2fs"
                        % (sample, sample, t_net, len(d), int(keep.sum()), t_nms, t_ras))
@@ -138,6 +148,9 @@ def cpu_baseline_3d(vol_np, model, sample, threads):
     t_ras = time.time() - t0
     tot = t_net + t_nms + t_ras
     return dict(value=round(x.size / tot / 1e6, 4), unit="Mvox/s", cores=threads, kind="reference",
+                note="measured on a crop (Qhull makes the full 256^3 reference run take minutes): any GPU/CPU ratio formed with value_3d is an "
+                     "extrapolation from this crop, not a same-size comparison; BASELINE.md section 2 has the survey's full-size 256^3 run "
+                     "(33.9 s NMS + 0.92 s raster at 8 threads = 0.48 Mvox/s, native post-processing only)",
                 sample="%d^3 crop of the bench volume: torch-CPU U-Net %.2fs (TF-CPU stand-in) + compiled reference 3D NMS "
                        "(oracle/_ref incl. Qhull, %d candidates -> %d) %.2fs + compiled reference rasteriser %.2fs"
                        % (sample, t_net, len(d), int(keep.sum()), t_nms, t_ras))
@@ -182,6 +195,43 @@ def run_leg(model, img, steps, warmup, world, dist_):
     return elapsed, net_ms, res, stats
 
 
+def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, dist_, rank):
+    """BASELINE.json configs 4/5: ONE large input, its blocks dealt round-robin to the ranks, local NMS per block on the device,
+    RCCL all_gather of the block survivors, final cross-tile NMS + rasteriser on rank 0 (stardist_amd/big.py, design A of
+    SURVEY.md 8e).  Strong scaling: the input is the same for every N.  Returns a dict (rank 0) or None."""
+    import torch
+    kw = dict(block_size=block, min_overlap=overlap, context=context, broadcast_result=False)
+    model.predict_instances_sharded(big, axes, **kw)                         # warm-up (MIOpen find, HIP graphs, arena growth)
+    if world > 1:
+        dist_.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    acc = {}
+    for _ in range(passes):
+        labels, res = model.predict_instances_sharded(big, axes, **kw)
+        for k, v in model._last_sharded_stats.items():
+            acc[k] = acc.get(k, 0) + v
+    torch.cuda.synchronize()
+    if world > 1:
+        dist_.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [None] * world
+    if world > 1:
+        tt = torch.tensor([elapsed], device=big.device, dtype=torch.float64)
+        dist_.all_reduce(tt, op=dist_.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist_.all_gather_object(per_rank, {k: (round(v / passes, 4) if isinstance(v, float) else v // passes) for k, v in acc.items()})
+    else:
+        per_rank = [{k: (round(v / passes, 4) if isinstance(v, float) else v // passes) for k, v in acc.items()}]
+    if rank != 0:
+        return None
+    n = int(np.prod(big.shape))
+    return {"value": round(n * passes / elapsed / 1e6, 3), "s_per_pass": round(elapsed / passes, 4), "passes": passes, "scaling": "strong",
+            "input_shape": list(big.shape), "block_size": block, "min_overlap": overlap, "context": context,
+            "instances": len(res["prob"]), "gathered_survivors": per_rank[0]["gathered"], "gathered_bytes": per_rank[0]["gathered_bytes"],
+            "per_rank": per_rank}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,6 +245,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--cpu-sample3d", type=int, default=96)
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--sharded", action="store_true", help="also run the block-sharded big-input legs at N=1 (always run for N>1)")
+    ap.add_argument("--sharded-size", type=int, default=16384)
+    ap.add_argument("--sharded-size3d", type=int, default=1024)
+    ap.add_argument("--skip-sharded-3d", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -225,6 +279,12 @@ def main():
     calibrate_heads(model, img)
     macs = conv_macs_per_input_pixel(model.net, model.config)
     elapsed, net_ms, res, st = run_leg(model, img, args.steps, args.warmup, world, dist_)
+    # second number (SURVEY.md 8d defines the metric host-array-in): the same steps with the image handed over as a host numpy array,
+    # i.e. including the 16.8 MB H2D copy; `value` stays the HBM-resident figure the contract asks for
+    torch.cuda.synchronize(); t0h = time.perf_counter()
+    for _ in range(args.steps):
+        model.predict_instances(img_np)
+    torch.cuda.synchronize(); elapsed_host = time.perf_counter() - t0h
     out = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -242,14 +302,20 @@ def main():
                   "other(select,sort,greedy-scan,raster,d2h)": round(ms_per_step - net_ms - float(pair_ms + s2[6] / 1e6 + s2[7] / 1e6), 3)}
         roof_conv = {"bound": "mfma", "kernel": "U-Net conv stack (MIOpen / CK kernels, fp32 NHWC)", "achieved": round(conv_tf, 3), "peak": peak,
                      "unit": "TFLOP/s", "frac": round(conv_tf / peak, 4), "traffic": None, "flops_per_launch": flops, "avg_ms": round(net_ms, 3)}
-        roof_pair = {"bound": "hbm", "kernel": "k_pairs (scan-beam polygon intersection, one thread per pair)", "achieved": round(pair_gbs, 3),
+        roof_pair = {"bound": "hbm", "kernel": "k_pairs_beam<32,8,6,4,64> (bound-slot scan-beam polygon intersection, one pair per lane, state in LDS)", "achieved": round(pair_gbs, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pair_gbs / HBM_PEAK_GBS, 6), "traffic": None,
                      "bytes_per_launch": round(pair_bytes_per_launch), "avg_launch_ms": round(float(pair_ms / pair_launches), 4),
                      "launches_per_step": float(pair_launches), "pairs_per_step": float(n_pairs),
-                     "note": "integer scan-beam sweep, one pair per lane: bound by instruction issue under lane divergence, not by HBM; compulsory traffic is tiny (SURVEY.md 8d); measured HBM traffic: profiles/"}
-        if H == 2048 and W == 2048 and abs(float(n_pairs) - PAIR_TRAFFIC_PAIRS_2048) < 0.02 * PAIR_TRAFFIC_PAIRS_2048 and int(pair_launches) == 7:
-            roof_pair["traffic"] = PAIR_TRAFFIC_BYTES_PER_LAUNCH_2048
-            roof_pair["traffic_source"] = "profiles/r01_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, raw)"
+                     "note": "integer scan-beam sweep, one pair per lane, per-pair state lane-interleaved in LDS: bound by instruction issue under lane "
+                             "divergence and by one sweep's serial latency, not by HBM; algorithmic bytes = 272 B/pair (SURVEY.md 8d)"}
+        try:
+            with open(PAIR_TRAFFIC_JSON) as fh:
+                tj = json.load(fh)
+            if abs(float(n_pairs) - tj["pairs_per_step"]) <= 0.02 * tj["pairs_per_step"] and H == tj.get("size", 2048):
+                roof_pair["traffic"] = tj["bytes_per_launch"]
+                roof_pair["traffic_source"] = tj["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         dominant = roof_pair if pair_ms + s2[6] / 1e6 > net_ms else roof_conv
         out = {
             "metric": "predict_instances() Mpix/s (2D) + Mvox/s (3D) end-to-end at 1/2/4/8 GPU",
@@ -262,12 +328,23 @@ def main():
                        "candidates": n_cand, "survivors": len(res[1]["prob"]), "prob_thresh": model.thresholds.prob,
                        "nms_thresh": model.thresholds.nms, "parallelism": "tiles-per-gpu x%d" % world},
             "stages_ms": stages, "roofline": dominant, "roofline_convs": roof_conv, "roofline_pair_kernel": roof_pair,
+            "value_host_input": {"value": round(H * W * args.steps / elapsed_host / 1e6, 3), "unit": "Mpix/s", "ms_per_step": round(1e3 * elapsed_host / args.steps, 3),
+                                 "note": "same steps with the image passed as a host numpy array (H2D of the input inside the timed region), this rank only"},
         }
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline_2d(img_np, model, min(args.cpu_sample, H), threads)
             except Exception as e:   # oracle/_ref must have travelled with the tree
                 out["cpu_baseline"] = {"value": None, "unit": "Mpix/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
+    # ---- config 4: one 16384^2 slide (the 2048^2 synthetic tile repeated), blocks 4096 / overlap 128 / context 128, sharded over the ranks
+    if world > 1 or args.sharded:
+        rep = max(1, args.sharded_size // H)
+        big = torch.from_numpy(synth.s2d_nuclei_image(H, W, seed=0)).to(dev).repeat(rep, rep)
+        r = run_sharded_leg(model, big, "YX", min(4096, big.shape[0]), 128, 128, 2, world, dist_, rank)
+        if rank == 0:
+            r["unit"] = "Mpix/s"
+            out["sharded_2d"] = r
+        del big
     del model, img
     torch.cuda.empty_cache()
 
@@ -305,6 +382,15 @@ def main():
                     out["cpu_baseline_3d"] = cpu_baseline_3d(vol_np, m3, min(args.cpu_sample3d, S), threads)
                 except Exception as e:
                     out["cpu_baseline_3d"] = {"value": None, "unit": "Mvox/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
+        # ---- config 5: one 1024^3 volume (the 256^3 synthetic volume repeated), 256^3 blocks / overlap 32 / context 32, sharded
+        if (world > 1 or args.sharded) and not args.skip_sharded_3d:
+            rep = max(1, args.sharded_size3d // S)
+            bigv = torch.from_numpy(synth.s3d_nuclei_image(S, seed=0)).to(dev).repeat(rep, rep, rep)
+            r = run_sharded_leg(m3, bigv, "ZYX", min(256, bigv.shape[0]), 32, 32, 1, world, dist_, rank)
+            if rank == 0:
+                r["unit"] = "Mvox/s"
+                out["sharded_3d"] = r
+            del bigv
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -9,9 +9,10 @@ one block (big.py:89-122); per-block results are relabelled with a running label
 Multi-GPU (not in the reference): blocks are dealt round-robin to the ranks of the default
 torch.distributed process group (one process per GPU, backend nccl = RCCL on ROCm, gloo on CPU).  The only
 exchanges are (1) an all_reduce(SUM) of the per-block survivor counts -> label offsets identical to the sequential
-loop, (2) an all_reduce(MAX) of the label image -- because offsets grow with the block index, MAX reproduces the
-sequential "later block overwrites" rule exactly, (3) an all_gather of the per-object records (400 B per 3D
-object).  No collective touches the per-block data path.
+loop, (2) the relabelled label blocks: written in block order straight into a shared np.memmap / zarr array when the caller
+passes one (block.write, big.py:319-326), otherwise sent point-to-point to rank 0, which writes them in block order -- never an
+all_reduce of the whole label image, (3) an all_gather of the per-object records (400 B per 3D object).  No collective touches
+the per-block data path.
 """
 import math
 from itertools import product
@@ -238,7 +239,8 @@ def relabel_with_offset(labels, offset):
 def predict_instances_big(model, img, axes, block_size, min_overlap, context=None, labels_out=None, labels_out_dtype=np.int32,
                           show_progress=True, distributed=None, **kwargs):
     """StarDistBase.predict_instances_big (base.py:838-983) + round-robin sharding of the blocks over the ranks of the
-    default torch.distributed group (when initialised, or distributed=True).  Every rank returns the full result."""
+    default torch.distributed group (when initialised, or distributed=True).  Every rank returns the full object dict; the label
+    image is complete on rank 0 (or in the shared memmap / zarr array passed as labels_out), not replicated."""
     from .models.base import axes_check_and_normalize, axes_dict
     n = img.ndim
     axes = axes_check_and_normalize(axes, length=n)
@@ -313,25 +315,49 @@ def predict_instances_big(model, img, axes, block_size, min_overlap, context=Non
         counts = tc.cpu().numpy()
     offsets = 1 + np.concatenate([[0], np.cumsum(counts)[:-1]])
 
-    # ---- phase 3: write my blocks; merge
+    # ---- phase 3: write my blocks; merge.  The label image is NOT reduced across ranks (1 GiB at 16384^2, 4 GiB at 1024^3):
+    #   * labels_out backed by shared storage (np.memmap on a file every rank opened, zarr-like objects with a `store`): every rank
+    #     writes the write regions of ITS blocks in place, as block.write does (big.py:319-326), in block order (a barrier per
+    #     block keeps the sequential loop's "later block overwrites" rule where the objects of two blocks overlap);
+    #   * otherwise rank 0 owns the result: the other ranks send the (cropped, relabelled) label block of each of their blocks
+    #     point-to-point, rank 0 writes them in block order.  Total traffic = one image, to one rank.
     polys_blocks = {}
-    for bi, (labels, polys) in mine.items():
+    shared_out = labels_out is not None and (isinstance(labels_out, np.memmap) or hasattr(labels_out, "store"))
+    for bi in sorted(mine):
+        labels, polys = mine[bi]
         labels = relabel_with_offset(labels, int(offsets[bi]))
-        if labels_out is not None:
-            blocks[bi].write(labels_out, labels.astype(labels_out.dtype, copy=False), axes=axes_out)
+        mine[bi] = (labels, polys)
         polys_blocks[bi] = polys
     if dist_ is not None and world > 1:
         import torch
-        if labels_out is not None:
-            # offsets grow with the block index, so MAX == "later block overwrites" of the sequential loop
-            tl = torch.from_numpy(np.ascontiguousarray(labels_out)).to(dev)
-            dist_.all_reduce(tl, op=dist_.ReduceOp.MAX)
-            labels_out[...] = tl.cpu().numpy()
+        if labels_out is not None and shared_out:
+            for bi in range(len(blocks)):
+                if bi in mine:
+                    blocks[bi].write(labels_out, mine[bi][0].astype(labels_out.dtype, copy=False), axes=axes_out)
+                    if hasattr(labels_out, "flush"):
+                        labels_out.flush()
+                dist_.barrier()
+        elif labels_out is not None:
+            for bi, block in enumerate(blocks):
+                owner = bi % world
+                shp = tuple(sl.stop - sl.start for sl in block.slice_crop_context(axes_out))
+                if owner == 0:
+                    if rank == 0:
+                        block.write(labels_out, mine[bi][0].astype(labels_out.dtype, copy=False), axes=axes_out)
+                elif rank == owner:
+                    dist_.send(torch.from_numpy(np.ascontiguousarray(mine[bi][0].astype(np.int32))).to(dev), dst=0)
+                elif rank == 0:
+                    buf = torch.empty(shp, dtype=torch.int32, device=dev)
+                    dist_.recv(buf, src=owner)
+                    block.write(labels_out, buf.cpu().numpy().astype(labels_out.dtype, copy=False), axes=axes_out)
         gathered = [None] * world
         dist_.all_gather_object(gathered, polys_blocks)
         polys_blocks = {}
         for g in gathered:
             polys_blocks.update(g)
+    elif labels_out is not None:
+        for bi in sorted(mine):
+            blocks[bi].write(labels_out, mine[bi][0].astype(labels_out.dtype, copy=False), axes=axes_out)
     polys_all = {}
     for bi in sorted(polys_blocks):
         for k, v in polys_blocks[bi].items():
@@ -340,8 +366,98 @@ def predict_instances_big(model, img, axes, block_size, min_overlap, context=Non
     return (labels_out if labels_out is not None else False), polys_all
 
 
+def _sharded_on_device(model, img, axes, axes_out, shape_out, blocks, dist_, rank, world, prob_thresh, nms_thresh, return_labels,
+                       predict_kwargs, nms_kwargs, broadcast_result):
+    """predict_instances_sharded with every candidate kept on the GPU from the selection kernel through the local NMS into the
+    collective: per block `predict_sparse_device` -> `_nms_sparse_device` -> write-region filter (torch), ONE all_gather of the
+    survivor counts and ONE padded all_gather of a packed float32 record [dist(R) | prob | centre(nd) | block id] per survivor
+    (141 B in 2D, 401 B + 8 in 3D; coordinates and block ids are < 2^24, exact in float32), de-duplication and canonical ordering
+    with torch sorts, final NMS + rasteriser on rank 0.  With the gloo backend (CPU tests) only the packed record visits the host.
+    Per-stage wall times and the gathered volume are left in model._last_sharded_stats."""
+    import time
+    import torch
+    dev = model.device
+    nd = len(axes_out)
+    R = model.config.n_rays
+    st = dict(blocks=0, candidates=0, local_survivors=0, t_predict=0.0, t_local_nms=0.0, t_exchange=0.0, t_final=0.0, gathered=0, gathered_bytes=0)
+
+    def tick():
+        torch.cuda.synchronize(dev)
+        return time.perf_counter()
+    recs = []
+    for bi, block in enumerate(blocks):
+        if bi % world != rank:
+            continue
+        t0 = tick()
+        res = model.predict_sparse_device(block.read(img, axes=axes), axes=axes, prob_thresh=prob_thresh, **predict_kwargs)
+        prob, dist, points = res[0], res[1], res[-1]
+        t1 = tick()
+        st["blocks"] += 1; st["candidates"] += int(prob.numel()); st["t_predict"] += t1 - t0
+        if prob.numel() == 0:
+            continue
+        pts_s, prob_s, dist_s = model._nms_sparse_device(dist, prob, points, nms_thresh=nms_thresh, **nms_kwargs)
+        bl = block.blocks_for_axes(axes_out)
+        start = torch.tensor([t.start for t in bl], device=dev, dtype=torch.int64).reshape(1, nd)
+        lo = torch.tensor([t.start + t.context_start for t in bl], device=dev, dtype=torch.int64).reshape(1, nd)
+        hi = torch.tensor([t.end - t.context_end for t in bl], device=dev, dtype=torch.int64).reshape(1, nd)
+        gp = pts_s.to(torch.int64) + start
+        inside = torch.all((gp >= lo) & (gp < hi), dim=1)
+        n_in = int(inside.sum())
+        rec = torch.empty((n_in, R + 1 + nd + 1), dtype=torch.float32, device=dev)
+        rec[:, :R] = dist_s[inside].float(); rec[:, R] = prob_s[inside].float()
+        rec[:, R + 1:R + 1 + nd] = gp[inside].float(); rec[:, R + 1 + nd] = float(bi)
+        recs.append(rec)
+        st["local_survivors"] += n_in; st["t_local_nms"] += tick() - t1
+    rec = torch.cat(recs) if recs else torch.zeros((0, R + 1 + nd + 1), dtype=torch.float32, device=dev)
+
+    t0 = tick()
+    if dist_ is not None and world > 1:
+        on_host = dist_.get_backend() != "nccl"
+        cdev = torch.device("cpu") if on_host else dev
+        cnt = torch.tensor([rec.shape[0]], dtype=torch.int64, device=cdev)
+        cnts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist_.all_gather(cnts, cnt)
+        cnts = [int(c.item()) for c in cnts]
+        cap = max(max(cnts), 1)
+        buf = torch.zeros((cap, rec.shape[1]), dtype=torch.float32, device=cdev)
+        buf[:rec.shape[0]] = rec.to(cdev)
+        out = [torch.empty_like(buf) for _ in range(world)]
+        dist_.all_gather(out, buf)
+        rec = torch.cat([o[:c] for o, c in zip(out, cnts)]).to(dev)
+        st["gathered_bytes"] = int(sum(cnts)) * rec.shape[1] * 4
+    st["gathered"] = int(rec.shape[0])
+    st["t_exchange"] = tick() - t0
+
+    t0 = tick()
+    # canonical order (block index, then the block's score order): the result does not depend on the number of ranks
+    order = torch.sort(rec[:, R + 1 + nd], stable=True)[1]
+    rec = rec[order]
+    pts = rec[:, R + 1:R + 1 + nd].to(torch.int64)
+    if rec.shape[0]:                                 # same pixel reported by two overlapping blocks: keep the first
+        key = pts[:, 0]
+        for d in range(1, nd):
+            key = key * int(shape_out[d]) + pts[:, d]
+        ks, ki = torch.sort(key, stable=True)
+        first = torch.ones_like(ks, dtype=torch.bool)
+        first[1:] = ks[1:] != ks[:-1]
+        sel = torch.sort(ki[first])[0]
+        rec, pts = rec[sel], pts[sel]
+    labels, res_dict = None, None
+    if rank == 0:
+        labels, res_dict = model._instances_from_prediction(shape_out, rec[:, R].contiguous(), rec[:, :R].contiguous(), points=pts,
+                                                            prob_thresh=prob_thresh, nms_thresh=nms_thresh, return_labels=return_labels, **nms_kwargs)
+    st["t_final"] = tick() - t0
+    model._last_sharded_stats = st
+    if broadcast_result and dist_ is not None and world > 1:
+        box = [res_dict]
+        dist_.broadcast_object_list(box, src=0)
+        res_dict = box[0]
+    return labels, res_dict
+
+
 def predict_instances_sharded(model, img, axes, block_size, min_overlap, context=None, prob_thresh=None, nms_thresh=None,
-                              return_labels=True, show_progress=False, distributed=None, predict_kwargs=None, nms_kwargs=None):
+                              return_labels=True, show_progress=False, distributed=None, predict_kwargs=None, nms_kwargs=None,
+                              broadcast_result=True):
     """Block-sharded prediction with a final cross-tile NMS (SURVEY.md 8e design A, the north-star's multi-GPU path).
 
     The blocks of `BlockND.cover` (big.py:426-450) are dealt round-robin to the ranks of the default torch.distributed group
@@ -390,6 +506,10 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
             dist_, rank, world = td, td.get_rank(), td.get_world_size()
     except ImportError:
         pass
+
+    if hasattr(model, "predict_sparse_device") and getattr(model, "device", None) is not None and str(model.device).startswith("cuda"):
+        return _sharded_on_device(model, img, axes, axes_out, shape_out, blocks, dist_, rank, world, prob_thresh, nms_thresh, return_labels,
+                                  predict_kwargs, nms_kwargs, broadcast_result)
 
     # ---- phase 1: my blocks -> local survivors inside the block's write region, global coordinates
     nd = len(axes_out)

@@ -477,6 +477,13 @@ class StarDistBase(object):
             pass
         return tuple(t.cpu().numpy() for t in r)
 
+    def predict_sparse_device(self, *args, **kwargs):
+        """predict_sparse without the trip to the host: (prob, dist[, prob_class], points) as tensors on self.device"""
+        r = None
+        for r in self._predict_sparse_generator(*args, **kwargs):
+            pass
+        return tuple(r)
+
     # ------------------------------------------------------------------ predict_instances   base.py:645-790
     def _predict_instances_generator(self, img, axes=None, normalizer=None, sparse=True, prob_thresh=None, nms_thresh=None,
                                      scale=None, n_tiles=None, show_tile_progress=True, verbose=False, return_labels=True,

@@ -71,6 +71,13 @@ class StarDist2D(StarDistBase):
         inds = non_maximum_suppression_sparse(dist, prob, points, nms_thresh=nms_thresh, **nms_kwargs)[3]
         return inds.cpu().numpy() if N.is_torch(inds) else np.asarray(inds)
 
+    def _nms_sparse_device(self, dist, prob, points, nms_thresh=None, **nms_kwargs):
+        """NMS of a candidate list given as device tensors: (points, prob, dist) of the survivors, best score first, still on
+        the device (used by the sharded predictor: no host round trip between selection, local NMS and the RCCL gather)"""
+        if nms_thresh is None: nms_thresh = self.thresholds.nms
+        r = non_maximum_suppression_sparse(dist, prob, points, nms_thresh=nms_thresh, **nms_kwargs)
+        return r[0], r[1], r[2]
+
     def _axes_div_by(self, query_axes):
         """model2d.py:566-574"""
         query_axes = axes_check_and_normalize(query_axes)

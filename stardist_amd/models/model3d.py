@@ -93,6 +93,14 @@ class StarDist3D(StarDistBase):
         inds = non_maximum_suppression_3d_sparse(dist, prob, points, rays, nms_thresh=nms_thresh, **nms_kwargs)[3]
         return inds.cpu().numpy() if N.is_torch(inds) else np.asarray(inds)
 
+    def _nms_sparse_device(self, dist, prob, points, nms_thresh=None, **nms_kwargs):
+        """NMS of a candidate list given as device tensors: (points, prob, dist) of the survivors, best score first, still on
+        the device (used by the sharded predictor: no host round trip between selection, local NMS and the RCCL gather)"""
+        if nms_thresh is None: nms_thresh = self.thresholds.nms
+        rays = rays_from_json(self.config.rays_json)
+        r = non_maximum_suppression_3d_sparse(dist, prob, points, rays, nms_thresh=nms_thresh, **nms_kwargs)
+        return r[0], r[1], r[2]
+
     def _axes_div_by(self, query_axes):
         """model3d.py:677-690"""
         if self.config.backbone == "unet":

@@ -80,7 +80,7 @@ def test_object_larger_than_overlap_raises():
         predict_instances_big(_FakeModel(2, 1), gt, "YX", 64, 16, context=4, show_progress=False)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, memmap_path):
     import torch.distributed as dist
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -88,28 +88,40 @@ def _worker(rank, world, port, q):
     from stardist_amd.big import predict_instances_big
     from test_cpu_big import _FakeModel, _gt_labels
     gt = _gt_labels((160, 200), n=80)
-    labels, polys = predict_instances_big(_FakeModel(2, 1), gt, "YX", 64, 16, context=8, show_progress=False)
-    q.put((rank, labels, polys["points"], polys["prob"]))
+    out = None
+    if memmap_path:      # the streaming form: every rank opens the same file and writes the write regions of its own blocks
+        out = np.lib.format.open_memmap(memmap_path, mode="r+")
+    labels, polys = predict_instances_big(_FakeModel(2, 1), gt, "YX", 64, 16, context=8, show_progress=False, labels_out=out)
+    q.put((rank, None if memmap_path else np.asarray(labels), polys["points"], polys["prob"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_equals_sequential_gloo_world2():
-    """N>1 path: blocks dealt round-robin to 2 ranks; result identical to the single-process loop on every rank"""
+@pytest.mark.parametrize("shared", [False, True])
+def test_sharded_equals_sequential_gloo_world2(shared, tmp_path):
+    """N>1 path: blocks dealt round-robin to 2 ranks.  Object dict identical to the single-process loop on every rank; the label
+    image is complete on rank 0 (block labels sent point-to-point, no all_reduce of the image) or in the shared memmap."""
     import torch.multiprocessing as mp
     from stardist_amd.big import predict_instances_big
     gt = _gt_labels((160, 200), n=80)
     ref_labels, ref_polys = predict_instances_big(_FakeModel(2, 1), gt, "YX", 64, 16, context=8, show_progress=False)
+    path = ""
+    if shared:
+        path = str(tmp_path / "labels.npy")
+        mm = np.lib.format.open_memmap(path, mode="w+", dtype=np.int32, shape=gt.shape); mm[...] = 0; mm.flush(); del mm
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 300
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + os.getpid() % 300 + (1 if shared else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, path)) for r in range(2)]
     for p in procs: p.start()
     res = [q.get(timeout=240) for _ in range(2)]
     for p in procs: p.join(60)
     for rank, labels, pts, prob in res:
-        assert np.array_equal(labels, ref_labels), rank
+        if rank == 0 and not shared:
+            assert np.array_equal(labels, ref_labels)
         assert np.array_equal(pts, ref_polys["points"]) and len(prob) == len(ref_polys["prob"])
+    if shared:
+        assert np.array_equal(np.load(path), ref_labels)
 
 
 # ---------------------------------------------------------------- design A: sharded prediction + final cross-tile NMS

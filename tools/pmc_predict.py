@@ -16,6 +16,9 @@ bench.calibrate_heads(m2, img)
 for _ in range(2):
     lab, res = m2.predict_instances(img)
 print("2D:", len(res["prob"]), "instances")
+from stardist_amd.lib import _native
+st = _native.last_stats["nms2d"]
+print("PAIRS_PER_STEP=%d PAIR_LAUNCHES_PER_STEP=%d GENERAL_PATH_PAIRS=%d SIZE=2048" % (st[0], st[5], st[1]), flush=True)
 if "--skip-3d" not in sys.argv:
     del m2, img
     torch.cuda.empty_cache()
