@@ -1263,6 +1263,33 @@ __global__ void k_keep3(const unsigned char* __restrict__ state, unsigned char* 
 
 }  // namespace
 
+namespace sd {
+// Convex hulls of n polyhedra (the half-spaces Qhull gives the reference in halfspaces_convex, stardist3d_impl.cpp:767-795):
+// planes[(i*cap + f)*4 .. +3] = (nz, ny, nx, offset) with inside <=> n.p + offset <= 0, count[i] facets (cap = 2*n_rays),
+// count[i] == -2 if the hull could not be built.  Buffers come from the CURRENT arena pass (caller has called begin()).
+int hull_planes(const float* d_dist, const float* d_points, const float* d_verts, int n, int R, double** planes, int** count, int* cap_out,
+                hipStream_t s) {
+  if (R < 4 || R > 800) { sd::set_error("hull_planes: n_rays=%d unsupported (4..800)", R); return -1; }
+  const int cap = 2 * R;
+  const size_t ldsH = (size_t)3 * R * sizeof(double) + (size_t)2 * R * sizeof(unsigned int) +
+                      (R <= HULL_FAST_MAXR ? (size_t)12 * R * sizeof(unsigned int) + (size_t)R * R + 4 : 0);
+  if (ldsH > 150 * 1024) { sd::set_error("hull_planes: n_rays too large for LDS staging"); return -1; }
+  if (ldsH > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_hull, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsH));
+  sd::Arena& A = sd::arena();
+  double* pl = A.take_n<double>((size_t)n * cap * 4);
+  unsigned short* adj = A.take_n<unsigned short>((size_t)n * cap * 3);
+  int* cnt = A.take_n<int>(n);
+  int* list = A.take_n<int>(n);
+  if (!pl || !adj || !cnt || !list) return -1;
+  hipLaunchKernelGGL(k_iota3, dim3(sd::div_up(n, 256)), dim3(256), 0, s, list, n);
+  const unsigned int bh = n < 32768 ? (unsigned int)n : 32768u;
+  hipLaunchKernelGGL(k_hull, dim3(bh), dim3(64), ldsH, s, list, (unsigned int)n, d_dist, d_points, d_verts, R, cap, pl, adj, cnt);
+  SD_LAUNCH_CHECK();
+  *planes = pl; *count = cnt; *cap_out = cap;
+  return 0;
+}
+}  // namespace sd
+
 extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const float* d_points, int n_polys, int n_rays, int n_faces,
                                const float* d_verts, const int* d_faces, float threshold, int use_bbox, int use_kdtree, int verbose,
                                uint8_t* d_keep, int64_t* stats, void* stream_) {

@@ -12,28 +12,36 @@
 // counter; a second pass maps index -> labels[index] with the first-writer / overlap rule.
 //
 // render_mode 0 ("full") in the reference is   kernel OR (hull AND union-of-tetrahedra)
-// (:1474-1477) where `hull` are Qhull's convex-hull half-spaces of the same vertices.
-// Geometrically union-of-tetrahedra is a subset of the hull, so the hull test only acts as an
-// early-out; it is NOT evaluated here (Qhull is not restated): mode 0 computes
-// kernel OR union-of-tetrahedra.  The two can differ only for a voxel that the fp32
-// tetrahedron test accepts although it lies outside the double-precision hull, i.e. within
-// ~1e-6 voxel of a hull face -- see DESIGN.md ("3D rasteriser: hull test").
-// render_mode 2 ("hull") would need the hull itself and fails loudly.
+// (:1474-1477) where `hull` are Qhull's convex-hull half-spaces of the same vertices; render_mode 2
+// ("hull") paints the hull itself.  The hulls come from the gift-wrapping kernel of the 3D NMS (nms3d.hip
+// k_hull, fp64, facets verified against every vertex), not from Qhull: same facets, planes not normalised
+// (the sign test is scale invariant), so a voxel can differ only if it lies within rounding distance
+// (~1e-12 voxel) of a hull facet -- see DESIGN.md ("3D rasteriser: hull test").  A polyhedron whose hull
+// cannot be built (degenerate vertex set; Qhull would throw) is treated as hull = all space in mode 0
+// and fails loudly in mode 2.
 #include "common.h"
 #include "geom3d.h"
 #include "../../include/stardist_hip.h"
 #include <limits.h>
 #include <vector>
 
+namespace sd {
+int hull_planes(const float* d_dist, const float* d_points, const float* d_verts, int n, int R, double** planes, int** count, int* cap_out,
+                hipStream_t s);
+}
+
 namespace {
 
 __global__ void __launch_bounds__(256) k_paint3d(const float* __restrict__ dist, const float* __restrict__ points,
                                                  const float* __restrict__ verts, const int* __restrict__ faces, int p0, int p1,
                                                  int n_rays, int n_faces, int nz, int ny, int nx, int render_mode,
-                                                 int* __restrict__ first, int* __restrict__ count, int* __restrict__ result_dbg) {
+                                                 int* __restrict__ first, int* __restrict__ count, int* __restrict__ result_dbg,
+                                                 const double* __restrict__ hullPlanes, const int* __restrict__ hullCount, int hullCap,
+                                                 int* __restrict__ hullFail) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* hs = (double*)smem;                          // n_faces * 4
-  float* pv = (float*)(hs + 4 * n_faces);              // n_rays * 3
+  double* hh = hs + 4 * n_faces;                       // hullCap * 4 (modes 0 and 2)
+  float* pv = (float*)(hh + 4 * hullCap);              // n_rays * 3
   int* fc = (int*)(pv + 3 * n_rays);                   // n_faces * 3
   __shared__ int sb[6];
   for (int k = threadIdx.x; k < 3 * n_faces; k += blockDim.x) fc[k] = faces[k];
@@ -55,6 +63,12 @@ __global__ void __launch_bounds__(256) k_paint3d(const float* __restrict__ dist,
     __syncthreads();
     for (int f = threadIdx.x; f < n_faces; f += blockDim.x)
       sd3::build_halfspace(&pv[3 * fc[3 * f]], &pv[3 * fc[3 * f + 1]], &pv[3 * fc[3 * f + 2]], &hs[4 * f]);   // :804-812
+    int nh = 0;                                                       // hull facets of this polyhedron (halfspaces_convex :767-795)
+    if (hullPlanes) {
+      nh = hullCount[p];
+      if (nh < 0) { nh = 0; if (threadIdx.x == 0 && render_mode == 2) atomicAdd(hullFail, 1); }
+      for (int k = threadIdx.x; k < 4 * nh; k += blockDim.x) hh[k] = hullPlanes[(size_t)p * hullCap * 4 + k];
+    }
     __syncthreads();
     const int zlo = max(0, sb[0]), zhi = min(nz - 1, sb[1]);
     const int ylo = max(0, sb[2]), yhi = min(ny - 1, sb[3]);
@@ -74,7 +88,17 @@ __global__ void __launch_bounds__(256) k_paint3d(const float* __restrict__ dist,
           if (hs[4 * f] * (double)z + hs[4 * f + 1] * (double)y + hs[4 * f + 2] * (double)x + hs[4 * f + 3] > 0) { in_kernel = false; break; }
         }
         inside = in_kernel;
-        if (!inside && render_mode == 0) inside = sd3::inside_polyhedron(z, y, x, cz, cy, cx, pv, fc, n_faces);
+        if (!inside && render_mode == 0) {                            // (in convex hull AND in rendered) :1474-1477
+          bool in_hull = true;
+          for (int f = 0; f < nh; ++f)
+            if (hh[4 * f] * (double)z + hh[4 * f + 1] * (double)y + hh[4 * f + 2] * (double)x + hh[4 * f + 3] > 0) { in_hull = false; break; }
+          inside = in_hull && sd3::inside_polyhedron(z, y, x, cz, cy, cx, pv, fc, n_faces);
+        }
+      } else if (render_mode == 2) {                                  // "convex" :1485-1487
+        bool in_hull = true;
+        for (int f = 0; f < nh; ++f)
+          if (hh[4 * f] * (double)z + hh[4 * f + 1] * (double)y + hh[4 * f + 2] * (double)x + hh[4 * f + 3] > 0) { in_hull = false; break; }
+        inside = in_hull && nh >= 4;
       } else if (render_mode == 3) {
         inside = true;
       } else if (render_mode == 4) {                                // "debug": flag kernel-but-not-polyhedron voxels with -1
@@ -132,13 +156,22 @@ extern "C" int sd_polyhedron_to_label_device(const float* d_dist, const float* d
     fflush(stdout);
   }
   if (n_polys <= 0 || nz <= 0 || ny <= 0 || nx <= 0) return 0;
-  if (render_mode == 2) { sd::set_error("sd_polyhedron_to_label: render_mode 'hull' needs the convex hull (Qhull) and is not implemented"); return -1; }
   if (render_mode < 0 || render_mode > 4) { sd::set_error("sd_polyhedron_to_label: unknown render_mode %d", render_mode); return -1; }
-  const size_t lds = (size_t)n_faces * 4 * sizeof(double) + (size_t)n_rays * 3 * sizeof(float) + (size_t)n_faces * 3 * sizeof(int);
+  const bool need_hull = (render_mode == 0 || render_mode == 2);
+  const int hullCapL = need_hull ? 2 * n_rays : 0;
+  const size_t lds = (size_t)(n_faces + hullCapL) * 4 * sizeof(double) + (size_t)n_rays * 3 * sizeof(float) + (size_t)n_faces * 3 * sizeof(int);
   if (lds > 150 * 1024) { sd::set_error("sd_polyhedron_to_label: n_rays/n_faces too large for LDS staging"); return -1; }
+  if (lds > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_paint3d, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const long long nvox = (long long)nz * ny * nx;
   sd::Arena& A = sd::arena();
   if (A.begin(s)) return -1;
+  double* hullPlanes = nullptr; int* hullCount = nullptr; int hullCap = 0;
+  int* hullFail = A.take_n<int>(1);
+  if (!hullFail) return -1;
+  SD_CHECK(hipMemsetAsync(hullFail, 0, sizeof(int), s));
+  if (need_hull && n_rays >= 4) {
+    if (sd::hull_planes(d_dist, d_points, d_verts, n_polys, n_rays, &hullPlanes, &hullCount, &hullCap, s)) return -1;
+  } else if (render_mode == 2) { sd::set_error("sd_polyhedron_to_label: render_mode 'hull' needs n_rays >= 4"); return -1; }
   int* first = A.take_n<int>(nvox);
   int* count = A.take_n<int>(nvox);
   if (!first || !count) return -1;
@@ -153,7 +186,7 @@ extern "C" int sd_polyhedron_to_label_device(const float* d_dist, const float* d
     SD_CHECK(hipMemsetAsync(count, 0, nvox * sizeof(int), s));
     const int blocks = n_polys < 8192 ? n_polys : 8192;
     hipLaunchKernelGGL(k_paint3d, dim3(blocks), dim3(256), lds, s, d_dist, d_points, d_verts, d_faces, 0, n_polys, n_rays, n_faces,
-                       nz, ny, nx, render_mode, first, count, d_result);
+                       nz, ny, nx, render_mode, first, count, d_result, hullPlanes, hullCount, hullCapL, hullFail);
     SD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_resolve3d, dim3(gb), dim3(256), 0, s, d_result, first, count, nvox, d_labels, use_overlap_label, overlap_label);
     SD_LAUNCH_CHECK();
@@ -163,10 +196,16 @@ extern "C" int sd_polyhedron_to_label_device(const float* d_dist, const float* d
       hipLaunchKernelGGL(k_fill, dim3(gb), dim3(256), 0, s, first, nvox, INT_MAX);
       SD_CHECK(hipMemsetAsync(count, 0, nvox * sizeof(int), s));
       hipLaunchKernelGGL(k_paint3d, dim3(1), dim3(256), lds, s, d_dist, d_points, d_verts, d_faces, p, p + 1, n_rays, n_faces, nz, ny,
-                         nx, render_mode, first, count, d_result);
+                         nx, render_mode, first, count, d_result, hullPlanes, hullCount, hullCapL, hullFail);
       hipLaunchKernelGGL(k_resolve3d_seq, dim3(gb), dim3(256), 0, s, d_result, first, count, nvox, h_labels[p], use_overlap_label, overlap_label);
       SD_LAUNCH_CHECK();
     }
+  }
+  if (render_mode == 2) {
+    int hf = 0;
+    SD_CHECK(hipMemcpyAsync(&hf, hullFail, sizeof(int), hipMemcpyDeviceToHost, s));
+    SD_CHECK(hipStreamSynchronize(s));
+    if (hf) { sd::set_error("sd_polyhedron_to_label: the convex hull of %d polyhedra could not be built (degenerate vertices; Qhull raises here)", hf); return -1; }
   }
   return 0;
 }

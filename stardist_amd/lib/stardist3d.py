@@ -60,8 +60,6 @@ def c_polyhedron_to_label(dist, points, verts, faces, labels, render_mode, verbo
     labels = np.ascontiguousarray(labels, np.int32)
     out = np.zeros((nz, ny, nx), np.int32)
     if dist.shape[0]:
-        if int(render_mode) == 2:
-            raise N.NativeError("render mode 'hull' needs the convex hull (Qhull) and is not implemented")
         N.lib()._LIB_polyhedron_to_label(N.ptr(dist), N.ptr(points), N.ptr(verts), N.ptr(faces), dist.shape[0], dist.shape[1],
                                          faces.shape[0], N.ptr(labels), nz, ny, nx, int(render_mode), int(verbose),
                                          int(use_overlap_label), int(overlap_label), N.ptr(out))

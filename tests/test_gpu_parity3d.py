@@ -43,8 +43,9 @@ def test_star_dist3d_bit_exact(refmods, n_rays, grid):
     assert np.array_equal(d, ref_d), np.abs(d - ref_d).max()
 
 
-@pytest.mark.parametrize("mode,overlap", [(0, None), (1, None), (3, None), (0, 77), (0, -3)])
+@pytest.mark.parametrize("mode,overlap", [(0, None), (1, None), (2, None), (3, None), (4, None), (0, 77), (0, -3), (2, 5)])
 def test_polyhedron_to_label_identical(refmods, mode, overlap):
+    """all five render modes of stardist3d_impl.cpp:1469-1509: full, kernel, hull (convex), bbox, debug"""
     from oracle import synth
     from stardist_amd.lib import stardist3d as sd3
     rays = _rays(96)
