@@ -107,8 +107,17 @@ class StarDistBase(object):
         self.net = self._build()
         from .unet import init_he_normal_
         init_he_normal_(self.net, seed)
-        if self.logdir is not None and os.path.exists(os.path.join(self.logdir, "weights.npz")):
-            self.load_weights_npz(os.path.join(self.logdir, "weights.npz"))
+        if self.logdir is not None:
+            # model folder weights: the .npz written by tools/keras_to_npz.py / save_weights_npz, else the Keras .h5 (needs h5py)
+            for wname in ("weights.npz", "weights_best.npz", "weights_last.npz"):
+                if os.path.exists(os.path.join(self.logdir, wname)):
+                    self.load_weights_npz(os.path.join(self.logdir, wname))
+                    break
+            else:
+                for wname in ("weights_best.h5", "weights_last.h5", "weights_now.h5"):
+                    if os.path.exists(os.path.join(self.logdir, wname)):
+                        self.load_weights_h5(os.path.join(self.logdir, wname))
+                        break
         self.net = self.net.to(self.device).eval()
         if self.device.type == "cuda":
             # let MIOpen time its solvers per conv shape once (find mode) instead of the immediate-mode heuristic:
@@ -131,6 +140,57 @@ class StarDistBase(object):
 
     def _is_multiclass(self):
         return self.config.n_classes is not None
+
+    @classmethod
+    def from_pretrained(cls, name_or_alias=None, **kwargs):
+        """csbdeep BaseModel.from_pretrained: `StarDist2D.from_pretrained('2D_versatile_fluo')`; without an argument the
+        registered models are printed and None is returned (registry: stardist/models/__init__.py:19-27)."""
+        from . import pretrained
+        if name_or_alias is None:
+            pretrained.print_registered(cls.__name__)
+            return None
+        folder = pretrained.get_model_folder(cls.__name__, name_or_alias)
+        print("Found model '%s' for '%s'." % (os.path.basename(folder), cls.__name__))
+        return cls(config=None, name=os.path.basename(folder), basedir=os.path.dirname(folder), **kwargs)
+
+    def load_weights_h5(self, path):
+        """Keras HDF5 weights of a csbdeep model folder (needs h5py): converted in memory to the .npz layout, then loaded by name"""
+        try:
+            import h5py  # noqa: F401
+        except ImportError:
+            raise ImportError("reading %s needs h5py; convert it once with tools/keras_to_npz.py on a machine that has it" % path)
+        import io
+        import sys as _sys
+        _sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools"))
+        from keras_to_npz import convert
+        buf = io.BytesIO()
+        convert(path, buf)
+        buf.seek(0)
+        self.load_weights_npz(buf)
+
+    def save_weights_npz(self, path):
+        """inverse of load_weights_npz: Keras variable names and layouts ((k..., cin, cout) kernels), heads under their layer names"""
+        import torch.nn as nn
+        named = {id(self.net.prob): "prob", id(self.net.dist): "dist"}
+        if isinstance(self.net.features, nn.Sequential):
+            named[id(self.net.features[0])] = "features"
+        if self.net.n_classes is not None:
+            named[id(self.net.prob_class)] = "prob_class"
+            if isinstance(self.net.features_class, nn.Sequential):
+                named[id(self.net.features_class[0])] = "features_class"
+        out, k = {}, 0
+        for m in self.net.modules():
+            if isinstance(m, (nn.Conv2d, nn.Conv3d)):
+                if id(m) in named:
+                    name = named[id(m)]
+                else:
+                    name = "conv%dd_%d" % (self.config.n_dim, k); k += 1
+                w = m.weight.detach().cpu().numpy()
+                nd = w.ndim - 2
+                out[name + "/kernel:0"] = np.ascontiguousarray(np.transpose(w, tuple(range(2, 2 + nd)) + (1, 0)))
+                if m.bias is not None:
+                    out[name + "/bias:0"] = m.bias.detach().cpu().numpy()
+        np.savez(path, **out)
 
     def load_weights_npz(self, path):
         """weights exported from Keras (tools/keras_to_npz.py) as {layer_name/kernel:0, layer_name/bias:0, ...}.

@@ -1,0 +1,61 @@
+"""CPU: the pre-trained model registry and from_pretrained (csbdeep BaseModel.from_pretrained + stardist/models/__init__.py:19-27),
+on the reference's own example model folders (config.json / thresholds.json fixtures, tests/golden/make_pretrained_fixture.py) with
+seeded weights written in the Keras .npz layout (the real weight files are not available offline)."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_registry_matches_reference_registrations():
+    from stardist_amd.models import pretrained
+    keys, aliases = pretrained.get_registered_models("StarDist2D")
+    assert keys == ("2D_versatile_fluo", "2D_versatile_he", "2D_paper_dsb2018", "2D_demo")
+    assert pretrained.get_registered_models("StarDist3D", return_aliases=False) == ("3D_demo",)
+    assert pretrained.resolve("StarDist2D", "Versatile (fluorescent nuclei)") == "2D_versatile_fluo"
+    assert pretrained.resolve("StarDist2D", "Versatile (H&E nuclei)") == "2D_versatile_he"
+    assert pretrained.resolve("StarDist2D", "DSB 2018 (from StarDist 2D paper)") == "2D_paper_dsb2018"
+    assert pretrained._MODELS["StarDist2D"]["2D_versatile_fluo"]["md5"] == "8db40dacb5a1311b8d2c447ad934fb8a"
+    with pytest.raises(ValueError):
+        pretrained.resolve("StarDist2D", "3D_demo")
+
+
+@pytest.mark.parametrize("cls_name,key", [("StarDist2D", "2D_demo"), ("StarDist3D", "3D_demo")])
+def test_from_pretrained_loads_config_thresholds_and_weights(cls_name, key, tmp_path, monkeypatch, capsys):
+    import torch
+    import stardist_amd.models as M
+    cls = getattr(M, cls_name)
+    cache = tmp_path / "cache"
+    shutil.copytree(os.path.join(ROOT, "tests", "golden", "pretrained"), str(cache))
+    monkeypatch.setenv("STARDIST_AMD_MODELS", str(cache))
+    monkeypatch.setenv("HOME", str(tmp_path / "nohome"))
+    # 1) no weights in the folder: seeded init, config and thresholds from the folder
+    m0 = cls.from_pretrained(key, device="cpu")
+    assert "Found model '%s'" % key in capsys.readouterr().out
+    if key == "2D_demo":
+        assert m0.config.n_rays == 32 and tuple(m0.config.grid) == (2, 2) and m0.config.net_conv_after_unet == 128
+        assert abs(m0.thresholds.prob - 0.4861655269131771) < 1e-12 and m0.thresholds.nms == 0.5
+    else:
+        assert m0.config.n_dim == 3 and m0.config.backbone == "resnet" and tuple(m0.config.grid) == (1, 2, 2) and m0.config.n_rays == 96
+    # 2) weights written in the Keras layout by another instance are picked up by from_pretrained (round trip)
+    src = cls(m0.config, basedir=None, device="cpu", seed=123)
+    src.save_weights_npz(str(cache / cls_name / key / "weights_best.npz"))
+    m1 = cls.from_pretrained(key, device="cpu")
+    for (n1, p1), (n2, p2) in zip(src.net.state_dict().items(), m1.net.state_dict().items()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+    # the loaded model predicts like the source model
+    shape = (32, 48) if m0.config.n_dim == 2 else (8, 32, 32)
+    x = np.random.RandomState(0).rand(*shape).astype(np.float32)
+    a, b = src.predict(x), m1.predict(x)
+    assert all(np.array_equal(u, v) for u, v in zip(a, b))
+    # 3) aliases, listing, unknown names, missing folders
+    assert cls.from_pretrained(None) is None and key in capsys.readouterr().out
+    with pytest.raises(ValueError):
+        cls.from_pretrained("no such model")
+    if cls_name == "StarDist2D":
+        with pytest.raises(FileNotFoundError) as e:
+            cls.from_pretrained("Versatile (fluorescent nuclei)")          # registered, but neither cached nor downloadable offline
+        assert "python_2D_versatile_fluo.zip" in str(e.value)
