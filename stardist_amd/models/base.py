@@ -190,6 +190,10 @@ class StarDistBase(object):
                 out[name + "/kernel:0"] = np.ascontiguousarray(np.transpose(w, tuple(range(2, 2 + nd)) + (1, 0)))
                 if m.bias is not None:
                     out[name + "/bias:0"] = m.bias.detach().cpu().numpy()
+        for j, m in enumerate(mm for mm in self.net.modules() if isinstance(mm, (nn.BatchNorm2d, nn.BatchNorm3d))):
+            base = "batch_normalization_%d/" % j
+            out[base + "gamma:0"] = m.weight.detach().cpu().numpy(); out[base + "beta:0"] = m.bias.detach().cpu().numpy()
+            out[base + "moving_mean:0"] = m.running_mean.cpu().numpy(); out[base + "moving_variance:0"] = m.running_var.cpu().numpy()
         np.savez(path, **out)
 
     def load_weights_npz(self, path):
@@ -238,6 +242,19 @@ class StarDistBase(object):
             put(m, by_name[n])
         for m, kn in zip(backbone, rest):
             put(m, kn)
+        # batch normalisation layers (unet_batch_norm=True), in graph order: gamma, beta, moving_mean, moving_variance
+        bns = [m for m in self.net.modules() if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d))]
+        gam = [k for k in data.files if k.endswith("gamma:0")]
+        if len(gam) != len(bns):
+            raise ValueError("weight file has %d batch-normalisation layers, network has %d" % (len(gam), len(bns)))
+        for m, gk in zip(bns, gam):
+            base = gk[:-len("gamma:0")]
+            with torch.no_grad():
+                for attr, suffix in ((m.weight, "gamma:0"), (m.bias, "beta:0"), (m.running_mean, "moving_mean:0"), (m.running_var, "moving_variance:0")):
+                    v = data[base + suffix]
+                    if tuple(v.shape) != tuple(attr.shape):
+                        raise ValueError("%s%s does not fit its layer" % (base, suffix))
+                    attr.copy_(torch.from_numpy(v))
 
     # ------------------------------------------------------------------ helpers
     def _normalize_axes(self, img, axes):

@@ -101,17 +101,25 @@ class ConvAct(nn.Sequential):
     framework element-wise kernels; everywhere else (CPU, training, other activations) it is the plain Sequential."""
 
     def forward(self, x):
+        if len(self) != 2:                      # [conv, batch-norm, activation] (unet_batch_norm=True): plain modules
+            return super().forward(x)
         conv, act = self[0], self[1]
         kind = 0 if isinstance(act, nn.Identity) else (1 if isinstance(act, nn.ReLU) else -1)
         y = _conv_bias_act(conv, x, kind) if kind >= 0 else None
         return super().forward(x) if y is None else y
 
 
-def _conv(nd, cin, cout, k, act="relu", bias=True):
+def _conv(nd, cin, cout, k, act="relu", bias=True, batch_norm=False):
     k = tuple(k) if isinstance(k, (tuple, list)) else (k,) * nd
     Conv = nn.Conv2d if nd == 2 else nn.Conv3d
     assert all(kk % 2 == 1 for kk in k), "Keras 'same' padding restated for odd kernels only"
-    return ConvAct(Conv(cin, cout, k, padding=tuple(kk // 2 for kk in k), bias=bias), _act(act))
+    conv = Conv(cin, cout, k, padding=tuple(kk // 2 for kk in k), bias=bias)
+    if batch_norm:
+        # csbdeep conv_block2/3 (csbdeep/internals/blocks.py): Conv -> BatchNormalization -> Activation; Keras defaults
+        # epsilon = 1e-3, momentum 0.99 (inference uses the moving statistics)
+        BN = nn.BatchNorm2d if nd == 2 else nn.BatchNorm3d
+        return ConvAct(conv, BN(cout, eps=1e-3, momentum=0.01), _act(act))
+    return ConvAct(conv, _act(act))
 
 
 class UNetBlock(nn.Module):
@@ -121,9 +129,9 @@ class UNetBlock(nn.Module):
     def __init__(self, nd, cin, n_depth, n_filter_base, kernel_size, n_conv_per_depth, activation, last_activation, pool,
                  batch_norm=False):
         super().__init__()
-        if batch_norm:
-            raise NotImplementedError("unet_batch_norm=True is not supported yet")
         self.nd, self.n_depth, self.pool = nd, n_depth, tuple(pool)
+        import functools
+        _conv = functools.partial(globals()["_conv"], batch_norm=batch_norm)
         self.down = nn.ModuleList()
         c = cin
         for n in range(n_depth):

@@ -1,0 +1,69 @@
+"""Command line script to perform prediction in 2D (mirror of stardist/scripts/predict2d.py: same options)."""
+import argparse
+import pathlib
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter, description="""
+Prediction script for a 2D stardist model, usage: stardist-predict2d -i input.tif -m model_folder_or_pretrained_name -o output_folder
+""")
+    parser.add_argument("-i", "--input", type=str, nargs="+", required=True, help="input file (tiff)")
+    parser.add_argument("-o", "--outdir", type=str, default=".", help="output directory")
+    parser.add_argument("--outname", type=str, default="{img}.stardist.tif", help="output file name (tiff)")
+    group = parser.add_mutually_exclusive_group(required=True)
+    group.add_argument("-m", "--model", type=str, default=None, help="model folder / pretrained model to use")
+    parser.add_argument("--axes", type=str, default=None, help="axes to use for the input, e.g. 'XYC'")
+    parser.add_argument("--n_tiles", type=int, nargs=2, default=None, help="number of tiles to use for prediction")
+    parser.add_argument("--pnorm", type=float, nargs=2, default=[1, 99.8], help="pmin/pmax to use for normalization")
+    parser.add_argument("--prob_thresh", type=float, default=None, help="prob_thresh for model (if not given use model default)")
+    parser.add_argument("--nms_thresh", type=float, default=None, help="nms_thresh for model (if not given use model default)")
+    parser.add_argument("--device", type=str, default=None, help="torch device (default: cuda if available)")
+    parser.add_argument("-v", "--verbose", action="store_true")
+    args = parser.parse_args(argv)
+
+    from stardist_amd.models import StarDist2D, pretrained
+    from stardist_amd.scripts._io import imread, imwrite
+    from stardist_amd.utils import normalize
+
+    if pathlib.Path(args.model).is_dir():
+        p = pathlib.Path(args.model).resolve()
+        model = StarDist2D(None, name=p.name, basedir=str(p.parent), device=args.device)
+    else:
+        try:
+            model = StarDist2D.from_pretrained(args.model, device=args.device)
+        except ValueError:
+            model = None
+    if model is None:
+        pretrained.print_registered("StarDist2D")
+        raise ValueError("unknown model: %s" % args.model)
+
+    for fname in args.input:
+        if args.verbose:
+            print("reading image %s" % fname)
+        if 2 == 3 and pathlib.Path(fname).suffix.lower() not in (".tif", ".tiff"):
+            raise ValueError("only tiff files supported in 3D for now")
+        img = imread(fname)
+        ok_ndim = (2, 3) if 2 == 2 else (3, 4)
+        if img.ndim not in ok_ndim:
+            raise ValueError("currently only %dd and %dd images are supported by the prediction script" % ok_ndim)
+        axes = args.axes
+        if axes is None:
+            axes = {2: "YX", 3: "YXC"}[img.ndim] if 2 == 2 else {3: "ZYX", 4: "ZYXC"}[img.ndim]
+        if len(axes) != img.ndim:
+            raise ValueError("dimension of input (%d) not the same as length of given axes (%d)" % (img.ndim, len(axes)))
+        if args.verbose:
+            print("loaded image of size %s\nnormalizing..." % (img.shape,))
+        img = normalize(img, *args.pnorm)
+        n_tiles = args.n_tiles
+        if n_tiles is not None and len(n_tiles) != img.ndim:          # the option names the spatial axes only
+            sp = iter(n_tiles)
+            n_tiles = tuple(next(sp) if a in "XYZ" else 1 for a in axes)
+        labels, _ = model.predict_instances(img, axes=axes, n_tiles=n_tiles, prob_thresh=args.prob_thresh, nms_thresh=args.nms_thresh)
+        out = pathlib.Path(args.outdir)
+        out.mkdir(parents=True, exist_ok=True)
+        imwrite(out / args.outname.format(img=pathlib.Path(fname).with_suffix("").name), labels)
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -244,3 +244,32 @@ def test_gemm_form_of_small_convolutions_equals_conv(nd):
     w = torch.randn((4, 5) + (3, 3, 3)[:nd], generator=g)
     ref = (F.conv2d if nd == 2 else F.conv3d)(x, w, padding=1)
     assert torch.allclose(_gemm_conv(x, w), ref, atol=1e-5)
+
+
+def test_unet_batch_norm_matches_keras_semantics_and_round_trips(tmp_path):
+    """unet_batch_norm=True (model2d.py:218): Conv -> BatchNormalization(eps 1e-3, moving statistics) -> activation"""
+    import torch
+    import torch.nn as nn
+    from stardist_amd.models import Config2D, StarDist2D
+    cfg = Config2D(n_rays=8, unet_n_depth=1, unet_n_filter_base=4, unet_batch_norm=True)
+    m = StarDist2D(cfg, basedir=None, device="cpu", seed=0)
+    bns = [b for b in m.net.modules() if isinstance(b, nn.BatchNorm2d)]
+    assert len(bns) == 6 and all(b.eps == 1e-3 for b in bns)      # every conv of the unet block (2 down + 2 middle + 2 up)
+    g = torch.Generator().manual_seed(1)
+    for b in bns:                       # non-trivial statistics
+        with torch.no_grad():
+            b.weight.copy_(torch.rand(b.weight.shape, generator=g) + 0.5); b.bias.copy_(torch.randn(b.bias.shape, generator=g))
+            b.running_mean.copy_(torch.randn(b.bias.shape, generator=g)); b.running_var.copy_(torch.rand(b.bias.shape, generator=g) + 0.1)
+    # first block by hand: y = relu(gamma * (conv(x) - mean) / sqrt(var + 1e-3) + beta)
+    x = torch.randn(1, 1, 16, 16, generator=g)
+    blk = m.net.backbone.down[0][0]
+    conv, bn = blk[0], blk[1]
+    want = torch.relu(bn.weight.view(1, -1, 1, 1) * (conv(x) - bn.running_mean.view(1, -1, 1, 1)) / torch.sqrt(bn.running_var.view(1, -1, 1, 1) + 1e-3) + bn.bias.view(1, -1, 1, 1))
+    with torch.no_grad():
+        assert torch.allclose(blk(x), want, atol=1e-6)
+    path = str(tmp_path / "w.npz")
+    m.save_weights_npz(path)
+    m2 = StarDist2D(cfg, basedir=None, device="cpu", seed=5)
+    m2.load_weights_npz(path)
+    for (n1, p1), (n2, p2) in zip(m.net.state_dict().items(), m2.net.state_dict().items()):
+        assert n1 == n2 and (torch.equal(p1, p2) or "num_batches" in n1), n1
