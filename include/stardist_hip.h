@@ -113,6 +113,14 @@ int sd_nms3d_device(const float* d_scores, const float* d_dist, const float* d_p
                     const int* d_faces, float threshold, int use_bbox, int use_kdtree,
                     int verbose, uint8_t* d_keep, int64_t* stats, void* stream);
 
+/* Test probe of the two volume stages of the 3D cascade: for every pair (i, j) of d_pairs (int32 [n_pairs][2], indices into the
+ * n_polys candidates) the intersection volume of the two KERNELS (replaces qhull_overlap_kernel, stardist3d_impl.cpp:830-869,
+ * 0 if the midpoint of the centres is not interior) and of the two CONVEX HULLS (replaces qhull_overlap_convex_hulls, :872-939,
+ * 1e10 on failure), as float64.  Either output pointer may be NULL. */
+int sd_hiv_pairs_device(const float* d_dist, const float* d_points, int n_polys, int n_rays, int n_faces,
+                        const float* d_verts, const int* d_faces, const int32_t* d_pairs, int n_pairs,
+                        double* d_vol_kernel, double* d_vol_hull, void* stream);
+
 /* ---- 3D label rasteriser --------------------------------------------------------------------
  * name, signature and semantics of the reference's C ABI
  *   (stardist/lib/stardist3d_lib.h:69-77 -> _COMMON_polyhedron_to_label,

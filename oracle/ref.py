@@ -100,3 +100,21 @@ def clipper_paths(xa, ya, xb, yb):
         paths.append(out[2 * k:2 * (k + lens[r])].reshape(-1, 2).copy())
         k += lens[r]
     return paths
+
+
+def pair_volumes(dist, points, verts, faces, pairs, kernel=True, hull=True):
+    """reference qhull_overlap_kernel / qhull_overlap_convex_hulls (stardist3d_impl.cpp:830-939) per pair, float32 as they return"""
+    if "qh" not in _cache:
+        lib = ctypes.CDLL(os.path.join(_REF, "libqhull_ref.so"))
+        lib.ref_pair_volumes.restype = None
+        _cache["qh"] = lib
+    dist = np.ascontiguousarray(dist, np.float32); points = np.ascontiguousarray(points, np.float32)
+    verts = np.ascontiguousarray(verts, np.float32); faces = np.ascontiguousarray(faces, np.int32)
+    pairs = np.ascontiguousarray(pairs, np.int32)
+    vk = np.zeros(len(pairs), np.float32) if kernel else None
+    vh = np.zeros(len(pairs), np.float32) if hull else None
+    vp = ctypes.c_void_p
+    _cache["qh"].ref_pair_volumes(vp(dist.ctypes.data), vp(points.ctypes.data), vp(verts.ctypes.data), vp(faces.ctypes.data), vp(pairs.ctypes.data),
+                                  ctypes.c_int(len(pairs)), ctypes.c_int(dist.shape[1]), ctypes.c_int(len(faces)),
+                                  vp(vk.ctypes.data) if kernel else None, vp(vh.ctypes.data) if hull else None)
+    return vk, vh

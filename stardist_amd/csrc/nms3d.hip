@@ -714,7 +714,8 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
                                                const float* __restrict__ pts, const float* __restrict__ verts,
                                                const int* __restrict__ faces, const int* __restrict__ faceAdj, int R, int F,
                                                const float* __restrict__ volume, float thr, unsigned char* __restrict__ state,
-                                               int2* __restrict__ pairs5, unsigned int* pair5Count, Stats* st, unsigned int wsBytes) {
+                                               int2* __restrict__ pairs5, unsigned int* pair5Count, Stats* st, unsigned int wsBytes,
+                                               double* __restrict__ volOut = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* hs = (double*)smem;                 // 2F * 4
   float* pv1 = (float*)(hs + 8 * F);          // 3R   (dead once hs is built: aliased by the polygon workspace)
@@ -791,6 +792,7 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
         vol = hiv_volume_wave(hs, Mc, zero3, L, W, lane, st);
       }
     }
+    if (volOut) { if (lane == 0) volOut[p] = vol; continue; }     // pair-level probe (sd_hiv_pairs_device): the volume itself
     if (lane == 0) {
       atomicAdd(&st->kernel, 1ull);
       if (vol != vol) atomicAdd(&st->overflow, 1ull);   // polygon capacity overflow (reported as an error by the host)
@@ -1112,7 +1114,8 @@ __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, u
                                                const int* __restrict__ faces, int R, int F, int cap, const double* __restrict__ hullPlanes,
                                                const unsigned short* __restrict__ hullAdj, const int* __restrict__ hullCount,
                                                const float* __restrict__ volume, float thr,
-                                               int2* __restrict__ pairs5, unsigned int* pair5Count, Stats* st, int no_lb) {
+                                               int2* __restrict__ pairs5, unsigned int* pair5Count, Stats* st, int no_lb,
+                                               double* __restrict__ volOut = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* hs = (double*)smem;                   // 2*cap*4
   unsigned short* seed = (unsigned short*)(smem + (size_t)8 * cap * sizeof(double) + hiv_poly_bytes_dev());   // 2*cap*3
@@ -1178,6 +1181,7 @@ __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, u
         if (lane == 0) atomicAdd(&st->ub_decided, 1ull);
       } else vol = hiv_volume_wave(hs, Mc, zero3, L, W, lane, st);
     }
+    if (volOut) { if (lane == 0) volOut[p] = vol; continue; }     // pair-level probe
     if (lane == 0) {
       atomicAdd(&st->convex, 1ull);
       if (vol != vol) atomicAdd(&st->overflow, 1ull);
@@ -1267,6 +1271,12 @@ namespace sd {
 // Convex hulls of n polyhedra (the half-spaces Qhull gives the reference in halfspaces_convex, stardist3d_impl.cpp:767-795):
 // planes[(i*cap + f)*4 .. +3] = (nz, ny, nx, offset) with inside <=> n.p + offset <= 0, count[i] facets (cap = 2*n_rays),
 // count[i] == -2 if the hull could not be built.  Buffers come from the CURRENT arena pass (caller has called begin()).
+static unsigned short* g_last_hull_adj = nullptr;
+unsigned short* last_hull_adj() { return g_last_hull_adj; }
+int hull_planes(const float* d_dist, const float* d_points, const float* d_verts, int n, int R, double** planes, int** count, int* cap_out,
+                hipStream_t s);
+int hull_planes_adj(const float* d_dist, const float* d_points, const float* d_verts, int n, int R, double** planes, int** count, int* cap_out,
+                    hipStream_t s) { return hull_planes(d_dist, d_points, d_verts, n, R, planes, count, cap_out, s); }
 int hull_planes(const float* d_dist, const float* d_points, const float* d_verts, int n, int R, double** planes, int** count, int* cap_out,
                 hipStream_t s) {
   if (R < 4 || R > 800) { sd::set_error("hull_planes: n_rays=%d unsupported (4..800)", R); return -1; }
@@ -1285,10 +1295,58 @@ int hull_planes(const float* d_dist, const float* d_points, const float* d_verts
   const unsigned int bh = n < 32768 ? (unsigned int)n : 32768u;
   hipLaunchKernelGGL(k_hull, dim3(bh), dim3(64), ldsH, s, list, (unsigned int)n, d_dist, d_points, d_verts, R, cap, pl, adj, cnt);
   SD_LAUNCH_CHECK();
-  *planes = pl; *count = cnt; *cap_out = cap;
+  *planes = pl; *count = cnt; *cap_out = cap; g_last_hull_adj = adj;
   return 0;
 }
 }  // namespace sd
+
+// Pair-level probe of the two volume stages (tests): for every pair (i, j) the EXACT intersection volume of the two kernels
+// (reference: qhull_overlap_kernel :830-869, error value 0) and of the two convex hulls (qhull_overlap_convex_hulls :872-939,
+// error value 1e10), computed by the same wave-cooperative fp64 routines the NMS cascade runs, with the bound shortcuts off.
+extern "C" int sd_hiv_pairs_device(const float* d_dist, const float* d_points, int n_polys, int n_rays, int n_faces, const float* d_verts,
+                                   const int* d_faces, const int32_t* d_pairs, int n_pairs, double* d_vol_kernel, double* d_vol_hull, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  const int N = n_polys, R = n_rays, F = n_faces;
+  if (n_pairs <= 0) return 0;
+  if (R < 4 || F < 4 || R > 800) { sd::set_error("sd_hiv_pairs: need 4 <= n_rays <= 800 and n_faces >= 4"); return -1; }
+  const size_t hivBytes = hiv_poly_bytes();
+  const size_t ws3 = ((size_t)3 * R * sizeof(double) + 2 * R > hivBytes ? (((size_t)3 * R * sizeof(double) + 2 * R + 15) & ~(size_t)15) : hivBytes);
+  const size_t lds3 = (size_t)8 * F * sizeof(double) + ws3 + (size_t)10 * F * sizeof(unsigned short);
+  const size_t lds4 = (size_t)16 * R * sizeof(double) + hivBytes + (size_t)20 * R * sizeof(unsigned short);
+  if (lds3 > 150 * 1024 || lds4 > 150 * 1024) { sd::set_error("sd_hiv_pairs: n_rays/n_faces too large for LDS staging"); return -1; }
+  if (lds3 > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_stage3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+  if (lds4 > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_stage4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+  sd::Arena& A = sd::arena();
+  if (A.begin(s)) return -1;
+  float* volume = A.take_n<float>(N);                       // only read by the (disabled) bound shortcuts
+  int* faceAdj = A.take_n<int>((size_t)3 * F);
+  Stats* d_st = (Stats*)A.take(sizeof(Stats));
+  unsigned int* dummyCount = A.take_n<unsigned int>(1);
+  unsigned char* state = A.take_n<unsigned char>(N);
+  if (!volume || !faceAdj || !d_st || !dummyCount || !state) return -1;
+  SD_CHECK(hipMemsetAsync(volume, 0, (size_t)N * sizeof(float), s));
+  SD_CHECK(hipMemsetAsync(d_st, 0, sizeof(Stats), s));
+  hipLaunchKernelGGL(k_face_adj, dim3(sd::div_up(F, 64)), dim3(64), 0, s, d_faces, F, faceAdj);
+  const int2* pairs = (const int2*)d_pairs;
+  const unsigned int nb = (unsigned int)n_pairs < 16384u ? (unsigned int)n_pairs : 16384u;
+  if (d_vol_kernel) {
+    hipLaunchKernelGGL(k_stage3, dim3(nb), dim3(64), lds3, s, pairs, (unsigned int)n_pairs, d_dist, d_points, d_verts, d_faces, faceAdj, R, F, volume,
+                       0.f, state, (int2*)nullptr, dummyCount, d_st, (unsigned int)ws3 | 0x80000000u, d_vol_kernel);
+    SD_LAUNCH_CHECK();
+  }
+  if (d_vol_hull) {
+    double* planes = nullptr; int* count = nullptr; int cap = 0;
+    if (sd::hull_planes_adj(d_dist, d_points, d_verts, N, R, &planes, &count, &cap, s)) return -1;
+    hipLaunchKernelGGL(k_stage4, dim3(nb), dim3(64), lds4, s, pairs, (unsigned int)n_pairs, d_dist, d_points, d_verts, d_faces, R, F, cap, planes,
+                       sd::last_hull_adj(), count, volume, 0.f, (int2*)nullptr, dummyCount, d_st, 1, d_vol_hull);
+    SD_LAUNCH_CHECK();
+  }
+  Stats hst;
+  SD_CHECK(hipMemcpyAsync(&hst, d_st, sizeof(Stats), hipMemcpyDeviceToHost, s));
+  SD_CHECK(hipStreamSynchronize(s));
+  if (hst.overflow) { sd::set_error("sd_hiv_pairs: %llu pairs exceeded the polygon capacity of the volume routine", hst.overflow); return -1; }
+  return 0;
+}
 
 extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const float* d_points, int n_polys, int n_rays, int n_faces,
                                const float* d_verts, const int* d_faces, float threshold, int use_bbox, int use_kdtree, int verbose,

@@ -42,6 +42,7 @@ SIGNATURES = {
     "sd_polygons_to_label_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "_LIB_non_maximum_suppression_sparse": (None, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _i, _i, _i, _vp]),
     "sd_nms3d_device": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
+    "sd_hiv_pairs_device": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "_LIB_polyhedron_to_label": (None, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sd_polyhedron_to_label_device": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "sd_select_candidates_device": (_i, [_vp, _vp, _i, _vp, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -151,3 +151,20 @@ def c_dist_to_centroid(dist, verts, faces, absolute):
     """stardist3d.cpp:196-243 -> _COMMON_dist_to_centroid (:1558-1589): dist (Z,Y,X,R) -> centroids (Z,Y,X,3) float32 (z,y,x),
     relative to the voxel or (absolute=1) in volume coordinates."""
     return _analysis_call(_dist_to_centroid_t, dist, verts, faces, int(absolute))
+
+
+def hiv_pair_volumes(dist, points, verts, faces, pairs, kernel=True, hull=True):
+    """Pair-level probe (tests): intersection volume of the kernels / of the convex hulls of polyhedra pairs[:,0], pairs[:,1]
+    as the 3D NMS cascade computes them (float64).  Returns (vol_kernel | None, vol_hull | None)."""
+    import torch
+    N.require_device()
+    dev = torch.device("cuda")
+    d = torch.from_numpy(np.ascontiguousarray(dist, np.float32)).to(dev); p = torch.from_numpy(np.ascontiguousarray(points, np.float32)).to(dev)
+    v = torch.from_numpy(np.ascontiguousarray(verts, np.float32)).to(dev); f = torch.from_numpy(np.ascontiguousarray(faces, np.int32)).to(dev)
+    pr = torch.from_numpy(np.ascontiguousarray(pairs, np.int32)).to(dev)
+    vk = torch.zeros(len(pairs), dtype=torch.float64, device=dev) if kernel else None
+    vh = torch.zeros(len(pairs), dtype=torch.float64, device=dev) if hull else None
+    N.dcall(d, "sd_hiv_pairs_device", N.tptr(d), N.tptr(p), d.shape[0], d.shape[1], f.shape[0], N.tptr(v), N.tptr(f), N.tptr(pr), len(pairs),
+            N.tptr(vk) if kernel else None, N.tptr(vh) if hull else None)
+    torch.cuda.synchronize()
+    return (vk.cpu().numpy() if kernel else None), (vh.cpu().numpy() if hull else None)

@@ -152,3 +152,34 @@ def test_dist_to_volume_and_centroid_vs_reference(refmods):
     assert np.allclose(dist_to_volume(dist, rays), m3.c_dist_to_volume(dist, V, F), rtol=1e-5, atol=1e-4)
     for mode in ("absolute", "relative"):
         assert np.allclose(dist_to_centroid(dist, rays, mode), m3.c_dist_to_centroid(dist, V, F, int(mode == "absolute")), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("n_rays,noise", [(96, 0.05), (96, 0.3), (32, 0.2)])
+def test_pair_volumes_match_qhull(refmods, n_rays, noise):
+    """stages 3 and 4 at the pair level (the analogue of the 2D Clipper probe): the wave-cooperative fp64 half-space-intersection
+    volume vs the reference's qhull_overlap_kernel / qhull_overlap_convex_hulls (stardist3d_impl.cpp:830-939, float) on 12 000
+    random overlapping pairs, incl. Qhull's error values (0 for an infeasible interior point of the kernels, 1e10 for the hulls)"""
+    from stardist_amd.lib import stardist3d as sd3
+    rays = _rays(n_rays)
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    rng = np.random.RandomState(n_rays)
+    n = 3000
+    d = (8.0 * (1 + noise * rng.uniform(-1, 1, (n, n_rays)))).astype(np.float32)
+    p = rng.uniform(20, 44, (n, 3)).astype(np.float32)
+    i = rng.randint(0, n, 40000); j = rng.randint(0, n, 40000)
+    sep = np.sqrt(((p[i] - p[j]) ** 2).sum(1))
+    sel = np.flatnonzero((i != j) & (sep < 14))[:12000]
+    pairs = np.stack([i[sel], j[sel]], 1).astype(np.int32)
+    assert len(pairs) >= 10000
+    rk, rh = refmods.pair_volumes(d, p, V, F, pairs)
+    gk, gh = sd3.hiv_pair_volumes(d, p, V, F, pairs)
+    # kernels: same zero pattern (Qhull error / empty) and float-level agreement elsewhere
+    assert np.array_equal(rk == 0, gk.astype(np.float32) == 0), np.flatnonzero((rk == 0) != (gk.astype(np.float32) == 0))[:10]
+    nz = rk != 0
+    relk = np.abs(gk[nz] - rk[nz]) / np.maximum(np.abs(rk[nz]), 1e-3)
+    bigh = rh > 1e9
+    assert np.array_equal(bigh, gh > 1e9), np.flatnonzero(bigh != (gh > 1e9))[:10]
+    relh = np.abs(gh[~bigh] - rh[~bigh]) / np.maximum(np.abs(rh[~bigh]), 1e-3)
+    print("kernel volumes: %d non-zero, max rel diff %.3g; hull volumes: %d finite, max rel diff %.3g" % (nz.sum(), relk.max() if nz.any() else 0, (~bigh).sum(), relh.max()))
+    assert nz.sum() > 1000 and (~bigh).sum() > 5000
+    assert (relk.max() if nz.any() else 0) < 2e-6 and relh.max() < 2e-6         # the reference returns float32
