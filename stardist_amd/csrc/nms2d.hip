@@ -441,6 +441,29 @@ __global__ void __launch_bounds__(256) k_tail_emit(const int* __restrict__ U, in
     if (lane == 0) { segStart[w] = (unsigned int)base; segCnt[w] = cnt; }
   }
 }
+// One replayed greedy round for the whole chip (thread per candidate of the tail list).  Decisions only ever go
+// UNDECIDED -> final, and a kernel boundary makes the previous step's decisions visible to every CU, so running this a fixed
+// number of times needs no host round trip; whatever is still undecided afterwards (dependency chains longer than that) is
+// finished by the single-workgroup loop below.
+__global__ void __launch_bounds__(256) k_tail_step(const int* __restrict__ U, int nU, unsigned char* state, const int2* __restrict__ pairs,
+                                                   const unsigned char* __restrict__ supp, const unsigned int* __restrict__ segStart,
+                                                   const int* __restrict__ segCnt, unsigned long long pairCap) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nU) return;
+  const int j = U[t];
+  if (state[j] != ST_UNDECIDED) return;
+  bool wait = false, sup = false;
+  const unsigned int e0 = segStart[t];
+  const int c = segCnt[t];
+  for (int e = 0; e < c && !sup; ++e) {
+    if ((unsigned long long)e0 + e >= pairCap) { wait = true; break; }
+    const unsigned char si = state[pairs[e0 + e].x];
+    if (si == ST_UNDECIDED) wait = true;
+    else if (si == ST_KEPT && supp[e0 + e]) sup = true;
+  }
+  if (sup) state[j] = ST_SUPPRESSED;
+  else if (!wait) state[j] = ST_KEPT;
+}
 // one workgroup; 'left' receives the number of candidates still undecided (0 unless something is inconsistent)
 __global__ void __launch_bounds__(1024) k_tail_resolve(const int* __restrict__ U, int nU, volatile unsigned char* state,
                                                        const int2* __restrict__ pairs, const unsigned char* __restrict__ supp,
@@ -725,6 +748,8 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
                          &d_cnt->nPairs, pairCap, segStart, segCnt);
       SD_LAUNCH_CHECK();
       if (run_pairs(supp)) return -1;
+      for (int it = 0; it < 10; ++it)
+        hipLaunchKernelGGL(k_tail_step, dim3(sd::div_up(nU, 256)), dim3(256), 0, s, Ucur, nU, state, pairs, supp, segStart, segCnt, pairCap);
       hipLaunchKernelGGL(k_tail_resolve, dim3(1), dim3(1024), 0, s, Ucur, nU, state, pairs, supp, segStart, segCnt, pairCap, &d_cnt->left);
       SD_LAUNCH_CHECK();
       SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));

@@ -13,7 +13,8 @@ img = torch.from_numpy(synth.s2d_nuclei_image(2048, 2048, seed=0)).to(dev)
 m2 = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
 m2.thresholds = dict(prob=0.5, nms=0.4)
 bench.calibrate_heads(m2, img)
-for _ in range(2):
+N2 = int(os.environ.get("SD_PMC_STEPS", "2"))
+for _ in range(N2):
     lab, res = m2.predict_instances(img)
 print("2D:", len(res["prob"]), "instances")
 from stardist_amd.lib import _native
@@ -26,6 +27,6 @@ if "--skip-3d" not in sys.argv:
     m3 = StarDist3D(Config3D(rays=96), basedir=None, device=dev, seed=0)
     m3.thresholds = dict(prob=0.5, nms=0.3)
     bench.calibrate_heads(m3, vol, frac=0.009, radius=8.5, noise=0.03)
-    for _ in range(2):
+    for _ in range(N2):
         lab, res = m3.predict_instances(vol)
     print("3D:", len(res["prob"]), "instances")

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Profiles of one round, all from the same workload (tools/pmc_predict.py = the bench's 2D 2048^2 and 3D 256^3 predict_instances):
+#   0. unprofiled warm run: fills MIOpen's find db, so that the profiled runs launch no find-mode trial kernels
+#   1. rocprofv3 --kernel-trace (per-kernel durations of SD_PMC_STEPS steps + calibration, no trial kernels)
+#   2./3. --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes: they do not fit one)
+#   4. --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 (MFMA utilisation of the convolutions)
+# usage (GPU box): tools/profile_round.sh r02      -> gpurun_out/r02/*.md, pair_kernel_traffic.json
+R=${GRAFT_REPO_ROOT:-/root/repo}
+tag=$1
+O=$R/gpurun_out/$tag; mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+export SD_PMC_STEPS=3
+python $R/tools/pmc_predict.py > $O/warm.log 2>&1
+rm -rf /tmp/prof_kt; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python $R/tools/pmc_predict.py > $O/kernel_trace.log 2>&1
+db=$(find /tmp/prof_kt -name '*.db' | head -1)
+python $R/tools/rocpd_summary.py $db --md > $O/kernel_stats.md 2>&1
+i=0
+for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_INSTS_VALU"; do
+  i=$((i+1)); rm -rf /tmp/pmc_$i
+  timeout 600 rocprofv3 --kernel-trace --pmc $P --output-format csv -d /tmp/pmc_$i -o p -- python $R/tools/pmc_predict.py > $O/pmc_$i.log 2>&1
+done
+f1=$(find /tmp/pmc_1 -name 'p_counter_collection.csv' | head -1); f2=$(find /tmp/pmc_2 -name 'p_counter_collection.csv' | head -1); f3=$(find /tmp/pmc_3 -name 'p_counter_collection.csv' | head -1)
+python $R/tools/profile_traffic.py ${f1%_counter_collection.csv} ${f2%_counter_collection.csv} $O/pmc_1.log $O/pair_kernel_traffic.json $O/pmc_hbm_traffic.md > $O/traffic.log 2>&1
+python $R/tools/pmc_multi.py ${f3%_counter_collection.csv} > $O/pmc_mfma.md 2>&1
+head -40 $O/kernel_stats.md; cat $O/traffic.log | cut -c1-600
