@@ -214,7 +214,8 @@ __global__ void __launch_bounds__(256) k_neighbours(int N, GridP g, Flags f, con
 // from round to round, so only the candidates whose wait target has just been decided go to the list scan (A2).
 __global__ void __launch_bounds__(256) k_round_triage(const int* __restrict__ U, int nU, const unsigned char* __restrict__ state,
                                                       const int* __restrict__ waitOn, int* __restrict__ Unext, int* __restrict__ K,
-                                                      int* __restrict__ S, int* counters /*0:nUnext 1:nK 2:nS*/) {
+                                                      int* __restrict__ S, int* counters /*0:nUnext 1:nK 2:nS*/,
+                                                      const unsigned char* __restrict__ pend) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   int kind = 0, i = -1;                       // 0 drop, 1 still waiting, 2 becomes a survivor, 3 needs the list scan
@@ -222,7 +223,8 @@ __global__ void __launch_bounds__(256) k_round_triage(const int* __restrict__ U,
     i = U[t];
     if (state[i] != ST_SUPPRESSED) {
       const int wo = waitOn[i];
-      if (wo == WAIT_NONE) kind = 2;
+      if (pend[i]) kind = 1;                  // a survivor's pair with i is deferred to the general path: i cannot be promoted yet
+      else if (wo == WAIT_NONE) kind = 2;
       else if (wo >= 0 && state[wo] == ST_UNDECIDED) kind = 1;
       else kind = 3;
     }
@@ -242,7 +244,7 @@ __global__ void __launch_bounds__(256) k_round_triage(const int* __restrict__ U,
 __global__ void __launch_bounds__(256) k_round_scan(const int* __restrict__ S, const unsigned char* __restrict__ state,
                                                     const i64* __restrict__ nbrStart, const int* __restrict__ nbr,
                                                     int* __restrict__ waitOn, int* __restrict__ Unext, int* __restrict__ K,
-                                                    int* counters /*0:nUnext 1:nK 2:nS*/) {
+                                                    int* counters /*0:nUnext 1:nK 2:nS*/, const unsigned char* __restrict__ pend) {
   const int lane = threadIdx.x & 63;
   const int nS = counters[2];
   const int nWaves = gridDim.x * (blockDim.x >> 6);
@@ -259,6 +261,7 @@ __global__ void __launch_bounds__(256) k_round_scan(const int* __restrict__ S, c
     }
     if (lane == 0) {
       if (found >= 0) { waitOn[i] = found; Unext[atomicAdd(&counters[0], 1)] = i; }
+      else if (pend[i]) { waitOn[i] = WAIT_NONE; Unext[atomicAdd(&counters[0], 1)] = i; }
       else { waitOn[i] = WAIT_NONE; K[atomicAdd(&counters[1], 1)] = i; }
     }
   }
@@ -345,12 +348,13 @@ enum { BEAM_CAPFLAGS = sdclip::ST_OVERFLOW_IL | sdclip::ST_OVERFLOW_REC | sdclip
 // (greedy round, i is a survivor); else supp[pair index] = 1 (tail batch: i is still undecided, the result is kept per edge).
 template <int MAXV, int K, int MAXIL, int MAXREC, int S, typename CNT>
 __global__ void __launch_bounds__(S) k_pairs_beam(const int2* __restrict__ pairs, const unsigned int* __restrict__ idx, const CNT* __restrict__ nPtr,
-                                                  const sdclip::PolyPrep<MAXV>* __restrict__ prep,
+                                                  const unsigned int* __restrict__ firstPtr, const sdclip::PolyPrep<MAXV>* __restrict__ prep,
                                                   const float* __restrict__ area, float thr, unsigned char* __restrict__ state,
                                                   unsigned char* __restrict__ supp, PairQueues q) {
   typedef sdclip::Beam<MAXV, K, MAXIL, MAXREC, sdclip::LdsStorage<S>> BeamT;
   const unsigned long long n = (unsigned long long)*nPtr;
-  for (unsigned long long t = (unsigned long long)blockIdx.x * S + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * S) {
+  const unsigned long long first = firstPtr ? (unsigned long long)*firstPtr : 0ull;      // entries before `first` are already queued for the general path
+  for (unsigned long long t = first + (unsigned long long)blockIdx.x * S + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * S) {
     const unsigned int p = idx ? idx[t] : (unsigned int)t;
     const int2 ij = pairs[p];
     BeamT bm;
@@ -441,18 +445,47 @@ __global__ void __launch_bounds__(256) k_tail_emit(const int* __restrict__ U, in
     if (lane == 0) { segStart[w] = (unsigned int)base; segCnt[w] = cnt; }
   }
 }
+// ---- deferral of the general path.  A pair of a normal round that needs the general path (joins / capacities) is NOT evaluated
+// in that round: it is appended to the deferred list, j is marked pending (it can still be suppressed by another survivor's pair,
+// but cannot be promoted), and all deferred pairs are evaluated by ONE launch of the general kernel in the tail batch -- instead
+// of one latency-bound launch per round.  Per candidate the deferred pairs form a linked list (defHead / defNext).
+struct Deferred { int2* pairs; int* next; int* head; unsigned char* pend; unsigned int* count; unsigned int cap; };
+__global__ void k_defer(const int2* __restrict__ pairs, const unsigned int* __restrict__ exact, const unsigned int* __restrict__ nExact, unsigned int qcap,
+                        Deferred d) {
+  unsigned int n = *nExact; if (n > qcap) n = qcap;
+  for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const int2 ij = pairs[exact[t]];
+    const unsigned int k = atomicAdd(d.count, 1u);
+    if (k < d.cap) { d.pairs[k] = ij; d.pend[ij.y] = 1; d.next[k] = atomicExch(&d.head[ij.y], (int)k); }
+  }
+}
+// tail batch: the deferred pairs become entries 0 .. nDef-1 of the tail's pair list and of its general-path queue
+__global__ void k_tail_init(Deferred d, int2* __restrict__ pairs, unsigned int* __restrict__ exact, unsigned long long* nPairs,
+                            unsigned int* nExact, unsigned int* firstNew) {
+  unsigned int n = *d.count; if (n > d.cap) n = d.cap;
+  for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) { pairs[t] = d.pairs[t]; exact[t] = t; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *nPairs = n; *nExact = n; *firstNew = n; }
+}
+// deferred pairs of candidate j: true if one of them suppresses it (their survivors i are KEPT by construction)
+__device__ __forceinline__ bool deferred_suppresses(int j, const int* __restrict__ defHead, const int* __restrict__ defNext,
+                                                    const unsigned char* __restrict__ supp) {
+  for (int k = defHead[j]; k >= 0; k = defNext[k]) if (supp[k]) return true;
+  return false;
+}
+
 // One replayed greedy round for the whole chip (thread per candidate of the tail list).  Decisions only ever go
 // UNDECIDED -> final, and a kernel boundary makes the previous step's decisions visible to every CU, so running this a fixed
 // number of times needs no host round trip; whatever is still undecided afterwards (dependency chains longer than that) is
 // finished by the single-workgroup loop below.
 __global__ void __launch_bounds__(256) k_tail_step(const int* __restrict__ U, int nU, unsigned char* state, const int2* __restrict__ pairs,
                                                    const unsigned char* __restrict__ supp, const unsigned int* __restrict__ segStart,
-                                                   const int* __restrict__ segCnt, unsigned long long pairCap) {
+                                                   const int* __restrict__ segCnt, unsigned long long pairCap,
+                                                   const int* __restrict__ defHead, const int* __restrict__ defNext) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nU) return;
   const int j = U[t];
   if (state[j] != ST_UNDECIDED) return;
-  bool wait = false, sup = false;
+  bool wait = false, sup = deferred_suppresses(j, defHead, defNext, supp);
   const unsigned int e0 = segStart[t];
   const int c = segCnt[t];
   for (int e = 0; e < c && !sup; ++e) {
@@ -468,7 +501,8 @@ __global__ void __launch_bounds__(256) k_tail_step(const int* __restrict__ U, in
 __global__ void __launch_bounds__(1024) k_tail_resolve(const int* __restrict__ U, int nU, volatile unsigned char* state,
                                                        const int2* __restrict__ pairs, const unsigned char* __restrict__ supp,
                                                        const unsigned int* __restrict__ segStart, const int* __restrict__ segCnt,
-                                                       unsigned long long pairCap, int* left) {
+                                                       unsigned long long pairCap, int* left, const int* __restrict__ defHead,
+                                                       const int* __restrict__ defNext) {
   __shared__ int changed, undecided;
   for (int iter = 0; iter <= nU; ++iter) {
     if (threadIdx.x == 0) { changed = 0; undecided = 0; }
@@ -476,7 +510,7 @@ __global__ void __launch_bounds__(1024) k_tail_resolve(const int* __restrict__ U
     for (int t = threadIdx.x; t < nU; t += blockDim.x) {
       const int j = U[t];
       if (state[j] != ST_UNDECIDED) continue;
-      bool wait = false, sup = false;
+      bool wait = false, sup = deferred_suppresses(j, defHead, defNext, supp);
       const unsigned int e0 = segStart[t];
       const int c = segCnt[t];
       for (int e = 0; e < c && !sup; ++e) {
@@ -526,19 +560,19 @@ struct BeamPath {
     return 0;
   }
   // tier 1 (K = 8): all pairs of the round; capacity spills -> q.spill
-  static int tier1(const int2* pairs, const unsigned long long* nPairs, const void* prep, const float* area, float thr,
+  static int tier1(const int2* pairs, const unsigned long long* nPairs, const unsigned int* first, const void* prep, const float* area, float thr,
                    unsigned char* state, unsigned char* supp, PairQueues q, hipStream_t s) {
     static const size_t lds = beam_lds_bytes<MAXV, 8, 6, 4, 64>();
-    hipLaunchKernelGGL((k_pairs_beam<MAXV, 8, 6, 4, 64, unsigned long long>), dim3(256 * 4), dim3(64), lds, s, pairs, (const unsigned int*)nullptr, nPairs, (const Prep*)prep, area, thr, state, supp, q);
+    hipLaunchKernelGGL((k_pairs_beam<MAXV, 8, 6, 4, 64, unsigned long long>), dim3(256 * 4), dim3(64), lds, s, pairs, (const unsigned int*)nullptr, nPairs, first, (const Prep*)prep, area, thr, state, supp, q);
     SD_LAUNCH_CHECK();
     return 0;
   }
   // tier 2 (K = 15, larger lists): the spills of tier 1 (or, for n_rays > 32, all pairs); its spills -> general path
   template <typename CNT>
-  static int tier2(const int2* pairs, const unsigned int* idx, const CNT* nPairs, const void* prep, const float* area, float thr,
+  static int tier2(const int2* pairs, const unsigned int* idx, const CNT* nPairs, const unsigned int* first, const void* prep, const float* area, float thr,
                    unsigned char* state, unsigned char* supp, PairQueues q, hipStream_t s) {
     static const size_t lds = beam_lds_bytes<MAXV, 15, 16, 8, 32>();
-    hipLaunchKernelGGL((k_pairs_beam<MAXV, 15, 16, 8, 32, CNT>), dim3(256 * 3), dim3(32), lds, s, pairs, idx, nPairs, (const Prep*)prep, area, thr, state, supp, q);
+    hipLaunchKernelGGL((k_pairs_beam<MAXV, 15, 16, 8, 32, CNT>), dim3(256 * 3), dim3(32), lds, s, pairs, idx, nPairs, first, (const Prep*)prep, area, thr, state, supp, q);
     SD_LAUNCH_CHECK();
     return 0;
   }
@@ -700,25 +734,49 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   static const int tailMax = getenv("SD_NMS_TAIL_MAX") ? atoi(getenv("SD_NMS_TAIL_MAX")) : 65536;
   const int tailT = tailDiv > 0 ? ((N / tailDiv) < tailMax ? (N / tailDiv) : tailMax) : -1;
   unsigned char* supp = nullptr; unsigned int* segStart = nullptr; int* segCnt = nullptr;
-  // one beam-path pass over the current pair list (tier 1, tier 2, general path); suppOut == nullptr applies to state
+  // deferral of the general path to the tail batch (only with a tail batch to run it in)
+  static const bool deferEnv = !(getenv("SD_NMS_DEFER") && atoi(getenv("SD_NMS_DEFER")) == 0);
+  const bool deferOn = tailT >= 0 && deferEnv;
+  Deferred dfr{nullptr, nullptr, nullptr, nullptr, nullptr, qCap};
+  unsigned int* firstNew = A.take_n<unsigned int>(1);
+  dfr.pend = A.take_n<unsigned char>(N);
+  dfr.head = A.take_n<int>(N);
+  dfr.count = A.take_n<unsigned int>(1);
+  if (!firstNew || !dfr.pend || !dfr.head || !dfr.count) return -1;
+  SD_CHECK(hipMemsetAsync(dfr.pend, 0, N, s));
+  SD_CHECK(hipMemsetAsync(dfr.head, 0xFF, (size_t)N * sizeof(int), s));
+  SD_CHECK(hipMemsetAsync(dfr.count, 0, sizeof(unsigned int), s));
+  if (deferOn) {
+    dfr.pairs = A.take_n<int2>(qCap);
+    dfr.next = A.take_n<int>(qCap);
+    if (!dfr.pairs || !dfr.next) return -1;
+  }
+  i64 nDeferred = 0;
+  // one beam-path pass over the current pair list (tier 1, tier 2, then the general path -- or its deferral); suppOut == nullptr
+  // applies decisions to state (normal round), else records them per pair (tail batch, whose first *firstNew entries are the
+  // deferred pairs, already queued for the general path)
   auto run_pairs = [&](unsigned char* suppOut) -> int {
+    const unsigned int* first = suppOut ? firstNew : nullptr;
     if (stats) SD_CHECK(hipEventRecord(ev0, s));
     PairQueues q1{spillPairs, &d_cnt->nSpill, exactPairs, &d_cnt->nExact, qCap};
     PairQueues q2{exactPairs, &d_cnt->nExact, exactPairs, &d_cnt->nExact, qCap};   // what tier 2 cannot hold goes to the general path
     int rc;
     if (R <= 32) {
-      rc = BeamPath<32, 64>::tier1(pairs, &d_cnt->nPairs, prep, area, threshold, state, suppOut, q1, s);
+      rc = BeamPath<32, 64>::tier1(pairs, &d_cnt->nPairs, first, prep, area, threshold, state, suppOut, q1, s);
       if (stats) SD_CHECK(hipEventRecord(ev1, s));
-      if (!rc) rc = BeamPath<32, 64>::tier2(pairs, spillPairs, &d_cnt->nSpill, prep, area, threshold, state, suppOut, q2, s);
+      if (!rc) rc = BeamPath<32, 64>::tier2(pairs, spillPairs, &d_cnt->nSpill, (const unsigned int*)nullptr, prep, area, threshold, state, suppOut, q2, s);
     } else {
-      if (R <= 64) rc = BeamPath<64, 64>::tier2(pairs, (const unsigned int*)nullptr, &d_cnt->nPairs, prep, area, threshold, state, suppOut, q2, s);
-      else if (R <= 128) rc = BeamPath<128, 32>::tier2(pairs, (const unsigned int*)nullptr, &d_cnt->nPairs, prep, area, threshold, state, suppOut, q2, s);
-      else rc = BeamPath<256, 16>::tier2(pairs, (const unsigned int*)nullptr, &d_cnt->nPairs, prep, area, threshold, state, suppOut, q2, s);
+      if (R <= 64) rc = BeamPath<64, 64>::tier2(pairs, (const unsigned int*)nullptr, &d_cnt->nPairs, first, prep, area, threshold, state, suppOut, q2, s);
+      else if (R <= 128) rc = BeamPath<128, 32>::tier2(pairs, (const unsigned int*)nullptr, &d_cnt->nPairs, first, prep, area, threshold, state, suppOut, q2, s);
+      else rc = BeamPath<256, 16>::tier2(pairs, (const unsigned int*)nullptr, &d_cnt->nPairs, first, prep, area, threshold, state, suppOut, q2, s);
       if (stats) SD_CHECK(hipEventRecord(ev1, s));
     }
     if (rc) return -1;
     if (stats) SD_CHECK(hipEventRecord(ev2, s));
-    if (sd::clip_full_pairs(pairs, exactPairs, &d_cnt->nExact, qCap, R, vx, vy, area, threshold, state, suppOut, &d_cnt->nErr, s)) return -1;
+    if (!suppOut && deferOn) {
+      hipLaunchKernelGGL(k_defer, dim3(64), dim3(256), 0, s, pairs, exactPairs, &d_cnt->nExact, qCap, dfr);
+      SD_LAUNCH_CHECK();
+    } else if (sd::clip_full_pairs(pairs, exactPairs, &d_cnt->nExact, qCap, R, vx, vy, area, threshold, state, suppOut, &d_cnt->nErr, s)) return -1;
     if (stats) SD_CHECK(hipEventRecord(ev3, s));
     return 0;
   };
@@ -735,42 +793,55 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
     }
     return 0;
   };
+  bool forceTail = false;
   while (nU > 0) {
     ++rounds;
-    if (nU <= tailT && rounds > 1) {
+    if (tailT >= 0 && ((nU <= tailT && rounds > 1) || forceTail)) {
       // ---- tail batch: every remaining (undecided, undecided) pair at once, then the greedy rounds replayed on the device
       if (!supp) { supp = A.take_n<unsigned char>(pairCap); segStart = A.take_n<unsigned int>(N); segCnt = A.take_n<int>(N); }
       if (!supp || !segStart || !segCnt) return -1;
       SD_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), s));
       SD_CHECK(hipMemsetAsync(supp, 0, pairCap, s));
       const int wg = sd::div_up(nU, 4) < 2048 ? sd::div_up(nU, 4) : 2048;
+      hipLaunchKernelGGL(k_tail_init, dim3(64), dim3(256), 0, s, dfr, pairs, exactPairs, &d_cnt->nPairs, &d_cnt->nExact, firstNew);
       hipLaunchKernelGGL(k_tail_emit, dim3(wg), dim3(256), 0, s, Ucur, nU, state, nbrStart, nbr, f, d_points, bbox, radius, area, pairs,
                          &d_cnt->nPairs, pairCap, segStart, segCnt);
       SD_LAUNCH_CHECK();
       if (run_pairs(supp)) return -1;
+      hipEvent_t evr0 = nullptr, evr1 = nullptr;
+      const bool tr = stats && getenv("SD_TRACE");
+      if (tr) { SD_CHECK(hipEventCreate(&evr0)); SD_CHECK(hipEventCreate(&evr1)); SD_CHECK(hipEventRecord(evr0, s)); }
       for (int it = 0; it < 10; ++it)
-        hipLaunchKernelGGL(k_tail_step, dim3(sd::div_up(nU, 256)), dim3(256), 0, s, Ucur, nU, state, pairs, supp, segStart, segCnt, pairCap);
-      hipLaunchKernelGGL(k_tail_resolve, dim3(1), dim3(1024), 0, s, Ucur, nU, state, pairs, supp, segStart, segCnt, pairCap, &d_cnt->left);
+        hipLaunchKernelGGL(k_tail_step, dim3(sd::div_up(nU, 256)), dim3(256), 0, s, Ucur, nU, state, pairs, supp, segStart, segCnt, pairCap, dfr.head, dfr.next);
+      hipLaunchKernelGGL(k_tail_resolve, dim3(1), dim3(1024), 0, s, Ucur, nU, state, pairs, supp, segStart, segCnt, pairCap, &d_cnt->left, dfr.head, dfr.next);
       SD_LAUNCH_CHECK();
+      if (tr) { SD_CHECK(hipEventRecord(evr1, s)); SD_CHECK(hipEventSynchronize(evr1)); float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, evr0, evr1));
+                printf("tail replay (10 steps + resolve loop): %.3f ms\n", ms); (void)hipEventDestroy(evr0); (void)hipEventDestroy(evr1); }
       SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
       SD_CHECK(hipStreamSynchronize(s));
       h.nU = nU; h.nK = 0;
+      if ((i64)h.nPairs >= nDeferred) h.nPairs -= (unsigned long long)nDeferred;      // the deferred pairs were counted in their rounds
+      if ((i64)h.nExact >= nDeferred) h.nExact -= (unsigned int)nDeferred;
       if (account("tail batch after round")) return -1;
       if (h.left) { sd::set_error("sd_nms2d: tail batch left candidates undecided (internal error)"); return -1; }
       nU = 0;
       break;
     }
     SD_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), s));
-    hipLaunchKernelGGL(k_round_triage, dim3(sd::div_up(nU, 256)), dim3(256), 0, s, Ucur, nU, state, waitOn, Unext, K, Sl, (int*)d_cnt);
+    hipLaunchKernelGGL(k_round_triage, dim3(sd::div_up(nU, 256)), dim3(256), 0, s, Ucur, nU, state, waitOn, Unext, K, Sl, (int*)d_cnt, dfr.pend);
     const int wgrid = sd::div_up(nU, 4) < 2048 ? sd::div_up(nU, 4) : 2048;
-    hipLaunchKernelGGL(k_round_scan, dim3(wgrid), dim3(256), 0, s, Sl, state, nbrStart, nbr, waitOn, Unext, K, (int*)d_cnt);
+    hipLaunchKernelGGL(k_round_scan, dim3(wgrid), dim3(256), 0, s, Sl, state, nbrStart, nbr, waitOn, Unext, K, (int*)d_cnt, dfr.pend);
     hipLaunchKernelGGL(k_round_emit, dim3(wgrid), dim3(256), 0, s, K, &d_cnt->nK, state, nbrStart, nbr, f, d_points, bbox,
                        radius, area, pairs, &d_cnt->nPairs, pairCap);
     SD_LAUNCH_CHECK();
     if (run_pairs(nullptr)) return -1;
     SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
     SD_CHECK(hipStreamSynchronize(s));
-    if (h.nK == 0 && h.nU > 0) { sd::set_error("sd_nms2d: greedy scan made no progress (internal error)"); return -1; }
+    if (h.nK == 0 && h.nU > 0) {
+      if (deferOn && nDeferred > 0 && !forceTail) forceTail = true;      // everything left waits on deferred pairs: run the tail batch now
+      else { sd::set_error("sd_nms2d: greedy scan made no progress (internal error)"); return -1; }
+    }
+    if (deferOn) nDeferred += h.nExact;
     if (account("round")) return -1;
     nU = h.nU;
     int* t = Ucur; Ucur = Unext; Unext = t;
