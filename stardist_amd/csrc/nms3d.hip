@@ -456,7 +456,7 @@ __device__ __forceinline__ double hiv_rad2(const HivLds& W, int lane, int n) {
 }
 
 __device__ __forceinline__ double hiv_face_term_lds(const double* __restrict__ hs, int M, int k, const double c[3], double L, const HivLds& W,
-                                                    int lane, bool& fallback, int* dbg) {
+                                                    int lane, bool& fallback, int* dbg, const double* __restrict__ balls = nullptr) {
 #pragma clang fp contract(fast)
   fallback = false;
   HivFrame fr = hiv_frame(hs, k, c);
@@ -472,8 +472,25 @@ __device__ __forceinline__ double hiv_face_term_lds(const double* __restrict__ h
     }
   }
   int n = 4;
-  W.S[0 * 64 + lane] = -L; W.T[0 * 64 + lane] = -L; W.S[1 * 64 + lane] = L; W.T[1 * 64 + lane] = -L;
-  W.S[2 * 64 + lane] = L; W.T[2 * 64 + lane] = L; W.S[3 * 64 + lane] = -L; W.T[3 * 64 + lane] = L;
+  // initial polygon: the intersection region lies inside the outer balls of BOTH polyhedra, so this face's polygon lies inside
+  // the discs in which its plane cuts them: start from the intersection of the discs' bounding squares instead of the +-L box
+  // (a tight start makes the cutter lists short: most half-spaces cannot reach a polygon of the objects' own size)
+  double s_lo = -L, s_hi = L, t_lo = -L, t_hi = L;
+  if (balls) {
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq) {
+      const double qz = balls[4 * bq] - fr.oz, qy = balls[4 * bq + 1] - fr.oy, qx = balls[4 * bq + 2] - fr.ox, r = balls[4 * bq + 3];
+      const double dn = qz * hs[4 * k] + qy * hs[4 * k + 1] + qx * hs[4 * k + 2];      // signed distance of the ball centre to the plane (unit normal)
+      const double rho2 = r * r - dn * dn;
+      if (!(rho2 > 0)) return 0;                                                        // the plane misses the ball: empty face
+      const double rho = sqrt(rho2) * (1.0 + 1e-9) + 1e-9;
+      const double s0 = qz * fr.uz + qy * fr.uy + qx * fr.ux, t0 = qz * fr.vz + qy * fr.vy + qx * fr.vx;
+      s_lo = fmax(s_lo, s0 - rho); s_hi = fmin(s_hi, s0 + rho); t_lo = fmax(t_lo, t0 - rho); t_hi = fmin(t_hi, t0 + rho);
+    }
+    if (!(s_lo < s_hi && t_lo < t_hi)) return 0;
+  }
+  W.S[0 * 64 + lane] = s_lo; W.T[0 * 64 + lane] = t_lo; W.S[1 * 64 + lane] = s_hi; W.T[1 * 64 + lane] = t_lo;
+  W.S[2 * 64 + lane] = s_hi; W.T[2 * 64 + lane] = t_hi; W.S[3 * 64 + lane] = s_lo; W.T[3 * 64 + lane] = t_hi;
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     if (sd[q] < 0 || n == 0) continue;
@@ -490,19 +507,26 @@ __device__ __forceinline__ double hiv_face_term_lds(const double* __restrict__ h
   }
   double rad2 = hiv_rad2(W, lane, n);
   const double radm = sqrt(rad2) * (1.0 + 1e-12);
-  // phase 1 (no divergence): half-spaces that do not contain the ball around the polygon go to this lane's list
+  // phase 1 (no divergence): half-spaces whose TRACE LINE in this face's plane reaches the disc around the polygon go to this
+  // lane's list.  (The 3D ball test alone -- half-space does not contain the ball around the polygon -- let through every
+  // half-space that is steep against this face: 77 % of the faces overflowed the list into the divergent loop below.  The
+  // in-plane test is the one phase 2 applies anyway; here it runs for all half-spaces in lock step.)
   int nl = 0, m_rest = M;
   for (int m0 = 0; m0 < M; m0 += 4) {
-    double e4[4];
+    double e4[4], n4[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int m = (m0 + q < M) ? m0 + q : M - 1;
-      e4[q] = hs[4 * m] * fr.oz + hs[4 * m + 1] * fr.oy + hs[4 * m + 2] * fr.ox + hs[4 * m + 3];
+      const double mz_ = hs[4 * m], my_ = hs[4 * m + 1], mx_ = hs[4 * m + 2];
+      e4[q] = mz_ * fr.oz + my_ * fr.oy + mx_ * fr.ox + hs[4 * m + 3];
+      const double a_ = mz_ * fr.uz + my_ * fr.uy + mx_ * fr.ux, b_ = mz_ * fr.vz + my_ * fr.vy + mx_ * fr.vx;
+      n4[q] = a_ * a_ + b_ * b_;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int m = m0 + q;
-      const bool cand = (m < M) && !(e4[q] + radm <= 0) && m != k && m != sd[0] && m != sd[1] && m != sd[2];
+      const bool misses = (e4[q] + radm <= 0) || (e4[q] <= 0 && e4[q] * e4[q] >= rad2 * n4[q] * (1.0 + 1e-12));
+      const bool cand = (m < M) && !misses && m != k && m != sd[0] && m != sd[1] && m != sd[2];
       if (cand) {
         if (nl < HIV_LCAP) { W.list[nl * 64 + lane] = (unsigned short)m; ++nl; }
         else if (m < m_rest) m_rest = m;
@@ -510,15 +534,23 @@ __device__ __forceinline__ double hiv_face_term_lds(const double* __restrict__ h
     }
   }
   dbg[0] += nl; if (m_rest < M) dbg[2] += 1;
-  // phase 2: every lane walks its own short list
-  for (int t = 0; t < nl && n > 0; ++t) {
-    const int m = W.list[t * 64 + lane];
-    HIV_LINE(fr, hs, m, a, b, e)
-    const double n2 = a * a + b * b;
-    if (e <= 0 && e * e >= rad2 * n2 * (1.0 + 1e-12)) continue;      // the trace line does not reach the polygon
-    dbg[1] += 1;
-    if (!hiv_clip_lds(W, lane, n, a, b, e)) { fallback = true; return 0; }
-    rad2 = hiv_rad2(W, lane, n);
+  // phase 2: every lane walks its own short list -- twice.  The first pass only clips with DEEP cutters (trace line closer to the
+  // polygon centre than half its radius, or centre outside): they shrink the polygon quickly, so that in the second pass most of
+  // the shallow cutters no longer reach it and are rejected by the one-comparison test instead of a clip (the result does not
+  // depend on the clipping order).
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int t = 0; t < nl && n > 0; ++t) {
+      const int m = W.list[t * 64 + lane];
+      if (m == (int)HIV_NONE) continue;
+      HIV_LINE(fr, hs, m, a, b, e)
+      const double n2 = a * a + b * b;
+      if (e <= 0 && e * e >= rad2 * n2 * (1.0 + 1e-12)) { W.list[t * 64 + lane] = (unsigned short)HIV_NONE; continue; }   // does not reach the polygon (it only shrinks)
+      if (pass == 0 && e <= 0 && e * e >= 0.25 * rad2 * n2) continue;                                                       // shallow: second pass
+      W.list[t * 64 + lane] = (unsigned short)HIV_NONE;
+      dbg[1] += 1;
+      if (!hiv_clip_lds(W, lane, n, a, b, e)) { fallback = true; return 0; }
+      rad2 = hiv_rad2(W, lane, n);
+    }
   }
   // list overflow (rare): the remaining half-spaces one by one
   for (int m = m_rest; m < M && n > 0; ++m) {
@@ -540,7 +572,7 @@ __device__ __forceinline__ double hiv_face_term_lds(const double* __restrict__ h
 
 // sum of the face terms of the M half-spaces in hs (one wave); NaN when a face exceeded even the fallback capacity
 __device__ __forceinline__ double hiv_volume_wave(const double* __restrict__ hs, int M, const double c[3], double L, const HivLds& W, int lane,
-                                                  Stats* st) {
+                                                  Stats* st, const double* __restrict__ balls = nullptr) {
   double acc = 0;
   int nfb = 0;
   int dbg[3] = {0, 0, 0};
@@ -548,7 +580,7 @@ __device__ __forceinline__ double hiv_volume_wave(const double* __restrict__ hs,
     const int k = k0 + lane;
     if (k < M) {
       bool fb;
-      double term = hiv_face_term_lds(hs, M, k, c, L, W, lane, fb, dbg);
+      double term = hiv_face_term_lds(hs, M, k, c, L, W, lane, fb, dbg, balls);
       if (fb) { term = hiv_face_term(hs, M, k, c, L); ++nfb; }
       acc += term;
     }
@@ -789,7 +821,9 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
       } else {
         const double sep = sqrt((double)(c1[0] - c2[0]) * (c1[0] - c2[0]) + (double)(c1[1] - c2[1]) * (c1[1] - c2[1]) + (double)(c1[2] - c2[2]) * (c1[2] - c2[2]));
         const double L = 4.0 * (2.0 * ext + sep + 1.0);
-        vol = hiv_volume_wave(hs, Mc, zero3, L, W, lane, st);
+        const double balls[8] = {(double)c1[0] - c[0], (double)c1[1] - c[1], (double)c1[2] - c[2], ext1 * (1.0 + 1e-6) + 1e-6,
+                                 (double)c2[0] - c[0], (double)c2[1] - c[1], (double)c2[2] - c[2], ext2 * (1.0 + 1e-6) + 1e-6};
+        vol = hiv_volume_wave(hs, Mc, zero3, L, W, lane, st, balls);
       }
     }
     if (volOut) { if (lane == 0) volOut[p] = vol; continue; }     // pair-level probe (sd_hiv_pairs_device): the volume itself
@@ -1179,7 +1213,11 @@ __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, u
       } else if (ub * (1.0 + 1e-9) / A_min_d < thr_lo && !no_lb) {
         vol = ub;                                       // certainly not above the threshold -> pair kept
         if (lane == 0) atomicAdd(&st->ub_decided, 1ull);
-      } else vol = hiv_volume_wave(hs, Mc, zero3, L, W, lane, st);
+      } else {
+        const double balls[8] = {(double)c1[0] - c[0], (double)c1[1] - c[1], (double)c1[2] - c[2], ext1 * (1.0 + 1e-6) + 1e-6,
+                                 (double)c2[0] - c[0], (double)c2[1] - c[1], (double)c2[2] - c[2], ext2 * (1.0 + 1e-6) + 1e-6};
+        vol = hiv_volume_wave(hs, Mc, zero3, L, W, lane, st, balls);
+      }
     }
     if (volOut) { if (lane == 0) volOut[p] = vol; continue; }     // pair-level probe
     if (lane == 0) {
