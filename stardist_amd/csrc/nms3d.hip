@@ -389,7 +389,7 @@ __device__ __noinline__ double hiv_face_term(const double* __restrict__ hs, int 
 // done in place.  Anything unusual (capacity, more than one run because of rounding) sets `fallback` and the caller
 // recomputes this face with the routine above.  The result does not depend on the clipping order (up to rounding).
 #define HIV_CAPL 16
-#define HIV_LCAP 40
+#define HIV_LCAP 56
 #define HIV_NONE 0xFFFFu
 struct HivLds {
   double* S; double* T;                 // polygon vertices [HIV_CAPL][64]
