@@ -49,9 +49,11 @@ def calibrate_heads(model, img, frac=0.10, radius=10.0, noise=0.1):
     h = net.features.register_forward_hook(lambda m, i, o: feats.__setitem__("f", o))
     limit = net._INDEX_LIMIT
     net._INDEX_LIMIT = 2 ** 62          # whole-volume head for the statistics (the timed path runs it in slabs)
+    net.fused_heads = False             # ... through the plain modules, so that the hook sees the features
     with torch.no_grad():
         model.predict(img)
     net._INDEX_LIMIT = limit
+    del net.fused_heads
     model.__dict__.pop("_graphs", None)   # the captured HIP graph of this pass has the whole-volume head baked in
     h.remove()
     f = feats["f"].float()
@@ -156,6 +158,15 @@ def cpu_baseline_3d(vol_np, model, sample, threads):
                        % (sample, t_net, len(d), int(keep.sum()), t_nms, t_ras))
 
 
+def net_macs(model, macs):
+    """multiply-accumulates per input pixel the timed network region executes: with the sparse head (models/unet.py) the distance head
+    is evaluated on the candidate pixels only, outside that region -- its dense MACs are not counted"""
+    if getattr(model, "_head_mode", "dense") != "sparse":
+        return macs
+    d = model.net.dist
+    return macs - d.in_channels * d.out_channels / float(np.prod(model.config.grid))
+
+
 def run_leg(model, img, steps, warmup, world, dist_):
     """W untimed + K timed predict_instances, barrier + synchronize on both sides, max over ranks.
     Returns (elapsed_s, avg net ms, last result, summed native stats)."""
@@ -164,9 +175,9 @@ def run_leg(model, img, steps, warmup, world, dist_):
     pairs = []
     orig_forward = model._net_forward
 
-    def timed_forward(x):
+    def timed_forward(x, **kw):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); r = orig_forward(x); b.record()
+        a.record(); r = orig_forward(x, **kw); b.record()
         pairs.append((a, b))
         return r
     model._net_forward = timed_forward
@@ -291,7 +302,7 @@ def main():
         p, d = model.predict(img)
         n_cand = int(((p > model.thresholds.prob)[2:-2, 2:-2]).sum())
         s2 = st.get("nms2d", np.zeros(16, np.int64)) / max(1, args.steps)
-        flops = 2.0 * macs * H * W
+        flops = 2.0 * net_macs(model, macs) * H * W
         conv_tf = flops / (net_ms * 1e-3) / 1e12
         pair_ms, pair_launches, n_pairs = s2[4] / 1e6, max(1.0, s2[5]), s2[0]
         # algorithmic bytes of the pair kernel: SURVEY.md 8(d) pair-traffic model B_pair = 2*(4R+4D) = 272 B per pair (R=32, D=2)
@@ -362,7 +373,7 @@ def main():
         if rank == 0:
             s3 = st3.get("nms3d", np.zeros(16, np.int64)) / steps3
             ms3 = 1e3 * elapsed3 / steps3
-            flops3 = 2.0 * macs3 * S ** 3
+            flops3 = 2.0 * net_macs(m3, macs3) * S ** 3
             conv3_tf = flops3 / (net3_ms * 1e-3) / 1e12
             out["value_3d"] = round(world * S ** 3 * steps3 / elapsed3 / 1e6, 3)
             out["unit_3d"] = "Mvox/s"

@@ -144,7 +144,7 @@ int sd_polyhedron_to_label_device(const float* d_dist, const float* d_points,
  * prob (n_pix,) float32 and dist (n_pix, n_rays) float32 are the network heads over a grid of
  * `ndim` (2 or 3) dims `shape`; selects pixels with prob > thresh that are at least b[2*d] /
  * b[2*d+1] grid cells from the low / high face of dim d, in C order (== np.where order).
- * Writes out_prob (cap,), out_dist (cap, n_rays) = max(dist, 1e-3f), out_points (cap, ndim)
+ * Writes out_prob (cap,), out_dist (cap, n_rays) = max(dist, 1e-3f) (skipped when d_dist is NULL), out_points (cap, ndim)
  * int32 grid indices (NOT yet multiplied by the grid) and *d_count (int32) = number found
  * (may exceed cap: then only the first cap are written). */
 int sd_select_candidates_device(const float* d_prob, const float* d_dist, int ndim,
@@ -177,6 +177,26 @@ void _LIB_star_dist3d(const unsigned short* src, const int nz, const int ny, con
  * act: 0 = linear, 1 = relu. */
 int sd_bias_act_device(float* d_x, const float* d_bias, long long n_outer, int n_channels,
                        long long inner, int act, void* stream);
+/* x = act((x + addend) + bias): epilogue of a convolution over a channel concatenation that is evaluated as two
+ * convolutions over the two sources (Concatenate + Conv of csbdeep's unet_block up path, blocks.py) -- the
+ * concatenated tensor is never written. addend has the layout of x. */
+int sd_add_bias_act_device(float* d_x, const float* d_addend, const float* d_bias, long long n_outer,
+                           int n_channels, long long inner, int act, void* stream);
+
+/* features epilogue + one-channel head: out = act(in + bias) over channels-last [n_pix][n_channels] float32 (in place when
+ * d_out == d_in; n_channels 32, 64, 128 or 256) and, when d_w is given, d_dot[p] = sum_c out[p][c] * d_w[c] + d_wbias[0], through the
+ * logistic function when sigmoid != 0: the object-probability head of the reference's models (Conv 1x1, sigmoid:
+ * stardist/models/model2d.py:338-341, model3d.py:436-439) evaluated while the features are in registers. */
+int sd_bias_act_dot_device(const float* d_in, float* d_out, const float* d_bias, long long n_pix, int n_channels,
+                           int act, const float* d_w, const float* d_wbias, int sigmoid, float* d_dot, void* stream);
+/* distance head on selected pixels: d_out[i][r] = max(clamp_min, d_bias[r] + sum_k d_feat[d_rows[i]][k] * d_w[r][k]) for
+ * i < n_rows, r < n_out (d_rows == NULL: row i itself, i.e. the dense head).  d_feat is channels-last [n_pix][n_channels],
+ * d_w the Conv 1x1 kernel [n_out][n_channels] (model2d.py:342-343, model3d.py:440-441).  With d_rows = the candidate pixels
+ * (prob > prob_thresh) this is what predict_sparse (stardist/models/base.py:553-610) keeps of the dense prediction.
+ * fp32 MFMA, one fixed fma chain per output whatever rows are batched together. */
+int sd_head_rows_device(const float* d_feat, int n_channels, const long long* d_rows, long long n_rows,
+                        const float* d_w, const float* d_bias, int n_out, float clamp_min, float* d_out,
+                        void* stream);
 
 #ifdef __cplusplus
 }

@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(BLOCK) k_write(const float* __restrict__ prob,
           const int o = off + rank;
           ++rank;
           if (o < cap) {
-            for (int k = lane; k < R; k += 64) odist[(size_t)o * R + k] = fmaxf(1e-3f, dist[(size_t)idx * R + k]);
+            if (dist) for (int k = lane; k < R; k += 64) odist[(size_t)o * R + k] = fmaxf(1e-3f, dist[(size_t)idx * R + k]);
             if (lane == 0) {
               oprob[o] = prob[idx];
               long long rem = idx;

@@ -9,10 +9,13 @@
 namespace {
 
 // channels-last: x is [n_pix][C], C % 4 == 0
-__global__ void __launch_bounds__(256) k_bias_act_cl4(float4* __restrict__ x, const float4* __restrict__ bias, long long n4, int C4, int act) {
+template <bool ADD>
+__global__ void __launch_bounds__(256) k_bias_act_cl4(float4* __restrict__ x, const float4* __restrict__ addend, const float4* __restrict__ bias,
+                                                      long long n4, int C4, int act) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     float4 v = x[i];
+    if (ADD) { const float4 a = addend[i]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
     const float4 b = bias[(int)(i % C4)];
     v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
     if (act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -21,31 +24,183 @@ __global__ void __launch_bounds__(256) k_bias_act_cl4(float4* __restrict__ x, co
 }
 
 // generic: x is [n_outer][C][inner]
-__global__ void __launch_bounds__(256) k_bias_act(float* __restrict__ x, const float* __restrict__ bias, long long n, int C, long long inner, int act) {
+template <bool ADD>
+__global__ void __launch_bounds__(256) k_bias_act(float* __restrict__ x, const float* __restrict__ addend, const float* __restrict__ bias, long long n,
+                                                  int C, long long inner, int act) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    float v = x[i] + bias[(int)((i / inner) % C)];
+    float v = x[i];
+    if (ADD) v += addend[i];
+    v += bias[(int)((i / inner) % C)];
     if (act == 1) v = fmaxf(v, 0.f);
     x[i] = v;
   }
 }
 
+// ---- features epilogue + probability head ----------------------------------------------------------------------------------
+// channels-last [n_pix][C], C = 4*LPP: LPP lanes hold one pixel.  out = act(in + bias) (in place when out == in) and, when w is
+// given, dot[p] = (sigmoid)(sum_c out[p][c] * w[c] + wb): the 1x1 convolution to ONE channel (the object-probability head,
+// model2d.py:338-341 / model3d.py:436-439) done while the features are in registers instead of a second pass over them.
+// Fixed summation order (4 products per lane in channel order, then an xor butterfly), the same for every caller.
+template <int LPP>
+__global__ void __launch_bounds__(256) k_bias_act_dot(const float4* __restrict__ in, float4* __restrict__ out, const float4* __restrict__ bias,
+                                                      long long n_pix, int act, const float4* __restrict__ w, const float* __restrict__ wb,
+                                                      int sigm, float* __restrict__ dot) {
+  const int s = threadIdx.x % LPP;
+  const long long groups = (long long)gridDim.x * (256 / LPP);
+  const float4 b = bias[s];
+  float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+  float w0 = 0.f;
+  if (w) { wv = w[s]; w0 = wb ? wb[0] : 0.f; }
+  for (long long p = (long long)blockIdx.x * (256 / LPP) + threadIdx.x / LPP; p < n_pix; p += groups) {
+    float4 v = in[p * LPP + s];
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    if (act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    out[p * LPP + s] = v;
+    if (w) {
+      float d = v.x * wv.x;
+      d += v.y * wv.y; d += v.z * wv.z; d += v.w * wv.w;
+#pragma unroll
+      for (int o = LPP / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+      if (s == 0) {
+        d += w0;
+        dot[p] = sigm ? 1.f / (1.f + expf(-d)) : d;
+      }
+    }
+  }
+}
+
+// ---- distance head on selected rows -----------------------------------------------------------------------------------------
+// out[i][r] = max(clamp, bias[r] + sum_k feat[rows[i]][k] * W[r][k]): the 1x1 convolution to n_rays channels (model2d.py:342-343 /
+// model3d.py:440-441) as an fp32-MFMA GEMM over the rows that are asked for -- every pixel (rows == nullptr: the dense head) or the
+// candidate pixels only (the sparse prediction path, base.py:553-610: no dense distance tensor is ever written).
+// One wave = 32 rows x all columns: v_mfma_f32_32x32x2_f32, lane (i = lane&31, h = lane>>5) feeds row i with the channels of its
+// half h*C/2.. in order, so a row's result is ONE fixed fma chain (bias first) whatever other rows share the tile: the dense and the
+// sparse path agree bit for bit.  W^T is staged once per workgroup in LDS as [k][32*CT (+1 pad)].
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int CT>
+__global__ void __launch_bounds__(256) k_head_rows(const float* __restrict__ feat, int C, const long long* __restrict__ rows, long long n_rows,
+                                                   const float* __restrict__ W, const float* __restrict__ bias, int R, float clampv,
+                                                   float* __restrict__ out) {
+  extern __shared__ float Wl[];
+  constexpr int RP = CT * 32 + 1;
+  for (int e = threadIdx.x; e < C * CT * 32; e += 256) {
+    const int c = e / C, k = e - c * C;                       // coalesced read of W[c][k], transposed store
+    Wl[k * RP + c] = c < R ? W[e] : 0.f;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const int KH = C >> 1;
+  float bcol[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) bcol[ct] = (bias && ct * 32 + i < R) ? bias[ct * 32 + i] : 0.f;
+  const long long n_tiles = (n_rows + 31) >> 5;
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long long)gridDim.x * 4) {
+    const long long ri = tile * 32 + i;
+    const long long src = ri < n_rows ? (rows ? rows[ri] : ri) : (rows ? rows[0] : 0);
+    const float4* ap = (const float4*)(feat + src * C + h * KH);
+    f32x16 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] = bcol[ct];
+    const float* wl = Wl + (size_t)h * KH * RP + i;
+    for (int j4 = 0; j4 < KH / 4; ++j4) {
+      const float4 a = ap[j4];
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* wk = wl + (size_t)(j4 * 4 + e) * RP;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], wk[ct * 32], acc[ct], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int col = ct * 32 + i;
+      if (col < R) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long orow = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (orow < n_rows) out[orow * R + col] = fmaxf(acc[ct][r], clampv);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
-extern "C" int sd_bias_act_device(float* d_x, const float* d_bias, long long n_outer, int n_channels, long long inner, int act, void* stream_) {
+static int bias_act_impl(float* d_x, const float* d_add, const float* d_bias, long long n_outer, int n_channels, long long inner, int act, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   if (n_outer <= 0 || inner <= 0) return 0;
   if (n_channels <= 0 || (act != 0 && act != 1)) { sd::set_error("sd_bias_act: bad arguments"); return -1; }
   const long long n = n_outer * (long long)n_channels * inner;
-  if (inner == 1 && n_channels % 4 == 0 && ((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_bias & 15) == 0) {
+  if (inner == 1 && n_channels % 4 == 0 && ((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_bias & 15) == 0 && ((uintptr_t)d_add & 15) == 0) {
     const long long n4 = n / 4;
     const long long blocks = (n4 + 255) / 256;
-    hipLaunchKernelGGL(k_bias_act_cl4, dim3((unsigned int)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, (float4*)d_x, (const float4*)d_bias, n4,
-                       n_channels / 4, act);
+    const dim3 g((unsigned int)(blocks < 65536 ? blocks : 65536));
+    if (d_add) hipLaunchKernelGGL(k_bias_act_cl4<true>, g, dim3(256), 0, s, (float4*)d_x, (const float4*)d_add, (const float4*)d_bias, n4, n_channels / 4, act);
+    else hipLaunchKernelGGL(k_bias_act_cl4<false>, g, dim3(256), 0, s, (float4*)d_x, (const float4*)nullptr, (const float4*)d_bias, n4, n_channels / 4, act);
   } else {
     const long long blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(k_bias_act, dim3((unsigned int)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, d_x, d_bias, n, n_channels, inner, act);
+    const dim3 g((unsigned int)(blocks < 65536 ? blocks : 65536));
+    if (d_add) hipLaunchKernelGGL(k_bias_act<true>, g, dim3(256), 0, s, d_x, d_add, d_bias, n, n_channels, inner, act);
+    else hipLaunchKernelGGL(k_bias_act<false>, g, dim3(256), 0, s, d_x, (const float*)nullptr, d_bias, n, n_channels, inner, act);
   }
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sd_bias_act_device(float* d_x, const float* d_bias, long long n_outer, int n_channels, long long inner, int act, void* stream_) {
+  return bias_act_impl(d_x, nullptr, d_bias, n_outer, n_channels, inner, act, stream_);
+}
+
+extern "C" int sd_add_bias_act_device(float* d_x, const float* d_addend, const float* d_bias, long long n_outer, int n_channels, long long inner, int act,
+                                      void* stream_) {
+  if (!d_addend) { sd::set_error("sd_add_bias_act: null addend"); return -1; }
+  return bias_act_impl(d_x, d_addend, d_bias, n_outer, n_channels, inner, act, stream_);
+}
+
+extern "C" int sd_bias_act_dot_device(const float* d_in, float* d_out, const float* d_bias, long long n_pix, int n_channels, int act,
+                                      const float* d_w, const float* d_wbias, int sigmoid, float* d_dot, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (n_pix <= 0) return 0;
+  const int lpp = n_channels / 4;
+  if (n_channels % 4 || (lpp != 8 && lpp != 16 && lpp != 32 && lpp != 64) || (act != 0 && act != 1) || !d_in || !d_out || !d_bias || (d_w && !d_dot) ||
+      (((uintptr_t)d_in | (uintptr_t)d_out | (uintptr_t)d_bias | (uintptr_t)d_w) & 15)) {
+    sd::set_error("sd_bias_act_dot: n_channels must be 32, 64, 128 or 256, pointers 16-byte aligned, act 0|1");
+    return -1;
+  }
+  const long long per_block = 256 / lpp;
+  long long blocks = (n_pix + per_block - 1) / per_block;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  const dim3 g((unsigned int)blocks), b(256);
+#define SD_BAD(L) hipLaunchKernelGGL(k_bias_act_dot<L>, g, b, 0, s, (const float4*)d_in, (float4*)d_out, (const float4*)d_bias, n_pix, act, (const float4*)d_w, d_wbias, sigmoid, d_dot)
+  if (lpp == 8) SD_BAD(8); else if (lpp == 16) SD_BAD(16); else if (lpp == 32) SD_BAD(32); else SD_BAD(64);
+#undef SD_BAD
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sd_head_rows_device(const float* d_feat, int n_channels, const long long* d_rows, long long n_rows, const float* d_w, const float* d_bias,
+                                   int n_out, float clamp_min, float* d_out, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (n_rows <= 0 || n_out <= 0) return 0;
+  const int ct = (n_out + 31) / 32;
+  const size_t lds = (size_t)n_channels * (ct * 32 + 1) * sizeof(float);
+  if (n_channels < 8 || n_channels % 8 || ct > 4 || lds > 64 * 1024 || !d_feat || !d_w || !d_out || ((uintptr_t)d_feat & 15)) {
+    sd::set_error("sd_head_rows: n_channels must be a multiple of 8, n_out <= 128, n_channels * n_out <= 16k, feat 16-byte aligned");
+    return -1;
+  }
+  const long long tiles = (n_rows + 31) / 32;
+  long long blocks = (tiles + 3) / 4;
+  if (blocks > 256 * 3) blocks = 256 * 3;
+  const dim3 g((unsigned int)blocks), b(256);
+#define SD_HR(T) hipLaunchKernelGGL(k_head_rows<T>, g, b, lds, s, d_feat, n_channels, d_rows, n_rows, d_w, d_bias, n_out, clamp_min, d_out)
+  if (ct == 1) SD_HR(1); else if (ct == 2) SD_HR(2); else if (ct == 3) SD_HR(3); else SD_HR(4);
+#undef SD_HR
   SD_LAUNCH_CHECK();
   return 0;
 }

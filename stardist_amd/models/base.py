@@ -286,8 +286,10 @@ class StarDistBase(object):
             return np.transpose(data, perm)
         return _permute_axes
 
-    def _net_forward(self, x):
-        """x: torch tensor with axes_net semantics (channels last) -> tuple of channels-last outputs.
+    def _net_forward(self, x, sparse_head=False):
+        """x: torch tensor with axes_net semantics (channels last) -> tuple of channels-last outputs (prob, dist[, prob_class]).
+        sparse_head=True (GPU, fused heads: models/unet.py): (prob, features[, prob_class]) when self._head_mode == "sparse" after
+        the call -- the distance head is then evaluated on the selected rows only (_select_rows); otherwise as above.
 
         On the GPU the forward pass is captured once per input shape into a HIP graph (torch.cuda.CUDAGraph) and
         replayed: the network is ~60 small conv launches whose host-side dispatch (MIOpen solver lookup + launch)
@@ -298,9 +300,10 @@ class StarDistBase(object):
         mf = torch.channels_last if nd == 2 else torch.channels_last_3d
         use_graph = (self.device.type == "cuda") and getattr(self, "use_hip_graph", True)
         if not use_graph:
-            ys = self._net_eager(xc.contiguous(memory_format=mf))
+            ys = self._net_eager(xc.contiguous(memory_format=mf), sparse_head)
+            self._head_mode = getattr(self.net, "head_mode", "dense")
         else:
-            key = (tuple(xc.shape), xc.dtype)
+            key = (tuple(xc.shape), xc.dtype, bool(sparse_head))
             cache = self.__dict__.setdefault("_graphs", {})
             if key not in cache:
                 if len(cache) >= 8:                                  # bounded: tiles of a big image share few shapes
@@ -311,33 +314,34 @@ class StarDistBase(object):
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):                        # warm-up outside capture (MIOpen find, workspaces)
                     for _ in range(2):
-                        self._net_eager(static_in)
+                        self._net_eager(static_in, sparse_head)
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 try:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
-                        static_out = self._net_eager(static_in)
-                    cache[key] = (g, static_in, static_out)
+                        static_out = self._net_eager(static_in, sparse_head)
+                    cache[key] = (g, static_in, static_out, getattr(self.net, "head_mode", "dense"))
                 except Exception as e:                               # capture unsupported for some solver: stay eager
                     import warnings
                     warnings.warn("HIP graph capture of the network failed (%r); running eagerly" % (e,))
                     self.use_hip_graph = False
-                    return self._net_forward(x)
-            g, static_in, static_out = cache[key]
+                    return self._net_forward(x, sparse_head)
+            g, static_in, static_out, self._head_mode = cache[key]
             static_in.copy_(xc)
             g.replay()
             ys = static_out
         return tuple(y[0].permute(*(list(range(1, nd + 1)) + [0])) for y in ys)   # (...,C) views
 
-    def _net_eager(self, xc):
+    def _net_eager(self, xc, sparse_head=False):
         import torch
+        kw = dict(sparse_head=True) if sparse_head else {}
         with torch.no_grad():
             if self.compute_dtype != torch.float32:
                 with torch.autocast(device_type=self.device.type, dtype=self.compute_dtype):
-                    ys = self.net(xc)
+                    ys = self.net(xc, **kw)
                 return tuple(y.float() for y in ys)
-            return tuple(self.net(xc.float()))
+            return tuple(self.net(xc.float(), **kw))
 
     def _predict_setup(self, img, axes, normalizer, n_tiles):
         import torch
@@ -501,6 +505,33 @@ class StarDistBase(object):
                 return oprob[:n], odist[:n], opts[:n].to(torch.int64)
             cap = n
 
+    def _select_rows(self, prob, feat, origin, prob_thresh, bs):
+        """_select for the sparse head: threshold + border + ordered compaction on `prob` (a crop, starting at `origin`, of the
+        grid the channels-last feature tensor `feat` (..., C) lives on), then the distance head on the selected rows of feat."""
+        import torch
+        prob = prob.contiguous()
+        nd = prob.dim()
+        shape = np.asarray(prob.shape, np.int32)
+        b = np.asarray([v for pair in bs for v in pair], np.int32)
+        cnt = torch.zeros(1, dtype=torch.int32, device=prob.device)
+        cap = max(1024, int(prob.numel() // 64))
+        while True:
+            oprob = torch.empty(cap, dtype=torch.float32, device=prob.device)
+            opts = torch.empty((cap, nd), dtype=torch.int32, device=prob.device)
+            N.dcall(prob, "sd_select_candidates_device", N.tptr(prob), None, nd, N.ptr(shape), N.ptr(b), 0,
+                    float(np.float32(prob_thresh)), cap, N.tptr(oprob), None, N.tptr(opts), N.tptr(cnt))
+            n = int(cnt.item())
+            if n <= cap:
+                break
+            cap = n
+        pts = opts[:n].to(torch.int64)
+        full = feat.shape[:-1]
+        rows = torch.zeros(n, dtype=torch.int64, device=prob.device)
+        for d in range(nd):
+            rows = rows * int(full[d]) + (pts[:, d] + int(origin[d]))
+        odist = self.net.dist_rows(feat, rows, 1e-3)          # max(dist, 1e-3): base.py:512-513 / select.hip
+        return oprob[:n], odist, pts
+
     def _predict_sparse_generator(self, img, prob_thresh=None, axes=None, normalizer=None, n_tiles=None,
                                   show_tile_progress=True, b=2, **predict_kwargs):
         import torch
@@ -513,13 +544,15 @@ class StarDistBase(object):
             sh = [s // grid_dict.get(a, 1) for a, s in zip(axes_net, x.shape)]
             pl, dl, ptl, pcl = [], [], [], []
             for s_tile, s_src, s_dst in self._tile_slices(x, n_tiles, axes_net, axes_net_div_by):
-                res = self._net_forward(x[s_tile])
+                res = self._net_forward(x[s_tile], sparse_head=True)
                 g = lambda sl: [slice(s.start // grid_dict.get(a, 1), s.stop // grid_dict.get(a, 1)) for s, a in zip(sl, axes_net) if a != "C"]
                 gsrc, gdst = g(s_src), g(s_dst)
                 prob_tile = res[0][..., 0][tuple(gsrc)]
-                dist_tile = res[1][tuple(gsrc)]
                 bs = [(b if s.start == 0 else 0, b if s.stop == _sh else 0) for s, _sh in zip(gdst, [v for v, a in zip(sh, axes_net) if a != "C"])]   # base.py:583
-                p_, d_, pt_ = self._select(prob_tile, dist_tile, prob_thresh, bs)
+                if self._head_mode == "sparse":
+                    p_, d_, pt_ = self._select_rows(prob_tile, res[1], [s.start for s in gsrc], prob_thresh, bs)
+                else:
+                    p_, d_, pt_ = self._select(prob_tile, res[1][tuple(gsrc)], prob_thresh, bs)
                 off = torch.tensor([s.start for s in gdst], device=self.device, dtype=torch.int64).reshape(1, nd)
                 pl.append(p_); dl.append(d_); ptl.append((pt_ + off) * gridt)
                 if self._is_multiclass():
@@ -531,10 +564,13 @@ class StarDistBase(object):
             proba, dista, pointsa = torch.cat(pl), torch.cat(dl), torch.cat(ptl)
             if self._is_multiclass(): prob_classa = torch.cat(pcl)
         else:
-            res = self._net_forward(x)
+            res = self._net_forward(x, sparse_head=True)
             prob = res[0][..., 0]
             bs = [(b, b)] * nd if np.isscalar(b) else list(b)
-            proba, dista, pts = self._select(prob, res[1], prob_thresh, bs)
+            if self._head_mode == "sparse":
+                proba, dista, pts = self._select_rows(prob, res[1], [0] * nd, prob_thresh, bs)
+            else:
+                proba, dista, pts = self._select(prob, res[1], prob_thresh, bs)
             pointsa = pts * gridt
             if self._is_multiclass():
                 pc = res[2].reshape(-1, res[2].shape[-1])

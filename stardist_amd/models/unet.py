@@ -69,6 +69,53 @@ def _conv_nobias(conv, x):
     return conv._conv_forward(x, conv.weight, None)
 
 
+# A convolution over a channel concatenation [a, b] equals conv(a, W[:, :Ca]) + conv(b, W[:, Ca:]).  For the large
+# (full-resolution) levels of the up path the two-source form is used on the GPU: the concatenated tensor is never written
+# (2D 2048^2: 1 GiB, 3D 256^3: 4 GiB), and MIOpen's kernel for the 4 GiB input of the 256^3 level runs at 33 TFLOP/s where
+# the two 32-channel halves run at 97 (56 ms -> 19 ms, tools/probe_bigconv.py).  The partial sums are added in float32 by
+# the same pass that applies bias + activation (sd_add_bias_act_device).
+_SPLIT_CONCAT_MIN_ELEMS = 2 ** 28
+
+
+def _split_weights(conv, ca):
+    """the two input-channel halves of conv.weight, cached per module (inference only: invalidated when the weight changes)"""
+    key = (conv.weight.data_ptr(), conv.weight._version, ca)
+    cache = conv.__dict__.get("_sd_split")
+    if cache is None or cache[0] != key:
+        mf = torch.channels_last if conv.weight.dim() == 4 else torch.channels_last_3d
+        wa = conv.weight[:, :ca].detach().contiguous(memory_format=mf)
+        wb = conv.weight[:, ca:].detach().contiguous(memory_format=mf)
+        cache = (key, wa, wb)
+        conv.__dict__["_sd_split"] = cache
+    return cache[1], cache[2]
+
+
+def _conv_cat_bias_act(conv, a, b, kind):
+    """act(conv(cat([a, b], 1)) + bias) without the concatenation; None if not applicable (caller concatenates)"""
+    if not (a.is_cuda and conv.bias is not None and a.dtype == torch.float32 and b.dtype == torch.float32 and not torch.is_grad_enabled()
+            and not torch.is_autocast_enabled() and kind in (0, 1) and a.numel() + b.numel() >= _SPLIT_CONCAT_MIN_ELEMS
+            and conv.groups == 1 and a.shape[1] + b.shape[1] == conv.in_channels):
+        return None
+    from ..lib import _native as N
+    wa, wb = _split_weights(conv, a.shape[1])
+    st, pd, dl = conv.stride, conv.padding, conv.dilation
+    f = F.conv2d if a.dim() == 4 else F.conv3d
+    y = f(a, wa, None, st, pd, dl)
+    z = f(b, wb, None, st, pd, dl)
+    C = y.shape[1]
+    cl = torch.channels_last if y.dim() == 4 else torch.channels_last_3d
+    if y.dtype == torch.float32 and y.is_contiguous(memory_format=cl) and z.is_contiguous(memory_format=cl):
+        n_outer, inner = y.numel() // C, 1
+    elif y.dtype == torch.float32 and y.is_contiguous() and z.is_contiguous():
+        n_outer, inner = y.shape[0], y.numel() // (y.shape[0] * C)
+    else:
+        y = y.add_(z).add_(conv.bias.to(y.dtype).view((1, C) + (1,) * (y.dim() - 2)))
+        return torch.relu_(y) if kind == 1 else y
+    N.dcall(y, "sd_add_bias_act_device", ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(z.data_ptr()), ctypes.c_void_p(conv.bias.data_ptr()),
+            n_outer, C, inner, kind)
+    return y
+
+
 def _conv_bias_act(conv, x, kind):
     """conv + bias + (0 linear | 1 relu) with the element-wise part done by the native one-pass kernel; None if not applicable"""
     if not (x.is_cuda and conv.bias is not None and x.dtype == torch.float32 and not torch.is_grad_enabled()):
@@ -165,8 +212,12 @@ class UNetBlock(nn.Module):
         x = self.middle(x)
         for blk, skip in zip(self.up, reversed(skips)):
             x = F.interpolate(x, scale_factor=tuple(float(p) for p in self.pool), mode="nearest")
-            x = torch.cat([x, skip], dim=1)
-            x = blk(x)
+            first = blk[0]
+            y = None
+            if isinstance(first, ConvAct) and len(first) == 2:
+                kind = 0 if isinstance(first[1], nn.Identity) else (1 if isinstance(first[1], nn.ReLU) else -1)
+                y = _conv_cat_bias_act(first[0], x, skip, kind)
+            x = blk(torch.cat([x, skip], dim=1)) if y is None else blk[1:](y)
         return x
 
 
@@ -301,11 +352,110 @@ class StarDistNet(nn.Module):
                 o[:, :, z0:z1] = p[:, :, z0 - a:z0 - a + (z1 - z0)]
         return tuple(outs)
 
-    def forward(self, x):
+    # ---- fused heads (GPU inference) ----------------------------------------------------------------------------------------
+    # features conv -> ONE pass doing bias + activation + the probability head (sd_bias_act_dot_device) -> distance head as an fp32-MFMA
+    # GEMM over the rows asked for (sd_head_rows_device): every pixel for the dense prediction, or -- sparse_head=True -- none here:
+    # the caller selects the candidate pixels from the probabilities and evaluates the distance head on those rows only
+    # (StarDistBase._predict_sparse_generator), so the dense n_rays-channel tensor of the reference's predict_sparse
+    # (base.py:553-610: full prediction, then masking) is never written.  Both paths run the same kernels with a fixed summation
+    # order per output, hence agree bit for bit.
+    fused_heads = True                        # False: plain module path on the GPU as well (statistics hooks, A/B timing)
+
+    def _fused_heads_ok(self, base):
+        f = self.features
+        if not (self.fused_heads and base.is_cuda and base.shape[0] == 1 and base.dtype == torch.float32 and not torch.is_grad_enabled()
+                and not torch.is_autocast_enabled() and isinstance(f, ConvAct) and len(f) == 2 and f[0].bias is not None):
+            return False
+        kind = 0 if isinstance(f[1], nn.Identity) else (1 if isinstance(f[1], nn.ReLU) else -1)
+        C, R = f[0].out_channels, self.dist.out_channels
+        return kind >= 0 and C in (32, 64, 128, 256) and R <= 128 and C * (((R + 31) // 32) * 32 + 1) * 4 <= 64 * 1024
+
+    def dist_rows(self, feat, rows, clamp_min):
+        """distance head on rows of the channels-last feature matrix feat (n_pix, C): (len(rows), n_rays); rows None = all"""
+        from ..lib import _native as N
+        C, R = feat.shape[-1], self.dist.out_channels
+        feat = feat.reshape(-1, C)
+        n = feat.shape[0] if rows is None else int(rows.shape[0])
+        out = torch.empty((n, R), dtype=torch.float32, device=feat.device)
+        if n:
+            w = self.dist.weight.detach().reshape(R, C).contiguous()
+            b = self.dist.bias
+            N.dcall(feat, "sd_head_rows_device", ctypes.c_void_p(feat.data_ptr()), C, ctypes.c_void_p(rows.data_ptr() if rows is not None else None),
+                    n, ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(b.data_ptr() if b is not None else None), R, float(clamp_min),
+                    ctypes.c_void_p(out.data_ptr()))
+        return out
+
+    def _heads_fused(self, base, sparse_head):
+        from ..lib import _native as N
+        conv, act = self.features[0], self.features[1]
+        kind = 1 if isinstance(act, nn.ReLU) else 0
+        nd = base.dim() - 2
+        cl = torch.channels_last if nd == 2 else torch.channels_last_3d
+        S = tuple(base.shape[2:])
+        D, plane = S[0], int(np.prod(S[1:]))
+        C = conv.out_channels
+        wp = self.prob.weight.detach().reshape(-1).contiguous()
+        bp = self.prob.bias
+        prob = torch.empty((1, 1) + S, dtype=torch.float32, device=base.device)
+        per_plane = max(base.shape[1], C) * plane
+        if per_plane * D <= self._INDEX_LIMIT:
+            slabs, feat = [(0, D, 0, D)], None
+        else:                                   # MIOpen indexes with int32: features conv on z-slabs with a halo (see _heads_slabbed)
+            halo = conv.kernel_size[0] // 2
+            cz = max(1, (self._INDEX_LIMIT // per_plane) - 2 * halo)
+            slabs = [(z0, min(D, z0 + cz), max(0, z0 - halo), min(D, min(D, z0 + cz) + halo)) for z0 in range(0, D, cz)]
+            feat = torch.empty((1, C) + S, dtype=torch.float32, device=base.device).contiguous(memory_format=cl)
+        for z0, z1, a, b in slabs:
+            y = _conv_nobias(conv, base[:, :, a:b] if (a, b) != (0, D) else base)
+            if not (y.dtype == torch.float32 and y.is_contiguous(memory_format=cl)):
+                y = y.float().contiguous(memory_format=cl)
+            if feat is None:
+                feat = y
+            src = y.data_ptr() + (z0 - a) * plane * C * 4
+            N.dcall(y, "sd_bias_act_dot_device", ctypes.c_void_p(src), ctypes.c_void_p(feat.data_ptr() + z0 * plane * C * 4),
+                    ctypes.c_void_p(conv.bias.data_ptr()), (z1 - z0) * plane, C, kind, ctypes.c_void_p(wp.data_ptr()),
+                    ctypes.c_void_p(bp.data_ptr() if bp is not None else None), 1, ctypes.c_void_p(prob.data_ptr() + z0 * plane * 4))
+        if sparse_head:
+            return prob, feat
+        R = self.dist.out_channels
+        dist = self.dist_rows(feat.permute(*([0] + list(range(2, nd + 2)) + [1])), None, float("-inf"))
+        return prob, dist.view((1,) + S + (R,)).permute(*([0, nd + 1] + list(range(1, nd + 1))))
+
+    def forward(self, x, sparse_head=False):
+        """(prob, dist[, prob_class]); with sparse_head=True and the fused heads available: (prob, features[, prob_class]) and
+        self.head_mode == "sparse" -- the distance head is then evaluated by the caller on the rows it selects (dist_rows)"""
         pool = F.max_pool2d if self.nd == 2 else F.max_pool3d
         for st in self.pre:
             x = pool(st["convs"](x), st.pool)
-        return self._heads_slabbed(self.backbone(x))
+        base = self.backbone(x)
+        self.head_mode = "dense"
+        if self._fused_heads_ok(base):
+            out = self._heads_fused(base, sparse_head)
+            if sparse_head:
+                self.head_mode = "sparse"
+            if self.n_classes is not None:
+                out = tuple(out) + (self._class_head_slabbed(base),)
+            return tuple(out)
+        return self._heads_slabbed(base)
+
+    def _class_head_slabbed(self, base):
+        head = lambda t: torch.softmax(self.prob_class(self.features_class(t)), dim=1)
+        widest = max(base.shape[1], self.prob_class.in_channels, self.prob_class.out_channels)
+        per_plane = base.shape[0] * widest * int(np.prod(base.shape[3:]))
+        D = base.shape[2]
+        if per_plane * D <= self._INDEX_LIMIT:
+            return head(base)
+        halo = self.features_class[0].kernel_size[0] // 2 if isinstance(self.features_class, nn.Sequential) else 0
+        cz = max(1, (self._INDEX_LIMIT // per_plane) - 2 * halo)
+        out = None
+        for z0 in range(0, D, cz):
+            z1 = min(D, z0 + cz)
+            a, b = max(0, z0 - halo), min(D, z1 + halo)
+            part = head(base[:, :, a:b])
+            if out is None:
+                out = torch.empty(part.shape[:2] + (D,) + part.shape[3:], dtype=part.dtype, device=part.device)
+            out[:, :, z0:z1] = part[:, :, z0 - a:z0 - a + (z1 - z0)]
+        return out
 
 
 def init_he_normal_(net, seed=0):

@@ -1,0 +1,139 @@
+"""GPU: the fused network heads (stardist_amd/csrc/unet_ops.hip) through the C ABI against float64 torch arithmetic:
+features epilogue + probability head (sd_bias_act_dot_device), distance head as fp32-MFMA GEMM on selected rows
+(sd_head_rows_device) -- dense and sparse evaluation of the same row agree bit for bit -- and the two-source epilogue of
+Concatenate+Conv (sd_add_bias_act_device).  Reference semantics: Conv 1x1 heads of model2d.py:338-343 / model3d.py:436-441."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _vp(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else None)
+
+
+@pytest.mark.parametrize("C", [32, 64, 128, 256])
+@pytest.mark.parametrize("act", [0, 1])
+def test_bias_act_dot(C, act):
+    import torch
+    from stardist_amd.lib import _native as N
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C + act)
+    n = 10007
+    x = torch.randn(n, C, generator=g).to(dev)
+    bias = torch.randn(C, generator=g).to(dev)
+    w = (torch.randn(C, generator=g) * 0.2).to(dev)
+    wb = torch.randn(1, generator=g).to(dev)
+    ref = x + bias
+    if act:
+        ref = torch.relu(ref)
+    for inplace in (False, True):
+        for sigm in (0, 1):
+            src = x.clone()
+            out = src if inplace else torch.full_like(x, float("nan"))
+            dot = torch.full((n,), float("nan"), device=dev)
+            N.dcall(src, "sd_bias_act_dot_device", _vp(src), _vp(out), _vp(bias), n, C, act, _vp(w), _vp(wb), sigm, _vp(dot))
+            assert torch.equal(out, ref)
+            d64 = ref.double() @ w.double() + wb.double()
+            if sigm:
+                d64 = torch.sigmoid(d64)
+            err = float((dot.double() - d64).abs().max())
+            assert err <= (2e-6 if sigm else 2e-5), err
+    # without a head: plain epilogue
+    src = x.clone()
+    N.dcall(src, "sd_bias_act_dot_device", _vp(src), _vp(src), _vp(bias), n, C, act, None, None, 0, None)
+    assert torch.equal(src, ref)
+    with pytest.raises(RuntimeError):
+        N.dcall(src, "sd_bias_act_dot_device", _vp(src), _vp(src), _vp(bias), n, 48, act, None, None, 0, None)
+
+
+@pytest.mark.parametrize("C,R", [(128, 32), (128, 96), (32, 32), (64, 7), (64, 100), (256, 32)])
+def test_head_rows_matches_float64_and_dense_equals_sparse(C, R):
+    import torch
+    from stardist_amd.lib import _native as N
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C * 1000 + R)
+    n_pix = 5003
+    feat = torch.relu(torch.randn(n_pix, C, generator=g)).to(dev)
+    W = (torch.randn(R, C, generator=g) * 0.3).to(dev)
+    b = torch.randn(R, generator=g).to(dev)
+    ref = feat.double() @ W.double().t() + b.double()
+    scale = (feat.double().abs() @ W.double().abs().t() + b.double().abs())          # sum |a b|: the float32 error scale
+
+    def run(rows, clamp):
+        n = n_pix if rows is None else rows.numel()
+        out = torch.full((n, R), float("nan"), device=dev)
+        N.dcall(feat, "sd_head_rows_device", _vp(feat), C, _vp(rows), n, _vp(W), _vp(b), R, float(clamp), _vp(out))
+        return out
+    dense = run(None, float("-inf"))
+    assert float(((dense.double() - ref).abs() / scale).max()) <= 2e-6
+    rows = torch.randperm(n_pix, generator=g)[:777].to(dev)
+    rows[5] = rows[6]                                                               # duplicates are fine
+    sparse = run(rows, float("-inf"))
+    assert torch.equal(sparse, dense[rows])                                          # same fma chain whatever the batch
+    for n in (1, 31, 32, 33, 64):                                                    # ragged tiles
+        assert torch.equal(run(rows[:n].contiguous(), float("-inf")), dense[rows[:n]])
+    clamped = run(rows, 1e-3)
+    assert torch.equal(clamped, torch.clamp_min(dense[rows], 1e-3))
+    # no bias
+    out = torch.empty((n_pix, R), device=dev)
+    N.dcall(feat, "sd_head_rows_device", _vp(feat), C, None, n_pix, _vp(W), None, R, float("-inf"), _vp(out))
+    assert float(((out.double() - (ref - b.double())).abs() / scale).max()) <= 2e-6
+    with pytest.raises(RuntimeError):
+        N.dcall(feat, "sd_head_rows_device", _vp(feat), 130, None, 1, _vp(W), None, R, 0.0, _vp(out))
+
+
+def test_add_bias_act():
+    import torch
+    from stardist_amd.lib import _native as N
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    for shape, C, inner in (((4099, 32), 32, 1), ((3, 6, 1001), 6, 1001)):
+        x = torch.randn(*shape, generator=g).to(dev); y = torch.randn(*shape, generator=g).to(dev)
+        bias = torch.randn(C, generator=g).to(dev)
+        n_outer = x.numel() // (C * inner)
+        for act in (0, 1):
+            t = x.clone()
+            N.dcall(t, "sd_add_bias_act_device", _vp(t), _vp(y), _vp(bias), n_outer, C, inner, act)
+            ref = (x + y) + (bias if inner == 1 else bias.view(1, C, 1))
+            assert torch.equal(t, torch.relu(ref) if act else ref)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_model_sparse_head_equals_dense_prediction(dim):
+    """predict_sparse (distance head on the candidate rows only, also through the tiled path) returns exactly the masked dense
+    prediction: the reference's predict_sparse contract, base.py:553-610"""
+    import torch
+    import bench
+    from oracle import synth
+    from stardist_amd.models import Config2D, Config3D, StarDist2D, StarDist3D
+    dev = torch.device("cuda:0")
+    if dim == 2:
+        img = synth.s2d_nuclei_image(384, 320, seed=2)
+        m = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
+        bench.calibrate_heads(m, torch.from_numpy(img).to(dev), frac=0.05)
+        tiles = (2, 2)
+    else:
+        img = synth.s3d_nuclei_image(64, seed=2)
+        m = StarDist3D(Config3D(rays=96), basedir=None, device=dev, seed=0)
+        bench.calibrate_heads(m, torch.from_numpy(img).to(dev), frac=0.02, radius=8.5, noise=0.03)
+        tiles = (1, 2, 2)
+    thr = float(m.thresholds.prob)
+    for n_tiles in (None, tiles):
+        prob, dist = m.predict(img, n_tiles=n_tiles)[:2]
+        ps, ds, pts = m.predict_sparse(img, prob_thresh=thr, n_tiles=n_tiles)
+        assert m._head_mode == "sparse"
+        mask = prob > thr
+        b = 2
+        inner = np.zeros_like(mask); inner[(slice(b, -b),) * dim] = True
+        mask &= inner
+        want_pts = np.stack(np.nonzero(mask), 1)
+        if n_tiles is not None:                      # candidates come tile by tile (as in the reference): compare in C order
+            order = np.lexsort(pts.T[::-1])
+            ps, ds, pts = ps[order], ds[order], pts[order]
+        assert np.array_equal(pts, want_pts)
+        idx = tuple(want_pts.T)
+        assert np.array_equal(ps, prob[idx])
+        assert np.array_equal(ds, np.maximum(dist[idx], 1e-3))

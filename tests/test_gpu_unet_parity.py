@@ -21,11 +21,16 @@ def _models(kind):
     raise ValueError(kind)
 
 
-@pytest.mark.parametrize("kind", ["unet2d", "unet3d", "resnet3d"])
-def test_gpu_forward_matches_cpu_float32_and_is_deterministic(kind):
+@pytest.mark.parametrize("kind", ["unet2d", "unet3d", "resnet3d", "unet2d-split", "unet3d-split"])
+def test_gpu_forward_matches_cpu_float32_and_is_deterministic(kind, monkeypatch):
     import torch
     import bench
     from oracle import synth
+    if kind.endswith("-split"):
+        # the two-source form of Concatenate+Conv (used from 2**28 elements on: 2048^2 / 256^3 top level) forced at test size
+        import stardist_amd.models.unet as U
+        monkeypatch.setattr(U, "_SPLIT_CONCAT_MIN_ELEMS", 0)
+        kind = kind[:-6]
     make, (dim, size), calib = _models(kind)
     img = synth.s2d_nuclei_image(size, size, seed=1) if dim == "2d" else synth.s3d_nuclei_image(size, seed=1)
     dev = torch.device("cuda:0")
