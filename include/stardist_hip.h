@@ -183,6 +183,14 @@ int sd_bias_act_device(float* d_x, const float* d_bias, long long n_outer, int n
 int sd_add_bias_act_device(float* d_x, const float* d_addend, const float* d_bias, long long n_outer,
                            int n_channels, long long inner, int act, void* stream);
 
+/* point-level probe of the reference's inside_polyhedron (stardist/lib/stardist3d_impl.cpp:153-191) for ONE polyhedron
+ * (d_dist: n_rays, d_centre: 3, zyx) on n points (d_points: n x 3, zyx): d_out[t] = 1 if inside.  use_cone_map != 0 evaluates
+ * the predicate only on the faces whose cone can contain the point's direction (csrc/geom3d.h), as stage 5 of the NMS does;
+ * both settings give identical results. */
+int sd_inside_polyhedron_device(const float* d_dist, const float* d_centre, int n_rays, int n_faces,
+                                const float* d_verts, const int* d_faces, const float* d_points,
+                                long long n, int use_cone_map, uint8_t* d_out, void* stream);
+
 /* features epilogue + one-channel head: out = act(in + bias) over channels-last [n_pix][n_channels] float32 (in place when
  * d_out == d_in; n_channels 32, 64, 128 or 256) and, when d_w is given, d_dot[p] = sum_c out[p][c] * d_w[c] + d_wbias[0], through the
  * logistic function when sigmoid != 0: the object-probability head of the reference's models (Conv 1x1, sigmoid:

@@ -1236,12 +1236,14 @@ __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, u
 __global__ void __launch_bounds__(256) k_stage5(const int2* __restrict__ pairs, unsigned int nPairs, const float* __restrict__ dist,
                                                 const float* __restrict__ pts, const float* __restrict__ verts,
                                                 const int* __restrict__ faces, int R, int F, const int* __restrict__ bbox,
-                                                const float* __restrict__ volume, float thr, unsigned char* __restrict__ state, Stats* st) {
+                                                const float* __restrict__ volume, float thr, unsigned char* __restrict__ state, Stats* st,
+                                                sd3::ConeMap cm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* pv1 = (float*)smem;       // 3R
   float* pv2 = pv1 + 3 * R;        // 3R
   int* fc = (int*)(pv2 + 3 * R);   // 3F
   __shared__ unsigned int s_count;
+  __shared__ int s_unsafe[2];      // cone map preconditions violated (geom3d.h): some dist < 1 or a coordinate beyond 8192
   for (int k = threadIdx.x; k < 3 * F; k += blockDim.x) fc[k] = faces[k];
   for (unsigned int p = blockIdx.x; p < nPairs; p += gridDim.x) {
     const int2 ij = pairs[p];
@@ -1253,8 +1255,20 @@ __global__ void __launch_bounds__(256) k_stage5(const int2* __restrict__ pairs, 
       pv1[3 * k] = c1[0] + d1 * verts[3 * k]; pv1[3 * k + 1] = c1[1] + d1 * verts[3 * k + 1]; pv1[3 * k + 2] = c1[2] + d1 * verts[3 * k + 2];
       pv2[3 * k] = c2[0] + d2 * verts[3 * k]; pv2[3 * k + 1] = c2[1] + d2 * verts[3 * k + 1]; pv2[3 * k + 2] = c2[2] + d2 * verts[3 * k + 2];
     }
-    if (threadIdx.x == 0) s_count = 0;
+    if (threadIdx.x == 0) { s_count = 0; s_unsafe[0] = cm.list ? 0 : 1; s_unsafe[1] = cm.list ? 0 : 1; }
     __syncthreads();
+    if (cm.list) {
+      for (int k = threadIdx.x; k < R; k += blockDim.x) {
+        const float d1 = dist[(size_t)ij.x * R + k], d2 = dist[(size_t)ij.y * R + k];
+        const float m1 = fmaxf(fmaxf(fabsf(pv1[3 * k]), fabsf(pv1[3 * k + 1])), fabsf(pv1[3 * k + 2]));
+        const float m2 = fmaxf(fmaxf(fabsf(pv2[3 * k]), fabsf(pv2[3 * k + 1])), fabsf(pv2[3 * k + 2]));
+        if (!(d1 >= 1.f) || !(m1 < 8192.f)) s_unsafe[0] = 1;
+        if (!(d2 >= 1.f) || !(m2 < 8192.f)) s_unsafe[1] = 1;
+      }
+      __syncthreads();
+    }
+    const bool safe1 = !s_unsafe[0] && fabsf(c1[0]) < 8192.f && fabsf(c1[1]) < 8192.f && fabsf(c1[2]) < 8192.f;
+    const bool safe2 = !s_unsafe[1] && fabsf(c2[0]) < 8192.f && fabsf(c2[1]) < 8192.f && fabsf(c2[2]) < 8192.f;
     // the reference sweeps the whole bbox of i; lattice points outside j's (rounded) bbox cannot be inside j
     const int* b1 = bbox + 6 * (size_t)ij.x;
     const int* b2 = bbox + 6 * (size_t)ij.y;
@@ -1269,8 +1283,8 @@ __global__ void __launch_bounds__(256) k_stage5(const int2* __restrict__ pairs, 
         const float x = (float)(xlo + (int)(t % bx));
         const i64 r = t / bx;
         const float y = (float)(ylo + (int)(r % by)), z = (float)(zlo + (int)(r / by));
-        if (sd3::inside_polyhedron(z, y, x, c1[0], c1[1], c1[2], pv1, fc, F) &&
-            sd3::inside_polyhedron(z, y, x, c2[0], c2[1], c2[2], pv2, fc, F)) ++local;
+        if (sd3::inside_polyhedron_mapped(z, y, x, c1[0], c1[1], c1[2], pv1, fc, F, cm, safe1) &&
+            sd3::inside_polyhedron_mapped(z, y, x, c2[0], c2[1], c2[2], pv2, fc, F, cm, safe2)) ++local;
       }
     }
     for (int o = 32; o; o >>= 1) local += __shfl_xor(local, o);
@@ -1297,6 +1311,11 @@ __global__ void __launch_bounds__(256) k_stage5(const int2* __restrict__ pairs, 
   }
 }
 
+__global__ void k_cone_map(const float* __restrict__ verts, const int* __restrict__ faces, int F, unsigned short* __restrict__ list,
+                           signed char* __restrict__ count) {
+  const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell < SD_CM_CELLS) sd3::cone_map_build_cell(cell, verts, faces, F, list, count);
+}
 __global__ void k_iota3(int* a, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = i; }
 __global__ void k_keep3(const unsigned char* __restrict__ state, unsigned char* __restrict__ keep, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1383,6 +1402,56 @@ extern "C" int sd_hiv_pairs_device(const float* d_dist, const float* d_points, i
   SD_CHECK(hipMemcpyAsync(&hst, d_st, sizeof(Stats), hipMemcpyDeviceToHost, s));
   SD_CHECK(hipStreamSynchronize(s));
   if (hst.overflow) { sd::set_error("sd_hiv_pairs: %llu pairs exceeded the polygon capacity of the volume routine", hst.overflow); return -1; }
+  return 0;
+}
+
+// point-level probe of the voxel test of stage 5 / the rasteriser (inside_polyhedron, stardist3d_impl.cpp:153-191): out[t] = 1
+// if point t lies in the union of the tetrahedra (centre, face) of ONE polyhedron; use_cone_map selects the face lists of
+// geom3d.h instead of the loop over every face -- both must agree on every point (tests/test_gpu_parity3d.py).
+namespace {
+__global__ void __launch_bounds__(256) k_inside_probe(const float* __restrict__ dist, const float* __restrict__ centre, int R, int F,
+                                                      const float* __restrict__ verts, const int* __restrict__ faces,
+                                                      const float* __restrict__ points, long long n, sd3::ConeMap cm, unsigned char* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* pv = (float*)smem;
+  __shared__ int s_unsafe;
+  const float cz = centre[0], cy = centre[1], cx = centre[2];
+  if (threadIdx.x == 0) s_unsafe = cm.list ? 0 : 1;
+  __syncthreads();
+  for (int k = threadIdx.x; k < R; k += blockDim.x) {
+    const float d = dist[k];
+    pv[3 * k] = cz + d * verts[3 * k]; pv[3 * k + 1] = cy + d * verts[3 * k + 1]; pv[3 * k + 2] = cx + d * verts[3 * k + 2];
+    const float m = fmaxf(fmaxf(fabsf(pv[3 * k]), fabsf(pv[3 * k + 1])), fabsf(pv[3 * k + 2]));
+    if (!(d >= 1.f) || !(m < 8192.f)) s_unsafe = 1;
+  }
+  __syncthreads();
+  const bool safe = !s_unsafe && fabsf(cz) < 8192.f && fabsf(cy) < 8192.f && fabsf(cx) < 8192.f;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
+    out[t] = sd3::inside_polyhedron_mapped(points[3 * t], points[3 * t + 1], points[3 * t + 2], cz, cy, cx, pv, faces, F, cm, safe) ? 1 : 0;
+}
+}  // namespace
+extern "C" int sd_inside_polyhedron_device(const float* d_dist, const float* d_centre, int n_rays, int n_faces, const float* d_verts,
+                                           const int* d_faces, const float* d_points, long long n, int use_cone_map, uint8_t* d_out,
+                                           void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (n <= 0) return 0;
+  if (n_rays < 4 || n_faces < 4 || n_rays > 800 || n_faces > 65535) { sd::set_error("sd_inside_polyhedron: need 4 <= n_rays <= 800, 4 <= n_faces <= 65535"); return -1; }
+  sd::Arena& A = sd::arena();
+  if (A.begin(s)) return -1;
+  sd3::ConeMap cm{nullptr, nullptr};
+  if (use_cone_map) {
+    unsigned short* l = A.take_n<unsigned short>((size_t)SD_CM_CELLS * SD_CM_CAP);
+    signed char* c = A.take_n<signed char>(SD_CM_CELLS);
+    if (!l || !c) return -1;
+    hipLaunchKernelGGL(k_cone_map, dim3(sd::div_up(SD_CM_CELLS, 64)), dim3(64), 0, s, d_verts, d_faces, n_faces, l, c);
+    SD_LAUNCH_CHECK();
+    cm.list = l; cm.count = c;
+  }
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_inside_probe, dim3((unsigned int)blocks), dim3(256), (size_t)3 * n_rays * sizeof(float), s, d_dist, d_centre, n_rays, n_faces, d_verts,
+                     d_faces, d_points, n, cm, d_out);
+  SD_LAUNCH_CHECK();
   return 0;
 }
 
@@ -1539,6 +1608,16 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
                      nbrCount, (const i64*)nbrStart, nbr, W);
   SD_LAUNCH_CHECK();
 
+  // cone map for the voxel tests of stage 5 (geom3d.h); SD_NMS3D_NO_CONEMAP=1 tests every face as the reference does
+  sd3::ConeMap cmap{nullptr, nullptr};
+  if (F <= 65535 && !(getenv("SD_NMS3D_NO_CONEMAP") && atoi(getenv("SD_NMS3D_NO_CONEMAP")))) {
+    unsigned short* cmList = A.take_n<unsigned short>((size_t)SD_CM_CELLS * SD_CM_CAP);
+    signed char* cmCount = A.take_n<signed char>(SD_CM_CELLS);
+    if (!cmList || !cmCount) return -1;
+    hipLaunchKernelGGL(k_cone_map, dim3(sd::div_up(SD_CM_CELLS, 64)), dim3(64), 0, s, d_verts, d_faces, F, cmList, cmCount);
+    SD_LAUNCH_CHECK();
+    cmap.list = cmList; cmap.count = cmCount;
+  }
   const unsigned int pairCap = (unsigned int)((totalNbr / 2 + 64) < (1ll << 31) ? (totalNbr / 2 + 64) : ((1ll << 31) - 1));
   int* U0 = A.take_n<int>(N);
   int* U1 = A.take_n<int>(N);
@@ -1623,7 +1702,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
           const unsigned int b5 = h.nP5 < 16384u ? h.nP5 : 16384u;
           if (stats) SD_CHECK(hipEventRecord(ev0, s));
           hipLaunchKernelGGL(k_stage5, dim3(b5), dim3(256), lds5, s, pairs5, h.nP5, d_dist, d_points, d_verts, d_faces, R, F, bbox, volume,
-                             threshold, state, d_st);
+                             threshold, state, d_st, cmap);
           SD_LAUNCH_CHECK();
           if (stats) { SD_CHECK(hipEventRecord(ev1, s)); SD_CHECK(hipEventSynchronize(ev1)); float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns5 += ms * 1e6; }
         }

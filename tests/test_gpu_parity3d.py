@@ -183,3 +183,78 @@ def test_pair_volumes_match_qhull(refmods, n_rays, noise):
     print("kernel volumes: %d non-zero, max rel diff %.3g; hull volumes: %d finite, max rel diff %.3g" % (nz.sum(), relk.max() if nz.any() else 0, (~bigh).sum(), relh.max()))
     assert nz.sum() > 1000 and (~bigh).sum() > 5000
     assert (relk.max() if nz.any() else 0) < 2e-6 and relh.max() < 2e-6         # the reference returns float32
+
+
+@pytest.mark.parametrize("n_rays,aniso", [(96, None), (32, None), (64, (2.0, 1.0, 1.0)), (11, None), (300, None)])
+def test_inside_polyhedron_cone_map_equals_full_loop(n_rays, aniso):
+    """stage 5 of the NMS tests a voxel only against the faces whose cone can contain its direction (csrc/geom3d.h): on lattice
+    points, random points, points on the faces / on the cone boundaries (vertices, edge planes) and next to the centre the result
+    must equal the loop over every face (inside_polyhedron, stardist3d_impl.cpp:153-191), also when the map's preconditions fail
+    (dist < 1, far-away coordinates) and it has to step aside"""
+    import ctypes
+    import torch
+    from stardist_amd.lib import _native as N
+    dev = torch.device("cuda:0")
+    rays = _rays(n_rays, aniso)
+    V = np.ascontiguousarray(rays.vertices, np.float32); Fc = np.ascontiguousarray(rays.faces, np.int32)
+    tV, tF = torch.from_numpy(V).to(dev), torch.from_numpy(Fc).to(dev)
+    rng = np.random.RandomState(n_rays)
+    total = 0
+    for case in range(8):
+        radius = [9.0, 9.0, 3.0, 25.0, 0.7, 9.0, 9.0, 1.5][case]
+        noise = [0.0, 0.3, 0.6, 0.1, 0.2, 0.9, 0.05, 0.5][case]
+        c = rng.uniform(20, 40, 3).astype(np.float32)
+        if case == 3:
+            c = np.float32([9000.25, 31.5, 17.75])                        # beyond the coordinate bound: full loop
+        if case == 6:
+            c = np.float32([30, 31, 32])                                   # lattice centre: voxels exactly on cone boundaries
+        d = (radius * (1 + noise * rng.uniform(-1, 1, n_rays))).astype(np.float32)
+        d = np.maximum(d, 1e-3).astype(np.float32)
+        ext = float(d.max() * np.abs(V).max()) + 2
+        g = np.arange(-int(ext) - 1, int(ext) + 2, dtype=np.float32)
+        lat = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) + np.round(c)
+        rnd = (c + rng.uniform(-ext, ext, (20000, 3))).astype(np.float32)
+        verts = (c + d[:, None] * V).astype(np.float32)
+        tri = verts[Fc]                                                      # (F, 3, 3)
+        w = rng.dirichlet((1, 1, 1), (len(Fc), 8)).astype(np.float32)       # points on the faces
+        onface = np.einsum("fkt,ftd->fkd", w, tri).reshape(-1, 3)
+        t = rng.uniform(0, 1.2, (n_rays, 8, 1)).astype(np.float32)           # along the rays (cone apex lines)
+        onray = (c + t * d[:, None, None] * V[:, None, :]).reshape(-1, 3)
+        e = np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]])  # points in the side planes (centre, edge)
+        u = rng.uniform(0, 1, (len(e), 4, 1)).astype(np.float32); sc = rng.uniform(0, 1.1, (len(e), 4, 1)).astype(np.float32)
+        onside = (c + sc * ((u * e[:, None, 0] + (1 - u) * e[:, None, 1]) - c)).reshape(-1, 3)
+        near = (c + rng.uniform(-0.6, 0.6, (2000, 3))).astype(np.float32)
+        pts = np.ascontiguousarray(np.concatenate([lat, rnd, onface, onray, onside, near, c[None]]).astype(np.float32))
+        tp = torch.from_numpy(pts).to(dev); td = torch.from_numpy(d).to(dev); tc = torch.from_numpy(c).to(dev)
+        outs = []
+        for use_map in (0, 1):
+            o = torch.empty(len(pts), dtype=torch.uint8, device=dev)
+            N.dcall(tp, "sd_inside_polyhedron_device", N.tptr(td), N.tptr(tc), n_rays, len(Fc), N.tptr(tV), N.tptr(tF), N.tptr(tp), len(pts), use_map,
+                    N.tptr(o))
+            outs.append(o.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1]), (case, int((outs[0] != outs[1]).sum()))
+        assert 0 < outs[0].sum() < len(pts)
+        total += len(pts)
+    assert total > 100000
+
+
+@pytest.mark.parametrize("n_rays,noise,thr", [(96, 0.3, 0.3), (32, 0.5, 0.5), (96, 0.3, 0.6)])
+def test_nms3d_cone_map_does_not_change_survivors(refmods, monkeypatch, n_rays, noise, thr):
+    """stage 5 with the cone map vs the loop over every face (SD_NMS3D_NO_CONEMAP=1) vs the reference: same survivors and the same
+    cascade counters (pairs rendered, suppressed by the rendered overlap) on candidate sets that do reach stage 5"""
+    import torch
+    from stardist_amd.lib import stardist3d as sd3
+    rays = _rays(n_rays)
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    d, p, s = _random_candidates((22, 33, 44), n_rays, noise, seed=n_rays)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    args = (t(d), t(p), t(np.float32(V)), t(F), t(s), 1, 1, 0, np.float32(thr))
+    keep_map, st_map = sd3.c_non_max_suppression_inds(*args, return_stats=True)
+    st_map = st_map.copy()
+    monkeypatch.setenv("SD_NMS3D_NO_CONEMAP", "1")
+    keep_full, st_full = sd3.c_non_max_suppression_inds(*args, return_stats=True)
+    monkeypatch.delenv("SD_NMS3D_NO_CONEMAP")
+    ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(thr))
+    assert np.array_equal(keep_map.cpu().numpy(), keep_full.cpu().numpy()) and np.array_equal(keep_full.cpu().numpy(), ref_keep)
+    assert st_map[3] > 0, "no pair reached the render stage: %s" % st_map.tolist()
+    assert np.array_equal(st_map[[0, 1, 2, 3, 6, 7]], st_full[[0, 1, 2, 3, 6, 7]])
