@@ -194,7 +194,8 @@ int sd_inside_polyhedron_device(const float* d_dist, const float* d_centre, int 
 /* features epilogue + one-channel head: out = act(in + bias) over channels-last [n_pix][n_channels] float32 (in place when
  * d_out == d_in; n_channels 32, 64, 128 or 256) and, when d_w is given, d_dot[p] = sum_c out[p][c] * d_w[c] + d_wbias[0], through the
  * logistic function when sigmoid != 0: the object-probability head of the reference's models (Conv 1x1, sigmoid:
- * stardist/models/model2d.py:338-341, model3d.py:436-439) evaluated while the features are in registers. */
+ * stardist/models/model2d.py:338-341, model3d.py:436-439) evaluated while the features are in registers.
+ * d_bias == NULL: no bias; d_out == NULL (d_w given): the features are only read and just d_dot is written. */
 int sd_bias_act_dot_device(const float* d_in, float* d_out, const float* d_bias, long long n_pix, int n_channels,
                            int act, const float* d_w, const float* d_wbias, int sigmoid, float* d_dot, void* stream);
 /* distance head on selected pixels: d_out[i][r] = max(clamp_min, d_bias[r] + sum_k d_feat[d_rows[i]][k] * d_w[r][k]) for
@@ -205,6 +206,23 @@ int sd_bias_act_dot_device(const float* d_in, float* d_out, const float* d_bias,
 int sd_head_rows_device(const float* d_feat, int n_channels, const long long* d_rows, long long n_rows,
                         const float* d_w, const float* d_bias, int n_out, float clamp_min, float* d_out,
                         void* stream);
+
+/* ---- network convolutions (hand-written, f32 matrix cores) --------------------------------------------------------------
+ * One Keras Conv2D(3x3) / Conv3D(3x3x3), padding='same', stride 1, + bias + activation of the reference's U-Net (csbdeep unet_block as
+ * built by stardist/models/model2d.py:310-349 and model3d.py:360-399), channels-last float32:
+ *     out[z][y][x][co] = act(bias[co] + sum_{ci,kz,ky,kx} in[z+kz-1][y+ky-1][x+kx-1][ci] * w[co][ci][kz][ky][kx])   (zero padding)
+ * kz = 1: 2D (D must be 1), kz = 3: 3D.  The input channels are the concatenation [source 0 (c0 channels), source 1 (c1 channels)]
+ * -- Concatenate([up, skip]) of the up path without the concatenated tensor; d_src1 == NULL: one source.  `up` is a bit mask of the
+ * axes (1: x, 2: y, 4: z) along which a source has half the output resolution and is read through nearest-neighbour 2x up-sampling
+ * (UpSampling2D/3D folded into the operand fetch).  stride = floats per pixel of a source.
+ * Supported: c0, c1 multiples of 32 with c0 + c1 <= 256 and c_out a multiple of 32; and the first layer c0 = 1 (c_out % 4 == 0).
+ * d_wpacked: the kernel in the device layout written by sd_conv3_pack_weights_host (sd_conv3_packed_floats floats).
+ * act: 0 linear, 1 relu.  Exact float32: each output is one fma chain in a fixed order (bias first), repeatable bit for bit. */
+long long sd_conv3_packed_floats(int c_in, int c_out, int kz);
+int sd_conv3_pack_weights_host(const float* w /* [c_out][c_in][kz][3][3] */, int c_in, int c_out, int kz, float* packed);
+int sd_conv3_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1, int up1,
+                          int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, int c_out, int act,
+                          float* d_out, void* stream);
 
 #ifdef __cplusplus
 }

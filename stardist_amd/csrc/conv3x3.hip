@@ -1,0 +1,336 @@
+// conv3x3.hip -- the network's 3x3 (2D) and 3x3x3 (3D) convolutions as hand-written implicit GEMMs on the f32 matrix cores.
+//
+// Replaces Keras Conv2D / Conv3D(kernel 3, 'same') + bias + ReLU of the csbdeep unet_block the reference builds in
+// stardist/models/model2d.py:310-349 and model3d.py:360-399 (and the UpSampling + Concatenate in front of the first convolution
+// of an up level):
+//   * k_conv3<NT>: input channels in chunks of 32, each chunk from its own source tensor so that Concatenate([up, skip]) never
+//     exists in memory; a source may be half resolution along any axis = nearest 2x up-sampling folded into the operand fetch;
+//     32*NT output channels per workgroup, bias + activation in the epilogue.  A 3x3x3 convolution is the sum of three z planes
+//     of 3x3 taps: the work list of an output tile is (chunk, kz) "units", each = one halo tile + one 9-tap weight block in LDS.
+//     Layout and k order: conv3x3_layout.h.  Persistent workgroups (one per CU); the next unit's halo tile and weight block are
+//     fetched (tile: into registers, weights: LDS-direct into the second weight buffer) while the matrix cores work on the current one.  Exact float32: every output is ONE fma chain in a fixed order (bias first), so results do not depend on
+//     tiling, launch geometry or run.
+//   * k_conv3_c1: the first layer (1 input channel, K = 9 or 27): HBM-write bound, plain FMAs.
+// Bound: MFMA (f32: 64 FLOP/clk/SIMD); algorithmic bytes 4*(C_in + C_out) per pixel.
+#include "common.h"
+#include "conv3x3_layout.h"
+#include "stardist_hip.h"
+
+namespace {
+
+using namespace sdconv;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Src {
+  const float* p;      // channels-last [D >> shz][H >> shy][W >> shx][stride], already offset to this chunk's first channel
+  int stride;          // floats per pixel
+  int shz, shy, shx;   // 1: the source is half resolution along that axis (nearest-neighbour up-sampling by 2)
+};
+
+struct Params {
+  Src src[MAX_CHUNKS];
+  int D, H, W;
+  int kz;              // z taps: 1 (2D) or 3
+  int n_units;         // chunks * kz
+  const float* wp;     // packed weights [groups][n_units][wunit_floats(NT)]
+  const float* bias;
+  float* out;          // [D][H][W][c_out]
+  int c_out, act;
+  int tiles_x, tiles_plane, n_tiles, groups;
+};
+
+// Halo tile of unit u of output tile t, 16 bytes per (thread, n), plus the unit's weight block.  Branch-free: coordinates are
+// clamped into the volume so that every load is legal and all loads of a thread issue back to back; out-of-volume elements (the
+// zero padding of 'same') and the unused tail of the last n are zeroed by a select afterwards.
+template <int NT>
+__device__ __forceinline__ void load_unit(const Params& P, int g, int t, int u, float4 (&pre)[PRE_F4], float* __restrict__ Wnext, int tid) {
+  const int c = u / P.kz, dz = P.kz == 3 ? u - c * 3 - 1 : 0;
+  const Src S = P.src[c];
+  const int tz = t / P.tiles_plane, tr = t - tz * P.tiles_plane;
+  const int ty0 = (tr / P.tiles_x) * TH - 1, tx0 = (tr % P.tiles_x) * TW - 1;
+  const int z = tz + dz;
+  const bool zin = z >= 0 && z < P.D;
+  const int ws = P.W >> S.shx, hs = P.H >> S.shy;
+  const float* base = S.p + (size_t)(min(max(z, 0), P.D - 1) >> S.shz) * hs * ws * S.stride;
+#pragma unroll
+  for (int n = 0; n < PRE_F4; ++n) {
+    int e = tid + n * THREADS;
+    e = e < TILE_F4 ? e : TILE_F4 - 1;
+    int ty, tx, q4;
+    stage_elem(e, ty, tx, q4);
+    const int gy = ty0 + ty, gx = tx0 + tx;
+    const bool inside = zin && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+    const int cy = min(max(gy, 0), P.H - 1) >> S.shy, cx = min(max(gx, 0), P.W - 1) >> S.shx;
+    const float4 v = *(const float4*)(base + ((size_t)cy * ws + cx) * S.stride + q4 * 4);
+    pre[n] = inside ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // the unit's weight block: a linear 36 KiB copy, global -> LDS without passing through registers (global_load_lds_dwordx4:
+  // LDS destination = wave-uniform base + lane * 16); wave w, instruction n moves the n*4+w-th KiB
+  const float* wsrc = P.wp + ((size_t)g * P.n_units + u) * (9 * 4 * 2 * 32 * NT * 4);
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int n = 0; n < 9 * NT; ++n) {
+    const int kib = n * 4 + wave;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kib * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(Wnext + kib * 256), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void store_unit(float* __restrict__ tileL, const float4 (&pre)[PRE_F4], int tid) {
+#pragma unroll
+  for (int n = 0; n < PRE_F4; ++n) {
+    const int e = tid + n * THREADS;
+    if (e < TILE_F4) {
+      int ty, tx, q4;
+      stage_elem(e, ty, tx, q4);
+      *(float4*)(tileL + tile_off(ty, tx, q4 * 4)) = pre[n];
+    }
+  }
+}
+
+__device__ __forceinline__ float comp(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+
+// One unit: 12 operand groups (dx, j); a group = the four halo rows the wave's two output rows touch (A) and the three taps dy of
+// that column (B) = 7 (NT = 1) or 10 (NT = 2) ds_read_b128 feeding 24 NT MFMAs.  The operands of group g+1 are read while the
+// matrix cores work on group g (two register sets).
+template <int NT>
+__device__ __forceinline__ void compute_unit(const float* __restrict__ tileL, const float* __restrict__ wl, f32x16 (&acc)[2][NT], int wave, int i, int h) {
+  float4 A[2][4], B[2][3][NT];
+#define SD_LOAD_GROUP(gi, buf)                                                                          \
+  do {                                                                                                   \
+    const int dx_ = (gi) >> 2, j_ = (gi) & 3;                                                            \
+    _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) A[buf][rr] = *(const float4*)(tileL + a_off(wave * 2, rr, dx_, j_, i, h)); \
+    _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                                     \
+      _Pragma("unroll") for (int ct = 0; ct < NT; ++ct) B[buf][dy][ct] = *(const float4*)(wl + wl_off(dy * 3 + dx_, j_, h, ct, i, NT)); \
+  } while (0)
+  SD_LOAD_GROUP(0, 0);
+#pragma unroll
+  for (int gi = 0; gi < 12; ++gi) {
+    const int buf = gi & 1;
+    if (gi + 1 < 12) SD_LOAD_GROUP(gi + 1, buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);        // keep the reads of the next group ahead of this group's MFMAs
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+          const float bv = comp(B[buf][dy][ct], e);
+          acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(A[buf][dy], e), bv, acc[0][ct], 0, 0, 0);
+          acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(A[buf][dy + 1], e), bv, acc[1][ct], 0, 0, 0);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef SD_LOAD_GROUP
+}
+
+// One step of the pipeline: start fetching the next unit (halo tile -> registers, weight block -> LDS-direct into `wnext`), run the
+// matrix cores on the current unit (tile + `wcur`), then move the fetched tile into LDS.  The three LDS regions are disjoint; the
+// __restrict__ qualifiers carry that to the waitcnt insertion, which otherwise orders every ds_read behind the in-flight
+// LDS-direct loads (vmcnt(0) in front of the first MFMA group = no overlap).
+template <int NT>
+__device__ __forceinline__ void unit_step(const Params& P, int g, bool have, int tn, int un, float* __restrict__ tileL, const float* __restrict__ wcur,
+                                          float* __restrict__ wnext, f32x16 (&acc)[2][NT], int tid, int wave, int i, int h) {
+  float4 pre[PRE_F4];
+  if (have) load_unit<NT>(P, g, tn, un, pre, wnext, tid);
+  __builtin_amdgcn_sched_barrier(0);
+  compute_unit<NT>(tileL, wcur, acc, wave, i, h);
+  __syncthreads();
+  if (have) store_unit(tileL, pre, tid);
+  __syncthreads();
+}
+
+template <int NT>
+__global__ void __launch_bounds__(THREADS) k_conv3(const Params P) {
+  extern __shared__ float4 smem4[];
+  float* tileL = (float*)smem4;
+  float* Wl = tileL + TILE_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
+  // workgroup -> (output-channel group g, tile slot q): consecutive workgroups go round-robin over the 8 XCDs, so the `groups`
+  // workgroups b, b+8, b+16, ... (same XCD, same L2) take the same tile sequence and differ in g
+  const int b = blockIdx.x, span = 8 * P.groups, blk = b / span, rem = b - blk * span;
+  int g, q;
+  if ((blk + 1) * span <= (int)gridDim.x) { g = rem >> 3; q = blk * 8 + (rem & 7); }
+  else { const int tail = gridDim.x - blk * span, per = tail / P.groups; g = rem / per; q = blk * 8 + rem % per; }   // last partial span
+  const int Q = gridDim.x / P.groups;
+  if (q >= P.n_tiles) return;
+  float bias_r[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) bias_r[ct] = P.bias ? P.bias[g * 32 * NT + ct * 32 + i] : 0.f;
+  constexpr int WU = 9 * 4 * 2 * 32 * NT * 4;          // floats of one weight block; two buffers, used alternately
+  {
+    float4 pre[PRE_F4];
+    load_unit<NT>(P, g, q, 0, pre, Wl, tid);
+    store_unit(tileL, pre, tid);
+  }
+  __syncthreads();                                     // (the compiler drains the LDS-direct loads before the barrier)
+  int wb = 0;
+  for (int t = q; t < P.n_tiles; t += Q) {
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][ct][r] = bias_r[ct];
+    for (int u = 0; u < P.n_units; ++u) {
+      const bool last = u == P.n_units - 1;
+      const int tn = last ? t + Q : t, un = last ? 0 : u + 1;
+      unit_step<NT>(P, g, tn < P.n_tiles, tn, un, tileL, Wl + wb * WU, Wl + (wb ^ 1) * WU, acc, tid, wave, i, h);
+      wb ^= 1;
+    }
+    // epilogue: activation + store (the stores drain while the next tile is being computed: nothing waits on them before the
+    // next unit's prefetch has been consumed, a full compute phase later)
+    const int tz = t / P.tiles_plane, tr = t - tz * P.tiles_plane;
+    const int y0 = (tr / P.tiles_x) * TH + wave * 2, x0 = (tr % P.tiles_x) * TW;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int y = y0 + p;
+      if (y < P.H) {
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+          float* orow = P.out + ((size_t)tz * P.H + y) * P.W * P.c_out + g * 32 * NT + ct * 32 + i;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int x = x0 + acc_col(r, h);
+            const float v = P.act == 1 ? fmaxf(acc[p][ct][r], 0.f) : acc[p][ct][r];
+            if (x < P.W) orow[(size_t)x * P.c_out] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// first layer: one input channel.  thread = (pixel, 4 output channels); w4 is [taps][c_out/4] float4 (tap-major, taps = 9 kz)
+template <int KZ>
+__global__ void __launch_bounds__(256) k_conv3_c1(const float* __restrict__ x, int D, int H, int W, const float4* __restrict__ w4,
+                                                  const float4* __restrict__ bias4, int c4, int act, float4* __restrict__ out) {
+  const long long n = (long long)D * H * W * c4;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+    const int q = (int)(idx % c4);
+    const long long pix = idx / c4;
+    const int xx = (int)(pix % W);
+    const long long rest = pix / W;
+    const int y = (int)(rest % H), z = (int)(rest / H);
+    float4 s = bias4 ? bias4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int tap = 0; tap < 9 * KZ; ++tap) {
+      const int gz = z + (KZ == 3 ? tap / 9 - 1 : 0), gy = y + (tap % 9) / 3 - 1, gx = xx + tap % 3 - 1;
+      const float v = (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[((size_t)gz * H + gy) * W + gx] : 0.f;
+      const float4 wv = w4[tap * c4 + q];
+      s.x = __builtin_fmaf(v, wv.x, s.x); s.y = __builtin_fmaf(v, wv.y, s.y);
+      s.z = __builtin_fmaf(v, wv.z, s.z); s.w = __builtin_fmaf(v, wv.w, s.w);
+    }
+    if (act == 1) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+    out[idx] = s;
+  }
+}
+
+template <int NT>
+int launch_conv(const Params& P, hipStream_t s) {
+  static bool attr_set[16] = {};
+  static int n_cu[16] = {};
+  int dev = 0;
+  SD_CHECK(hipGetDevice(&dev));
+  const size_t lds = (size_t)(TILE_FLOATS + 2 * wunit_floats(NT)) * sizeof(float);
+  if (dev >= 16 || !attr_set[dev]) {
+    SD_CHECK(hipFuncSetAttribute((const void*)k_conv3<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (dev < 16) attr_set[dev] = true;
+  }
+  int cus = dev < 16 ? n_cu[dev] : 0;
+  if (cus <= 0) {
+    SD_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus <= 0) cus = 256;
+    if (dev < 16) n_cu[dev] = cus;
+  }
+  long long blocks = (long long)(cus / P.groups) * P.groups;      // one persistent workgroup per CU, a whole number per group
+  if (blocks < P.groups) blocks = P.groups;
+  const long long want = (long long)P.n_tiles * P.groups;
+  if (blocks > want) blocks = want;
+  hipLaunchKernelGGL((k_conv3<NT>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" long long sd_conv3_packed_floats(int c_in, int c_out, int kz) {
+  if (kz != 1 && kz != 3) return -1;
+  if (c_in == 1) return c_out % 4 == 0 && c_out > 0 ? 9LL * kz * c_out : -1;
+  if (c_in <= 0 || c_in % 32 || c_in > 32 * sdconv::MAX_CHUNKS || c_out <= 0 || c_out % 32) return -1;
+  return (long long)sdconv::packed_floats(c_in, c_out, kz);
+}
+
+extern "C" int sd_conv3_pack_weights_host(const float* w, int c_in, int c_out, int kz, float* packed) {
+  if (!w || !packed || sd_conv3_packed_floats(c_in, c_out, kz) < 0) {
+    sd::set_error("sd_conv3_pack_weights: kz 1|3, c_in 1 (c_out %% 4 == 0) or a multiple of 32 up to 256 (c_out %% 32 == 0)");
+    return -1;
+  }
+  if (c_in == 1) {
+    const int taps = 9 * kz;
+    for (int tap = 0; tap < taps; ++tap)
+      for (int co = 0; co < c_out; ++co) packed[tap * c_out + co] = w[(size_t)co * taps + tap];
+    return 0;
+  }
+  sdconv::pack_weights(w, c_in, c_out, kz, packed);
+  return 0;
+}
+
+extern "C" int sd_conv3_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1, int up1,
+                                     int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, int c_out, int act,
+                                     float* d_out, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (D <= 0 || H <= 0 || W <= 0) return 0;
+  const int c_in = c0 + (d_src1 ? c1 : 0);
+  if (!d_src0 || !d_wpacked || !d_out || (act != 0 && act != 1) || sd_conv3_packed_floats(c_in, c_out, kz) < 0 || (kz == 1 && D != 1) ||
+      (((uintptr_t)d_src0 | (uintptr_t)d_src1 | (uintptr_t)d_wpacked | (uintptr_t)d_out | (uintptr_t)d_bias) & 15)) {
+    sd::set_error("sd_conv3_ndhwc: unsupported channel counts (%d + %d -> %d), kz, act or misaligned pointers", c0, d_src1 ? c1 : 0, c_out);
+    return -1;
+  }
+  if (c_in == 1) {
+    if (d_src1 || up0 || stride0 != 1) { sd::set_error("sd_conv3_ndhwc: the one-channel layer takes one full-resolution source"); return -1; }
+    const int c4 = c_out / 4;
+    const long long n = (long long)D * H * W * c4;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    if (kz == 1)
+      hipLaunchKernelGGL(k_conv3_c1<1>, dim3((unsigned)blocks), dim3(256), 0, s, d_src0, D, H, W, (const float4*)d_wpacked, (const float4*)d_bias, c4,
+                         act, (float4*)d_out);
+    else
+      hipLaunchKernelGGL(k_conv3_c1<3>, dim3((unsigned)blocks), dim3(256), 0, s, d_src0, D, H, W, (const float4*)d_wpacked, (const float4*)d_bias, c4,
+                         act, (float4*)d_out);
+    SD_LAUNCH_CHECK();
+    return 0;
+  }
+  const int ups[2] = {up0, d_src1 ? up1 : 0};
+  for (int k = 0; k < 2; ++k) {
+    const int up = ups[k];
+    if (up < 0 || up > 7 || ((up & 1) && (W & 1)) || ((up & 2) && (H & 1)) || ((up & 4) && (D & 1))) {
+      sd::set_error("sd_conv3_ndhwc: up is a bit mask (1: x, 2: y, 4: z); an up-sampled axis needs an even output size");
+      return -1;
+    }
+  }
+  if ((c0 % 32) || (d_src1 && (c1 % 32)) || stride0 < c0 || (stride0 & 3) || (d_src1 && (stride1 < c1 || (stride1 & 3)))) {
+    sd::set_error("sd_conv3_ndhwc: sources must hold multiples of 32 channels, strides multiples of 4 floats");
+    return -1;
+  }
+  Params P;
+  int nc = 0;
+  for (int k = 0; k < c0 / 32; ++k) P.src[nc++] = Src{d_src0 + k * 32, stride0, (up0 >> 2) & 1, (up0 >> 1) & 1, up0 & 1};
+  if (d_src1) for (int k = 0; k < c1 / 32; ++k) P.src[nc++] = Src{d_src1 + k * 32, stride1, (up1 >> 2) & 1, (up1 >> 1) & 1, up1 & 1};
+  for (int k = nc; k < MAX_CHUNKS; ++k) P.src[k] = P.src[0];
+  P.D = D; P.H = H; P.W = W; P.kz = kz; P.n_units = nc * kz;
+  P.wp = d_wpacked; P.bias = d_bias; P.out = d_out; P.c_out = c_out; P.act = act;
+  P.tiles_x = (W + TW - 1) / TW;
+  P.tiles_plane = P.tiles_x * ((H + TH - 1) / TH);
+  const long long nt_ll = (long long)P.tiles_plane * D;
+  if (nt_ll > 0x7fffffffLL) { sd::set_error("sd_conv3_ndhwc: too many tiles"); return -1; }
+  P.n_tiles = (int)nt_ll;
+  const int nt = sdconv::nt_for(c_out);
+  P.groups = c_out / (32 * nt);
+  (void)nt;
+  return launch_conv<1>(P, s);
+}

@@ -1,0 +1,87 @@
+// conv3x3_layout.h -- index algebra of the hand-written 3x3 / 3x3x3 convolution (conv3x3.hip), shared between the device code,
+// the host-side weight packer of the C ABI and the host emulation harness (tests/host/conv_check.cpp), so that the layout is
+// written down exactly once.
+//
+// The reference's network (csbdeep unet_block as called from stardist/models/model2d.py:310-349, model3d.py:360-399) is a chain
+// of 3x3(x3) 'same' convolutions, each followed by bias + ReLU, with nearest-neighbour up-sampling and channel concatenation on the
+// way up.  Here one such layer is an implicit GEMM on the f32-input matrix cores (v_mfma_f32_32x32x2_f32, exact float32 = one fma
+// chain per output):
+//
+//   output tile  = TH x TW = 8 x 32 pixels of one z plane per workgroup (4 waves x 2 rows of 32 pixels), 32*NT output channels
+//   M (A rows)   = the 32 pixels of one tile row,  N (B columns) = 32 output channels,  K = taps x input channels
+//   unit         = (32-channel input chunk c, z tap kz): the (TH+2) x (TW+2) halo tile of that chunk in plane z + kz - 1 and the
+//                  matching 9-tap weight block, both staged in LDS per unit (a 3x3x3 convolution = 3 units per chunk, a 3x3 one 1).
+//                  Tile pixel stride 36 floats: the 4 floats of padding make the 16 lanes of a ds_read_b128 group hit 16
+//                  different bank quadruples.
+//   weights      = packed so that lane (i, h) reads the four k-steps of one (tap, j) group as one float4
+//   k order      = unit-major (chunk, then kz); inside a unit: column tap dx, channel group j, row tap dy, step e; lane half
+//                  h = 0 / 1 feeds channel h*16 + j*4 + e (the MFMA's two k rows)
+#pragma once
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#define SDC_HD __host__ __device__ inline
+#else
+#define SDC_HD inline
+#endif
+
+namespace sdconv {
+
+constexpr int TH = 8, TW = 32;                    // output tile (rows, columns)
+constexpr int HALO_H = TH + 2, HALO_W = TW + 2;
+constexpr int CHUNK = 32;                         // input channels per unit
+constexpr int PIX_STRIDE = 36;                    // floats per pixel of the LDS tile
+constexpr int TILE_FLOATS = HALO_H * HALO_W * PIX_STRIDE;
+constexpr int TILE_F4 = HALO_H * HALO_W * (CHUNK / 4);       // float4 elements of one staged halo tile
+constexpr int THREADS = 256;
+constexpr int PRE_F4 = (TILE_F4 + THREADS - 1) / THREADS;    // float4 registers per thread for the prefetch of the next tile
+constexpr int MAX_CHUNKS = 8;                     // up to 256 input channels
+
+// 32-wide output-channel tiles a workgroup computes at once (registers: 2*NT accumulator tiles per wave, 9*NT float4 of weight
+// prefetch per thread; LDS: NT*36 KiB of weights).  NT = 2 halves the input staging per output channel but its prefetch registers
+// spill (256 arch VGPRs), so every layer runs as c_out/32 groups of 32 output channels; the groups of one tile are co-scheduled
+// on one XCD (conv3x3.hip) so that the re-read of the input tile is an L2 hit.
+SDC_HD int nt_for(int c_out) { (void)c_out; return 1; }
+// packed weight floats of one (group, unit): 9 taps x 4 j x 2 h x (32 NT) output channels x 4 e
+SDC_HD int wunit_floats(int nt) { return 9 * 4 * 2 * 32 * nt * 4; }
+SDC_HD size_t packed_floats(int c_in, int c_out, int kz) { return (size_t)c_out * c_in * 9 * kz; }
+// channel (within the chunk) that k-step (j, e) of lane half h multiplies
+SDC_HD int chan_of(int j, int h, int e) { return h * 16 + j * 4 + e; }
+// position of W[group g, unit u, tap, j, h, n (output channel within the group), e] in the packed array
+SDC_HD size_t wpack_index(int g, int u, int tap, int j, int h, int n, int e, int n_units, int nt) {
+  return ((((((size_t)g * n_units + u) * 9 + tap) * 4 + j) * 2 + h) * (32 * nt) + n) * 4 + e;
+}
+// float offset, inside one (group, unit) block in LDS, of the float4 lane (i, h) reads as B operand for (tap, j, output tile ct)
+SDC_HD int wl_off(int tap, int j, int h, int ct, int i, int nt) { return (((tap * 4 + j) * 2 + h) * (32 * nt) + ct * 32 + i) * 4; }
+// float offset in the LDS tile of (halo row ty, halo column tx, channel ch)
+SDC_HD int tile_off(int ty, int tx, int ch) { return (ty * HALO_W + tx) * PIX_STRIDE + ch; }
+// float offset of the float4 lane (i, h) reads as A operand: output row `row` of the tile (0..TH-1), tap (dy, dx), group j
+SDC_HD int a_off(int row, int dy, int dx, int j, int i, int h) { return tile_off(row + dy, i + dx, h * 16 + j * 4); }
+// accumulator register r of lane half h holds tile column ...
+SDC_HD int acc_col(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// staging: float4 element e (0..TILE_F4-1) of a halo tile -> halo pixel and channel quad
+SDC_HD void stage_elem(int e, int& ty, int& tx, int& q4) {
+  const int pix = e >> 3;
+  q4 = e & 7;
+  ty = pix / HALO_W;
+  tx = pix - ty * HALO_W;
+}
+
+// Pack a PyTorch / Keras-converted kernel w[c_out][c_in][kz][3][3] (float32; kz = 1: Conv2D, 3: Conv3D) for the device kernel.
+// c_in, c_out multiples of 32.  `out` holds packed_floats(c_in, c_out, kz) floats.
+inline void pack_weights(const float* w, int c_in, int c_out, int kz, float* out) {
+  const int nt = nt_for(c_out), n_chunks = c_in / CHUNK, groups = c_out / (32 * nt), n_units = n_chunks * kz;
+  for (int g = 0; g < groups; ++g)
+    for (int c = 0; c < n_chunks; ++c)
+      for (int z = 0; z < kz; ++z)
+        for (int tap = 0; tap < 9; ++tap)
+          for (int j = 0; j < 4; ++j)
+            for (int h = 0; h < 2; ++h)
+              for (int n = 0; n < 32 * nt; ++n)
+                for (int e = 0; e < 4; ++e) {
+                  const int co = g * 32 * nt + n, ci = c * CHUNK + chan_of(j, h, e);
+                  out[wpack_index(g, c * kz + z, tap, j, h, n, e, n_units, nt)] = w[(((size_t)co * c_in + ci) * kz + z) * 9 + tap];
+                }
+}
+
+}  // namespace sdconv

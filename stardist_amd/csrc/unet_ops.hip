@@ -42,13 +42,15 @@ __global__ void __launch_bounds__(256) k_bias_act(float* __restrict__ x, const f
 // given, dot[p] = (sigmoid)(sum_c out[p][c] * w[c] + wb): the 1x1 convolution to ONE channel (the object-probability head,
 // model2d.py:338-341 / model3d.py:436-439) done while the features are in registers instead of a second pass over them.
 // Fixed summation order (4 products per lane in channel order, then an xor butterfly), the same for every caller.
+// bias == nullptr: nothing is added; out == nullptr: the features are only read (they already hold bias + activation, written by
+// the hand-written convolution's epilogue) and just the dot product is produced.
 template <int LPP>
 __global__ void __launch_bounds__(256) k_bias_act_dot(const float4* __restrict__ in, float4* __restrict__ out, const float4* __restrict__ bias,
                                                       long long n_pix, int act, const float4* __restrict__ w, const float* __restrict__ wb,
                                                       int sigm, float* __restrict__ dot) {
   const int s = threadIdx.x % LPP;
   const long long groups = (long long)gridDim.x * (256 / LPP);
-  const float4 b = bias[s];
+  const float4 b = bias ? bias[s] : make_float4(0.f, 0.f, 0.f, 0.f);
   float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
   float w0 = 0.f;
   if (w) { wv = w[s]; w0 = wb ? wb[0] : 0.f; }
@@ -56,7 +58,7 @@ __global__ void __launch_bounds__(256) k_bias_act_dot(const float4* __restrict__
     float4 v = in[p * LPP + s];
     v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
     if (act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    out[p * LPP + s] = v;
+    if (out) out[p * LPP + s] = v;
     if (w) {
       float d = v.x * wv.x;
       d += v.y * wv.y; d += v.z * wv.z; d += v.w * wv.w;
@@ -168,7 +170,7 @@ extern "C" int sd_bias_act_dot_device(const float* d_in, float* d_out, const flo
   hipStream_t s = (hipStream_t)stream_;
   if (n_pix <= 0) return 0;
   const int lpp = n_channels / 4;
-  if (n_channels % 4 || (lpp != 8 && lpp != 16 && lpp != 32 && lpp != 64) || (act != 0 && act != 1) || !d_in || !d_out || !d_bias || (d_w && !d_dot) ||
+  if (n_channels % 4 || (lpp != 8 && lpp != 16 && lpp != 32 && lpp != 64) || (act != 0 && act != 1) || !d_in || (!d_out && !d_w) || (d_w && !d_dot) ||
       (((uintptr_t)d_in | (uintptr_t)d_out | (uintptr_t)d_bias | (uintptr_t)d_w) & 15)) {
     sd::set_error("sd_bias_act_dot: n_channels must be 32, 64, 128 or 256, pointers 16-byte aligned, act 0|1");
     return -1;

@@ -51,6 +51,9 @@ SIGNATURES = {
     "sd_inside_polyhedron_device": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp]),
     "sd_bias_act_dot_device": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "sd_head_rows_device": (_i, [_vp, _i, _vp, ctypes.c_longlong, _vp, _vp, _i, ctypes.c_float, _vp, _vp]),
+    "sd_conv3_packed_floats": (ctypes.c_longlong, [_i, _i, _i]),
+    "sd_conv3_pack_weights_host": (_i, [_vp, _i, _i, _i, _vp]),
+    "sd_conv3_ndhwc_device": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "_LIB_non_maximum_suppression_2d": (None, [_vp, _vp, _i, _i, _f, _i, _i, _i, _vp]),
     "_LIB_polygon_to_label": (None, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "_LIB_star_dist": (None, [_vp, _i, _i, _i, _i, _i, _vp]),

@@ -116,6 +116,80 @@ def _conv_cat_bias_act(conv, a, b, kind):
     return y
 
 
+# ---- hand-written 3x3 / 3x3x3 convolutions (csrc/conv3x3.hip) ---------------------------------------------------------------
+# Conv2D(3x3) / Conv3D(3x3x3) 'same' layers with 1 or a multiple of 32 (<= 256) input channels and a multiple of 32 output channels
+# -- including Concatenate([UpSampling(x), skip]) in front of them -- run as implicit GEMMs on the f32 matrix cores with up-sampling,
+# concatenation, bias and activation folded in: one kernel instead of interpolate + cat + conv + epilogue, exact float32 with a fixed
+# summation order.  STARDIST_AMD_CONV=miopen switches them off (every layer through MIOpen, as before); the choice is read per call
+# so tests can compare both.
+def hand_conv_enabled():
+    import os
+    return os.environ.get("STARDIST_AMD_CONV", "hand") != "miopen"
+
+
+def _packed_conv_weights(conv):
+    """conv.weight in the device layout of sd_conv3_ndhwc_device, cached per module (inference: invalidated when the weight changes)"""
+    from ..lib import _native as N
+    key = (conv.weight.data_ptr(), conv.weight._version, str(conv.weight.device))
+    cache = conv.__dict__.get("_sd_packed")
+    if cache is None or cache[0] != key:
+        w = np.ascontiguousarray(conv.weight.detach().float().cpu().numpy())
+        co, ci, kz = int(w.shape[0]), int(w.shape[1]), (3 if w.ndim == 5 else 1)
+        n = int(N.lib().sd_conv3_packed_floats(ci, co, kz))
+        if n < 0:
+            raise ValueError("sd_conv3: unsupported channel counts %d -> %d" % (ci, co))
+        packed = np.empty(n, np.float32)
+        N.check(N.lib().sd_conv3_pack_weights_host(N.ptr(w), ci, co, kz, N.ptr(packed)))
+        cache = (key, torch.from_numpy(packed).to(conv.weight.device))
+        conv.__dict__["_sd_packed"] = cache
+    return cache[1]
+
+
+def _hand_conv(conv, srcs, kind):
+    """act(conv(cat(srcs, 1)) + bias) by the hand-written kernel; srcs = [(tensor (1, C, *spatial) channels-last float32, up)] with
+    up = per-axis tuple of 0/1 (or one int for all axes): 1 where the source has half the output resolution and the reference
+    up-samples it (nearest, x2) first.  None when the layer is not covered."""
+    nd = 2 if isinstance(conv, nn.Conv2d) else (3 if isinstance(conv, nn.Conv3d) else 0)
+    if not (nd and kind in (0, 1) and hand_conv_enabled() and not torch.is_grad_enabled()
+            and not torch.is_autocast_enabled() and tuple(conv.kernel_size) == (3,) * nd and tuple(conv.stride) == (1,) * nd
+            and tuple(conv.padding) == (1,) * nd and tuple(conv.dilation) == (1,) * nd and conv.groups == 1
+            and conv.weight.dtype == torch.float32 and 1 <= len(srcs) <= 2):
+        return None
+    cl = torch.channels_last if nd == 2 else torch.channels_last_3d
+    cs, ups = [], []
+    for t, up in srcs:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == nd + 2 and t.shape[0] == 1 and t.device == conv.weight.device):
+            return None
+        cs.append(int(t.shape[1]))
+        ups.append(tuple(int(bool(v)) for v in up) if isinstance(up, (tuple, list)) else (int(bool(up)),) * nd)
+    co = conv.out_channels
+    if sum(cs) != conv.in_channels:
+        return None
+    if cs == [1]:
+        ok = co % 4 == 0 and not any(ups[0])
+    else:
+        ok = all(c % 32 == 0 and c > 0 for c in cs) and sum(cs) <= 256 and co % 32 == 0
+    if not ok:
+        return None
+    shape = tuple(int(s) << u for s, u in zip(srcs[0][0].shape[2:], ups[0]))          # output = full resolution
+    for (t, _), up in zip(srcs, ups):
+        if tuple(int(s) << u for s, u in zip(t.shape[2:], up)) != shape:
+            return None
+    from ..lib import _native as N
+    # channels-last operands (a pooling layer may hand over a tensor in the default layout: one copy at its resolution)
+    srcs = [(t if t.is_contiguous(memory_format=cl) and t.data_ptr() % 16 == 0 else t.clone(memory_format=cl), up) for t, up in srcs]
+    wp = _packed_conv_weights(conv)
+    out = torch.empty((1, co) + shape, dtype=torch.float32, device=conv.weight.device, memory_format=cl)
+    D, H, W = ((1,) + shape) if nd == 2 else shape
+    mask = lambda up: sum(b << k for k, b in enumerate(reversed(up)))                     # bit 0: x, 1: y, 2: z
+    a, b = srcs[0][0], (srcs[1][0] if len(srcs) == 2 else None)
+    N.dcall(a, "sd_conv3_ndhwc_device", ctypes.c_void_p(a.data_ptr()), cs[0], cs[0], mask(ups[0]),
+            ctypes.c_void_p(b.data_ptr()) if b is not None else None, cs[1] if b is not None else 0, cs[1] if b is not None else 0,
+            mask(ups[1]) if b is not None else 0, D, H, W, 1 if nd == 2 else 3, ctypes.c_void_p(wp.data_ptr()),
+            ctypes.c_void_p(conv.bias.data_ptr()) if conv.bias is not None else None, co, kind, ctypes.c_void_p(out.data_ptr()))
+    return out
+
+
 def _conv_bias_act(conv, x, kind):
     """conv + bias + (0 linear | 1 relu) with the element-wise part done by the native one-pass kernel; None if not applicable"""
     if not (x.is_cuda and conv.bias is not None and x.dtype == torch.float32 and not torch.is_grad_enabled()):
@@ -123,6 +197,9 @@ def _conv_bias_act(conv, x, kind):
     if torch.is_autocast_enabled():
         return None                      # reduced-precision autocast: the native epilogue is float32 only -> plain Sequential
     from ..lib import _native as N
+    y = _hand_conv(conv, [(x, 0)], kind)
+    if y is not None:
+        return y
     y = _conv_nobias(conv, x)
     if y.dtype != torch.float32:         # gate on the convolution OUTPUT (the kernel reads/writes 4 bytes per element)
         y = y + conv.bias.to(y.dtype).view((1, y.shape[1]) + (1,) * (y.dim() - 2))
@@ -211,11 +288,17 @@ class UNetBlock(nn.Module):
             x = pool(x, self.pool)
         x = self.middle(x)
         for blk, skip in zip(self.up, reversed(skips)):
-            x = F.interpolate(x, scale_factor=tuple(float(p) for p in self.pool), mode="nearest")
             first = blk[0]
-            y = None
+            y, kind = None, -1
             if isinstance(first, ConvAct) and len(first) == 2:
                 kind = 0 if isinstance(first[1], nn.Identity) else (1 if isinstance(first[1], nn.ReLU) else -1)
+                if all(p in (1, 2) for p in self.pool):
+                    y = _hand_conv(first[0], [(x, tuple(p == 2 for p in self.pool)), (skip, 0)], kind)   # UpSampling + Concatenate + Conv + bias + act
+                    if y is not None:
+                        x = blk[1:](y)
+                        continue
+            x = F.interpolate(x, scale_factor=tuple(float(p) for p in self.pool), mode="nearest")
+            if kind >= 0:
                 y = _conv_cat_bias_act(first[0], x, skip, kind)
             x = blk(torch.cat([x, skip], dim=1)) if y is None else blk[1:](y)
         return x
@@ -398,7 +481,12 @@ class StarDistNet(nn.Module):
         bp = self.prob.bias
         prob = torch.empty((1, 1) + S, dtype=torch.float32, device=base.device)
         per_plane = max(base.shape[1], C) * plane
-        if per_plane * D <= self._INDEX_LIMIT:
+        y = _hand_conv(conv, [(base, 0)], kind)               # features conv with bias + activation fused (64-bit indexing: no slabs)
+        if y is not None:                                     # ... then the probability head alone: one read of the features
+            N.dcall(y, "sd_bias_act_dot_device", ctypes.c_void_p(y.data_ptr()), None, None, D * plane, C, 0, ctypes.c_void_p(wp.data_ptr()),
+                    ctypes.c_void_p(bp.data_ptr() if bp is not None else None), 1, ctypes.c_void_p(prob.data_ptr()))
+            feat, slabs = y, []
+        elif per_plane * D <= self._INDEX_LIMIT:
             slabs, feat = [(0, D, 0, D)], None
         else:                                   # MIOpen indexes with int32: features conv on z-slabs with a halo (see _heads_slabbed)
             halo = conv.kernel_size[0] // 2

@@ -1,0 +1,121 @@
+"""GPU: the hand-written 3x3 / 3x3x3 convolution (stardist_amd/csrc/conv3x3.hip, f32 matrix cores) through the C ABI against the
+same layer in float64 (torch on the CPU): Conv2D / Conv3D(kernel 3, 'same') + bias + activation of the reference's U-Net (csbdeep
+unet_block as built by stardist/models/model2d.py:310-349, model3d.py:360-399), with UpSampling + Concatenate folded in for the
+first layer of an up level.
+Tolerance 1e-5 relative to the output scale (BASELINE north_star: 1e-5 on probabilities / distances)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(srcs, conv, kind):
+    import torch
+    import torch.nn.functional as F
+    nd = conv.weight.dim() - 2
+    xs = []
+    for t, up in srcs:
+        t = t.detach().cpu().double()
+        up = up if isinstance(up, tuple) else (up,) * nd
+        if any(up):
+            t = F.interpolate(t, scale_factor=tuple(2.0 if u else 1.0 for u in up), mode="nearest")
+        xs.append(t)
+    f = F.conv2d if nd == 2 else F.conv3d
+    y = f(torch.cat(xs, 1), conv.weight.detach().cpu().double(), conv.bias.detach().cpu().double(), padding=1)
+    return torch.relu(y) if kind == 1 else y
+
+
+CASES = [  # (spatial shape, [(channels, up)], c_out)
+    ((64, 96), [(32, 0)], 32), ((50, 70), [(32, 0)], 64), ((8, 32), [(32, 0)], 128), ((40, 33), [(64, 0)], 32), ((72, 64), [(64, 0)], 64),
+    ((48, 80), [(32, 1), (32, 0)], 32), ((30, 46), [(1, 0)], 32), ((512, 512), [(32, 0)], 32), ((512, 384), [(32, 1), (32, 0)], 32),
+    ((256, 512), [(32, 0)], 128), ((32, 64), [(128, 1), (128, 0)], 128), ((24, 40), [(128, 0)], 256), ((16, 32), [(256, 0)], 128),
+    ((12, 20, 36), [(32, 0)], 32), ((6, 16, 40), [(1, 0)], 32), ((8, 24, 64), [(32, 1), (32, 0)], 32), ((10, 16, 32), [(64, 0)], 64),
+    ((4, 8, 32), [(64, 1), (64, 0)], 64), ((8, 16, 32), [(32, (0, 1, 1)), (32, 0)], 32), ((32, 64, 64), [(32, 0)], 128),
+    ((6, 10, 34), [(64, 0)], 128),
+]
+
+
+@pytest.mark.parametrize("shape,chans,c_out", CASES)
+@pytest.mark.parametrize("kind", [0, 1])
+def test_conv3_matches_float64(shape, chans, c_out, kind):
+    import torch
+    from stardist_amd.models import unet as U
+    dev = torch.device("cuda:0")
+    nd = len(shape)
+    g = torch.Generator().manual_seed(int(np.prod(shape)) * 131 + c_out + kind)
+    cin = sum(c for c, _ in chans)
+    conv = (torch.nn.Conv2d if nd == 2 else torch.nn.Conv3d)(cin, c_out, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * float(np.sqrt(2.0 / (3 ** nd * cin))))
+        conv.bias.copy_(torch.randn(c_out, generator=g) * 0.5)
+    conv = conv.to(dev)
+    cl = torch.channels_last if nd == 2 else torch.channels_last_3d
+    srcs = []
+    for c, up in chans:
+        upt = up if isinstance(up, tuple) else (up,) * nd
+        t = torch.randn((1, c) + tuple(s >> u for s, u in zip(shape, upt)), generator=g).to(dev).contiguous(memory_format=cl)
+        srcs.append((t, upt))
+    with torch.no_grad():
+        y = U._hand_conv(conv, srcs, kind)
+        assert y is not None, "layer not taken by the hand-written kernel"
+        y2 = U._hand_conv(conv, srcs, kind)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (1, c_out) + tuple(shape) and y.is_contiguous(memory_format=cl)
+    assert torch.equal(y, y2), "not repeatable"
+    ref = _ref(srcs, conv, kind)
+    err = float((y.cpu().double() - ref).abs().max())
+    scale = max(1.0, float(ref.abs().max()))
+    assert err <= 1e-5 * scale, (err, scale)
+
+
+def test_conv3x3_rejects_what_it_does_not_cover():
+    import torch
+    from stardist_amd.models import unet as U
+    dev = torch.device("cuda:0")
+    x = torch.randn(1, 48, 16, 16, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        assert U._hand_conv(torch.nn.Conv2d(48, 32, 3, padding=1).to(dev), [(x, 0)], 1) is None          # 48 channels
+        assert U._hand_conv(torch.nn.Conv2d(32, 32, 3, padding=1, stride=2).to(dev), [(x, 0)], 1) is None
+        x32 = torch.randn(1, 32, 16, 16, device=dev).contiguous(memory_format=torch.channels_last)
+        assert U._hand_conv(torch.nn.Conv2d(32, 32, 5, padding=2).to(dev), [(x32, 0)], 1) is None        # 5x5
+        assert U._hand_conv(torch.nn.Conv2d(32, 32, 3, padding=1).to(dev), [(x32.contiguous(), 0)], 1) is None   # not channels-last
+
+
+def test_network_hand_conv_equals_miopen_path(monkeypatch):
+    """the whole 2D network with the hand-written layers vs every layer through MIOpen: same float32 arithmetic up to summation
+    order; both within 1e-5 of each other on prob, 1e-5 relative on dist"""
+    import torch
+    from oracle import synth
+    from stardist_amd.models import Config2D, StarDist2D
+    dev = torch.device("cuda:0")
+    img = torch.from_numpy(synth.s2d_nuclei_image(256, 320, seed=3)).to(dev)
+    model = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
+    monkeypatch.setenv("STARDIST_AMD_CONV", "hand")
+    p1, d1 = model.predict(img)
+    p1b, d1b = model.predict(img)
+    model.__dict__.pop("_graphs", None)
+    monkeypatch.setenv("STARDIST_AMD_CONV", "miopen")
+    p0, d0 = model.predict(img)
+    model.__dict__.pop("_graphs", None)
+    assert np.array_equal(p1, p1b) and np.array_equal(d1, d1b)
+    assert float(np.abs(p1 - p0).max()) <= 1e-5
+    assert float((np.abs(d1 - d0) / np.maximum(1.0, np.abs(d0))).max()) <= 1e-5
+
+
+def test_network3d_hand_conv_equals_miopen_path(monkeypatch):
+    import torch
+    from oracle import synth
+    from stardist_amd.models import Config3D, StarDist3D
+    dev = torch.device("cuda:0")
+    vol = torch.from_numpy(synth.s3d_nuclei_image(48, seed=2)).to(dev)
+    model = StarDist3D(Config3D(rays=32), basedir=None, device=dev, seed=0)
+    monkeypatch.setenv("STARDIST_AMD_CONV", "hand")
+    p1, d1 = model.predict(vol)
+    model.__dict__.pop("_graphs", None)
+    monkeypatch.setenv("STARDIST_AMD_CONV", "miopen")
+    p0, d0 = model.predict(vol)
+    model.__dict__.pop("_graphs", None)
+    assert float(np.abs(p1 - p0).max()) <= 1e-5
+    assert float((np.abs(d1 - d0) / np.maximum(1.0, np.abs(d0))).max()) <= 1e-5

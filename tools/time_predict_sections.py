@@ -1,0 +1,69 @@
+"""Where the 2D predict_instances step spends its time outside the network: every stage wrapped in synchronize + perf_counter
+(serialises the stream, so the sum is an upper bound of the pipelined step).  usage: python tools/time_predict_sections.py [--size 2048]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from oracle import synth  # noqa: E402
+from stardist_amd.models import Config2D, StarDist2D  # noqa: E402
+import stardist_amd.models.model2d as M2  # noqa: E402
+import stardist_amd.nms as NMS  # noqa: E402
+import stardist_amd.geometry.geom2d as G2  # noqa: E402
+
+acc = {}
+
+
+def wrap(mod, name, label):
+    orig = getattr(mod, name)
+
+    def f(*a, **k):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        r = orig(*a, **k)
+        torch.cuda.synchronize(); acc[label] = acc.get(label, 0.0) + time.perf_counter() - t0
+        return r
+    setattr(mod, name, f)
+    return orig
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=10)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    img = torch.from_numpy(synth.s2d_nuclei_image(a.size, a.size, seed=0)).to(dev)
+    model = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
+    bench.calibrate_heads(model, img)
+    for _ in range(3):
+        model.predict_instances(img)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(a.steps):
+        model.predict_instances(img)
+    torch.cuda.synchronize(); whole = (time.perf_counter() - t0) / a.steps
+    wrap(model, "_net_forward", "net_forward")
+    wrap(model, "_select_rows", "select+dist_rows")
+    wrap(M2, "non_maximum_suppression_sparse", "nms_sparse(sort+gather+nms+gather)")
+    wrap(NMS, "non_maximum_suppression_inds", "  nms_inds(native)")
+    wrap(NMS, "_argsort_desc", "  argsort")
+    wrap(M2, "polygons_to_label", "raster")
+    wrap(M2, "dist_to_coord", "dist_to_coord")
+    wrap(M2, "to_host", "labels_to_host")
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(a.steps):
+        model.predict_instances(img)
+    torch.cuda.synchronize(); ser = (time.perf_counter() - t0) / a.steps
+    print("pipelined step %.3f ms; serialised step %.3f ms" % (1e3 * whole, 1e3 * ser))
+    for k, v in acc.items():
+        print("  %-42s %8.3f ms" % (k, 1e3 * v / a.steps))
+    print("  %-42s %8.3f ms" % ("unaccounted (python glue, to-numpy copies)", 1e3 * (ser - sum(v for k, v in acc.items() if not k.startswith("  ")) / a.steps)))
+
+
+if __name__ == "__main__":
+    main()
