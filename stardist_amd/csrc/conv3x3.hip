@@ -43,8 +43,11 @@ struct Params {
 // Halo tile of unit u of output tile t, 16 bytes per (thread, n), plus the unit's weight block.  Branch-free: coordinates are
 // clamped into the volume so that every load is legal and all loads of a thread issue back to back; out-of-volume elements (the
 // zero padding of 'same') and the unused tail of the last n are zeroed by a select afterwards.
+constexpr int WUNIT = 9 * 4 * 2 * 32 * 4;     // floats of one weight block (NT = 1)
+constexpr int WMAIN = 8 * 4 * 2 * 32 * 4;     // ... of its taps 0..7
+
 template <int NT>
-__device__ __forceinline__ void load_unit(const Params& P, int g, int t, int u, float4 (&pre)[PRE_F4], float* __restrict__ Wnext, int tid) {
+__device__ __forceinline__ void load_unit(const Params& P, int g, int t, int u, float4 (&pre)[PRE_F4], float4& w8, float* __restrict__ Wnext, int tid) {
   const int c = u / P.kz, dz = P.kz == 3 ? u - c * 3 - 1 : 0;
   const Src S = P.src[c];
   const int tz = t / P.tiles_plane, tr = t - tz * P.tiles_plane;
@@ -65,19 +68,22 @@ __device__ __forceinline__ void load_unit(const Params& P, int g, int t, int u, 
     const float4 v = *(const float4*)(base + ((size_t)cy * ws + cx) * S.stride + q4 * 4);
     pre[n] = inside ? v : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  // the unit's weight block: a linear 36 KiB copy, global -> LDS without passing through registers (global_load_lds_dwordx4:
-  // LDS destination = wave-uniform base + lane * 16); wave w, instruction n moves the n*4+w-th KiB
-  const float* wsrc = P.wp + ((size_t)g * P.n_units + u) * (9 * 4 * 2 * 32 * NT * 4);
+  // the unit's weight block (36 KiB, tap-major): taps 0..7 = 32 KiB global -> LDS without passing through registers
+  // (global_load_lds_dwordx4: LDS destination = wave-uniform base + lane * 16; wave w, instruction n moves the n*4+w-th KiB); both
+  // 32 KiB buffers lie in the first 64 KiB of LDS, whatever width of M0 the DMA honours.  Tap 8 (4 KiB) rides along in a register.
+  const float* wsrc = P.wp + ((size_t)g * P.n_units + u) * WUNIT;
   const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-  for (int n = 0; n < 9 * NT; ++n) {
+  for (int n = 0; n < 8; ++n) {
     const int kib = n * 4 + wave;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kib * 256 + lane * 4),
                                      (__attribute__((address_space(3))) void*)(Wnext + kib * 256), 16, 0, 0);
   }
+  w8 = ((const float4*)(wsrc + WMAIN))[tid];
 }
 
-__device__ __forceinline__ void store_unit(float* __restrict__ tileL, const float4 (&pre)[PRE_F4], int tid) {
+__device__ __forceinline__ void store_unit(float* __restrict__ tileL, float* __restrict__ W8next, const float4 (&pre)[PRE_F4], const float4& w8, int tid) {
+  ((float4*)W8next)[tid] = w8;
 #pragma unroll
   for (int n = 0; n < PRE_F4; ++n) {
     const int e = tid + n * THREADS;
@@ -95,14 +101,15 @@ __device__ __forceinline__ float comp(const float4& v, int e) { return e == 0 ? 
 // that column (B) = 7 (NT = 1) or 10 (NT = 2) ds_read_b128 feeding 24 NT MFMAs.  The operands of group g+1 are read while the
 // matrix cores work on group g (two register sets).
 template <int NT>
-__device__ __forceinline__ void compute_unit(const float* __restrict__ tileL, const float* __restrict__ wl, f32x16 (&acc)[2][NT], int wave, int i, int h) {
+__device__ __forceinline__ void compute_unit(const float* __restrict__ tileL, const float* __restrict__ wl, const float* __restrict__ w8, f32x16 (&acc)[2][NT],
+                                             int wave, int i, int h) {
   float4 A[2][4], B[2][3][NT];
 #define SD_LOAD_GROUP(gi, buf)                                                                          \
   do {                                                                                                   \
     const int dx_ = (gi) >> 2, j_ = (gi) & 3;                                                            \
     _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) A[buf][rr] = *(const float4*)(tileL + a_off(wave * 2, rr, dx_, j_, i, h)); \
     _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                                     \
-      _Pragma("unroll") for (int ct = 0; ct < NT; ++ct) B[buf][dy][ct] = *(const float4*)(wl + wl_off(dy * 3 + dx_, j_, h, ct, i, NT)); \
+      _Pragma("unroll") for (int ct = 0; ct < NT; ++ct) B[buf][dy][ct] = *(const float4*)((dy * 3 + dx_ == 8 ? w8 - WMAIN : wl) + wl_off(dy * 3 + dx_, j_, h, ct, i, NT)); \
   } while (0)
   SD_LOAD_GROUP(0, 0);
 #pragma unroll
@@ -131,21 +138,24 @@ __device__ __forceinline__ void compute_unit(const float* __restrict__ tileL, co
 // LDS-direct loads (vmcnt(0) in front of the first MFMA group = no overlap).
 template <int NT>
 __device__ __forceinline__ void unit_step(const Params& P, int g, bool have, int tn, int un, float* __restrict__ tileL, const float* __restrict__ wcur,
-                                          float* __restrict__ wnext, f32x16 (&acc)[2][NT], int tid, int wave, int i, int h) {
-  float4 pre[PRE_F4];
-  if (have) load_unit<NT>(P, g, tn, un, pre, wnext, tid);
+                                          const float* __restrict__ w8cur, float* __restrict__ wnext, float* __restrict__ w8next, f32x16 (&acc)[2][NT],
+                                          int tid, int wave, int i, int h) {
+  float4 pre[PRE_F4], w8 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (have) load_unit<NT>(P, g, tn, un, pre, w8, wnext, tid);
   __builtin_amdgcn_sched_barrier(0);
-  compute_unit<NT>(tileL, wcur, acc, wave, i, h);
+  compute_unit<NT>(tileL, wcur, w8cur, acc, wave, i, h);
   __syncthreads();
-  if (have) store_unit(tileL, pre, tid);
+  if (have) store_unit(tileL, w8next, pre, w8, tid);
   __syncthreads();
 }
 
 template <int NT>
 __global__ void __launch_bounds__(THREADS) k_conv3(const Params P) {
   extern __shared__ float4 smem4[];
-  float* tileL = (float*)smem4;
-  float* Wl = tileL + TILE_FLOATS;
+  // LDS map (floats): [0, 2 WMAIN) the two weight buffers' taps 0..7 (DMA destinations, below 64 KiB), then their tap-8 blocks, then the halo tile
+  float* Wl = (float*)smem4;
+  float* W8 = Wl + 2 * WMAIN;
+  float* tileL = W8 + 2 * (WUNIT - WMAIN);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
   // workgroup -> (output-channel group g, tile slot q): consecutive workgroups go round-robin over the 8 XCDs, so the `groups`
   // workgroups b, b+8, b+16, ... (same XCD, same L2) take the same tile sequence and differ in g
@@ -158,11 +168,11 @@ __global__ void __launch_bounds__(THREADS) k_conv3(const Params P) {
   float bias_r[NT];
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) bias_r[ct] = P.bias ? P.bias[g * 32 * NT + ct * 32 + i] : 0.f;
-  constexpr int WU = 9 * 4 * 2 * 32 * NT * 4;          // floats of one weight block; two buffers, used alternately
+  static_assert(NT == 1, "LDS map and weight staging are written for 32 output channels per workgroup");
   {
-    float4 pre[PRE_F4];
-    load_unit<NT>(P, g, q, 0, pre, Wl, tid);
-    store_unit(tileL, pre, tid);
+    float4 pre[PRE_F4], w8;
+    load_unit<NT>(P, g, q, 0, pre, w8, Wl, tid);
+    store_unit(tileL, W8, pre, w8, tid);
   }
   __syncthreads();                                     // (the compiler drains the LDS-direct loads before the barrier)
   int wb = 0;
@@ -177,7 +187,8 @@ __global__ void __launch_bounds__(THREADS) k_conv3(const Params P) {
     for (int u = 0; u < P.n_units; ++u) {
       const bool last = u == P.n_units - 1;
       const int tn = last ? t + Q : t, un = last ? 0 : u + 1;
-      unit_step<NT>(P, g, tn < P.n_tiles, tn, un, tileL, Wl + wb * WU, Wl + (wb ^ 1) * WU, acc, tid, wave, i, h);
+      unit_step<NT>(P, g, tn < P.n_tiles, tn, un, tileL, Wl + wb * WMAIN, W8 + wb * (WUNIT - WMAIN), Wl + (wb ^ 1) * WMAIN,
+                    W8 + (wb ^ 1) * (WUNIT - WMAIN), acc, tid, wave, i, h);
       wb ^= 1;
     }
     // epilogue: activation + store (the stores drain while the next tile is being computed: nothing waits on them before the
