@@ -80,7 +80,11 @@ def test_conv3x3_rejects_what_it_does_not_cover():
         assert U._hand_conv(torch.nn.Conv2d(32, 32, 3, padding=1, stride=2).to(dev), [(x, 0)], 1) is None
         x32 = torch.randn(1, 32, 16, 16, device=dev).contiguous(memory_format=torch.channels_last)
         assert U._hand_conv(torch.nn.Conv2d(32, 32, 5, padding=2).to(dev), [(x32, 0)], 1) is None        # 5x5
-        assert U._hand_conv(torch.nn.Conv2d(32, 32, 3, padding=1).to(dev), [(x32.contiguous(), 0)], 1) is None   # not channels-last
+        # a source in the default (NCHW) layout is converted, not rejected
+        conv = torch.nn.Conv2d(32, 32, 3, padding=1).to(dev)
+        xc = x32.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)                                     # same values, NCHW-contiguous storage
+        xc = xc.contiguous()
+        assert torch.equal(U._hand_conv(conv, [(xc, 0)], 1), U._hand_conv(conv, [(x32, 0)], 1))
 
 
 def test_network_hand_conv_equals_miopen_path(monkeypatch):
