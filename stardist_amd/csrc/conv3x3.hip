@@ -21,85 +21,127 @@ namespace {
 using namespace sdconv;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));      // native 16-byte vector: plain loads/stores in any address space
 
 struct Src {
-  const float* p;      // channels-last [D >> shz][H >> shy][W >> shx][stride], already offset to this chunk's first channel
+  const float* p;      // channels-last [D >> shz][H >> shy][W >> shx][stride]
   int stride;          // floats per pixel
   int shz, shy, shx;   // 1: the source is half resolution along that axis (nearest-neighbour up-sampling by 2)
 };
 
 struct Params {
-  Src src[MAX_CHUNKS];
+  Src kind[2];                         // the (at most two) source tensors
+  int chunk_kind[MAX_CHUNKS];          // 32-channel chunk c comes from kind[chunk_kind[c]] ...
+  int chunk_choff[MAX_CHUNKS];         // ... starting at this channel
+  const float* zero;                   // 16 bytes of zeros (tail of the packed weights): where out-of-image halo elements are read from
   int D, H, W;
   int kz;              // z taps: 1 (2D) or 3
   int n_units;         // chunks * kz
-  const float* wp;     // packed weights [groups][n_units][wunit_floats(NT)]
+  const float* wp;     // packed weights [groups][n_units][WUNIT]
   const float* bias;
   float* out;          // [D][H][W][c_out]
   int c_out, act;
   int tiles_x, tiles_plane, n_tiles, groups;
 };
 
-// Halo tile of unit u of output tile t, 16 bytes per (thread, n), plus the unit's weight block.  Branch-free: coordinates are
-// clamped into the volume so that every load is legal and all loads of a thread issue back to back; out-of-volume elements (the
-// zero padding of 'same') and the unused tail of the last n are zeroed by a select afterwards.
 constexpr int WUNIT = 9 * 4 * 2 * 32 * 4;     // floats of one weight block (NT = 1)
 constexpr int WMAIN = 8 * 4 * 2 * 32 * 4;     // ... of its taps 0..7
 
-template <int NT>
-__device__ __forceinline__ void load_unit(const Params& P, int g, int t, int u, float4 (&pre)[PRE_F4], float4& w8, float* __restrict__ Wnext, int tid) {
-  const int c = u / P.kz, dz = P.kz == 3 ? u - c * 3 - 1 : 0;
-  const Src S = P.src[c];
-  const int tz = t / P.tiles_plane, tr = t - tz * P.tiles_plane;
-  const int ty0 = (tr / P.tiles_x) * TH - 1, tx0 = (tr % P.tiles_x) * TW - 1;
-  const int z = tz + dz;
-  const bool zin = z >= 0 && z < P.D;
-  const int ws = P.W >> S.shx, hs = P.H >> S.shy;
-  const float* base = S.p + (size_t)(min(max(z, 0), P.D - 1) >> S.shz) * hs * ws * S.stride;
+// Per-thread staging constants, computed once per kernel: where this thread's PRE_F4 float4 elements of a halo tile live in LDS,
+// and -- for tiles whose halo lies inside the image -- their byte offsets from the halo's first source pixel, per source tensor
+// (a half-resolution source maps halo row ty to source row ((ty - 1) >> 1) + 1 relative to the row of halo row 0, because a
+// tile's first halo row/column is odd: 8k - 1 / 32m - 1).
+struct Stage {
+  int lds[PRE_F4];
+  unsigned goff[2][PRE_F4];
+};
+
+__device__ __forceinline__ void stage_init(const Params& P, Stage& st, int tid) {
 #pragma unroll
   for (int n = 0; n < PRE_F4; ++n) {
     int e = tid + n * THREADS;
     e = e < TILE_F4 ? e : TILE_F4 - 1;
     int ty, tx, q4;
     stage_elem(e, ty, tx, q4);
-    const int gy = ty0 + ty, gx = tx0 + tx;
-    const bool inside = zin && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
-    const int cy = min(max(gy, 0), P.H - 1) >> S.shy, cx = min(max(gx, 0), P.W - 1) >> S.shx;
-    const float4 v = *(const float4*)(base + ((size_t)cy * ws + cx) * S.stride + q4 * 4);
-    pre[n] = inside ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    st.lds[n] = tile_off(ty, tx, q4 * 4);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const Src S = P.kind[k];
+      const int ry = src_rel(ty, S.shy), rx = src_rel(tx, S.shx);
+      st.goff[k][n] = (unsigned)(((ry * (P.W >> S.shx) + rx) * S.stride + q4 * 4) * 4);
+    }
   }
+}
+
+// Halo tile of unit u of output tile t -> registers (16 bytes per (thread, n)), the unit's weight block -> LDS.
+// Only ADDRESSES differ between tiles: inside the image (the rule) an element's address is a wave-uniform base + the precomputed
+// per-thread offset; on border tiles it is computed per element, and elements outside the volume (the zero padding of 'same')
+// point at a 16-byte block of zeros.  The loads themselves are unconditional and issue back to back after the addresses are
+// known, so nothing has to be selected, merged or waited for before the matrix cores start on the current unit.
+template <int NT>
+__device__ __forceinline__ void load_unit(const Params& P, const Stage& st, int g, int t, int u, v4f (&pre)[PRE_F4], v4f& w8,
+                                          float* __restrict__ Wnext, int tid, int wave) {
+  const int c = u / P.kz, dz = P.kz == 3 ? u - c * 3 - 1 : 0;
+  const int k = P.chunk_kind[c];
+  const Src S = P.kind[k];
+  const float* sp = S.p + P.chunk_choff[c];
+  const int tz = t / P.tiles_plane, tr = t - tz * P.tiles_plane;
+  const int ty0 = (tr / P.tiles_x) * TH - 1, tx0 = (tr % P.tiles_x) * TW - 1;
+  const int z = tz + dz;
+  const bool zin = z >= 0 && z < P.D;
+  const int ws = P.W >> S.shx, hs = P.H >> S.shy;
+  const float* plane = sp + (size_t)(min(max(z, 0), P.D - 1) >> S.shz) * hs * ws * S.stride;
+  typedef const __attribute__((address_space(1))) char* gptr;      // explicitly global: the asm fence below hides the provenance
+  gptr addr[PRE_F4];
+  if (zin && ty0 >= 0 && ty0 + HALO_H <= P.H && tx0 >= 0 && tx0 + HALO_W <= P.W) {
+    const int by = src_base(ty0, S.shy), bx = src_base(tx0, S.shx);
+    gptr base = (gptr)(plane + ((size_t)by * ws + bx) * S.stride);
+#pragma unroll
+    for (int n = 0; n < PRE_F4; ++n) addr[n] = base + (k ? st.goff[1][n] : st.goff[0][n]);
+  } else {
+#pragma unroll
+    for (int n = 0; n < PRE_F4; ++n) {
+      int e = tid + n * THREADS;
+      e = e < TILE_F4 ? e : TILE_F4 - 1;
+      int ty, tx, q4;
+      stage_elem(e, ty, tx, q4);
+      const int gy = ty0 + ty, gx = tx0 + tx;
+      const bool inside = zin && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+      const int cy = min(max(gy, 0), P.H - 1) >> S.shy, cx = min(max(gx, 0), P.W - 1) >> S.shx;
+      addr[n] = inside ? (gptr)(plane + ((size_t)cy * ws + cx) * S.stride + q4 * 4) : (gptr)P.zero;
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < PRE_F4; ++n) asm volatile("" : "+v"(addr[n]));        // addresses are final here: the loads below stay below
+#pragma unroll
+  for (int n = 0; n < PRE_F4; ++n) pre[n] = *(const __attribute__((address_space(1))) v4f*)addr[n];
   // the unit's weight block (36 KiB, tap-major): taps 0..7 = 32 KiB global -> LDS without passing through registers
   // (global_load_lds_dwordx4: LDS destination = wave-uniform base + lane * 16; wave w, instruction n moves the n*4+w-th KiB); both
   // 32 KiB buffers lie in the first 64 KiB of LDS, whatever width of M0 the DMA honours.  Tap 8 (4 KiB) rides along in a register.
   const float* wsrc = P.wp + ((size_t)g * P.n_units + u) * WUNIT;
-  const int wave = tid >> 6, lane = tid & 63;
+  const int lane = tid & 63;
 #pragma unroll
   for (int n = 0; n < 8; ++n) {
     const int kib = n * 4 + wave;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + kib * 256 + lane * 4),
                                      (__attribute__((address_space(3))) void*)(Wnext + kib * 256), 16, 0, 0);
   }
-  w8 = ((const float4*)(wsrc + WMAIN))[tid];
+  w8 = ((const v4f*)(wsrc + WMAIN))[tid];
 }
 
-__device__ __forceinline__ void store_unit(float* __restrict__ tileL, float* __restrict__ W8next, const float4 (&pre)[PRE_F4], const float4& w8, int tid) {
-  ((float4*)W8next)[tid] = w8;
+__device__ __forceinline__ void store_unit(const Stage& st, float* __restrict__ tileL, float* __restrict__ W8next, const v4f (&pre)[PRE_F4],
+                                           const v4f& w8, int tid) {
+  ((v4f*)W8next)[tid] = w8;
 #pragma unroll
-  for (int n = 0; n < PRE_F4; ++n) {
-    const int e = tid + n * THREADS;
-    if (e < TILE_F4) {
-      int ty, tx, q4;
-      stage_elem(e, ty, tx, q4);
-      *(float4*)(tileL + tile_off(ty, tx, q4 * 4)) = pre[n];
-    }
-  }
+  for (int n = 0; n < PRE_F4; ++n)
+    if (n < PRE_F4 - 1 || tid < TILE_F4 - (PRE_F4 - 1) * THREADS) *(v4f*)(tileL + st.lds[n]) = pre[n];
 }
 
 __device__ __forceinline__ float comp(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
 
 // One unit: 12 operand groups (dx, j); a group = the four halo rows the wave's two output rows touch (A) and the three taps dy of
-// that column (B) = 7 (NT = 1) or 10 (NT = 2) ds_read_b128 feeding 24 NT MFMAs.  The operands of group g+1 are read while the
-// matrix cores work on group g (two register sets).
+// that column (B) = 7 ds_read_b128 feeding 24 MFMAs.  The operands of group g+1 are read while the matrix cores work on group g
+// (two register sets).
 template <int NT>
 __device__ __forceinline__ void compute_unit(const float* __restrict__ tileL, const float* __restrict__ wl, const float* __restrict__ w8, f32x16 (&acc)[2][NT],
                                              int wave, int i, int h) {
@@ -133,30 +175,32 @@ __device__ __forceinline__ void compute_unit(const float* __restrict__ tileL, co
 }
 
 // One step of the pipeline: start fetching the next unit (halo tile -> registers, weight block -> LDS-direct into `wnext`), run the
-// matrix cores on the current unit (tile + `wcur`), then move the fetched tile into LDS.  The three LDS regions are disjoint; the
+// matrix cores on the current unit (tile + `wcur`), then move the fetched tile into LDS.  The LDS regions are disjoint; the
 // __restrict__ qualifiers carry that to the waitcnt insertion, which otherwise orders every ds_read behind the in-flight
 // LDS-direct loads (vmcnt(0) in front of the first MFMA group = no overlap).
 template <int NT>
-__device__ __forceinline__ void unit_step(const Params& P, int g, bool have, int tn, int un, float* __restrict__ tileL, const float* __restrict__ wcur,
-                                          const float* __restrict__ w8cur, float* __restrict__ wnext, float* __restrict__ w8next, f32x16 (&acc)[2][NT],
-                                          int tid, int wave, int i, int h) {
-  float4 pre[PRE_F4], w8 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (have) load_unit<NT>(P, g, tn, un, pre, w8, wnext, tid);
+__device__ __forceinline__ void unit_step(const Params& P, const Stage& st, int g, bool have, int tn, int un, float* __restrict__ tileL,
+                                          const float* __restrict__ wcur, const float* __restrict__ w8cur, float* __restrict__ wnext,
+                                          float* __restrict__ w8next, f32x16 (&acc)[2][NT], int tid, int wave, int i, int h) {
+  v4f pre[PRE_F4], w8 = {0.f, 0.f, 0.f, 0.f};
+  if (have) load_unit<NT>(P, st, g, tn, un, pre, w8, wnext, tid, wave);
   __builtin_amdgcn_sched_barrier(0);
   compute_unit<NT>(tileL, wcur, w8cur, acc, wave, i, h);
   __syncthreads();
-  if (have) store_unit(tileL, w8next, pre, w8, tid);
+  if (have) store_unit(st, tileL, w8next, pre, w8, tid);
   __syncthreads();
 }
 
+// One workgroup per CU by LDS footprint (120 KiB): one wave per SIMD, so the whole register file is this wave's
 template <int NT>
-__global__ void __launch_bounds__(THREADS) k_conv3(const Params P) {
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_conv3(const Params P) {
   extern __shared__ float4 smem4[];
   // LDS map (floats): [0, 2 WMAIN) the two weight buffers' taps 0..7 (DMA destinations, below 64 KiB), then their tap-8 blocks, then the halo tile
   float* Wl = (float*)smem4;
   float* W8 = Wl + 2 * WMAIN;
   float* tileL = W8 + 2 * (WUNIT - WMAIN);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // wave-uniform: row bases and DMA destinations stay scalar
   // workgroup -> (output-channel group g, tile slot q): consecutive workgroups go round-robin over the 8 XCDs, so the `groups`
   // workgroups b, b+8, b+16, ... (same XCD, same L2) take the same tile sequence and differ in g
   const int b = blockIdx.x, span = 8 * P.groups, blk = b / span, rem = b - blk * span;
@@ -169,13 +213,16 @@ __global__ void __launch_bounds__(THREADS) k_conv3(const Params P) {
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) bias_r[ct] = P.bias ? P.bias[g * 32 * NT + ct * 32 + i] : 0.f;
   static_assert(NT == 1, "LDS map and weight staging are written for 32 output channels per workgroup");
+  Stage st;
+  stage_init(P, st, tid);
   {
-    float4 pre[PRE_F4], w8;
-    load_unit<NT>(P, g, q, 0, pre, w8, Wl, tid);
-    store_unit(tileL, W8, pre, w8, tid);
+    v4f pre[PRE_F4], w8;
+    load_unit<NT>(P, st, g, q, 0, pre, w8, Wl, tid, wave);
+    store_unit(st, tileL, W8, pre, w8, tid);
   }
   __syncthreads();                                     // (the compiler drains the LDS-direct loads before the barrier)
   int wb = 0;
+  const unsigned lane_off = (unsigned)((h * 4 * P.c_out + i) * 4);     // this lane's byte offset inside an output row segment
   for (int t = q; t < P.n_tiles; t += Q) {
     f32x16 acc[2][NT];
 #pragma unroll
@@ -187,26 +234,37 @@ __global__ void __launch_bounds__(THREADS) k_conv3(const Params P) {
     for (int u = 0; u < P.n_units; ++u) {
       const bool last = u == P.n_units - 1;
       const int tn = last ? t + Q : t, un = last ? 0 : u + 1;
-      unit_step<NT>(P, g, tn < P.n_tiles, tn, un, tileL, Wl + wb * WMAIN, W8 + wb * (WUNIT - WMAIN), Wl + (wb ^ 1) * WMAIN,
+      unit_step<NT>(P, st, g, tn < P.n_tiles, tn, un, tileL, Wl + wb * WMAIN, W8 + wb * (WUNIT - WMAIN), Wl + (wb ^ 1) * WMAIN,
                     W8 + (wb ^ 1) * (WUNIT - WMAIN), acc, tid, wave, i, h);
       wb ^= 1;
     }
     // epilogue: activation + store (the stores drain while the next tile is being computed: nothing waits on them before the
-    // next unit's prefetch has been consumed, a full compute phase later)
+    // next unit's prefetch has been consumed, a full compute phase later).  Row bases and the 16 column offsets are scalar;
+    // a lane adds its own offset once.  Accumulator register r holds tile column (r & 3) + 8 (r >> 2) + 4 h.
     const int tz = t / P.tiles_plane, tr = t - tz * P.tiles_plane;
     const int y0 = (tr / P.tiles_x) * TH + wave * 2, x0 = (tr % P.tiles_x) * TW;
+    const bool xfull = x0 + TW <= P.W, relu = P.act == 1;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int y = y0 + p;
       if (y < P.H) {
+        char* rowb = (char*)(P.out + (((size_t)tz * P.H + y) * P.W + x0) * P.c_out + g * 32 * NT);
+        float v[16];
+        if (relu) {
 #pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-          float* orow = P.out + ((size_t)tz * P.H + y) * P.W * P.c_out + g * 32 * NT + ct * 32 + i;
+          for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[p][0][r], 0.f);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = acc[p][0][r];
+        }
+        if (xfull) {                                   // the rule: whole tile row inside the image, 16 unpredicated stores
+#pragma unroll
+          for (int r = 0; r < 16; ++r) *(float*)(rowb + (size_t)((r & 3) + 8 * (r >> 2)) * P.c_out * 4 + lane_off) = v[r];
+        } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int x = x0 + acc_col(r, h);
-            const float v = P.act == 1 ? fmaxf(acc[p][ct][r], 0.f) : acc[p][ct][r];
-            if (x < P.W) orow[(size_t)x * P.c_out] = v;
+            const int col = (r & 3) + 8 * (r >> 2);
+            if (x0 + col + 4 * h < P.W) *(float*)(rowb + (size_t)col * P.c_out * 4 + lane_off) = v[r];
           }
         }
       }
@@ -272,7 +330,7 @@ extern "C" long long sd_conv3_packed_floats(int c_in, int c_out, int kz) {
   if (kz != 1 && kz != 3) return -1;
   if (c_in == 1) return c_out % 4 == 0 && c_out > 0 ? 9LL * kz * c_out : -1;
   if (c_in <= 0 || c_in % 32 || c_in > 32 * sdconv::MAX_CHUNKS || c_out <= 0 || c_out % 32) return -1;
-  return (long long)sdconv::packed_floats(c_in, c_out, kz);
+  return (long long)sdconv::packed_floats(c_in, c_out, kz) + 4;      // + 16 bytes of zeros (the kernel's zero padding source)
 }
 
 extern "C" int sd_conv3_pack_weights_host(const float* w, int c_in, int c_out, int kz, float* packed) {
@@ -287,6 +345,7 @@ extern "C" int sd_conv3_pack_weights_host(const float* w, int c_in, int c_out, i
     return 0;
   }
   sdconv::pack_weights(w, c_in, c_out, kz, packed);
+  for (int k = 0; k < 4; ++k) packed[sdconv::packed_floats(c_in, c_out, kz) + k] = 0.f;
   return 0;
 }
 
@@ -330,10 +389,13 @@ extern "C" int sd_conv3_ndhwc_device(const float* d_src0, int c0, int stride0, i
   }
   Params P;
   int nc = 0;
-  for (int k = 0; k < c0 / 32; ++k) P.src[nc++] = Src{d_src0 + k * 32, stride0, (up0 >> 2) & 1, (up0 >> 1) & 1, up0 & 1};
-  if (d_src1) for (int k = 0; k < c1 / 32; ++k) P.src[nc++] = Src{d_src1 + k * 32, stride1, (up1 >> 2) & 1, (up1 >> 1) & 1, up1 & 1};
-  for (int k = nc; k < MAX_CHUNKS; ++k) P.src[k] = P.src[0];
+  P.kind[0] = Src{d_src0, stride0, (up0 >> 2) & 1, (up0 >> 1) & 1, up0 & 1};
+  P.kind[1] = d_src1 ? Src{d_src1, stride1, (up1 >> 2) & 1, (up1 >> 1) & 1, up1 & 1} : P.kind[0];
+  for (int k = 0; k < MAX_CHUNKS; ++k) { P.chunk_kind[k] = 0; P.chunk_choff[k] = 0; }
+  for (int k = 0; k < c0 / 32; ++k) { P.chunk_kind[nc] = 0; P.chunk_choff[nc++] = k * 32; }
+  if (d_src1) for (int k = 0; k < c1 / 32; ++k) { P.chunk_kind[nc] = 1; P.chunk_choff[nc++] = k * 32; }
   P.D = D; P.H = H; P.W = W; P.kz = kz; P.n_units = nc * kz;
+  P.zero = d_wpacked + sdconv::packed_floats(c_in, c_out, kz);
   P.wp = d_wpacked; P.bias = d_bias; P.out = d_out; P.c_out = c_out; P.act = act;
   P.tiles_x = (W + TW - 1) / TW;
   P.tiles_plane = P.tiles_x * ((H + TH - 1) / TH);

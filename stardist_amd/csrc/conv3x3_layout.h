@@ -67,6 +67,13 @@ SDC_HD void stage_elem(int e, int& ty, int& tx, int& q4) {
   tx = pix - ty * HALO_W;
 }
 
+// Halo coordinates of a tile start at t0 = 8k - 1 (rows) / 32m - 1 (columns): always odd.  For a half-resolution source (sh = 1)
+// halo index t maps to source index (t0 + t) >> 1 = src_base(t0, 1) + src_rel(t, 1), both parts non-negative inside the image;
+// for a full-resolution source (sh = 0) to t0 + t.  The kernel's fast path adds a wave-uniform base built from src_base to
+// per-thread constants built from src_rel.
+SDC_HD int src_rel(int t, int sh) { return sh ? ((t - 1) >> 1) + 1 : t; }
+SDC_HD int src_base(int t0, int sh) { return sh ? ((t0 + 1) >> 1) - 1 : t0; }
+
 // Pack a PyTorch / Keras-converted kernel w[c_out][c_in][kz][3][3] (float32; kz = 1: Conv2D, 3: Conv3D) for the device kernel.
 // c_in, c_out multiples of 32.  `out` holds packed_floats(c_in, c_out, kz) floats.
 inline void pack_weights(const float* w, int c_in, int c_out, int kz, float* out) {

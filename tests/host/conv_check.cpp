@@ -36,7 +36,10 @@ static void emulate_tile(const SrcH* src, int n_chunks, int kz, int g, int D, in
       const int gy = ty0 + ty, gx = tx0 + tx;
       for (int k = 0; k < 4; ++k) {
         float v = 0.f;
-        if (z >= 0 && z < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+        const bool fast = z >= 0 && z < D && ty0 >= 0 && ty0 + HALO_H <= H && tx0 >= 0 && tx0 + HALO_W <= W;      // the kernel's interior-tile path
+        if (fast)
+          v = S.p[(((size_t)(z >> S.shz) * hs + src_base(ty0, S.shy) + src_rel(ty, S.shy)) * ws + src_base(tx0, S.shx) + src_rel(tx, S.shx)) * S.stride + q4 * 4 + k];
+        else if (z >= 0 && z < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
           v = S.p[(((size_t)(z >> S.shz) * hs + (gy >> S.shy)) * ws + (gx >> S.shx)) * S.stride + q4 * 4 + k];
         tileL[tile_off(ty, tx, q4 * 4) + k] = v;
       }
@@ -129,6 +132,8 @@ int main() {
   srand(1);
   int bad = 0;
   bad += run_case(1, 16, 64, 1, 32, 0, 0, 0, 32, 1);
+  bad += run_case(1, 32, 128, 1, 32, 3, 32, 0, 32, 1);        // interior tiles with an up-sampled source
+  bad += run_case(4, 24, 96, 3, 32, 5, 32, 0, 32, 0);         // 3D, z and x up-sampled only
   bad += run_case(1, 13, 45, 1, 32, 0, 0, 0, 64, 0);
   bad += run_case(1, 10, 34, 1, 64, 0, 0, 0, 32, 1);
   bad += run_case(1, 12, 36, 1, 32, 3, 32, 0, 32, 1);

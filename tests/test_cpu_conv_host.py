@@ -25,10 +25,11 @@ def test_pack_weights_abi():
     for ci, co, kz in ((32, 32, 1), (32, 64, 1), (64, 128, 1), (256, 32, 1), (32, 32, 3), (64, 64, 3)):
         w = rs.randn(*((co, ci) + ((3, 3, 3) if kz == 3 else (3, 3)))).astype(np.float32)
         n = l.sd_conv3_packed_floats(ci, co, kz)
-        assert n == co * ci * 9 * kz
+        assert n == co * ci * 9 * kz + 4                       # + 16 bytes of zeros: the kernel's zero-padding source
         out = np.empty(n, np.float32)
         N.check(l.sd_conv3_pack_weights_host(N.ptr(w), ci, co, kz, N.ptr(out)))
-        o = out.reshape(co // 32, (ci // 32) * kz, 9, 4, 2, 32, 4)        # [group][unit = chunk*kz + z][tap][j][h][n][e]
+        assert not out[-4:].any()
+        o = out[:-4].reshape(co // 32, (ci // 32) * kz, 9, 4, 2, 32, 4)        # [group][unit = chunk*kz + z][tap][j][h][n][e]
         w5 = w.reshape(co, ci, kz, 9)
         for g in range(o.shape[0]):
             for u in range(o.shape[1]):
