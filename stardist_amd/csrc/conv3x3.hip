@@ -222,7 +222,6 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1,
   }
   __syncthreads();                                     // (the compiler drains the LDS-direct loads before the barrier)
   int wb = 0;
-  const unsigned lane_off = (unsigned)((h * 4 * P.c_out + i) * 4);     // this lane's byte offset inside an output row segment
   for (int t = q; t < P.n_tiles; t += Q) {
     f32x16 acc[2][NT];
 #pragma unroll
@@ -238,35 +237,37 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1,
                     W8 + (wb ^ 1) * (WUNIT - WMAIN), acc, tid, wave, i, h);
       wb ^= 1;
     }
-    // epilogue: activation + store (the stores drain while the next tile is being computed: nothing waits on them before the
-    // next unit's prefetch has been consumed, a full compute phase later).  Row bases and the 16 column offsets are scalar;
-    // a lane adds its own offset once.  Accumulator register r holds tile column (r & 3) + 8 (r >> 2) + 4 h.
-    const int tz = t / P.tiles_plane, tr = t - tz * P.tiles_plane;
-    const int y0 = (tr / P.tiles_x) * TH + wave * 2, x0 = (tr % P.tiles_x) * TW;
-    const bool xfull = x0 + TW <= P.W, relu = P.act == 1;
+    // epilogue: activation, then a transpose through LDS so that a lane stores 16 bytes (4 channels of one pixel) instead of 4:
+    // 8 global_store_dwordx4 per wave instead of 32 global_store_dword.  An accumulator register holds ONE channel (i) of 16
+    // pixels, channels-last memory wants 32 channels of one pixel together.  Scratch = the weight buffer the matrix cores have
+    // just finished with (every wave is past the barrier behind that compute); a wave uses exactly the eight 1-KiB chunks
+    // n*4 + wave that its own LDS-direct loads refill in the next step, so no barrier is needed -- program order within the wave is enough.
+    // The stores drain while the next tile is being computed.  Accumulator register r holds tile column (r & 3) + 8 (r >> 2) + 4 h.
+    {
+      float* scr = Wl + (wb ^ 1) * WMAIN + wave * 256;            // chunk n of this wave: scr + n * 1024 floats
+      const bool relu = P.act == 1;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int y = y0 + p;
-      if (y < P.H) {
-        char* rowb = (char*)(P.out + (((size_t)tz * P.H + y) * P.W + x0) * P.c_out + g * 32 * NT);
-        float v[16];
-        if (relu) {
+      for (int p = 0; p < 2; ++p)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[p][0][r], 0.f);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = acc[p][0][r];
+        for (int r = 0; r < 16; ++r) {
+          const int pp = p * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;   // pixel of the wave's 64 (two rows of 32)
+          const float v = relu ? fmaxf(acc[p][0][r], 0.f) : acc[p][0][r];
+          scr[(pp >> 3) * 1024 + (pp & 7) * 32 + i] = v;
         }
-        if (xfull) {                                   // the rule: whole tile row inside the image, 16 unpredicated stores
+      const int tz = t / P.tiles_plane, tr = t - tz * P.tiles_plane;
+      const int y0 = (tr / P.tiles_x) * TH + wave * 2, x0 = (tr % P.tiles_x) * TW;
+      const bool xfull = x0 + TW <= P.W;
+      const int px = lane >> 3, c4 = lane & 7;                      // this lane's pixel within a chunk's 8, its channel quad
+      v4f vv[8];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) *(float*)(rowb + (size_t)((r & 3) + 8 * (r >> 2)) * P.c_out * 4 + lane_off) = v[r];
-        } else {
+      for (int n = 0; n < 8; ++n) vv[n] = *(const v4f*)(scr + n * 1024 + lane * 4);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int col = (r & 3) + 8 * (r >> 2);
-            if (x0 + col + 4 * h < P.W) *(float*)(rowb + (size_t)col * P.c_out * 4 + lane_off) = v[r];
-          }
-        }
+      for (int n = 0; n < 8; ++n) asm volatile("" : "+v"(vv[n]));      // all eight reads in flight before the first store
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        const int y = y0 + (n >> 2), x = x0 + (n & 3) * 8 + px;
+        if (y < P.H && (xfull || x < P.W))
+          *(v4f*)(P.out + (((size_t)tz * P.H + y) * P.W + x) * P.c_out + g * 32 * NT + c4 * 4) = vv[n];
       }
     }
   }
