@@ -12,6 +12,8 @@
 //     tiling, launch geometry or run.
 //   * k_conv3_c1: the first layer (1 input channel, K = 9 or 27): HBM-write bound, plain FMAs.
 // Bound: MFMA (f32: 64 FLOP/clk/SIMD); algorithmic bytes 4*(C_in + C_out) per pixel.
+#include <stdlib.h>
+
 #include "common.h"
 #include "conv3x3_layout.h"
 #include "stardist_hip.h"
@@ -41,6 +43,7 @@ struct Params {
   const float* bias;
   float* out;          // [D][H][W][c_out]
   int c_out, act;
+  int debug;           // SD_CONV_DEBUG (timing experiments only): 1 = skip the output stores, 2 = read every halo element from the zero block
   int tiles_x, tiles_plane, n_tiles, groups;
 };
 
@@ -93,7 +96,10 @@ __device__ __forceinline__ void load_unit(const Params& P, const Stage& st, int 
   const float* plane = sp + (size_t)(min(max(z, 0), P.D - 1) >> S.shz) * hs * ws * S.stride;
   typedef const __attribute__((address_space(1))) char* gptr;      // explicitly global: the asm fence below hides the provenance
   gptr addr[PRE_F4];
-  if (zin && ty0 >= 0 && ty0 + HALO_H <= P.H && tx0 >= 0 && tx0 + HALO_W <= P.W) {
+  if (P.debug & 2) {
+#pragma unroll
+    for (int n = 0; n < PRE_F4; ++n) addr[n] = (gptr)P.zero;
+  } else if (zin && ty0 >= 0 && ty0 + HALO_H <= P.H && tx0 >= 0 && tx0 + HALO_W <= P.W) {
     const int by = src_base(ty0, S.shy), bx = src_base(tx0, S.shx);
     gptr base = (gptr)(plane + ((size_t)by * ws + bx) * S.stride);
 #pragma unroll
@@ -266,7 +272,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1,
 #pragma unroll
       for (int n = 0; n < 8; ++n) {
         const int y = y0 + (n >> 2), x = x0 + (n & 3) * 8 + px;
-        if (y < P.H && (xfull || x < P.W))
+        if (y < P.H && (xfull || x < P.W) && !(P.debug & 1))
           *(v4f*)(P.out + (((size_t)tz * P.H + y) * P.W + x) * P.c_out + g * 32 * NT + c4 * 4) = vv[n];
       }
     }
@@ -397,6 +403,7 @@ extern "C" int sd_conv3_ndhwc_device(const float* d_src0, int c0, int stride0, i
   if (d_src1) for (int k = 0; k < c1 / 32; ++k) { P.chunk_kind[nc] = 1; P.chunk_choff[nc++] = k * 32; }
   P.D = D; P.H = H; P.W = W; P.kz = kz; P.n_units = nc * kz;
   P.zero = d_wpacked + sdconv::packed_floats(c_in, c_out, kz);
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SD_CONV_DEBUG"); dbg = e ? atoi(e) : 0; } P.debug = dbg; }
   P.wp = d_wpacked; P.bias = d_bias; P.out = d_out; P.c_out = c_out; P.act = act;
   P.tiles_x = (W + TW - 1) / TW;
   P.tiles_plane = P.tiles_x * ((H + TH - 1) / TH);
