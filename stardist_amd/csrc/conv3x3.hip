@@ -305,6 +305,59 @@ __global__ void __launch_bounds__(256) k_conv3_c1(const float* __restrict__ x, i
   }
 }
 
+// first layer, 32 output channels (the networks' case): thread = one pixel, all 32 channels.  The weights are wave-uniform (scalar
+// loads, SGPR operands of the FMAs), the 9 / 27 input taps are read once per pixel instead of once per channel quad, and the
+// 128 bytes a thread produces are transposed through LDS (row pitch 36 floats) so that a wave writes its 64 pixels as eight
+// fully coalesced 1-KiB stores.  HBM-write bound (128 B/pixel).
+template <int KZ>
+__global__ void __launch_bounds__(256) k_conv3_c1x32(const float* __restrict__ x, int D, int H, int W, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, int act, float* __restrict__ out) {
+  __shared__ float rows[4][64 * 36];
+  const long long n_pix = (long long)D * H * W;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long wbase = ((long long)blockIdx.x * 4 + wave) * 64;       // first pixel of this wave
+  if (wbase >= n_pix) return;
+  const long long pix = wbase + lane;
+  const bool live = pix < n_pix;
+  const long long pc = live ? pix : n_pix - 1;
+  const int xx = (int)(pc % W);
+  const long long rest = pc / W;
+  const int y = (int)(rest % H), z = (int)(rest / H);
+  float acc[32];
+#pragma unroll
+  for (int co = 0; co < 32; ++co) acc[co] = bias ? bias[co] : 0.f;
+  // rows of three taps: the loop over (dz, dy) stays rolled so that only one row's 96 weights occupy scalar registers at a time
+#pragma unroll 1
+  for (int r3 = 0; r3 < 3 * KZ; ++r3) {
+    const int gz = z + (KZ == 3 ? r3 / 3 - 1 : 0), gy = y + r3 % 3 - 1;
+    const bool rin = gz >= 0 && gz < D && gy >= 0 && gy < H;
+    const float* xr = x + ((size_t)min(max(gz, 0), D - 1) * H + min(max(gy, 0), H - 1)) * W;
+    const float* wr = w + r3 * 96;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int gx = xx + dx - 1;
+      const float v = (rin && gx >= 0 && gx < W) ? xr[min(max(gx, 0), W - 1)] : 0.f;
+#pragma unroll
+      for (int co = 0; co < 32; ++co) acc[co] = __builtin_fmaf(v, wr[dx * 32 + co], acc[co]);
+    }
+  }
+  float* row = rows[wave] + lane * 36;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    v4f o = {acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
+    if (act == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    *(v4f*)(row + q * 4) = o;
+  }
+  // (only this wave touches rows[wave]: LDS operations of one wave complete in order)
+  const int px = lane >> 3, c4 = lane & 7;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const v4f o = *(const v4f*)(rows[wave] + (k * 8 + px) * 36 + c4 * 4);
+    const long long p2 = wbase + k * 8 + px;
+    if (p2 < n_pix) *(v4f*)(out + p2 * 32 + c4 * 4) = o;
+  }
+}
+
 template <int NT>
 int launch_conv(const Params& P, hipStream_t s) {
   static bool attr_set[16] = {};
@@ -369,6 +422,14 @@ extern "C" int sd_conv3_ndhwc_device(const float* d_src0, int c0, int stride0, i
   }
   if (c_in == 1) {
     if (d_src1 || up0 || stride0 != 1) { sd::set_error("sd_conv3_ndhwc: the one-channel layer takes one full-resolution source"); return -1; }
+    if (c_out == 32) {
+      const long long waves = ((long long)D * H * W + 63) / 64;
+      const dim3 g1((unsigned)((waves + 3) / 4));
+      if (kz == 1) hipLaunchKernelGGL(k_conv3_c1x32<1>, g1, dim3(256), 0, s, d_src0, D, H, W, d_wpacked, d_bias, act, d_out);
+      else hipLaunchKernelGGL(k_conv3_c1x32<3>, g1, dim3(256), 0, s, d_src0, D, H, W, d_wpacked, d_bias, act, d_out);
+      SD_LAUNCH_CHECK();
+      return 0;
+    }
     const int c4 = c_out / 4;
     const long long n = (long long)D * H * W * c4;
     long long blocks = (n + 255) / 256;

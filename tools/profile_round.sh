@@ -11,15 +11,19 @@ O=$R/gpurun_out/$tag; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 export SD_PMC_STEPS=3
 python $R/tools/pmc_predict.py > $O/warm.log 2>&1
-rm -rf /tmp/prof_kt; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python $R/tools/pmc_predict.py > $O/kernel_trace.log 2>&1
+# 1. the bench command itself under the kernel trace (its JSON line is kept next to the table: the per-kernel averages must agree with it)
+rm -rf /tmp/prof_kt; (cd $R && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_under_trace.log 2>&1)
 db=$(find /tmp/prof_kt -name '*.db' | head -1)
 python $R/tools/rocpd_summary.py $db --md > $O/kernel_stats.md 2>&1
+tail -1 $O/bench_under_trace.log > $O/bench_under_trace.json
 i=0
-for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_INSTS_VALU"; do
+for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
   i=$((i+1)); rm -rf /tmp/pmc_$i
   timeout 600 rocprofv3 --kernel-trace --pmc $P --output-format csv -d /tmp/pmc_$i -o p -- python $R/tools/pmc_predict.py > $O/pmc_$i.log 2>&1
 done
 f1=$(find /tmp/pmc_1 -name 'p_counter_collection.csv' | head -1); f2=$(find /tmp/pmc_2 -name 'p_counter_collection.csv' | head -1); f3=$(find /tmp/pmc_3 -name 'p_counter_collection.csv' | head -1)
 python $R/tools/profile_traffic.py ${f1%_counter_collection.csv} ${f2%_counter_collection.csv} $O/pmc_1.log $O/pair_kernel_traffic.json $O/pmc_hbm_traffic.md > $O/traffic.log 2>&1
-python $R/tools/pmc_multi.py ${f3%_counter_collection.csv} > $O/pmc_mfma.md 2>&1
+python $R/tools/pmc_multi.py ${f3%_counter_collection.csv} k_ > $O/pmc_mfma.md 2>&1
+f4=$(find /tmp/pmc_4 -name 'p_counter_collection.csv' | head -1)
+[ -n "$f4" ] && python $R/tools/pmc_multi.py ${f4%_counter_collection.csv} k_conv3 > $O/pmc_conv_stalls.md 2>&1
 head -40 $O/kernel_stats.md; cat $O/traffic.log | cut -c1-600

@@ -36,6 +36,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--size3d", type=int, default=256)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     img = torch.from_numpy(synth.s2d_nuclei_image(a.size, a.size, seed=0)).to(dev)
@@ -63,6 +64,41 @@ def main():
     for k, v in acc.items():
         print("  %-42s %8.3f ms" % (k, 1e3 * v / a.steps))
     print("  %-42s %8.3f ms" % ("unaccounted (python glue, to-numpy copies)", 1e3 * (ser - sum(v for k, v in acc.items() if not k.startswith("  ")) / a.steps)))
+    if a.size3d:
+        sections_3d(a, dev)
+
+
+def sections_3d(a, dev):
+    from stardist_amd.models import Config3D, StarDist3D
+    import stardist_amd.models.model3d as M3
+    acc.clear()
+    vol = torch.from_numpy(synth.s3d_nuclei_image(a.size3d, seed=0)).to(dev)
+    m3 = StarDist3D(Config3D(rays=96), basedir=None, device=dev, seed=0)
+    m3.thresholds = dict(prob=0.5, nms=0.3)
+    bench.calibrate_heads(m3, vol, frac=0.009, radius=8.5, noise=0.03)
+    for _ in range(2):
+        m3.predict_instances(vol)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(3):
+        m3.predict_instances(vol)
+    torch.cuda.synchronize(); whole = (time.perf_counter() - t0) / 3
+    wrap(m3, "_net_forward", "net_forward")
+    wrap(m3, "_select_rows", "select+dist_rows")
+    wrap(M3, "non_maximum_suppression_3d_sparse", "nms_sparse(sort+gather+nms+gather)")
+    wrap(NMS, "non_maximum_suppression_3d_inds", "  nms_3d_inds(sort+native)")
+    wrap(M3, "polyhedron_to_label", "raster")
+    wrap(M3, "relabel_sequential", "relabel_sequential")
+    wrap(M3, "to_host", "labels_to_host")
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(3):
+        m3.predict_instances(vol)
+    torch.cuda.synchronize(); ser = (time.perf_counter() - t0) / 3
+    print("3D: pipelined step %.3f ms; serialised step %.3f ms" % (1e3 * whole, 1e3 * ser))
+    for k, v in acc.items():
+        print("  %-42s %8.3f ms" % (k, 1e3 * v / 3))
+    print("  %-42s %8.3f ms" % ("unaccounted", 1e3 * (ser - sum(v for k, v in acc.items() if not k.startswith("  ")) / 3)))
+    from stardist_amd.lib import _native
+    print("  nms3d native stats:", [int(v) for v in _native.last_stats.get("nms3d", [])])
 
 
 if __name__ == "__main__":
