@@ -311,8 +311,14 @@ def main():
         stages = {"unet_forward": round(net_ms, 3), "nms_pair_kernel": round(float(pair_ms), 3),
                   "nms_exact_join_kernel": round(float(s2[6] / 1e6), 3), "nms_build_bin_neighbours": round(float(s2[7] / 1e6), 3),
                   "other(select,sort,greedy-scan,raster,d2h)": round(ms_per_step - net_ms - float(pair_ms + s2[6] / 1e6 + s2[7] / 1e6), 3)}
-        roof_conv = {"bound": "mfma", "kernel": "U-Net conv stack (MIOpen / CK kernels, fp32 NHWC)", "achieved": round(conv_tf, 3), "peak": peak,
-                     "unit": "TFLOP/s", "frac": round(conv_tf / peak, 4), "traffic": None, "flops_per_launch": flops, "avg_ms": round(net_ms, 3)}
+        from stardist_amd.models.unet import hand_conv_enabled
+        conv_kernel = ("network forward = one HIP graph: k_conv3<1> (hand-written f32-MFMA implicit GEMM, csrc/conv3x3.hip: every 3x3 layer incl. folded "
+                       "up-sampling / concatenation / bias / ReLU) + k_conv3_c1x32 + max-pool + probability-head pass" if hand_conv_enabled() and args.dtype == "float32"
+                       else "network forward (MIOpen / CK convolution kernels, NHWC) + epilogue passes")
+        roof_conv = {"bound": "mfma", "kernel": conv_kernel, "achieved": round(conv_tf, 3), "peak": peak,
+                     "unit": "TFLOP/s", "frac": round(conv_tf / peak, 4), "traffic": None, "flops_per_launch": flops, "avg_ms": round(net_ms, 3),
+                     "note": "algorithmic FLOPs of the convolutions (2 x MACs, recomputed from the instantiated module) / HIP-event time of the whole "
+                             "forward pass on the caller's stream; per-kernel durations: profiles/r02_bench_kernel_stats.md"}
         roof_pair = {"bound": "hbm", "kernel": "k_pairs_beam<32,8,6,4,64> (bound-slot scan-beam polygon intersection, one pair per lane, state in LDS)", "achieved": round(pair_gbs, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pair_gbs / HBM_PEAK_GBS, 6), "traffic": None,
                      "bytes_per_launch": round(pair_bytes_per_launch), "avg_launch_ms": round(float(pair_ms / pair_launches), 4),
@@ -386,7 +392,8 @@ def main():
             out["stages_ms_3d"] = {"unet_forward": round(net3_ms, 3), "nms_stage3_kernel_volume": round(float(s3[8] / 1e6), 3),
                                    "nms_stage4_hull_volume": round(float(s3[9] / 1e6), 3), "nms_stage5_render": round(float(s3[10] / 1e6), 3),
                                    "other": round(ms3 - net3_ms - float((s3[8] + s3[9] + s3[10]) / 1e6), 3)}
-            out["roofline_convs_3d"] = {"bound": "mfma", "achieved": round(conv3_tf, 3), "peak": peak, "unit": "TFLOP/s",
+            out["roofline_convs_3d"] = {"bound": "mfma", "kernel": "network forward (k_conv3<1> 3x3x3 layers as three z-plane units per 32-channel chunk)",
+                                        "achieved": round(conv3_tf, 3), "peak": peak, "unit": "TFLOP/s",
                                         "frac": round(conv3_tf / peak, 4), "flops_per_launch": flops3, "avg_ms": round(net3_ms, 3)}
             if not args.no_cpu_baseline and world == 1:
                 try:
