@@ -27,6 +27,15 @@ if __name__ == "__main__":
     md = "--md" in sys.argv
     if md:
         print("| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|")
+    # --group SUBSTR N: one more line for a kernel launched N times per step with different shapes (the hand-written convolution:
+    # 14 launches per 2D forward pass), so that its per-step total can be held against bench.py's HIP-event time of the forward pass
+    if "--group" in sys.argv:
+        i = sys.argv.index("--group"); sub, per = sys.argv[i + 1], int(sys.argv[i + 2])
+        sel = [r for r in rows if sub in r[0]]
+        calls, tot = sum(r[1] for r in sel), sum(r[2] for r in sel)
+        if calls:
+            print("%s`*%s*`: %d launches, %.3f ms in total = %.3f ms per group of %d launches (one forward pass)%s"
+                  % ("" if not md else "\n", sub, calls, tot / 1e6, tot / 1e6 / (calls / float(per)), per, "\n" if md else ""))
     for n, calls, t, a, mn, mx, pc in rows:
         n = n if len(n) < 90 else n[:87] + "..."
         if md:
