@@ -531,6 +531,56 @@ __global__ void __launch_bounds__(1024) k_tail_resolve(const int* __restrict__ U
   }
 }
 
+// ---- pair order.  The pair kernel runs one sweep per lane; lanes of a wave that sweep geometrically similar pairs take similar
+// control paths (the number of scan-beams and where the second polygon enters are functions of the centre offset).  The pair
+// list [first, n) is therefore bucketed by the quantised centre offset (dy major, dx minor) before tier 1: histogram, scan,
+// scatter of PAIR INDICES -- the kernels behind it already work on index lists.  Decisions are per pair, so the order (and the
+// arbitrary order inside a bucket) cannot change any result.
+constexpr int PAIR_BUCKETS = 1024;
+__device__ __forceinline__ int pair_bucket(const float* __restrict__ pts, int2 ij, float inv) {
+  const float dy = pts[2 * ij.y] - pts[2 * ij.x], dx = pts[2 * ij.y + 1] - pts[2 * ij.x + 1];
+  int by = (int)((dy * inv + 0.5f) * 32.f), bx = (int)((dx * inv + 0.5f) * 32.f);
+  by = by < 0 ? 0 : (by > 31 ? 31 : by); bx = bx < 0 ? 0 : (bx > 31 ? 31 : bx);
+  return by * 32 + bx;
+}
+__global__ void __launch_bounds__(256) k_pair_bucket_count(const int2* __restrict__ pairs, const unsigned long long* __restrict__ nPtr,
+                                                           const unsigned int* __restrict__ firstPtr, const float* __restrict__ pts, float inv,
+                                                           unsigned int* __restrict__ hist) {
+  __shared__ unsigned int h[PAIR_BUCKETS];
+  for (int b = threadIdx.x; b < PAIR_BUCKETS; b += 256) h[b] = 0;
+  __syncthreads();
+  const unsigned long long n = *nPtr, first = firstPtr ? *firstPtr : 0u;
+  for (unsigned long long t = first + (unsigned long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * 256)
+    atomicAdd(&h[pair_bucket(pts, pairs[t], inv)], 1u);
+  __syncthreads();
+  for (int b = threadIdx.x; b < PAIR_BUCKETS; b += 256) if (h[b]) atomicAdd(&hist[b], h[b]);
+}
+__global__ void __launch_bounds__(PAIR_BUCKETS) k_pair_bucket_scan(const unsigned int* __restrict__ hist, unsigned int* __restrict__ cursor,
+                                                                   unsigned long long* __restrict__ nOrdered) {
+  __shared__ unsigned int sh[PAIR_BUCKETS];
+  const int b = threadIdx.x;
+  const unsigned int v = hist[b];
+  sh[b] = v;
+  __syncthreads();
+  for (int o = 1; o < PAIR_BUCKETS; o <<= 1) {
+    const unsigned int add = b >= o ? sh[b - o] : 0u;
+    __syncthreads();
+    sh[b] += add;
+    __syncthreads();
+  }
+  cursor[b] = sh[b] - v;
+  if (b == PAIR_BUCKETS - 1) *nOrdered = sh[b];
+}
+__global__ void __launch_bounds__(256) k_pair_bucket_scatter(const int2* __restrict__ pairs, const unsigned long long* __restrict__ nPtr,
+                                                             const unsigned int* __restrict__ firstPtr, const float* __restrict__ pts, float inv,
+                                                             unsigned int* __restrict__ cursor, unsigned int* __restrict__ order, unsigned int cap) {
+  const unsigned long long n = *nPtr, first = firstPtr ? *firstPtr : 0u;
+  for (unsigned long long t = first + (unsigned long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * 256) {
+    const unsigned int k = atomicAdd(&cursor[pair_bucket(pts, pairs[t], inv)], 1u);
+    if (k < cap) order[k] = (unsigned int)t;
+  }
+}
+
 __global__ void k_iota(int* a, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = i; }
 __global__ void k_keep(const unsigned char* __restrict__ state, unsigned char* __restrict__ keep, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -560,10 +610,10 @@ struct BeamPath {
     return 0;
   }
   // tier 1 (K = 8): all pairs of the round; capacity spills -> q.spill
-  static int tier1(const int2* pairs, const unsigned long long* nPairs, const unsigned int* first, const void* prep, const float* area, float thr,
-                   unsigned char* state, unsigned char* supp, PairQueues q, hipStream_t s) {
+  static int tier1(const int2* pairs, const unsigned int* idx, const unsigned long long* nPairs, const unsigned int* first, const void* prep, const float* area,
+                   float thr, unsigned char* state, unsigned char* supp, PairQueues q, hipStream_t s) {
     static const size_t lds = beam_lds_bytes<MAXV, 8, 6, 4, 64>();
-    hipLaunchKernelGGL((k_pairs_beam<MAXV, 8, 6, 4, 64, unsigned long long>), dim3(256 * 4), dim3(64), lds, s, pairs, (const unsigned int*)nullptr, nPairs, first, (const Prep*)prep, area, thr, state, supp, q);
+    hipLaunchKernelGGL((k_pairs_beam<MAXV, 8, 6, 4, 64, unsigned long long>), dim3(256 * 4), dim3(64), lds, s, pairs, idx, nPairs, first, (const Prep*)prep, area, thr, state, supp, q);
     SD_LAUNCH_CHECK();
     return 0;
   }
@@ -720,7 +770,12 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   unsigned int* exactPairs = A.take_n<unsigned int>(qCap);
   int* Sl = A.take_n<int>(N);
   Counters* d_cnt = (Counters*)A.take(sizeof(Counters));
-  if (!U0 || !U1 || !K || !pairs || !spillPairs || !exactPairs || !Sl || !d_cnt) return -1;
+  // pair order (see k_pair_bucket_*): SD_NMS_PAIR_SORT=0 keeps emission order
+  static const bool pairSort = !(getenv("SD_NMS_PAIR_SORT") && atoi(getenv("SD_NMS_PAIR_SORT")) == 0);
+  unsigned int* pairOrder = pairSort && R <= 32 ? A.take_n<unsigned int>(qCap) : nullptr;
+  unsigned int* bucketHist = A.take_n<unsigned int>(2 * PAIR_BUCKETS);
+  unsigned long long* nOrdered = A.take_n<unsigned long long>(1);
+  if (!U0 || !U1 || !K || !pairs || !spillPairs || !exactPairs || !Sl || !d_cnt || !bucketHist || !nOrdered || (pairSort && R <= 32 && !pairOrder)) return -1;
   hipLaunchKernelGGL(k_iota, dim3(sd::div_up(N, 256)), dim3(256), 0, s, U0, N);
   int nU = N, rounds = 0;
   i64 totalPairs = 0, totalExact = 0, totalSpill = 0;
@@ -762,7 +817,17 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
     PairQueues q2{exactPairs, &d_cnt->nExact, exactPairs, &d_cnt->nExact, qCap};   // what tier 2 cannot hold goes to the general path
     int rc;
     if (R <= 32) {
-      rc = BeamPath<32, 64>::tier1(pairs, &d_cnt->nPairs, first, prep, area, threshold, state, suppOut, q1, s);
+      if (pairOrder) {
+        const float inv = 1.f / (4.f * (max_dist + 1.f));                 // centre offsets lie in (-2 max_dist, 2 max_dist)
+        SD_CHECK(hipMemsetAsync(bucketHist, 0, PAIR_BUCKETS * sizeof(unsigned int), s));
+        hipLaunchKernelGGL(k_pair_bucket_count, dim3(512), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, d_points, inv, bucketHist);
+        hipLaunchKernelGGL(k_pair_bucket_scan, dim3(1), dim3(PAIR_BUCKETS), 0, s, bucketHist, bucketHist + PAIR_BUCKETS, nOrdered);
+        hipLaunchKernelGGL(k_pair_bucket_scatter, dim3(512), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, d_points, inv, bucketHist + PAIR_BUCKETS,
+                           pairOrder, qCap);
+        SD_LAUNCH_CHECK();
+        rc = BeamPath<32, 64>::tier1(pairs, pairOrder, nOrdered, (const unsigned int*)nullptr, prep, area, threshold, state, suppOut, q1, s);
+      } else
+        rc = BeamPath<32, 64>::tier1(pairs, (const unsigned int*)nullptr, &d_cnt->nPairs, first, prep, area, threshold, state, suppOut, q1, s);
       if (stats) SD_CHECK(hipEventRecord(ev1, s));
       if (!rc) rc = BeamPath<32, 64>::tier2(pairs, spillPairs, &d_cnt->nSpill, (const unsigned int*)nullptr, prep, area, threshold, state, suppOut, q2, s);
     } else {
