@@ -536,47 +536,59 @@ __global__ void __launch_bounds__(1024) k_tail_resolve(const int* __restrict__ U
 // list [first, n) is therefore bucketed by the quantised centre offset (dy major, dx minor) before tier 1: histogram, scan,
 // scatter of PAIR INDICES -- the kernels behind it already work on index lists.  Decisions are per pair, so the order (and the
 // arbitrary order inside a bucket) cannot change any result.
-constexpr int PAIR_BUCKETS = 1024;
-__device__ __forceinline__ int pair_bucket(const float* __restrict__ pts, int2 ij, float inv) {
+constexpr int PAIR_BUCKETS = 4096;
+// key = (local-minima class of the two polygons [nl], dy bin [ny], dx bin [nx]); nl * ny * nx <= PAIR_BUCKETS
+struct PairKey { const char* prep; size_t prepStride; float inv; int nl, ny, nx; };
+__device__ __forceinline__ int pair_bucket(const float* __restrict__ pts, int2 ij, const PairKey& k) {
   const float dy = pts[2 * ij.y] - pts[2 * ij.x], dx = pts[2 * ij.y + 1] - pts[2 * ij.x + 1];
-  int by = (int)((dy * inv + 0.5f) * 32.f), bx = (int)((dx * inv + 0.5f) * 32.f);
-  by = by < 0 ? 0 : (by > 31 ? 31 : by); bx = bx < 0 ? 0 : (bx > 31 ? 31 : bx);
-  return by * 32 + bx;
+  int by = (int)((dy * k.inv + 0.5f) * (float)k.ny), bx = (int)((dx * k.inv + 0.5f) * (float)k.nx);
+  by = by < 0 ? 0 : (by >= k.ny ? k.ny - 1 : by); bx = bx < 0 ? 0 : (bx >= k.nx ? k.nx - 1 : bx);
+  int lm = 0;
+  if (k.nl > 1) {                                    // n_lm is the second int of a PolyPrep record (clip_beam.h)
+    int a = *(const int*)(k.prep + (size_t)ij.x * k.prepStride + 4), b = *(const int*)(k.prep + (size_t)ij.y * k.prepStride + 4);
+    a = a < 1 ? 0 : (a > 4 ? 3 : a - 1); b = b < 1 ? 0 : (b > 4 ? 3 : b - 1);
+    lm = (a * 4 + b) % k.nl;
+  }
+  return (lm * k.ny + by) * k.nx + bx;
 }
 __global__ void __launch_bounds__(256) k_pair_bucket_count(const int2* __restrict__ pairs, const unsigned long long* __restrict__ nPtr,
-                                                           const unsigned int* __restrict__ firstPtr, const float* __restrict__ pts, float inv,
+                                                           const unsigned int* __restrict__ firstPtr, const float* __restrict__ pts, PairKey key,
                                                            unsigned int* __restrict__ hist) {
   __shared__ unsigned int h[PAIR_BUCKETS];
   for (int b = threadIdx.x; b < PAIR_BUCKETS; b += 256) h[b] = 0;
   __syncthreads();
   const unsigned long long n = *nPtr, first = firstPtr ? *firstPtr : 0u;
   for (unsigned long long t = first + (unsigned long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * 256)
-    atomicAdd(&h[pair_bucket(pts, pairs[t], inv)], 1u);
+    atomicAdd(&h[pair_bucket(pts, pairs[t], key)], 1u);
   __syncthreads();
   for (int b = threadIdx.x; b < PAIR_BUCKETS; b += 256) if (h[b]) atomicAdd(&hist[b], h[b]);
 }
-__global__ void __launch_bounds__(PAIR_BUCKETS) k_pair_bucket_scan(const unsigned int* __restrict__ hist, unsigned int* __restrict__ cursor,
-                                                                   unsigned long long* __restrict__ nOrdered) {
-  __shared__ unsigned int sh[PAIR_BUCKETS];
-  const int b = threadIdx.x;
-  const unsigned int v = hist[b];
-  sh[b] = v;
+__global__ void __launch_bounds__(1024) k_pair_bucket_scan(const unsigned int* __restrict__ hist, unsigned int* __restrict__ cursor,
+                                                           unsigned long long* __restrict__ nOrdered) {
+  __shared__ unsigned int sh[1024];
+  const int t = threadIdx.x;
+  unsigned int v[PAIR_BUCKETS / 1024], tot = 0;
+#pragma unroll
+  for (int k = 0; k < PAIR_BUCKETS / 1024; ++k) { v[k] = hist[t * (PAIR_BUCKETS / 1024) + k]; tot += v[k]; }
+  sh[t] = tot;
   __syncthreads();
-  for (int o = 1; o < PAIR_BUCKETS; o <<= 1) {
-    const unsigned int add = b >= o ? sh[b - o] : 0u;
+  for (int o = 1; o < 1024; o <<= 1) {
+    const unsigned int add = t >= o ? sh[t - o] : 0u;
     __syncthreads();
-    sh[b] += add;
+    sh[t] += add;
     __syncthreads();
   }
-  cursor[b] = sh[b] - v;
-  if (b == PAIR_BUCKETS - 1) *nOrdered = sh[b];
+  unsigned int run = sh[t] - tot;
+#pragma unroll
+  for (int k = 0; k < PAIR_BUCKETS / 1024; ++k) { cursor[t * (PAIR_BUCKETS / 1024) + k] = run; run += v[k]; }
+  if (t == 1023) *nOrdered = sh[t];
 }
 __global__ void __launch_bounds__(256) k_pair_bucket_scatter(const int2* __restrict__ pairs, const unsigned long long* __restrict__ nPtr,
-                                                             const unsigned int* __restrict__ firstPtr, const float* __restrict__ pts, float inv,
+                                                             const unsigned int* __restrict__ firstPtr, const float* __restrict__ pts, PairKey key,
                                                              unsigned int* __restrict__ cursor, unsigned int* __restrict__ order, unsigned int cap) {
   const unsigned long long n = *nPtr, first = firstPtr ? *firstPtr : 0u;
   for (unsigned long long t = first + (unsigned long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * 256) {
-    const unsigned int k = atomicAdd(&cursor[pair_bucket(pts, pairs[t], inv)], 1u);
+    const unsigned int k = atomicAdd(&cursor[pair_bucket(pts, pairs[t], key)], 1u);
     if (k < cap) order[k] = (unsigned int)t;
   }
 }
@@ -818,11 +830,14 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
     int rc;
     if (R <= 32) {
       if (pairOrder) {
-        const float inv = 1.f / (4.f * (max_dist + 1.f));                 // centre offsets lie in (-2 max_dist, 2 max_dist)
+        static const int keyMode = getenv("SD_NMS_PAIR_KEY") ? atoi(getenv("SD_NMS_PAIR_KEY")) : 0;
+        static const int modes[6][3] = {{1, 32, 32}, {1, 64, 16}, {1, 64, 64}, {16, 16, 16}, {16, 32, 8}, {4, 32, 32}};
+        const int* md = modes[keyMode >= 0 && keyMode < 6 ? keyMode : 0];
+        const PairKey key{(const char*)prep, prepStride, 1.f / (4.f * (max_dist + 1.f)), md[0], md[1], md[2]};   // offsets lie in (-2 max_dist, 2 max_dist)
         SD_CHECK(hipMemsetAsync(bucketHist, 0, PAIR_BUCKETS * sizeof(unsigned int), s));
-        hipLaunchKernelGGL(k_pair_bucket_count, dim3(512), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, d_points, inv, bucketHist);
-        hipLaunchKernelGGL(k_pair_bucket_scan, dim3(1), dim3(PAIR_BUCKETS), 0, s, bucketHist, bucketHist + PAIR_BUCKETS, nOrdered);
-        hipLaunchKernelGGL(k_pair_bucket_scatter, dim3(512), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, d_points, inv, bucketHist + PAIR_BUCKETS,
+        hipLaunchKernelGGL(k_pair_bucket_count, dim3(512), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, d_points, key, bucketHist);
+        hipLaunchKernelGGL(k_pair_bucket_scan, dim3(1), dim3(1024), 0, s, bucketHist, bucketHist + PAIR_BUCKETS, nOrdered);
+        hipLaunchKernelGGL(k_pair_bucket_scatter, dim3(512), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, d_points, key, bucketHist + PAIR_BUCKETS,
                            pairOrder, qCap);
         SD_LAUNCH_CHECK();
         rc = BeamPath<32, 64>::tier1(pairs, pairOrder, nOrdered, (const unsigned int*)nullptr, prep, area, threshold, state, suppOut, q1, s);
