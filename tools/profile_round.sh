@@ -15,7 +15,7 @@ python $R/tools/pmc_predict.py > $O/warm.log 2>&1
 rm -rf /tmp/prof_kt; (cd $R && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_under_trace.log 2>&1)
 db=$(find /tmp/prof_kt -name '*.db' | head -1)
 python $R/tools/rocpd_summary.py $db --md > $O/kernel_stats.md 2>&1
-tail -1 $O/bench_under_trace.log > $O/bench_under_trace.json
+grep "^{" $O/bench_under_trace.log > $O/bench_under_trace.json
 i=0
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
   i=$((i+1)); rm -rf /tmp/pmc_$i
