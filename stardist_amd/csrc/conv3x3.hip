@@ -15,45 +15,18 @@
 #include <stdlib.h>
 
 #include "common.h"
-#include "conv3x3_layout.h"
+#include "conv3x3_device.h"
 #include "stardist_hip.h"
 
 namespace {
 
-using namespace sdconv;
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float v4f __attribute__((ext_vector_type(4)));      // native 16-byte vector: plain loads/stores in any address space
-
-struct Src {
-  const float* p;      // channels-last [D >> shz][H >> shy][W >> shx][stride]
-  int stride;          // floats per pixel
-  int shz, shy, shx;   // 1: the source is half resolution along that axis (nearest-neighbour up-sampling by 2)
-};
-
-struct Params {
-  Src kind[2];                         // the (at most two) source tensors
-  int chunk_kind[MAX_CHUNKS];          // 32-channel chunk c comes from kind[chunk_kind[c]] ...
-  int chunk_choff[MAX_CHUNKS];         // ... starting at this channel
-  const float* zero;                   // 16 bytes of zeros (tail of the packed weights): where out-of-image halo elements are read from
-  int D, H, W;
-  int kz;              // z taps: 1 (2D) or 3
-  int n_units;         // chunks * kz
-  const float* wp;     // packed weights [groups][n_units][WUNIT]
-  const float* bias;
-  float* out;          // [D][H][W][c_out]
-  int c_out, act;
-  int debug;           // SD_CONV_DEBUG (timing experiments only): 1 = skip the output stores, 2 = read every halo element from the zero block
-  int tiles_x, tiles_plane, n_tiles, groups;
-};
+using namespace sdconvdev;
 
 constexpr int WUNIT = 9 * 4 * 2 * 32 * 4;     // floats of one weight block (NT = 1)
 constexpr int WMAIN = 8 * 4 * 2 * 32 * 4;     // ... of its taps 0..7
 
 // Per-thread staging constants, computed once per kernel: where this thread's PRE_F4 float4 elements of a halo tile live in LDS,
-// and -- for tiles whose halo lies inside the image -- their byte offsets from the halo's first source pixel, per source tensor
-// (a half-resolution source maps halo row ty to source row ((ty - 1) >> 1) + 1 relative to the row of halo row 0, because a
-// tile's first halo row/column is odd: 8k - 1 / 32m - 1).
+// and their source offsets on interior tiles (goff_init, conv3x3_device.h)
 struct Stage {
   int lds[PRE_F4];
   unsigned goff[2][PRE_F4];
@@ -67,60 +40,15 @@ __device__ __forceinline__ void stage_init(const Params& P, Stage& st, int tid) 
     int ty, tx, q4;
     stage_elem(e, ty, tx, q4);
     st.lds[n] = tile_off(ty, tx, q4 * 4);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const Src S = P.kind[k];
-      const int ry = src_rel(ty, S.shy), rx = src_rel(tx, S.shx);
-      st.goff[k][n] = (unsigned)(((ry * (P.W >> S.shx) + rx) * S.stride + q4 * 4) * 4);
-    }
   }
+  goff_init(P, st.goff, tid);
 }
 
-// Halo tile of unit u of output tile t -> registers (16 bytes per (thread, n)), the unit's weight block -> LDS.
-// Only ADDRESSES differ between tiles: inside the image (the rule) an element's address is a wave-uniform base + the precomputed
-// per-thread offset; on border tiles it is computed per element, and elements outside the volume (the zero padding of 'same')
-// point at a 16-byte block of zeros.  The loads themselves are unconditional and issue back to back after the addresses are
-// known, so nothing has to be selected, merged or waited for before the matrix cores start on the current unit.
+// Halo tile of unit u of output tile t -> registers (halo_fetch), the unit's weight block -> LDS.
 template <int NT>
 __device__ __forceinline__ void load_unit(const Params& P, const Stage& st, int g, int t, int u, v4f (&pre)[PRE_F4], v4f& w8,
                                           float* __restrict__ Wnext, int tid, int wave) {
-  const int c = u / P.kz, dz = P.kz == 3 ? u - c * 3 - 1 : 0;
-  const int k = P.chunk_kind[c];
-  const Src S = P.kind[k];
-  const float* sp = S.p + P.chunk_choff[c];
-  const int tz = t / P.tiles_plane, tr = t - tz * P.tiles_plane;
-  const int ty0 = (tr / P.tiles_x) * TH - 1, tx0 = (tr % P.tiles_x) * TW - 1;
-  const int z = tz + dz;
-  const bool zin = z >= 0 && z < P.D;
-  const int ws = P.W >> S.shx, hs = P.H >> S.shy;
-  const float* plane = sp + (size_t)(min(max(z, 0), P.D - 1) >> S.shz) * hs * ws * S.stride;
-  typedef const __attribute__((address_space(1))) char* gptr;      // explicitly global: the asm fence below hides the provenance
-  gptr addr[PRE_F4];
-  if (P.debug & 2) {
-#pragma unroll
-    for (int n = 0; n < PRE_F4; ++n) addr[n] = (gptr)P.zero;
-  } else if (zin && ty0 >= 0 && ty0 + HALO_H <= P.H && tx0 >= 0 && tx0 + HALO_W <= P.W) {
-    const int by = src_base(ty0, S.shy), bx = src_base(tx0, S.shx);
-    gptr base = (gptr)(plane + ((size_t)by * ws + bx) * S.stride);
-#pragma unroll
-    for (int n = 0; n < PRE_F4; ++n) addr[n] = base + (k ? st.goff[1][n] : st.goff[0][n]);
-  } else {
-#pragma unroll
-    for (int n = 0; n < PRE_F4; ++n) {
-      int e = tid + n * THREADS;
-      e = e < TILE_F4 ? e : TILE_F4 - 1;
-      int ty, tx, q4;
-      stage_elem(e, ty, tx, q4);
-      const int gy = ty0 + ty, gx = tx0 + tx;
-      const bool inside = zin && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
-      const int cy = min(max(gy, 0), P.H - 1) >> S.shy, cx = min(max(gx, 0), P.W - 1) >> S.shx;
-      addr[n] = inside ? (gptr)(plane + ((size_t)cy * ws + cx) * S.stride + q4 * 4) : (gptr)P.zero;
-    }
-  }
-#pragma unroll
-  for (int n = 0; n < PRE_F4; ++n) asm volatile("" : "+v"(addr[n]));        // addresses are final here: the loads below stay below
-#pragma unroll
-  for (int n = 0; n < PRE_F4; ++n) pre[n] = *(const __attribute__((address_space(1))) v4f*)addr[n];
+  halo_fetch(P, st.goff, t, u, pre, tid);
   // the unit's weight block (36 KiB, tap-major): taps 0..7 = 32 KiB global -> LDS without passing through registers
   // (global_load_lds_dwordx4: LDS destination = wave-uniform base + lane * 16; wave w, instruction n moves the n*4+w-th KiB); both
   // 32 KiB buffers lie in the first 64 KiB of LDS, whatever width of M0 the DMA honours.  Tap 8 (4 KiB) rides along in a register.
@@ -141,6 +69,13 @@ __device__ __forceinline__ void store_unit(const Stage& st, float* __restrict__ 
 #pragma unroll
   for (int n = 0; n < PRE_F4; ++n)
     if (n < PRE_F4 - 1 || tid < TILE_F4 - (PRE_F4 - 1) * THREADS) *(v4f*)(tileL + st.lds[n]) = pre[n];
+}
+
+// the two accumulator tiles of a wave as the plain array store_tile takes (NT == 1)
+template <int NT>
+__device__ __forceinline__ const f32x16 (&acc_rows(const f32x16 (&acc)[2][NT]))[2] {
+  static_assert(NT == 1, "");
+  return reinterpret_cast<const f32x16(&)[2]>(acc);
 }
 
 __device__ __forceinline__ float comp(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
@@ -207,13 +142,8 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1,
   float* tileL = W8 + 2 * (WUNIT - WMAIN);
   const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // wave-uniform: row bases and DMA destinations stay scalar
-  // workgroup -> (output-channel group g, tile slot q): consecutive workgroups go round-robin over the 8 XCDs, so the `groups`
-  // workgroups b, b+8, b+16, ... (same XCD, same L2) take the same tile sequence and differ in g
-  const int b = blockIdx.x, span = 8 * P.groups, blk = b / span, rem = b - blk * span;
-  int g, q;
-  if ((blk + 1) * span <= (int)gridDim.x) { g = rem >> 3; q = blk * 8 + (rem & 7); }
-  else { const int tail = gridDim.x - blk * span, per = tail / P.groups; g = rem / per; q = blk * 8 + rem % per; }   // last partial span
-  const int Q = gridDim.x / P.groups;
+  int g, q, Q;
+  wg_slot(P, g, q, Q);
   if (q >= P.n_tiles) return;
   float bias_r[NT];
 #pragma unroll
@@ -243,39 +173,10 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1,
                     W8 + (wb ^ 1) * (WUNIT - WMAIN), acc, tid, wave, i, h);
       wb ^= 1;
     }
-    // epilogue: activation, then a transpose through LDS so that a lane stores 16 bytes (4 channels of one pixel) instead of 4:
-    // 8 global_store_dwordx4 per wave instead of 32 global_store_dword.  An accumulator register holds ONE channel (i) of 16
-    // pixels, channels-last memory wants 32 channels of one pixel together.  Scratch = the weight buffer the matrix cores have
-    // just finished with (every wave is past the barrier behind that compute); a wave uses exactly the eight 1-KiB chunks
-    // n*4 + wave that its own LDS-direct loads refill in the next step, so no barrier is needed -- program order within the wave is enough.
-    // The stores drain while the next tile is being computed.  Accumulator register r holds tile column (r & 3) + 8 (r >> 2) + 4 h.
-    {
-      float* scr = Wl + (wb ^ 1) * WMAIN + wave * 256;            // chunk n of this wave: scr + n * 1024 floats
-      const bool relu = P.act == 1;
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int pp = p * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;   // pixel of the wave's 64 (two rows of 32)
-          const float v = relu ? fmaxf(acc[p][0][r], 0.f) : acc[p][0][r];
-          scr[(pp >> 3) * 1024 + (pp & 7) * 32 + i] = v;
-        }
-      const int tz = t / P.tiles_plane, tr = t - tz * P.tiles_plane;
-      const int y0 = (tr / P.tiles_x) * TH + wave * 2, x0 = (tr % P.tiles_x) * TW;
-      const bool xfull = x0 + TW <= P.W;
-      const int px = lane >> 3, c4 = lane & 7;                      // this lane's pixel within a chunk's 8, its channel quad
-      v4f vv[8];
-#pragma unroll
-      for (int n = 0; n < 8; ++n) vv[n] = *(const v4f*)(scr + n * 1024 + lane * 4);
-#pragma unroll
-      for (int n = 0; n < 8; ++n) asm volatile("" : "+v"(vv[n]));      // all eight reads in flight before the first store
-#pragma unroll
-      for (int n = 0; n < 8; ++n) {
-        const int y = y0 + (n >> 2), x = x0 + (n & 3) * 8 + px;
-        if (y < P.H && (xfull || x < P.W) && !(P.debug & 1))
-          *(v4f*)(P.out + (((size_t)tz * P.H + y) * P.W + x) * P.c_out + g * 32 * NT + c4 * 4) = vv[n];
-      }
-    }
+    // epilogue (store_tile): scratch = the weight buffer the matrix cores have just finished with (every wave is past the barrier
+    // behind that compute); a wave uses exactly the eight 1-KiB chunks n*4 + wave that its own LDS-direct loads refill in the next
+    // step, so no barrier is needed -- program order within the wave is enough.  The stores drain while the next tile is computed.
+    store_tile<1024>(P, acc_rows(acc), Wl + (wb ^ 1) * WMAIN + wave * 256, g, t, wave, lane);
   }
 }
 
