@@ -224,6 +224,16 @@ int sd_conv3_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, con
                           int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, int c_out, int act,
                           float* d_out, void* stream);
 
+/* The same layer with every f32 product evaluated as six bf16 x bf16 products (operands split into three bf16 terms each, f32
+ * accumulation) on the bf16 matrix cores: f32-level accuracy (the dropped cross terms are below 2^-24 of a product) at 6/16 of the
+ * f32-MFMA time.  Same arguments; c0, c1 multiples of 32 only (the one-channel first layer stays on sd_conv3_ndhwc_device); the
+ * weights are packed by sd_conv3_bf16x6_pack_weights_host.  Opt-in: the exact-f32 kernel above is the default network path. */
+long long sd_conv3_bf16x6_packed_floats(int c_in, int c_out, int kz);
+int sd_conv3_bf16x6_pack_weights_host(const float* w /* [c_out][c_in][kz][3][3] */, int c_in, int c_out, int kz, float* packed);
+int sd_conv3_bf16x6_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1,
+                                 int up1, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, int c_out,
+                                 int act, float* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

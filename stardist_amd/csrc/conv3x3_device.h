@@ -113,7 +113,7 @@ __device__ __forceinline__ void halo_fetch(const Params& P, const unsigned (&gof
 // pixel together.  `scr` = this wave's eight 1-KiB scratch chunks, chunk n at scr + n * chunk_stride floats; the caller guarantees
 // that no other wave touches them (see the kernels).
 template <int chunk_stride>
-__device__ __forceinline__ void store_tile(const Params& P, const f32x16 (&acc)[2], float* scr, int g, int t, int wave, int lane) {
+__device__ __forceinline__ void tile_to_scratch(const Params& P, const f32x16 (&acc)[2], float* scr, int lane) {
   const int i = lane & 31, h = lane >> 5;
   const bool relu = P.act == 1;
 #pragma unroll
@@ -124,6 +124,9 @@ __device__ __forceinline__ void store_tile(const Params& P, const f32x16 (&acc)[
       const float v = relu ? fmaxf(acc[p][r], 0.f) : acc[p][r];
       scr[(pp >> 3) * chunk_stride + (pp & 7) * 32 + i] = v;
     }
+}
+template <int chunk_stride>
+__device__ __forceinline__ void scratch_to_global(const Params& P, const float* scr, int g, int t, int wave, int lane) {
   const int tz = t / P.tiles_plane, tr = t - tz * P.tiles_plane;
   const int y0 = (tr / P.tiles_x) * TH + wave * 2, x0 = (tr % P.tiles_x) * TW;
   const bool xfull = x0 + TW <= P.W;
@@ -139,6 +142,11 @@ __device__ __forceinline__ void store_tile(const Params& P, const f32x16 (&acc)[
     if (y < P.H && (xfull || x < P.W) && !(P.debug & 1))
       *(v4f*)(P.out + (((size_t)tz * P.H + y) * P.W + x) * P.c_out + g * 32 + c4 * 4) = vv[n];
   }
+}
+template <int chunk_stride>
+__device__ __forceinline__ void store_tile(const Params& P, const f32x16 (&acc)[2], float* scr, int g, int t, int wave, int lane) {
+  tile_to_scratch<chunk_stride>(P, acc, scr, lane);
+  scratch_to_global<chunk_stride>(P, scr, g, t, wave, lane);
 }
 
 }  // namespace sdconvdev

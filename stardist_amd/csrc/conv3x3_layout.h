@@ -91,4 +91,56 @@ inline void pack_weights(const float* w, int c_in, int c_out, int kz, float* out
                 }
 }
 
+// ---- split-bf16 variant (conv3x3_bf16.hip) -------------------------------------------------------------------------------------
+// Every f32 operand x is written as hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (round to nearest
+// even; the two remainders are exact in f32), and a product a*b is evaluated as the six bf16 x bf16 products hi*hi + hi*mid + mid*hi +
+// hi*lo + lo*hi + mid*mid (each exact in f32, accumulated in f32 by v_mfma_f32_32x32x16_bf16); the three dropped terms are below
+// 2^-24 of the product.  bf16 MFMA runs at 16x the f32-MFMA rate, so six of them are 2.7x faster than one f32 MFMA.
+//   LDS tile   : 208 bytes per halo pixel = 3 planes (hi, mid, lo) x 32 channels x 2 bytes + 16 bytes of padding (52 dwords:
+//                the 16 lanes of a ds_read_b128 group hit 16 distinct bank quadruples)
+//   k order    : a 32x32x16 MFMA takes 8 values per lane; lane half h of 16-channel block b holds channels b*16 + h*8 + 0..7
+//                for BOTH operands (which k index the hardware gives a slot is irrelevant as long as A and B agree)
+//   sub-unit   : the weights of one (unit, row tap dy) = 3 dx x 2 blocks x 3 planes x 2 h x 32 output channels x 16 bytes = 18 KiB
+constexpr int BPIX = 208;
+constexpr int BTILE_BYTES = HALO_H * HALO_W * BPIX;
+constexpr int BWSUB_BYTES = 3 * 2 * 3 * 2 * 32 * 16;
+// byte offset of the 16 bytes (8 channels) lane half h reads as A operand: halo pixel (ty, tx), plane p, 16-channel block b
+SDC_HD int btile_off(int ty, int tx, int p, int b, int h) { return (ty * HALO_W + tx) * BPIX + p * 64 + b * 32 + h * 16; }
+// byte offset where the 4 channels q4*4 .. q4*4+3 of plane p of halo pixel (ty, tx) are stored (8 bytes)
+SDC_HD int btile_store_off(int ty, int tx, int p, int q4) { return (ty * HALO_W + tx) * BPIX + p * 64 + q4 * 8; }
+// byte offset, inside a sub-unit block, of the 16 bytes lane (i = output channel, h) reads as B operand
+SDC_HD int bw_off(int dx, int b, int p, int h, int i) { return ((((dx * 2 + b) * 3 + p) * 2 + h) * 32 + i) * 16; }
+SDC_HD size_t bpacked_bytes(int c_in, int c_out, int kz) { return (size_t)(c_out / 32) * (c_in / CHUNK) * kz * 3 * BWSUB_BYTES; }
+
+SDC_HD unsigned f2u(float f) { unsigned u; __builtin_memcpy(&u, &f, 4); return u; }
+SDC_HD float u2f(unsigned u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+// bf16(f), round to nearest even, as f32 bits (low 16 bits zero)
+SDC_HD unsigned bf16_bits(float f) { unsigned u = f2u(f); u += 0x7FFFu + ((u >> 16) & 1u); return u & 0xFFFF0000u; }
+SDC_HD void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = bf16_bits(x);
+  const float r = x - u2f(hi);
+  mid = bf16_bits(r);
+  lo = bf16_bits(r - u2f(mid));
+}
+
+// Pack w[c_out][c_in][kz][3][3] (float32) into the three bf16 planes of the device layout: [group][unit][dy][sub-unit block].
+inline void pack_weights_bf16(const float* w, int c_in, int c_out, int kz, unsigned short* out) {
+  const int n_chunks = c_in / CHUNK, groups = c_out / 32, n_units = n_chunks * kz;
+  for (int g = 0; g < groups; ++g)
+    for (int c = 0; c < n_chunks; ++c)
+      for (int z = 0; z < kz; ++z)
+        for (int dy = 0; dy < 3; ++dy)
+          for (int dx = 0; dx < 3; ++dx)
+            for (int b = 0; b < 2; ++b)
+              for (int h = 0; h < 2; ++h)
+                for (int i = 0; i < 32; ++i)
+                  for (int j = 0; j < 8; ++j) {
+                    const int co = g * 32 + i, ci = c * CHUNK + b * 16 + h * 8 + j;
+                    unsigned pl[3];
+                    split3(w[(((size_t)co * c_in + ci) * kz + z) * 9 + dy * 3 + dx], pl[0], pl[1], pl[2]);
+                    const size_t sub = (((size_t)g * n_units + c * kz + z) * 3 + dy) * BWSUB_BYTES;
+                    for (int p = 0; p < 3; ++p) out[(sub + bw_off(dx, b, p, h, i)) / 2 + j] = (unsigned short)(pl[p] >> 16);
+                  }
+}
+
 }  // namespace sdconv

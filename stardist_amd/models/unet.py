@@ -122,26 +122,34 @@ def _conv_cat_bias_act(conv, a, b, kind):
 # concatenation, bias and activation folded in: one kernel instead of interpolate + cat + conv + epilogue, exact float32 with a fixed
 # summation order.  STARDIST_AMD_CONV=miopen switches them off (every layer through MIOpen, as before); the choice is read per call
 # so tests can compare both.
-def hand_conv_enabled():
+def conv_mode():
+    """'hand' (default: exact f32 MFMA kernel), 'bf16x6' (opt-in: six bf16 MFMAs per f32 product, f32-level accuracy), 'miopen'"""
     import os
-    return os.environ.get("STARDIST_AMD_CONV", "hand") != "miopen"
+    m = os.environ.get("STARDIST_AMD_CONV", "hand")
+    return m if m in ("miopen", "bf16x6") else "hand"
 
 
-def _packed_conv_weights(conv):
-    """conv.weight in the device layout of sd_conv3_ndhwc_device, cached per module (inference: invalidated when the weight changes)"""
+def hand_conv_enabled():
+    return conv_mode() != "miopen"
+
+
+def _packed_conv_weights(conv, split=False):
+    """conv.weight in the device layout of sd_conv3_ndhwc_device (split=True: of sd_conv3_bf16x6_ndhwc_device), cached per module
+    (inference: invalidated when the weight changes)"""
     from ..lib import _native as N
     key = (conv.weight.data_ptr(), conv.weight._version, str(conv.weight.device))
-    cache = conv.__dict__.get("_sd_packed")
+    slot, prefix = ("_sd_packed_bf16", "sd_conv3_bf16x6") if split else ("_sd_packed", "sd_conv3")
+    cache = conv.__dict__.get(slot)
     if cache is None or cache[0] != key:
         w = np.ascontiguousarray(conv.weight.detach().float().cpu().numpy())
         co, ci, kz = int(w.shape[0]), int(w.shape[1]), (3 if w.ndim == 5 else 1)
-        n = int(N.lib().sd_conv3_packed_floats(ci, co, kz))
+        n = int(getattr(N.lib(), prefix + "_packed_floats")(ci, co, kz))
         if n < 0:
-            raise ValueError("sd_conv3: unsupported channel counts %d -> %d" % (ci, co))
+            raise ValueError("%s: unsupported channel counts %d -> %d" % (prefix, ci, co))
         packed = np.empty(n, np.float32)
-        N.check(N.lib().sd_conv3_pack_weights_host(N.ptr(w), ci, co, kz, N.ptr(packed)))
+        N.check(getattr(N.lib(), prefix + "_pack_weights_host")(N.ptr(w), ci, co, kz, N.ptr(packed)))
         cache = (key, torch.from_numpy(packed).to(conv.weight.device))
-        conv.__dict__["_sd_packed"] = cache
+        conv.__dict__[slot] = cache
     return cache[1]
 
 
@@ -178,12 +186,13 @@ def _hand_conv(conv, srcs, kind):
     from ..lib import _native as N
     # channels-last operands (a pooling layer may hand over a tensor in the default layout: one copy at its resolution)
     srcs = [(t if t.is_contiguous(memory_format=cl) and t.data_ptr() % 16 == 0 else t.clone(memory_format=cl), up) for t, up in srcs]
-    wp = _packed_conv_weights(conv)
+    split = conv_mode() == "bf16x6" and cs != [1]
+    wp = _packed_conv_weights(conv, split)
     out = torch.empty((1, co) + shape, dtype=torch.float32, device=conv.weight.device, memory_format=cl)
     D, H, W = ((1,) + shape) if nd == 2 else shape
     mask = lambda up: sum(b << k for k, b in enumerate(reversed(up)))                     # bit 0: x, 1: y, 2: z
     a, b = srcs[0][0], (srcs[1][0] if len(srcs) == 2 else None)
-    N.dcall(a, "sd_conv3_ndhwc_device", ctypes.c_void_p(a.data_ptr()), cs[0], cs[0], mask(ups[0]),
+    N.dcall(a, "sd_conv3_bf16x6_ndhwc_device" if split else "sd_conv3_ndhwc_device", ctypes.c_void_p(a.data_ptr()), cs[0], cs[0], mask(ups[0]),
             ctypes.c_void_p(b.data_ptr()) if b is not None else None, cs[1] if b is not None else 0, cs[1] if b is not None else 0,
             mask(ups[1]) if b is not None else 0, D, H, W, 1 if nd == 2 else 3, ctypes.c_void_p(wp.data_ptr()),
             ctypes.c_void_p(conv.bias.data_ptr()) if conv.bias is not None else None, co, kind, ctypes.c_void_p(out.data_ptr()))

@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 #include "../../stardist_amd/csrc/conv3x3_layout.h"
@@ -86,6 +87,82 @@ static void emulate_tile(const SrcH* src, int n_chunks, int kz, int g, int D, in
   }
 }
 
+
+// ---- split-bf16 variant (conv3x3_bf16.hip): halo staging with the three-way split, packed sub-unit weight blocks, per-lane 16-byte
+// operand fetch, v_mfma_f32_32x32x16_bf16 semantics (8 values per lane and operand; slot (h, j) of A meets slot (h, j) of B), the six
+// plane pairs, same accumulator map
+static float bf16_to_f(unsigned short v) { return u2f((unsigned)v << 16); }
+static void emulate_tile_bf16(const SrcH* src, int n_chunks, int kz, int g, int D, int H, int W, const unsigned short* wp, const float* bias, int c_out,
+                              int act, int t, int tiles_x, int tiles_plane, float* out) {
+  const int n_units = n_chunks * kz;
+  std::vector<unsigned char> tileB(BTILE_BYTES);
+  std::vector<float> acc((size_t)4 * 2 * 64 * 16);
+  auto A = [&](int wave, int p, int lane, int r) -> float& { return acc[(((size_t)wave * 2 + p) * 64 + lane) * 16 + r]; };
+  for (int wave = 0; wave < 4; ++wave) for (int p = 0; p < 2; ++p) for (int lane = 0; lane < 64; ++lane)
+    for (int r = 0; r < 16; ++r) A(wave, p, lane, r) = bias ? bias[g * 32 + (lane & 31)] : 0.f;
+  const int tz = t / tiles_plane, tr = t - tz * tiles_plane;
+  const int ty0 = (tr / tiles_x) * TH - 1, tx0 = (tr % tiles_x) * TW - 1;
+  for (int u = 0; u < n_units; ++u) {
+    const int c = u / kz, dz = kz == 3 ? u - c * 3 - 1 : 0;
+    const SrcH& S = src[c];
+    const int z = tz + dz;
+    const int ws = W >> S.shx, hs = H >> S.shy;
+    for (int e = 0; e < TILE_F4; ++e) {
+      int ty, tx, q4; stage_elem(e, ty, tx, q4);
+      const int gy = ty0 + ty, gx = tx0 + tx;
+      for (int k = 0; k < 4; ++k) {
+        float v = 0.f;
+        if (z >= 0 && z < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+          v = S.p[(((size_t)(z >> S.shz) * hs + (gy >> S.shy)) * ws + (gx >> S.shx)) * S.stride + q4 * 4 + k];
+        unsigned pl[3]; split3(v, pl[0], pl[1], pl[2]);
+        for (int p = 0; p < 3; ++p) {
+          const unsigned short b = (unsigned short)(pl[p] >> 16);
+          memcpy(&tileB[btile_store_off(ty, tx, p, q4) + k * 2], &b, 2);
+        }
+      }
+    }
+    for (int dy = 0; dy < 3; ++dy) {
+      const unsigned char* w = (const unsigned char*)wp + (((size_t)g * n_units + u) * 3 + dy) * BWSUB_BYTES;
+      static const int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+      for (int wave = 0; wave < 4; ++wave)
+        for (int gi = 0; gi < 6; ++gi) {
+          const int dx = gi >> 1, b = gi & 1;
+          for (int k = 0; k < 6; ++k)
+            for (int p = 0; p < 2; ++p) {
+              float a[64][8], bb[64][8];
+              for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, h = lane >> 5;
+                unsigned short av[8], bv[8];
+                memcpy(av, &tileB[btile_off(wave * 2 + dy + p, i + dx, PA[k], b, h)], 16);
+                memcpy(bv, w + bw_off(dx, b, PB[k], h, i), 16);
+                for (int j = 0; j < 8; ++j) { a[lane][j] = bf16_to_f(av[j]); bb[lane][j] = bf16_to_f(bv[j]); }
+              }
+              for (int lane = 0; lane < 64; ++lane) {
+                const int n = lane & 31, h = lane >> 5;
+                for (int r = 0; r < 16; ++r) {
+                  const int m = acc_col(r, h);
+                  float v = A(wave, p, lane, r);
+                  for (int hh = 0; hh < 2; ++hh) for (int j = 0; j < 8; ++j) v += a[hh * 32 + m][j] * bb[hh * 32 + n][j];   // exact products, f32 sums
+                  A(wave, p, lane, r) = v;
+                }
+              }
+            }
+        }
+    }
+  }
+  const int x0 = (tr % tiles_x) * TW;
+  for (int wave = 0; wave < 4; ++wave) for (int p = 0; p < 2; ++p) {
+    const int y = (tr / tiles_x) * TH + wave * 2 + p;
+    if (y >= H) continue;
+    for (int lane = 0; lane < 64; ++lane) for (int r = 0; r < 16; ++r) {
+      const int x = x0 + acc_col(r, lane >> 5);
+      float v = A(wave, p, lane, r);
+      if (act == 1) v = fmaxf(v, 0.f);
+      if (x < W) out[(((size_t)tz * H + y) * W + x) * c_out + g * 32 + (lane & 31)] = v;
+    }
+  }
+}
+
 // up masks: bit 0 x, bit 1 y, bit 2 z
 static int run_case(int D, int H, int W, int kz, int c0, int up0, int c1, int up1, int c_out, int act) {
   const int c_in = c0 + c1;
@@ -104,10 +181,14 @@ static int run_case(int D, int H, int W, int kz, int c0, int up0, int c1, int up
   for (int k = 0; k < c1 / 32; ++k) src[nc++] = SrcH{s1.data() + k * 32, c1, sh(up1, 2), sh(up1, 1), sh(up1, 0)};
   const int nt = nt_for(c_out), groups = c_out / (32 * nt);
   const int tiles_x = (W + TW - 1) / TW, tiles_plane = tiles_x * ((H + TH - 1) / TH), n_tiles = tiles_plane * D;
-  std::vector<float> out((size_t)D * H * W * c_out, NAN);
-  for (int g = 0; g < groups; ++g) for (int t = 0; t < n_tiles; ++t)
+  std::vector<float> out((size_t)D * H * W * c_out, NAN), outb((size_t)D * H * W * c_out, NAN);
+  std::vector<unsigned short> wpb(bpacked_bytes(c_in, c_out, kz) / 2);
+  pack_weights_bf16(w.data(), c_in, c_out, kz, wpb.data());
+  for (int g = 0; g < groups; ++g) for (int t = 0; t < n_tiles; ++t) {
     emulate_tile(src, nc, kz, g, D, H, W, wp.data(), bias.data(), c_out, act, t, tiles_x, tiles_plane, out.data());
-  double worst = 0;
+    emulate_tile_bf16(src, nc, kz, g, D, H, W, wpb.data(), bias.data(), c_out, act, t, tiles_x, tiles_plane, outb.data());
+  }
+  double worst = 0, worstb = 0;
   auto in = [&](int z, int y, int x, int ci) -> double {
     if (z < 0 || z >= D || y < 0 || y >= H || x < 0 || x >= W) return 0.0;
     const bool first = ci < c0;
@@ -122,10 +203,12 @@ static int run_case(int D, int H, int W, int kz, int c0, int up0, int c1, int up
     if (act == 1 && s < 0) s = 0;
     const double d = fabs(s - out[(((size_t)z * H + y) * W + x) * c_out + co]);
     if (!(d <= worst)) worst = d;        // catches NaN (unwritten outputs)
+    const double db = fabs(s - outb[(((size_t)z * H + y) * W + x) * c_out + co]);
+    if (!(db <= worstb)) worstb = db;
   }
-  printf("D=%d H=%d W=%d kz=%d  %d(up%d)+%d(up%d) -> %d act=%d  groups=%d units=%d  max|err|=%.3g\n", D, H, W, kz, c0, up0, c1, up1, c_out, act, groups,
-         nc * kz, worst);
-  return worst < 3e-5 ? 0 : 1;
+  printf("D=%d H=%d W=%d kz=%d  %d(up%d)+%d(up%d) -> %d act=%d  groups=%d units=%d  max|err| f32 %.3g  split-bf16 %.3g\n", D, H, W, kz, c0, up0, c1, up1, c_out, act, groups,
+         nc * kz, worst, worstb);
+  return worst < 3e-5 && worstb < 3e-5 ? 0 : 1;
 }
 
 int main() {

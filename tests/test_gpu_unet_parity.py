@@ -21,11 +21,15 @@ def _models(kind):
     raise ValueError(kind)
 
 
-@pytest.mark.parametrize("kind", ["unet2d", "unet3d", "resnet3d", "unet2d-split", "unet3d-split"])
+@pytest.mark.parametrize("kind", ["unet2d", "unet3d", "resnet3d", "unet2d-split", "unet3d-split", "unet2d-bf16x6", "unet3d-bf16x6"])
 def test_gpu_forward_matches_cpu_float32_and_is_deterministic(kind, monkeypatch):
     import torch
     import bench
     from oracle import synth
+    if kind.endswith("-bf16x6"):
+        # the opt-in split-bf16 convolution kernel (six bf16 MFMAs per f32 product): same <= 1e-5 bar against float64
+        monkeypatch.setenv("STARDIST_AMD_CONV", "bf16x6")
+        kind = kind[:-7]
     if kind.endswith("-split"):
         # the two-source form of Concatenate+Conv (used from 2**28 elements on: 2048^2 / 256^3 top level) forced at test size
         import stardist_amd.models.unet as U

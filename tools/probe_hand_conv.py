@@ -25,6 +25,10 @@ def timeit(fn, reps):
     return a.elapsed_time(b) / reps
 
 
+args_split = True
+skip_lib = False
+
+
 def layer(nd, shape, chans, cout, reps, dev):
     cl = torch.channels_last if nd == 2 else torch.channels_last_3d
     cin = sum(c for c, _ in chans)
@@ -34,6 +38,13 @@ def layer(nd, shape, chans, cout, reps, dev):
 
     def hand():
         return U._hand_conv(conv, srcs, 1)
+
+    def split():
+        os.environ["STARDIST_AMD_CONV"] = "bf16x6"
+        try:
+            return U._hand_conv(conv, srcs, 1)
+        finally:
+            os.environ["STARDIST_AMD_CONV"] = "hand"
 
     def lib():
         xs = [F.interpolate(t, scale_factor=2.0, mode="nearest") if any(u) else t for t, u in srcs]
@@ -45,16 +56,17 @@ def layer(nd, shape, chans, cout, reps, dev):
             os.environ["STARDIST_AMD_CONV"] = "hand"
     with torch.no_grad():
         th = timeit(hand, reps)
+        ts = timeit(split, reps) if cin >= 32 and args_split else float("nan")
         try:
-            tl = timeit(lib, reps)
+            tl = float("nan") if skip_lib else timeit(lib, reps)
         except Exception as e:          # e.g. int32 index limit of the library on the biggest 3D layer
             tl = float("nan"); print("   library path failed:", repr(e)[:100])
         err = float("nan")
         if np.prod(shape) * cout < 2 ** 29 and tl == tl:
             err = float((hand() - lib()).abs().max())
-    print("%dD %-16s %-22s -> %3d : hand %8.3f ms %6.1f TF/s | miopen+glue %8.3f ms %6.1f TF/s | x%.2f  maxdiff %.2e"
+    print("%dD %-16s %-22s -> %3d : hand %8.3f ms %6.1f TF/s | miopen+glue %8.3f ms %6.1f TF/s | x%.2f  maxdiff %.2e | bf16x6 %8.3f ms %6.1f TF/s-equivalent"
           % (nd, "x".join(map(str, shape)), "+".join("%d%s" % (c, "^" if u else "") for c, u in chans), cout, th, flops / th / 1e9, tl, flops / tl / 1e9,
-             tl / th, err), flush=True)
+             tl / th, err, ts, flops / ts / 1e9), flush=True)
     return th, tl
 
 
@@ -63,7 +75,10 @@ def main():
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--size3d", type=int, default=256)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--no-lib", action="store_true", help="skip the MIOpen comparison (saves its find-mode warm-up)")
     a = ap.parse_args()
+    global skip_lib
+    skip_lib = a.no_lib
     dev = torch.device("cuda:0")
     tot = [0.0, 0.0]
     if a.size:
