@@ -206,6 +206,32 @@ def run_leg(model, img, steps, warmup, world, dist_):
     return elapsed, net_ms, res, stats
 
 
+def run_split_leg(model, img, steps, warmup, world, dist_):
+    """The same steps with the opt-in split-bf16 convolution kernel (csrc/conv3x3_bf16.hip: six bf16 MFMAs per f32 product, f32-level
+    accuracy -- tests/test_gpu_unet_parity.py holds it to the same 1e-5 bar against float64).  Reported NEXT TO `value`, never as it:
+    `value` is measured with the exact-f32 kernel.  Returns a dict, or an error note (this leg must never take the bench down)."""
+    old = os.environ.get("STARDIST_AMD_CONV")
+    graphs = model.__dict__.pop("_graphs", None)
+    os.environ["STARDIST_AMD_CONV"] = "bf16x6"
+    try:
+        elapsed, net_ms, res, _ = run_leg(model, img, steps, warmup, world, dist_)
+        n = int(np.prod(img.shape))
+        return {"value": round(world * n * steps / elapsed / 1e6, 3), "ms_per_step": round(1e3 * elapsed / steps, 3), "unet_forward_ms": round(net_ms, 3),
+                "instances": len(res[1]["prob"]), "steps": steps,
+                "arithmetic": "f32 operands split into three bf16 terms, six bf16 x bf16 MFMA products per f32 product, f32 accumulation "
+                              "(STARDIST_AMD_CONV=bf16x6); outputs within 2e-6 of a float64 evaluation, like the exact-f32 kernel"}
+    except Exception as e:                       # pragma: no cover
+        return {"value": None, "error": repr(e)[:200]}
+    finally:
+        if old is None:
+            os.environ.pop("STARDIST_AMD_CONV", None)
+        else:
+            os.environ["STARDIST_AMD_CONV"] = old
+        model.__dict__.pop("_graphs", None)
+        if graphs is not None:
+            model._graphs = graphs
+
+
 def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, dist_, rank):
     """BASELINE.json configs 4/5: ONE large input, its blocks dealt round-robin to the ranks, local NMS per block on the device,
     RCCL all_gather of the block survivors, final cross-tile NMS + rasteriser on rank 0 (stardist_amd/big.py, design A of
@@ -260,6 +286,7 @@ def main():
     ap.add_argument("--sharded-size", type=int, default=16384)
     ap.add_argument("--sharded-size3d", type=int, default=1024)
     ap.add_argument("--skip-sharded-3d", action="store_true")
+    ap.add_argument("--no-split-leg", action="store_true", help="skip the extra legs with the opt-in split-bf16 convolution kernel")
     args = ap.parse_args()
 
     import torch
@@ -353,6 +380,11 @@ def main():
                 out["cpu_baseline"] = cpu_baseline_2d(img_np, model, min(args.cpu_sample, H), threads)
             except Exception as e:   # oracle/_ref must have travelled with the tree
                 out["cpu_baseline"] = {"value": None, "unit": "Mpix/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
+    if args.dtype == "float32" and not args.no_split_leg:
+        r = run_split_leg(model, img, max(1, min(args.steps, 10)), 2, world, dist_)
+        if rank == 0:
+            r["unit"] = "Mpix/s"
+            out["split_bf16"] = r
     # ---- config 4: one 16384^2 slide (the 2048^2 synthetic tile repeated), blocks 4096 / overlap 128 / context 128, sharded over the ranks
     if world > 1 or args.sharded:
         rep = max(1, args.sharded_size // H)
@@ -400,6 +432,11 @@ def main():
                     out["cpu_baseline_3d"] = cpu_baseline_3d(vol_np, m3, min(args.cpu_sample3d, S), threads)
                 except Exception as e:
                     out["cpu_baseline_3d"] = {"value": None, "unit": "Mvox/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
+        if args.dtype == "float32" and not args.no_split_leg:
+            r = run_split_leg(m3, vol, steps3, 1, world, dist_)
+            if rank == 0:
+                r["unit"] = "Mvox/s"
+                out["split_bf16_3d"] = r
         # ---- config 5: one 1024^3 volume (the 256^3 synthetic volume repeated), 256^3 blocks / overlap 32 / context 32, sharded
         if (world > 1 or args.sharded) and not args.skip_sharded_3d:
             rep = max(1, args.sharded_size3d // S)
