@@ -314,7 +314,9 @@ def main():
     img_np = synth.s2d_nuclei_image(H, W, seed=rank)
     img = torch.from_numpy(img_np).to(dev)
     model = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0, compute_dtype=args.dtype)
-    calibrate_heads(model, img)
+    # every rank calibrates on the SAME image (seed 0), so that all ranks run identical weights -- the sharded legs deal the blocks of one
+    # input over the ranks and must see one model; the timed tile of a rank is its own (seed = rank)
+    calibrate_heads(model, img if rank == 0 else torch.from_numpy(synth.s2d_nuclei_image(H, W, seed=0)).to(dev))
     macs = conv_macs_per_input_pixel(model.net, model.config)
     elapsed, net_ms, res, st = run_leg(model, img, args.steps, args.warmup, world, dist_)
     # second number (SURVEY.md 8d defines the metric host-array-in): the same steps with the image handed over as a host numpy array,
@@ -404,7 +406,8 @@ def main():
         vol = torch.from_numpy(vol_np).to(dev)
         m3 = StarDist3D(Config3D(rays=96), basedir=None, device=dev, seed=0, compute_dtype=args.dtype)
         m3.thresholds = dict(prob=0.5, nms=0.3)
-        calibrate_heads(m3, vol, frac=0.009, radius=8.5, noise=0.03)   # near-spherical objects
+        calibrate_heads(m3, vol if rank == 0 else torch.from_numpy(synth.s3d_nuclei_image(S, seed=0)).to(dev),
+                        frac=0.009, radius=8.5, noise=0.03)   # near-spherical objects; same image on every rank
         macs3 = conv_macs_per_input_pixel(m3.net, m3.config)
         steps3 = max(1, min(args.steps, 3))
         elapsed3, net3_ms, res3, st3 = run_leg(m3, vol, steps3, 1, world, dist_)
