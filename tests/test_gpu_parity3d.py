@@ -43,6 +43,20 @@ def test_star_dist3d_bit_exact(refmods, n_rays, grid):
     assert np.array_equal(d, ref_d), np.abs(d - ref_d).max()
 
 
+_REF_KEEP = {}
+
+
+def _ref_keep_random(refmods, shape, n_rays, noise, thr):
+    """the compiled reference's survivors on a seeded random candidate set; the single-threaded Qhull run takes up to 35 s, and two
+    tests look at the same sets -- computed once per process"""
+    key = (tuple(shape), n_rays, noise, float(thr))
+    if key not in _REF_KEEP:
+        rays = _rays(n_rays)
+        d, p, s = _random_candidates(shape, n_rays, noise, seed=n_rays)
+        _REF_KEEP[key] = refmods.stardist3d().c_non_max_suppression_inds(d, p, rays.vertices, rays.faces.astype(np.int32), s, 1, 1, 0, np.float32(thr))
+    return _REF_KEEP[key]
+
+
 @pytest.mark.parametrize("mode,overlap", [(0, None), (1, None), (2, None), (3, None), (4, None), (0, 77), (0, -3), (2, 5)])
 def test_polyhedron_to_label_identical(refmods, mode, overlap):
     """all five render modes of stardist3d_impl.cpp:1469-1509: full, kernel, hull (convex), bbox, debug"""
@@ -70,7 +84,7 @@ def test_nms3d_random_survivors(refmods, shape, n_rays, noise, thr):
     rays = _rays(n_rays)
     d, p, s = _random_candidates(shape, n_rays, noise, seed=n_rays)
     V, F = rays.vertices, rays.faces.astype(np.int32)
-    ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(thr))
+    ref_keep = _ref_keep_random(refmods, shape, n_rays, noise, thr)
     keep, stats = sd3.c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(thr), return_stats=True)
     diff = np.flatnonzero(keep != ref_keep)
     assert len(diff) == 0, "survivor mismatch at %s of %d (stats %s)" % (diff[:10], len(d), stats.tolist())
@@ -254,7 +268,7 @@ def test_nms3d_cone_map_does_not_change_survivors(refmods, monkeypatch, n_rays, 
     monkeypatch.setenv("SD_NMS3D_NO_CONEMAP", "1")
     keep_full, st_full = sd3.c_non_max_suppression_inds(*args, return_stats=True)
     monkeypatch.delenv("SD_NMS3D_NO_CONEMAP")
-    ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(thr))
+    ref_keep = _ref_keep_random(refmods, (22, 33, 44), n_rays, noise, thr)
     assert np.array_equal(keep_map.cpu().numpy(), keep_full.cpu().numpy()) and np.array_equal(keep_full.cpu().numpy(), ref_keep)
     assert st_map[3] > 0, "no pair reached the render stage: %s" % st_map.tolist()
     assert np.array_equal(st_map[[0, 1, 2, 3, 6, 7]], st_full[[0, 1, 2, 3, 6, 7]])
