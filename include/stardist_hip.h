@@ -29,10 +29,19 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------ */
-const char* sd_last_error(void);          /* message of the last failed call (thread-unsafe)   */
+const char* sd_last_error(void);          /* message of the calling thread's last failed call  */
 int sd_version(void);                     /* ABI version, currently 1                          */
 int sd_device_count(void);                /* number of visible HIP devices (0 without a GPU)   */
 int sd_release_workspace(void);           /* free the cached device workspace                  */
+/* Switches between EQUIVALENT formulations (same results; the parity suite runs both settings against the reference):
+ *   "nms3d_volume_bounds" 1|0  decide 3D pairs from rigorous volume bounds where possible / always compute the exact volume
+ *   "nms3d_cone_map"      1|0  stage-5 voxel tests through the cone map / over every face as the reference does
+ *   "nms3d_refine_mesh"   1|0  refined direction mesh for the volume bounds
+ *   "probe_tier"          1|2  capacity tier sd_clip_pairs_device runs first;  "probe_no_general" 1: do not fall back to the general path
+ *   "trace"               1    print per-round counters to stdout
+ * Nothing in the library reads the process environment.  sd_get_option returns -1 for an unknown name. */
+int sd_set_option(const char* name, int value);
+int sd_get_option(const char* name);
 
 /* ---- 2D non-maximum suppression ------------------------------------------------------------
  * replaces stardist.lib.stardist2d.c_non_max_suppression_inds
@@ -223,6 +232,11 @@ int sd_conv3_pack_weights_host(const float* w /* [c_out][c_in][kz][3][3] */, int
 int sd_conv3_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1, int up1,
                           int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, int c_out, int act,
                           float* d_out, void* stream);
+/* ... with a residual: out = act(conv + bias + res), res channels-last [D][H][W][res_stride] -- Add([shortcut, x]) + Activation that
+ * closes a csbdeep resnet_block (stardist/models/model3d.py:417-422), folded into the convolution's epilogue.  d_res == NULL: none. */
+int sd_conv3_res_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1, int up1,
+                              int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, const float* d_res,
+                              int res_stride, int c_out, int act, float* d_out, void* stream);
 
 /* The same layer with every f32 product evaluated as six bf16 x bf16 products (operands split into three bf16 terms each, f32
  * accumulation) on the bf16 matrix cores: f32-level accuracy (the dropped cross terms are below 2^-24 of a product) at 6/16 of the
@@ -233,6 +247,25 @@ int sd_conv3_bf16x6_pack_weights_host(const float* w /* [c_out][c_in][kz][3][3] 
 int sd_conv3_bf16x6_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1,
                                  int up1, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, int c_out,
                                  int act, float* d_out, void* stream);
+int sd_conv3_bf16x6_res_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1,
+                                     int up1, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias,
+                                     const float* d_res, int res_stride, int c_out, int act, float* d_out, void* stream);
+
+/* ---- general convolution (any kernel size, stride, padding, channel counts) ------------------------------------------------
+ * Every other convolution of the reference's networks, channels-last float32, exact f32 on the matrix cores with one fixed fma chain
+ * per output (bias first, residual last): the 7x7x7 stem, the strided first convolution and the strided 1x1x1 shortcut projection of
+ * csbdeep's resnet_block (stardist/models/model3d.py:400-447), first layers with n_channel_in = 3 (model2d.py:310-316), 1x1 heads
+ * with few channels (prob_class, model2d.py:345-347).
+ *     out[zo][yo][xo][co] = act(bias[co] + sum in[zo*sz - pz + dz][yo*sy - py + dy][xo*sx - px + dx][ci] * w[co][ci][dz][dy][dx] (+ res))
+ * with zeros outside the input; (pz, py, px) = padding BEFORE the first element (TensorFlow 'same' with a stride pads asymmetrically,
+ * so the caller states it); (Do, Ho, Wo) = output extent.  2D: kz = sz = 1, pz = 0, D = Do = 1.  c_in a multiple of 32, or
+ * taps * c_in <= 6144 (small-channel form); any c_out.  src_stride / res_stride / out_stride = floats per pixel of those tensors.
+ * d_wpacked: written by sd_convg_pack_weights_host (sd_convg_packed_floats floats; -1 = unsupported shape). */
+long long sd_convg_packed_floats(int c_in, int c_out, int kz, int ky, int kx);
+int sd_convg_pack_weights_host(const float* w /* [c_out][c_in][kz][ky][kx] */, int c_in, int c_out, int kz, int ky, int kx, float* packed);
+int sd_convg_ndhwc_device(const float* d_src, int c_in, int src_stride, int D, int H, int W, int kz, int ky, int kx, int sz, int sy,
+                          int sx, int pz, int py, int px, int Do, int Ho, int Wo, const float* d_wpacked, const float* d_bias,
+                          const float* d_res, int res_stride, int c_out, int act, float* d_out, int out_stride, void* stream);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # every float expression restated from them must round after each operation.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wno-unused-result", "-I" + os.path.join(HERE, "..", "include")]
+# probe builds only (tools/time_nms2d_bench.py and friends): SD_BUILD_DEBUG_SWITCHES=1 compiles the A/B tuning knobs in, which are then
+# read from the environment (SD_NMS_PAIR_SORT, SD_NMS_PAIR_KEY, SD_NMS_TAIL_DIV, SD_NMS_TAIL_MAX, SD_NMS_DEFER); release builds ignore them
+if os.environ.get("SD_BUILD_DEBUG_SWITCHES") == "1":
+    FLAGS.append("-DSD_DEBUG_SWITCHES")
 
 
 def _sources():

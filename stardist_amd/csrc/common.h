@@ -47,4 +47,17 @@ Arena& arena();
 
 static inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Result-preserving switches between equivalent formulations (set through sd_set_option of the C ABI, documented there): the parity
+// suite runs both settings against the reference.  Nothing in a release build reads the process environment.
+enum Option { OPT_NMS3D_VOLUME_BOUNDS, OPT_NMS3D_CONE_MAP, OPT_NMS3D_REFINE_MESH, OPT_PROBE_TIER, OPT_PROBE_NO_GENERAL, OPT_TRACE, OPT_COUNT };
+int option(Option o);
+
+// A/B tuning knobs of the probe scripts (pair order, tail-batch thresholds, ...): environment variables in builds made with
+// -DSD_DEBUG_SWITCHES (tools/build_debug.sh) only; a release build compiles the defaults in.
+#ifdef SD_DEBUG_SWITCHES
+int tuning_env(const char* name, int dflt);
+#else
+static inline int tuning_env(const char*, int dflt) { return dflt; }
+#endif
+
 }  // namespace sd

@@ -12,8 +12,6 @@
 //     tiling, launch geometry or run.
 //   * k_conv3_c1: the first layer (1 input channel, K = 9 or 27): HBM-write bound, plain FMAs.
 // Bound: MFMA (f32: 64 FLOP/clk/SIMD); algorithmic bytes 4*(C_in + C_out) per pixel.
-#include <stdlib.h>
-
 #include "common.h"
 #include "conv3x3_device.h"
 #include "stardist_hip.h"
@@ -310,15 +308,19 @@ extern "C" int sd_conv3_pack_weights_host(const float* w, int c_in, int c_out, i
   return 0;
 }
 
-extern "C" int sd_conv3_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1, int up1,
-                                     int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, int c_out, int act,
-                                     float* d_out, void* stream_) {
+extern "C" int sd_conv3_res_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1, int up1,
+                                         int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, const float* d_res,
+                                         int res_stride, int c_out, int act, float* d_out, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   if (D <= 0 || H <= 0 || W <= 0) return 0;
   const int c_in = c0 + (d_src1 ? c1 : 0);
   if (!d_src0 || !d_wpacked || !d_out || (act != 0 && act != 1) || sd_conv3_packed_floats(c_in, c_out, kz) < 0 || (kz == 1 && D != 1) ||
       (((uintptr_t)d_src0 | (uintptr_t)d_src1 | (uintptr_t)d_wpacked | (uintptr_t)d_out | (uintptr_t)d_bias) & 15)) {
     sd::set_error("sd_conv3_ndhwc: unsupported channel counts (%d + %d -> %d), kz, act or misaligned pointers", c0, d_src1 ? c1 : 0, c_out);
+    return -1;
+  }
+  if (d_res && (c_in == 1 || res_stride < c_out || (res_stride & 3) || ((uintptr_t)d_res & 15))) {
+    sd::set_error("sd_conv3_ndhwc: the residual needs a 32-channel-chunk layer, 16-byte alignment and a stride >= c_out");
     return -1;
   }
   if (c_in == 1) {
@@ -365,7 +367,7 @@ extern "C" int sd_conv3_ndhwc_device(const float* d_src0, int c0, int stride0, i
   if (d_src1) for (int k = 0; k < c1 / 32; ++k) { P.chunk_kind[nc] = 1; P.chunk_choff[nc++] = k * 32; }
   P.D = D; P.H = H; P.W = W; P.kz = kz; P.n_units = nc * kz;
   P.zero = d_wpacked + sdconv::packed_floats(c_in, c_out, kz);
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SD_CONV_DEBUG"); dbg = e ? atoi(e) : 0; } P.debug = dbg; }
+  P.res = d_res; P.res_stride = res_stride;
   P.wp = d_wpacked; P.bias = d_bias; P.out = d_out; P.c_out = c_out; P.act = act;
   P.tiles_x = (W + TW - 1) / TW;
   P.tiles_plane = P.tiles_x * ((H + TH - 1) / TH);
@@ -376,4 +378,11 @@ extern "C" int sd_conv3_ndhwc_device(const float* d_src0, int c0, int stride0, i
   P.groups = c_out / (32 * nt);
   (void)nt;
   return launch_conv<1>(P, s);
+}
+
+extern "C" int sd_conv3_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1, int up1,
+                                     int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, int c_out, int act,
+                                     float* d_out, void* stream_) {
+  return sd_conv3_res_ndhwc_device(d_src0, c0, stride0, up0, d_src1, c1, stride1, up1, D, H, W, kz, d_wpacked, d_bias, nullptr, 0, c_out, act,
+                                   d_out, stream_);
 }

@@ -201,9 +201,9 @@ extern "C" int sd_conv3_bf16x6_pack_weights_host(const float* w, int c_in, int c
   return 0;
 }
 
-extern "C" int sd_conv3_bf16x6_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1, int up1,
-                                            int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, int c_out, int act,
-                                            float* d_out, void* stream_) {
+extern "C" int sd_conv3_bf16x6_res_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1,
+                                                int up1, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias,
+                                                const float* d_res, int res_stride, int c_out, int act, float* d_out, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   if (D <= 0 || H <= 0 || W <= 0) return 0;
   const int c_in = c0 + (d_src1 ? c1 : 0);
@@ -232,7 +232,11 @@ extern "C" int sd_conv3_bf16x6_ndhwc_device(const float* d_src0, int c0, int str
   if (d_src1) for (int k = 0; k < c1 / 32; ++k) { P.chunk_kind[nc] = 1; P.chunk_choff[nc++] = k * 32; }
   P.D = D; P.H = H; P.W = W; P.kz = kz; P.n_units = nc * kz;
   P.zero = d_wpacked + (n_packed - 4);
-  P.debug = 0;
+  if (d_res && (res_stride < c_out || (res_stride & 3) || ((uintptr_t)d_res & 15))) {
+    sd::set_error("sd_conv3_bf16x6: the residual needs 16-byte alignment and a stride >= c_out");
+    return -1;
+  }
+  P.res = d_res; P.res_stride = res_stride;
   P.wp = d_wpacked; P.bias = d_bias; P.out = d_out; P.c_out = c_out; P.act = act;
   P.tiles_x = (W + TW - 1) / TW;
   P.tiles_plane = P.tiles_x * ((H + TH - 1) / TH);
@@ -262,4 +266,11 @@ extern "C" int sd_conv3_bf16x6_ndhwc_device(const float* d_src0, int c0, int str
   hipLaunchKernelGGL(k_conv3_bf16, dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
   SD_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int sd_conv3_bf16x6_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1, int up1,
+                                            int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, int c_out, int act,
+                                            float* d_out, void* stream_) {
+  return sd_conv3_bf16x6_res_ndhwc_device(d_src0, c0, stride0, up0, d_src1, c1, stride1, up1, D, H, W, kz, d_wpacked, d_bias, nullptr, 0,
+                                          c_out, act, d_out, stream_);
 }

@@ -30,7 +30,8 @@ struct Params {
   const float* bias;
   float* out;          // [D][H][W][c_out]
   int c_out, act;
-  int debug;           // SD_CONV_DEBUG (timing experiments only): 1 = skip the output stores, 2 = read every halo element from the zero block
+  const float* res;    // optional residual [D][H][W][res_stride]: out = act(conv + bias + res) -- the Add + Activation that closes a
+  int res_stride;      // csbdeep resnet_block, folded into the epilogue (nullptr: none)
   int tiles_x, tiles_plane, n_tiles, groups;
 };
 
@@ -80,10 +81,7 @@ __device__ __forceinline__ void halo_fetch(const Params& P, const unsigned (&gof
   const float* plane = sp + (size_t)(min(max(z, 0), P.D - 1) >> S.shz) * hs * ws * S.stride;
   typedef const __attribute__((address_space(1))) char* gptr;      // explicitly global: the asm fence below hides the provenance
   gptr addr[PRE_F4];
-  if (P.debug & 2) {
-#pragma unroll
-    for (int n = 0; n < PRE_F4; ++n) addr[n] = (gptr)P.zero;
-  } else if (zin && ty0 >= 0 && ty0 + HALO_H <= P.H && tx0 >= 0 && tx0 + HALO_W <= P.W) {
+  if (zin && ty0 >= 0 && ty0 + HALO_H <= P.H && tx0 >= 0 && tx0 + HALO_W <= P.W) {
     const int by = src_base(ty0, S.shy), bx = src_base(tx0, S.shx);
     gptr base = (gptr)(plane + ((size_t)by * ws + bx) * S.stride);
 #pragma unroll
@@ -115,7 +113,7 @@ __device__ __forceinline__ void halo_fetch(const Params& P, const unsigned (&gof
 template <int chunk_stride>
 __device__ __forceinline__ void tile_to_scratch(const Params& P, const f32x16 (&acc)[2], float* scr, int lane) {
   const int i = lane & 31, h = lane >> 5;
-  const bool relu = P.act == 1;
+  const bool relu = P.act == 1 && !P.res;           // with a residual the activation follows the addition (scratch_to_global)
 #pragma unroll
   for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -139,8 +137,15 @@ __device__ __forceinline__ void scratch_to_global(const Params& P, const float* 
 #pragma unroll
   for (int n = 0; n < 8; ++n) {
     const int y = y0 + (n >> 2), x = x0 + (n & 3) * 8 + px;
-    if (y < P.H && (xfull || x < P.W) && !(P.debug & 1))
-      *(v4f*)(P.out + (((size_t)tz * P.H + y) * P.W + x) * P.c_out + g * 32 + c4 * 4) = vv[n];
+    if (y < P.H && (xfull || x < P.W)) {
+      const size_t pix = ((size_t)tz * P.H + y) * P.W + x;
+      v4f o = vv[n];
+      if (P.res) {
+        o += *(const v4f*)(P.res + pix * P.res_stride + g * 32 + c4 * 4);
+        if (P.act == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      }
+      *(v4f*)(P.out + pix * P.c_out + g * 32 + c4 * 4) = o;
+    }
   }
 }
 template <int chunk_stride>

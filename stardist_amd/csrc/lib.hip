@@ -2,10 +2,12 @@
 #include "common.h"
 #include "../../include/stardist_hip.h"
 #include <stdarg.h>
+#include <stdlib.h>
 
 namespace sd {
 
-static char g_err[1024] = "";
+// per thread: two threads driving two devices do not overwrite each other's message
+static thread_local char g_err[1024] = "";
 char* err_buf() { return g_err; }
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -13,6 +15,13 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+static int g_opt[OPT_COUNT] = {1, 1, 1, 1, 0, 0};
+static const char* const g_opt_name[OPT_COUNT] = {"nms3d_volume_bounds", "nms3d_cone_map", "nms3d_refine_mesh", "probe_tier", "probe_no_general", "trace"};
+int option(Option o) { return g_opt[o]; }
+#ifdef SD_DEBUG_SWITCHES
+int tuning_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#endif
 
 // one workspace arena per HIP device: a call carves its slices from the arena of the device that is current when it runs
 // (the Python wrappers make the tensors' device current, stardist_amd/lib/_native.py dcall)
@@ -62,6 +71,17 @@ void Arena::release() {
 }  // namespace sd
 
 extern "C" {
+int sd_set_option(const char* name, int value) {
+  for (int k = 0; name && k < sd::OPT_COUNT; ++k)
+    if (!strcmp(name, sd::g_opt_name[k])) { sd::g_opt[k] = value; return 0; }
+  sd::set_error("sd_set_option: unknown option '%s'", name ? name : "(null)");
+  return -1;
+}
+int sd_get_option(const char* name) {
+  for (int k = 0; name && k < sd::OPT_COUNT; ++k)
+    if (!strcmp(name, sd::g_opt_name[k])) return sd::g_opt[k];
+  return -1;
+}
 const char* sd_last_error(void) { return sd::err_buf(); }
 int sd_version(void) { return 1; }
 int sd_device_count(void) {

@@ -783,7 +783,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   int* Sl = A.take_n<int>(N);
   Counters* d_cnt = (Counters*)A.take(sizeof(Counters));
   // pair order (see k_pair_bucket_*): SD_NMS_PAIR_SORT=0 keeps emission order
-  static const bool pairSort = !(getenv("SD_NMS_PAIR_SORT") && atoi(getenv("SD_NMS_PAIR_SORT")) == 0);
+  static const bool pairSort = sd::tuning_env("SD_NMS_PAIR_SORT", 1) != 0;
   unsigned int* pairOrder = pairSort && R <= 32 ? A.take_n<unsigned int>(qCap) : nullptr;
   unsigned int* bucketHist = A.take_n<unsigned int>(2 * PAIR_BUCKETS);
   unsigned long long* nOrdered = A.take_n<unsigned long long>(1);
@@ -797,12 +797,12 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   if (stats) { SD_CHECK(hipEventCreate(&ev2)); SD_CHECK(hipEventCreate(&ev3)); }
   EvGuard evguard2{ev2, ev3};
   // tail batch threshold: undecided candidates at or below which the remaining rounds are replayed on the device
-  static const int tailDiv = getenv("SD_NMS_TAIL_DIV") ? atoi(getenv("SD_NMS_TAIL_DIV")) : 6;
-  static const int tailMax = getenv("SD_NMS_TAIL_MAX") ? atoi(getenv("SD_NMS_TAIL_MAX")) : 65536;
+  static const int tailDiv = sd::tuning_env("SD_NMS_TAIL_DIV", 6);
+  static const int tailMax = sd::tuning_env("SD_NMS_TAIL_MAX", 65536);
   const int tailT = tailDiv > 0 ? ((N / tailDiv) < tailMax ? (N / tailDiv) : tailMax) : -1;
   unsigned char* supp = nullptr; unsigned int* segStart = nullptr; int* segCnt = nullptr;
   // deferral of the general path to the tail batch (only with a tail batch to run it in)
-  static const bool deferEnv = !(getenv("SD_NMS_DEFER") && atoi(getenv("SD_NMS_DEFER")) == 0);
+  static const bool deferEnv = sd::tuning_env("SD_NMS_DEFER", 1) != 0;
   const bool deferOn = tailT >= 0 && deferEnv;
   Deferred dfr{nullptr, nullptr, nullptr, nullptr, nullptr, qCap};
   unsigned int* firstNew = A.take_n<unsigned int>(1);
@@ -832,7 +832,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
       if (pairOrder) {
         // measured on the 2048^2 bench set (pair kernels incl. the bucketing, ms): emission order 9.9 | 32x32 7.85 | 64x16 7.38 | 64x64 6.70 |
         // 16 local-minima classes x 16x16 8.53: resolution of the offset is what counts (64x64 = whole pixels at radius 10)
-        static const int keyMode = getenv("SD_NMS_PAIR_KEY") ? atoi(getenv("SD_NMS_PAIR_KEY")) : 2;
+        static const int keyMode = sd::tuning_env("SD_NMS_PAIR_KEY", 2);
         static const int modes[6][3] = {{1, 32, 32}, {1, 64, 16}, {1, 64, 64}, {16, 16, 16}, {16, 32, 8}, {4, 32, 32}};
         const int* md = modes[keyMode >= 0 && keyMode < 6 ? keyMode : 2];
         const PairKey key{(const char*)prep, prepStride, 1.f / (4.f * (max_dist + 1.f)), md[0], md[1], md[2]};   // offsets lie in (-2 max_dist, 2 max_dist)
@@ -871,7 +871,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
       SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); SD_CHECK(hipEventElapsedTime(&ms2, ev2, ev3));
       if (h.nPairs) { ns_pairs += ms * 1e6; ++n_pair_launches; }
       ns_full += ms2 * 1e6;
-      if (getenv("SD_TRACE")) printf("%s %d: nU=%d nK=%d pairs=%llu spill=%u exact=%u pair_kernel=%.3f ms general_path=%.3f ms\n", what, rounds, h.nU, h.nK, h.nPairs, h.nSpill, h.nExact, ms, ms2);
+      if (sd::option(sd::OPT_TRACE)) printf("%s %d: nU=%d nK=%d pairs=%llu spill=%u exact=%u pair_kernel=%.3f ms general_path=%.3f ms\n", what, rounds, h.nU, h.nK, h.nPairs, h.nSpill, h.nExact, ms, ms2);
     }
     return 0;
   };
@@ -891,7 +891,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
       SD_LAUNCH_CHECK();
       if (run_pairs(supp)) return -1;
       hipEvent_t evr0 = nullptr, evr1 = nullptr;
-      const bool tr = stats && getenv("SD_TRACE");
+      const bool tr = stats && sd::option(sd::OPT_TRACE);
       if (tr) { SD_CHECK(hipEventCreate(&evr0)); SD_CHECK(hipEventCreate(&evr1)); SD_CHECK(hipEventRecord(evr0, s)); }
       for (int it = 0; it < 10; ++it)
         hipLaunchKernelGGL(k_tail_step, dim3(sd::div_up(nU, 256)), dim3(256), 0, s, Ucur, nU, state, pairs, supp, segStart, segCnt, pairCap, dfr.head, dfr.next);

@@ -117,7 +117,7 @@ int launch_probe(const int* xa, const int* ya, const int* xb, const int* yb, int
   if (lds2 > lds) lds = lds2;
   lds += 64;
   hipLaunchKernelGGL((k_probe<MAXV, K, BIL, BREC, S, MAXIL, MAXREC, MAXPT, MAXJ>), dim3((n + S - 1) / S), dim3(S), lds, s, xa, ya, xb, yb, n, R, prepbuf, out, flags,
-                     getenv("SD_PROBE_NOFULL") ? 1 : 0);
+                     sd::option(sd::OPT_PROBE_NO_GENERAL) ? 1 : 0);
   SD_LAUNCH_CHECK();
   return 0;
 }
@@ -181,7 +181,7 @@ extern "C" int sd_clip_pairs_device(const int32_t* d_xa, const int32_t* d_ya, co
   const int R = n_verts;
   if (R < 1 || R > 256) { sd::set_error("sd_clip_pairs: n_verts=%d unsupported (1..256)", R); return -1; }
   i64* out = (i64*)d_out_twice_area;
-  static const int tier = getenv("SD_PROBE_TIER") ? atoi(getenv("SD_PROBE_TIER")) : 1;   // 1: K = 8 capacities (as the NMS's first tier), 2: K = 15
+  const int tier = sd::option(sd::OPT_PROBE_TIER);   // 1: K = 8 capacities (as the NMS's first tier), 2: K = 15
   if (R <= 32 && tier == 1) return launch_probe<32, 8, 6, 4, 64, 64, 32, 192, 64>(d_xa, d_ya, d_xb, d_yb, n_pairs, R, out, d_out_flags, s);
   if (R <= 32) return launch_probe<32, 15, 16, 8, 32, 64, 32, 192, 64>(d_xa, d_ya, d_xb, d_yb, n_pairs, R, out, d_out_flags, s);
   if (R <= 64) return launch_probe<64, 15, 16, 8, 32, 96, 48, 384, 96>(d_xa, d_ya, d_xb, d_yb, n_pairs, R, out, d_out_flags, s);

@@ -1577,7 +1577,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   if (stats) { SD_CHECK(hipEventCreate(&ev0)); SD_CHECK(hipEventCreate(&ev1)); }
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evguard{ev0, ev1};
   double ns3 = 0, ns4 = 0, ns5 = 0;
-  const bool trace = getenv("SD_TRACE") != nullptr;
+  const bool trace = sd::option(sd::OPT_TRACE) != 0;
   if (!use_kdtree && !use_bbox && threshold < 0) {   // every (0, j) passes and iou >= 0 > thr at stage 2
     SD_CHECK(hipMemsetAsync(d_keep, 0, N, s));
     SD_CHECK(hipMemsetAsync(d_keep, 1, 1, s));
@@ -1685,7 +1685,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   SD_CHECK(hipMemcpyAsync(&h_mesh_sa, d_mesh_sa, sizeof(double), hipMemcpyDeviceToHost, s));
   SD_CHECK(hipStreamSynchronize(s));
   const bool mesh_ok = h_mesh[0] == 0 && fabs(h_mesh_sa - 4.0 * M_PI) < 1e-6;
-  const bool use_bounds = mesh_ok && getenv("SD_NMS3D_NO_LB") == nullptr;
+  const bool use_bounds = mesh_ok && sd::option(sd::OPT_NMS3D_VOLUME_BOUNDS) != 0;
   if (trace) printf("ray mesh: open/degenerate flags %d, orientation +%d/-%d, solid angle %.9f -> volume bounds %s\n", h_mesh[0], h_mesh[1], h_mesh[2],
                     h_mesh_sa, use_bounds ? "on" : "off");
   // direction mesh of the volume bounds: refined once (k_refine_mesh) when its ray-cast workspace fits the LDS the stages have anyway
@@ -1693,7 +1693,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   {
     const int R2 = R + 3 * F / 2, F2 = 4 * F;
     const size_t need = (size_t)3 * R2 * sizeof(double) + (size_t)2 * R2;
-    if (use_bounds && F % 2 == 0 && need <= hivBytes && need <= ws3 && R2 < 65535 && !(getenv("SD_NMS3D_NO_REFINE") && atoi(getenv("SD_NMS3D_NO_REFINE")))) {
+    if (use_bounds && F % 2 == 0 && need <= hivBytes && need <= ws3 && R2 < 65535 && sd::option(sd::OPT_NMS3D_REFINE_MESH) != 0) {
       float* v2 = A.take_n<float>((size_t)3 * R2);
       int* f2 = A.take_n<int>((size_t)3 * F2);
       int* edgeId = A.take_n<int>((size_t)3 * F);
@@ -1714,7 +1714,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
 
   // cone map for the voxel tests of stage 5 (geom3d.h); SD_NMS3D_NO_CONEMAP=1 tests every face as the reference does
   sd3::ConeMap cmap{nullptr, nullptr};
-  if (F <= 65535 && !(getenv("SD_NMS3D_NO_CONEMAP") && atoi(getenv("SD_NMS3D_NO_CONEMAP")))) {
+  if (F <= 65535 && sd::option(sd::OPT_NMS3D_CONE_MAP) != 0) {
     unsigned short* cmList = A.take_n<unsigned short>((size_t)SD_CM_CELLS * SD_CM_CAP);
     signed char* cmCount = A.take_n<signed char>(SD_CM_CELLS);
     if (!cmList || !cmCount) return -1;

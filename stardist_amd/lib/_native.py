@@ -30,6 +30,8 @@ SIGNATURES = {
     "sd_version": (_i, []),
     "sd_device_count": (_i, []),
     "sd_release_workspace": (_i, []),
+    "sd_set_option": (_i, [ctypes.c_char_p, _i]),
+    "sd_get_option": (_i, [ctypes.c_char_p]),
     "sd_nms2d_host": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "sd_nms2d_device": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "sd_clip_pairs_device": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
@@ -54,6 +56,11 @@ SIGNATURES = {
     "sd_conv3_packed_floats": (ctypes.c_longlong, [_i, _i, _i]),
     "sd_conv3_pack_weights_host": (_i, [_vp, _i, _i, _i, _vp]),
     "sd_conv3_ndhwc_device": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "sd_conv3_res_ndhwc_device": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "sd_conv3_bf16x6_res_ndhwc_device": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "sd_convg_packed_floats": (ctypes.c_longlong, [_i, _i, _i, _i, _i]),
+    "sd_convg_pack_weights_host": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "sd_convg_ndhwc_device": (_i, [_vp] + [_i] * 17 + [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "sd_conv3_bf16x6_packed_floats": (ctypes.c_longlong, [_i, _i, _i]),
     "sd_conv3_bf16x6_pack_weights_host": (_i, [_vp, _i, _i, _i, _vp]),
     "sd_conv3_bf16x6_ndhwc_device": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
@@ -89,6 +96,22 @@ def lib():
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+class option(object):
+    """context manager: `with option("nms3d_volume_bounds", 0): ...` (sd_set_option; restored on exit)"""
+
+    def __init__(self, name, value):
+        self.name, self.value = name.encode(), int(value)
+
+    def __enter__(self):
+        self.old = lib().sd_get_option(self.name)
+        check(lib().sd_set_option(self.name, self.value))
+        return self
+
+    def __exit__(self, *exc):
+        lib().sd_set_option(self.name, self.old)
+        return False
 
 
 def require_device():

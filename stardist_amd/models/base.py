@@ -108,16 +108,15 @@ class StarDistBase(object):
         from .unet import init_he_normal_
         init_he_normal_(self.net, seed)
         if self.logdir is not None:
-            # model folder weights: the .npz written by tools/keras_to_npz.py / save_weights_npz, else the Keras .h5 (needs h5py)
-            for wname in ("weights.npz", "weights_best.npz", "weights_last.npz"):
-                if os.path.exists(os.path.join(self.logdir, wname)):
-                    self.load_weights_npz(os.path.join(self.logdir, wname))
+            # model folder weights, 'best' before 'last' before 'now' as csbdeep's _find_and_load_weights(prefer='best'); per name the
+            # converted .npz (tools/keras_to_npz.py / save_weights_npz) before the Keras .h5 (needs h5py)
+            for stem in ("weights_best", "weights_last", "weights_now", "weights"):
+                if os.path.exists(os.path.join(self.logdir, stem + ".npz")):
+                    self.load_weights_npz(os.path.join(self.logdir, stem + ".npz"))
                     break
-            else:
-                for wname in ("weights_best.h5", "weights_last.h5", "weights_now.h5"):
-                    if os.path.exists(os.path.join(self.logdir, wname)):
-                        self.load_weights_h5(os.path.join(self.logdir, wname))
-                        break
+                if os.path.exists(os.path.join(self.logdir, stem + ".h5")):
+                    self.load_weights_h5(os.path.join(self.logdir, stem + ".h5"))
+                    break
         self.net = self.net.to(self.device).eval()
         if self.device.type == "cuda":
             # let MIOpen time its solvers per conv shape once (find mode) instead of the immediate-mode heuristic:
@@ -149,22 +148,25 @@ class StarDistBase(object):
         if name_or_alias is None:
             pretrained.print_registered(cls.__name__)
             return None
+        try:
+            pretrained.resolve(cls.__name__, name_or_alias)
+        except ValueError:
+            # csbdeep BaseModel.from_pretrained: an unknown name is reported on stderr, the registry is printed, None is returned
+            import sys as _sys
+            print("Could not find model with name or alias '%s'" % (name_or_alias,), file=_sys.stderr)
+            _sys.stderr.flush()
+            pretrained.print_registered(cls.__name__)
+            return None
         folder = pretrained.get_model_folder(cls.__name__, name_or_alias)
         print("Found model '%s' for '%s'." % (os.path.basename(folder), cls.__name__))
         return cls(config=None, name=os.path.basename(folder), basedir=os.path.dirname(folder), **kwargs)
 
     def load_weights_h5(self, path):
         """Keras HDF5 weights of a csbdeep model folder (needs h5py): converted in memory to the .npz layout, then loaded by name"""
-        try:
-            import h5py  # noqa: F401
-        except ImportError:
-            raise ImportError("reading %s needs h5py; convert it once with tools/keras_to_npz.py on a machine that has it" % path)
         import io
-        import sys as _sys
-        _sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools"))
-        from keras_to_npz import convert
+        from .pretrained import keras_h5_to_npz
         buf = io.BytesIO()
-        convert(path, buf)
+        keras_h5_to_npz(path, buf)
         buf.seek(0)
         self.load_weights_npz(buf)
 
@@ -303,7 +305,9 @@ class StarDistBase(object):
             ys = self._net_eager(xc.contiguous(memory_format=mf), sparse_head)
             self._head_mode = getattr(self.net, "head_mode", "dense")
         else:
-            key = (tuple(xc.shape), xc.dtype, bool(sparse_head))
+            from .unet import conv_mode
+            # everything the captured kernels depend on besides the weights: shape, head form, convolution kernel family
+            key = (tuple(xc.shape), xc.dtype, bool(sparse_head), conv_mode(), bool(getattr(self.net, "fused_heads", True)))
             cache = self.__dict__.setdefault("_graphs", {})
             if key not in cache:
                 if len(cache) >= 8:                                  # bounded: tiles of a big image share few shapes

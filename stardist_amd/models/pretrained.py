@@ -100,3 +100,31 @@ def get_model_folder(cls_name, key_or_alias):
     if not os.path.exists(os.path.join(d, "config.json")):
         raise FileNotFoundError("archive %s did not contain %s/config.json" % (zpath, key))
     return d
+
+
+def keras_h5_to_npz(src, dst):
+    """Keras HDF5 weight file (weights_best.h5 / weights_last.h5 of a csbdeep model folder, or the folder itself) -> the .npz that
+    StarDistBase.load_weights_npz reads: one entry per variable, named "<layer>/<variable>" ("conv2d_1/kernel:0"), in the order of the
+    file's `layer_names` attribute (= Keras graph order); kernels stay in Keras layout (k..., cin, cout).  Needs h5py."""
+    try:
+        import h5py
+    except ImportError:
+        raise ImportError("reading %s needs h5py; convert it once with tools/keras_to_npz.py on a machine that has it" % (src,))
+    import numpy as np
+    if os.path.isdir(src):
+        for name in ("weights_best.h5", "weights_last.h5", "weights_now.h5"):
+            if os.path.exists(os.path.join(src, name)):
+                src = os.path.join(src, name)
+                break
+        else:
+            raise FileNotFoundError("no weights_*.h5 in %s" % src)
+    out = {}
+    text = lambda n: n.decode() if isinstance(n, bytes) else n
+    with h5py.File(src, "r") as f:
+        g = f["model_weights"] if "model_weights" in f else f
+        for ln in map(text, g.attrs["layer_names"]):
+            lg = g[ln]
+            for wn in map(text, lg.attrs.get("weight_names", [])):
+                out[wn if wn.startswith(ln) else ln + "/" + wn.split("/")[-1]] = np.asarray(lg[wn])
+    np.savez(dst, **out)
+    return list(out)

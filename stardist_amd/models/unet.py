@@ -133,35 +133,116 @@ def hand_conv_enabled():
     return conv_mode() != "miopen"
 
 
-def _packed_conv_weights(conv, split=False):
-    """conv.weight in the device layout of sd_conv3_ndhwc_device (split=True: of sd_conv3_bf16x6_ndhwc_device), cached per module
-    (inference: invalidated when the weight changes)"""
+# convolutions that could not be taken by a hand-written kernel in GPU inference (reason strings): parity tests assert this stays
+# empty for the configurations they pin, so a silent detour through library kernels cannot hide behind a green test
+library_fallbacks = []
+
+
+def _bn_fold(conv, bn):
+    """(kernel, bias) float32 numpy of conv followed by an inference BatchNormalization (csbdeep conv_block: Conv -> BN -> Activation,
+    Keras moving statistics): w' = w * s, b' = (b - mean) * s + beta with s = gamma / sqrt(var + eps), folded in float64"""
+    w = conv.weight.detach().double().cpu().numpy()
+    b = conv.bias.detach().double().cpu().numpy() if conv.bias is not None else np.zeros(w.shape[0])
+    if bn is not None:
+        g = bn.weight.detach().double().cpu().numpy() if bn.weight is not None else np.ones(w.shape[0])
+        beta = bn.bias.detach().double().cpu().numpy() if bn.bias is not None else np.zeros(w.shape[0])
+        sc = g / np.sqrt(bn.running_var.detach().double().cpu().numpy() + bn.eps)
+        w = w * sc.reshape((-1,) + (1,) * (w.ndim - 1))
+        b = (b - bn.running_mean.detach().double().cpu().numpy()) * sc + beta
+    return np.ascontiguousarray(w, np.float32), np.ascontiguousarray(b, np.float32)
+
+
+def _packed_conv_weights(conv, form="conv3", bn=None):
+    """(packed kernel, bias) on the device for the native layer `form`: 'conv3' (sd_conv3_ndhwc_device), 'bf16x6'
+    (sd_conv3_bf16x6_ndhwc_device) or 'general' (sd_convg_ndhwc_device); an inference batch-norm layer behind the convolution is
+    folded in.  Cached per module (inference: invalidated when a parameter changes)."""
     from ..lib import _native as N
-    key = (conv.weight.data_ptr(), conv.weight._version, str(conv.weight.device))
-    slot, prefix = ("_sd_packed_bf16", "sd_conv3_bf16x6") if split else ("_sd_packed", "sd_conv3")
+    ver = lambda t: None if t is None else (t.data_ptr(), t._version)
+    key = (ver(conv.weight), ver(conv.bias), str(conv.weight.device)) + \
+        (() if bn is None else (ver(bn.weight), ver(bn.bias), ver(bn.running_mean), ver(bn.running_var), bn.eps))
+    slot = "_sd_packed_" + form
     cache = conv.__dict__.get(slot)
     if cache is None or cache[0] != key:
-        w = np.ascontiguousarray(conv.weight.detach().float().cpu().numpy())
-        co, ci, kz = int(w.shape[0]), int(w.shape[1]), (3 if w.ndim == 5 else 1)
-        n = int(getattr(N.lib(), prefix + "_packed_floats")(ci, co, kz))
-        if n < 0:
-            raise ValueError("%s: unsupported channel counts %d -> %d" % (prefix, ci, co))
-        packed = np.empty(n, np.float32)
-        N.check(getattr(N.lib(), prefix + "_pack_weights_host")(N.ptr(w), ci, co, kz, N.ptr(packed)))
-        cache = (key, torch.from_numpy(packed).to(conv.weight.device))
+        w, b = _bn_fold(conv, bn)
+        co, ci = int(w.shape[0]), int(w.shape[1])
+        k = tuple(int(v) for v in w.shape[2:])
+        L = N.lib()
+        if form == "general":
+            kz, ky, kx = ((1,) + k) if len(k) == 2 else k
+            n = int(L.sd_convg_packed_floats(ci, co, kz, ky, kx))
+            if n < 0:
+                raise ValueError("sd_convg: unsupported layer %d -> %d, kernel %s" % (ci, co, k))
+            packed = np.zeros(n, np.float32)
+            N.check(L.sd_convg_pack_weights_host(N.ptr(w), ci, co, kz, ky, kx, N.ptr(packed)))
+        else:
+            prefix = "sd_conv3_bf16x6" if form == "bf16x6" else "sd_conv3"
+            kz = 3 if w.ndim == 5 else 1
+            n = int(getattr(L, prefix + "_packed_floats")(ci, co, kz))
+            if n < 0:
+                raise ValueError("%s: unsupported channel counts %d -> %d" % (prefix, ci, co))
+            packed = np.empty(n, np.float32)
+            N.check(getattr(L, prefix + "_pack_weights_host")(N.ptr(w), ci, co, kz, N.ptr(packed)))
+        has_bias = conv.bias is not None or bn is not None
+        cache = (key, torch.from_numpy(packed).to(conv.weight.device), torch.from_numpy(b).to(conv.weight.device) if has_bias else None)
         conv.__dict__[slot] = cache
-    return cache[1]
+    return cache[1], cache[2]
 
 
-def _hand_conv(conv, srcs, kind):
-    """act(conv(cat(srcs, 1)) + bias) by the hand-written kernel; srcs = [(tensor (1, C, *spatial) channels-last float32, up)] with
+def tf_same_pad_before(n, k, s):
+    """TensorFlow 'SAME': total = max(k - s, 0) if n % s == 0 else max(k - n % s, 0); the smaller half goes in front"""
+    total = max(k - s, 0) if n % s == 0 else max(k - n % s, 0)
+    return total // 2
+
+
+def _general_conv(conv, x, kind, res=None, bn=None, tf_same=False):
+    """act(conv(x) + bias (+ res)) by the general hand-written kernel (any kernel size / stride / channel counts; csrc/conv_general.hip).
+    tf_same: Keras padding='same' semantics for a strided layer (asymmetric, computed from the input size) instead of conv.padding.
+    None when the layer is not covered."""
+    nd = x.dim() - 2
+    if not (nd in (2, 3) and x.shape[0] == 1 and conv.groups == 1 and all(d == 1 for d in conv.dilation) and conv.weight.dtype == torch.float32
+            and x.dtype == torch.float32 and x.is_cuda and x.device == conv.weight.device and x.shape[1] == conv.in_channels):
+        return None
+    from ..lib import _native as N
+    k3 = (1,) * (3 - nd) + tuple(int(v) for v in conv.kernel_size)
+    s3 = (1,) * (3 - nd) + tuple(int(v) for v in conv.stride)
+    if int(N.lib().sd_convg_packed_floats(conv.in_channels, conv.out_channels, *k3)) < 0:
+        return None
+    S3 = (1,) * (3 - nd) + tuple(int(v) for v in x.shape[2:])
+    if tf_same:
+        p3 = tuple(tf_same_pad_before(n, k, st) for n, k, st in zip(S3, k3, s3))
+        O3 = tuple(-(-n // st) for n, st in zip(S3, s3))
+    else:
+        if not all(isinstance(v, int) for v in conv.padding):
+            return None
+        p3 = (0,) * (3 - nd) + tuple(int(v) for v in conv.padding)
+        O3 = tuple((n + 2 * p - k) // st + 1 for n, p, k, st in zip(S3, p3, k3, s3))
+    if any(o <= 0 for o in O3):
+        return None
+    cl = torch.channels_last if nd == 2 else torch.channels_last_3d
+    if not (x.is_contiguous(memory_format=cl) and x.data_ptr() % 16 == 0):
+        x = x.clone(memory_format=cl)
+    co = conv.out_channels
+    wp, bias = _packed_conv_weights(conv, "general", bn)
+    out = torch.empty((1, co) + O3[3 - nd:], dtype=torch.float32, device=x.device, memory_format=cl)
+    if res is not None:
+        if not (tuple(res.shape) == tuple(out.shape) and res.dtype == torch.float32 and res.is_contiguous(memory_format=cl)):
+            return None
+    N.dcall(x, "sd_convg_ndhwc_device", ctypes.c_void_p(x.data_ptr()), conv.in_channels, conv.in_channels, *S3, *k3, *s3, *p3, *O3,
+            ctypes.c_void_p(wp.data_ptr()), ctypes.c_void_p(bias.data_ptr()) if bias is not None else None,
+            ctypes.c_void_p(res.data_ptr()) if res is not None else None, co, co, kind, ctypes.c_void_p(out.data_ptr()), co)
+    return out
+
+
+def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False):
+    """act(conv(cat(srcs, 1)) + bias (+ res)) by a hand-written kernel; srcs = [(tensor (1, C, *spatial) channels-last float32, up)] with
     up = per-axis tuple of 0/1 (or one int for all axes): 1 where the source has half the output resolution and the reference
-    up-samples it (nearest, x2) first.  None when the layer is not covered."""
+    up-samples it (nearest, x2) first.  res: residual added before the activation (resnet_block's Add); bn: inference batch-norm layer
+    between convolution and activation (folded into kernel and bias).  3x3(x3) stride-1 'same' layers over 32-channel chunks (and the
+    one-channel first layer) go to csrc/conv3x3.hip, everything else with one full-resolution source to csrc/conv_general.hip.
+    None when the layer is not covered."""
     nd = 2 if isinstance(conv, nn.Conv2d) else (3 if isinstance(conv, nn.Conv3d) else 0)
-    if not (nd and kind in (0, 1) and hand_conv_enabled() and not torch.is_grad_enabled()
-            and not torch.is_autocast_enabled() and tuple(conv.kernel_size) == (3,) * nd and tuple(conv.stride) == (1,) * nd
-            and tuple(conv.padding) == (1,) * nd and tuple(conv.dilation) == (1,) * nd and conv.groups == 1
-            and conv.weight.dtype == torch.float32 and 1 <= len(srcs) <= 2):
+    if not (nd and kind in (0, 1) and hand_conv_enabled() and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
+            and conv.groups == 1 and conv.weight.dtype == torch.float32 and 1 <= len(srcs) <= 2) or (bn is not None and bn.training):
         return None
     cl = torch.channels_last if nd == 2 else torch.channels_last_3d
     cs, ups = [], []
@@ -173,11 +254,15 @@ def _hand_conv(conv, srcs, kind):
     co = conv.out_channels
     if sum(cs) != conv.in_channels:
         return None
+    is3 = (tuple(conv.kernel_size) == (3,) * nd and tuple(conv.stride) == (1,) * nd and tuple(conv.padding) == (1,) * nd
+           and tuple(conv.dilation) == (1,) * nd and not tf_same)
     if cs == [1]:
-        ok = co % 4 == 0 and not any(ups[0])
+        ok = is3 and co % 4 == 0 and not any(ups[0]) and res is None
     else:
-        ok = all(c % 32 == 0 and c > 0 for c in cs) and sum(cs) <= 256 and co % 32 == 0
+        ok = is3 and all(c % 32 == 0 and c > 0 for c in cs) and sum(cs) <= 256 and co % 32 == 0
     if not ok:
+        if len(srcs) == 1 and not any(ups[0]):
+            return _general_conv(conv, srcs[0][0], kind, res, bn, tf_same)
         return None
     shape = tuple(int(s) << u for s, u in zip(srcs[0][0].shape[2:], ups[0]))          # output = full resolution
     for (t, _), up in zip(srcs, ups):
@@ -187,15 +272,18 @@ def _hand_conv(conv, srcs, kind):
     # channels-last operands (a pooling layer may hand over a tensor in the default layout: one copy at its resolution)
     srcs = [(t if t.is_contiguous(memory_format=cl) and t.data_ptr() % 16 == 0 else t.clone(memory_format=cl), up) for t, up in srcs]
     split = conv_mode() == "bf16x6" and cs != [1]
-    wp = _packed_conv_weights(conv, split)
+    wp, bias = _packed_conv_weights(conv, "bf16x6" if split else "conv3", bn)
     out = torch.empty((1, co) + shape, dtype=torch.float32, device=conv.weight.device, memory_format=cl)
+    if res is not None and not (tuple(res.shape) == tuple(out.shape) and res.dtype == torch.float32 and res.is_contiguous(memory_format=cl)):
+        return None
     D, H, W = ((1,) + shape) if nd == 2 else shape
     mask = lambda up: sum(b << k for k, b in enumerate(reversed(up)))                     # bit 0: x, 1: y, 2: z
     a, b = srcs[0][0], (srcs[1][0] if len(srcs) == 2 else None)
-    N.dcall(a, "sd_conv3_bf16x6_ndhwc_device" if split else "sd_conv3_ndhwc_device", ctypes.c_void_p(a.data_ptr()), cs[0], cs[0], mask(ups[0]),
+    N.dcall(a, "sd_conv3_bf16x6_res_ndhwc_device" if split else "sd_conv3_res_ndhwc_device", ctypes.c_void_p(a.data_ptr()), cs[0], cs[0], mask(ups[0]),
             ctypes.c_void_p(b.data_ptr()) if b is not None else None, cs[1] if b is not None else 0, cs[1] if b is not None else 0,
             mask(ups[1]) if b is not None else 0, D, H, W, 1 if nd == 2 else 3, ctypes.c_void_p(wp.data_ptr()),
-            ctypes.c_void_p(conv.bias.data_ptr()) if conv.bias is not None else None, co, kind, ctypes.c_void_p(out.data_ptr()))
+            ctypes.c_void_p(bias.data_ptr()) if bias is not None else None, ctypes.c_void_p(res.data_ptr()) if res is not None else None,
+            co if res is not None else 0, co, kind, ctypes.c_void_p(out.data_ptr()))
     return out
 
 
@@ -209,6 +297,8 @@ def _conv_bias_act(conv, x, kind):
     y = _hand_conv(conv, [(x, 0)], kind)
     if y is not None:
         return y
+    if hand_conv_enabled():
+        library_fallbacks.append("%s %d->%d k%s s%s" % (type(conv).__name__, conv.in_channels, conv.out_channels, tuple(conv.kernel_size), tuple(conv.stride)))
     y = _conv_nobias(conv, x)
     if y.dtype != torch.float32:         # gate on the convolution OUTPUT (the kernel reads/writes 4 bytes per element)
         y = y + conv.bias.to(y.dtype).view((1, y.shape[1]) + (1,) * (y.dim() - 2))
@@ -233,11 +323,18 @@ class ConvAct(nn.Sequential):
     (linear / relu) activation are done by one in-place pass of the native library (sd_bias_act_device) instead of two
     framework element-wise kernels; everywhere else (CPU, training, other activations) it is the plain Sequential."""
 
+    def parts(self):
+        """(conv, batch-norm or None, kind) with kind 0 linear / 1 relu / -1 another activation"""
+        conv, bn, act = (self[0], None, self[1]) if len(self) == 2 else (self[0], self[1], self[2])
+        return conv, bn, (0 if isinstance(act, nn.Identity) else (1 if isinstance(act, nn.ReLU) else -1))
+
     def forward(self, x):
-        if len(self) != 2:                      # [conv, batch-norm, activation] (unet_batch_norm=True): plain modules
-            return super().forward(x)
-        conv, act = self[0], self[1]
-        kind = 0 if isinstance(act, nn.Identity) else (1 if isinstance(act, nn.ReLU) else -1)
+        conv, bn, kind = self.parts()
+        if bn is not None:                      # [conv, batch-norm, activation] (unet_batch_norm=True): folded into the hand-written layer
+            y = _hand_conv(conv, [(x, 0)], kind, bn=bn) if (x.is_cuda and kind >= 0) else None
+            if y is None and x.is_cuda and hand_conv_enabled() and not torch.is_grad_enabled() and not torch.is_autocast_enabled():
+                library_fallbacks.append("ConvAct+BN %d->%d" % (conv.in_channels, conv.out_channels))
+            return super().forward(x) if y is None else y
         y = _conv_bias_act(conv, x, kind) if kind >= 0 else None
         return super().forward(x) if y is None else y
 
@@ -298,16 +395,18 @@ class UNetBlock(nn.Module):
         x = self.middle(x)
         for blk, skip in zip(self.up, reversed(skips)):
             first = blk[0]
-            y, kind = None, -1
-            if isinstance(first, ConvAct) and len(first) == 2:
-                kind = 0 if isinstance(first[1], nn.Identity) else (1 if isinstance(first[1], nn.ReLU) else -1)
-                if all(p in (1, 2) for p in self.pool):
-                    y = _hand_conv(first[0], [(x, tuple(p == 2 for p in self.pool)), (skip, 0)], kind)   # UpSampling + Concatenate + Conv + bias + act
+            y, kind, bn = None, -1, None
+            if isinstance(first, ConvAct):
+                conv0, bn, kind = first.parts()
+                if all(p in (1, 2) for p in self.pool) and kind >= 0 and x.is_cuda:
+                    y = _hand_conv(conv0, [(x, tuple(p == 2 for p in self.pool)), (skip, 0)], kind, bn=bn)   # UpSampling + Concatenate + Conv (+ BN) + bias + act
                     if y is not None:
                         x = blk[1:](y)
                         continue
+                    if hand_conv_enabled() and not torch.is_grad_enabled() and not torch.is_autocast_enabled():
+                        library_fallbacks.append("up-level %d->%d" % (conv0.in_channels, conv0.out_channels))
             x = F.interpolate(x, scale_factor=tuple(float(p) for p in self.pool), mode="nearest")
-            if kind >= 0:
+            if kind >= 0 and bn is None:
                 y = _conv_cat_bias_act(first[0], x, skip, kind)
             x = blk(torch.cat([x, skip], dim=1)) if y is None else blk[1:](y)
         return x
@@ -344,7 +443,40 @@ class ResNetBlock(nn.Module):
             pads += [total // 2, total - total // 2]
         return F.pad(x, pads)
 
+    def _forward_hand(self, x):
+        """the block on the hand-written kernels: strided first convolution (TensorFlow 'same' padding) with its activation, body
+        convolutions, the strided 1x1 projection, and Add + Activation folded into the last convolution's epilogue; None if a layer is
+        not covered"""
+        kind = lambda a: 0 if isinstance(a, nn.Identity) else (1 if isinstance(a, nn.ReLU) else -1)
+        layers = list(self.body)
+        if not (x.is_cuda and hand_conv_enabled() and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
+                and kind(layers[0]) >= 0 and kind(self.act) >= 0):
+            return None
+        y = _hand_conv(self.first, [(x, 0)], kind(layers[0]), tf_same=True)
+        if y is None:
+            return None
+        sc = x
+        if self.proj is not None:
+            sc = _hand_conv(self.proj, [(x, 0)], 0, tf_same=True)
+            if sc is None:
+                return None
+        convs = [(layers[k], layers[k + 1] if k + 1 < len(layers) else None) for k in range(1, len(layers), 2)]
+        for conv, act in convs:
+            last = act is None
+            k = kind(self.act) if last else kind(act)
+            if k < 0:
+                return None
+            y = _hand_conv(conv, [(y, 0)], k, res=sc if last else None)
+            if y is None:
+                return None
+        return y
+
     def forward(self, x):
+        y = self._forward_hand(x)
+        if y is not None:
+            return y
+        if x.is_cuda and hand_conv_enabled() and not torch.is_grad_enabled() and not torch.is_autocast_enabled():
+            library_fallbacks.append("ResNetBlock %d" % self.first.in_channels)
         y = self.body(self.first(self._same_pad(x)))
         if self.proj is not None:
             x = self.proj(x)
@@ -413,8 +545,14 @@ class StarDistNet(nn.Module):
         if dist is None:
             dist = self.dist(f)
         if self.n_classes is not None:
-            return prob, dist, torch.softmax(self.prob_class(self.features_class(base)), dim=1)
+            return prob, dist, self._class_head(base)
         return prob, dist
+
+    def _class_head(self, base):
+        """softmax(prob_class(features_class(base))): the multi-class head (model2d.py:339-347, model3d.py:443-452)"""
+        f = self.features_class(base)
+        y = _conv_bias_act(self.prob_class, f, 0)
+        return torch.softmax(y if y is not None else self.prob_class(f), dim=1)
 
     # MIOpen convolutions index with int32: a tensor of >= 2**31 elements (e.g. 128 feature channels on a 256^3 volume)
     # silently drops PyTorch to its im2col+GEMM fallback, ~3x slower.  The head (features conv + 1x1 output convs) is
@@ -536,7 +674,9 @@ class StarDistNet(nn.Module):
         return self._heads_slabbed(base)
 
     def _class_head_slabbed(self, base):
-        head = lambda t: torch.softmax(self.prob_class(self.features_class(t)), dim=1)
+        head = self._class_head
+        if base.is_cuda and hand_conv_enabled() and not torch.is_grad_enabled() and not torch.is_autocast_enabled():
+            return head(base)                       # hand-written kernels index with 64 bits: no slabs
         widest = max(base.shape[1], self.prob_class.in_channels, self.prob_class.out_channels)
         per_plane = base.shape[0] * widest * int(np.prod(base.shape[3:]))
         D = base.shape[2]

@@ -24,8 +24,10 @@ def recorder(monkeypatch):
     monkeypatch.setattr(N, "dcall", fake_dcall)
     # the wrapper insists on CUDA tensors; run its logic on CPU tensors by dropping exactly that check
     src = inspect.getsource(U._hand_conv)
-    assert "t.is_cuda and " in src
+    gsrc = inspect.getsource(U._general_conv)
+    assert "t.is_cuda and " in src and "x.is_cuda and " in gsrc
     ns = dict(U.__dict__)
+    exec(gsrc.replace("x.is_cuda and ", ""), ns)
     exec(src.replace("t.is_cuda and ", ""), ns)
     return ns["_hand_conv"], calls
 
@@ -44,13 +46,13 @@ def test_dispatch_2d_and_3d(recorder, monkeypatch):
         y = hand(torch.nn.Conv2d(64, 32, 3, padding=1), [(_t((1, 32, 8, 12), cl2), (1, 1)), (_t((1, 32, 16, 24), cl2), 0)], 1)
         assert tuple(y.shape) == (1, 32, 16, 24) and y.is_contiguous(memory_format=cl2)
         name, a = calls[-1]
-        assert name == "sd_conv3_ndhwc_device"
-        #      c0  stride0 up0        c1  stride1 up1   D  H   W   kz                 c_out act
-        assert a[1:4] == [32, 32, 3] and a[5:8] == [32, 32, 0] and a[8:12] == [1, 16, 24, 1] and a[14:16] == [32, 1]
+        assert name == "sd_conv3_res_ndhwc_device"
+        #      c0  stride0 up0        c1  stride1 up1   D  H   W   kz            res, res_stride     c_out act
+        assert a[1:4] == [32, 32, 3] and a[5:8] == [32, 32, 0] and a[8:12] == [1, 16, 24, 1] and a[14:16] == [None, 0] and a[16:18] == [32, 1]
         y = hand(torch.nn.Conv3d(64, 64, 3, padding=1), [(_t((1, 32, 4, 8, 8), cl3), (1, 1, 1)), (_t((1, 32, 8, 16, 16), cl3), 0)], 0)
         assert tuple(y.shape) == (1, 64, 8, 16, 16) and y.is_contiguous(memory_format=cl3)
         name, a = calls[-1]
-        assert a[1:4] == [32, 32, 7] and a[8:12] == [8, 16, 16, 3] and a[14:16] == [64, 0]
+        assert a[1:4] == [32, 32, 7] and a[8:12] == [8, 16, 16, 3] and a[16:18] == [64, 0]
         hand(torch.nn.Conv3d(64, 32, 3, padding=1), [(_t((1, 32, 8, 8, 8), cl3), (0, 1, 1)), (_t((1, 32, 8, 16, 16), cl3), 0)], 1)
         assert calls[-1][1][3] == 3                                   # z not up-sampled: mask = x | y
         y = hand(torch.nn.Conv3d(1, 32, 3, padding=1), [(_t((1, 1, 6, 8, 10), cl3), 0)], 1)
@@ -58,6 +60,55 @@ def test_dispatch_2d_and_3d(recorder, monkeypatch):
         # a source in the default layout is converted, not rejected
         y = hand(torch.nn.Conv2d(32, 32, 3, padding=1), [(torch.randn(1, 32, 8, 8), 0)], 1)
         assert y is not None
+        # residual (resnet_block's Add + Activation in the epilogue)
+        r = _t((1, 64, 8, 16, 16), cl3)
+        y = hand(torch.nn.Conv3d(64, 64, 3, padding=1), [(_t((1, 64, 8, 16, 16), cl3), 0)], 1, res=r)
+        assert calls[-1][0] == "sd_conv3_res_ndhwc_device" and calls[-1][1][14:18] == [r.data_ptr(), 64, 64, 1]
+
+
+def test_dispatch_general_kernel(recorder, monkeypatch):
+    """layers that are not stride-1 3x3 over 32-channel chunks go to sd_convg_ndhwc_device: the ResNet stem / strided convolutions /
+    1x1 projection (model3d.py:400-447, TensorFlow 'same' padding for strided layers), 3-channel first layers, narrow heads"""
+    import torch
+    from stardist_amd.models.unet import tf_same_pad_before
+    hand, calls = recorder
+    monkeypatch.delenv("STARDIST_AMD_CONV", raising=False)
+    cl2, cl3 = torch.channels_last, torch.channels_last_3d
+    assert [tf_same_pad_before(n, 3, 2) for n in (8, 9)] == [0, 1] and tf_same_pad_before(8, 7, 1) == 3 and tf_same_pad_before(9, 1, 2) == 0
+    with torch.no_grad():
+        y = hand(torch.nn.Conv3d(1, 32, 7, padding=3), [(_t((1, 1, 6, 9, 10), cl3), 0)], 0)
+        name, a = calls[-1]
+        #                                       c_in xs  D  H  W   k        s        p        Do Ho Wo
+        assert name == "sd_convg_ndhwc_device" and a[1:18] == [1, 1, 6, 9, 10, 7, 7, 7, 1, 1, 1, 3, 3, 3, 6, 9, 10] and tuple(y.shape) == (1, 32, 6, 9, 10)
+        assert a[20:26] == [None, 32, 32, 0, y.data_ptr(), 32]
+        y = hand(torch.nn.Conv3d(32, 64, 3, stride=(1, 2, 2), padding=0), [(_t((1, 32, 6, 9, 10), cl3), 0)], 1, tf_same=True)
+        a = calls[-1][1]
+        assert a[6:18] == [3, 3, 3, 1, 2, 2, 1, 1, 0, 6, 5, 5] and tuple(y.shape) == (1, 64, 6, 5, 5) and a[23] == 1
+        y = hand(torch.nn.Conv3d(32, 64, 1, stride=(1, 2, 2)), [(_t((1, 32, 6, 9, 10), cl3), 0)], 0, tf_same=True)
+        assert calls[-1][1][6:18] == [1, 1, 1, 1, 2, 2, 0, 0, 0, 6, 5, 5]
+        y = hand(torch.nn.Conv2d(3, 32, 3, padding=1), [(_t((1, 3, 8, 12), cl2), 0)], 1)
+        assert calls[-1][1][1:18] == [3, 3, 1, 8, 12, 1, 3, 3, 1, 1, 1, 0, 1, 1, 1, 8, 12]
+        y = hand(torch.nn.Conv2d(128, 5, 1), [(_t((1, 128, 8, 12), cl2), 0)], 0)
+        assert calls[-1][0] == "sd_convg_ndhwc_device" and tuple(y.shape) == (1, 5, 8, 12)
+        # batch-norm between convolution and activation: folded into kernel and bias (same entry point)
+        bn = torch.nn.BatchNorm2d(32).eval()
+        n0 = len(calls)
+        assert hand(torch.nn.Conv2d(32, 32, 3, padding=1), [(_t((1, 32, 8, 8), cl2), 0)], 1, bn=bn) is not None and len(calls) == n0 + 1
+        assert hand(torch.nn.Conv2d(32, 32, 3, padding=1), [(_t((1, 32, 8, 8), cl2), 0)], 1, bn=torch.nn.BatchNorm2d(32).train()) is None
+
+
+def test_bn_fold_matches_module():
+    import torch
+    from stardist_amd.models.unet import _bn_fold
+    torch.manual_seed(0)
+    conv, bn = torch.nn.Conv2d(8, 16, 3, padding=1).double(), torch.nn.BatchNorm2d(16, eps=1e-3).double().eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-1, 1); bn.running_mean.uniform_(-1, 1); bn.running_var.uniform_(0.5, 2)
+        w, b = _bn_fold(conv, bn)
+        x = torch.randn(1, 8, 10, 10, dtype=torch.float64)
+        want = bn(conv(x))
+        got = torch.nn.functional.conv2d(x, torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1)
+    assert float((want - got).abs().max()) < 1e-5
 
 
 def test_dispatch_rejections_and_modes(recorder, monkeypatch):
@@ -67,18 +118,19 @@ def test_dispatch_rejections_and_modes(recorder, monkeypatch):
     x32, x48 = _t((1, 32, 8, 8), cl2), _t((1, 48, 8, 8), cl2)
     with torch.no_grad():
         monkeypatch.delenv("STARDIST_AMD_CONV", raising=False)
-        assert hand(torch.nn.Conv2d(48, 32, 3, padding=1), [(x48, 0)], 1) is None                 # not a multiple of 32
-        assert hand(torch.nn.Conv2d(32, 32, 5, padding=2), [(x32, 0)], 1) is None                 # 5x5
-        assert hand(torch.nn.Conv2d(32, 32, 3, padding=1, stride=2), [(x32, 0)], 1) is None       # strided
-        assert hand(torch.nn.Conv2d(32, 40, 3, padding=1), [(x32, 0)], 1) is None                 # c_out not a multiple of 32
+        assert hand(torch.nn.Conv2d(48, 32, 3, padding=1), [(x48, 0)], 1) is not None and calls[-1][0] == "sd_convg_ndhwc_device"   # small-channel form
+        assert hand(torch.nn.Conv2d(1000, 32, 3, padding=1), [(_t((1, 1000, 8, 8), cl2), 0)], 1) is None   # neither 32-chunks nor small
+        for conv in (torch.nn.Conv2d(32, 32, 5, padding=2), torch.nn.Conv2d(32, 32, 3, padding=1, stride=2), torch.nn.Conv2d(32, 40, 3, padding=1)):
+            assert hand(conv, [(x32, 0)], 1) is not None and calls[-1][0] == "sd_convg_ndhwc_device"   # 5x5 / strided / c_out 40: general kernel
+        assert hand(torch.nn.Conv2d(32, 32, 3, padding=1, dilation=2), [(x32, 0)], 1) is None     # dilated
         assert hand(torch.nn.Conv2d(32, 32, 3, padding=1), [(x32, 0)], -1) is None                # activation it does not fuse
         assert hand(torch.nn.Conv2d(64, 32, 3, padding=1), [(x32, 1), (_t((1, 32, 8, 8), cl2), 0)], 1) is None   # shapes do not match after x2
         n0 = len(calls)
         monkeypatch.setenv("STARDIST_AMD_CONV", "miopen")
         assert hand(torch.nn.Conv2d(32, 32, 3, padding=1), [(x32, 0)], 1) is None and len(calls) == n0
         monkeypatch.setenv("STARDIST_AMD_CONV", "bf16x6")
-        assert hand(torch.nn.Conv2d(32, 32, 3, padding=1), [(x32, 0)], 1) is not None and calls[-1][0] == "sd_conv3_bf16x6_ndhwc_device"
-        assert hand(torch.nn.Conv2d(1, 32, 3, padding=1), [(_t((1, 1, 8, 8), cl2), 0)], 1) is not None and calls[-1][0] == "sd_conv3_ndhwc_device"
+        assert hand(torch.nn.Conv2d(32, 32, 3, padding=1), [(x32, 0)], 1) is not None and calls[-1][0] == "sd_conv3_bf16x6_res_ndhwc_device"
+        assert hand(torch.nn.Conv2d(1, 32, 3, padding=1), [(_t((1, 1, 8, 8), cl2), 0)], 1) is not None and calls[-1][0] == "sd_conv3_res_ndhwc_device"
     with torch.enable_grad():
         monkeypatch.delenv("STARDIST_AMD_CONV", raising=False)
         assert hand(torch.nn.Conv2d(32, 32, 3, padding=1), [(x32, 0)], 1) is None                 # training: plain modules

@@ -75,16 +75,14 @@ def test_conv3_matches_float64(shape, chans, c_out, kind, mode, monkeypatch):
     assert err <= (1e-5 if mode == "hand" else 2e-5) * scale, (err, scale)
 
 
-def test_conv3x3_rejects_what_it_does_not_cover():
+def test_layout_conversion_and_refusals():
     import torch
     from stardist_amd.models import unet as U
     dev = torch.device("cuda:0")
-    x = torch.randn(1, 48, 16, 16, device=dev).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
-        assert U._hand_conv(torch.nn.Conv2d(48, 32, 3, padding=1).to(dev), [(x, 0)], 1) is None          # 48 channels
-        assert U._hand_conv(torch.nn.Conv2d(32, 32, 3, padding=1, stride=2).to(dev), [(x, 0)], 1) is None
         x32 = torch.randn(1, 32, 16, 16, device=dev).contiguous(memory_format=torch.channels_last)
-        assert U._hand_conv(torch.nn.Conv2d(32, 32, 5, padding=2).to(dev), [(x32, 0)], 1) is None        # 5x5
+        assert U._hand_conv(torch.nn.Conv2d(32, 32, 3, padding=1, dilation=2).to(dev), [(x32, 0)], 1) is None   # dilated: not covered
+        assert U._hand_conv(torch.nn.Conv2d(32, 32, 3, padding=1).to(dev), [(x32, 0)], 2) is None               # activation it does not fuse
         # a source in the default (NCHW) layout is converted, not rejected
         conv = torch.nn.Conv2d(32, 32, 3, padding=1).to(dev)
         xc = x32.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)                                     # same values, NCHW-contiguous storage
@@ -92,45 +90,82 @@ def test_conv3x3_rejects_what_it_does_not_cover():
         assert torch.equal(U._hand_conv(conv, [(xc, 0)], 1), U._hand_conv(conv, [(x32, 0)], 1))
 
 
-def test_network_hand_conv_equals_miopen_path(monkeypatch):
-    """the whole 2D network with the hand-written layers vs every layer through MIOpen: same float32 arithmetic up to summation
-    order; both within 1e-5 of each other on prob, 1e-5 relative on dist"""
-    import torch
-    from oracle import synth
-    from stardist_amd.models import Config2D, StarDist2D
-    dev = torch.device("cuda:0")
-    img = torch.from_numpy(synth.s2d_nuclei_image(256, 320, seed=3)).to(dev)
-    model = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
-    monkeypatch.setenv("STARDIST_AMD_CONV", "hand")
-    p1, d1 = model.predict(img)
-    p1b, d1b = model.predict(img)
-    model.__dict__.pop("_graphs", None)
-    monkeypatch.setenv("STARDIST_AMD_CONV", "miopen")
-    p0, d0 = model.predict(img)
-    model.__dict__.pop("_graphs", None)
-    assert np.array_equal(p1, p1b) and np.array_equal(d1, d1b)
-    # two float32 evaluations with different summation orders, one of them (MIOpen's split-K kernels on small inputs) not even
-    # repeatable: a guard against gross disagreement (a layout or weight-mapping bug shows up at the 1e-1 level); the accuracy claim
-    # itself is checked against float64 in tests/test_gpu_unet_parity.py
-    ep, ed = float(np.abs(p1 - p0).max()), float((np.abs(d1 - d0) / np.maximum(1.0, np.abs(d0))).max())
-    assert ep <= 2e-4 and ed <= 2e-4, (ep, ed)
+# ---- the general kernel (csrc/conv_general.hip) and the residual epilogue ------------------------------------------------------
+GENERAL = [  # nd, c_in, c_out, kernel, stride, spatial, tf_same, residual
+    (3, 1, 32, 7, (1, 1, 1), (20, 40, 70), False, False),        # ResNet stem (model3d.py:414)
+    (3, 32, 64, 3, (1, 2, 2), (12, 33, 70), True, False),        # strided first convolution of a resnet_block, odd extent
+    (3, 32, 64, 1, (1, 2, 2), (12, 33, 70), True, False),        # its 1x1x1 shortcut projection
+    (3, 64, 64, 3, (2, 2, 2), (9, 20, 34), True, True),          # strided in z as well, with residual
+    (3, 64, 64, 3, (1, 1, 1), (6, 18, 40), False, True),         # conv3x3.hip with the Add + Activation epilogue
+    (2, 64, 64, 3, (1, 1), (40, 72), False, True),
+    (2, 3, 32, 3, (1, 1), (90, 130), False, False),              # H&E first layer (model2d.py:310-316, n_channel_in = 3)
+    (2, 128, 5, 1, (1, 1), (64, 96), False, False),              # prob_class head (n_classes + 1 channels)
+    (2, 32, 32, 5, (1, 1), (48, 80), False, False),              # unet_kernel_size = (5, 5)
+    (2, 128, 1, 1, (1, 1), (33, 47), False, False),
+]
 
 
-def test_network3d_hand_conv_equals_miopen_path(monkeypatch):
+@pytest.mark.parametrize("nd,ci,co,k,stride,S,tf_same,with_res", GENERAL)
+@pytest.mark.parametrize("kind", [0, 1])
+def test_general_and_residual_layers_match_float64(nd, ci, co, k, stride, S, tf_same, with_res, kind):
     import torch
-    from oracle import synth
-    from stardist_amd.models import Config3D, StarDist3D
+    import torch.nn.functional as F
+    from stardist_amd.models import unet as U
     dev = torch.device("cuda:0")
-    vol = torch.from_numpy(synth.s3d_nuclei_image(48, seed=2)).to(dev)
-    model = StarDist3D(Config3D(rays=32), basedir=None, device=dev, seed=0)
-    monkeypatch.setenv("STARDIST_AMD_CONV", "hand")
-    p1, d1 = model.predict(vol)
-    model.__dict__.pop("_graphs", None)
-    monkeypatch.setenv("STARDIST_AMD_CONV", "miopen")
-    p0, d0 = model.predict(vol)
-    model.__dict__.pop("_graphs", None)
-    # two float32 evaluations with different summation orders, one of them (MIOpen's split-K kernels on small inputs) not even
-    # repeatable: a guard against gross disagreement (a layout or weight-mapping bug shows up at the 1e-1 level); the accuracy claim
-    # itself is checked against float64 in tests/test_gpu_unet_parity.py
-    ep, ed = float(np.abs(p1 - p0).max()), float((np.abs(d1 - d0) / np.maximum(1.0, np.abs(d0))).max())
-    assert ep <= 2e-4 and ed <= 2e-4, (ep, ed)
+    g = torch.Generator().manual_seed(ci * 7919 + co * 31 + k + kind)
+    Conv = torch.nn.Conv2d if nd == 2 else torch.nn.Conv3d
+    conv = Conv(ci, co, k, stride=stride, padding=0 if tf_same else k // 2)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * float(np.sqrt(2.0 / (k ** nd * ci))))
+        conv.bias.copy_(torch.randn(co, generator=g) * 0.5)
+    cl = torch.channels_last if nd == 2 else torch.channels_last_3d
+    x = torch.randn((1, ci) + tuple(S), generator=g)
+    # float64 reference
+    xd = x.double()
+    if tf_same:
+        pads = []
+        for d in reversed(range(nd)):
+            n, st = S[d], stride[d]
+            tot = max(k - st, 0) if n % st == 0 else max(k - n % st, 0)
+            pads += [tot // 2, tot - tot // 2]
+        xd = F.pad(xd, pads)
+    ref = (F.conv2d if nd == 2 else F.conv3d)(xd, conv.weight.double(), conv.bias.double(), stride=stride, padding=0 if tf_same else k // 2)
+    res = torch.randn(ref.shape, generator=g) if with_res else None
+    if res is not None:
+        ref = ref + res.double()
+    if kind == 1:
+        ref = torch.relu(ref)
+    conv = conv.to(dev)
+    xg = x.to(dev).contiguous(memory_format=cl)
+    rg = res.to(dev).contiguous(memory_format=cl) if res is not None else None
+    with torch.no_grad():
+        y = U._hand_conv(conv, [(xg, 0)], kind, res=rg, tf_same=tf_same)
+        assert y is not None, "layer not taken by a hand-written kernel"
+        y2 = U._hand_conv(conv, [(xg, 0)], kind, res=rg, tf_same=tf_same)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == tuple(ref.shape) and y.is_contiguous(memory_format=cl)
+    assert torch.equal(y, y2), "not repeatable"
+    err = float((y.cpu().double() - ref).abs().max())
+    assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err
+
+
+def test_batch_norm_layer_folded_matches_float64():
+    """csbdeep conv_block with batch_norm=True: Conv -> BatchNormalization (moving statistics) -> Activation, folded into the
+    hand-written layer's kernel and bias"""
+    import torch
+    from stardist_amd.models import unet as U
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    blk = U._conv(2, 32, 64, 3, "relu", batch_norm=True)
+    with torch.no_grad():
+        bn = blk[1]
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5); bn.running_mean.uniform_(-0.5, 0.5); bn.running_var.uniform_(0.5, 2.0)
+    blk.eval()
+    x = torch.randn(1, 32, 70, 90)
+    with torch.no_grad():
+        ref = blk.double()(x.double())
+        blk = blk.float().to(dev)
+        del U.library_fallbacks[:]
+        y = blk(x.to(dev).contiguous(memory_format=torch.channels_last))
+    assert not U.library_fallbacks, U.library_fallbacks
+    assert float((y.cpu().double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))

@@ -114,3 +114,58 @@ def test_predict_instances_3d_end_to_end_equals_oracle_composition(refmods, over
     assert labels.shape == lab_ref.shape and np.array_equal(labels, lab_ref)
     if overlap_label is not None:
         assert (labels == overlap_label).any()           # the synthetic spheres do overlap: the branch is exercised
+
+
+@pytest.mark.parametrize("case", ["2D_demo-fixture", "default-synthetic"])
+def test_predict_instances_2d_end_to_end_equals_oracle_composition(refmods, case, monkeypatch, tmp_path):
+    """BASELINE config 1's substitute: the reference's `models/examples/2D_demo` topology (config.json: grid (2,2),
+    thresholds.json) with seeded weights on the reference's own fixture image tests/data/img2d.tif (stored in
+    tests/golden/fixture_images.npz), normalised as tests/test_model2D.py:19 does -- and the default (grid 1) model on a synthetic
+    tile.  StarDist2D.predict_instances (dense path: both sides see ONE forward pass) vs the reference composition on the same
+    prob/dist maps: _ind_prob_thresh -> sort -> points * grid -> compiled c_non_max_suppression_inds -> polygons_to_label
+    (stardist/nms.py:76-132, model2d.py:512-563, geom2d.py:130-197).  Label image and result dict must be identical."""
+    import shutil
+    import torch
+    import bench
+    from oracle import port, synth
+    from stardist_amd import nms
+    from stardist_amd.models import Config2D, StarDist2D
+    from stardist_amd.utils import normalize
+    dev = torch.device("cuda:0")
+    if case == "2D_demo-fixture":
+        cache = tmp_path / "cache"
+        shutil.copytree(os.path.join(ROOT, "tests", "golden", "pretrained"), str(cache))
+        monkeypatch.setenv("STARDIST_AMD_MODELS", str(cache))
+        model = StarDist2D.from_pretrained("2D_demo", device=dev)
+        assert tuple(model.config.grid) == (2, 2) and abs(model.thresholds.prob - 0.4861655269131771) < 1e-12 and model.thresholds.nms == 0.5
+        img = normalize(np.load(os.path.join(ROOT, "tests", "golden", "fixture_images.npz"))["img2d"])
+        assert img.shape == (256, 256) and img.dtype == np.float32
+        bench.calibrate_heads(model, torch.from_numpy(img).to(dev), frac=0.08, radius=7.0)
+    else:
+        model = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
+        img = synth.s2d_nuclei_image(384, 512, seed=4)
+        bench.calibrate_heads(model, torch.from_numpy(img).to(dev))
+    pt, nt, grid = model.thresholds.prob, model.thresholds.nms, tuple(model.config.grid)
+    (labels, res), (prob, dist) = model.predict_instances(img, return_predict=True)
+    prob = np.asarray(prob); dist = np.asarray(dist)
+    assert prob.shape == tuple(s // g for s, g in zip(img.shape, grid)) and dist.shape == prob.shape + (32,)
+    # ---- reference composition
+    mask = port.ind_prob_thresh(prob, pt, b=2)
+    pts = np.stack(np.where(mask), 1)
+    di, sc = dist[mask], prob[mask]
+    order = nms._argsort_desc(sc)                       # ties: stable order on both sides (DESIGN.md deviation 6)
+    di, sc, pts = di[order], sc[order], pts[order]
+    pts = pts * np.array(grid).reshape(1, 2)
+    refmods.set_threads(min(os.cpu_count() or 1, 16))
+    keep = refmods.stardist2d().c_non_max_suppression_inds(np.ascontiguousarray(di, np.float32), np.ascontiguousarray(pts.astype(np.int32).astype(np.float32)),
+                                                           1, 1, 0, np.float32(nt)).astype(bool)
+    assert 10 < keep.sum() < len(keep)
+    lab_ref = port.polygons_to_label(di[keep], pts[keep], prob=sc[keep], shape=img.shape)
+    coord_ref = port.dist_to_coord(di[keep], pts[keep])
+    assert np.array_equal(res["points"], pts[keep]) and np.array_equal(res["prob"], sc[keep])
+    assert res["coord"].dtype == np.float32 and np.array_equal(res["coord"], coord_ref)
+    assert labels.shape == lab_ref.shape and labels.dtype == lab_ref.dtype and np.array_equal(labels, lab_ref)
+    assert labels.max() == keep.sum()
+    # the sparse path (default of predict_instances) gives the same instances
+    labels_s, res_s = model.predict_instances(img)
+    assert np.array_equal(labels_s, labels) and np.array_equal(res_s["coord"], res["coord"]) and np.array_equal(res_s["prob"], res["prob"])

@@ -110,9 +110,9 @@ def test_nms3d_volume_bounds_do_not_change_decisions(refmods, monkeypatch):
     V, F = rays.vertices, rays.faces.astype(np.int32)
     d, p, s, nobj = synth.s3d_nuclei(96, rays.vertices)
     keep_bounds = sd3.c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(0.3))
-    monkeypatch.setenv("SD_NMS3D_NO_LB", "1")
-    keep_exact = sd3.c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(0.3))
-    monkeypatch.delenv("SD_NMS3D_NO_LB")
+    from stardist_amd.lib import _native as N
+    with N.option("nms3d_volume_bounds", 0):
+        keep_exact = sd3.c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(0.3))
     ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(0.3))
     assert np.array_equal(keep_bounds, keep_exact) and np.array_equal(keep_exact, ref_keep)
 
@@ -254,7 +254,7 @@ def test_inside_polyhedron_cone_map_equals_full_loop(n_rays, aniso):
 
 @pytest.mark.parametrize("n_rays,noise,thr", [(96, 0.3, 0.3), (32, 0.5, 0.5), (96, 0.3, 0.6)])
 def test_nms3d_cone_map_does_not_change_survivors(refmods, monkeypatch, n_rays, noise, thr):
-    """stage 5 with the cone map vs the loop over every face (SD_NMS3D_NO_CONEMAP=1) vs the reference: same survivors and the same
+    """stage 5 with the cone map vs the loop over every face (option nms3d_cone_map = 0) vs the reference: same survivors and the same
     cascade counters (pairs rendered, suppressed by the rendered overlap) on candidate sets that do reach stage 5"""
     import torch
     from stardist_amd.lib import stardist3d as sd3
@@ -265,9 +265,9 @@ def test_nms3d_cone_map_does_not_change_survivors(refmods, monkeypatch, n_rays, 
     args = (t(d), t(p), t(np.float32(V)), t(F), t(s), 1, 1, 0, np.float32(thr))
     keep_map, st_map = sd3.c_non_max_suppression_inds(*args, return_stats=True)
     st_map = st_map.copy()
-    monkeypatch.setenv("SD_NMS3D_NO_CONEMAP", "1")
-    keep_full, st_full = sd3.c_non_max_suppression_inds(*args, return_stats=True)
-    monkeypatch.delenv("SD_NMS3D_NO_CONEMAP")
+    from stardist_amd.lib import _native as N
+    with N.option("nms3d_cone_map", 0):
+        keep_full, st_full = sd3.c_non_max_suppression_inds(*args, return_stats=True)
     ref_keep = _ref_keep_random(refmods, (22, 33, 44), n_rays, noise, thr)
     assert np.array_equal(keep_map.cpu().numpy(), keep_full.cpu().numpy()) and np.array_equal(keep_full.cpu().numpy(), ref_keep)
     assert st_map[3] > 0, "no pair reached the render stage: %s" % st_map.tolist()
