@@ -129,7 +129,8 @@ def test_general_and_residual_layers_match_float64(nd, ci, co, k, stride, S, tf_
             tot = max(k - st, 0) if n % st == 0 else max(k - n % st, 0)
             pads += [tot // 2, tot - tot // 2]
         xd = F.pad(xd, pads)
-    ref = (F.conv2d if nd == 2 else F.conv3d)(xd, conv.weight.double(), conv.bias.double(), stride=stride, padding=0 if tf_same else k // 2)
+    with torch.no_grad():
+        ref = (F.conv2d if nd == 2 else F.conv3d)(xd, conv.weight.double(), conv.bias.double(), stride=stride, padding=0 if tf_same else k // 2)
     res = torch.randn(ref.shape, generator=g) if with_res else None
     if res is not None:
         ref = ref + res.double()
