@@ -90,6 +90,14 @@ int sd_star_dist3d_device(const uint16_t* d_src, int Z, int Y, int X, const floa
                           const float* d_dy, const float* d_dx, int n_rays, int grid_z,
                           int grid_y, int grid_x, float* d_dst, void* stream);
 
+/* ---- training target: per-object normalised distance transform ----------------------------
+ * replaces stardist.utils.edt_prob (stardist/utils.py:71-125; called by the data generators).
+ * lbl (Z, Y, X) int32 label image (2D: Z = 1), labels 1..max_label are objects, everything else background;
+ * (sz, sy, sx) axis spacing (the reference's `anisotropy`); prob (Z, Y, X) float32: for an object pixel the Euclidean distance
+ * (float64) to the nearest pixel inside the image with another label, divided by (the object's maximum + 1e-10); else 0. */
+int sd_edt_prob_device(const int32_t* d_lbl, int Z, int Y, int X, double sz, double sy, double sx, int max_label,
+                       float* d_prob, void* stream);
+
 /* ---- 2D label rasteriser --------------------------------------------------------------------
  * replaces the Python loop stardist.geometry.geom2d.polygons_to_label_coord
  *   (stardist/geometry/geom2d.py:149-166: skimage.draw.polygon per object, later objects

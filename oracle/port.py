@@ -207,3 +207,40 @@ def relabel_sequential(label_field, offset=1):
     inverse_map[offset:] = labels0
     relabeled = forward_map[label_field]
     return relabeled, forward_map, inverse_map
+
+
+# ----------------------------------------------------------------------------- utils.py
+def edt_prob(lbl_img, anisotropy=None):
+    """stardist/utils.py:71-125 (`_edt_prob_scipy`: per object, scipy's exact EDT of the object mask on its bounding box grown by one
+    pixel where it does not touch the image border, divided by the object's maximum + 1e-10).  Restated without scipy as an
+    exhaustive search: the grown box always contains an object pixel's nearest non-object pixel, so the value is the float64
+    distance to the nearest pixel INSIDE THE IMAGE with another label.  Pinned to goldens made by the reference function
+    (tests/test_cpu_oracle.py).  O(object pixels x image pixels): small test images only."""
+    import warnings
+    lbl = np.asarray(lbl_img)
+    nd = lbl.ndim
+    samp = np.ones(nd) if anisotropy is None else np.asarray(anisotropy, np.float64)
+    constant = lbl.min() == lbl.max() and lbl.flat[0] > 0
+    if constant:
+        lbl = np.pad(lbl, ((1, 1),) * nd, mode="constant")
+        warnings.warn("EDT of constant label image is ill-defined. (Assuming background around it.)")
+    coords = np.stack(np.meshgrid(*[np.arange(s) for s in lbl.shape], indexing="ij"), -1).reshape(-1, nd).astype(np.float64)
+    flat = lbl.reshape(-1)
+    prob = np.zeros(flat.shape, np.float32)
+    for l in np.unique(flat):
+        if l <= 0:
+            continue
+        inside = np.flatnonzero(flat == l)
+        other = coords[flat != l]
+        d = np.empty(len(inside))
+        for a in range(0, len(inside), 256):
+            diff = (coords[inside[a:a + 256], None, :] - other[None]) * samp
+            acc = np.zeros(diff.shape[:2])
+            for k in range(nd):                                  # scipy sums the squared axis terms in axis order
+                acc += diff[..., k] * diff[..., k]
+            d[a:a + 256] = np.sqrt(acc.min(axis=1))
+        prob[inside] = d / (d.max() + 1e-10)
+    prob = prob.reshape(lbl.shape)
+    if constant:
+        prob = prob[(slice(1, -1),) * nd].copy()
+    return prob

@@ -40,6 +40,7 @@ SIGNATURES = {
     "sd_star_dist2d_device": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "sd_star_dist3d_host": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sd_star_dist3d_device": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "sd_edt_prob_device": (_i, [_vp, _i, _i, _i, ctypes.c_double, ctypes.c_double, ctypes.c_double, _i, _vp, _vp]),
     "sd_polygons_to_label_host": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sd_polygons_to_label_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "_LIB_non_maximum_suppression_sparse": (None, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _i, _i, _i, _vp]),

@@ -56,95 +56,81 @@ def to_host(t):
 
 # ----------------------------------------------------------------------------- training-side target: edt_prob
 def edt_prob(lbl_img, anisotropy=None):
-    """Per-object normalised Euclidean distance transform (stardist/utils.py:71-125; the scipy variant `_edt_prob_scipy`,
-    which the reference uses when the optional `edt` package is absent): for every label id the EDT of its mask (computed
-    on the object's bounding box grown by one pixel where it does not touch the image border), divided by its maximum."""
+    """Per-object normalised Euclidean distance transform of a label image (the object-probability training target; what
+    stardist/utils.py:71-125 `edt_prob` returns) computed on the GPU by csrc/edt.hip: for every pixel of an object the distance
+    (float64, axis spacing `anisotropy`) to the nearest pixel inside the image that carries another label, divided by the object's
+    maximum; background 0.  numpy in -> numpy float32 out; a torch device tensor in -> a device tensor out.
+    A constant non-zero image is ill-defined; like the reference it is treated as surrounded by background (with a warning)."""
+    import ctypes
     import warnings
-    from scipy.ndimage import distance_transform_edt, find_objects
-
-    def grow(sl, interior):
-        return tuple(slice(s.start - int(w[0]), s.stop + int(w[1])) for s, w in zip(sl, interior))
-
-    def shrink(interior):
-        return tuple(slice(int(w[0]), (-1 if w[1] else None)) for w in interior)
-    lbl_img = np.asarray(lbl_img)
-    constant_img = lbl_img.min() == lbl_img.max() and lbl_img.flat[0] > 0
-    if constant_img:
-        lbl_img = np.pad(lbl_img, ((1, 1),) * lbl_img.ndim, mode="constant")
+    import torch
+    from .lib import _native as N
+    N.require_device()
+    as_np = not N.is_torch(lbl_img)
+    lab = torch.from_numpy(np.ascontiguousarray(lbl_img).astype(np.int32, copy=False)).cuda() if as_np else lbl_img.to(torch.int32).contiguous()
+    nd = lab.dim()
+    if nd not in (2, 3):
+        raise ValueError("edt_prob: label image must be 2D or 3D")
+    samp = (1.0,) * nd if anisotropy is None else tuple(float(a) for a in anisotropy)
+    if len(samp) != nd:
+        raise ValueError("edt_prob: anisotropy must have one entry per axis")
+    if lab.numel() == 0:
+        out = torch.zeros(lab.shape, dtype=torch.float32, device=lab.device)
+        return out.cpu().numpy() if as_np else out
+    lo, hi = int(lab.min()), int(lab.max())
+    padded = lo == hi and lo > 0
+    if padded:
         warnings.warn("EDT of constant label image is ill-defined. (Assuming background around it.)")
-    objects = find_objects(lbl_img)
-    prob = np.zeros(lbl_img.shape, np.float32)
-    for i, sl in enumerate(objects, 1):
-        if sl is None:
-            continue
-        interior = [(s.start > 0, s.stop < sz) for s, sz in zip(sl, lbl_img.shape)]
-        shrink_slice = shrink(interior)
-        grown_mask = lbl_img[grow(sl, interior)] == i
-        mask = grown_mask[shrink_slice]
-        edt = distance_transform_edt(grown_mask, sampling=anisotropy)[shrink_slice][mask]
-        prob[sl][mask] = edt / (np.max(edt) + 1e-10)
-    if constant_img:
-        prob = prob[(slice(1, -1),) * lbl_img.ndim].copy()
-    return prob
+        lab = torch.nn.functional.pad(lab, (1, 1) * nd).contiguous()
+    Z, Y, X = ((1,) + tuple(lab.shape)) if nd == 2 else tuple(lab.shape)
+    sz, sy, sx = ((1.0,) + samp) if nd == 2 else samp
+    out = torch.empty(lab.shape, dtype=torch.float32, device=lab.device)
+    N.dcall(lab, "sd_edt_prob_device", ctypes.c_void_p(lab.data_ptr()), Z, Y, X, sz, sy, sx, max(hi, 0), ctypes.c_void_p(out.data_ptr()))
+    if padded:
+        out = out[(slice(1, -1),) * nd].contiguous()
+    return out.cpu().numpy() if as_np else out
 
 
-# ----------------------------------------------------------------------------- ImageJ ROI export (stardist/utils.py:195-268)
+# ----------------------------------------------------------------------------- ImageJ ROI export
+# File layout from ImageJ's ij/io/RoiDecoder.java (all big-endian): 64-byte header -- "Iout", int16 version (>= 217; 227 written),
+# byte roi type (0 = polygon) + 1 unused byte, int16 top / left / bottom / right, uint16 n coordinates, ..., int16 options at 50
+# (128 = SUB_PIXEL_RESOLUTION), ..., int32 position at 56 -- then n int16 x offsets from `left`, n int16 y offsets from `top` and,
+# with the sub-pixel option, n float32 x and n float32 y absolute coordinates.  ImageJ puts the centre of pixel (0, 0) at (0.5, 0.5).
+_ROI_HEADER = 64
+
+
 def polyroi_bytearray(x, y, pos=None, subpixel=True):
-    """Byte array of an ImageJ polygon ROI (RoiDecoder.java layout): 64-byte big-endian header ('Iout', version 227, type 0,
-    bbox, n, subpixel flag 128 at byte 50, position at 56), int16 coordinates relative to the bbox, then float32 sub-pixel
-    coordinates.  ImageJ's pixel centre is (0.5, 0.5), hence the +0.5."""
+    """one ImageJ polygon ROI as bytes (same arguments and bytes as stardist/utils.py:195-251)"""
     import struct
-
-    def _int16(v): return int(v).to_bytes(2, byteorder="big", signed=True)
-
-    def _uint16(v): return int(v).to_bytes(2, byteorder="big", signed=False)
-
-    def _int32(v): return int(v).to_bytes(4, byteorder="big", signed=True)
-    subpixel = bool(subpixel)
-    x_raw = np.asarray(x).ravel() + 0.5
-    y_raw = np.asarray(y).ravel() + 0.5
-    x = np.round(x_raw); y = np.round(y_raw)
-    assert len(x) == len(y)
-    top, left, bottom, right = y.min(), x.min(), y.max(), x.max()
-    n = len(x)
-    header = 64
-    B = bytearray(header + n * 2 * 2 + subpixel * n * 2 * 4)
-    B[0:4] = b"Iout"
-    B[4:6] = _int16(227); B[6:8] = _int16(0)
-    B[8:10] = _int16(top); B[10:12] = _int16(left); B[12:14] = _int16(bottom); B[14:16] = _int16(right)
-    B[16:18] = _uint16(n)
+    fx = np.asarray(x, np.float64).ravel() + 0.5
+    fy = np.asarray(y, np.float64).ravel() + 0.5
+    if fx.shape != fy.shape:
+        raise ValueError("x and y must have the same length")
+    ix, iy = np.round(fx), np.round(fy)
+    n = fx.size
+    top, left, bottom, right = int(iy.min()), int(ix.min()), int(iy.max()), int(ix.max())
+    head = bytearray(_ROI_HEADER)
+    struct.pack_into(">4shBx4hH", head, 0, b"Iout", 227, 0, top, left, bottom, right, n)
     if subpixel:
-        B[50:52] = _int16(128)
+        struct.pack_into(">h", head, 50, 128)
     if pos is not None:
-        B[56:60] = _int32(pos)
-    for i, (_x, _y) in enumerate(zip(x, y)):
-        xs = header + 2 * i
-        ys = xs + 2 * n
-        B[xs:xs + 2] = _int16(_x - left)
-        B[ys:ys + 2] = _int16(_y - top)
+        struct.pack_into(">i", head, 56, int(pos))
+    body = (ix - left).astype(">i2").tobytes() + (iy - top).astype(">i2").tobytes()
     if subpixel:
-        base1 = header + n * 2 * 2
-        base2 = base1 + n * 4
-        for i, (_x, _y) in enumerate(zip(x_raw, y_raw)):
-            B[base1 + 4 * i:base1 + 4 * i + 4] = struct.pack(">f", _x)
-            B[base2 + 4 * i:base2 + 4 * i + 4] = struct.pack(">f", _y)
-    return B
+        body += fx.astype(">f4").tobytes() + fy.astype(">f4").tobytes()
+    return head + body
 
 
 def export_imagej_rois(fname, polygons, set_position=True, subpixel=True, compression=None):
-    """polygons: array (n, 2, n_rays) (the `coord` entry of predict_instances' dict: [y, x]) or a list of such arrays, one
-    per image position; writes <fname>.zip with one '<pos>_<i>.roi' per polygon (stardist/utils.py:254-268)"""
-    from pathlib import Path
-    from zipfile import ZIP_DEFLATED, ZipFile
-    if compression is None:
-        compression = ZIP_DEFLATED
-    if isinstance(polygons, np.ndarray):
-        polygons = (polygons,)
-    fname = Path(fname)
-    if fname.suffix == ".zip":
-        fname = fname.with_suffix("")
-    with ZipFile(str(fname) + ".zip", mode="w", compression=compression) as roizip:
-        for pos, polygroup in enumerate(polygons, start=1):
-            for i, poly in enumerate(polygroup, start=1):
-                roi = polyroi_bytearray(poly[1], poly[0], pos=(pos if set_position else None), subpixel=subpixel)
-                roizip.writestr("{pos:03d}_{i:03d}.roi".format(pos=pos, i=i), bytes(roi))
+    """ImageJ ROI archive of predicted polygons (what stardist/utils.py:254-268 writes): `polygons` is the `coord` array of
+    predict_instances' dict -- (n, 2, n_rays), rows (y, x) -- or a sequence of such arrays, one per stack position; entry
+    'PPP_III.roi' holds polygon III of position PPP (both 1-based)."""
+    import zipfile
+    groups = (polygons,) if isinstance(polygons, np.ndarray) else polygons
+    target = str(fname)
+    if not target.endswith(".zip"):
+        target += ".zip"
+    with zipfile.ZipFile(target, mode="w", compression=zipfile.ZIP_DEFLATED if compression is None else compression) as zf:
+        for pos, group in enumerate(groups, start=1):
+            for k, (ys, xs) in enumerate(group, start=1):
+                zf.writestr("%03d_%03d.roi" % (pos, k), bytes(polyroi_bytearray(xs, ys, pos=pos if set_position else None, subpixel=subpixel)))

@@ -172,18 +172,24 @@ def test_glue_functions_equal_reference_golden():
         assert np.array_equal(port.ind_prob_thresh(prob, thr, b=b), g["thresh_%s_mask" % k])
 
 
-def test_edt_prob_and_imagej_roi_export_equal_reference_functions(tmp_path):
-    """stardist/utils.py edt_prob (scipy variant) / polyroi_bytearray / export_imagej_rois: goldens made by the reference's own
-    functions (tests/golden/make_utils_golden.py)"""
+def test_oracle_edt_prob_equals_reference_function():
+    """oracle.port.edt_prob (exhaustive nearest-other-label search) against goldens made by the reference's own _edt_prob_scipy
+    (tests/golden/make_utils_golden.py): the checker the GPU kernel is compared with on larger inputs"""
     import warnings
+    from oracle import port
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "utils_reference.npz"))
+    assert np.array_equal(port.edt_prob(g["edt_lab2"]), g["edt_prob2"])
+    assert np.array_equal(port.edt_prob(g["edt_lab3"], anisotropy=(2.0, 1.0, 1.0)), g["edt_prob3"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert np.array_equal(port.edt_prob(g["edt_const"]), g["edt_prob_const"])
+
+
+def test_imagej_roi_export_equals_reference_functions(tmp_path):
+    """polyroi_bytearray / export_imagej_rois: goldens made by the reference's own functions (tests/golden/make_utils_golden.py)"""
     import zipfile
     from stardist_amd import utils
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "utils_reference.npz"))
-    assert np.array_equal(utils.edt_prob(g["edt_lab2"]), g["edt_prob2"])
-    assert np.array_equal(utils.edt_prob(g["edt_lab3"], anisotropy=(2.0, 1.0, 1.0)), g["edt_prob3"])
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        assert np.array_equal(utils.edt_prob(g["edt_const"]), g["edt_prob_const"])
     polys = g["roi_polys"]
     assert bytes(utils.polyroi_bytearray(polys[0][1], polys[0][0], pos=3, subpixel=True)) == g["roi_bytes_sub"].tobytes()
     assert bytes(utils.polyroi_bytearray(polys[1][1], polys[1][0], pos=None, subpixel=False)) == g["roi_bytes_int"].tobytes()

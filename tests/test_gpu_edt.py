@@ -1,0 +1,47 @@
+"""GPU: edt_prob (csrc/edt.hip, the training target of stardist/utils.py:71-125) against the goldens made by the reference's own
+function and against the exhaustive oracle (oracle.port.edt_prob, itself pinned to those goldens) on larger label images."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_edt_prob_equals_reference_goldens():
+    from stardist_amd import utils
+    g = np.load(os.path.join(ROOT, "tests", "golden", "utils_reference.npz"))
+    assert np.array_equal(utils.edt_prob(g["edt_lab2"]), g["edt_prob2"])
+    assert np.array_equal(utils.edt_prob(g["edt_lab3"], anisotropy=(2.0, 1.0, 1.0)), g["edt_prob3"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert np.array_equal(utils.edt_prob(g["edt_const"]), g["edt_prob_const"])
+
+
+def _blobs(shape, n, seed):
+    rs = np.random.RandomState(seed)
+    lab = np.zeros(shape, np.int32)
+    grid = np.stack(np.meshgrid(*[np.arange(s) for s in shape], indexing="ij"), -1)
+    for k in range(1, n + 1):
+        c = np.array([rs.uniform(0, s) for s in shape])
+        r = rs.uniform(2.5, 9.0, len(shape))
+        lab[(((grid - c) / r) ** 2).sum(-1) <= 1.0] = k if k != 5 else 40            # touching objects, a gap in the ids
+    return lab
+
+
+@pytest.mark.parametrize("shape,n,aniso", [((96, 120), 30, None), ((70, 64), 12, (1.5, 1.0)), ((14, 40, 48), 14, (2.0, 1.0, 1.0)),
+                                           ((1, 33, 40), 6, None), ((30, 1, 25), 4, (1.0, 3.0, 0.5))])
+def test_edt_prob_equals_exhaustive_oracle(shape, n, aniso):
+    import torch
+    from oracle import port
+    from stardist_amd import utils
+    lab = _blobs(shape, n, seed=len(shape) * 100 + n)
+    want = port.edt_prob(lab, anisotropy=aniso)
+    got = utils.edt_prob(lab, anisotropy=aniso)
+    assert got.dtype == np.float32 and got.shape == lab.shape
+    assert np.array_equal(got, want), float(np.abs(got - want).max())
+    t = utils.edt_prob(torch.from_numpy(lab).cuda(), anisotropy=aniso)                   # device tensor in -> device tensor out
+    assert t.is_cuda and np.array_equal(t.cpu().numpy(), want)
+    assert (got[lab == 0] == 0).all() and got.max() <= 1.0
