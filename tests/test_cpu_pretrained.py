@@ -60,3 +60,19 @@ def test_from_pretrained_loads_config_thresholds_and_weights(cls_name, key, tmp_
         with pytest.raises(FileNotFoundError) as e:
             cls.from_pretrained("Versatile (fluorescent nuclei)")          # registered, but neither cached nor downloadable offline
         assert "python_2D_versatile_fluo.zip" in str(e.value)
+
+
+@pytest.mark.parametrize("cls_name,key", [("StarDist2D", "fixture2d"), ("StarDist3D", "fixture3d")])
+def test_keras_layout_fixture_written_by_an_independent_script_loads_and_predicts(cls_name, key):
+    """tests/golden/make_keras_fixture.py (no stardist_amd import) writes Keras-named, Keras-layout weights in Keras' layer order and
+    the outputs of its own numpy forward pass (grid (2,2) U-Net: unnamed pre-convolutions + csbdeep block names; ResNet: 7x7x7 stem,
+    strided SAME-padded block convolutions, shortcut projection stored after the block's last convolution).  The loader maps them by
+    name / graph order with kernel transposition; the module must reproduce the independent evaluation."""
+    import stardist_amd.models as M
+    d = os.path.join(ROOT, "tests", "golden", "keras_fixture", cls_name)
+    m = getattr(M, cls_name)(config=None, name=key, basedir=d, device="cpu")
+    e = np.load(os.path.join(d, key, "expected.npz"))
+    prob, dist = m.predict(e["x"])[:2]
+    assert prob.shape == e["prob"].shape and dist.shape == e["dist"].shape
+    assert np.abs(prob - e["prob"]).max() <= 2e-6
+    assert np.abs(dist - np.maximum(e["dist"], 1e-3)).max() <= 2e-5 * max(1.0, float(np.abs(e["dist"]).max()))
