@@ -109,6 +109,11 @@ int sd_polygons_to_label_host(const float* coord, const int32_t* labels, int n_p
                               int H, int W, int32_t* result);
 int sd_polygons_to_label_device(const float* d_coord, const int32_t* d_labels, int n_polys,
                                 int n_rays, int H, int W, int32_t* d_result, void* stream);
+/* ... only the window [y0, y0 + H) x [x0, x0 + W) of an HI x WI image (d_result (H, W)): the pixels are the ones the whole-image
+ * call writes there -- each rank of a block-sharded prediction renders the write regions of its own blocks (stardist/big.py:319-326
+ * block.write) from the global polygon list. */
+int sd_polygons_to_label_window_device(const float* d_coord, const int32_t* d_labels, int n_polys, int n_rays, int HI, int WI,
+                                       int y0, int x0, int H, int W, int32_t* d_result, void* stream);
 
 /* ---- 3D non-maximum suppression -------------------------------------------------------------
  * name, signature and semantics of the reference's C ABI
@@ -154,6 +159,12 @@ int sd_polyhedron_to_label_device(const float* d_dist, const float* d_points,
                                   int n_rays, int n_faces, const int* d_labels, int nz, int ny,
                                   int nx, int render_mode, int verbose, int use_overlap_label,
                                   int overlap_label, int* d_result, void* stream);
+/* ... only the window [z0, z0 + nz) x [y0, y0 + ny) x [x0, x0 + nx) of an NZ x NY x NX volume; d_result (nz, ny, nx) must be
+ * zero-initialised by the caller like the whole-volume result (the implementation only writes inside polyhedra). */
+int sd_polyhedron_to_label_window_device(const float* d_dist, const float* d_points, const float* d_verts, const int* d_faces,
+                                         int n_polys, int n_rays, int n_faces, const int* d_labels, int NZ, int NY, int NX,
+                                         int z0, int y0, int x0, int nz, int ny, int nx, int render_mode, int verbose,
+                                         int use_overlap_label, int overlap_label, int* d_result, void* stream);
 
 /* ---- candidate selection --------------------------------------------------------------------
  * replaces the numpy glue stardist.nms._ind_prob_thresh + np.where + gather

@@ -239,8 +239,9 @@ def relabel_with_offset(labels, offset):
 def predict_instances_big(model, img, axes, block_size, min_overlap, context=None, labels_out=None, labels_out_dtype=np.int32,
                           show_progress=True, distributed=None, **kwargs):
     """StarDistBase.predict_instances_big (base.py:838-983) + round-robin sharding of the blocks over the ranks of the
-    default torch.distributed group (when initialised, or distributed=True).  Every rank returns the full object dict; the label
-    image is complete on rank 0 (or in the shared memmap / zarr array passed as labels_out), not replicated."""
+    default torch.distributed group (when initialised, or distributed=True).  Every rank returns the full object dict.  The label
+    image is NOT replicated: it is returned by rank 0 only (the other ranks return None for it and do not allocate it), or lives in
+    the shared memmap / zarr array passed as labels_out (returned by every rank)."""
     from .models.base import axes_check_and_normalize, axes_dict
     n = img.ndim
     axes = axes_check_and_normalize(axes, length=n)
@@ -278,13 +279,16 @@ def predict_instances_big(model, img, axes, block_size, min_overlap, context=Non
         pass
 
     want_labels = not (np.isscalar(labels_out) and bool(labels_out) is False)
+    owns_labels = True              # False on ranks != 0 of a multi-rank run without a shared labels_out: rank 0 alone holds the image
     if want_labels:
         if labels_out is None:
-            labels_out = np.zeros(shape_out, dtype=labels_out_dtype)
+            owns_labels = rank == 0 or world == 1
+            labels_out = np.zeros(shape_out, dtype=labels_out_dtype) if owns_labels else None
         elif tuple(labels_out.shape) != tuple(shape_out):
             raise ValueError("'labels_out' must have shape %s (axes %s)." % (shape_out, axes_out))
     else:
         labels_out = None
+    out_dtype = np.dtype(labels_out.dtype if labels_out is not None else labels_out_dtype)
 
     kwargs_override = dict(axes=axes, overlap_label=None, return_labels=True, return_predict=False)
     if show_progress:
@@ -323,6 +327,12 @@ def predict_instances_big(model, img, axes, block_size, min_overlap, context=Non
     #     point-to-point, rank 0 writes them in block order.  Total traffic = one image, to one rank.
     polys_blocks = {}
     shared_out = labels_out is not None and (isinstance(labels_out, np.memmap) or hasattr(labels_out, "store"))
+    # wire type of a label block: the output dtype (never narrower: label ids may exceed 2^31 in an int64 output)
+    import torch as _torch
+    wire = {np.dtype(np.int64): _torch.int64, np.dtype(np.uint32): _torch.int64, np.dtype(np.uint64): _torch.int64,
+            np.dtype(np.int16): _torch.int16, np.dtype(np.uint8): _torch.uint8}.get(out_dtype, _torch.int32)
+    if wire == _torch.int32 and out_dtype.itemsize <= 4 and len(offsets) and int(offsets[-1] + counts[-1]) >= 2 ** 31:
+        raise OverflowError("label ids exceed the int32 range of labels_out_dtype=%s" % out_dtype)
     for bi in sorted(mine):
         labels, polys = mine[bi]
         labels = relabel_with_offset(labels, int(offsets[bi]))
@@ -337,7 +347,8 @@ def predict_instances_big(model, img, axes, block_size, min_overlap, context=Non
                     if hasattr(labels_out, "flush"):
                         labels_out.flush()
                 dist_.barrier()
-        elif labels_out is not None:
+        elif want_labels:
+            np_wire = {_torch.int64: np.int64, _torch.int32: np.int32, _torch.int16: np.int16, _torch.uint8: np.uint8}[wire]
             for bi, block in enumerate(blocks):
                 owner = bi % world
                 shp = tuple(sl.stop - sl.start for sl in block.slice_crop_context(axes_out))
@@ -345,9 +356,9 @@ def predict_instances_big(model, img, axes, block_size, min_overlap, context=Non
                     if rank == 0:
                         block.write(labels_out, mine[bi][0].astype(labels_out.dtype, copy=False), axes=axes_out)
                 elif rank == owner:
-                    dist_.send(torch.from_numpy(np.ascontiguousarray(mine[bi][0].astype(np.int32))).to(dev), dst=0)
+                    dist_.send(torch.from_numpy(np.ascontiguousarray(mine[bi][0].astype(np_wire))).to(dev), dst=0)
                 elif rank == 0:
-                    buf = torch.empty(shp, dtype=torch.int32, device=dev)
+                    buf = torch.empty(shp, dtype=wire, device=dev)
                     dist_.recv(buf, src=owner)
                     block.write(labels_out, buf.cpu().numpy().astype(labels_out.dtype, copy=False), axes=axes_out)
         gathered = [None] * world
@@ -363,119 +374,57 @@ def predict_instances_big(model, img, axes, block_size, min_overlap, context=Non
         for k, v in polys_blocks[bi].items():
             polys_all.setdefault(k, []).append(v)
     polys_all = {k: (np.concatenate(v) if k in OBJECT_KEYS else v[0]) for k, v in polys_all.items()}
+    if want_labels and not owns_labels:
+        return None, polys_all                                      # the label image lives on rank 0
     return (labels_out if labels_out is not None else False), polys_all
 
 
-def _sharded_on_device(model, img, axes, axes_out, shape_out, blocks, dist_, rank, world, prob_thresh, nms_thresh, return_labels,
-                       predict_kwargs, nms_kwargs, broadcast_result):
-    """predict_instances_sharded with every candidate kept on the GPU from the selection kernel through the local NMS into the
-    collective: per block `predict_sparse_device` -> `_nms_sparse_device` -> write-region filter (torch), ONE all_gather of the
-    survivor counts and ONE padded all_gather of a packed float32 record [dist(R) | prob | centre(nd) | block id] per survivor
-    (141 B in 2D, 401 B + 8 in 3D; coordinates and block ids are < 2^24, exact in float32), de-duplication and canonical ordering
-    with torch sorts, final NMS + rasteriser on rank 0.  With the gloo backend (CPU tests) only the packed record visits the host.
-    Per-stage wall times and the gathered volume are left in model._last_sharded_stats."""
-    import time
-    import torch
-    dev = model.device
+def _exclusive_intervals(blocks, axes_out):
+    """per block and output axis: [lo, hi) = the part of the block's write region no other block's write region covers
+    (neighbouring write regions overlap by >= min_overlap, non-neighbouring ones never: Block.cover)"""
     nd = len(axes_out)
-    R = model.config.n_rays
-    st = dict(blocks=0, candidates=0, local_survivors=0, t_predict=0.0, t_local_nms=0.0, t_exchange=0.0, t_final=0.0, gathered=0, gathered_bytes=0)
-
-    def tick():
-        torch.cuda.synchronize(dev)
-        return time.perf_counter()
-    recs = []
-    for bi, block in enumerate(blocks):
-        if bi % world != rank:
-            continue
-        t0 = tick()
-        res = model.predict_sparse_device(block.read(img, axes=axes), axes=axes, prob_thresh=prob_thresh, **predict_kwargs)
-        prob, dist, points = res[0], res[1], res[-1]
-        t1 = tick()
-        st["blocks"] += 1; st["candidates"] += int(prob.numel()); st["t_predict"] += t1 - t0
-        if prob.numel() == 0:
-            continue
-        pts_s, prob_s, dist_s = model._nms_sparse_device(dist, prob, points, nms_thresh=nms_thresh, **nms_kwargs)
-        bl = block.blocks_for_axes(axes_out)
-        start = torch.tensor([t.start for t in bl], device=dev, dtype=torch.int64).reshape(1, nd)
-        lo = torch.tensor([t.start + t.context_start for t in bl], device=dev, dtype=torch.int64).reshape(1, nd)
-        hi = torch.tensor([t.end - t.context_end for t in bl], device=dev, dtype=torch.int64).reshape(1, nd)
-        gp = pts_s.to(torch.int64) + start
-        inside = torch.all((gp >= lo) & (gp < hi), dim=1)
-        n_in = int(inside.sum())
-        rec = torch.empty((n_in, R + 1 + nd + 1), dtype=torch.float32, device=dev)
-        rec[:, :R] = dist_s[inside].float(); rec[:, R] = prob_s[inside].float()
-        rec[:, R + 1:R + 1 + nd] = gp[inside].float(); rec[:, R + 1 + nd] = float(bi)
-        recs.append(rec)
-        st["local_survivors"] += n_in; st["t_local_nms"] += tick() - t1
-    rec = torch.cat(recs) if recs else torch.zeros((0, R + 1 + nd + 1), dtype=torch.float32, device=dev)
-
-    t0 = tick()
-    if dist_ is not None and world > 1:
-        on_host = dist_.get_backend() != "nccl"
-        cdev = torch.device("cpu") if on_host else dev
-        cnt = torch.tensor([rec.shape[0]], dtype=torch.int64, device=cdev)
-        cnts = [torch.zeros_like(cnt) for _ in range(world)]
-        dist_.all_gather(cnts, cnt)
-        cnts = [int(c.item()) for c in cnts]
-        cap = max(max(cnts), 1)
-        buf = torch.zeros((cap, rec.shape[1]), dtype=torch.float32, device=cdev)
-        buf[:rec.shape[0]] = rec.to(cdev)
-        out = [torch.empty_like(buf) for _ in range(world)]
-        dist_.all_gather(out, buf)
-        rec = torch.cat([o[:c] for o, c in zip(out, cnts)]).to(dev)
-        st["gathered_bytes"] = int(sum(cnts)) * rec.shape[1] * 4
-    st["gathered"] = int(rec.shape[0])
-    st["t_exchange"] = tick() - t0
-
-    t0 = tick()
-    # canonical order (block index, then the block's score order): the result does not depend on the number of ranks
-    order = torch.sort(rec[:, R + 1 + nd], stable=True)[1]
-    rec = rec[order]
-    pts = rec[:, R + 1:R + 1 + nd].to(torch.int64)
-    if rec.shape[0]:                                 # same pixel reported by two overlapping blocks: keep the first
-        key = pts[:, 0]
-        for d in range(1, nd):
-            key = key * int(shape_out[d]) + pts[:, d]
-        ks, ki = torch.sort(key, stable=True)
-        first = torch.ones_like(ks, dtype=torch.bool)
-        first[1:] = ks[1:] != ks[:-1]
-        sel = torch.sort(ki[first])[0]
-        rec, pts = rec[sel], pts[sel]
-    labels, res_dict = None, None
-    if rank == 0:
-        labels, res_dict = model._instances_from_prediction(shape_out, rec[:, R].contiguous(), rec[:, :R].contiguous(), points=pts,
-                                                            prob_thresh=prob_thresh, nms_thresh=nms_thresh, return_labels=return_labels, **nms_kwargs)
-    st["t_final"] = tick() - t0
-    model._last_sharded_stats = st
-    if broadcast_result and dist_ is not None and world > 1:
-        box = [res_dict]
-        dist_.broadcast_object_list(box, src=0)
-        res_dict = box[0]
-    return labels, res_dict
+    per_axis = [sorted(set((t.start + t.context_start, t.end - t.context_end) for b in blocks for t in [b.blocks_for_axes(axes_out)[a]])) for a in range(nd)]
+    out = np.empty((len(blocks), nd, 2), np.float64)
+    for bi, b in enumerate(blocks):
+        for a, t in enumerate(b.blocks_for_axes(axes_out)):
+            ws = per_axis[a]
+            k = ws.index((t.start + t.context_start, t.end - t.context_end))
+            out[bi, a, 0] = ws[k - 1][1] if k > 0 else -np.inf
+            out[bi, a, 1] = ws[k + 1][0] if k + 1 < len(ws) else np.inf
+    return out
 
 
 def predict_instances_sharded(model, img, axes, block_size, min_overlap, context=None, prob_thresh=None, nms_thresh=None,
-                              return_labels=True, show_progress=False, distributed=None, predict_kwargs=None, nms_kwargs=None,
-                              broadcast_result=True):
+                              return_labels=True, labels_out=None, show_progress=False, distributed=None, predict_kwargs=None,
+                              nms_kwargs=None, broadcast_result=True):
     """Block-sharded prediction with a final cross-tile NMS (SURVEY.md 8e design A, the north-star's multi-GPU path).
 
     The blocks of `BlockND.cover` (big.py:426-450) are dealt round-robin to the ranks of the default torch.distributed group
-    (one process per GPU; RCCL when the backend is "nccl").  Per block: network + candidate selection (`predict_sparse`) +
-    LOCAL NMS on the block incl. its context; of the local survivors a block keeps those whose centre lies in its write region
-    (= block minus context; neighbouring write regions overlap by >= min_overlap, so an object in an overlap band is seen
-    with full context by both blocks).  The kept survivors of all ranks -- 141 B (2D) / 401 B (3D) each -- are exchanged
-    with one all_gather of the counts and one padded all_gather per array; exact duplicates (same pixel reported by two
-    blocks) are dropped, then rank 0 runs the SAME NMS once more over the union in global score order (cross-tile conflicts
-    in the overlap bands) and rasterises the final instances.  Unlike `predict_instances_big` (design B, the reference's own semantics: per-block NMS +
-    bbox responsibility rule, no cross-tile NMS) label ids follow the global score order, as in `predict_instances`.
+    (one process per GPU; RCCL when the backend is "nccl").  Per block, on the owning rank and on the device: network + candidate
+    selection (`predict_sparse`) + LOCAL NMS on the block incl. its context; a block keeps the local survivors whose centre lies in its
+    write region (= block minus context; neighbouring write regions overlap by >= min_overlap, so an object in an overlap band is
+    seen with full context by both blocks).  Exchange: the kept survivors -- one packed float32 record
+    [dist(R) | prob | centre(nd) | block id | class probabilities] each, 141 B (2D) / 401 B (3D) + 4 -- go to rank 0 with ONE gather
+    (after an all_gather of the counts).  Rank 0 drops exact duplicates (same pixel reported by two blocks) and runs the SAME NMS
+    once more, restricted to the survivors that can meet a survivor of another block: two survivors of one block never suppress
+    each other (the local NMS kept both), so a survivor whose bounding box, grown by the largest bounding radius of all survivors,
+    stays inside the part of its block's write region that no other block covers is final as it is ("interior"); only the
+    "band" survivors enter the cross-tile NMS.  The result equals the NMS over the whole union.  The final instances, in global score
+    order (= label ids, as predict_instances numbers them), are broadcast, and every rank renders the write regions of ITS blocks
+    from that list (windowed rasteriser; pixels in overlapping write regions come out identical on both owners).
 
-    Returns (labels, dict) on rank 0 and (None, dict) on the other ranks (the label image is not broadcast)."""
+    Label image: `labels_out=None` -- the tiles are sent to rank 0, which returns the whole image (ranks != 0 return None);
+    a shared `np.memmap` / zarr-like array -- every rank writes its tiles in place (big.py:319-326 block.write), returned on every rank;
+    `labels_out="local"` -- nothing is moved: every rank returns [(block index, slices, tile), ...] for its blocks.
+    Unlike `predict_instances_big` (design B, the reference's own semantics: per-block NMS + bbox responsibility rule, no
+    cross-tile NMS) label ids follow the global score order.  Per-stage wall times and counters: model._last_sharded_stats.
+
+    Returns (labels, dict) on rank 0; (labels-or-None, dict) on the other ranks (dict None there with broadcast_result=False)."""
+    import time
+    import torch
     from .models.base import axes_check_and_normalize, axes_dict
     predict_kwargs = dict(predict_kwargs or {})
     nms_kwargs = dict(nms_kwargs or {})
-    if getattr(model.config, "n_classes", None) is not None:
-        raise NotImplementedError("predict_instances_sharded: multi-class heads are not supported yet")
     n = img.ndim
     axes = axes_check_and_normalize(axes, length=n)
     grid = model._axes_div_by(axes)
@@ -506,69 +455,206 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
             dist_, rank, world = td, td.get_rank(), td.get_world_size()
     except ImportError:
         pass
+    multi = dist_ is not None and world > 1
 
-    if hasattr(model, "predict_sparse_device") and getattr(model, "device", None) is not None and str(model.device).startswith("cuda"):
-        return _sharded_on_device(model, img, axes, axes_out, shape_out, blocks, dist_, rank, world, prob_thresh, nms_thresh, return_labels,
-                                  predict_kwargs, nms_kwargs, broadcast_result)
-
-    # ---- phase 1: my blocks -> local survivors inside the block's write region, global coordinates
+    # the product path keeps every candidate on the GPU (device tensors through selection, local NMS, exchange, final NMS, raster); a model
+    # without predict_sparse_device (the CPU tests' stand-in, whose kernels are the oracle) is driven through numpy at the same places
+    on_dev = hasattr(model, "predict_sparse_device") and str(getattr(model, "device", "cpu")).startswith("cuda")
+    dev = model.device if on_dev else torch.device("cpu")
     nd = len(axes_out)
-    k_pts, k_prob, k_dist, k_blk = [], [], [], []
+    R = model.config.n_rays
+    n_cls = (model.config.n_classes + 1) if getattr(model.config, "n_classes", None) is not None else 0
+    W = R + 1 + nd + 1 + n_cls                                      # record width
+    c_prob, c_pts, c_blk, c_cls = R, R + 1, R + 1 + nd, R + 2 + nd
+    st = dict(blocks=0, candidates=0, local_survivors=0, t_predict=0.0, t_local_nms=0.0, t_exchange=0.0, t_final=0.0, t_final_nms=0.0,
+              t_raster=0.0, gathered=0, gathered_bytes=0, unique=0, band=0, interior=0, instances=0)
+
+    def tick():
+        if on_dev:
+            torch.cuda.synchronize(dev)
+        return time.perf_counter()
+
+    def as_t(a, dtype=None):
+        t = a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(dev) if dtype is None else t.to(dev, dtype)
+
+    def local_nms(dist, prob, points):
+        """indices of the survivors, best score first"""
+        if on_dev:
+            return model._nms_sparse_device(dist, prob, points, nms_thresh=nms_thresh, **nms_kwargs)[3]
+        keep = model._nms_sparse(dist.numpy(), prob.numpy(), points.numpy(), nms_thresh=nms_thresh, **nms_kwargs)
+        return torch.from_numpy(np.asarray(keep).astype(np.int64))
+
+    # ---- phase 1: my blocks -> local survivors with their centre in the block's write region, global coordinates
+    recs = []
     for bi, block in enumerate(blocks):
         if bi % world != rank:
             continue
-        res = model.predict_sparse(block.read(img, axes=axes), axes=axes, prob_thresh=prob_thresh, **predict_kwargs)
-        prob, dist, points = np.asarray(res[0]), np.asarray(res[1]), np.asarray(res[-1])
-        if len(prob) == 0:
+        t0 = tick()
+        x = block.read(img, axes=axes)
+        res = (model.predict_sparse_device if on_dev else model.predict_sparse)(x, axes=axes, prob_thresh=prob_thresh, **predict_kwargs)
+        prob, dist, points = as_t(res[0]), as_t(res[1]), as_t(res[-1])
+        pcls = as_t(res[2]) if n_cls else None
+        t1 = tick()
+        st["blocks"] += 1; st["candidates"] += int(prob.numel()); st["t_predict"] += t1 - t0
+        if prob.numel() == 0:
             continue
-        keep = np.asarray(model._nms_sparse(dist, prob, points, nms_thresh=nms_thresh, **nms_kwargs)).astype(np.int64)
+        keep = local_nms(dist, prob, points)
         bl = block.blocks_for_axes(axes_out)
-        start = np.array([t.start for t in bl]).reshape(1, nd)
-        lo = np.array([t.start + t.context_start for t in bl]).reshape(1, nd)
-        hi = np.array([t.end - t.context_end for t in bl]).reshape(1, nd)
-        gp = points[keep].astype(np.int64) + start
-        inside = np.all((gp >= lo) & (gp < hi), axis=1)
-        k_pts.append(gp[inside]); k_prob.append(prob[keep][inside]); k_dist.append(dist[keep][inside])
-        k_blk.append(np.full(int(inside.sum()), bi, np.int64))
-    n_rays = model.config.n_rays
-    pts = np.concatenate(k_pts) if k_pts else np.zeros((0, nd), np.int64)
-    prob = np.concatenate(k_prob).astype(np.float32) if k_prob else np.zeros((0,), np.float32)
-    dst = np.concatenate(k_dist).astype(np.float32) if k_dist else np.zeros((0, n_rays), np.float32)
-    blk = np.concatenate(k_blk) if k_blk else np.zeros((0,), np.int64)
+        start = torch.tensor([t.start for t in bl], device=dev, dtype=torch.int64).reshape(1, nd)
+        lo = torch.tensor([t.start + t.context_start for t in bl], device=dev, dtype=torch.int64).reshape(1, nd)
+        hi = torch.tensor([t.end - t.context_end for t in bl], device=dev, dtype=torch.int64).reshape(1, nd)
+        gp = points[keep].to(torch.int64) + start
+        inside = torch.all((gp >= lo) & (gp < hi), dim=1)
+        keep, gp = keep[inside], gp[inside]
+        rec = torch.empty((int(keep.numel()), W), dtype=torch.float32, device=dev)
+        rec[:, :R] = dist[keep].float(); rec[:, c_prob] = prob[keep].float()
+        rec[:, c_pts:c_pts + nd] = gp.float(); rec[:, c_blk] = float(bi)     # coordinates and block ids are < 2^24: exact in float32
+        if n_cls:
+            rec[:, c_cls:] = pcls[keep].float()
+        recs.append(rec)
+        st["local_survivors"] += int(keep.numel()); st["t_local_nms"] += tick() - t1
+    rec = torch.cat(recs) if recs else torch.zeros((0, W), dtype=torch.float32, device=dev)
 
-    # ---- phase 2: exchange (counts, then padded arrays); every rank ends up with the union
-    if dist_ is not None and world > 1:
-        import torch
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist_.get_backend() == "nccl" else torch.device("cpu")
-        cnt = torch.tensor([len(prob)], dtype=torch.int64, device=dev)
+    # ---- phase 2: one gather of the records to rank 0 (counts first; padded to the largest rank)
+    t0 = tick()
+    cdev = dev
+    if multi:
+        cdev = dev if dist_.get_backend() == "nccl" else torch.device("cpu")
+        cnt = torch.tensor([rec.shape[0]], dtype=torch.int64, device=cdev)
         cnts = [torch.zeros_like(cnt) for _ in range(world)]
         dist_.all_gather(cnts, cnt)
         cnts = [int(c.item()) for c in cnts]
         cap = max(max(cnts), 1)
+        buf = torch.zeros((cap, W), dtype=torch.float32, device=cdev)
+        buf[:rec.shape[0]] = rec.to(cdev)
+        out = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+        dist_.gather(buf, out, dst=0)
+        if rank == 0:
+            rec = torch.cat([o[:c] for o, c in zip(out, cnts)]).to(dev)
+        st["gathered_bytes"] = int(sum(cnts)) * W * 4
+        st["gathered"] = int(sum(cnts))
+    else:
+        st["gathered"] = int(rec.shape[0])
+    st["t_exchange"] = tick() - t0
 
-        def exchange(a, dtype):
-            t = torch.zeros((cap,) + a.shape[1:], dtype=dtype, device=dev)
-            if len(a):
-                t[:len(a)] = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-            out = [torch.empty_like(t) for _ in range(world)]
-            dist_.all_gather(out, t)
-            return np.concatenate([o[:c].cpu().numpy() for o, c in zip(out, cnts)])
-        pts, prob, dst, blk = exchange(pts, torch.int64), exchange(prob, torch.float32), exchange(dst, torch.float32), exchange(blk, torch.int64)
-    # canonical order (block index, then the block's score order): the result does not depend on the number of ranks
-    order = np.argsort(blk, kind="stable")
-    pts, prob, dst = pts[order], prob[order], dst[order]
-    if len(pts):                                     # same pixel reported by two overlapping blocks: keep the first
-        _, first = np.unique(pts, axis=0, return_index=True)
-        first.sort()
-        pts, prob, dst = pts[first], prob[first], dst[first]
-
-    # ---- phase 3: rank 0: final NMS over the union + rasterisation
-    labels, res_dict = None, None
+    # ---- phase 3 (rank 0): duplicates, interior / band split, cross-tile NMS over the band, global score order
+    t0 = tick()
+    final = None
     if rank == 0:
-        labels, res_dict = model._instances_from_prediction(shape_out, prob, dst, points=pts, prob_thresh=prob_thresh, nms_thresh=nms_thresh,
-                                                            return_labels=return_labels, **nms_kwargs)
-    if dist_ is not None and world > 1:
-        box = [res_dict]
-        dist_.broadcast_object_list(box, src=0)
-        res_dict = box[0]
+        order = torch.sort(rec[:, c_blk], stable=True)[1]           # canonical order (block index, then the block's score order):
+        rec = rec[order]                                            # the result does not depend on the number of ranks
+        pts = rec[:, c_pts:c_pts + nd].to(torch.int64)
+        if rec.shape[0]:                                            # same pixel reported by two overlapping blocks: keep the first
+            key = pts[:, 0]
+            for d in range(1, nd):
+                key = key * int(shape_out[d]) + pts[:, d]
+            ks, ki = torch.sort(key, stable=True)
+            first = torch.ones_like(ks, dtype=torch.bool)
+            first[1:] = ks[1:] != ks[:-1]
+            sel = torch.sort(ki[first])[0]
+            rec, pts = rec[sel], pts[sel]
+        nU = int(rec.shape[0])
+        st["unique"] = nU
+        if nU:
+            vmax = 1.0
+            if nd == 3:
+                from .rays3d import rays_from_json
+                vmax = float(np.abs(rays_from_json(model.config.rays_json).vertices).max())
+            rad = rec[:, :R].amax(dim=1).double() * vmax + 1.0      # bounding radius per axis (+1: integer truncation / rounding of vertices)
+            margin = (rad + float(rad.max()) + 1.0).reshape(-1, 1)
+            ex = torch.from_numpy(_exclusive_intervals(blocks, axes_out)).to(dev)[rec[:, c_blk].to(torch.int64)]   # (nU, nd, 2)
+            c = pts.double()
+            interior = torch.all((c - margin >= ex[:, :, 0]) & (c + margin < ex[:, :, 1]), dim=1)
+        else:
+            interior = torch.zeros((0,), dtype=torch.bool, device=dev)
+        band = torch.nonzero(~interior).reshape(-1)
+        st["band"], st["interior"] = int(band.numel()), nU - int(band.numel())
+        t1 = tick()
+        keep_mask = interior.clone()
+        if band.numel():
+            kb = local_nms(rec[band, :R].contiguous(), rec[band, c_prob].contiguous(), pts[band].contiguous())
+            keep_mask[band[kb]] = True
+        st["t_final_nms"] = tick() - t1
+        from .nms import _argsort_desc
+        so = _argsort_desc(rec[:, c_prob])                          # the order predict_instances' NMS works in and returns
+        final = rec[so[keep_mask[so]]].contiguous()
+        st["instances"] = int(final.shape[0])
+    if multi and (return_labels or broadcast_result):               # the final instances to every rank (M x record)
+        m = torch.tensor([final.shape[0] if rank == 0 else 0], dtype=torch.int64, device=cdev)
+        dist_.broadcast(m, src=0)
+        fb = final.to(cdev) if rank == 0 else torch.empty((int(m.item()), W), dtype=torch.float32, device=cdev)
+        dist_.broadcast(fb, src=0)
+        final = fb.to(dev)
+
+    res_dict = None
+    f_pts = f_prob = f_dist = f_cls = None
+    if final is not None:
+        f_pts, f_prob, f_dist = final[:, c_pts:c_pts + nd].to(torch.int64), final[:, c_prob].contiguous(), final[:, :R].contiguous()
+        f_cls = final[:, c_cls:].contiguous() if n_cls else None
+        cv = (lambda t: t) if on_dev else (lambda t: None if t is None else t.numpy())
+        if rank == 0 or broadcast_result:
+            kw = dict(prob_class=cv(f_cls)) if n_cls else {}
+            res_dict = model._instances_from_survivors(shape_out, cv(f_pts), cv(f_prob), cv(f_dist), return_labels=False, **kw)[1]
+
+    # ---- phase 4: labels -- every rank renders the write regions of its blocks from the final list
+    t1 = tick()
+    labels = None
+    if return_labels and final is not None:
+        cv = (lambda t: t) if on_dev else (lambda t: t.numpy())
+        if not multi and not (isinstance(labels_out, str) and labels_out == "local"):
+            labels = model._instances_from_survivors(shape_out, cv(f_pts), cv(f_prob), cv(f_dist), return_labels=True)[0]
+            if labels_out is not None and not np.isscalar(labels_out):
+                labels_out[...] = labels
+                labels = labels_out
+        else:
+            tiles = []
+            for bi, block in enumerate(blocks):
+                if bi % world != rank:
+                    continue
+                bl = block.blocks_for_axes(axes_out)
+                sl = tuple(slice(t.start + t.context_start, t.end - t.context_end) for t in bl)
+                window = (tuple(s.start for s in sl), tuple(s.stop - s.start for s in sl))
+                tile = model._instances_from_survivors(shape_out, cv(f_pts), cv(f_prob), cv(f_dist), return_labels=True, window=window)[0]
+                tiles.append((bi, sl, as_t(tile)))
+            if nd == 3:                                             # relabel_sequential over the whole volume (model3d.py:646): ids that are
+                present = torch.zeros(int(final.shape[0]) + 1, dtype=torch.int32, device=dev)   # hidden everywhere are closed up
+                for _, _, t in tiles:
+                    present[torch.unique(t).to(torch.int64)] = 1
+                if multi:
+                    pc = present.to(cdev)
+                    dist_.all_reduce(pc, op=dist_.ReduceOp.MAX)
+                    present = pc.to(dev)
+                present[0] = 0
+                fwd = torch.cumsum(present, 0).to(torch.int32) * present
+                tiles = [(bi, sl, fwd[t.to(torch.int64)]) for bi, sl, t in tiles]
+            if isinstance(labels_out, str) and labels_out == "local":
+                labels = tiles
+            elif labels_out is not None and (isinstance(labels_out, np.memmap) or hasattr(labels_out, "store")):
+                for bi, sl, t in tiles:                             # overlapping write regions hold identical pixels: no ordering needed
+                    labels_out[sl] = t.cpu().numpy().astype(labels_out.dtype, copy=False)
+                if hasattr(labels_out, "flush"):
+                    labels_out.flush()
+                dist_.barrier()
+                labels = labels_out
+            else:                                                   # the whole image on rank 0: tiles point-to-point, in block order
+                if rank == 0:
+                    labels = np.zeros(shape_out, np.int32) if labels_out is None else labels_out
+                mine = {bi: (sl, t) for bi, sl, t in tiles}
+                for bi, block in enumerate(blocks):
+                    owner = bi % world
+                    bl = block.blocks_for_axes(axes_out)
+                    sl = tuple(slice(t.start + t.context_start, t.end - t.context_end) for t in bl)
+                    if owner == 0:
+                        if rank == 0:
+                            labels[sl] = mine[bi][1].cpu().numpy()
+                    elif rank == owner:
+                        dist_.send(mine[bi][1].to(torch.int32).contiguous().to(cdev), dst=0)
+                    elif rank == 0:
+                        buf = torch.empty(tuple(s.stop - s.start for s in sl), dtype=torch.int32, device=cdev)
+                        dist_.recv(buf, src=owner)
+                        labels[sl] = buf.cpu().numpy()
+    st["t_raster"] = tick() - t1
+    st["t_final"] = tick() - t0
+    model._last_sharded_stats = st
     return labels, res_dict

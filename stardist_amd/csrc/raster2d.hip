@@ -31,7 +31,8 @@ __device__ __forceinline__ int point_in_polygon(const double* xp, const double* 
   return (r_cross & 1) ? 1 : 0;
 }
 
-__global__ void __launch_bounds__(256) k_paint(const float* __restrict__ coord, int n_polys, int R, int H, int W,
+// paints the window [y0, y0 + H) x [x0, x0 + W) of an HI x WI image: pixel tests in image coordinates, stores window-relative
+__global__ void __launch_bounds__(256) k_paint(const float* __restrict__ coord, int n_polys, int R, int HI, int WI, int y0, int x0, int H, int W,
                                                int* __restrict__ img) {
   extern __shared__ double sv[];   // r[R] | c[R]
   double* sr = sv; double* scol = sv + R;
@@ -57,15 +58,19 @@ __global__ void __launch_bounds__(256) k_paint(const float* __restrict__ coord, 
     cmin = fminf(fminf(red[0][2], red[1][2]), fminf(red[2][2], red[3][2]));
     cmax = fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3]));
     // int(max(0, min)) truncates a non-negative value; ceil on the max; clip to the image
-    const long long minr = (long long)fmaxf(0.f, rmin), minc = (long long)fmaxf(0.f, cmin);
+    long long minr = (long long)fmaxf(0.f, rmin), minc = (long long)fmaxf(0.f, cmin);
     long long maxr = (long long)ceilf(rmax), maxc = (long long)ceilf(cmax);
-    if (maxr > H - 1) maxr = H - 1;
-    if (maxc > W - 1) maxc = W - 1;
+    if (maxr > HI - 1) maxr = HI - 1;
+    if (maxc > WI - 1) maxc = WI - 1;
+    if (minr < y0) minr = y0;
+    if (minc < x0) minc = x0;
+    if (maxr > y0 + H - 1) maxr = y0 + H - 1;
+    if (maxc > x0 + W - 1) maxc = x0 + W - 1;
     if (maxr < minr || maxc < minc) continue;
     const long long nr = maxr - minr + 1, nc = maxc - minc + 1;
     for (long long t = threadIdx.x; t < nr * nc; t += blockDim.x) {
       const int r_i = (int)(minr + t / nc), c_i = (int)(minc + t % nc);
-      if (point_in_polygon(scol, sr, R, (double)c_i, (double)r_i)) atomicMax(&img[(size_t)r_i * W + c_i], p + 1);
+      if (point_in_polygon(scol, sr, R, (double)c_i, (double)r_i)) atomicMax(&img[(size_t)(r_i - y0) * W + (c_i - x0)], p + 1);
     }
   }
 }
@@ -77,20 +82,26 @@ __global__ void k_map_labels(int* __restrict__ img, long long n, const int* __re
 
 }  // namespace
 
-extern "C" int sd_polygons_to_label_device(const float* d_coord, const int32_t* d_labels, int n_polys, int n_rays,
-                                           int H, int W, int32_t* d_result, void* stream) {
+extern "C" int sd_polygons_to_label_window_device(const float* d_coord, const int32_t* d_labels, int n_polys, int n_rays, int HI, int WI,
+                                                  int y0, int x0, int H, int W, int32_t* d_result, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (H <= 0 || W <= 0) return 0;
+  if (y0 < 0 || x0 < 0 || y0 + H > HI || x0 + W > WI) { sd::set_error("sd_polygons_to_label_window: window outside the image"); return -1; }
   SD_CHECK(hipMemsetAsync(d_result, 0, (size_t)H * W * sizeof(int32_t), s));
   if (n_polys <= 0 || n_rays <= 0) return 0;
   if ((size_t)n_rays * 2 * sizeof(double) > 60000) { sd::set_error("sd_polygons_to_label: n_rays=%d too large", n_rays); return -1; }
   const int blocks = n_polys < 65535 * 16 ? n_polys : 65535 * 16;
-  hipLaunchKernelGGL(k_paint, dim3(blocks), dim3(256), 2 * n_rays * sizeof(double), s, d_coord, n_polys, n_rays, H, W, d_result);
+  hipLaunchKernelGGL(k_paint, dim3(blocks), dim3(256), 2 * n_rays * sizeof(double), s, d_coord, n_polys, n_rays, HI, WI, y0, x0, H, W, d_result);
   SD_LAUNCH_CHECK();
   const long long n = (long long)H * W;
   hipLaunchKernelGGL(k_map_labels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_result, n, d_labels);
   SD_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int sd_polygons_to_label_device(const float* d_coord, const int32_t* d_labels, int n_polys, int n_rays,
+                                           int H, int W, int32_t* d_result, void* stream) {
+  return sd_polygons_to_label_window_device(d_coord, d_labels, n_polys, n_rays, H, W, 0, 0, H, W, d_result, stream);
 }
 
 extern "C" int sd_polygons_to_label_host(const float* coord, const int32_t* labels, int n_polys, int n_rays, int H, int W,

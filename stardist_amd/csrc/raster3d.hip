@@ -34,7 +34,8 @@ namespace {
 
 __global__ void __launch_bounds__(256) k_paint3d(const float* __restrict__ dist, const float* __restrict__ points,
                                                  const float* __restrict__ verts, const int* __restrict__ faces, int p0, int p1,
-                                                 int n_rays, int n_faces, int nz, int ny, int nx, int render_mode,
+                                                 int n_rays, int n_faces, int NZ, int NY, int NX, int z0, int y0, int x0, int nz, int ny, int nx,
+                                                 int render_mode,
                                                  int* __restrict__ first, int* __restrict__ count, int* __restrict__ result_dbg,
                                                  const double* __restrict__ hullPlanes, const int* __restrict__ hullCount, int hullCap,
                                                  int* __restrict__ hullFail) {
@@ -70,9 +71,10 @@ __global__ void __launch_bounds__(256) k_paint3d(const float* __restrict__ dist,
       for (int k = threadIdx.x; k < 4 * nh; k += blockDim.x) hh[k] = hullPlanes[(size_t)p * hullCap * 4 + k];
     }
     __syncthreads();
-    const int zlo = max(0, sb[0]), zhi = min(nz - 1, sb[1]);
-    const int ylo = max(0, sb[2]), yhi = min(ny - 1, sb[3]);
-    const int xlo = max(0, sb[4]), xhi = min(nx - 1, sb[5]);
+    // clipped to the volume (:1461-1463) and to the window [z0, z0 + nz) x [y0, y0 + ny) x [x0, x0 + nx) that is rendered
+    const int zlo = max(max(0, sb[0]), z0), zhi = min(min(NZ - 1, sb[1]), z0 + nz - 1);
+    const int ylo = max(max(0, sb[2]), y0), yhi = min(min(NY - 1, sb[3]), y0 + ny - 1);
+    const int xlo = max(max(0, sb[4]), x0), xhi = min(min(NX - 1, sb[5]), x0 + nx - 1);
     if (zhi < zlo || yhi < ylo || xhi < xlo) continue;
     const long long bz = zhi - zlo + 1, by = yhi - ylo + 1, bx = xhi - xlo + 1;
     const long long nvox = bz * by * bx;
@@ -103,10 +105,10 @@ __global__ void __launch_bounds__(256) k_paint3d(const float* __restrict__ dist,
         inside = true;
       } else if (render_mode == 4) {                                // "debug": flag kernel-but-not-polyhedron voxels with -1
         if (sd3::inside_polyhedron_kernel(z, y, x, pv, fc, n_faces) && !sd3::inside_polyhedron(z, y, x, cz, cy, cx, pv, fc, n_faces))
-          result_dbg[((size_t)zi * ny + yi) * nx + xi] = -1;
+          result_dbg[((size_t)(zi - z0) * ny + (yi - y0)) * nx + (xi - x0)] = -1;
       }
       if (inside) {
-        const size_t off = ((size_t)zi * ny + yi) * nx + xi;
+        const size_t off = ((size_t)(zi - z0) * ny + (yi - y0)) * nx + (xi - x0);
         atomicMin(&first[off], p);
         atomicAdd(&count[off], 1);
       }
@@ -144,11 +146,15 @@ __global__ void k_fill(int* a, long long n, int v) {
 
 }  // namespace
 
-extern "C" int sd_polyhedron_to_label_device(const float* d_dist, const float* d_points, const float* d_verts, const int* d_faces,
-                                             int n_polys, int n_rays, int n_faces, const int* d_labels, int nz, int ny, int nx,
-                                             int render_mode, int verbose, int use_overlap_label, int overlap_label,
-                                             int* d_result, void* stream) {
+extern "C" int sd_polyhedron_to_label_window_device(const float* d_dist, const float* d_points, const float* d_verts, const int* d_faces,
+                                                    int n_polys, int n_rays, int n_faces, const int* d_labels, int NZ, int NY, int NX, int z0,
+                                                    int y0, int x0, int nz, int ny, int nx, int render_mode, int verbose,
+                                                    int use_overlap_label, int overlap_label, int* d_result, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (z0 < 0 || y0 < 0 || x0 < 0 || z0 + nz > NZ || y0 + ny > NY || x0 + nx > NX) {
+    sd::set_error("sd_polyhedron_to_label_window: window outside the volume");
+    return -1;
+  }
   if (verbose >= 1) {
     printf("+++++++++++++++ polyhedra to label +++++++++++++++ \n");
     printf("n_polys           = %d \nn_rays            = %d \nn_faces           = %d \nnz, ny, nx        = %d %d %d \n", n_polys, n_rays, n_faces, nz, ny, nx);
@@ -186,7 +192,7 @@ extern "C" int sd_polyhedron_to_label_device(const float* d_dist, const float* d
     SD_CHECK(hipMemsetAsync(count, 0, nvox * sizeof(int), s));
     const int blocks = n_polys < 8192 ? n_polys : 8192;
     hipLaunchKernelGGL(k_paint3d, dim3(blocks), dim3(256), lds, s, d_dist, d_points, d_verts, d_faces, 0, n_polys, n_rays, n_faces,
-                       nz, ny, nx, render_mode, first, count, d_result, hullPlanes, hullCount, hullCapL, hullFail);
+                       NZ, NY, NX, z0, y0, x0, nz, ny, nx, render_mode, first, count, d_result, hullPlanes, hullCount, hullCapL, hullFail);
     SD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_resolve3d, dim3(gb), dim3(256), 0, s, d_result, first, count, nvox, d_labels, use_overlap_label, overlap_label);
     SD_LAUNCH_CHECK();
@@ -195,8 +201,8 @@ extern "C" int sd_polyhedron_to_label_device(const float* d_dist, const float* d
     for (int p = 0; p < n_polys; ++p) {
       hipLaunchKernelGGL(k_fill, dim3(gb), dim3(256), 0, s, first, nvox, INT_MAX);
       SD_CHECK(hipMemsetAsync(count, 0, nvox * sizeof(int), s));
-      hipLaunchKernelGGL(k_paint3d, dim3(1), dim3(256), lds, s, d_dist, d_points, d_verts, d_faces, p, p + 1, n_rays, n_faces, nz, ny,
-                         nx, render_mode, first, count, d_result, hullPlanes, hullCount, hullCapL, hullFail);
+      hipLaunchKernelGGL(k_paint3d, dim3(1), dim3(256), lds, s, d_dist, d_points, d_verts, d_faces, p, p + 1, n_rays, n_faces, NZ, NY, NX,
+                         z0, y0, x0, nz, ny, nx, render_mode, first, count, d_result, hullPlanes, hullCount, hullCapL, hullFail);
       hipLaunchKernelGGL(k_resolve3d_seq, dim3(gb), dim3(256), 0, s, d_result, first, count, nvox, h_labels[p], use_overlap_label, overlap_label);
       SD_LAUNCH_CHECK();
     }
@@ -208,6 +214,14 @@ extern "C" int sd_polyhedron_to_label_device(const float* d_dist, const float* d
     if (hf) { sd::set_error("sd_polyhedron_to_label: the convex hull of %d polyhedra could not be built (degenerate vertices; Qhull raises here)", hf); return -1; }
   }
   return 0;
+}
+
+extern "C" int sd_polyhedron_to_label_device(const float* d_dist, const float* d_points, const float* d_verts, const int* d_faces,
+                                             int n_polys, int n_rays, int n_faces, const int* d_labels, int nz, int ny, int nx,
+                                             int render_mode, int verbose, int use_overlap_label, int overlap_label,
+                                             int* d_result, void* stream) {
+  return sd_polyhedron_to_label_window_device(d_dist, d_points, d_verts, d_faces, n_polys, n_rays, n_faces, d_labels, nz, ny, nx, 0, 0, 0, nz,
+                                              ny, nx, render_mode, verbose, use_overlap_label, overlap_label, d_result, stream);
 }
 
 extern "C" void _LIB_polyhedron_to_label(const float* dist, const float* points, const float* verts, const int* faces,

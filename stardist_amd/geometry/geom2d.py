@@ -46,8 +46,9 @@ def dist_to_coord(dist, points, scale_dist=(1, 1)):
     return coord
 
 
-def polygons_to_label_coord(coord, shape, labels=None):
-    """geom2d.py:149-166: paint polygons in the given order (later overwrite earlier), value labels[i]+1."""
+def polygons_to_label_coord(coord, shape, labels=None, window=None):
+    """geom2d.py:149-166: paint polygons in the given order (later overwrite earlier), value labels[i]+1.
+    window = ((y0, x0), (h, w)) (device tensors): only that part of the image is rendered and returned."""
     from ..lib.stardist2d import c_polygons_to_label
     assert coord.ndim == 3 and coord.shape[1] == 2
     n = len(coord)
@@ -56,7 +57,13 @@ def polygons_to_label_coord(coord, shape, labels=None):
         if labels is None:
             labels = torch.arange(n, device=coord.device)
         assert len(labels) == n
-        return c_polygons_to_label(coord, labels.to(torch.int32), shape)
+        if window is not None and n:                               # polygons whose bounding box misses the window are dropped up front
+            (y0, x0), (h, w) = window
+            lo, hi = coord.amin(dim=2), coord.amax(dim=2)
+            hit = (hi[:, 0] >= y0 - 1) & (lo[:, 0] <= y0 + h) & (hi[:, 1] >= x0 - 1) & (lo[:, 1] <= x0 + w)
+            coord, labels = coord[hit], labels[hit]
+        return c_polygons_to_label(coord, labels.to(torch.int32), shape, window=window)
+    assert window is None, "window rendering takes device tensors"
     coord = np.asarray(coord)
     if labels is None:
         labels = np.arange(n)
@@ -67,7 +74,7 @@ def polygons_to_label_coord(coord, shape, labels=None):
     return c_polygons_to_label(coord, labels.astype(np.int32), shape)
 
 
-def polygons_to_label(dist, points, shape, prob=None, thr=-np.inf, scale_dist=(1, 1)):
+def polygons_to_label(dist, points, shape, prob=None, thr=-np.inf, scale_dist=(1, 1), window=None):
     """geom2d.py:169-197: label ids are consecutive and adhere to the order given."""
     assert dist.ndim == 2 and points.ndim == 2 and len(dist) == len(points) and points.shape[1] == 2
     if N.is_torch(dist):
@@ -78,7 +85,8 @@ def polygons_to_label(dist, points, shape, prob=None, thr=-np.inf, scale_dist=(1
         ind = torch.sort(prob, stable=True)[1]
         points, dist = points[ind], dist[ind]
         coord = dist_to_coord(dist, points, scale_dist=scale_dist)
-        return polygons_to_label_coord(coord, shape=shape, labels=ind)
+        return polygons_to_label_coord(coord, shape=shape, labels=ind, window=window)
+    assert window is None, "window rendering takes device tensors"
     dist = np.asarray(dist); points = np.asarray(points)
     prob = np.inf * np.ones(len(points)) if prob is None else np.asarray(prob)
     assert len(points) == len(prob) and prob.ndim == 1

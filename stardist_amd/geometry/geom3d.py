@@ -22,8 +22,9 @@ def star_dist3D(lbl, rays, grid=(1, 1, 1), mode="hip"):
 
 
 def polyhedron_to_label(dist, points, rays, shape, prob=None, thr=-np.inf, labels=None, mode="full", verbose=True,
-                        overlap_label=None):
-    """geom3d.py:100-198: filters prob >= thr, sorts by descending prob, paints first-writer-wins."""
+                        overlap_label=None, window=None):
+    """geom3d.py:100-198: filters prob >= thr, sorts by descending prob, paints first-writer-wins.
+    window = ((z0, y0, x0), (nz, ny, nx)) (device tensors): only that part of the volume is rendered and returned."""
     from ..lib.stardist3d import c_polyhedron_to_label
     if len(points) == 0:
         if verbose:
@@ -53,9 +54,16 @@ def polyhedron_to_label(dist, points, rays, shape, prob=None, thr=-np.inf, label
         points, dist, labels = points[ind], dist[ind], labels[ind]
         verts = torch.as_tensor(np.ascontiguousarray(rays.vertices, np.float32), device=dev)
         faces = torch.as_tensor(np.ascontiguousarray(rays.faces, np.int32), device=dev)
+        if window is not None:                                     # polyhedra whose bounding box misses the window are dropped up front
+            o = torch.tensor(window[0], device=dev, dtype=torch.float32); e = o + torch.tensor(window[1], device=dev, dtype=torch.float32)
+            reach = dist.float().amax(dim=1, keepdim=True) * verts.abs().amax(dim=0, keepdim=True) + 2.0
+            pf = points.float()
+            hit = torch.all((pf + reach >= o) & (pf - reach <= e), dim=1)
+            points, dist, labels = points[hit], dist[hit], labels[hit]
         return c_polyhedron_to_label(dist.float().contiguous(), points.float().contiguous(), verts, faces, labels.to(torch.int32).contiguous(),
                                      np.int32(modes[mode]), np.int32(verbose), np.int32(overlap_label is not None),
-                                     np.int32(0 if overlap_label is None else overlap_label), shape)
+                                     np.int32(0 if overlap_label is None else overlap_label), shape, window=window)
+    assert window is None, "window rendering takes device tensors"
     dist = np.asanyarray(dist); points = np.asanyarray(points)
     if dist.ndim == 1: dist = dist.reshape(1, -1)
     if points.ndim == 1: points = points.reshape(1, -1)

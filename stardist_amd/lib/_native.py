@@ -43,6 +43,8 @@ SIGNATURES = {
     "sd_edt_prob_device": (_i, [_vp, _i, _i, _i, ctypes.c_double, ctypes.c_double, ctypes.c_double, _i, _vp, _vp]),
     "sd_polygons_to_label_host": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sd_polygons_to_label_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "sd_polygons_to_label_window_device": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sd_polyhedron_to_label_window_device": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp] + [_i] * 13 + [_vp, _vp]),
     "_LIB_non_maximum_suppression_sparse": (None, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _i, _i, _i, _vp]),
     "sd_nms3d_device": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp]),
     "sd_hiv_pairs_device": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

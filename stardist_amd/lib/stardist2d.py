@@ -59,9 +59,10 @@ def c_star_dist(src, n_rays, grid_y, grid_x):
     return dst
 
 
-def c_polygons_to_label(coord, labels, shape):
+def c_polygons_to_label(coord, labels, shape, window=None):
     """New native for the reference's Python rasteriser loop (geom2d.py:149-166).
-    coord (n,2,R) f32 painted in order, value labels[i]+1; returns int32 (H,W)."""
+    coord (n,2,R) f32 painted in order, value labels[i]+1; returns int32 (H,W).
+    window = ((y0, x0), (h, w)) (device tensors only): just that part of the `shape` image is rendered and returned."""
     N.require_device()
     H, W = int(shape[0]), int(shape[1])
     if N.is_torch(coord):
@@ -69,9 +70,12 @@ def c_polygons_to_label(coord, labels, shape):
         coord = coord.contiguous().float()
         labels = labels.contiguous().to(torch.int32)
         n, _, R = coord.shape
-        out = torch.empty((H, W), dtype=torch.int32, device=coord.device)
-        N.dcall(coord, "sd_polygons_to_label_device", N.tptr(coord), N.tptr(labels), n, R, H, W, N.tptr(out))
+        (y0, x0), (h, w) = ((0, 0), (H, W)) if window is None else window
+        out = torch.empty((int(h), int(w)), dtype=torch.int32, device=coord.device)
+        N.dcall(coord, "sd_polygons_to_label_window_device", N.tptr(coord), N.tptr(labels), n, R, H, W, int(y0), int(x0), int(h), int(w), N.tptr(out))
         return out
+    if window is not None:
+        raise ValueError("window rendering takes device tensors")
     coord = np.ascontiguousarray(coord, np.float32)
     labels = np.ascontiguousarray(labels, np.int32)
     n = coord.shape[0]

@@ -41,20 +41,24 @@ def c_non_max_suppression_inds(dist, points, verts, faces, scores, use_bbox, use
     return (keep, stats) if return_stats else keep
 
 
-def c_polyhedron_to_label(dist, points, verts, faces, labels, render_mode, verbose, use_overlap_label, overlap_label, shape):
-    """stardist3d.cpp:82-143 -> stardist3d_impl.cpp:1404-1525. Returns a new zero-initialised int32 (nz,ny,nx) volume."""
+def c_polyhedron_to_label(dist, points, verts, faces, labels, render_mode, verbose, use_overlap_label, overlap_label, shape, window=None):
+    """stardist3d.cpp:82-143 -> stardist3d_impl.cpp:1404-1525. Returns a new zero-initialised int32 (nz,ny,nx) volume.
+    window = ((z0, y0, x0), (nz, ny, nx)) (device tensors only): just that part of the `shape` volume is rendered and returned."""
     N.require_device()
     nz, ny, nx = (int(v) for v in shape)
     if N.is_torch(dist):
         import torch
         dist = dist.contiguous().float(); points = points.contiguous().float()
         verts = verts.contiguous().float(); faces = faces.contiguous().to(torch.int32); labels = labels.contiguous().to(torch.int32)
-        out = torch.zeros((nz, ny, nx), dtype=torch.int32, device=dist.device)
+        (z0, y0, x0), (wz, wy, wx) = ((0, 0, 0), (nz, ny, nx)) if window is None else window
+        out = torch.zeros((wz, wy, wx), dtype=torch.int32, device=dist.device)
         if dist.shape[0]:
-            N.dcall(dist, "sd_polyhedron_to_label_device", N.tptr(dist), N.tptr(points), N.tptr(verts), N.tptr(faces), dist.shape[0],
-                                                          dist.shape[1], faces.shape[0], N.tptr(labels), nz, ny, nx, int(render_mode),
-                                                          int(verbose), int(use_overlap_label), int(overlap_label), N.tptr(out))
+            N.dcall(dist, "sd_polyhedron_to_label_window_device", N.tptr(dist), N.tptr(points), N.tptr(verts), N.tptr(faces), dist.shape[0],
+                    dist.shape[1], faces.shape[0], N.tptr(labels), nz, ny, nx, int(z0), int(y0), int(x0), int(wz), int(wy), int(wx),
+                    int(render_mode), int(verbose), int(use_overlap_label), int(overlap_label), N.tptr(out))
         return out
+    if window is not None:
+        raise ValueError("window rendering takes device tensors")
     dist = np.ascontiguousarray(dist, np.float32); points = np.ascontiguousarray(points, np.float32)
     verts = np.ascontiguousarray(verts, np.float32); faces = np.ascontiguousarray(faces, np.int32)
     labels = np.ascontiguousarray(labels, np.int32)

@@ -39,6 +39,11 @@ class StarDist2D(StarDistBase):
             if prob_class is not None:
                 inds = tuple(p // g for p, g in zip(points.T, self.config.grid))
                 prob_class = prob_class[inds]
+        return self._instances_from_survivors(img_shape, points, probi, disti, prob_class=prob_class, return_labels=return_labels, scale=scale)
+
+    def _instances_from_survivors(self, img_shape, points, probi, disti, prob_class=None, return_labels=True, scale=None, window=None):
+        """the part of model2d.py:536-563 behind the NMS: label image and result dict of survivors given best score first.
+        window = ((y0, x0), (h, w)): only that part of the label image is rendered (block-sharded prediction, stardist_amd/big.py)."""
         if scale is not None:
             if not (isinstance(scale, dict) and "X" in scale and "Y" in scale):
                 raise ValueError("scale must be a dictionary with entries for 'X' and 'Y'")
@@ -51,16 +56,18 @@ class StarDist2D(StarDistBase):
         else:
             rescale = (1, 1)
         if return_labels:
-            labels = polygons_to_label(disti, points, prob=probi, shape=img_shape, scale_dist=rescale)
+            labels = polygons_to_label(disti, points, prob=probi, shape=img_shape, scale_dist=rescale, window=window)
         else:
             labels = None
+        if window is not None:
+            return labels, None
         coord = dist_to_coord(disti, points, scale_dist=rescale)
         to_np = (lambda t: t.cpu().numpy()) if N.is_torch(coord) else (lambda t: t)
         if labels is not None and N.is_torch(labels):
             labels = to_host(labels)
         res_dict = dict(coord=to_np(coord), points=to_np(points), prob=to_np(probi))
         if prob_class is not None:
-            prob_class = np.asarray(to_np(prob_class))
+            prob_class = np.asarray(to_np(prob_class) if N.is_torch(prob_class) else prob_class)
             class_id = np.argmax(prob_class, axis=-1)
             res_dict.update(dict(class_prob=prob_class, class_id=class_id))
         return labels, res_dict
@@ -76,7 +83,7 @@ class StarDist2D(StarDistBase):
         the device (used by the sharded predictor: no host round trip between selection, local NMS and the RCCL gather)"""
         if nms_thresh is None: nms_thresh = self.thresholds.nms
         r = non_maximum_suppression_sparse(dist, prob, points, nms_thresh=nms_thresh, **nms_kwargs)
-        return r[0], r[1], r[2]
+        return r[0], r[1], r[2], r[3]
 
     def _axes_div_by(self, query_axes):
         """model2d.py:566-574"""

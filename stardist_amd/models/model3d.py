@@ -45,6 +45,16 @@ class StarDist3D(StarDistBase):
                 prob_class = tonp(prob_class)[inds]
         verbose = nms_kwargs.get("verbose", False)
         verbose and print("render polygons...")
+        return self._instances_from_survivors(img_shape, points, probi, disti, prob_class=prob_class, return_labels=return_labels, scale=scale,
+                                              overlap_label=overlap_label, verbose=verbose, rays=rays)
+
+    def _instances_from_survivors(self, img_shape, points, probi, disti, prob_class=None, return_labels=True, scale=None, overlap_label=None,
+                                  verbose=False, rays=None, window=None):
+        """the part of model3d.py:616-674 behind the NMS: label volume (polyhedron rasteriser + relabel_sequential) and result dict of
+        survivors given best score first.  window = ((z0, y0, x0), (nz, ny, nx)): only that part of the volume is rendered, with the
+        polyhedra's running numbers as labels (the block-sharded prediction compacts them globally, stardist_amd/big.py)."""
+        if rays is None:
+            rays = rays_from_json(self.config.rays_json)
         if scale is not None:
             if not (isinstance(scale, dict) and "X" in scale and "Y" in scale and "Z" in scale):
                 raise ValueError("scale must be a dictionary with entries for 'X', 'Y', and 'Z'")
@@ -55,6 +65,9 @@ class StarDist3D(StarDistBase):
             else:
                 points = points * np.array(rescale).reshape(1, 3)
             rays = rays.copy(scale=rescale)
+        if window is not None:
+            return polyhedron_to_label(disti, points, rays=rays, prob=probi, shape=img_shape, overlap_label=overlap_label, verbose=verbose,
+                                       window=window), None
         if return_labels:
             labels = polyhedron_to_label(disti, points, rays=rays, prob=probi, shape=img_shape, overlap_label=overlap_label, verbose=verbose)
             if N.is_torch(labels):
@@ -99,7 +112,7 @@ class StarDist3D(StarDistBase):
         if nms_thresh is None: nms_thresh = self.thresholds.nms
         rays = rays_from_json(self.config.rays_json)
         r = non_maximum_suppression_3d_sparse(dist, prob, points, rays, nms_thresh=nms_thresh, **nms_kwargs)
-        return r[0], r[1], r[2]
+        return r[0], r[1], r[2], r[3]
 
     def _axes_div_by(self, query_axes):
         """model3d.py:677-690"""

@@ -92,7 +92,9 @@ def _worker(rank, world, port, q, memmap_path):
     if memmap_path:      # the streaming form: every rank opens the same file and writes the write regions of its own blocks
         out = np.lib.format.open_memmap(memmap_path, mode="r+")
     labels, polys = predict_instances_big(_FakeModel(2, 1), gt, "YX", 64, 16, context=8, show_progress=False, labels_out=out)
-    q.put((rank, None if memmap_path else np.asarray(labels), polys["points"], polys["prob"]))
+    if not memmap_path:
+        assert (labels is None) == (rank != 0), "without a shared labels_out the label image lives on rank 0 only (ADVICE r2)"
+    q.put((rank, None if (memmap_path or labels is None) else np.asarray(labels), polys["points"], polys["prob"]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -157,10 +159,15 @@ class _FieldModel(object):
         return ind[keep]
 
     def _instances_from_prediction(self, shape, prob, dist, points=None, prob_thresh=None, nms_thresh=None, return_labels=True, **kw):
-        from oracle import port
         s = self._nms_sparse(dist, prob, points, nms_thresh)
-        d, p, pr = dist[s], points[s], prob[s]
+        return self._instances_from_survivors(shape, points[s], prob[s], dist[s], return_labels=return_labels)
+
+    def _instances_from_survivors(self, shape, p, pr, d, return_labels=True, window=None, **kw):
+        from oracle import port
         labels = port.polygons_to_label(d, p, shape, prob=pr) if return_labels else None
+        if window is not None:
+            (y0, x0), (h, w) = window
+            return labels[y0:y0 + h, x0:x0 + w].copy(), None
         return labels, dict(coord=port.dist_to_coord(d, p), points=p, prob=pr)
 
 
@@ -177,7 +184,7 @@ def _field(shape=(192, 224), seed=3):
     return np.concatenate([prob[..., None], dist.astype(np.float32)], -1), lbl
 
 
-def _sharded_worker(rank, world, port_, q):
+def _sharded_worker(rank, world, port_, q, mm_path=None):
     import torch.distributed as dist
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port_)
@@ -185,13 +192,19 @@ def _sharded_worker(rank, world, port_, q):
     from stardist_amd.big import predict_instances_sharded
     from test_cpu_big import _FieldModel, _field
     x, _ = _field()
-    labels, res = predict_instances_sharded(_FieldModel(), x, "YXC", 96, 32, context=16)
-    q.put((rank, labels, res["points"], res["prob"]))
+    m = _FieldModel()
+    labels, res = predict_instances_sharded(m, x, "YXC", 96, 32, context=16)
+    st = dict(m._last_sharded_stats)
+    # rank-local tiles (nothing moved) and a shared memmap written by the owners
+    tiles, _ = predict_instances_sharded(m, x, "YXC", 96, 32, context=16, labels_out="local")
+    mm = np.load(mm_path, mmap_mode="r+")
+    predict_instances_sharded(m, x, "YXC", 96, 32, context=16, labels_out=mm)
+    q.put((rank, labels, res["points"], res["prob"], [(bi, tuple((s.start, s.stop) for s in sl), t.numpy()) for bi, sl, t in tiles], st))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_cross_tile_nms_equals_whole_image(refmods):
+def test_sharded_cross_tile_nms_equals_whole_image(refmods, tmp_path):
     """design A: per-block local NMS + survivor exchange + final NMS on rank 0 == predict_instances on the whole image"""
     from stardist_amd.big import predict_instances_sharded
     m = _FieldModel()
@@ -199,22 +212,36 @@ def test_sharded_cross_tile_nms_equals_whole_image(refmods):
     p, d, pts = m.predict_sparse(x)
     ref_labels, ref_res = m._instances_from_prediction(x.shape[:2], p, d, points=pts)
     assert len(ref_res["prob"]) >= 0.9 * lbl.max() > 10
-    labels, res = predict_instances_sharded(m, x, "YXC", 96, 32, context=16)              # single process, 9 blocks
+    labels, res = predict_instances_sharded(m, x, "YXC", 96, 32, context=16)              # single process, 20 blocks
     assert np.array_equal(res["points"], ref_res["points"]) and np.array_equal(labels, ref_labels)
+    st = m._last_sharded_stats
+    # the cross-tile NMS only sees the survivors near a write-region boundary; the others are final after their block's NMS
+    assert st["band"] + st["interior"] == st["unique"] <= st["gathered"] and st["interior"] > 0 and st["band"] > 0 and st["instances"] == len(ref_res["prob"])
+    tiles, _ = predict_instances_sharded(m, x, "YXC", 96, 32, context=16, labels_out="local")
+    assert len(tiles) == 20 and all(np.array_equal(t.numpy(), ref_labels[sl]) for _, sl, t in tiles)
     import torch.multiprocessing as mp
+    mm_path = str(tmp_path / "labels.npy")
+    mm = np.lib.format.open_memmap(mm_path, mode="w+", dtype=np.int32, shape=x.shape[:2]); mm[...] = 0; mm.flush(); del mm
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port_ = 29950 + os.getpid() % 40
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port_, q)) for r in range(2)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port_, q, mm_path)) for r in range(2)]
     for pr in procs: pr.start()
     out = [q.get(timeout=240) for _ in range(2)]
     for pr in procs: pr.join(60)
-    for rank, lab, pts2, prob2 in out:
+    seen = set()
+    for rank, lab, pts2, prob2, tiles2, st2 in out:
         assert np.array_equal(pts2, ref_res["points"]) and np.allclose(prob2, ref_res["prob"]), rank
         if rank == 0:
             assert np.array_equal(lab, ref_labels)
+            assert st2["gathered"] == st["gathered"] and st2["band"] == st["band"] and st2["gathered_bytes"] == st["gathered"] * (32 + 1 + 2 + 1) * 4
         else:
             assert lab is None
+        for bi, sl, t in tiles2:                                  # every rank rendered the write regions of ITS blocks, with global ids
+            assert bi % 2 == rank and np.array_equal(t, ref_labels[tuple(slice(a, b) for a, b in sl)])
+            seen.add(bi)
+    assert seen == set(range(20))
+    assert np.array_equal(np.load(mm_path), ref_labels)
 
 
 @pytest.mark.parametrize("name,axes", [("2d", "YX"), ("2dg", "YX"), ("3d", "ZYX")])

@@ -130,3 +130,47 @@ def test_predict_instances_sharded_single_rank_equals_whole_image():
     d = np.sqrt(((a[:, None] - b[None]) ** 2).sum(-1)).min(1)
     assert (d <= 1.5).mean() >= 0.98
     assert np.count_nonzero((ls > 0) != (l1 > 0)) <= 2e-3 * l1.size
+
+
+@pytest.mark.parametrize("dim", ["2d", "3d", "2d-multiclass"])
+def test_sharded_window_tiles_equal_whole_image_raster_and_band_nms_equals_union_nms(dim):
+    """design A on the device: (1) the tiles every rank renders for the write regions of its blocks (windowed rasterisers, 3D incl. the
+    global relabel_sequential) are the corresponding parts of the label image the whole-image rasteriser produces from the same
+    final instances; (2) restricting the cross-tile NMS to the band survivors gives the instances of an NMS over the whole union
+    (the round-2 formulation); (3) multi-class: class probabilities travel with the survivors."""
+    import torch
+    import bench
+    from oracle import synth
+    from stardist_amd.models import Config2D, Config3D, StarDist2D, StarDist3D
+    dev = torch.device("cuda:0")
+    if dim == "3d":
+        img = synth.s3d_nuclei_image(96, seed=5)
+        model = StarDist3D(Config3D(rays=96), basedir=None, device=dev, seed=0)
+        model.thresholds = dict(prob=0.5, nms=0.3)
+        bench.calibrate_heads(model, torch.from_numpy(img).to(dev), frac=0.02, radius=8.5, noise=0.03)
+        args = dict(axes="ZYX", block_size=64, min_overlap=16, context=8)
+    else:
+        img = synth.s2d_nuclei_image(768, 1024, seed=5)
+        model = StarDist2D(Config2D(n_rays=32, n_classes=(3 if dim == "2d-multiclass" else None)), basedir=None, device=dev, seed=0)
+        bench.calibrate_heads(model, torch.from_numpy(img).to(dev), frac=0.05)
+        args = dict(axes="YX", block_size=384, min_overlap=64, context=64)
+    labels, res = model.predict_instances_sharded(img, **args)
+    st = dict(model._last_sharded_stats)
+    assert st["band"] + st["interior"] == st["unique"] and st["interior"] > 0 and st["band"] > 0 and st["instances"] == len(res["prob"]) > 20
+    tiles, res2 = model.predict_instances_sharded(img, labels_out="local", **args)
+    assert np.array_equal(res2["points"], res["points"]) and len(tiles) == st["blocks"]
+    for bi, sl, t in tiles:
+        assert np.array_equal(t.cpu().numpy(), labels[sl]), bi
+    if dim == "2d-multiclass":
+        assert res["class_prob"].shape == (len(res["prob"]), 4) and np.allclose(res["class_prob"].sum(1), 1, atol=1e-5)
+        assert np.array_equal(res["class_id"], res["class_prob"].argmax(1))
+    # (2): all survivors through the final NMS -- force every survivor into the band by a huge margin
+    import stardist_amd.big as B
+    orig = B._exclusive_intervals
+    B._exclusive_intervals = lambda blocks, axes_out: np.stack([np.full((len(blocks), len(axes_out)), np.inf), np.full((len(blocks), len(axes_out)), -np.inf)], -1)
+    try:
+        labels_u, res_u = model.predict_instances_sharded(img, **args)
+        assert model._last_sharded_stats["interior"] == 0
+    finally:
+        B._exclusive_intervals = orig
+    assert np.array_equal(res_u["points"], res["points"]) and np.array_equal(res_u["prob"], res["prob"]) and np.array_equal(labels_u, labels)
