@@ -10,8 +10,13 @@ NMS -> label rasteriser -> labels + survivor dict back on the host.
   second leg (value_3d, Mvox/s): configs[2], StarDist3D Rays_GoldenSpiral(96) on a 256^3 volume
   (runs in the same invocation after the 2D leg; `--skip-3d` drops it).
 
-N > 1: one process per GPU (torchrun), every rank owns its own input of the same size ("weak"
-scaling: independent tiles, no data-path collective); value = all ranks' pixels / max-over-ranks time.
+Every run also reports BASELINE.json configs 4/5 -- `sharded_2d` (one 16384^2 slide) and `sharded_3d` (one 1024^3 volume) through
+predict_instances_sharded: blocks dealt over the ranks, local NMS, one gather of the survivors, cross-tile NMS over the band on rank
+0, write regions rendered by their owners -- with t_predict / t_local_nms / t_exchange / t_final, gathered count and bytes.
+
+N = 1: `value` is the 2048^2 tile leg (configs[1]).  N > 1 (one process per GPU, torchrun): `value` is the sharded 16384^2 slide
+(strong scaling of one input, the north star's scaling curve; `scaling: "strong"`), and `value_tiles` carries the weak-scaling figure
+(every rank its own 2048^2 tile, no data-path collective; all ranks' pixels / max-over-ranks time).
 
 Weights are seeded random (no checkpoints offline).  The two 1x1 heads are re-scaled once, before
 timing, so that the network's own outputs have the candidate statistics of the reference's NMS
@@ -149,13 +154,14 @@ def cpu_baseline_3d(vol_np, model, sample, threads):
     m3.c_polyhedron_to_label(d[keep], pts[keep], V, F, np.arange(1, keep.sum() + 1, dtype=np.int32), 0, 0, 0, 0, x.shape)
     t_ras = time.time() - t0
     tot = t_net + t_nms + t_ras
-    return dict(value=round(x.size / tot / 1e6, 4), unit="Mvox/s", cores=threads, kind="reference",
-                note="measured on a crop (Qhull makes the full 256^3 reference run take minutes): any GPU/CPU ratio formed with value_3d is an "
-                     "extrapolation from this crop, not a same-size comparison; BASELINE.md section 2 has the survey's full-size 256^3 run "
-                     "(33.9 s NMS + 0.92 s raster at 8 threads = 0.48 Mvox/s, native post-processing only)",
-                sample="%d^3 crop of the bench volume: torch-CPU U-Net %.2fs (TF-CPU stand-in) + compiled reference 3D NMS "
+    full = sample >= vol_np.shape[0]
+    return dict(value=round(x.size / tot / 1e6, 4), unit="Mvox/s", cores=threads, kind="reference", seconds=round(tot, 2), same_size=bool(full),
+                note=("the whole bench volume: a same-size comparison with value_3d" if full else
+                      "measured on a crop (the full-size reference run was predicted to exceed --cpu-budget3d): any GPU/CPU ratio formed with "
+                      "value_3d is an extrapolation from this crop, not a same-size comparison"),
+                sample="%s of the bench volume: torch-CPU U-Net %.2fs (TF-CPU stand-in) + compiled reference 3D NMS "
                        "(oracle/_ref incl. Qhull, %d candidates -> %d) %.2fs + compiled reference rasteriser %.2fs"
-                       % (sample, t_net, len(d), int(keep.sum()), t_nms, t_ras))
+                       % ("all %d^3 voxels" % sample if full else "%d^3 crop" % sample, t_net, len(d), int(keep.sum()), t_nms, t_ras))
 
 
 def net_macs(model, macs):
@@ -233,12 +239,20 @@ def run_split_leg(model, img, steps, warmup, world, dist_):
 
 
 def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, dist_, rank):
-    """BASELINE.json configs 4/5: ONE large input, its blocks dealt round-robin to the ranks, local NMS per block on the device,
-    RCCL all_gather of the block survivors, final cross-tile NMS + rasteriser on rank 0 (stardist_amd/big.py, design A of
-    SURVEY.md 8e).  Strong scaling: the input is the same for every N.  Returns a dict (rank 0) or None."""
+    """BASELINE.json configs 4/5: ONE large input, its blocks dealt round-robin to the ranks; per block network + selection + local NMS on
+    the device; one gather of the surviving records to rank 0; cross-tile NMS over the band survivors only; final instances broadcast and
+    every rank renders the write regions of its blocks (stardist_amd/big.py, design A of SURVEY.md 8e).  Strong scaling: the input is
+    the same for every N.  N = 1: the label image comes back as ONE host array (as predict_instances returns it); N > 1: the tiles stay on
+    the ranks that rendered them (labels_out="local"), as the reference's block.write leaves them in the shared output.
+    Returns a dict (rank 0) or None."""
     import torch
     kw = dict(block_size=block, min_overlap=overlap, context=context, broadcast_result=False)
-    model.predict_instances_sharded(big, axes, **kw)                         # warm-up (MIOpen find, HIP graphs, arena growth)
+    if world > 1:
+        kw["labels_out"] = "local"
+    # warm-up on ONE block's worth of the input (HIP graph of the block shape, arena growth): a full pass of the 1024^3 volume is ~30 s
+    warm = big[tuple(slice(0, block) for _ in range(big.dim()))]
+    model.predict_instances_sharded(warm, axes, block_size=block, min_overlap=overlap, context=context, distributed=False)
+    del warm
     if world > 1:
         dist_.barrier()
     torch.cuda.synchronize()
@@ -252,20 +266,28 @@ def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, di
     if world > 1:
         dist_.barrier()
     elapsed = time.perf_counter() - t0
+    mean = {k: (round(v / passes, 4) if isinstance(v, float) else v // passes) for k, v in acc.items()}
     per_rank = [None] * world
     if world > 1:
         tt = torch.tensor([elapsed], device=big.device, dtype=torch.float64)
         dist_.all_reduce(tt, op=dist_.ReduceOp.MAX)
         elapsed = float(tt.item())
-        dist_.all_gather_object(per_rank, {k: (round(v / passes, 4) if isinstance(v, float) else v // passes) for k, v in acc.items()})
+        dist_.all_gather_object(per_rank, mean)
     else:
-        per_rank = [{k: (round(v / passes, 4) if isinstance(v, float) else v // passes) for k, v in acc.items()}]
+        per_rank = [mean]
     if rank != 0:
         return None
     n = int(np.prod(big.shape))
-    return {"value": round(n * passes / elapsed / 1e6, 3), "s_per_pass": round(elapsed / passes, 4), "passes": passes, "scaling": "strong",
-            "input_shape": list(big.shape), "block_size": block, "min_overlap": overlap, "context": context,
-            "instances": len(res["prob"]), "gathered_survivors": per_rank[0]["gathered"], "gathered_bytes": per_rank[0]["gathered_bytes"],
+    r0 = per_rank[0]
+    s_pass = elapsed / passes
+    return {"value": round(n * passes / elapsed / 1e6, 3), "s_per_pass": round(s_pass, 4), "passes": passes, "scaling": "strong",
+            "input_shape": list(big.shape), "block_size": block, "min_overlap": overlap, "context": context, "blocks": sum(p["blocks"] for p in per_rank),
+            "instances": r0["instances"], "candidates": sum(p["candidates"] for p in per_rank),
+            "gathered_survivors": r0["gathered"], "gathered_bytes": r0["gathered_bytes"], "band_survivors": r0["band"], "interior_survivors": r0["interior"],
+            "t_predict": max(p["t_predict"] for p in per_rank), "t_local_nms": max(p["t_local_nms"] for p in per_rank), "t_exchange": r0["t_exchange"],
+            "t_final": r0["t_final"], "t_final_nms": r0["t_final_nms"], "t_raster": max(p["t_raster"] for p in per_rank),
+            "t_final_frac": round(r0["t_final"] / s_pass, 4),
+            "labels": "one host array on rank 0" if world == 1 else "rank-local tiles of the owned write regions (not gathered)",
             "per_rank": per_rank}
 
 
@@ -280,9 +302,10 @@ def main():
     ap.add_argument("--skip-3d", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048)
-    ap.add_argument("--cpu-sample3d", type=int, default=96)
+    ap.add_argument("--cpu-sample3d", type=int, default=128)
+    ap.add_argument("--cpu-budget3d", type=float, default=75.0, help="run the 3D CPU baseline at full size if the crop predicts at most this many seconds")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--sharded", action="store_true", help="also run the block-sharded big-input legs at N=1 (always run for N>1)")
+    ap.add_argument("--no-sharded", action="store_true", help="skip the block-sharded big-input legs (configs 4/5; run by default at every N)")
     ap.add_argument("--sharded-size", type=int, default=16384)
     ap.add_argument("--sharded-size3d", type=int, default=1024)
     ap.add_argument("--skip-sharded-3d", action="store_true")
@@ -347,7 +370,7 @@ def main():
         roof_conv = {"bound": "mfma", "kernel": conv_kernel, "achieved": round(conv_tf, 3), "peak": peak,
                      "unit": "TFLOP/s", "frac": round(conv_tf / peak, 4), "traffic": None, "flops_per_launch": flops, "avg_ms": round(net_ms, 3),
                      "note": "algorithmic FLOPs of the convolutions (2 x MACs, recomputed from the instantiated module) / HIP-event time of the whole "
-                             "forward pass on the caller's stream; per-kernel durations: profiles/r02_bench_kernel_stats.md"}
+                             "forward pass on the caller's stream; per-kernel durations: profiles/r03_bench_kernel_stats.md"}
         roof_pair = {"bound": "hbm", "kernel": "k_pairs_beam<32,8,6,4,64> (bound-slot scan-beam polygon intersection, one pair per lane, state in LDS)", "achieved": round(pair_gbs, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pair_gbs / HBM_PEAK_GBS, 6), "traffic": None,
                      "bytes_per_launch": round(pair_bytes_per_launch), "avg_launch_ms": round(float(pair_ms / pair_launches), 4),
@@ -388,13 +411,25 @@ def main():
             r["unit"] = "Mpix/s"
             out["split_bf16"] = r
     # ---- config 4: one 16384^2 slide (the 2048^2 synthetic tile repeated), blocks 4096 / overlap 128 / context 128, sharded over the ranks
-    if world > 1 or args.sharded:
+    if not args.no_sharded:
         rep = max(1, args.sharded_size // H)
         big = torch.from_numpy(synth.s2d_nuclei_image(H, W, seed=0)).to(dev).repeat(rep, rep)
         r = run_sharded_leg(model, big, "YX", min(4096, big.shape[0]), 128, 128, 2, world, dist_, rank)
         if rank == 0:
             r["unit"] = "Mpix/s"
             out["sharded_2d"] = r
+            if world > 1:
+                # N > 1: the headline is ONE 16384^2 slide whose blocks are dealt over the ranks (BASELINE.json config 4, the north star's
+                # scaling curve), not N independent tiles; the tile figure stays next to it
+                out["value_tiles"] = {"value": out["value"], "unit": "Mpix/s", "ms_per_step": out["ms_per_step"], "scaling": "weak",
+                                      "note": "every rank its own %dx%d tile, no collective" % (H, W)}
+                out["value"], out["scaling"] = r["value"], "strong"
+                out["ms_per_step"] = round(1e3 * r["s_per_pass"], 3)
+                out["steps"], out["warmup"] = r["passes"], 1
+                out["config"]["workload"] = ("predict_instances_sharded on ONE %dx%d synthetic slide (BASELINE.json config 4): blocks %d / overlap 128 / "
+                                             "context 128 dealt round-robin over the ranks, local NMS per block, gather of the survivors, cross-tile "
+                                             "NMS over the band on rank 0, write regions rendered by their owners" % (big.shape[0], big.shape[1], r["block_size"]))
+                out["config"]["parallelism"] = "blocks-of-one-slide x%d (strong scaling; `value_tiles` = independent tile per rank)" % world
         del big
     del model, img
     torch.cuda.empty_cache()
@@ -409,13 +444,15 @@ def main():
         calibrate_heads(m3, vol if rank == 0 else torch.from_numpy(synth.s3d_nuclei_image(S, seed=0)).to(dev),
                         frac=0.009, radius=8.5, noise=0.03)   # near-spherical objects; same image on every rank
         macs3 = conv_macs_per_input_pixel(m3.net, m3.config)
-        steps3 = max(1, min(args.steps, 3))
-        elapsed3, net3_ms, res3, st3 = run_leg(m3, vol, steps3, 1, world, dist_)
+        steps3 = max(1, min(args.steps, 5))
+        elapsed3, net3_ms, res3, st3 = run_leg(m3, vol, steps3, 2, world, dist_)
         if rank == 0:
             s3 = st3.get("nms3d", np.zeros(16, np.int64)) / steps3
             ms3 = 1e3 * elapsed3 / steps3
             flops3 = 2.0 * net_macs(m3, macs3) * S ** 3
             conv3_tf = flops3 / (net3_ms * 1e-3) / 1e12
+            out["value_definition"] = ("`value` / `value_3d`: input resident in HBM when the timed region starts (the bench contract); `value_host_input`: "
+                                       "the same step from a host numpy array in to (labels, dict) out, SURVEY.md 8d's definition")
             out["value_3d"] = round(world * S ** 3 * steps3 / elapsed3 / 1e6, 3)
             out["unit_3d"] = "Mvox/s"
             out["ms_per_step_3d"] = round(ms3, 3)
@@ -432,7 +469,13 @@ def main():
                                         "frac": round(conv3_tf / peak, 4), "flops_per_launch": flops3, "avg_ms": round(net3_ms, 3)}
             if not args.no_cpu_baseline and world == 1:
                 try:
-                    out["cpu_baseline_3d"] = cpu_baseline_3d(vol_np, m3, min(args.cpu_sample3d, S), threads)
+                    cb = cpu_baseline_3d(vol_np, m3, min(args.cpu_sample3d, S), threads)
+                    # same-size baseline when the host can afford it: the crop's time scaled by the voxel ratio predicts the full run
+                    if args.cpu_sample3d < S and cb.get("seconds", 1e9) * (S / float(min(args.cpu_sample3d, S))) ** 3 <= args.cpu_budget3d:
+                        crop = cb
+                        cb = cpu_baseline_3d(vol_np, m3, S, threads)
+                        cb["crop_run"] = {"sample": crop["sample"], "value": crop["value"]}
+                    out["cpu_baseline_3d"] = cb
                 except Exception as e:
                     out["cpu_baseline_3d"] = {"value": None, "unit": "Mvox/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
         if args.dtype == "float32" and not args.no_split_leg:
@@ -441,7 +484,7 @@ def main():
                 r["unit"] = "Mvox/s"
                 out["split_bf16_3d"] = r
         # ---- config 5: one 1024^3 volume (the 256^3 synthetic volume repeated), 256^3 blocks / overlap 32 / context 32, sharded
-        if (world > 1 or args.sharded) and not args.skip_sharded_3d:
+        if not args.no_sharded and not args.skip_sharded_3d:
             rep = max(1, args.sharded_size3d // S)
             bigv = torch.from_numpy(synth.s3d_nuclei_image(S, seed=0)).to(dev).repeat(rep, rep, rep)
             r = run_sharded_leg(m3, bigv, "ZYX", min(256, bigv.shape[0]), 32, 32, 1, world, dist_, rank)
