@@ -396,7 +396,7 @@ def _exclusive_intervals(blocks, axes_out):
 
 def predict_instances_sharded(model, img, axes, block_size, min_overlap, context=None, prob_thresh=None, nms_thresh=None,
                               return_labels=True, labels_out=None, show_progress=False, distributed=None, predict_kwargs=None,
-                              nms_kwargs=None, broadcast_result=True):
+                              nms_kwargs=None, broadcast_result=True, pipeline=True):
     """Block-sharded prediction with a final cross-tile NMS (SURVEY.md 8e design A, the north-star's multi-GPU path).
 
     The blocks of `BlockND.cover` (big.py:426-450) are dealt round-robin to the ranks of the default torch.distributed group
@@ -418,6 +418,9 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
     `labels_out="local"` -- nothing is moved: every rank returns [(block index, slices, tile), ...] for its blocks.
     Unlike `predict_instances_big` (design B, the reference's own semantics: per-block NMS + bbox responsibility rule, no
     cross-tile NMS) label ids follow the global score order.  Per-stage wall times and counters: model._last_sharded_stats.
+
+    pipeline=True (device path): the network of block k+1 runs on the main HIP stream while the local NMS of block k runs on a second
+    stream (see phase 1); pipeline=False serialises them and times each stage on its own.
 
     Returns (labels, dict) on rank 0; (labels-or-None, dict) on the other ranks (dict None there with broadcast_result=False)."""
     import time
@@ -466,7 +469,7 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
     n_cls = (model.config.n_classes + 1) if getattr(model.config, "n_classes", None) is not None else 0
     W = R + 1 + nd + 1 + n_cls                                      # record width
     c_prob, c_pts, c_blk, c_cls = R, R + 1, R + 1 + nd, R + 2 + nd
-    st = dict(blocks=0, candidates=0, local_survivors=0, t_predict=0.0, t_local_nms=0.0, t_exchange=0.0, t_final=0.0, t_final_nms=0.0,
+    st = dict(blocks=0, candidates=0, local_survivors=0, t_phase1=0.0, t_predict=0.0, t_local_nms=0.0, t_exchange=0.0, t_final=0.0, t_final_nms=0.0,
               t_raster=0.0, gathered=0, gathered_bytes=0, unique=0, band=0, interior=0, instances=0)
 
     def tick():
@@ -487,18 +490,8 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
 
     # ---- phase 1: my blocks -> local survivors with their centre in the block's write region, global coordinates
     recs = []
-    for bi, block in enumerate(blocks):
-        if bi % world != rank:
-            continue
-        t0 = tick()
-        x = block.read(img, axes=axes)
-        res = (model.predict_sparse_device if on_dev else model.predict_sparse)(x, axes=axes, prob_thresh=prob_thresh, **predict_kwargs)
-        prob, dist, points = as_t(res[0]), as_t(res[1]), as_t(res[-1])
-        pcls = as_t(res[2]) if n_cls else None
-        t1 = tick()
-        st["blocks"] += 1; st["candidates"] += int(prob.numel()); st["t_predict"] += t1 - t0
-        if prob.numel() == 0:
-            continue
+
+    def block_record(bi, block, prob, dist, points, pcls):
         keep = local_nms(dist, prob, points)
         bl = block.blocks_for_axes(axes_out)
         start = torch.tensor([t.start for t in bl], device=dev, dtype=torch.int64).reshape(1, nd)
@@ -512,8 +505,60 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
         rec[:, c_pts:c_pts + nd] = gp.float(); rec[:, c_blk] = float(bi)     # coordinates and block ids are < 2^24: exact in float32
         if n_cls:
             rec[:, c_cls:] = pcls[keep].float()
-        recs.append(rec)
-        st["local_survivors"] += int(keep.numel()); st["t_local_nms"] += tick() - t1
+        return rec
+
+    mine = [bi for bi in range(len(blocks)) if bi % world == rank]
+    pipelined = bool(pipeline) and on_dev and hasattr(model, "predict_sparse_begin") and set(predict_kwargs) <= {"normalizer"} and len(mine) > 1
+    st["pipelined"] = int(pipelined)
+    if pipelined:
+        # Software pipeline over two HIP streams: while the NMS of block k runs (latency-bound integer / fp64 kernels driven by a host
+        # round loop, on `side`), the network of block k+1 (MFMA-bound, one graph replay) is already running on the main stream.
+        # t_predict / t_local_nms are then the times the HOST waited for each (they overlap on the device).
+        main = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        t_begin = time.perf_counter()
+        fin = model.predict_sparse_begin(blocks[mine[0]].read(img, axes=axes), axes=axes, prob_thresh=prob_thresh, **predict_kwargs)
+        for k, bi in enumerate(mine):
+            t0 = time.perf_counter()
+            res = fin()                                            # selection of block k (waits for its forward pass)
+            prob, dist, points = res[0], res[1], res[-1]
+            pcls = res[2] if n_cls else None
+            ready = torch.cuda.Event()
+            ready.record(main)
+            if k + 1 < len(mine):                                   # forward pass of block k+1: enqueued, not waited for
+                fin = model.predict_sparse_begin(blocks[mine[k + 1]].read(img, axes=axes), axes=axes, prob_thresh=prob_thresh, **predict_kwargs)
+            t1 = time.perf_counter()
+            st["blocks"] += 1; st["candidates"] += int(prob.numel()); st["t_predict"] += t1 - t0
+            if prob.numel():
+                side.wait_event(ready)
+                for t in (prob, dist, points, pcls):
+                    if t is not None:
+                        t.record_stream(side)
+                with torch.cuda.stream(side):
+                    rec = block_record(bi, blocks[bi], prob, dist, points, pcls)
+                recs.append(rec)
+                st["local_survivors"] += int(rec.shape[0])
+            st["t_local_nms"] += time.perf_counter() - t1
+        main.wait_stream(side)
+        for r_ in recs:
+            r_.record_stream(main)
+        st["t_phase1"] = tick() - t_begin
+    else:
+        for bi in mine:
+            block = blocks[bi]
+            t0 = tick()
+            x = block.read(img, axes=axes)
+            res = (model.predict_sparse_device if on_dev else model.predict_sparse)(x, axes=axes, prob_thresh=prob_thresh, **predict_kwargs)
+            prob, dist, points = as_t(res[0]), as_t(res[1]), as_t(res[-1])
+            pcls = as_t(res[2]) if n_cls else None
+            t1 = tick()
+            st["blocks"] += 1; st["candidates"] += int(prob.numel()); st["t_predict"] += t1 - t0
+            if prob.numel() == 0:
+                continue
+            rec = block_record(bi, block, prob, dist, points, pcls)
+            recs.append(rec)
+            st["local_survivors"] += int(rec.shape[0]); st["t_local_nms"] += tick() - t1
+        st["t_phase1"] = st["t_predict"] + st["t_local_nms"]
     rec = torch.cat(recs) if recs else torch.zeros((0, W), dtype=torch.float32, device=dev)
 
     # ---- phase 2: one gather of the records to rank 0 (counts first; padded to the largest rank)

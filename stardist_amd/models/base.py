@@ -569,24 +569,50 @@ class StarDistBase(object):
             if self._is_multiclass(): prob_classa = torch.cat(pcl)
         else:
             res = self._net_forward(x, sparse_head=True)
-            prob = res[0][..., 0]
-            bs = [(b, b)] * nd if np.isscalar(b) else list(b)
-            if self._head_mode == "sparse":
-                proba, dista, pts = self._select_rows(prob, res[1], [0] * nd, prob_thresh, bs)
-            else:
-                proba, dista, pts = self._select(prob, res[1], prob_thresh, bs)
-            pointsa = pts * gridt
-            if self._is_multiclass():
-                pc = res[2].reshape(-1, res[2].shape[-1])
-                lin = pts[:, 0]
-                for d in range(1, nd): lin = lin * prob.shape[d] + pts[:, d]
-                prob_classa = pc[lin]
+            yield self._sparse_finish(res, self._head_mode, x, resizer, axes_net, prob_thresh, b)
+            return
         idx = resizer.filter_points(x.dim(), pointsa, axes_net)
         proba, dista, pointsa = proba[idx], dista[idx], pointsa[idx]
         if self._is_multiclass():
             yield proba, dista, prob_classa[idx], pointsa
         else:
             yield proba, dista, pointsa
+
+    def _sparse_finish(self, res, head_mode, x, resizer, axes_net, prob_thresh, b):
+        """candidate selection behind an (untiled) forward pass: threshold + border + ordered compaction, distance head on the selected rows"""
+        import torch
+        nd = self.config.n_dim
+        gridt = torch.tensor(self.config.grid, device=self.device, dtype=torch.int64).reshape(1, nd)
+        prob = res[0][..., 0]
+        bs = [(b, b)] * nd if np.isscalar(b) else list(b)
+        if head_mode == "sparse":
+            proba, dista, pts = self._select_rows(prob, res[1], [0] * nd, prob_thresh, bs)
+        else:
+            proba, dista, pts = self._select(prob, res[1], prob_thresh, bs)
+        pointsa = pts * gridt
+        prob_classa = None
+        if self._is_multiclass():
+            pc = res[2].reshape(-1, res[2].shape[-1])
+            lin = pts[:, 0]
+            for d in range(1, nd): lin = lin * prob.shape[d] + pts[:, d]
+            prob_classa = pc[lin]
+        idx = resizer.filter_points(x.dim(), pointsa, axes_net)
+        proba, dista, pointsa = proba[idx], dista[idx], pointsa[idx]
+        if self._is_multiclass():
+            return proba, dista, prob_classa[idx], pointsa
+        return proba, dista, pointsa
+
+    def predict_sparse_begin(self, img, prob_thresh=None, axes=None, normalizer=None, b=2):
+        """Two-phase predict_sparse_device for software pipelining (stardist_amd/big.py): ENQUEUES normalisation, padding and the
+        network's forward pass (one HIP graph replay) on torch's current stream without waiting for it, and returns `finish`;
+        finish() does the candidate selection (its candidate count is the first host synchronisation) and returns what
+        predict_sparse_device returns.  The forward pass writes into the graph's static output buffers: call finish() before the
+        next predict_sparse_begin / predict* on this model."""
+        if prob_thresh is None: prob_thresh = self.thresholds.prob
+        x, axes, axes_net, axes_net_div_by, resizer, n_tiles, grid, grid_dict, channel = self._predict_setup(img, axes, normalizer, None)
+        res = self._net_forward(x, sparse_head=True)
+        head_mode = self._head_mode
+        return lambda: self._sparse_finish(res, head_mode, x, resizer, axes_net, prob_thresh, b)
 
     def predict_sparse(self, *args, **kwargs):
         r = None

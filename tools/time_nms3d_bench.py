@@ -10,6 +10,8 @@ from stardist_amd.lib import _native, stardist3d as sd3
 from stardist_amd.models import Config3D, StarDist3D
 from stardist_amd.rays3d import rays_from_json
 dev = torch.device("cuda:0")
+if os.environ.get("SD_TRACE"):
+    _native.lib().sd_set_option(b"trace", 1)      # per-round counters on stdout
 S = int(os.environ.get("SD_SIZE3D", "256"))
 vol = torch.from_numpy(synth.s3d_nuclei_image(S, seed=0)).to(dev)
 m = StarDist3D(Config3D(rays=96), basedir=None, device=dev, seed=0)
