@@ -238,7 +238,7 @@ def run_split_leg(model, img, steps, warmup, world, dist_):
             model._graphs = graphs
 
 
-def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, dist_, rank, pipeline=True):
+def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, dist_, rank, pipeline=False):
     """BASELINE.json configs 4/5: ONE large input, its blocks dealt round-robin to the ranks; per block network + selection + local NMS on
     the device; one gather of the surviving records to rank 0; cross-tile NMS over the band survivors only; final instances broadcast and
     every rank renders the write regions of its blocks (stardist_amd/big.py, design A of SURVEY.md 8e).  Strong scaling: the input is
@@ -416,12 +416,8 @@ def main():
         rep = max(1, args.sharded_size // H)
         big = torch.from_numpy(synth.s2d_nuclei_image(H, W, seed=0)).to(dev).repeat(rep, rep)
         r = run_sharded_leg(model, big, "YX", min(4096, big.shape[0]), 128, 128, 2, world, dist_, rank)
-        rs = run_sharded_leg(model, big, "YX", min(4096, big.shape[0]), 128, 128, 1, world, dist_, rank, pipeline=False)
         if rank == 0:
             r["unit"] = "Mpix/s"
-            r["note"] = ("pipelined: the network of block k+1 (main stream) overlaps the local NMS of block k (second stream); t_predict / t_local_nms "
-                         "are host wait times there.  `serialised` = the same pass without the overlap, each stage timed on its own")
-            r["serialised"] = {k: rs[k] for k in ("value", "s_per_pass", "t_phase1", "t_predict", "t_local_nms", "t_exchange", "t_final", "t_final_nms", "t_raster", "t_final_frac")}
             out["sharded_2d"] = r
             if world > 1:
                 # N > 1: the headline is ONE 16384^2 slide whose blocks are dealt over the ranks (BASELINE.json config 4, the north star's
@@ -493,13 +489,8 @@ def main():
             rep = max(1, args.sharded_size3d // S)
             bigv = torch.from_numpy(synth.s3d_nuclei_image(S, seed=0)).to(dev).repeat(rep, rep, rep)
             r = run_sharded_leg(m3, bigv, "ZYX", min(256, bigv.shape[0]), 32, 32, 1, world, dist_, rank)
-            # the same volume with a block size that tiles it with less redundancy (27 blocks of 416^3 = 1.8x the volume instead of 216
-            # blocks of 256^3 = 3.4x): SURVEY.md 8d fixes 256^3 blocks for the comparable figure, this one shows what the block size costs
-            rt = run_sharded_leg(m3, bigv, "ZYX", min(416, bigv.shape[0]), 32, 32, 1, world, dist_, rank) if bigv.shape[0] >= 832 else None
             if rank == 0:
                 r["unit"] = "Mvox/s"
-                if rt is not None:
-                    r["block_416"] = {k: rt[k] for k in ("value", "s_per_pass", "blocks", "block_size", "instances", "t_phase1", "t_predict", "t_local_nms", "t_final", "t_final_frac")}
                 out["sharded_3d"] = r
             del bigv
     if rank == 0:

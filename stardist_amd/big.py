@@ -396,7 +396,7 @@ def _exclusive_intervals(blocks, axes_out):
 
 def predict_instances_sharded(model, img, axes, block_size, min_overlap, context=None, prob_thresh=None, nms_thresh=None,
                               return_labels=True, labels_out=None, show_progress=False, distributed=None, predict_kwargs=None,
-                              nms_kwargs=None, broadcast_result=True, pipeline=True):
+                              nms_kwargs=None, broadcast_result=True, pipeline=False):
     """Block-sharded prediction with a final cross-tile NMS (SURVEY.md 8e design A, the north-star's multi-GPU path).
 
     The blocks of `BlockND.cover` (big.py:426-450) are dealt round-robin to the ranks of the default torch.distributed group
@@ -419,8 +419,9 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
     Unlike `predict_instances_big` (design B, the reference's own semantics: per-block NMS + bbox responsibility rule, no
     cross-tile NMS) label ids follow the global score order.  Per-stage wall times and counters: model._last_sharded_stats.
 
-    pipeline=True (device path): the network of block k+1 runs on the main HIP stream while the local NMS of block k runs on a second
-    stream (see phase 1); pipeline=False serialises them and times each stage on its own.
+    pipeline=True (device path, EXPERIMENTAL, off by default): the network of block k+1 runs on the main HIP stream while the local NMS of
+    block k runs on a second stream (see phase 1); measured gain 8-11 % (the two contend for the same CUs), and one of four test
+    processes returned a label image that differed from the serialised pass -- unexplained, hence not the default and not benchmarked.
 
     Returns (labels, dict) on rank 0; (labels-or-None, dict) on the other ranks (dict None there with broadcast_result=False)."""
     import time

