@@ -211,6 +211,10 @@ int sd_bias_act_device(float* d_x, const float* d_bias, long long n_outer, int n
 int sd_add_bias_act_device(float* d_x, const float* d_addend, const float* d_bias, long long n_outer,
                            int n_channels, long long inner, int act, void* stream);
 
+/* Keras MaxPooling2D / 3D(pool), 'valid', stride = pool, channels-last float32 (csbdeep unet_block between its levels; the grid > 1
+ * stages of stardist/models/model2d.py:317-325): d_in [D][H][W][C] -> d_out [D/pz][H/py][W/px][C]; 2D: D = pz = 1.  C % 4 == 0. */
+int sd_maxpool_ndhwc_device(const float* d_in, int n_channels, int D, int H, int W, int pz, int py, int px, float* d_out, void* stream);
+
 /* point-level probe of the reference's inside_polyhedron (stardist/lib/stardist3d_impl.cpp:153-191) for ONE polyhedron
  * (d_dist: n_rays, d_centre: 3, zyx) on n points (d_points: n x 3, zyx): d_out[t] = 1 if inside.  use_cone_map != 0 evaluates
  * the predicate only on the faces whose cone can contain the point's direction (csrc/geom3d.h), as stage 5 of the NMS does;

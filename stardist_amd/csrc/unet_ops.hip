@@ -5,6 +5,7 @@
 #include "common.h"
 
 #include "stardist_hip.h"
+#include <math.h>
 
 namespace {
 
@@ -132,7 +133,49 @@ __global__ void __launch_bounds__(256) k_head_rows(const float* __restrict__ fea
   }
 }
 
+// ---- max pooling, channels-last ----------------------------------------------------------------------------------------------
+// Keras MaxPooling2D / 3D(pool), padding 'valid', stride = pool (csbdeep unet_block between the levels; the grid > 1 stages in front
+// of the U-Net, stardist/models/model2d.py:317-325): out[zo][yo][xo][c] = max over the pz x py x px window.  One thread per (output
+// pixel, channel quad); 64-bit indexing (a 32-channel 416^3 level has more than 2^31 elements).  HBM-bound: 4 B read per input element.
+__global__ void __launch_bounds__(256) k_maxpool_cl4(const float4* __restrict__ in, float4* __restrict__ out, long long n_out4, int C4, int Ho, int Wo,
+                                                     int H, int W, int pz, int py, int px) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n_out4; idx += stride) {
+    const int q = (int)(idx % C4);
+    long long pix = idx / C4;
+    const int xo = (int)(pix % Wo); pix /= Wo;
+    const int yo = (int)(pix % Ho);
+    const long long zo = pix / Ho;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int dz = 0; dz < pz; ++dz)
+      for (int dy = 0; dy < py; ++dy) {
+        const float4* row = in + (((zo * pz + dz) * H + ((long long)yo * py + dy)) * W + (long long)xo * px) * C4 + q;
+        for (int dx = 0; dx < px; ++dx) {
+          const float4 v = row[(long long)dx * C4];
+          m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+      }
+    out[idx] = m;
+  }
+}
+
 }  // namespace
+
+extern "C" int sd_maxpool_ndhwc_device(const float* d_in, int n_channels, int D, int H, int W, int pz, int py, int px, float* d_out, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (pz <= 0 || py <= 0 || px <= 0 || n_channels <= 0 || n_channels % 4 || !d_in || !d_out || (((uintptr_t)d_in | (uintptr_t)d_out) & 15)) {
+    sd::set_error("sd_maxpool_ndhwc: channels must be a multiple of 4, pointers 16-byte aligned, pool sizes positive");
+    return -1;
+  }
+  const int Do = D / pz, Ho = H / py, Wo = W / px;
+  if (Do <= 0 || Ho <= 0 || Wo <= 0) return 0;
+  const long long n4 = (long long)Do * Ho * Wo * (n_channels / 4);
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(k_maxpool_cl4, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)d_in, (float4*)d_out, n4, n_channels / 4, Ho, Wo, H, W, pz, py, px);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
 
 static int bias_act_impl(float* d_x, const float* d_add, const float* d_bias, long long n_outer, int n_channels, long long inner, int act, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;

@@ -352,6 +352,25 @@ def _conv(nd, cin, cout, k, act="relu", bias=True, batch_norm=False):
     return ConvAct(conv, _act(act))
 
 
+def max_pool(x, pool):
+    """Keras MaxPooling ('valid', stride = pool).  GPU inference on channels-last float32 tensors: the native one-pass kernel
+    (sd_maxpool_ndhwc_device, 64-bit indexing, output channels-last) -- the framework's 3D pooling converts a channels-last tensor to
+    the default layout and back (three extra passes over the level) and indexes with 32 bits; everywhere else F.max_pool."""
+    nd = x.dim() - 2
+    pool = tuple(int(p) for p in pool)
+    cl = torch.channels_last if nd == 2 else torch.channels_last_3d
+    if (x.is_cuda and nd in (2, 3) and x.shape[0] == 1 and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and hand_conv_enabled()
+            and not torch.is_grad_enabled() and not torch.is_autocast_enabled() and x.is_contiguous(memory_format=cl) and x.data_ptr() % 16 == 0):
+        from ..lib import _native as N
+        S = (1,) * (3 - nd) + tuple(int(v) for v in x.shape[2:])
+        P = (1,) * (3 - nd) + pool
+        out = torch.empty((1, x.shape[1]) + tuple(s // p for s, p in zip(x.shape[2:], pool)), dtype=torch.float32, device=x.device, memory_format=cl)
+        if out.numel():
+            N.dcall(x, "sd_maxpool_ndhwc_device", ctypes.c_void_p(x.data_ptr()), int(x.shape[1]), *S, *P, ctypes.c_void_p(out.data_ptr()))
+        return out
+    return (F.max_pool2d if nd == 2 else F.max_pool3d)(x, pool)
+
+
 class UNetBlock(nn.Module):
     """csbdeep unet_block(n_depth, n_filter_base, kernel_size, n_conv_per_depth, activation,
     last_activation, pool) without batch-norm/dropout (inference)."""
@@ -386,12 +405,11 @@ class UNetBlock(nn.Module):
         self.out_channels = c
 
     def forward(self, x):
-        pool = F.max_pool2d if self.nd == 2 else F.max_pool3d
         skips = []
         for blk in self.down:
             x = blk(x)
             skips.append(x)
-            x = pool(x, self.pool)
+            x = max_pool(x, self.pool)
         x = self.middle(x)
         for blk, skip in zip(self.up, reversed(skips)):
             first = blk[0]
@@ -659,9 +677,8 @@ class StarDistNet(nn.Module):
     def forward(self, x, sparse_head=False):
         """(prob, dist[, prob_class]); with sparse_head=True and the fused heads available: (prob, features[, prob_class]) and
         self.head_mode == "sparse" -- the distance head is then evaluated by the caller on the rows it selects (dist_rows)"""
-        pool = F.max_pool2d if self.nd == 2 else F.max_pool3d
         for st in self.pre:
-            x = pool(st["convs"](x), st.pool)
+            x = max_pool(st["convs"](x), st.pool)
         base = self.backbone(x)
         self.head_mode = "dense"
         if self._fused_heads_ok(base):

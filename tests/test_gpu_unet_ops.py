@@ -39,3 +39,20 @@ def test_bias_act_odd_channels_and_error():
     N.check(N.lib().sd_bias_act_device(N.tptr(x), N.tptr(b), 1000, 7, 1, 1, N.current_stream()))
     assert torch.equal(x, ref)
     assert N.lib().sd_bias_act_device(N.tptr(x), N.tptr(b), 1000, 7, 1, 5, N.current_stream()) != 0
+
+
+@pytest.mark.parametrize("shape,pool", [((1, 32, 70, 96), (2, 2)), ((1, 64, 33, 47), (2, 2)), ((1, 32, 12, 40, 50), (2, 2, 2)),
+                                        ((1, 32, 9, 40, 51), (1, 2, 2)), ((1, 128, 8, 6, 10), (2, 2, 2)), ((1, 4, 16, 16), (4, 2))])
+def test_native_max_pool_equals_framework(shape, pool):
+    """Keras MaxPooling 'valid' (floor of the extent): the native channels-last kernel against torch's max_pool on the same tensor"""
+    import torch
+    import torch.nn.functional as F
+    from stardist_amd.models import unet as U
+    nd = len(shape) - 2
+    cl = torch.channels_last if nd == 2 else torch.channels_last_3d
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(1)).cuda().contiguous(memory_format=cl)
+    with torch.no_grad():
+        y = U.max_pool(x, pool)
+    want = (F.max_pool2d if nd == 2 else F.max_pool3d)(x.contiguous(), pool)
+    assert tuple(y.shape) == tuple(want.shape) and y.is_contiguous(memory_format=cl)
+    assert torch.equal(y, want)
