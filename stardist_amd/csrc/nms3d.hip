@@ -127,12 +127,21 @@ __global__ void k_cell_count3(const float* __restrict__ pts, int N, Grid3 g, int
   candCell[i] = cell;
   atomicAdd(&cellCount[cell], 1);
 }
+// what the broad phase needs of a candidate, stored in CELL ORDER: a wave that scans the rows of cells around its candidate reads
+// contiguous 40-byte records (mostly L2 hits: neighbouring candidates scan the same rows) instead of gathering 36 bytes per test
+// through an index list
+struct CellRec3 { float p[3]; int idx; int bb[6]; };
 __global__ void k_cell_fill3(int N, const int* __restrict__ candCell, const int* __restrict__ cellStart, int* __restrict__ cellFill,
-                             int* __restrict__ cellItems) {
+                             const float* __restrict__ pts, const int* __restrict__ bbox, CellRec3* __restrict__ cellRec) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int c = candCell[i];
-  cellItems[cellStart[c] + atomicAdd(&cellFill[c], 1)] = i;
+  CellRec3 r;
+  r.p[0] = pts[3 * (size_t)i]; r.p[1] = pts[3 * (size_t)i + 1]; r.p[2] = pts[3 * (size_t)i + 2];
+  r.idx = i;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) r.bb[k] = bbox[6 * (size_t)i + k];
+  cellRec[cellStart[c] + atomicAdd(&cellFill[c], 1)] = r;
 }
 
 struct Flags3 { int use_kdtree, use_bbox, thr_nonneg; float thr, max_dist; };
@@ -151,18 +160,23 @@ __device__ __forceinline__ bool may_interact3(const Flags3 f, const float* pi, c
   return true;
 }
 
+// one wave per candidate, taken in cell order; consecutive workgroups go round-robin over the 8 XCDs, so block b is given the
+// (b % 8)-th eighth of the cell-ordered list: the candidates of one region of space stay on one XCD's L2
 template <int MODE>
-__global__ void __launch_bounds__(256) k_neighbours3(int N, Grid3 g, Flags3 f, const float* __restrict__ pts, const int* __restrict__ bbox,
+__global__ void __launch_bounds__(256) k_neighbours3(int N, Grid3 g, Flags3 f, const CellRec3* __restrict__ cellRec,
                                                      const int* __restrict__ candCell, const int* __restrict__ cellStart,
-                                                     const int* __restrict__ cellItems, int* __restrict__ nbrCount,
+                                                     int* __restrict__ nbrCount,
                                                      const i64* __restrict__ nbrStart, int* __restrict__ nbr, int W) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * (blockDim.x >> 6) + wave;
-  if (i >= N) return;
+  const int blk = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+  const int slot = blk * (blockDim.x >> 6) + wave;
+  if (slot >= N) return;
+  const CellRec3 me = cellRec[slot];
+  const int i = me.idx;
   const int c = candCell[i];
   const int cz = c / (g.ny * g.nx), cy = (c / g.nx) % g.ny, cx = c % g.nx;
-  const float* pi = pts + 3 * (size_t)i;
-  const int* bi = bbox + 6 * (size_t)i;
+  const float* pi = me.p;
+  const int* bi = me.bb;
   int total = 0;
   const i64 base = MODE ? nbrStart[i] : 0;
   const int x_lo = max(cx - W, 0), x_hi = min(cx + W, g.nx - 1);
@@ -175,8 +189,9 @@ __global__ void __launch_bounds__(256) k_neighbours3(int N, Grid3 g, Flags3 f, c
         bool hit = false;
         int j = -1;
         if (idx < end) {
-          j = cellItems[idx];
-          if (j != i) hit = may_interact3(f, pi, pts + 3 * (size_t)j, bi, bbox + 6 * (size_t)j);
+          const CellRec3 o = cellRec[idx];
+          j = o.idx;
+          if (j != i) hit = may_interact3(f, pi, o.p, bi, o.bb);
         }
         const unsigned long long m = __ballot(hit);
         if (MODE && hit) nbr[base + total + __popcll(m & ((1ull << lane) - 1))] = j;
@@ -1644,10 +1659,10 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   int* cellCount = A.take_n<int>(nCells + 1);
   int* cellStart = A.take_n<int>(nCells + 1);
   int* cellFill = A.take_n<int>(nCells + 1);
-  int* cellItems = A.take_n<int>(N);
+  CellRec3* cellRec = A.take_n<CellRec3>(N);
   int* nbrCount = A.take_n<int>(N + 1);
   i64* nbrStart = A.take_n<i64>(N + 1);
-  if (!cellCount || !cellStart || !cellFill || !cellItems || !nbrCount || !nbrStart) return -1;
+  if (!cellCount || !cellStart || !cellFill || !cellRec || !nbrCount || !nbrStart) return -1;
   SD_CHECK(hipMemsetAsync(cellCount, 0, (nCells + 1) * sizeof(int), s));
   SD_CHECK(hipMemsetAsync(cellFill, 0, (nCells + 1) * sizeof(int), s));
   hipLaunchKernelGGL(k_cell_count3, dim3(sd::div_up(N, 256)), dim3(256), 0, s, d_points, N, gr, cellCount, candCell);
@@ -1658,13 +1673,14 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   void* scanTmp = A.take(tb1 + 256);
   if (!scanTmp) return -1;
   SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tb1, cellCount, cellStart, nCells + 1, s));
-  hipLaunchKernelGGL(k_cell_fill3, dim3(sd::div_up(N, 256)), dim3(256), 0, s, N, candCell, cellStart, cellFill, cellItems);
+  hipLaunchKernelGGL(k_cell_fill3, dim3(sd::div_up(N, 256)), dim3(256), 0, s, N, candCell, cellStart, cellFill, d_points, bbox, cellRec);
   SD_LAUNCH_CHECK();
+  const int nbBlocks = (sd::div_up(N, 4) + 7) & ~7;
   Flags3 f;
   f.use_kdtree = use_kdtree; f.use_bbox = use_bbox; f.thr_nonneg = (threshold >= 0.f); f.thr = threshold; f.max_dist = max_dist;
   Flags3 fs = f;
   SD_CHECK(hipMemsetAsync(nbrCount, 0, (N + 1) * sizeof(int), s));
-  hipLaunchKernelGGL((k_neighbours3<0>), dim3(sd::div_up(N, 4)), dim3(256), 0, s, N, gr, fs, d_points, bbox, candCell, cellStart, cellItems,
+  hipLaunchKernelGGL((k_neighbours3<0>), dim3(nbBlocks), dim3(256), 0, s, N, gr, fs, cellRec, candCell, cellStart,
                      nbrCount, (const i64*)nullptr, (int*)nullptr, W);
   SD_LAUNCH_CHECK();
   SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tb1, nbrCount, nbrStart, N + 1, s));
@@ -1708,7 +1724,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   }
   int* nbr = A.take_n<int>((size_t)totalNbr);
   if (!nbr) return -1;
-  hipLaunchKernelGGL((k_neighbours3<1>), dim3(sd::div_up(N, 4)), dim3(256), 0, s, N, gr, fs, d_points, bbox, candCell, cellStart, cellItems,
+  hipLaunchKernelGGL((k_neighbours3<1>), dim3(nbBlocks), dim3(256), 0, s, N, gr, fs, cellRec, candCell, cellStart,
                      nbrCount, (const i64*)nbrStart, nbr, W);
   SD_LAUNCH_CHECK();
 
