@@ -234,8 +234,40 @@ struct Stats { unsigned long long upper, lower, kernel, render, kept_pre, sup_pr
                unsigned long long cyc[6]; };   // SD_TRACE: stage-3 wave cycles spent in load+half-spaces / cull / bounds / exact volume / total
 #define SD_PROF_BIT 0x40000000u
 
-// emit: exact neighbour predicate + cascade stages 1 and 2 (:1199-1248)
-__global__ void __launch_bounds__(256) k_round_emit3(const int* __restrict__ K, int nK, unsigned char* __restrict__ state,
+// Where a cascade stage records "i suppresses j".  Normal round (i is already KEPT): straight into the state array.  Tail batch
+// (i is still undecided, the pair is evaluated speculatively): appended to an edge list; the greedy order is replayed over those
+// edges afterwards (k_tail3_mark / k_tail3_promote).
+struct SuppSink {
+  unsigned char* state; int2* edges; unsigned int* count; unsigned int cap;
+  __device__ __forceinline__ void suppress(int i, int j) const {
+    if (edges) { const unsigned int pos = atomicAdd(count, 1u); if (pos < cap) edges[pos] = make_int2(i, j); }
+    else state[j] = ST_SUPPRESSED;
+  }
+};
+
+// Tail replay: the fixed point of the sequential loop over the remaining candidates -- j is suppressed iff some KEPT i < j has a
+// suppressing edge (i, j).  One sweep over the edges marks what the decided sources imply, one sweep over the candidates promotes
+// every j none of whose sources is still undecided; decisions only move UNDECIDED -> final, so sweeps can simply be repeated.
+__global__ void k_tail3_mark(const int2* __restrict__ edges, unsigned int n, unsigned char* __restrict__ state, unsigned char* __restrict__ blocked) {
+  const unsigned int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int2 ij = edges[e];
+  const unsigned char si = ((volatile unsigned char*)state)[ij.x];
+  if (si == ST_KEPT) state[ij.y] = ST_SUPPRESSED;
+  else if (si == ST_UNDECIDED) blocked[ij.y] = 1;
+}
+__global__ void k_tail3_promote(const int* __restrict__ U, int nU, unsigned char* __restrict__ state, unsigned char* __restrict__ blocked, int* left) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nU) return;
+  const int j = U[t];
+  if (state[j] != ST_UNDECIDED) return;
+  if (blocked[j]) { blocked[j] = 0; atomicAdd(left, 1); }
+  else state[j] = ST_KEPT;
+}
+
+// emit: exact neighbour predicate + cascade stages 1 and 2 (:1199-1248).  tail != 0: K is the list of the still undecided candidates,
+// none of which is marked kept; every pair of undecided candidates the sequential loop could still evaluate is emitted.
+__global__ void __launch_bounds__(256) k_round_emit3(const int* __restrict__ K, int nK, SuppSink sink, int tail,
                                                      const i64* __restrict__ nbrStart, const int* __restrict__ nbr, Flags3 f, Aniso an,
                                                      const float* __restrict__ pts, const int* __restrict__ bbox,
                                                      const float* __restrict__ volume, const float* __restrict__ r_outer,
@@ -245,7 +277,9 @@ __global__ void __launch_bounds__(256) k_round_emit3(const int* __restrict__ K, 
   const int w = blockIdx.x * (blockDim.x >> 6) + wave;
   if (w >= nK) return;
   const int i = K[w];
-  if (lane == 0) state[i] = ST_KEPT;
+  unsigned char* state = sink.state;
+  if (tail) { if (state[i] != ST_UNDECIDED) return; }
+  else if (lane == 0) state[i] = ST_KEPT;
   const i64 beg = nbrStart[i], end = nbrStart[i + 1];
   const float* pi = pts + 3 * (size_t)i;
   const float rad = f.max_dist + r_outer[i];
@@ -276,7 +310,7 @@ __global__ void __launch_bounds__(256) k_round_emit3(const int* __restrict__ K, 
             A_inter = sd3::intersect_sphere_isotropic(r_inner_iso[i], pi, r_inner_iso[j], pj, an.a);   // :1232-1237
             c_lower = 1;
             iou = (float)fmax(0.0, (double)A_inter / ((double)A_min + 1e-10));                    // :1241
-            if (iou > f.thr) { c_sup = 1; state[j] = ST_SUPPRESSED; }
+            if (iou > f.thr) { c_sup = 1; sink.suppress(i, j); }
             else emit = true;
           }
         }
@@ -821,7 +855,7 @@ __global__ void k_mesh_check(const float* __restrict__ verts, const int* __restr
 __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, unsigned int nPairs, const float* __restrict__ dist,
                                                const float* __restrict__ pts, const float* __restrict__ verts,
                                                const int* __restrict__ faces, const int* __restrict__ faceAdj, int R, int F,
-                                               const float* __restrict__ volume, float thr, unsigned char* __restrict__ state,
+                                               const float* __restrict__ volume, float thr, SuppSink sink,
                                                int2* __restrict__ pairs5, unsigned int* pair5Count, Stats* st, unsigned int wsBytes,
                                                const float* __restrict__ bverts, const int* __restrict__ bfaces, int bR, int bF,
                                                double* __restrict__ volOut = nullptr) {
@@ -928,7 +962,7 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
       const float A_inter_kernel = (float)vol;                                  // function returns float :679
       const float A_min = fminf(volume[ij.x], volume[ij.y]);
       const float iou = (float)((double)A_inter_kernel / ((double)A_min + 1e-10));   // :1269
-      if (iou > thr) { state[ij.y] = ST_SUPPRESSED; atomicAdd(&st->sup_kernel, 1ull); }
+      if (iou > thr) { sink.suppress(ij.x, ij.y); atomicAdd(&st->sup_kernel, 1ull); }
       else pairs5[atomicAdd(pair5Count, 1u)] = ij;
     }
   }
@@ -1337,7 +1371,7 @@ __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, u
 __global__ void __launch_bounds__(256) k_stage5(const int2* __restrict__ pairs, unsigned int nPairs, const float* __restrict__ dist,
                                                 const float* __restrict__ pts, const float* __restrict__ verts,
                                                 const int* __restrict__ faces, int R, int F, const int* __restrict__ bbox,
-                                                const float* __restrict__ volume, float thr, unsigned char* __restrict__ state, Stats* st,
+                                                const float* __restrict__ volume, float thr, SuppSink sink, Stats* st,
                                                 sd3::ConeMap cm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* pv1 = (float*)smem;       // 3R
@@ -1407,7 +1441,7 @@ __global__ void __launch_bounds__(256) k_stage5(const int2* __restrict__ pairs, 
       const float A_inter_render = (float)(int)res;
       const float iou = (float)((double)A_inter_render / ((double)A_min + 1e-10));       // :1325
       atomicAdd(&st->render, 1ull);
-      if (iou > thr) { state[ij.y] = ST_SUPPRESSED; atomicAdd(&st->sup_render, 1ull); }
+      if (iou > thr) { sink.suppress(ij.x, ij.y); atomicAdd(&st->sup_render, 1ull); }
     }
   }
 }
@@ -1489,7 +1523,7 @@ extern "C" int sd_hiv_pairs_device(const float* d_dist, const float* d_points, i
   const unsigned int nb = (unsigned int)n_pairs < 16384u ? (unsigned int)n_pairs : 16384u;
   if (d_vol_kernel) {
     hipLaunchKernelGGL(k_stage3, dim3(nb), dim3(64), lds3, s, pairs, (unsigned int)n_pairs, d_dist, d_points, d_verts, d_faces, faceAdj, R, F, volume,
-                       0.f, state, (int2*)nullptr, dummyCount, d_st, (unsigned int)ws3 | 0x80000000u, d_verts, d_faces, R, F, d_vol_kernel);
+                       0.f, SuppSink{state, nullptr, nullptr, 0u}, (int2*)nullptr, dummyCount, d_st, (unsigned int)ws3 | 0x80000000u, d_verts, d_faces, R, F, d_vol_kernel);
     SD_LAUNCH_CHECK();
   }
   if (d_vol_hull) {
@@ -1591,6 +1625,9 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (stats) { SD_CHECK(hipEventCreate(&ev0)); SD_CHECK(hipEventCreate(&ev1)); }
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evguard{ev0, ev1};
+  hipEvent_t evb0 = nullptr, evb1 = nullptr;          // broad phase (per-candidate precompute, grid, neighbour lists): the HBM-bound scan
+  if (stats) { SD_CHECK(hipEventCreate(&evb0)); SD_CHECK(hipEventCreate(&evb1)); SD_CHECK(hipEventRecord(evb0, s)); }
+  EvGuard evguardb{evb0, evb1};
   double ns3 = 0, ns4 = 0, ns5 = 0;
   const bool trace = sd::option(sd::OPT_TRACE) != 0;
   if (!use_kdtree && !use_bbox && threshold < 0) {   // every (0, j) passes and iou >= 0 > thr at stage 2
@@ -1727,6 +1764,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   hipLaunchKernelGGL((k_neighbours3<1>), dim3(nbBlocks), dim3(256), 0, s, N, gr, fs, cellRec, candCell, cellStart,
                      nbrCount, (const i64*)nbrStart, nbr, W);
   SD_LAUNCH_CHECK();
+  if (stats) SD_CHECK(hipEventRecord(evb1, s));
 
   // cone map for the voxel tests of stage 5 (geom3d.h); SD_NMS3D_NO_CONEMAP=1 tests every face as the reference does
   sd3::ConeMap cmap{nullptr, nullptr};
@@ -1765,16 +1803,36 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   int nU = N, rounds = 0;
   int* Ucur = U0; int* Unext = U1;
   Counters h;
+  // Tail batch: the late rounds hold few pairs, but every stage launch costs the latency of its slowest pair (an exact volume: ~1.5 ms).
+  // Once at most N/8 candidates are undecided, the cascade is run ONCE over every pair of undecided candidates the sequential loop could
+  // still evaluate (speculatively: i need not end up kept), suppressions are recorded as edges, and the remaining greedy order is
+  // replayed on the device over those edges (k_tail3_mark / k_tail3_promote).  Same fixed point: j is suppressed iff some KEPT i < j
+  // suppresses it.  sd_set_option("nms3d_tail_batch", 0) keeps the plain rounds (the parity suite runs both).
+  const int tailT = sd::option(sd::OPT_NMS3D_TAIL_BATCH) ? N / 8 : -1;
+  int2* supEdges = nullptr; unsigned int* supCount = nullptr; unsigned char* blocked = nullptr; int* d_left = nullptr;
   while (nU > 0) {
     ++rounds;
+    const bool tail = rounds > 1 && nU <= tailT;
     SD_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), s));
-    hipLaunchKernelGGL(k_round_decide3, dim3(sd::div_up(nU, 4)), dim3(256), 0, s, Ucur, nU, state, nbrStart, nbr, waitOn, Unext, Kl, (int*)d_cnt);
-    SD_LAUNCH_CHECK();
-    SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
-    SD_CHECK(hipStreamSynchronize(s));
-    if (h.nK == 0 && h.nU > 0) { sd::set_error("sd_nms3d: greedy scan made no progress (internal error)"); return -1; }
+    if (tail) {
+      if (!supEdges) {
+        supEdges = A.take_n<int2>(pairCap); supCount = A.take_n<unsigned int>(1); blocked = A.take_n<unsigned char>(N); d_left = A.take_n<int>(1);
+        if (!supEdges || !supCount || !blocked || !d_left) return -1;
+      }
+      SD_CHECK(hipMemsetAsync(supCount, 0, sizeof(unsigned int), s));
+      SD_CHECK(hipMemsetAsync(blocked, 0, N, s));
+      h.nK = nU; h.nU = 0;
+    } else {
+      hipLaunchKernelGGL(k_round_decide3, dim3(sd::div_up(nU, 4)), dim3(256), 0, s, Ucur, nU, state, nbrStart, nbr, waitOn, Unext, Kl, (int*)d_cnt);
+      SD_LAUNCH_CHECK();
+      SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+      SD_CHECK(hipStreamSynchronize(s));
+      if (h.nK == 0 && h.nU > 0) { sd::set_error("sd_nms3d: greedy scan made no progress (internal error)"); return -1; }
+    }
+    const SuppSink sink = tail ? SuppSink{state, supEdges, supCount, pairCap} : SuppSink{state, nullptr, nullptr, 0u};
+    const int nKeep = h.nK, nUndecided = h.nU;
     if (h.nK > 0) {
-      hipLaunchKernelGGL(k_round_emit3, dim3(sd::div_up(h.nK, 4)), dim3(256), 0, s, Kl, h.nK, state, nbrStart, nbr, f, an, d_points, bbox, volume,
+      hipLaunchKernelGGL(k_round_emit3, dim3(sd::div_up(nKeep, 4)), dim3(256), 0, s, tail ? Ucur : Kl, nKeep, sink, tail ? 1 : 0, nbrStart, nbr, f, an, d_points, bbox, volume,
                          r_outer, r_outer_iso, r_inner_iso, pairs3, &d_cnt->nP3, pairCap, d_st);
       SD_LAUNCH_CHECK();
       SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -1784,7 +1842,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
         const unsigned int b3 = h.nP3 < 16384u ? h.nP3 : 16384u;
         if (stats) SD_CHECK(hipEventRecord(ev0, s));
         hipLaunchKernelGGL(k_stage3, dim3(b3), dim3(64), lds3, s, pairs3, h.nP3, d_dist, d_points, d_verts, d_faces, faceAdj, R, F, volume,
-                           threshold, state, pairs4, &d_cnt->nP4, d_st, (unsigned int)ws3 | (use_bounds ? 0u : 0x80000000u) | (trace ? SD_PROF_BIT : 0u), bverts, bfaces, bR, bF);
+                           threshold, sink, pairs4, &d_cnt->nP4, d_st, (unsigned int)ws3 | (use_bounds ? 0u : 0x80000000u) | (trace ? SD_PROF_BIT : 0u), bverts, bfaces, bR, bF);
         SD_LAUNCH_CHECK();
         if (stats) SD_CHECK(hipEventRecord(ev1, s));
         SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -1822,13 +1880,34 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
           const unsigned int b5 = h.nP5 < 16384u ? h.nP5 : 16384u;
           if (stats) SD_CHECK(hipEventRecord(ev0, s));
           hipLaunchKernelGGL(k_stage5, dim3(b5), dim3(256), lds5, s, pairs5, h.nP5, d_dist, d_points, d_verts, d_faces, R, F, bbox, volume,
-                             threshold, state, d_st, cmap);
+                             threshold, sink, d_st, cmap);
           SD_LAUNCH_CHECK();
           if (stats) { SD_CHECK(hipEventRecord(ev1, s)); SD_CHECK(hipEventSynchronize(ev1)); float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns5 += ms * 1e6; }
         }
       }
     }
-    nU = h.nU;
+    if (tail) {
+      unsigned int nEdges = 0;
+      SD_CHECK(hipMemcpyAsync(&nEdges, supCount, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+      SD_CHECK(hipStreamSynchronize(s));
+      if (nEdges > pairCap) { sd::set_error("sd_nms3d: tail edge list overflow (internal error)"); return -1; }
+      if (trace) printf("tail batch after round %d: %d undecided candidates, %u suppressing edges\n", rounds - 1, nU, nEdges);
+      int left = 1, sweeps = 0;
+      while (left) {
+        for (int it = 0; it < 8; ++it) {
+          SD_CHECK(hipMemsetAsync(d_left, 0, sizeof(int), s));
+          if (nEdges) hipLaunchKernelGGL(k_tail3_mark, dim3(sd::div_up(nEdges, 256)), dim3(256), 0, s, supEdges, nEdges, state, blocked);
+          hipLaunchKernelGGL(k_tail3_promote, dim3(sd::div_up(nU, 256)), dim3(256), 0, s, Ucur, nU, state, blocked, d_left);
+        }
+        SD_LAUNCH_CHECK();
+        SD_CHECK(hipMemcpyAsync(&left, d_left, sizeof(int), hipMemcpyDeviceToHost, s));
+        SD_CHECK(hipStreamSynchronize(s));
+        if (++sweeps > N / 8 + 4) { sd::set_error("sd_nms3d: tail replay does not converge (internal error)"); return -1; }
+      }
+      nU = 0;
+      break;
+    }
+    nU = nUndecided;
     int* t = Ucur; Ucur = Unext; Unext = t;
   }
   hipLaunchKernelGGL(k_keep3, dim3(sd::div_up(N, 256)), dim3(256), 0, s, state, d_keep, N);
@@ -1842,6 +1921,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
     stats[4] = rounds; stats[5] = totalNbr; stats[6] = (int64_t)hs_.sup_kernel; stats[7] = (int64_t)hs_.sup_render;
     stats[8] = (int64_t)ns3; stats[9] = (int64_t)ns4; stats[10] = (int64_t)ns5; stats[11] = (int64_t)hs_.convex; stats[12] = (int64_t)hs_.kept_convex;
     stats[13] = (int64_t)hs_.hiv_faces; stats[14] = (int64_t)hs_.hiv_fallback;
+    { float msb = 0; SD_CHECK(hipEventElapsedTime(&msb, evb0, evb1)); stats[15] = (int64_t)(msb * 1e6); }
     if (trace) printf("hiv: faces %llu list entries %llu clips %llu list overflows %llu fallbacks %llu\n", hs_.hiv_faces, hs_.hiv_list, hs_.hiv_clips, hs_.hiv_rest, hs_.hiv_fallback);
     if (trace && hs_.cyc[5]) printf("stage 3 wave cycles per pair (clock64): load+half-spaces %.0f, cull %.0f, bounds %.0f, decide/exact %.0f, total %.0f (%llu pairs)\n",
                                     (double)hs_.cyc[0] / hs_.cyc[5], (double)hs_.cyc[1] / hs_.cyc[5], (double)hs_.cyc[2] / hs_.cyc[5], (double)hs_.cyc[3] / hs_.cyc[5],

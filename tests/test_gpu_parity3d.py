@@ -117,6 +117,25 @@ def test_nms3d_volume_bounds_do_not_change_decisions(refmods, monkeypatch):
     assert np.array_equal(keep_bounds, keep_exact) and np.array_equal(keep_exact, ref_keep)
 
 
+def test_nms3d_tail_batch_does_not_change_survivors(refmods):
+    """late greedy rounds as one speculative batch + device replay (nms3d.hip tail batch) vs plain rounds vs the reference"""
+    import torch
+    from oracle import synth
+    from stardist_amd.lib import _native as N, stardist3d as sd3
+    rays = _rays(96)
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    d, p, s, nobj = synth.s3d_nuclei(96, rays.vertices)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    args = (t(d), t(p), t(np.float32(V)), t(F), t(s), 1, 1, 0, np.float32(0.3))
+    keep_tail, st_tail = sd3.c_non_max_suppression_inds(*args, return_stats=True)
+    st_tail = st_tail.copy()
+    with N.option("nms3d_tail_batch", 0):
+        keep_rounds, st_rounds = sd3.c_non_max_suppression_inds(*args, return_stats=True)
+    ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(0.3))
+    assert np.array_equal(keep_tail.cpu().numpy(), keep_rounds.cpu().numpy()) and np.array_equal(keep_rounds.cpu().numpy(), ref_keep)
+    assert st_tail[4] < st_rounds[4], (st_tail[4], st_rounds[4])        # fewer host-driven rounds
+
+
 def test_nms3d_flags_and_edges(refmods):
     from stardist_amd.lib import stardist3d as sd3
     rays = _rays(32)
