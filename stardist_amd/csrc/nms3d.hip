@@ -1804,11 +1804,14 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   int* Ucur = U0; int* Unext = U1;
   Counters h;
   // Tail batch: the late rounds hold few pairs, but every stage launch costs the latency of its slowest pair (an exact volume: ~1.5 ms).
-  // Once at most N/8 candidates are undecided, the cascade is run ONCE over every pair of undecided candidates the sequential loop could
-  // still evaluate (speculatively: i need not end up kept), suppressions are recorded as edges, and the remaining greedy order is
-  // replayed on the device over those edges (k_tail3_mark / k_tail3_promote).  Same fixed point: j is suppressed iff some KEPT i < j
-  // suppresses it.  sd_set_option("nms3d_tail_batch", 0) keeps the plain rounds (the parity suite runs both).
-  const int tailT = sd::option(sd::OPT_NMS3D_TAIL_BATCH) ? N / 8 : -1;
+  // Once few candidates are undecided (N/128, at least 512), the cascade is run ONCE over every pair of undecided candidates the
+  // sequential loop could still evaluate (speculatively: i need not end up kept), suppressions are recorded as edges, and the remaining
+  // greedy order is replayed on the device over those edges (k_tail3_mark / k_tail3_promote).  Same fixed point: j is suppressed iff
+  // some KEPT i < j suppresses it.  The threshold is late on purpose: undecided candidates sit in dense clusters, so the speculative
+  // pair count grows quickly with them (measured on the 256^3 bench set: at N/8 = 16 404 undecided candidates 71 674 stage-3 pairs
+  // instead of the 2 397 the plain rounds evaluate -- slower than the rounds it replaces; at N/128 the three last rounds, ~7 ms of
+  // launch latency, become one pass).  sd_set_option("nms3d_tail_batch", 0) keeps the plain rounds (the parity suite runs both).
+  const int tailT = sd::option(sd::OPT_NMS3D_TAIL_BATCH) ? (N / 128 > 512 ? N / 128 : 512) : -1;
   int2* supEdges = nullptr; unsigned int* supCount = nullptr; unsigned char* blocked = nullptr; int* d_left = nullptr;
   while (nU > 0) {
     ++rounds;
