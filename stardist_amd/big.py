@@ -176,31 +176,80 @@ class BlockND(object):
     def __repr__(self):
         return "BlockND(%s|%s)" % (self.id, ",".join("%s=%03d:%03d" % (a, t.start, t.end) for t, a in zip(self.blocks, self.axes)))
 
+    def _responsible(self, bmin, bmax, axes=None):
+        """Block.is_responsible (big.py:89-122) for all objects at once.  bmin, bmax: (n_objects, ndim) integer arrays of bounding
+        boxes [min, max) relative to the block without context.  Returns (responsible bool (n,), first_violation): the index of the
+        first object (in array order) for which the reference raises NotFullyVisible, or -1.  `all(...)` in the reference stops at
+        the first axis that answers False, so an axis is only consulted for objects every earlier axis accepted."""
+        bl = self.blocks_for_axes(axes)
+        n = len(bmin)
+        alive = np.ones(n, bool)          # every earlier axis answered True
+        raised = np.zeros(n, bool)
+        for d, t in enumerate(bl):
+            lo, hi = bmin[:, d], bmax[:, d]
+            r_start = t._r_start
+            r_end = t.size - t.context_start - t.context_end
+            assert np.all((0 <= lo) & (lo < hi) & (hi <= r_end))
+            crit = (lo == 0) & (hi >= r_start)
+            viol = crit & ((hi == r_end) | (not t.at_begin))
+            raised |= alive & viol
+            resp = ~(hi < r_start) & ~((hi == r_end) & (not t.at_end))
+            alive &= resp & ~viol
+        bad = np.flatnonzero(raised)
+        return alive, (int(bad[0]) if len(bad) else -1)
+
     def filter_objects(self, labels, polys, axes=None):
-        """keep only the objects this block is responsible for (big.py:340-413); returns copies"""
-        from scipy import ndimage as ndi
-        assert np.issubdtype(labels.dtype, np.integer)
+        """keep only the objects this block is responsible for (big.py:340-413); returns copies.  Vectorised: bounding boxes of all
+        labels at once (scipy find_objects on the host, scatter-min/max on the device for torch tensors), the responsibility rule on
+        the (n, ndim) box arrays, one look-up table pass over the label image -- no Python loop over objects."""
         ndim = len(self.blocks_for_axes(axes))
         assert ndim in (2, 3)
-        assert labels.ndim == ndim and labels.shape == tuple(s.stop - s.start for s in self.slice_crop_context(axes))
-        labels_filtered = np.zeros_like(labels)
-        for lab, slices in enumerate(ndi.find_objects(labels), start=1):      # regionprops bbox == find_objects slices
-            if slices is None:
-                continue
-            try:
-                if self.is_responsible(slices, axes):
-                    sub = labels_filtered[slices]
-                    sub[labels[slices] == lab] = lab
-            except NotFullyVisible:
-                shape_object = tuple(s.stop - s.start for s in slices)
-                shape_min_overlap = tuple(t.min_overlap for t in self.blocks_for_axes(axes))
-                raise RuntimeError("Found object of shape %s, which violates the assumption of being smaller than 'min_overlap' %s. "
-                                   "Increase 'min_overlap' to avoid this problem." % (shape_object, shape_min_overlap))
+        shape_expected = tuple(s.stop - s.start for s in self.slice_crop_context(axes))
+        is_t = type(labels).__module__.startswith("torch")
+        if is_t:
+            import torch
+            assert not labels.dtype.is_floating_point
+            assert labels.dim() == ndim and tuple(labels.shape) == shape_expected
+            n = int(labels.max()) if labels.numel() else 0
+            big = int(max(labels.shape)) + 1
+            lin = labels.reshape(-1).to(torch.int64)
+            fg = torch.nonzero(lin > 0).reshape(-1)
+            lab = lin[fg]
+            bmin_t = torch.full((n + 1, ndim), big, dtype=torch.int64, device=labels.device)
+            bmax_t = torch.full((n + 1, ndim), -1, dtype=torch.int64, device=labels.device)
+            rem = fg
+            for d in reversed(range(ndim)):
+                c = rem % int(labels.shape[d]); rem = rem // int(labels.shape[d])
+                bmin_t[:, d].scatter_reduce_(0, lab, c, "amin"); bmax_t[:, d].scatter_reduce_(0, lab, c, "amax")
+            present = (bmax_t[:, 0] >= 0).cpu().numpy()
+            present[0] = False
+            ids = np.flatnonzero(present)
+            bmin, bmax = bmin_t.cpu().numpy()[ids], bmax_t.cpu().numpy()[ids] + 1
+        else:
+            from scipy import ndimage as ndi
+            assert np.issubdtype(labels.dtype, np.integer)
+            assert labels.ndim == ndim and labels.shape == shape_expected
+            objs = ndi.find_objects(labels)                                        # regionprops bbox == find_objects slices
+            ids = np.array([k + 1 for k, sl in enumerate(objs) if sl is not None], np.int64)
+            bmin = np.array([[s.start for s in objs[k - 1]] for k in ids], np.int64).reshape(len(ids), ndim)
+            bmax = np.array([[s.stop for s in objs[k - 1]] for k in ids], np.int64).reshape(len(ids), ndim)
+            n = len(objs)
+        resp, bad = self._responsible(bmin, bmax, axes)
+        if bad >= 0:
+            shape_object = tuple(int(v) for v in (bmax[bad] - bmin[bad]))
+            shape_min_overlap = tuple(t.min_overlap for t in self.blocks_for_axes(axes))
+            raise RuntimeError("Found object of shape %s, which violates the assumption of being smaller than 'min_overlap' %s. "
+                               "Increase 'min_overlap' to avoid this problem." % (shape_object, shape_min_overlap))
+        lut = np.zeros(n + 1, np.int64)
+        lut[ids[resp]] = ids[resp]
+        if is_t:
+            labels_filtered = torch.from_numpy(lut).to(labels.device).to(labels.dtype)[labels.to(torch.int64)]
+        else:
+            labels_filtered = lut.astype(labels.dtype)[labels]
         if polys is None:
             return labels_filtered
         assert isinstance(polys, dict) and any(k in polys for k in COORD_KEYS)
-        filtered_labels = np.unique(labels_filtered)
-        filtered_ind = [i - 1 for i in filtered_labels if i > 0]
+        filtered_ind = ids[resp] - 1
         polys_out = {k: (v[filtered_ind] if k in OBJECT_KEYS else v) for k, v in polys.items()}
         for k in COORD_KEYS:
             if k in polys_out:

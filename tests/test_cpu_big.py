@@ -264,3 +264,7 @@ def test_cover_crop_filter_objects_equal_reference_golden(name, axes):
         lf, pf = block.filter_objects(block.crop_context(lab, axes=axes), dict(points=pts, prob=np.linspace(1, 0.5, len(ids))), axes=axes)
         assert np.array_equal(lf, g["%s_b%d_labels" % (name, bi)]), (name, bi)
         assert np.allclose(pf["points"], g["%s_b%d_points" % (name, bi)]) and np.allclose(pf["prob"], g["%s_b%d_prob" % (name, bi)])
+        # the tensor form (bounding boxes by scatter-min/max, what runs on the device) gives the same block
+        import torch
+        lt, pt = block.filter_objects(torch.from_numpy(np.ascontiguousarray(block.crop_context(lab, axes=axes))), dict(points=pts, prob=np.linspace(1, 0.5, len(ids))), axes=axes)
+        assert np.array_equal(lt.numpy(), lf) and np.array_equal(pt["points"], pf["points"])
