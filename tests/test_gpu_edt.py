@@ -45,3 +45,27 @@ def test_edt_prob_equals_exhaustive_oracle(shape, n, aniso):
     t = utils.edt_prob(torch.from_numpy(lab).cuda(), anisotropy=aniso)                   # device tensor in -> device tensor out
     assert t.is_cuda and np.array_equal(t.cpu().numpy(), want)
     assert (got[lab == 0] == 0).all() and got.max() <= 1.0
+
+
+def test_training_targets_equal_reference_composition(refmods):
+    """stardist_targets (edt_prob + star_dist on the GPU) against the composition the reference's data generator does per sample
+    (model2d.py:63-104): oracle edt_prob + the compiled reference c_star_dist, incl. grid subsampling, negative labels and the mask channel"""
+    from oracle import port
+    from stardist_amd.rays3d import Rays_GoldenSpiral
+    from stardist_amd.targets import stardist_targets
+    labs = [_blobs((64, 80), 10, seed=s) for s in (1, 2)]
+    labs[1][5:9, 5:9] = -1
+    for grid in ((1, 1), (2, 2)):
+        prob, dm = stardist_targets(labs, n_rays=32, grid=grid)
+        for k, y in enumerate(labs):
+            y0 = np.maximum(y, 0)
+            want_p = port.edt_prob(y0[::grid[0], ::grid[1]])
+            want_d = port.star_dist(y0, 32, grid=grid)
+            assert np.array_equal(dm[k, ..., :-1], want_d) and np.array_equal(dm[k, ..., -1], want_p)
+            negm = y[::grid[0], ::grid[1]] < 0
+            assert np.array_equal(prob[k, ..., 0][~negm], want_p[~negm]) and (prob[k, ..., 0][negm] == -1).all()
+    rays = Rays_GoldenSpiral(24)
+    lab3 = [_blobs((12, 32, 36), 6, seed=7)]
+    prob, dm = stardist_targets(lab3, rays=rays, grid=(1, 2, 2), anisotropy=(2.0, 1.0, 1.0))
+    assert np.array_equal(dm[0, ..., :-1], port.star_dist3D(lab3[0], rays.vertices, grid=(1, 2, 2)))
+    assert np.array_equal(prob[0, ..., 0], port.edt_prob(lab3[0][:, ::2, ::2], anisotropy=(2.0, 1.0, 1.0)))
