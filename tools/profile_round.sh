@@ -4,15 +4,15 @@
 #   1. rocprofv3 --kernel-trace (per-kernel durations of SD_PMC_STEPS steps + calibration, no trial kernels)
 #   2./3. --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes: they do not fit one)
 #   4. --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 (MFMA utilisation of the convolutions)
-# usage (GPU box): tools/profile_round.sh r02      -> gpurun_out/r02/*.md, pair_kernel_traffic.json
+# usage (GPU box): tools/profile_round.sh r03      -> gpurun_out/r03/*.md, pair_kernel_traffic.json
 R=${GRAFT_REPO_ROOT:-/root/repo}
 tag=$1
 O=$R/gpurun_out/$tag; mkdir -p $O
-cd /tmp; export TMPDIR=/tmp
+cd /tmp; export TMPDIR=/tmp; ulimit -c 0
 export SD_PMC_STEPS=3
 python $R/tools/pmc_predict.py > $O/warm.log 2>&1
 # 1. the bench command itself under the kernel trace (its JSON line is kept next to the table: the per-kernel averages must agree with it)
-rm -rf /tmp/prof_kt; (cd $R && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_under_trace.log 2>&1)
+rm -rf /tmp/prof_kt; (cd $R && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python bench.py --no-cpu-baseline --no-sharded --no-split-leg --steps 5 --warmup 2 > $O/bench_under_trace.log 2>&1)
 db=$(find /tmp/prof_kt -name '*.db' | head -1)
 python $R/tools/rocpd_summary.py $db --md > $O/kernel_stats.md 2>&1
 grep "^{" $O/bench_under_trace.log > $O/bench_under_trace.json
