@@ -981,26 +981,53 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
 // runs the exhaustive search, so both paths emit the same facet set; the facets are sorted so that they are also emitted
 // in the same order.
 #define HULL_FAST_MAXR 192
-__device__ __forceinline__ int hull_pivot(const double* __restrict__ pv, int R, int iu, int iv, int it, const double u[3], const double e[3],
-                                          const double dref[3], const double g[3]) {
+// Partial pivot: the angular extreme about the edge among the points q = q0, q0 + qstep, ... (best = -1: none); (bx, by) are its
+// coordinates in the plane normal to the edge.  hull_pivot_merge combines two partial results; all points lie in a wedge < pi about a
+// hull edge, so the cross-product order is a total order there and the combination is associative (exact ties = four coplanar
+// points, which the facet verification turns into the exhaustive search anyway).
+struct PivotFrame { double u[3], x[3], y[3]; bool ok; };
+__device__ __forceinline__ PivotFrame hull_pivot_frame(const double u[3], const double e[3], const double dref[3], const double g[3]) {
+  PivotFrame F;
+  F.ok = false;
+  F.u[0] = u[0]; F.u[1] = u[1]; F.u[2] = u[2];
   const double en = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
-  if (!(en > 0)) return -1;
+  if (!(en > 0)) return F;
   const double e0 = e[0] / en, e1 = e[1] / en, e2 = e[2] / en;
   const double dr = dref[0] * e0 + dref[1] * e1 + dref[2] * e2;
   double x0 = dref[0] - dr * e0, x1 = dref[1] - dr * e1, x2 = dref[2] - dr * e2;
   const double xn = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
-  if (!(xn > 0)) return -1;
+  if (!(xn > 0)) return F;
   x0 /= xn; x1 /= xn; x2 /= xn;
   double y0 = e1 * x2 - e2 * x1, y1 = e2 * x0 - e0 * x2, y2 = e0 * x1 - e1 * x0;
   if ((g[0] - u[0]) * y0 + (g[1] - u[1]) * y1 + (g[2] - u[2]) * y2 < 0) { y0 = -y0; y1 = -y1; y2 = -y2; }
-  int best = -1;
-  double bx = 0, by = 0;
-  for (int q = 0; q < R; ++q) {
+  F.x[0] = x0; F.x[1] = x1; F.x[2] = x2; F.y[0] = y0; F.y[1] = y1; F.y[2] = y2;
+  F.ok = true;
+  return F;
+}
+__device__ __forceinline__ void hull_pivot_part(const double* __restrict__ pv, int R, int iu, int iv, int it, const PivotFrame& F, int q0, int qstep,
+                                                int& best, double& bx, double& by) {
+  best = -1; bx = 0; by = 0;
+  for (int q = q0; q < R; q += qstep) {
     if (q == iu || q == iv || q == it) continue;
-    const double d0 = pv[3 * q] - u[0], d1 = pv[3 * q + 1] - u[1], d2 = pv[3 * q + 2] - u[2];
-    const double xq = d0 * x0 + d1 * x1 + d2 * x2, yq = d0 * y0 + d1 * y1 + d2 * y2;
-    if (best < 0) { best = q; bx = xq; by = yq; }
-    else if (bx * yq - by * xq > 0) { best = q; bx = xq; by = yq; }     // q is counter-clockwise of the current extreme
+    const double d0 = pv[3 * q] - F.u[0], d1 = pv[3 * q + 1] - F.u[1], d2 = pv[3 * q + 2] - F.u[2];
+    const double xq = d0 * F.x[0] + d1 * F.x[1] + d2 * F.x[2], yq = d0 * F.y[0] + d1 * F.y[1] + d2 * F.y[2];
+    if (best < 0 || bx * yq - by * xq > 0) { best = q; bx = xq; by = yq; }     // q is counter-clockwise of the current extreme
+  }
+}
+__device__ __forceinline__ void hull_pivot_merge(int& best, double& bx, double& by, int obest, double obx, double oby) {
+  if (obest < 0) return;
+  if (best < 0) { best = obest; bx = obx; by = oby; return; }
+  const double cr = bx * oby - by * obx;
+  if (cr > 0 || (cr == 0 && obest < best)) { best = obest; bx = obx; by = oby; }
+}
+// the extreme over all points, computed by `grp` consecutive lanes (a power of two) that share the edge; every lane of the group
+// returns the same vertex
+__device__ __forceinline__ int hull_pivot_group(const double* __restrict__ pv, int R, int iu, int iv, int it, const PivotFrame& F, int sub, int grp) {
+  int best; double bx, by;
+  hull_pivot_part(pv, R, iu, iv, it, F, sub, grp, best, bx, by);
+  for (int o = grp >> 1; o; o >>= 1) {
+    const int ob = __shfl_xor(best, o); const double ox = __shfl_xor(bx, o), oy = __shfl_xor(by, o);
+    hull_pivot_merge(best, bx, by, ob, ox, oy);
   }
   return best;
 }
@@ -1021,10 +1048,14 @@ __device__ int hull_giftwrap(const double* __restrict__ pv, int R, int cap, int 
   {
     const double u[3] = {pv[3 * p0], pv[3 * p0 + 1], pv[3 * p0 + 2]};
     const double ey[3] = {0, 1, 0}, ex[3] = {0, 0, 1};
-    p1 = hull_pivot(pv, R, p0, -1, -1, u, ey, ex, g);
+    const PivotFrame F1 = hull_pivot_frame(u, ey, ex, g);
+    if (!F1.ok) return -1;
+    p1 = hull_pivot_group(pv, R, p0, -1, -1, F1, lane, 64);
     if (p1 < 0) return -1;
     const double e[3] = {pv[3 * p1] - u[0], pv[3 * p1 + 1] - u[1], pv[3 * p1 + 2] - u[2]};
-    p2 = hull_pivot(pv, R, p0, p1, -1, u, e, ey, g);
+    const PivotFrame F2 = hull_pivot_frame(u, e, ey, g);
+    if (!F2.ok) return -1;
+    p2 = hull_pivot_group(pv, R, p0, p1, -1, F2, lane, 64);
     if (p2 < 0) return -1;
   }
   int nfr = 0;            // entries in the current frontier (uniform)
@@ -1035,11 +1066,19 @@ __device__ int hull_giftwrap(const double* __restrict__ pv, int R, int cap, int 
   int prop_u = p0, prop_v = p1, prop_w = (lane == 0) ? p2 : -1;
   int round_start = 0;
   for (int round = 0; round < 8 * R && !failed; ++round) {
-    for (int base = 0; (round == 0 ? base == 0 : base < nfr) && !failed; base += 64) {
+    // the open edges of the frontier are pivoted `per` at a time; the 64 / per lanes of an edge's group split the R points among them
+    // (a small frontier -- the first and the last rounds of the breadth-first wrap -- costs R / grp steps instead of R)
+    int per = 64, grp = 1;
+    if (round > 0) { while (per > 1 && (per >> 1) >= nfr) { per >>= 1; grp <<= 1; } }
+    for (int base = 0; (round == 0 ? base == 0 : base < nfr) && !failed; base += per) {
       if (round > 0) {
         prop_w = -1;
-        if (base + lane < nfr) {
-          const unsigned int item = frCur[base + lane];
+        const int slot = lane / grp, sub = lane - slot * grp;
+        bool bad = false;
+        int cand_w = -1;
+        // (every lane of a group takes the same branch: the condition depends on the edge only)
+        if (base + slot < nfr) {
+          const unsigned int item = frCur[base + slot];
           prop_u = (int)(item & 1023u); prop_v = (int)((item >> 10) & 1023u);
           const int t = (int)((item >> 20) & 1023u);
           const int lo = prop_u < prop_v ? prop_u : prop_v, hi = prop_u < prop_v ? prop_v : prop_u;
@@ -1047,10 +1086,16 @@ __device__ int hull_giftwrap(const double* __restrict__ pv, int R, int cap, int 
             const double u[3] = {pv[3 * prop_u], pv[3 * prop_u + 1], pv[3 * prop_u + 2]};
             const double e[3] = {pv[3 * prop_v] - u[0], pv[3 * prop_v + 1] - u[1], pv[3 * prop_v + 2] - u[2]};
             const double dref[3] = {pv[3 * t] - u[0], pv[3 * t + 1] - u[1], pv[3 * t + 2] - u[2]};
-            prop_w = hull_pivot(pv, R, prop_u, prop_v, t, u, e, dref, g);
-            if (prop_w < 0) failed = true;
+            const PivotFrame F = hull_pivot_frame(u, e, dref, g);
+            if (!F.ok) bad = true;
+            else {
+              cand_w = hull_pivot_group(pv, R, prop_u, prop_v, t, F, sub, grp);
+              if (cand_w < 0) bad = true;
+            }
           }
         }
+        if (bad) failed = true;
+        if (sub == 0) prop_w = cand_w;                 // one proposal per edge, on the first lane of its group
       }
       failed = __any(failed);
       unsigned long long mask = __ballot(prop_w >= 0);
@@ -1241,12 +1286,38 @@ __global__ void __launch_bounds__(64) k_hull(const int* __restrict__ hullList, u
     if (s_n >= 4 && s_n <= cap) {
       const int nf = s_n;
       unsigned short* adj = hullAdj + (size_t)cand * cap * 3;
+      // facets per vertex (a hull vertex of a near-spherical point set has ~6): the neighbour across edge (x, y) is looked up among the
+      // facets of x instead of among all facets.  The table lives in the frontier buffers of the gift wrapping (R <= HULL_FAST_MAXR).
+      const bool table = R <= HULL_FAST_MAXR;
+      unsigned short* vf = (unsigned short*)frA;      // [R][VF_CAP]
+      int* vcnt = (int*)frB;                          // [R]
+      constexpr int VF_CAP = 12;
+      if (table) {
+        for (int k = lane; k < R; k += 64) vcnt[k] = 0;
+        __syncthreads();
+        for (int t = lane; t < nf; t += 64) {
+          const unsigned int tt = tri[t];
+          const unsigned int v[3] = {tt & 1023u, (tt >> 10) & 1023u, (tt >> 20) & 1023u};
+          for (int e = 0; e < 3; ++e) { const int pos = atomicAdd(&vcnt[v[e]], 1); if (pos < VF_CAP) vf[v[e] * VF_CAP + pos] = (unsigned short)t; }
+        }
+        __syncthreads();
+      }
       for (int t = lane; t < nf; t += 64) {
         const unsigned int tt = tri[t];
         const unsigned int v[3] = {tt & 1023u, (tt >> 10) & 1023u, (tt >> 20) & 1023u};
         for (int e = 0; e < 3; ++e) {
           const unsigned int x = v[e], y = v[(e + 1) % 3];
           unsigned int found = HIV_NONE;
+          if (table && vcnt[x] <= VF_CAP) {
+            // (the lowest facet index, like the scan over all facets below)
+            for (int k = 0; k < vcnt[x]; ++k) {
+              const unsigned int u = vf[x * VF_CAP + k];
+              if ((int)u == t) continue;
+              const unsigned int uu = tri[u];
+              const unsigned int a_ = uu & 1023u, b_ = (uu >> 10) & 1023u, c_ = (uu >> 20) & 1023u;
+              if ((a_ == y || b_ == y || c_ == y) && (found == HIV_NONE || u < found)) found = u;
+            }
+          } else
           for (int u = 0; u < nf && found == HIV_NONE; ++u) {
             if (u == t) continue;
             const unsigned int uu = tri[u];
