@@ -165,7 +165,7 @@ __device__ __forceinline__ bool may_interact3(const Flags3 f, const float* pi, c
 template <int MODE>
 __global__ void __launch_bounds__(256) k_neighbours3(int N, Grid3 g, Flags3 f, const CellRec3* __restrict__ cellRec,
                                                      const int* __restrict__ candCell, const int* __restrict__ cellStart,
-                                                     int* __restrict__ nbrCount,
+                                                     int* __restrict__ nbrCount, int* __restrict__ nbrLow,
                                                      const i64* __restrict__ nbrStart, int* __restrict__ nbr, int W) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int blk = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
@@ -177,8 +177,11 @@ __global__ void __launch_bounds__(256) k_neighbours3(int N, Grid3 g, Flags3 f, c
   const int cz = c / (g.ny * g.nx), cy = (c / g.nx) % g.ny, cx = c % g.nx;
   const float* pi = me.p;
   const int* bi = me.bb;
-  int total = 0;
-  const i64 base = MODE ? nbrStart[i] : 0;
+  // a candidate's list holds its lower-index neighbours first (what the greedy scan looks at: is a better candidate still undecided?),
+  // then the higher-index ones (what a survivor is paired with): each consumer reads its half only
+  int nLo = 0, nHi = 0;
+  const i64 baseLo = MODE ? nbrStart[i] : 0;
+  const i64 baseHi = MODE ? baseLo + nbrLow[i] : 0;
   const int x_lo = max(cx - W, 0), x_hi = min(cx + W, g.nx - 1);
   for (int zz = max(cz - W, 0); zz <= min(cz + W, g.nz - 1); ++zz)
     for (int yy = max(cy - W, 0); yy <= min(cy + W, g.ny - 1); ++yy) {
@@ -193,16 +196,20 @@ __global__ void __launch_bounds__(256) k_neighbours3(int N, Grid3 g, Flags3 f, c
           j = o.idx;
           if (j != i) hit = may_interact3(f, pi, o.p, bi, o.bb);
         }
-        const unsigned long long m = __ballot(hit);
-        if (MODE && hit) nbr[base + total + __popcll(m & ((1ull << lane) - 1))] = j;
-        total += __popcll(m);
+        const unsigned long long mLo = __ballot(hit && j < i), mHi = __ballot(hit && j > i);
+        const unsigned long long below = (1ull << lane) - 1;
+        if (MODE && hit) {
+          if (j < i) nbr[baseLo + nLo + __popcll(mLo & below)] = j;
+          else nbr[baseHi + nHi + __popcll(mHi & below)] = j;
+        }
+        nLo += __popcll(mLo); nHi += __popcll(mHi);
       }
     }
-  if (!MODE && lane == 0) nbrCount[i] = total;
+  if (!MODE && lane == 0) { nbrCount[i] = nLo + nHi; nbrLow[i] = nLo; }
 }
 
 __global__ void __launch_bounds__(256) k_round_decide3(const int* __restrict__ U, int nU, const unsigned char* __restrict__ state,
-                                                       const i64* __restrict__ nbrStart, const int* __restrict__ nbr,
+                                                       const i64* __restrict__ nbrStart, const int* __restrict__ nbrLow, const int* __restrict__ nbr,
                                                        int* __restrict__ waitOn, int* __restrict__ Unext, int* __restrict__ K, int* counters) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int w = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -212,7 +219,7 @@ __global__ void __launch_bounds__(256) k_round_decide3(const int* __restrict__ U
   const int wo = waitOn[i];
   bool pending = (wo >= 0) && (state[wo] == ST_UNDECIDED);
   if (!pending) {
-    const i64 beg = nbrStart[i], end = nbrStart[i + 1];
+    const i64 beg = nbrStart[i], end = beg + nbrLow[i];          // the lower-index neighbours
     int found = -1;
     for (i64 t = beg; t < end && found < 0; t += 64) {
       const i64 idx = t + lane;
@@ -268,7 +275,7 @@ __global__ void k_tail3_promote(const int* __restrict__ U, int nU, unsigned char
 // emit: exact neighbour predicate + cascade stages 1 and 2 (:1199-1248).  tail != 0: K is the list of the still undecided candidates,
 // none of which is marked kept; every pair of undecided candidates the sequential loop could still evaluate is emitted.
 __global__ void __launch_bounds__(256) k_round_emit3(const int* __restrict__ K, int nK, SuppSink sink, int tail,
-                                                     const i64* __restrict__ nbrStart, const int* __restrict__ nbr, Flags3 f, Aniso an,
+                                                     const i64* __restrict__ nbrStart, const int* __restrict__ nbrLow, const int* __restrict__ nbr, Flags3 f, Aniso an,
                                                      const float* __restrict__ pts, const int* __restrict__ bbox,
                                                      const float* __restrict__ volume, const float* __restrict__ r_outer,
                                                      const float* __restrict__ r_outer_iso, const float* __restrict__ r_inner_iso,
@@ -280,7 +287,7 @@ __global__ void __launch_bounds__(256) k_round_emit3(const int* __restrict__ K, 
   unsigned char* state = sink.state;
   if (tail) { if (state[i] != ST_UNDECIDED) return; }
   else if (lane == 0) state[i] = ST_KEPT;
-  const i64 beg = nbrStart[i], end = nbrStart[i + 1];
+  const i64 beg = nbrStart[i] + nbrLow[i], end = nbrStart[i + 1];   // the higher-index neighbours
   const float* pi = pts + 3 * (size_t)i;
   const float rad = f.max_dist + r_outer[i];
   const float rad2 = rad * rad;                                                // :1170
@@ -1561,6 +1568,20 @@ int hull_planes(const float* d_dist, const float* d_points, const float* d_verts
   *planes = pl; *count = cnt; *cap_out = cap; g_last_hull_adj = adj;
   return 0;
 }
+// cone map of a ray mesh (geom3d.h) in buffers of the CURRENT arena pass; *out stays {nullptr, nullptr} when the map is switched off
+// (sd_set_option("nms3d_cone_map", 0)) or the mesh has too many faces for its 16-bit face ids
+int cone_map(const float* d_verts, const int* d_faces, int F, sd3::ConeMap* out, hipStream_t s) {
+  out->list = nullptr; out->count = nullptr;
+  if (F > 65535 || sd::option(sd::OPT_NMS3D_CONE_MAP) == 0) return 0;
+  sd::Arena& A = sd::arena();
+  unsigned short* cmList = A.take_n<unsigned short>((size_t)SD_CM_CELLS * SD_CM_CAP);
+  signed char* cmCount = A.take_n<signed char>(SD_CM_CELLS);
+  if (!cmList || !cmCount) return -1;
+  hipLaunchKernelGGL(k_cone_map, dim3(sd::div_up(SD_CM_CELLS, 64)), dim3(64), 0, s, d_verts, d_faces, F, cmList, cmCount);
+  SD_LAUNCH_CHECK();
+  out->list = cmList; out->count = cmCount;
+  return 0;
+}
 }  // namespace sd
 
 // Pair-level probe of the two volume stages (tests): for every pair (i, j) the EXACT intersection volume of the two kernels
@@ -1769,8 +1790,9 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   int* cellFill = A.take_n<int>(nCells + 1);
   CellRec3* cellRec = A.take_n<CellRec3>(N);
   int* nbrCount = A.take_n<int>(N + 1);
+  int* nbrLow = A.take_n<int>(N + 1);
   i64* nbrStart = A.take_n<i64>(N + 1);
-  if (!cellCount || !cellStart || !cellFill || !cellRec || !nbrCount || !nbrStart) return -1;
+  if (!cellCount || !cellStart || !cellFill || !cellRec || !nbrCount || !nbrLow || !nbrStart) return -1;
   SD_CHECK(hipMemsetAsync(cellCount, 0, (nCells + 1) * sizeof(int), s));
   SD_CHECK(hipMemsetAsync(cellFill, 0, (nCells + 1) * sizeof(int), s));
   hipLaunchKernelGGL(k_cell_count3, dim3(sd::div_up(N, 256)), dim3(256), 0, s, d_points, N, gr, cellCount, candCell);
@@ -1789,7 +1811,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   Flags3 fs = f;
   SD_CHECK(hipMemsetAsync(nbrCount, 0, (N + 1) * sizeof(int), s));
   hipLaunchKernelGGL((k_neighbours3<0>), dim3(nbBlocks), dim3(256), 0, s, N, gr, fs, cellRec, candCell, cellStart,
-                     nbrCount, (const i64*)nullptr, (int*)nullptr, W);
+                     nbrCount, nbrLow, (const i64*)nullptr, (int*)nullptr, W);
   SD_LAUNCH_CHECK();
   SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tb1, nbrCount, nbrStart, N + 1, s));
   i64 totalNbr = 0;
@@ -1833,7 +1855,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   int* nbr = A.take_n<int>((size_t)totalNbr);
   if (!nbr) return -1;
   hipLaunchKernelGGL((k_neighbours3<1>), dim3(nbBlocks), dim3(256), 0, s, N, gr, fs, cellRec, candCell, cellStart,
-                     nbrCount, (const i64*)nbrStart, nbr, W);
+                     nbrCount, nbrLow, (const i64*)nbrStart, nbr, W);
   SD_LAUNCH_CHECK();
   if (stats) SD_CHECK(hipEventRecord(evb1, s));
 
@@ -1897,7 +1919,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
       SD_CHECK(hipMemsetAsync(blocked, 0, N, s));
       h.nK = nU; h.nU = 0;
     } else {
-      hipLaunchKernelGGL(k_round_decide3, dim3(sd::div_up(nU, 4)), dim3(256), 0, s, Ucur, nU, state, nbrStart, nbr, waitOn, Unext, Kl, (int*)d_cnt);
+      hipLaunchKernelGGL(k_round_decide3, dim3(sd::div_up(nU, 4)), dim3(256), 0, s, Ucur, nU, state, nbrStart, nbrLow, nbr, waitOn, Unext, Kl, (int*)d_cnt);
       SD_LAUNCH_CHECK();
       SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
       SD_CHECK(hipStreamSynchronize(s));
@@ -1906,7 +1928,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
     const SuppSink sink = tail ? SuppSink{state, supEdges, supCount, pairCap} : SuppSink{state, nullptr, nullptr, 0u};
     const int nKeep = h.nK, nUndecided = h.nU;
     if (h.nK > 0) {
-      hipLaunchKernelGGL(k_round_emit3, dim3(sd::div_up(nKeep, 4)), dim3(256), 0, s, tail ? Ucur : Kl, nKeep, sink, tail ? 1 : 0, nbrStart, nbr, f, an, d_points, bbox, volume,
+      hipLaunchKernelGGL(k_round_emit3, dim3(sd::div_up(nKeep, 4)), dim3(256), 0, s, tail ? Ucur : Kl, nKeep, sink, tail ? 1 : 0, nbrStart, nbrLow, nbr, f, an, d_points, bbox, volume,
                          r_outer, r_outer_iso, r_inner_iso, pairs3, &d_cnt->nP3, pairCap, d_st);
       SD_LAUNCH_CHECK();
       SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));

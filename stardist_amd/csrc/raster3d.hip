@@ -28,6 +28,7 @@
 namespace sd {
 int hull_planes(const float* d_dist, const float* d_points, const float* d_verts, int n, int R, double** planes, int** count, int* cap_out,
                 hipStream_t s);
+int cone_map(const float* d_verts, const int* d_faces, int F, sd3::ConeMap* out, hipStream_t s);
 }
 
 namespace {
@@ -38,24 +39,27 @@ __global__ void __launch_bounds__(256) k_paint3d(const float* __restrict__ dist,
                                                  int render_mode,
                                                  int* __restrict__ first, int* __restrict__ count, int* __restrict__ result_dbg,
                                                  const double* __restrict__ hullPlanes, const int* __restrict__ hullCount, int hullCap,
-                                                 int* __restrict__ hullFail) {
+                                                 int* __restrict__ hullFail, sd3::ConeMap cm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* hs = (double*)smem;                          // n_faces * 4
   double* hh = hs + 4 * n_faces;                       // hullCap * 4 (modes 0 and 2)
   float* pv = (float*)(hh + 4 * hullCap);              // n_rays * 3
   int* fc = (int*)(pv + 3 * n_rays);                   // n_faces * 3
   __shared__ int sb[6];
+  __shared__ int s_unsafe;        // cone map preconditions (geom3d.h): every dist >= 1, coordinates below 8192
   for (int k = threadIdx.x; k < 3 * n_faces; k += blockDim.x) fc[k] = faces[k];
   for (int p = p0 + blockIdx.x; p < p1; p += gridDim.x) {
     __syncthreads();
     const float cz = points[3 * p], cy = points[3 * p + 1], cx = points[3 * p + 2];
     if (threadIdx.x < 6) sb[threadIdx.x] = (threadIdx.x & 1) ? -1 : INT_MAX;   // polyhedron_bbox :541-543
+    if (threadIdx.x == 0) s_unsafe = (cm.list && fabsf(cz) < 8192.f && fabsf(cy) < 8192.f && fabsf(cx) < 8192.f) ? 0 : 1;
     __syncthreads();
     int z1 = INT_MAX, z2 = -1, y1 = INT_MAX, y2 = -1, x1 = INT_MAX, x2 = -1;
     for (int j = threadIdx.x; j < n_rays; j += blockDim.x) {
       const float d = dist[(size_t)p * n_rays + j];
       const float z = cz + d * verts[3 * j], y = cy + d * verts[3 * j + 1], x = cx + d * verts[3 * j + 2];   // :547-549, :577-579
       pv[3 * j] = z; pv[3 * j + 1] = y; pv[3 * j + 2] = x;
+      if (!(d >= 1.f) || !(fmaxf(fmaxf(fabsf(z), fabsf(y)), fabsf(x)) < 8192.f)) s_unsafe = 1;
       const int rz = sd3::round_to_int(z), ry = sd3::round_to_int(y), rx = sd3::round_to_int(x);
       z1 = min(z1, rz); z2 = max(z2, rz); y1 = min(y1, ry); y2 = max(y2, ry); x1 = min(x1, rx); x2 = max(x2, rx);
     }
@@ -72,6 +76,7 @@ __global__ void __launch_bounds__(256) k_paint3d(const float* __restrict__ dist,
     }
     __syncthreads();
     // clipped to the volume (:1461-1463) and to the window [z0, z0 + nz) x [y0, y0 + ny) x [x0, x0 + nx) that is rendered
+    const bool safe = !s_unsafe;
     const int zlo = max(max(0, sb[0]), z0), zhi = min(min(NZ - 1, sb[1]), z0 + nz - 1);
     const int ylo = max(max(0, sb[2]), y0), yhi = min(min(NY - 1, sb[3]), y0 + ny - 1);
     const int xlo = max(max(0, sb[4]), x0), xhi = min(min(NX - 1, sb[5]), x0 + nx - 1);
@@ -94,7 +99,8 @@ __global__ void __launch_bounds__(256) k_paint3d(const float* __restrict__ dist,
           bool in_hull = true;
           for (int f = 0; f < nh; ++f)
             if (hh[4 * f] * (double)z + hh[4 * f + 1] * (double)y + hh[4 * f + 2] * (double)x + hh[4 * f + 3] > 0) { in_hull = false; break; }
-          inside = in_hull && sd3::inside_polyhedron(z, y, x, cz, cy, cx, pv, fc, n_faces);
+          // union of the tetrahedra (centre, face): only the faces whose cone can hold the voxel's direction (same result, geom3d.h)
+          inside = in_hull && sd3::inside_polyhedron_mapped(z, y, x, cz, cy, cx, pv, fc, n_faces, cm, safe);
         }
       } else if (render_mode == 2) {                                  // "convex" :1485-1487
         bool in_hull = true;
@@ -178,6 +184,8 @@ extern "C" int sd_polyhedron_to_label_window_device(const float* d_dist, const f
   if (need_hull && n_rays >= 4) {
     if (sd::hull_planes(d_dist, d_points, d_verts, n_polys, n_rays, &hullPlanes, &hullCount, &hullCap, s)) return -1;
   } else if (render_mode == 2) { sd::set_error("sd_polyhedron_to_label: render_mode 'hull' needs n_rays >= 4"); return -1; }
+  sd3::ConeMap cmap{nullptr, nullptr};
+  if (render_mode == 0 && sd::cone_map(d_verts, d_faces, n_faces, &cmap, s)) return -1;
   int* first = A.take_n<int>(nvox);
   int* count = A.take_n<int>(nvox);
   if (!first || !count) return -1;
@@ -192,7 +200,7 @@ extern "C" int sd_polyhedron_to_label_window_device(const float* d_dist, const f
     SD_CHECK(hipMemsetAsync(count, 0, nvox * sizeof(int), s));
     const int blocks = n_polys < 8192 ? n_polys : 8192;
     hipLaunchKernelGGL(k_paint3d, dim3(blocks), dim3(256), lds, s, d_dist, d_points, d_verts, d_faces, 0, n_polys, n_rays, n_faces,
-                       NZ, NY, NX, z0, y0, x0, nz, ny, nx, render_mode, first, count, d_result, hullPlanes, hullCount, hullCapL, hullFail);
+                       NZ, NY, NX, z0, y0, x0, nz, ny, nx, render_mode, first, count, d_result, hullPlanes, hullCount, hullCapL, hullFail, cmap);
     SD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_resolve3d, dim3(gb), dim3(256), 0, s, d_result, first, count, nvox, d_labels, use_overlap_label, overlap_label);
     SD_LAUNCH_CHECK();
@@ -202,7 +210,7 @@ extern "C" int sd_polyhedron_to_label_window_device(const float* d_dist, const f
       hipLaunchKernelGGL(k_fill, dim3(gb), dim3(256), 0, s, first, nvox, INT_MAX);
       SD_CHECK(hipMemsetAsync(count, 0, nvox * sizeof(int), s));
       hipLaunchKernelGGL(k_paint3d, dim3(1), dim3(256), lds, s, d_dist, d_points, d_verts, d_faces, p, p + 1, n_rays, n_faces, NZ, NY, NX,
-                         z0, y0, x0, nz, ny, nx, render_mode, first, count, d_result, hullPlanes, hullCount, hullCapL, hullFail);
+                         z0, y0, x0, nz, ny, nx, render_mode, first, count, d_result, hullPlanes, hullCount, hullCapL, hullFail, cmap);
       hipLaunchKernelGGL(k_resolve3d_seq, dim3(gb), dim3(256), 0, s, d_result, first, count, nvox, h_labels[p], use_overlap_label, overlap_label);
       SD_LAUNCH_CHECK();
     }
