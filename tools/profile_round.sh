@@ -22,7 +22,7 @@ for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM
   timeout 600 rocprofv3 --kernel-trace --pmc $P --output-format csv -d /tmp/pmc_$i -o p -- python $R/tools/pmc_predict.py > $O/pmc_$i.log 2>&1
 done
 f1=$(find /tmp/pmc_1 -name 'p_counter_collection.csv' | head -1); f2=$(find /tmp/pmc_2 -name 'p_counter_collection.csv' | head -1); f3=$(find /tmp/pmc_3 -name 'p_counter_collection.csv' | head -1)
-python $R/tools/profile_traffic.py ${f1%_counter_collection.csv} ${f2%_counter_collection.csv} $O/pmc_1.log $O/pair_kernel_traffic.json $O/pmc_hbm_traffic.md > $O/traffic.log 2>&1
+python $R/tools/profile_traffic.py ${f1%_counter_collection.csv} ${f2%_counter_collection.csv} $O/pmc_1.log $O/pair_kernel_traffic.json $O/pmc_hbm_traffic.md $tag > $O/traffic.log 2>&1
 python $R/tools/pmc_multi.py ${f3%_counter_collection.csv} k_ > $O/pmc_mfma.md 2>&1
 f4=$(find /tmp/pmc_4 -name 'p_counter_collection.csv' | head -1)
 [ -n "$f4" ] && python $R/tools/pmc_multi.py ${f4%_counter_collection.csv} k_conv3 > $O/pmc_conv_stalls.md 2>&1

@@ -8,6 +8,7 @@ is stored, and 2x raw as the upper bound."""
 import collections, csv, json, re, sys
 
 fpre, wpre, log, out_json, out_md = sys.argv[1:6]
+tag = sys.argv[6] if len(sys.argv) > 6 else "rNN"
 
 
 def nm(n):
@@ -35,7 +36,7 @@ doc = {"kernel": key, "size": size, "pairs_per_step": pairs, "pair_launches_per_
        "algorithmic_bytes_per_launch": 272.0 * pairs / launches,
        "traffic_over_algorithmic": (f_kib + w_kib) * 1024 / (272.0 * pairs / launches),
        "traffic_over_algorithmic_upper": (2 * f_kib + w_kib) * 1024 / (272.0 * pairs / launches),
-       "source": "profiles/r02_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_predict.py --skip-3d, raw counters)"}
+       "source": "profiles/%s_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_predict.py, raw counters)" % tag}
 json.dump(doc, open(out_json, "w"), indent=1)
 with open(out_md, "w") as fh:
     fh.write("| kernel | launches | FETCH_SIZE MiB / launch (raw) | WRITE_SIZE MiB / launch |\n|---|---|---|---|\n")
