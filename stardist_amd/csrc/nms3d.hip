@@ -37,11 +37,25 @@ typedef long long i64;
 enum { ST_UNDECIDED = 0, ST_KEPT = 1, ST_SUPPRESSED = 2 };
 
 // ------------------------------------------------------------------ P1 / P2
+// The per-candidate kernels walk a candidate's R distances in face order (gathers).  A workgroup's rows are contiguous in memory: they are
+// read once, coalesced, into LDS (row pitch R + 1: the lanes of a wave, one row each, hit distinct banks) -- one pass over the 4 R bytes
+// of every candidate instead of line-by-line re-fetches of 128 interleaved rows (FETCH_SIZE was 12x the rows' size).
+__device__ __forceinline__ const float* stage_rows(const float* __restrict__ dist, int N, int R, float* lds, int staged) {
+  if (!staged) return dist + (size_t)min((int)(blockIdx.x * blockDim.x + threadIdx.x), N - 1) * R;     // several hundred rays: rows stay in memory
+  const int i0 = blockIdx.x * blockDim.x;
+  const int rows = min((int)blockDim.x, N - i0);
+  const float* src = dist + (size_t)i0 * R;
+  for (int e = threadIdx.x; e < rows * R; e += blockDim.x) { const int r = e / R; lds[r * (R + 1) + (e - r * R)] = src[e]; }
+  __syncthreads();
+  return lds + threadIdx.x * (R + 1);
+}
+
 __global__ void k_pre1(const float* __restrict__ dist, const float* __restrict__ pts, const float* __restrict__ verts,
-                       const int* __restrict__ faces, int N, int R, int F, float* __restrict__ volume, int* __restrict__ bbox) {
+                       const int* __restrict__ faces, int N, int R, int F, float* __restrict__ volume, int* __restrict__ bbox, int staged) {
+  extern __shared__ float rows_lds[];
+  const float* d = stage_rows(dist, N, R, rows_lds, staged);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  const float* d = dist + (size_t)i * R;
   float vol = 0.f;                                                            // polyhedron_volume :257-291
   for (int f = 0; f < F; ++f) {
     const int iA = faces[3 * f], iB = faces[3 * f + 1], iC = faces[3 * f + 2];
@@ -66,10 +80,11 @@ struct Aniso { float a[3]; };
 
 __global__ void k_pre2(const float* __restrict__ dist, const float* __restrict__ verts, const int* __restrict__ faces, int N, int R,
                        int F, Aniso an, float* __restrict__ r_outer, float* __restrict__ r_outer_iso, float* __restrict__ r_inner_iso,
-                       int* gmax /* max outer radius bits */) {
+                       int* gmax /* max outer radius bits */, int staged) {
+  extern __shared__ float rows_lds[];
+  const float* d = stage_rows(dist, N, R, rows_lds, staged);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  const float* d = dist + (size_t)i * R;
   float r = 0;                                                                // bounding_radius_outer :343-350
   float r2max = 0;                                                            // bounding_radius_outer_isotropic :401-418
   for (int k = 0; k < R; ++k) {
@@ -1740,7 +1755,14 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   const int gi_init[8] = {0, INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN, INT32_MAX, INT32_MIN, 0};
   SD_CHECK(hipMemcpyAsync(gi, gi_init, sizeof(gi_init), hipMemcpyHostToDevice, s));
   SD_CHECK(hipMemsetAsync(state, 0, N, s));
-  hipLaunchKernelGGL(k_pre1, dim3(sd::div_up(N, 128)), dim3(128), 0, s, d_dist, d_points, d_verts, d_faces, N, R, F, volume, bbox);
+  size_t ldsRows = (size_t)128 * (R + 1) * sizeof(float);
+  const int staged = ldsRows <= 150 * 1024 ? 1 : 0;
+  if (!staged) ldsRows = 0;
+  if (ldsRows > 64 * 1024) {
+    SD_CHECK(hipFuncSetAttribute((const void*)k_pre1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsRows));
+    SD_CHECK(hipFuncSetAttribute((const void*)k_pre2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsRows));
+  }
+  hipLaunchKernelGGL(k_pre1, dim3(sd::div_up(N, 128)), dim3(128), ldsRows, s, d_dist, d_points, d_verts, d_faces, N, R, F, volume, bbox, staged);
   SD_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_minmax3, dim3(sd::div_up(N, 256)), dim3(256), 0, s, d_points, N, gi + 1);
   // anisotropy: sequential fp32 accumulation over candidates (:1008-1010) on the host
@@ -1759,7 +1781,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
     an.a[0] = tmp / a0; an.a[1] = tmp / a1; an.a[2] = tmp / a2;
   }
   if (verbose) { printf("NMS: calculated anisotropy: %.2f \t %.2f \t %.2f \n", an.a[0], an.a[1], an.a[2]); fflush(stdout); }
-  hipLaunchKernelGGL(k_pre2, dim3(sd::div_up(N, 128)), dim3(128), 0, s, d_dist, d_verts, d_faces, N, R, F, an, r_outer, r_outer_iso, r_inner_iso, gi);
+  hipLaunchKernelGGL(k_pre2, dim3(sd::div_up(N, 128)), dim3(128), ldsRows, s, d_dist, d_verts, d_faces, N, R, F, an, r_outer, r_outer_iso, r_inner_iso, gi, staged);
   SD_LAUNCH_CHECK();
   int g[8];
   SD_CHECK(hipMemcpyAsync(g, gi, sizeof(g), hipMemcpyDeviceToHost, s));
