@@ -160,6 +160,7 @@ __global__ void k_cell_fill3(int N, const int* __restrict__ candCell, const int*
 }
 
 struct Flags3 { int use_kdtree, use_bbox, thr_nonneg; float thr, max_dist; };
+#define WAIT3_NONE (-2)
 
 __device__ __forceinline__ bool bbox_pos_overlap(const int* a, const int* b) {
   return (min(a[1], b[1]) - max(a[0], b[0]) > 0) && (min(a[3], b[3]) - max(a[2], b[2]) > 0) && (min(a[5], b[5]) - max(a[4], b[4]) > 0);
@@ -181,7 +182,7 @@ template <int MODE>
 __global__ void __launch_bounds__(256) k_neighbours3(int N, Grid3 g, Flags3 f, const CellRec3* __restrict__ cellRec,
                                                      const int* __restrict__ candCell, const int* __restrict__ cellStart,
                                                      int* __restrict__ nbrCount, int* __restrict__ nbrLow,
-                                                     const i64* __restrict__ nbrStart, int* __restrict__ nbr, int W) {
+                                                     const i64* __restrict__ nbrStart, int* __restrict__ nbr, int* __restrict__ waitOn, int W) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int blk = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
   const int slot = blk * (blockDim.x >> 6) + wave;
@@ -195,6 +196,7 @@ __global__ void __launch_bounds__(256) k_neighbours3(int N, Grid3 g, Flags3 f, c
   // a candidate's list holds its lower-index neighbours first (what the greedy scan looks at: is a better candidate still undecided?),
   // then the higher-index ones (what a survivor is paired with): each consumer reads its half only
   int nLo = 0, nHi = 0;
+  int minj = INT_MAX;                      // MODE 1: the best-scored neighbour above i = the first wait target of the greedy scan
   const i64 baseLo = MODE ? nbrStart[i] : 0;
   const i64 baseHi = MODE ? baseLo + nbrLow[i] : 0;
   const int x_lo = max(cx - W, 0), x_hi = min(cx + W, g.nx - 1);
@@ -214,26 +216,58 @@ __global__ void __launch_bounds__(256) k_neighbours3(int N, Grid3 g, Flags3 f, c
         const unsigned long long mLo = __ballot(hit && j < i), mHi = __ballot(hit && j > i);
         const unsigned long long below = (1ull << lane) - 1;
         if (MODE && hit) {
-          if (j < i) nbr[baseLo + nLo + __popcll(mLo & below)] = j;
+          if (j < i) { nbr[baseLo + nLo + __popcll(mLo & below)] = j; minj = min(minj, j); }
           else nbr[baseHi + nHi + __popcll(mHi & below)] = j;
         }
         nLo += __popcll(mLo); nHi += __popcll(mHi);
       }
     }
   if (!MODE && lane == 0) { nbrCount[i] = nLo + nHi; nbrLow[i] = nLo; }
+  if (MODE) {
+    for (int o = 32; o; o >>= 1) minj = min(minj, __shfl_xor(minj, o));
+    if (lane == 0) waitOn[i] = (minj < i) ? minj : WAIT3_NONE;
+  }
 }
 
-__global__ void __launch_bounds__(256) k_round_decide3(const int* __restrict__ U, int nU, const unsigned char* __restrict__ state,
+// Greedy round, step 1: one THREAD per undecided candidate, O(1).  waitOn[i] is the better-scored neighbour i was last seen waiting
+// for (seeded by k_neighbours3 with the best-scored one; WAIT3_NONE: it has none).  While that neighbour is undecided, i keeps
+// waiting; only the candidates whose wait target has just been decided go to the list scan (k_round_decide3 over the list S).
+__global__ void __launch_bounds__(256) k_round_triage3(const int* __restrict__ U, int nU, const unsigned char* __restrict__ state,
+                                                       const int* __restrict__ waitOn, int* __restrict__ Unext, int* __restrict__ K,
+                                                       int* __restrict__ S, int* counters /* 0: nUnext, 1: nK, 6: nS */) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int kind = 0, i = -1;                       // 0 drop, 1 still waiting, 2 becomes a survivor, 3 needs the list scan
+  if (t < nU) {
+    i = U[t];
+    if (state[i] != ST_SUPPRESSED) {
+      const int wo = waitOn[i];
+      if (wo == WAIT3_NONE) kind = 2;
+      else if (wo >= 0 && state[wo] == ST_UNDECIDED) kind = 1;
+      else kind = 3;
+    }
+  }
+#pragma unroll
+  for (int q = 1; q <= 3; ++q) {
+    const unsigned long long m = __ballot(kind == q);
+    if (!m) continue;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&counters[q == 3 ? 6 : q - 1], __popcll(m));
+    base = __shfl(base, 0);
+    if (kind == q) (q == 1 ? Unext : (q == 2 ? K : S))[base + __popcll(m & ((1ull << lane) - 1))] = i;
+  }
+}
+
+// step 2: one WAVE per candidate of the scan list S (its length is read on the device): is any better-scored neighbour still undecided?
+__global__ void __launch_bounds__(256) k_round_decide3(const int* __restrict__ U, const int* __restrict__ nUPtr, const unsigned char* __restrict__ state,
                                                        const i64* __restrict__ nbrStart, const int* __restrict__ nbrLow, const int* __restrict__ nbr,
                                                        int* __restrict__ waitOn, int* __restrict__ Unext, int* __restrict__ K, int* counters) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int w = blockIdx.x * (blockDim.x >> 6) + wave;
-  if (w >= nU) return;
+  const int nU = *nUPtr;
+  for (int w = blockIdx.x * (blockDim.x >> 6) + wave; w < nU; w += gridDim.x * (blockDim.x >> 6)) {
   const int i = U[w];
-  if (state[i] == ST_SUPPRESSED) return;
-  const int wo = waitOn[i];
-  bool pending = (wo >= 0) && (state[wo] == ST_UNDECIDED);
-  if (!pending) {
+  bool pending = false;
+  {
     const i64 beg = nbrStart[i], end = beg + nbrLow[i];          // the lower-index neighbours
     int found = -1;
     for (i64 t = beg; t < end && found < 0; t += 64) {
@@ -244,11 +278,12 @@ __global__ void __launch_bounds__(256) k_round_decide3(const int* __restrict__ U
       if (m) found = __shfl(j, __ffsll((long long)m) - 1);
     }
     pending = found >= 0;
-    if (lane == 0 && pending) waitOn[i] = found;
+    if (lane == 0) waitOn[i] = pending ? found : WAIT3_NONE;
   }
   if (lane == 0) {
     if (pending) Unext[atomicAdd(&counters[0], 1)] = i;
     else K[atomicAdd(&counters[1], 1)] = i;
+  }
   }
 }
 
@@ -1833,7 +1868,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   Flags3 fs = f;
   SD_CHECK(hipMemsetAsync(nbrCount, 0, (N + 1) * sizeof(int), s));
   hipLaunchKernelGGL((k_neighbours3<0>), dim3(nbBlocks), dim3(256), 0, s, N, gr, fs, cellRec, candCell, cellStart,
-                     nbrCount, nbrLow, (const i64*)nullptr, (int*)nullptr, W);
+                     nbrCount, nbrLow, (const i64*)nullptr, (int*)nullptr, (int*)nullptr, W);
   SD_LAUNCH_CHECK();
   SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tb1, nbrCount, nbrStart, N + 1, s));
   i64 totalNbr = 0;
@@ -1875,9 +1910,10 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
     }
   }
   int* nbr = A.take_n<int>((size_t)totalNbr);
-  if (!nbr) return -1;
+  int* waitOn = A.take_n<int>(N);
+  if (!nbr || !waitOn) return -1;
   hipLaunchKernelGGL((k_neighbours3<1>), dim3(nbBlocks), dim3(256), 0, s, N, gr, fs, cellRec, candCell, cellStart,
-                     nbrCount, nbrLow, (const i64*)nbrStart, nbr, W);
+                     nbrCount, nbrLow, (const i64*)nbrStart, nbr, waitOn, W);
   SD_LAUNCH_CHECK();
   if (stats) SD_CHECK(hipEventRecord(evb1, s));
 
@@ -1895,14 +1931,14 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   int* U0 = A.take_n<int>(N);
   int* U1 = A.take_n<int>(N);
   int* Kl = A.take_n<int>(N);
-  int* waitOn = A.take_n<int>(N);
+  int* Sl = A.take_n<int>(N);
   int2* pairs3 = A.take_n<int2>(pairCap);
   int2* pairs4 = A.take_n<int2>(pairCap);
   int2* pairs5 = A.take_n<int2>(pairCap);
-  struct Counters { int nU, nK; unsigned int nP3, nP4, nP5, nHull; };
+  struct Counters { int nU, nK; unsigned int nP3, nP4, nP5, nHull; int nS; };
   Counters* d_cnt = (Counters*)A.take(sizeof(Counters));
   Stats* d_st = (Stats*)A.take(sizeof(Stats));
-  if (!U0 || !U1 || !Kl || !waitOn || !pairs3 || !pairs4 || !pairs5 || !d_cnt || !d_st) return -1;
+  if (!U0 || !U1 || !Kl || !Sl || !pairs3 || !pairs4 || !pairs5 || !d_cnt || !d_st) return -1;
   const int hullCap = 2 * R;                       // a hull of R points has at most 2R-4 facets
   int* hullState = A.take_n<int>(N);
   int* hullCount = A.take_n<int>(N);
@@ -1912,7 +1948,6 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
 
   if (!hullState || !hullCount || !hullList) return -1;
   SD_CHECK(hipMemsetAsync(hullState, 0, (size_t)N * sizeof(int), s));
-  SD_CHECK(hipMemsetAsync(waitOn, 0xFF, (size_t)N * sizeof(int), s));
   SD_CHECK(hipMemsetAsync(d_st, 0, sizeof(Stats), s));
   hipLaunchKernelGGL(k_iota3, dim3(sd::div_up(N, 256)), dim3(256), 0, s, U0, N);
   int nU = N, rounds = 0;
@@ -1941,7 +1976,9 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
       SD_CHECK(hipMemsetAsync(blocked, 0, N, s));
       h.nK = nU; h.nU = 0;
     } else {
-      hipLaunchKernelGGL(k_round_decide3, dim3(sd::div_up(nU, 4)), dim3(256), 0, s, Ucur, nU, state, nbrStart, nbrLow, nbr, waitOn, Unext, Kl, (int*)d_cnt);
+      hipLaunchKernelGGL(k_round_triage3, dim3(sd::div_up(nU, 256)), dim3(256), 0, s, Ucur, nU, state, waitOn, Unext, Kl, Sl, (int*)d_cnt);
+      const int wgrid = sd::div_up(nU, 4) < 2048 ? sd::div_up(nU, 4) : 2048;
+      hipLaunchKernelGGL(k_round_decide3, dim3(wgrid), dim3(256), 0, s, Sl, &d_cnt->nS, state, nbrStart, nbrLow, nbr, waitOn, Unext, Kl, (int*)d_cnt);
       SD_LAUNCH_CHECK();
       SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
       SD_CHECK(hipStreamSynchronize(s));
