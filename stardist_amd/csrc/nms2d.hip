@@ -253,6 +253,22 @@ __global__ void __launch_bounds__(256) k_round_scan(const int* __restrict__ S, c
   const int lane = threadIdx.x & 63;
   const int nS = counters[2];
   const int nWaves = gridDim.x * (blockDim.x >> 6);
+  // a wave visits its candidates one after the other; the outcomes are collected (lane k keeps the k-th) and appended to the two
+  // lists with ONE atomic per list and 64 candidates -- an atomicAdd per candidate on a single counter serialises at the L2
+  // (10^5 candidates in the second round = 1 ms)
+  int myI = -1, myKind = 0, nbuf = 0;
+  auto flush = [&]() {
+#pragma unroll
+    for (int q = 1; q <= 2; ++q) {
+      const unsigned long long m = __ballot(lane < nbuf && myKind == q);
+      if (!m) continue;
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&counters[q - 1], __popcll(m));
+      base = __shfl(base, 0);
+      if (lane < nbuf && myKind == q) (q == 1 ? Unext : K)[base + __popcll(m & ((1ull << lane) - 1))] = myI;
+    }
+    nbuf = 0;
+  };
   for (int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); w < nS; w += nWaves) {
     const int i = S[w];
     const i64 beg = nbrStart[i], end = beg + nbrLow[i];        // the better-scored neighbours
@@ -264,12 +280,11 @@ __global__ void __launch_bounds__(256) k_round_scan(const int* __restrict__ S, c
       const unsigned long long m = __ballot(j >= 0);
       if (m) found = __shfl(j, __ffsll((long long)m) - 1);
     }
-    if (lane == 0) {
-      if (found >= 0) { waitOn[i] = found; Unext[atomicAdd(&counters[0], 1)] = i; }
-      else if (pend[i]) { waitOn[i] = WAIT_NONE; Unext[atomicAdd(&counters[0], 1)] = i; }
-      else { waitOn[i] = WAIT_NONE; K[atomicAdd(&counters[1], 1)] = i; }
-    }
+    if (lane == 0) waitOn[i] = found >= 0 ? found : WAIT_NONE;
+    if (lane == nbuf) { myI = i; myKind = (found >= 0 || pend[i]) ? 1 : 2; }
+    if (++nbuf == 64) flush();
   }
+  flush();
 }
 
 // Round kernel B: wave per new survivor: mark it, emit the pairs the reference would evaluate.

@@ -264,10 +264,22 @@ __global__ void __launch_bounds__(256) k_round_decide3(const int* __restrict__ U
                                                        int* __restrict__ waitOn, int* __restrict__ Unext, int* __restrict__ K, int* counters) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nU = *nUPtr;
+  // outcomes are collected per wave (lane k keeps the k-th) and appended with one atomic per list and 64 candidates
+  int myI = -1, myKind = 0, nbuf = 0;
+  auto flush = [&]() {
+#pragma unroll
+    for (int q = 1; q <= 2; ++q) {
+      const unsigned long long m = __ballot(lane < nbuf && myKind == q);
+      if (!m) continue;
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&counters[q - 1], __popcll(m));
+      base = __shfl(base, 0);
+      if (lane < nbuf && myKind == q) (q == 1 ? Unext : K)[base + __popcll(m & ((1ull << lane) - 1))] = myI;
+    }
+    nbuf = 0;
+  };
   for (int w = blockIdx.x * (blockDim.x >> 6) + wave; w < nU; w += gridDim.x * (blockDim.x >> 6)) {
-  const int i = U[w];
-  bool pending = false;
-  {
+    const int i = U[w];
     const i64 beg = nbrStart[i], end = beg + nbrLow[i];          // the lower-index neighbours
     int found = -1;
     for (i64 t = beg; t < end && found < 0; t += 64) {
@@ -277,14 +289,11 @@ __global__ void __launch_bounds__(256) k_round_decide3(const int* __restrict__ U
       const unsigned long long m = __ballot(j >= 0);
       if (m) found = __shfl(j, __ffsll((long long)m) - 1);
     }
-    pending = found >= 0;
-    if (lane == 0) waitOn[i] = pending ? found : WAIT3_NONE;
+    if (lane == 0) waitOn[i] = found >= 0 ? found : WAIT3_NONE;
+    if (lane == nbuf) { myI = i; myKind = found >= 0 ? 1 : 2; }
+    if (++nbuf == 64) flush();
   }
-  if (lane == 0) {
-    if (pending) Unext[atomicAdd(&counters[0], 1)] = i;
-    else K[atomicAdd(&counters[1], 1)] = i;
-  }
-  }
+  flush();
 }
 
 struct Stats { unsigned long long upper, lower, kernel, render, kept_pre, sup_pre, sup_kernel, sup_render, convex, kept_convex, overflow, hiv_faces, hiv_fallback, hiv_list, hiv_clips, hiv_rest, lb_decided, ub_decided;
