@@ -212,20 +212,20 @@ def run_leg(model, img, steps, warmup, world, dist_):
     return elapsed, net_ms, res, stats
 
 
-def run_split_leg(model, img, steps, warmup, world, dist_):
-    """The same steps with the opt-in split-bf16 convolution kernel (csrc/conv3x3_bf16.hip: six bf16 MFMAs per f32 product, f32-level
-    accuracy -- tests/test_gpu_unet_parity.py holds it to the same 1e-5 bar against float64).  Reported NEXT TO `value`, never as it:
-    `value` is measured with the exact-f32 kernel.  Returns a dict, or an error note (this leg must never take the bench down)."""
+def run_exact_leg(model, img, steps, warmup, world, dist_):
+    """The same steps with the exact-f32 convolution kernel (csrc/conv3x3.hip, STARDIST_AMD_CONV=hand: one f32 fma chain per output)
+    instead of the default split-bf16 kernel (csrc/conv3x3_bf16.hip: six bf16 MFMA products per f32 product, f32 accumulation; both are
+    held to the same 1e-5 bar against float64 by tests/test_gpu_unet_parity.py and tests/test_gpu_conv3x3.py).  Reported NEXT TO `value`.
+    Returns a dict, or an error note (this leg must never take the bench down)."""
     old = os.environ.get("STARDIST_AMD_CONV")
     graphs = model.__dict__.pop("_graphs", None)
-    os.environ["STARDIST_AMD_CONV"] = "bf16x6"
+    os.environ["STARDIST_AMD_CONV"] = "hand"
     try:
         elapsed, net_ms, res, _ = run_leg(model, img, steps, warmup, world, dist_)
         n = int(np.prod(img.shape))
         return {"value": round(world * n * steps / elapsed / 1e6, 3), "ms_per_step": round(1e3 * elapsed / steps, 3), "unet_forward_ms": round(net_ms, 3),
                 "instances": len(res[1]["prob"]), "steps": steps,
-                "arithmetic": "f32 operands split into three bf16 terms, six bf16 x bf16 MFMA products per f32 product, f32 accumulation "
-                              "(STARDIST_AMD_CONV=bf16x6); outputs within 2e-6 of a float64 evaluation, like the exact-f32 kernel"}
+                "arithmetic": "exact f32 MFMA (v_mfma_f32_32x32x2_f32), one fma chain per output (STARDIST_AMD_CONV=hand)"}
     except Exception as e:                       # pragma: no cover
         return {"value": None, "error": repr(e)[:200]}
     finally:
@@ -310,7 +310,8 @@ def main():
     ap.add_argument("--sharded-size", type=int, default=16384)
     ap.add_argument("--sharded-size3d", type=int, default=1024)
     ap.add_argument("--skip-sharded-3d", action="store_true")
-    ap.add_argument("--no-split-leg", action="store_true", help="skip the extra legs with the opt-in split-bf16 convolution kernel")
+    ap.add_argument("--no-split-leg", "--no-exact-leg", dest="no_split_leg", action="store_true",
+                    help="skip the extra legs with the exact-f32 convolution kernel")
     args = ap.parse_args()
 
     import torch
@@ -364,14 +365,23 @@ def main():
         stages = {"unet_forward": round(net_ms, 3), "nms_pair_kernel": round(float(pair_ms), 3),
                   "nms_exact_join_kernel": round(float(s2[6] / 1e6), 3), "nms_build_bin_neighbours": round(float(s2[7] / 1e6), 3),
                   "other(select,sort,greedy-scan,raster,d2h)": round(ms_per_step - net_ms - float(pair_ms + s2[6] / 1e6 + s2[7] / 1e6), 3)}
-        from stardist_amd.models.unet import hand_conv_enabled
-        conv_kernel = ("network forward = one HIP graph: k_conv3<1> (hand-written f32-MFMA implicit GEMM, csrc/conv3x3.hip: every 3x3 layer incl. folded "
-                       "up-sampling / concatenation / bias / ReLU) + k_conv3_c1x32 + max-pool + probability-head pass" if hand_conv_enabled() and args.dtype == "float32"
-                       else "network forward (MIOpen / CK convolution kernels, NHWC) + epilogue passes")
-        roof_conv = {"bound": "mfma", "kernel": conv_kernel, "achieved": round(conv_tf, 3), "peak": peak,
-                     "unit": "TFLOP/s", "frac": round(conv_tf / peak, 4), "traffic": None, "flops_per_launch": flops, "avg_ms": round(net_ms, 3),
-                     "note": "algorithmic FLOPs of the convolutions (2 x MACs, recomputed from the instantiated module) / HIP-event time of the whole "
-                             "forward pass on the caller's stream; per-kernel durations: profiles/r03_bench_kernel_stats.md"}
+        from stardist_amd.models.unet import conv_mode
+        mode = conv_mode() if args.dtype == "float32" else "miopen"
+        # roofline of the convolutions.  Split kernel (default): every f32 multiply-accumulate is six bf16 x bf16 MFMA products, so the
+        # matrix cores execute 6x the algorithmic FLOPs, on the bf16 pipe (dense peak 2.5 PFLOP/s); exact kernel: the FLOPs themselves on
+        # the f32 pipe (157.3 TFLOP/s).  `achieved` / `peak` / `frac` are those of the pipe the kernel runs on; `f32_equivalent_tflops` is
+        # the algorithmic rate either way.
+        mult, cpeak, pipe = (6.0, MFMA_BF16_PEAK_TFLOPS, "bf16") if mode == "bf16x6" else (1.0, peak, "f32" if args.dtype == "float32" else args.dtype)
+        conv_kernel = {"bf16x6": "network forward = one HIP graph: k_conv3_bf16 (hand-written split-bf16 implicit GEMM, csrc/conv3x3_bf16.hip: every 3x3 layer incl. "
+                                 "folded up-sampling / concatenation / bias / ReLU; v_mfma_f32_32x32x16_bf16, six products per f32 product, f32 accumulate) + "
+                                 "k_conv3_c1x32 + k_maxpool_cl4 + probability-head pass",
+                       "hand": "network forward = one HIP graph: k_conv3<1> (hand-written exact-f32 MFMA implicit GEMM, csrc/conv3x3.hip) + k_conv3_c1x32 + "
+                               "k_maxpool_cl4 + probability-head pass"}.get(mode, "network forward (MIOpen / CK convolution kernels, NHWC) + epilogue passes")
+        roof_conv = {"bound": "mfma", "pipe": pipe, "kernel": conv_kernel, "achieved": round(conv_tf * mult, 3), "peak": cpeak,
+                     "unit": "TFLOP/s", "frac": round(conv_tf * mult / cpeak, 4), "traffic": None, "flops_per_launch": flops * mult,
+                     "f32_equivalent_tflops": round(conv_tf, 3), "frac_of_f32_peak_equivalent": round(conv_tf / MFMA_F32_PEAK_TFLOPS, 4), "avg_ms": round(net_ms, 3),
+                     "note": "algorithmic FLOPs of the convolutions (2 x MACs, recomputed from the instantiated module; x6 executed products for the split "
+                             "kernel) / HIP-event time of the whole forward pass on the caller's stream; per-kernel durations: profiles/r03_bench_kernel_stats.md"}
         roof_pair = {"bound": "hbm", "kernel": "k_pairs_beam<32,8,6,4,64> (bound-slot scan-beam polygon intersection, one pair per lane, state in LDS)", "achieved": round(pair_gbs, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pair_gbs / HBM_PEAK_GBS, 6), "traffic": None,
                      "bytes_per_launch": round(pair_bytes_per_launch), "avg_launch_ms": round(float(pair_ms / pair_launches), 4),
@@ -392,6 +402,11 @@ def main():
             "value": round(world * H * W * args.steps / elapsed / 1e6, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dt, "data": "synthetic",
+            "arithmetic": ("float32 data, float32 accumulation; 3x3 convolution products " +
+                           ("as six bf16 x bf16 terms of operands split into three bf16 parts (f32-accurate: layers and networks within 3e-6 of a float64 "
+                            "evaluation, tests/test_gpu_conv3x3.py, test_gpu_unet_parity.py; `exact_f32` = the same step with the exact-f32 MFMA kernel)"
+                            if args.dtype == "float32" and conv_mode() == "bf16x6" else "in the named dtype") +
+                           "; NMS / rasteriser in the reference's own int64 / float32 / float64 arithmetic"),
             "config": {"workload": "StarDist2D 32-ray U-Net (depth 3, 32 base filters), %dx%d synthetic fluo tile per GPU, predict_instances "
                                    "(U-Net + select + 2D NMS + polygon raster), seeded random weights, heads calibrated to ~10%% candidates "
                                    "radius 10+-10%%" % (H, W),
@@ -407,10 +422,10 @@ def main():
             except Exception as e:   # oracle/_ref must have travelled with the tree
                 out["cpu_baseline"] = {"value": None, "unit": "Mpix/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
     if args.dtype == "float32" and not args.no_split_leg:
-        r = run_split_leg(model, img, max(1, min(args.steps, 10)), 2, world, dist_)
+        r = run_exact_leg(model, img, max(1, min(args.steps, 10)), 2, world, dist_)
         if rank == 0:
             r["unit"] = "Mpix/s"
-            out["split_bf16"] = r
+            out["exact_f32"] = r
     # ---- config 4: one 16384^2 slide (the 2048^2 synthetic tile repeated), blocks 4096 / overlap 128 / context 128, sharded over the ranks
     if not args.no_sharded:
         rep = max(1, args.sharded_size // H)
@@ -465,9 +480,11 @@ def main():
             out["stages_ms_3d"] = {"unet_forward": round(net3_ms, 3), "nms_stage3_kernel_volume": round(float(s3[8] / 1e6), 3),
                                    "nms_stage4_hull_volume": round(float(s3[9] / 1e6), 3), "nms_stage5_render": round(float(s3[10] / 1e6), 3),
                                    "other": round(ms3 - net3_ms - float((s3[8] + s3[9] + s3[10]) / 1e6), 3)}
-            out["roofline_convs_3d"] = {"bound": "mfma", "kernel": "network forward (k_conv3<1> 3x3x3 layers as three z-plane units per 32-channel chunk)",
-                                        "achieved": round(conv3_tf, 3), "peak": peak, "unit": "TFLOP/s",
-                                        "frac": round(conv3_tf / peak, 4), "flops_per_launch": flops3, "avg_ms": round(net3_ms, 3)}
+            out["roofline_convs_3d"] = {"bound": "mfma", "pipe": pipe, "kernel": "network forward (3x3x3 layers as three z-plane units per 32-channel chunk; kernel family as `roofline_convs`)",
+                                        "achieved": round(conv3_tf * mult, 3), "peak": cpeak, "unit": "TFLOP/s",
+                                        "frac": round(conv3_tf * mult / cpeak, 4), "flops_per_launch": flops3 * mult,
+                                        "f32_equivalent_tflops": round(conv3_tf, 3), "frac_of_f32_peak_equivalent": round(conv3_tf / MFMA_F32_PEAK_TFLOPS, 4),
+                                        "avg_ms": round(net3_ms, 3)}
             if not args.no_cpu_baseline and world == 1:
                 try:
                     cb = cpu_baseline_3d(vol_np, m3, min(args.cpu_sample3d, S), threads)
@@ -480,10 +497,10 @@ def main():
                 except Exception as e:
                     out["cpu_baseline_3d"] = {"value": None, "unit": "Mvox/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
         if args.dtype == "float32" and not args.no_split_leg:
-            r = run_split_leg(m3, vol, steps3, 1, world, dist_)
+            r = run_exact_leg(m3, vol, steps3, 1, world, dist_)
             if rank == 0:
                 r["unit"] = "Mvox/s"
-                out["split_bf16_3d"] = r
+                out["exact_f32_3d"] = r
         # ---- config 5: one 1024^3 volume (the 256^3 synthetic volume repeated), 256^3 blocks / overlap 32 / context 32, sharded
         if not args.no_sharded and not args.skip_sharded_3d:
             rep = max(1, args.sharded_size3d // S)

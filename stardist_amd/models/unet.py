@@ -123,10 +123,15 @@ def _conv_cat_bias_act(conv, a, b, kind):
 # summation order.  STARDIST_AMD_CONV=miopen switches them off (every layer through MIOpen, as before); the choice is read per call
 # so tests can compare both.
 def conv_mode():
-    """'hand' (default: exact f32 MFMA kernel), 'bf16x6' (opt-in: six bf16 MFMAs per f32 product, f32-level accuracy), 'miopen'"""
+    """Which kernel family the 3x3 / 3x3x3 layers over 32-channel chunks run on (STARDIST_AMD_CONV, read per call):
+      'bf16x6' (default)  csrc/conv3x3_bf16.hip: every f32 product as six bf16 x bf16 MFMA products with f32 accumulation -- f32-accurate
+                          (layers and networks within 3e-6 of a float64 evaluation, the same as the exact kernel; same 1e-5 tests), 1.33x faster
+      'hand' / 'f32'      csrc/conv3x3.hip: exact f32 MFMA kernel (one fma chain per output)
+      'miopen'            library kernels (A/B probes only; not deterministic across boxes)
+    The one-channel first layer and the general kernel (csrc/conv_general.hip) are exact f32 in every mode."""
     import os
-    m = os.environ.get("STARDIST_AMD_CONV", "hand")
-    return m if m in ("miopen", "bf16x6") else "hand"
+    m = os.environ.get("STARDIST_AMD_CONV", "bf16x6")
+    return "miopen" if m == "miopen" else ("hand" if m in ("hand", "f32") else "bf16x6")
 
 
 def hand_conv_enabled():

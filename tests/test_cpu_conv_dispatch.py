@@ -40,7 +40,7 @@ def _t(shape, cl):
 def test_dispatch_2d_and_3d(recorder, monkeypatch):
     import torch
     hand, calls = recorder
-    monkeypatch.delenv("STARDIST_AMD_CONV", raising=False)
+    monkeypatch.setenv("STARDIST_AMD_CONV", "hand")                       # the exact-f32 kernel's entry point (same arguments as the split one)
     cl2, cl3 = torch.channels_last, torch.channels_last_3d
     with torch.no_grad():
         y = hand(torch.nn.Conv2d(64, 32, 3, padding=1), [(_t((1, 32, 8, 12), cl2), (1, 1)), (_t((1, 32, 16, 24), cl2), 0)], 1)
@@ -128,8 +128,14 @@ def test_dispatch_rejections_and_modes(recorder, monkeypatch):
         n0 = len(calls)
         monkeypatch.setenv("STARDIST_AMD_CONV", "miopen")
         assert hand(torch.nn.Conv2d(32, 32, 3, padding=1), [(x32, 0)], 1) is None and len(calls) == n0
+        for mode, entry in (("bf16x6", "sd_conv3_bf16x6_res_ndhwc_device"), (None, "sd_conv3_bf16x6_res_ndhwc_device"), ("hand", "sd_conv3_res_ndhwc_device"),
+                            ("f32", "sd_conv3_res_ndhwc_device")):               # default = the split-bf16 kernel
+            if mode is None:
+                monkeypatch.delenv("STARDIST_AMD_CONV", raising=False)
+            else:
+                monkeypatch.setenv("STARDIST_AMD_CONV", mode)
+            assert hand(torch.nn.Conv2d(32, 32, 3, padding=1), [(x32, 0)], 1) is not None and calls[-1][0] == entry, mode
         monkeypatch.setenv("STARDIST_AMD_CONV", "bf16x6")
-        assert hand(torch.nn.Conv2d(32, 32, 3, padding=1), [(x32, 0)], 1) is not None and calls[-1][0] == "sd_conv3_bf16x6_res_ndhwc_device"
         assert hand(torch.nn.Conv2d(1, 32, 3, padding=1), [(_t((1, 1, 8, 8), cl2), 0)], 1) is not None and calls[-1][0] == "sd_conv3_res_ndhwc_device"
     with torch.enable_grad():
         monkeypatch.delenv("STARDIST_AMD_CONV", raising=False)

@@ -72,7 +72,8 @@ def test_conv3_matches_float64(shape, chans, c_out, kind, mode, monkeypatch):
     ref = _ref(srcs, conv, kind)
     err = float((y.cpu().double() - ref).abs().max())
     scale = max(1.0, float(ref.abs().max()))
-    assert err <= (1e-5 if mode == "hand" else 2e-5) * scale, (err, scale)
+    print("conv3 %s %s %s c_out %d kind %d: max err / scale = %.3g" % (mode, shape, chans, c_out, kind, err / scale))
+    assert err <= 1e-5 * scale, (err, scale)       # the same bar for the exact-f32 and the split-bf16 kernel
 
 
 def test_layout_conversion_and_refusals():

@@ -2,7 +2,7 @@
 in a HIP graph) against the SAME module evaluated on the CPU in float32 and float64 -- the <=1e-5 bar of the north star on
 probabilities and distances -- and run-to-run / process-to-process determinism (so that survivor indices are reproducible end to end).
 Topologies: default U-Nets, grid (2,2) (2D_demo / 2D_versatile_fluo), 3 input channels (2D_versatile_he), batch-norm, multi-class
-head, ResNet backbone (3D_demo), and the opt-in split-bf16 kernel.
+head, ResNet backbone (3D_demo) -- with the default split-bf16 convolution kernel and with the exact-f32 kernel.
 TensorFlow itself is not installed: this pins the GPU arithmetic, not the Keras graph translation, which
 tests/test_cpu_host_logic.py pins against a numpy restatement of the Keras semantics."""
 import numpy as np
@@ -52,8 +52,9 @@ def _image(dim, size):
     return synth.s3d_nuclei_image(size, seed=1)
 
 
+# every topology with the default convolution kernel (split-bf16 products, f32 accumulation); "-f32exact": the exact-f32 MFMA kernel
 KINDS = ["unet2d", "unet2d-grid2", "unet2d-he", "unet2d-bn", "unet2d-multiclass", "unet3d", "resnet3d",
-         "unet2d-split", "unet3d-split", "unet2d-bf16x6", "unet3d-bf16x6", "resnet3d-bf16x6"]
+         "unet2d-f32exact", "unet2d-grid2-f32exact", "unet2d-bn-f32exact", "unet3d-f32exact", "resnet3d-f32exact"]
 
 
 @pytest.mark.parametrize("kind", KINDS)
@@ -61,16 +62,13 @@ def test_gpu_forward_matches_cpu_float32_and_is_deterministic(kind, monkeypatch)
     import torch
     import bench
     import stardist_amd.models.unet as U
-    if kind.endswith("-bf16x6"):
-        # the opt-in split-bf16 convolution kernel (six bf16 MFMAs per f32 product): same <= 1e-5 bar against float64
-        monkeypatch.setenv("STARDIST_AMD_CONV", "bf16x6")
-        kind = kind[:-7]
+    if kind.endswith("-f32exact"):
+        # the exact-f32 MFMA kernel (STARDIST_AMD_CONV=hand); the default split-bf16 kernel is held to the same <= 1e-5 bar against float64
+        monkeypatch.setenv("STARDIST_AMD_CONV", "hand")
+        kind = kind[:-9]
     else:
         monkeypatch.delenv("STARDIST_AMD_CONV", raising=False)
-    if kind.endswith("-split"):
-        # the two-source form of Concatenate+Conv of the library path, forced at test size (the hand-written layers never concatenate)
-        monkeypatch.setattr(U, "_SPLIT_CONCAT_MIN_ELEMS", 0)
-        kind = kind[:-6]
+        assert U.conv_mode() == "bf16x6"
     make, (dim, size), calib = _models(kind)
     img = _image(dim, size)
     dev = torch.device("cuda:0")
