@@ -238,21 +238,38 @@ def run_exact_leg(model, img, steps, warmup, world, dist_):
             model._graphs = graphs
 
 
-def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, dist_, rank, pipeline=False):
+def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, dist_, rank, pipeline=True):
     """BASELINE.json configs 4/5: ONE large input, its blocks dealt round-robin to the ranks; per block network + selection + local NMS on
     the device; one gather of the surviving records to rank 0; cross-tile NMS over the band survivors only; final instances broadcast and
     every rank renders the write regions of its blocks (stardist_amd/big.py, design A of SURVEY.md 8e).  Strong scaling: the input is
     the same for every N.  N = 1: the label image comes back as ONE host array (as predict_instances returns it); N > 1: the tiles stay on
     the ranks that rendered them (labels_out="local"), as the reference's block.write leaves them in the shared output.
+    pipeline: the network of block k+1 runs on the main stream while the NMS of block k runs on a second one; the warm-up runs a
+    two-block input through both loops and the pipelined one is used only if it returns bit-identical instances and labels.
     Returns a dict (rank 0) or None."""
     import torch
+    # warm-up on TWO blocks' worth of the input (HIP graph of the block shape, arena growth): a full pass of the 1024^3 volume is ~10 s
+    warm = big[tuple(slice(0, block) for _ in range(big.dim() - 1)) + (slice(0, min(big.shape[-1], 2 * block - overlap - 2 * context)),)]
+    wkw = dict(block_size=block, min_overlap=overlap, context=context, distributed=False)
+    l0, r0_ = model.predict_instances_sharded(warm, axes, pipeline=False, **wkw)
+    check = "serial loop"
+    if pipeline:
+        l1, r1_ = model.predict_instances_sharded(warm, axes, pipeline=True, **wkw)
+        same = (bool(model._last_sharded_stats["pipelined"]) and np.array_equal(np.asarray(l0), np.asarray(l1))
+                and all(np.array_equal(np.asarray(r0_[k]), np.asarray(r1_[k])) for k in ("points", "prob")))
+        check = "two-block warm-up: pipelined == serial (labels, points, prob bit-identical)" if same else "two-block warm-up DISAGREED: serial loop used"
+        pipeline = same
+        del l1, r1_
+    if world > 1:                          # one decision for all ranks
+        flag = torch.tensor([int(pipeline)], device=big.device)
+        dist_.all_reduce(flag, op=dist_.ReduceOp.MIN)
+        if pipeline and not flag.item():
+            check = "another rank's two-block warm-up disagreed: serial loop used"
+        pipeline = bool(flag.item())
+    del warm, l0, r0_
     kw = dict(block_size=block, min_overlap=overlap, context=context, broadcast_result=False, pipeline=pipeline)
     if world > 1:
         kw["labels_out"] = "local"
-    # warm-up on ONE block's worth of the input (HIP graph of the block shape, arena growth): a full pass of the 1024^3 volume is ~30 s
-    warm = big[tuple(slice(0, block) for _ in range(big.dim()))]
-    model.predict_instances_sharded(warm, axes, block_size=block, min_overlap=overlap, context=context, distributed=False)
-    del warm
     if world > 1:
         dist_.barrier()
     torch.cuda.synchronize()
@@ -284,7 +301,7 @@ def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, di
             "input_shape": list(big.shape), "block_size": block, "min_overlap": overlap, "context": context, "blocks": sum(p["blocks"] for p in per_rank),
             "instances": r0["instances"], "candidates": sum(p["candidates"] for p in per_rank),
             "gathered_survivors": r0["gathered"], "gathered_bytes": r0["gathered_bytes"], "band_survivors": r0["band"], "interior_survivors": r0["interior"],
-            "pipelined": bool(r0["pipelined"]), "t_phase1": max(p["t_phase1"] for p in per_rank),
+            "pipelined": bool(r0["pipelined"]), "pipeline_check": check, "t_phase1": max(p["t_phase1"] for p in per_rank),
             "t_predict": max(p["t_predict"] for p in per_rank), "t_local_nms": max(p["t_local_nms"] for p in per_rank), "t_exchange": r0["t_exchange"],
             "t_final": r0["t_final"], "t_final_nms": r0["t_final_nms"], "t_raster": max(p["t_raster"] for p in per_rank),
             "t_final_frac": round(r0["t_final"] / s_pass, 4),
@@ -309,6 +326,11 @@ def main():
     ap.add_argument("--no-sharded", action="store_true", help="skip the block-sharded big-input legs (configs 4/5; run by default at every N)")
     ap.add_argument("--sharded-size", type=int, default=16384)
     ap.add_argument("--sharded-size3d", type=int, default=1024)
+    # block sizes (read size incl. context, as in the reference's BlockND.cover): 4480 -> 16 blocks of the 16384^2 slide (1.20x the slide's
+    # pixels, an equal number per rank at N = 1, 2, 4, 8); 416 -> 27 blocks of the 1024^3 volume (1.81x; a 32-channel level of one block is
+    # 9.2 GB, the 128-channel features 37 GB)
+    ap.add_argument("--sharded-block", type=int, default=4480)
+    ap.add_argument("--sharded-block3d", type=int, default=416)
     ap.add_argument("--skip-sharded-3d", action="store_true")
     ap.add_argument("--no-split-leg", "--no-exact-leg", dest="no_split_leg", action="store_true",
                     help="skip the extra legs with the exact-f32 convolution kernel")
@@ -426,11 +448,11 @@ def main():
         if rank == 0:
             r["unit"] = "Mpix/s"
             out["exact_f32"] = r
-    # ---- config 4: one 16384^2 slide (the 2048^2 synthetic tile repeated), blocks 4096 / overlap 128 / context 128, sharded over the ranks
+    # ---- config 4: one 16384^2 slide (the 2048^2 synthetic tile repeated), blocks 4480 / overlap 128 / context 128, sharded over the ranks
     if not args.no_sharded:
         rep = max(1, args.sharded_size // H)
         big = torch.from_numpy(synth.s2d_nuclei_image(H, W, seed=0)).to(dev).repeat(rep, rep)
-        r = run_sharded_leg(model, big, "YX", min(4096, big.shape[0]), 128, 128, 2, world, dist_, rank)
+        r = run_sharded_leg(model, big, "YX", min(args.sharded_block, big.shape[0]), 128, 128, 2, world, dist_, rank)
         if rank == 0:
             r["unit"] = "Mpix/s"
             out["sharded_2d"] = r
@@ -501,11 +523,11 @@ def main():
             if rank == 0:
                 r["unit"] = "Mvox/s"
                 out["exact_f32_3d"] = r
-        # ---- config 5: one 1024^3 volume (the 256^3 synthetic volume repeated), 256^3 blocks / overlap 32 / context 32, sharded
+        # ---- config 5: one 1024^3 volume (the 256^3 synthetic volume repeated), 416^3 blocks / overlap 32 / context 32, sharded
         if not args.no_sharded and not args.skip_sharded_3d:
             rep = max(1, args.sharded_size3d // S)
             bigv = torch.from_numpy(synth.s3d_nuclei_image(S, seed=0)).to(dev).repeat(rep, rep, rep)
-            r = run_sharded_leg(m3, bigv, "ZYX", min(256, bigv.shape[0]), 32, 32, 1, world, dist_, rank)
+            r = run_sharded_leg(m3, bigv, "ZYX", min(args.sharded_block3d, bigv.shape[0]), 32, 32, 1, world, dist_, rank)
             if rank == 0:
                 r["unit"] = "Mvox/s"
                 out["sharded_3d"] = r

@@ -162,6 +162,10 @@ def test_sharded_window_tiles_equal_whole_image_raster_and_band_nms_equals_union
     assert np.array_equal(res2["points"], res["points"]) and len(tiles) == st["blocks"]
     for bi, sl, t in tiles:
         assert np.array_equal(t.cpu().numpy(), labels[sl]), bi
+    # the two-stream loop (network of block k+1 on the main stream while the NMS of block k runs on a second one) returns the same result
+    labels_p, res_p = model.predict_instances_sharded(img, pipeline=True, **args)
+    assert model._last_sharded_stats["pipelined"] == 1
+    assert np.array_equal(labels_p, labels) and all(np.array_equal(res_p[k], res[k]) for k in res)
     if dim == "2d-multiclass":
         assert res["class_prob"].shape == (len(res["prob"]), 4) and np.allclose(res["class_prob"].sum(1), 1, atol=1e-5)
         assert np.array_equal(res["class_id"], res["class_prob"].argmax(1))
