@@ -360,8 +360,8 @@ extern "C" int sd_conv3_res_ndhwc_device(const float* d_src0, int c0, int stride
   }
   Params P;
   int nc = 0;
-  P.kind[0] = Src{d_src0, stride0, (up0 >> 2) & 1, (up0 >> 1) & 1, up0 & 1};
-  P.kind[1] = d_src1 ? Src{d_src1, stride1, (up1 >> 2) & 1, (up1 >> 1) & 1, up1 & 1} : P.kind[0];
+  P.kind[0] = make_src(d_src0, stride0, up0, H, W);
+  P.kind[1] = d_src1 ? make_src(d_src1, stride1, up1, H, W) : P.kind[0];
   for (int k = 0; k < MAX_CHUNKS; ++k) { P.chunk_kind[k] = 0; P.chunk_choff[k] = 0; }
   for (int k = 0; k < c0 / 32; ++k) { P.chunk_kind[nc] = 0; P.chunk_choff[nc++] = k * 32; }
   if (d_src1) for (int k = 0; k < c1 / 32; ++k) { P.chunk_kind[nc] = 1; P.chunk_choff[nc++] = k * 32; }

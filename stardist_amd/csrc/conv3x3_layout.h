@@ -67,6 +67,19 @@ SDC_HD void stage_elem(int e, int& ty, int& tx, int& q4) {
   tx = pix - ty * HALO_W;
 }
 
+// The split-bf16 kernel's assignment (conv3x3_bf16.hip): its LDS tile has a pixel stride of 52 dwords and a thread writes 8 bytes per
+// plane, so 8 lanes cover 16 banks of one pixel; pixels 4 apart start 16 banks apart (4 * 52 mod 64), adjacent ones overlap in 4 banks.
+// Inside each full block of 256 elements (32 pixels) the 8-lane groups of a wave therefore take pixels 4 apart (wave w: pixels
+// w, w + 4, ..., w + 28 of the block): every 16- or 32-lane group of a ds_write_b64 hits distinct banks.  The global loads are
+// unaffected (8 lanes still read one pixel's 128 contiguous bytes).  The last, partial block keeps the plain order.
+SDC_HD void stage_elem_b(int e, int& ty, int& tx, int& q4) {
+  q4 = e & 7;
+  const int n = e >> 8;
+  const int pix = n < (TILE_F4 >> 8) ? 32 * n + ((e >> 3) & 7) * 4 + ((e >> 6) & 3) : e >> 3;
+  ty = pix / HALO_W;
+  tx = pix - ty * HALO_W;
+}
+
 // Halo coordinates of a tile start at t0 = 8k - 1 (rows) / 32m - 1 (columns): always odd.  For a half-resolution source (sh = 1)
 // halo index t maps to source index (t0 + t) >> 1 = src_base(t0, 1) + src_rel(t, 1), both parts non-negative inside the image;
 // for a full-resolution source (sh = 0) to t0 + t.  The kernel's fast path adds a wave-uniform base built from src_base to
