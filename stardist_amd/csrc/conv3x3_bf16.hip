@@ -13,6 +13,16 @@
 //   * a unit's weights (3 planes x 18 KiB) do not fit next to that tile twice, so a unit is walked as three SUB-UNITS (row tap dy),
 //     each with its own 18-KiB weight block, double buffered, staged through registers;
 //   * per (column tap, 16-channel block): 6 + 3 ds_read_b128 feed 12 MFMAs.
+//
+// One workgroup per CU (137 KiB of LDS) means one wave per SIMD: nothing hides a wave's own latencies, and an MFMA occupies the matrix
+// pipe for 32 cycles while an ALU instruction issues in 4.  Everything that is not a matrix instruction is therefore placed BEHIND one
+// (sched_group_barrier patterns in compute_sub): the address arithmetic of the next unit's halo in the first sub-unit, the halo loads
+// themselves in the second, the f32 -> 3 x bf16 split of the arrived halo (v_cvt_pk_bf16_f32) in the third; after the last barrier of a
+// unit only the LDS stores of the split planes are left.  Per-tile quantities (tile coordinates: two integer divisions; source
+// offsets) are computed once per tile, and every scalar the in-shadow code needs sits in an SGPR before the first MFMA (a scalar load
+// from the kernel arguments inside the sequence waits on lgkmcnt(0), i.e. for all LDS operand reads in flight).
+// tools/conv_phase_profile.hip stamps the phases with s_memtime; profiles/r03_conv_bf16_phases_*.txt hold the before / after tables
+// (16 600 -> 13 300 cycles per unit of 6 912 MFMA cycles on the 256^3 32 -> 32 layer).
 #include <stdlib.h>
 
 #include "common.h"
@@ -173,7 +183,7 @@ __device__ __forceinline__ void compute_sub(const char* __restrict__ tileB, cons
 template <bool RES>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_conv3_bf16(const Params P) {
   extern __shared__ float4 smem4b[];
-  // LDS map (bytes): two weight buffers (LDS-direct destinations, below 64 KiB) | halo tile, 3 bf16 planes | 4 x 8 KiB epilogue scratch
+  // LDS map (bytes): two weight buffers of one sub-unit each | halo tile, 3 bf16 planes | 4 x 8 KiB epilogue scratch
   char* W = (char*)smem4b;
   char* tileB = W + 2 * BWSUB_BYTES;
   float* scratch = (float*)(tileB + BTILE_BYTES);

@@ -1,0 +1,13 @@
+#!/bin/bash
+# End-of-round measurement set on the GPU box: full GPU suite, smoke, the driver's bench command, the profile set of
+# tools/profile_round.sh, section timing, the 1M-candidate 3D NMS, the network-vs-float64 log.
+# usage: tools/gpu_round_end.sh <tag> <round tag for the profiles, e.g. r03>   -> gpurun_out/<tag>_*
+R=${GRAFT_REPO_ROOT:-/root/repo}; tag=$1; rtag=$2; O=$R/gpurun_out; mkdir -p $O; cd $R; ulimit -c 0
+( time timeout 600 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 ) > $O/${tag}_tests.log 2>&1
+timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/${tag}_smoke.log 2>&1
+timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${tag}_bench.json 2> $O/${tag}_bench.err
+timeout 900 tools/profile_round.sh $rtag > $O/${tag}_profile_stdout.log 2>&1
+timeout 200 python tools/time_predict_sections.py > $O/${tag}_sections.log 2>&1
+timeout 200 python tools/time_nms3d.py 480 2 > $O/${tag}_nms3d_1M.log 2>&1
+timeout 300 python -m pytest -s -q tests/test_gpu_unet_parity.py -m gpu > $O/${tag}_unet_parity.log 2>&1
+tail -3 $O/${tag}_tests.log; cat $O/${tag}_smoke.log | tail -1; cut -c1-200 $O/${tag}_bench.json
