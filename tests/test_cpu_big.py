@@ -199,6 +199,11 @@ def _sharded_worker(rank, world, port_, q, mm_path=None):
     tiles, _ = predict_instances_sharded(m, x, "YXC", 96, 32, context=16, labels_out="local")
     mm = np.load(mm_path, mmap_mode="r+")
     predict_instances_sharded(m, x, "YXC", 96, 32, context=16, labels_out=mm)
+    # bench.py's combination at N > 1: tiles stay local, the result dict stays on rank 0
+    tiles_b, res_b = predict_instances_sharded(m, x, "YXC", 96, 32, context=16, labels_out="local", broadcast_result=False)
+    assert (res_b is None) == (rank != 0) and len(tiles_b) == len(tiles)
+    assert all(np.array_equal(a[2].numpy(), b[2].numpy()) for a, b in zip(tiles, tiles_b))
+    assert rank != 0 or np.array_equal(res_b["points"], res["points"])
     q.put((rank, labels, res["points"], res["prob"], [(bi, tuple((s.start, s.stop) for s in sl), t.numpy()) for bi, sl, t in tiles], st))
     dist.barrier()
     dist.destroy_process_group()
