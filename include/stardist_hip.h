@@ -38,6 +38,8 @@ int sd_release_workspace(void);           /* free the cached device workspace   
  *   "nms3d_cone_map"      1|0  stage-5 voxel tests through the cone map / over every face as the reference does
  *   "nms3d_refine_mesh"   1|0  refined direction mesh for the volume bounds
  *   "nms3d_tail_batch"    1|0  late greedy rounds of the 3D NMS as one speculative batch + replay on the device / as plain rounds
+ *   "nms3d_split_exact"   1|0  exact volumes of the pairs the bounds leave undecided by four waves per pair in a second pass / by the
+ *                              wave that evaluated the bounds (bit-identical volumes)
  *   "probe_tier"          1|2  capacity tier sd_clip_pairs_device runs first;  "probe_no_general" 1: do not fall back to the general path
  *   "trace"               1    print per-round counters to stdout
  * Nothing in the library reads the process environment.  sd_get_option returns -1 for an unknown name. */

@@ -714,11 +714,50 @@ __device__ __forceinline__ double hiv_volume_wave(const double* __restrict__ hs,
   return acc / 3.0;
 }
 
+// The same sum by a workgroup of NW waves (k_stage3x / k_stage4x): wave w takes the faces k0 + 64 w + lane, every term goes to
+// terms[k] (LDS), and wave 0 adds them up in exactly the order of the one-wave routine (lane l: faces l, l + 64, ...; then the xor
+// butterfly) -- the result is bit-identical, only the latency of a pair is 1/NW.  W = THIS wave's polygon workspace.  The value is
+// returned in wave 0; every wave must call (workgroup barrier inside).
+template <int NW>
+__device__ __forceinline__ double hiv_volume_block(const double* __restrict__ hs, int M, const double c[3], double L, const HivLds& W, int lane, int wave,
+                                                   double* __restrict__ terms, Stats* st, const double* __restrict__ balls) {
+  int nfb = 0;
+  int dbg[3] = {0, 0, 0};
+  for (int k0 = 0; k0 < M; k0 += 64 * NW) {
+    const int k = k0 + 64 * wave + lane;
+    if (k < M) {
+      bool fb;
+      double term = hiv_face_term_lds(hs, M, k, c, L, W, lane, fb, dbg, balls);
+      if (fb) { term = hiv_face_term(hs, M, k, c, L); ++nfb; }
+      terms[k] = term;
+    }
+  }
+  for (int o = 32; o; o >>= 1) {
+    nfb += __shfl_xor(nfb, o);
+    dbg[0] += __shfl_xor(dbg[0], o); dbg[1] += __shfl_xor(dbg[1], o); dbg[2] += __shfl_xor(dbg[2], o);
+  }
+  if (lane == 0) {
+    if (wave == 0) atomicAdd(&st->hiv_faces, (unsigned long long)M);
+    if (nfb) atomicAdd(&st->hiv_fallback, (unsigned long long)nfb);
+    atomicAdd(&st->hiv_list, (unsigned long long)dbg[0]); atomicAdd(&st->hiv_clips, (unsigned long long)dbg[1]);
+    if (dbg[2]) atomicAdd(&st->hiv_rest, (unsigned long long)dbg[2]);
+  }
+  __syncthreads();
+  double acc = 0;
+  if (wave == 0) {
+    for (int k0 = 0; k0 < M; k0 += 64) { const int k = k0 + lane; if (k < M) acc += terms[k]; }
+    for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+  }
+  return acc / 3.0;
+}
+
 // Cull + compact + normalise the M half-spaces in hs (one wave, in place).  A half-space of one polyhedron that contains
 // the whole outer ball of the OTHER polyhedron cannot bound the intersection (exact, 1e-6 safety margin).
 // `second(k)` tells whether original half-space k belongs to polyhedron 2.  Fills pos/orig; returns the kept count.
 // The kept half-spaces are also translated so that the interior point c becomes the origin (offset = n.c + d < 0).
-template <class Second>
+// BS = false: called by ONE wave of a larger workgroup (k_stage3x / k_stage4x): no workgroup barrier -- a wave's own LDS accesses are
+// processed in order and all its lanes read a chunk before any of them writes, which is all the compaction needs.
+template <class Second, bool BS = true>
 __device__ __forceinline__ int hiv_cull_wave(double* hs, int M, const double b1[4], const double b2[4], const double c[3], unsigned short* pos,
                                              unsigned short* orig, int lane, Second second) {
   int kept = 0;
@@ -735,7 +774,7 @@ __device__ __forceinline__ int hiv_cull_wave(double* hs, int M, const double b1[
       if (nn > 0) { h0 /= nn; h1 /= nn; h2 /= nn; h3 /= nn; }
     }
     const unsigned long long mk = __ballot(keep);
-    __syncthreads();                               // all reads of this chunk done before compacted writes land
+    if (BS) __syncthreads(); else __builtin_amdgcn_wave_barrier();      // all reads of this chunk done before compacted writes land
     if (k < M) {
       if (keep) {
         const int p_ = kept + __popcll(mk & ((1ull << lane) - 1));
@@ -744,7 +783,7 @@ __device__ __forceinline__ int hiv_cull_wave(double* hs, int M, const double b1[
       } else pos[k] = (unsigned short)HIV_NONE;
     }
     kept += __popcll(mk);
-    __syncthreads();
+    if (BS) __syncthreads(); else __builtin_amdgcn_wave_barrier();
   }
   return kept;
 }
@@ -924,7 +963,9 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
                                                const float* __restrict__ volume, float thr, SuppSink sink,
                                                int2* __restrict__ pairs5, unsigned int* pair5Count, Stats* st, unsigned int wsBytes,
                                                const float* __restrict__ bverts, const int* __restrict__ bfaces, int bR, int bF,
-                                               double* __restrict__ volOut = nullptr) {
+                                               double* __restrict__ volOut = nullptr, int2* __restrict__ pairsX = nullptr,
+                                               unsigned int* __restrict__ nX = nullptr) {
+  // pairsX != nullptr: a pair the bounds leave undecided is queued for k_stage3x (NW waves per pair) instead of being integrated here
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* hs = (double*)smem;                 // 2F * 4
   float* pv1 = (float*)(hs + 8 * F);          // 3R   (dead once hs is built: aliased by the polygon workspace)
@@ -973,6 +1014,7 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
     infeasible = __any(infeasible);
     double vol = 0;
     int Mc = M;
+    bool deferred = false;
     if (!infeasible) {
       double ext = 0, ext1 = 0, ext2 = 0;
       for (int k = lane; k < R; k += 64) {
@@ -1007,6 +1049,9 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
       } else if (ub * (1.0 + 1e-9) / A_min_d < thr_lo && !(wsBytes >> 31)) {
         vol = ub;                                       // certainly not above the threshold
         if (lane == 0) atomicAdd(&st->ub_decided, 1ull);
+      } else if (pairsX) {
+        deferred = true;
+        if (lane == 0) pairsX[atomicAdd(nX, 1u)] = ij;
       } else {
         const double sep = sqrt((double)(c1[0] - c2[0]) * (c1[0] - c2[0]) + (double)(c1[1] - c2[1]) * (c1[1] - c2[1]) + (double)(c1[2] - c2[2]) * (c1[2] - c2[2]));
         const double L = 4.0 * (2.0 * ext + sep + 1.0);
@@ -1021,6 +1066,7 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
       atomicAdd(&st->cyc[2], (unsigned long long)(t3 - t2)); atomicAdd(&st->cyc[3], (unsigned long long)(t4 - t3));
       atomicAdd(&st->cyc[4], (unsigned long long)(t4 - t0)); atomicAdd(&st->cyc[5], 1ull);
     }
+    if (deferred) continue;
     if (volOut) { if (lane == 0) volOut[p] = vol; continue; }     // pair-level probe (sd_hiv_pairs_device): the volume itself
     if (lane == 0) {
       atomicAdd(&st->kernel, 1ull);
@@ -1032,6 +1078,108 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
       else pairs5[atomicAdd(pair5Count, 1u)] = ij;
     }
   }
+}
+
+// Exact kernel ∩ kernel volume of the pairs the bounds left undecided (queued by k_stage3), NW waves per pair.  An exact volume is
+// ~2 M wave cycles (one lane per face: six passes over the 2F half-spaces), ~1 ms: with one wave per pair every launch of a round
+// lasted at least that long, however few pairs it held.  Here the faces of a pair are spread over 64 NW lanes (the culled
+// half-spaces usually fit one pass), the terms are added in the one-wave order (hiv_volume_block: bit-identical volume).
+// LDS: hs | wave 0's workspace (aliases the vertex staging) | seed pos orig | terms | the other waves' workspaces.
+struct OddIsSecond { __device__ bool operator()(int k) const { return (k & 1) != 0; } };
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_stage3x(const int2* __restrict__ pairs, const unsigned int* __restrict__ nPairsPtr, unsigned int nPairsImm,
+                                                     const float* __restrict__ dist, const float* __restrict__ pts, const float* __restrict__ verts,
+                                                     const int* __restrict__ faces, const int* __restrict__ faceAdj, int R, int F,
+                                                     const float* __restrict__ volume, float thr, SuppSink sink, int2* __restrict__ pairs5,
+                                                     unsigned int* pair5Count, Stats* st, unsigned int wsBytes, double* __restrict__ volOut) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* hs = (double*)smem;
+  float* pv1 = (float*)(hs + 8 * F);
+  float* pv2 = pv1 + 3 * R;
+  unsigned short* seed = (unsigned short*)(smem + (size_t)8 * F * sizeof(double) + wsBytes);
+  unsigned short* pos = seed + 6 * F;
+  unsigned short* orig = pos + 2 * F;
+  double* terms = (double*)(smem + (((size_t)8 * F * sizeof(double) + wsBytes + (size_t)10 * F * sizeof(unsigned short) + 15) & ~(size_t)15));   // 2F
+  int* shared = (int*)(terms + 2 * F);                    // [0] = half-spaces kept by the cull
+  char* extra = (char*)(shared + 4);                      // NW - 1 further polygon workspaces
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  HivLds W;
+  W.S = wave == 0 ? hs + 8 * F : (double*)(extra + (size_t)(wave - 1) * hiv_poly_bytes_dev());
+  W.T = W.S + HIV_CAPL * 64; W.list = (unsigned short*)(W.T + HIV_CAPL * 64); W.seed = seed; W.pos = pos; W.orig = orig;
+  for (int idx = tid; idx < 6 * F; idx += 64 * NW) {
+    const int o_ = idx / 3, e_ = idx - 3 * o_;
+    const int a_ = faceAdj[3 * (o_ >> 1) + e_];
+    seed[idx] = (unsigned short)(a_ < 0 ? HIV_NONE : (unsigned int)(2 * a_ + (o_ & 1)));
+  }
+  const unsigned int nPairs = nPairsPtr ? *nPairsPtr : nPairsImm;
+  for (unsigned int p = blockIdx.x; p < nPairs; p += gridDim.x) {
+    const int2 ij = pairs[p];
+    __syncthreads();
+    const float* c1 = pts + 3 * (size_t)ij.x;
+    const float* c2 = pts + 3 * (size_t)ij.y;
+    for (int k = tid; k < R; k += 64 * NW) {
+      const float d1 = dist[(size_t)ij.x * R + k], d2 = dist[(size_t)ij.y * R + k];
+      pv1[3 * k] = c1[0] + d1 * verts[3 * k]; pv1[3 * k + 1] = c1[1] + d1 * verts[3 * k + 1]; pv1[3 * k + 2] = c1[2] + d1 * verts[3 * k + 2];
+      pv2[3 * k] = c2[0] + d2 * verts[3 * k]; pv2[3 * k + 1] = c2[1] + d2 * verts[3 * k + 1]; pv2[3 * k + 2] = c2[2] + d2 * verts[3 * k + 2];
+    }
+    __syncthreads();
+    for (int f = tid; f < F; f += 64 * NW) {
+      const int iA = faces[3 * f], iB = faces[3 * f + 1], iC = faces[3 * f + 2];
+      sd3::build_halfspace(&pv1[3 * iA], &pv1[3 * iB], &pv1[3 * iC], &hs[4 * (2 * f)]);
+      sd3::build_halfspace(&pv2[3 * iA], &pv2[3 * iB], &pv2[3 * iC], &hs[4 * (2 * f + 1)]);
+    }
+    __syncthreads();
+    const int M = 2 * F;
+    double c[3];
+    c[0] = .5 * (c1[0] + c2[0]); c[1] = .5 * (c1[1] + c2[1]); c[2] = .5 * (c1[2] + c2[2]);   // :857-859 (float add, then *.5 in double)
+    int bad = 0;
+    for (int k = tid; k < M; k += 64 * NW) {
+      double dd = hs[4 * k + 3];
+      dd += hs[4 * k] * c[0]; dd += hs[4 * k + 1] * c[1]; dd += hs[4 * k + 2] * c[2];
+      if (dd > 0 || !(dd < 0)) bad = 1;
+    }
+    const bool infeasible = __syncthreads_or(bad) != 0;
+    double vol = 0;
+    if (!infeasible) {
+      double ext = 0, ext1 = 0, ext2 = 0;                  // (every wave computes the same values)
+      for (int k = lane; k < R; k += 64) {
+        const float e1 = dist[(size_t)ij.x * R + k], e2 = dist[(size_t)ij.y * R + k];
+        ext1 = fmax(ext1, (double)e1); ext2 = fmax(ext2, (double)e2);
+      }
+      for (int o = 32; o; o >>= 1) { ext1 = fmax(ext1, __shfl_xor(ext1, o)); ext2 = fmax(ext2, __shfl_xor(ext2, o)); }
+      ext = fmax(ext1, ext2);
+      if (wave == 0) {
+        const double b1[4] = {(double)c1[0], (double)c1[1], (double)c1[2], ext1 * (1.0 + 1e-6) + 1e-6};
+        const double b2[4] = {(double)c2[0], (double)c2[1], (double)c2[2], ext2 * (1.0 + 1e-6) + 1e-6};
+        const int kept = hiv_cull_wave<OddIsSecond, false>(hs, M, b1, b2, c, pos, orig, lane, OddIsSecond());      // half-space 2f + w: polyhedron w
+        if (lane == 0) shared[0] = kept;
+      }
+      __syncthreads();
+      const int Mc = shared[0];
+      const double zero3[3] = {0, 0, 0};
+      const double sep = sqrt((double)(c1[0] - c2[0]) * (c1[0] - c2[0]) + (double)(c1[1] - c2[1]) * (c1[1] - c2[1]) + (double)(c1[2] - c2[2]) * (c1[2] - c2[2]));
+      const double L = 4.0 * (2.0 * ext + sep + 1.0);
+      const double balls[8] = {(double)c1[0] - c[0], (double)c1[1] - c[1], (double)c1[2] - c[2], ext1 * (1.0 + 1e-6) + 1e-6,
+                               (double)c2[0] - c[0], (double)c2[1] - c[1], (double)c2[2] - c[2], ext2 * (1.0 + 1e-6) + 1e-6};
+      vol = hiv_volume_block<NW>(hs, Mc, zero3, L, W, lane, wave, terms, st, balls);
+    }
+    if (tid == 0) {
+      if (volOut) volOut[p] = vol;
+      else {
+        atomicAdd(&st->kernel, 1ull);
+        if (vol != vol) atomicAdd(&st->overflow, 1ull);
+        const float A_inter_kernel = (float)vol;                                  // function returns float :679
+        const float A_min = fminf(volume[ij.x], volume[ij.y]);
+        const float iou = (float)((double)A_inter_kernel / ((double)A_min + 1e-10));   // :1269
+        if (iou > thr) { sink.suppress(ij.x, ij.y); atomicAdd(&st->sup_kernel, 1ull); }
+        else pairs5[atomicAdd(pair5Count, 1u)] = ij;
+      }
+    }
+  }
+}
+static inline size_t stage3x_lds(int F, size_t ws3, int nw) {
+  return (((size_t)8 * F * sizeof(double) + ws3 + (size_t)10 * F * sizeof(unsigned short) + 15) & ~(size_t)15) + (size_t)2 * F * sizeof(double) + 16 +
+         (size_t)(nw - 1) * hiv_poly_bytes();
 }
 
 // ------------------------------------------------------------------ stage 4: hull ∩ hull volume (:872-939)
@@ -1416,7 +1564,9 @@ __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, u
                                                const float* __restrict__ volume, float thr,
                                                int2* __restrict__ pairs5, unsigned int* pair5Count, Stats* st, int no_lb,
                                                const float* __restrict__ bverts, const int* __restrict__ bfaces, int bR, int bF,
-                                               double* __restrict__ volOut = nullptr) {
+                                               double* __restrict__ volOut = nullptr, int2* __restrict__ pairsX = nullptr,
+                                               unsigned int* __restrict__ nX = nullptr) {
+  // pairsX != nullptr: undecided pairs are queued for k_stage4x (as in k_stage3)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* hs = (double*)smem;                   // 2*cap*4
   unsigned short* seed = (unsigned short*)(smem + (size_t)8 * cap * sizeof(double) + hiv_poly_bytes_dev());   // 2*cap*3
@@ -1454,6 +1604,7 @@ __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, u
     }
     infeasible = __any(infeasible) || failed;
     double vol = 1.e10;                                             // err_value :927
+    bool deferred = false;
     if (!infeasible) {
       double ext = 0, ext1 = 0, ext2 = 0;
       for (int k = lane; k < R; k += 64) { ext1 = fmax(ext1, (double)dist[(size_t)ij.x * R + k]); ext2 = fmax(ext2, (double)dist[(size_t)ij.y * R + k]); }
@@ -1485,12 +1636,16 @@ __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, u
       } else if (ub * (1.0 + 1e-9) / A_min_d < thr_lo && !no_lb) {
         vol = ub;                                       // certainly not above the threshold -> pair kept
         if (lane == 0) atomicAdd(&st->ub_decided, 1ull);
+      } else if (pairsX) {
+        deferred = true;
+        if (lane == 0) pairsX[atomicAdd(nX, 1u)] = ij;
       } else {
         const double balls[8] = {(double)c1[0] - c[0], (double)c1[1] - c[1], (double)c1[2] - c[2], ext1 * (1.0 + 1e-6) + 1e-6,
                                  (double)c2[0] - c[0], (double)c2[1] - c[1], (double)c2[2] - c[2], ext2 * (1.0 + 1e-6) + 1e-6};
         vol = hiv_volume_wave(hs, Mc, zero3, L, W, lane, st, balls);
       }
     }
+    if (deferred) continue;
     if (volOut) { if (lane == 0) volOut[p] = vol; continue; }     // pair-level probe
     if (lane == 0) {
       atomicAdd(&st->convex, 1ull);
@@ -1502,6 +1657,96 @@ __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, u
       else pairs5[atomicAdd(pair5Count, 1u)] = ij;
     }
   }
+}
+
+// Exact hull ∩ hull volume of the pairs k_stage4 queued, NW waves per pair (see k_stage3x).
+// LDS: hs | wave 0's workspace | seed pos orig | terms | the other waves' workspaces.
+struct FromIndex { int n1; __device__ bool operator()(int k) const { return k >= n1; } };
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_stage4x(const int2* __restrict__ pairs, const unsigned int* __restrict__ nPairsPtr, unsigned int nPairsImm,
+                                                     const float* __restrict__ dist, const float* __restrict__ pts, int R, int cap,
+                                                     const double* __restrict__ hullPlanes, const unsigned short* __restrict__ hullAdj,
+                                                     const int* __restrict__ hullCount, const float* __restrict__ volume, float thr,
+                                                     int2* __restrict__ pairs5, unsigned int* pair5Count, Stats* st, double* __restrict__ volOut) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* hs = (double*)smem;
+  unsigned short* seed = (unsigned short*)(smem + (size_t)8 * cap * sizeof(double) + hiv_poly_bytes_dev());
+  unsigned short* pos = seed + 6 * cap;
+  unsigned short* orig = pos + 2 * cap;
+  double* terms = (double*)(smem + (((size_t)8 * cap * sizeof(double) + hiv_poly_bytes_dev() + (size_t)10 * cap * sizeof(unsigned short) + 15) & ~(size_t)15));   // 2 cap
+  int* shared = (int*)(terms + 2 * cap);
+  char* extra = (char*)(shared + 4);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  HivLds W;
+  W.S = wave == 0 ? hs + 8 * cap : (double*)(extra + (size_t)(wave - 1) * hiv_poly_bytes_dev());
+  W.T = W.S + HIV_CAPL * 64; W.list = (unsigned short*)(W.T + HIV_CAPL * 64); W.seed = seed; W.pos = pos; W.orig = orig;
+  const unsigned int nPairs = nPairsPtr ? *nPairsPtr : nPairsImm;
+  for (unsigned int p = blockIdx.x; p < nPairs; p += gridDim.x) {
+    const int2 ij = pairs[p];
+    __syncthreads();
+    const float* c1 = pts + 3 * (size_t)ij.x;
+    const float* c2 = pts + 3 * (size_t)ij.y;
+    const int n1 = hullCount[ij.x], n2 = hullCount[ij.y];
+    const bool failed = (n1 < 4 || n2 < 4);
+    const int M = failed ? 0 : n1 + n2;
+    if (!failed) {
+      const double* h1 = hullPlanes + (size_t)ij.x * cap * 4;
+      const double* h2 = hullPlanes + (size_t)ij.y * cap * 4;
+      for (int k = tid; k < 4 * n1; k += 64 * NW) hs[k] = h1[k];
+      for (int k = tid; k < 4 * n2; k += 64 * NW) hs[4 * n1 + k] = h2[k];
+      const unsigned short* a1 = hullAdj + (size_t)ij.x * cap * 3;
+      const unsigned short* a2 = hullAdj + (size_t)ij.y * cap * 3;
+      for (int k = tid; k < 3 * n1; k += 64 * NW) seed[k] = a1[k];
+      for (int k = tid; k < 3 * n2; k += 64 * NW) { const unsigned int t = a2[k]; seed[3 * n1 + k] = (unsigned short)(t == HIV_NONE ? HIV_NONE : t + n1); }
+    }
+    __syncthreads();
+    double c[3];
+    c[0] = .5 * ((double)c1[0] + (double)c2[0]); c[1] = .5 * ((double)c1[1] + (double)c2[1]); c[2] = .5 * ((double)c1[2] + (double)c2[2]);   // :919-921
+    int bad = 0;
+    for (int k = tid; k < M; k += 64 * NW) {
+      double dd = hs[4 * k + 3];
+      dd += hs[4 * k] * c[0]; dd += hs[4 * k + 1] * c[1]; dd += hs[4 * k + 2] * c[2];
+      if (dd > 0 || !(dd < 0)) bad = 1;
+    }
+    const bool infeasible = (__syncthreads_or(bad) != 0) || failed;
+    double vol = 1.e10;                                             // err_value :927
+    if (!infeasible) {
+      double ext = 0, ext1 = 0, ext2 = 0;
+      for (int k = lane; k < R; k += 64) { ext1 = fmax(ext1, (double)dist[(size_t)ij.x * R + k]); ext2 = fmax(ext2, (double)dist[(size_t)ij.y * R + k]); }
+      for (int o = 32; o; o >>= 1) { ext1 = fmax(ext1, __shfl_xor(ext1, o)); ext2 = fmax(ext2, __shfl_xor(ext2, o)); }
+      ext = fmax(ext1, ext2);
+      const double sep = sqrt((double)(c1[0] - c2[0]) * (c1[0] - c2[0]) + (double)(c1[1] - c2[1]) * (c1[1] - c2[1]) + (double)(c1[2] - c2[2]) * (c1[2] - c2[2]));
+      const double L = 4.0 * (2.0 * ext + sep + 1.0);
+      if (wave == 0) {
+        const double b1[4] = {(double)c1[0], (double)c1[1], (double)c1[2], ext1 * (1.0 + 1e-6) + 1e-6};
+        const double b2[4] = {(double)c2[0], (double)c2[1], (double)c2[2], ext2 * (1.0 + 1e-6) + 1e-6};
+        const int kept = hiv_cull_wave<FromIndex, false>(hs, M, b1, b2, c, pos, orig, lane, FromIndex{n1});
+        if (lane == 0) shared[0] = kept;
+      }
+      __syncthreads();
+      const int Mc = shared[0];
+      const double zero3[3] = {0, 0, 0};
+      const double balls[8] = {(double)c1[0] - c[0], (double)c1[1] - c[1], (double)c1[2] - c[2], ext1 * (1.0 + 1e-6) + 1e-6,
+                               (double)c2[0] - c[0], (double)c2[1] - c[1], (double)c2[2] - c[2], ext2 * (1.0 + 1e-6) + 1e-6};
+      vol = hiv_volume_block<NW>(hs, Mc, zero3, L, W, lane, wave, terms, st, balls);
+    }
+    if (tid == 0) {
+      if (volOut) volOut[p] = vol;
+      else {
+        atomicAdd(&st->convex, 1ull);
+        if (vol != vol) atomicAdd(&st->overflow, 1ull);
+        const float A_inter_convex = (float)vol;
+        const float A_min = fminf(volume[ij.x], volume[ij.y]);
+        const float iou = (float)((double)A_inter_convex / ((double)A_min + 1e-10));     // :1289
+        if (iou <= thr) atomicAdd(&st->kept_convex, 1ull);                                // :1291-1295
+        else pairs5[atomicAdd(pair5Count, 1u)] = ij;
+      }
+    }
+  }
+}
+static inline size_t stage4x_lds(int cap, int nw) {
+  return (((size_t)8 * cap * sizeof(double) + hiv_poly_bytes() + (size_t)10 * cap * sizeof(unsigned short) + 15) & ~(size_t)15) + (size_t)2 * cap * sizeof(double) + 16 +
+         (size_t)(nw - 1) * hiv_poly_bytes();
 }
 
 // ------------------------------------------------------------------ stage 5: voxel rendering (:587-636, 1305-1330)
@@ -1672,7 +1917,14 @@ extern "C" int sd_hiv_pairs_device(const float* d_dist, const float* d_points, i
   hipLaunchKernelGGL(k_face_adj, dim3(sd::div_up(F, 64)), dim3(64), 0, s, d_faces, F, faceAdj);
   const int2* pairs = (const int2*)d_pairs;
   const unsigned int nb = (unsigned int)n_pairs < 16384u ? (unsigned int)n_pairs : 16384u;
-  if (d_vol_kernel) {
+  const size_t lds3x = stage3x_lds(F, ws3, 4);
+  if (d_vol_kernel && sd::option(sd::OPT_NMS3D_SPLIT_EXACT) && lds3x <= 150 * 1024) {      // the routine the cascade uses: four waves per pair
+    if (lds3x > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_stage3x<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3x));
+    hipLaunchKernelGGL(k_stage3x<4>, dim3((unsigned int)n_pairs < 1024u ? (unsigned int)n_pairs : 1024u), dim3(256), lds3x, s, pairs, (const unsigned int*)nullptr,
+                       (unsigned int)n_pairs, d_dist, d_points, d_verts, d_faces, faceAdj, R, F, volume, 0.f, SuppSink{state, nullptr, nullptr, 0u}, (int2*)nullptr,
+                       dummyCount, d_st, (unsigned int)ws3, d_vol_kernel);
+    SD_LAUNCH_CHECK();
+  } else if (d_vol_kernel) {
     hipLaunchKernelGGL(k_stage3, dim3(nb), dim3(64), lds3, s, pairs, (unsigned int)n_pairs, d_dist, d_points, d_verts, d_faces, faceAdj, R, F, volume,
                        0.f, SuppSink{state, nullptr, nullptr, 0u}, (int2*)nullptr, dummyCount, d_st, (unsigned int)ws3 | 0x80000000u, d_verts, d_faces, R, F, d_vol_kernel);
     SD_LAUNCH_CHECK();
@@ -1680,8 +1932,14 @@ extern "C" int sd_hiv_pairs_device(const float* d_dist, const float* d_points, i
   if (d_vol_hull) {
     double* planes = nullptr; int* count = nullptr; int cap = 0;
     if (sd::hull_planes_adj(d_dist, d_points, d_verts, N, R, &planes, &count, &cap, s)) return -1;
-    hipLaunchKernelGGL(k_stage4, dim3(nb), dim3(64), lds4, s, pairs, (unsigned int)n_pairs, d_dist, d_points, d_verts, d_faces, R, F, cap, planes,
-                       sd::last_hull_adj(), count, volume, 0.f, (int2*)nullptr, dummyCount, d_st, 1, d_verts, d_faces, R, F, d_vol_hull);
+    const size_t lds4x = stage4x_lds(cap, 4);
+    if (sd::option(sd::OPT_NMS3D_SPLIT_EXACT) && lds4x <= 150 * 1024) {
+      if (lds4x > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_stage4x<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4x));
+      hipLaunchKernelGGL(k_stage4x<4>, dim3((unsigned int)n_pairs < 1024u ? (unsigned int)n_pairs : 1024u), dim3(256), lds4x, s, pairs, (const unsigned int*)nullptr,
+                         (unsigned int)n_pairs, d_dist, d_points, R, cap, planes, sd::last_hull_adj(), count, volume, 0.f, (int2*)nullptr, dummyCount, d_st, d_vol_hull);
+    } else
+      hipLaunchKernelGGL(k_stage4, dim3(nb), dim3(64), lds4, s, pairs, (unsigned int)n_pairs, d_dist, d_points, d_verts, d_faces, R, F, cap, planes,
+                         sd::last_hull_adj(), count, volume, 0.f, (int2*)nullptr, dummyCount, d_st, 1, d_verts, d_faces, R, F, d_vol_hull);
     SD_LAUNCH_CHECK();
   }
   Stats hst;
@@ -1770,6 +2028,15 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   if (lds3 > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_stage3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
   if (lds4 > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_stage4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
   if (lds5 > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_stage5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5));
+  // exact volumes of the undecided pairs by four waves per pair (k_stage3x): when the four workspaces fit
+  // (the launches of the later rounds hold few pairs and lasted as long as their slowest pair, an exact volume of ~1 ms by one wave;
+  // in the first round the one-wave form is faster: thousands of exact volumes keep every SIMD busy either way)
+  const size_t lds3x = stage3x_lds(F, ws3, 4), lds4x = stage4x_lds(2 * R, 4);
+  const bool split3 = sd::option(sd::OPT_NMS3D_SPLIT_EXACT) && lds3x <= 150 * 1024;
+  const bool split4 = sd::option(sd::OPT_NMS3D_SPLIT_EXACT) && lds4x <= 150 * 1024;
+  const unsigned int split3Max = 32768u, split4Max = 16384u;           // pairs per launch up to which the second pass pays
+  if (split3 && lds3x > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_stage3x<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3x));
+  if (split4 && lds4x > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_stage4x<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4x));
   if (ldsH > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_hull, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsH));
   sd::Arena& A = sd::arena();
   if (A.begin(s)) return -1;
@@ -1944,10 +2211,11 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   int2* pairs3 = A.take_n<int2>(pairCap);
   int2* pairs4 = A.take_n<int2>(pairCap);
   int2* pairs5 = A.take_n<int2>(pairCap);
-  struct Counters { int nU, nK; unsigned int nP3, nP4, nP5, nHull; int nS; };
+  int2* pairsX = (split3 || split4) ? A.take_n<int2>(pairCap) : nullptr;          // pairs whose exact volume is needed
+  struct Counters { int nU, nK; unsigned int nP3, nP4, nP5, nHull; int nS; unsigned int nX3, nX4; };
   Counters* d_cnt = (Counters*)A.take(sizeof(Counters));
   Stats* d_st = (Stats*)A.take(sizeof(Stats));
-  if (!U0 || !U1 || !Kl || !Sl || !pairs3 || !pairs4 || !pairs5 || !d_cnt || !d_st) return -1;
+  if (!U0 || !U1 || !Kl || !Sl || !pairs3 || !pairs4 || !pairs5 || !d_cnt || !d_st || ((split3 || split4) && !pairsX)) return -1;
   const int hullCap = 2 * R;                       // a hull of R points has at most 2R-4 facets
   int* hullState = A.take_n<int>(N);
   int* hullCount = A.take_n<int>(N);
@@ -2006,7 +2274,11 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
         const unsigned int b3 = h.nP3 < 16384u ? h.nP3 : 16384u;
         if (stats) SD_CHECK(hipEventRecord(ev0, s));
         hipLaunchKernelGGL(k_stage3, dim3(b3), dim3(64), lds3, s, pairs3, h.nP3, d_dist, d_points, d_verts, d_faces, faceAdj, R, F, volume,
-                           threshold, sink, pairs4, &d_cnt->nP4, d_st, (unsigned int)ws3 | (use_bounds ? 0u : 0x80000000u) | (trace ? SD_PROF_BIT : 0u), bverts, bfaces, bR, bF);
+                           threshold, sink, pairs4, &d_cnt->nP4, d_st, (unsigned int)ws3 | (use_bounds ? 0u : 0x80000000u) | (trace ? SD_PROF_BIT : 0u), bverts, bfaces, bR, bF,
+                           (double*)nullptr, (split3 && h.nP3 <= split3Max) ? pairsX : (int2*)nullptr, &d_cnt->nX3);
+        if (split3 && h.nP3 <= split3Max)
+          hipLaunchKernelGGL(k_stage3x<4>, dim3(h.nP3 < 256u ? h.nP3 : 256u), dim3(256), lds3x, s, pairsX, &d_cnt->nX3, 0u, d_dist, d_points, d_verts, d_faces, faceAdj,
+                             R, F, volume, threshold, sink, pairs4, &d_cnt->nP4, d_st, (unsigned int)ws3, (double*)nullptr);
         SD_LAUNCH_CHECK();
         if (stats) SD_CHECK(hipEventRecord(ev1, s));
         SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -2032,7 +2304,11 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
             SD_LAUNCH_CHECK();
           }
           hipLaunchKernelGGL(k_stage4, dim3(b4), dim3(64), lds4, s, pairs4, h.nP4, d_dist, d_points, d_verts, d_faces, R, F, hullCap, hullPlanes, hullAdj, hullCount,
-                             volume, threshold, pairs5, &d_cnt->nP5, d_st, use_bounds ? 0 : 1, bverts, bfaces, bR, bF);
+                             volume, threshold, pairs5, &d_cnt->nP5, d_st, use_bounds ? 0 : 1, bverts, bfaces, bR, bF, (double*)nullptr,
+                             (split4 && h.nP4 <= split4Max) ? pairsX : (int2*)nullptr, &d_cnt->nX4);
+          if (split4 && h.nP4 <= split4Max)
+            hipLaunchKernelGGL(k_stage4x<4>, dim3(h.nP4 < 256u ? h.nP4 : 256u), dim3(256), lds4x, s, pairsX, &d_cnt->nX4, 0u, d_dist, d_points, R, hullCap, hullPlanes, hullAdj,
+                               hullCount, volume, threshold, pairs5, &d_cnt->nP5, d_st, (double*)nullptr);
           SD_LAUNCH_CHECK();
           if (stats) SD_CHECK(hipEventRecord(ev1, s));
           SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));

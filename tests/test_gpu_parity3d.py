@@ -137,6 +137,41 @@ def test_nms3d_tail_batch_does_not_change_survivors(refmods):
     assert st_tail[4] <= st_rounds[4], (st_tail[4], st_rounds[4])       # never more host-driven rounds
 
 
+def test_nms3d_split_exact_does_not_change_survivors_or_volumes(refmods):
+    """exact volumes by four waves per pair in a second pass (k_stage3x / k_stage4x) vs by the wave that evaluated the bounds: the
+    same survivors as the reference, with and without the bound shortcuts, and bit-identical pair volumes"""
+    import torch
+    from oracle import synth
+    from stardist_amd.lib import _native as N, stardist3d as sd3
+    rays = _rays(96)
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    d, p, s, nobj = synth.s3d_nuclei(96, rays.vertices)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    args = (t(d), t(p), t(np.float32(V)), t(F), t(s), 1, 1, 0, np.float32(0.3))
+    refmods.stardist3d(); refmods.set_threads(1)
+    ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(0.3))
+    keeps = {}
+    for split in (1, 0):
+        for bounds in (1, 0):
+            with N.option("nms3d_split_exact", split), N.option("nms3d_volume_bounds", bounds):
+                keeps[split, bounds] = sd3.c_non_max_suppression_inds(*args).cpu().numpy()
+    for k, v in keeps.items():
+        assert np.array_equal(v, ref_keep), k
+    rs = np.random.RandomState(0)
+    o = np.argsort(-s, kind="stable")[:4000]
+    pairs = np.stack([rs.randint(0, 4000, 3000), rs.randint(0, 4000, 3000)], 1).astype(np.int32)
+    pairs = pairs[pairs[:, 0] != pairs[:, 1]]
+    dd, pp = np.ascontiguousarray(d[o]), np.ascontiguousarray(p[o])
+    close = np.linalg.norm(pp[pairs[:, 0]] - pp[pairs[:, 1]], axis=1) < 14
+    pairs = np.ascontiguousarray(pairs[close][:600])
+    vols = {}
+    for split in (1, 0):
+        with N.option("nms3d_split_exact", split):
+            vols[split] = [np.asarray(v) for v in sd3.hiv_pair_volumes(dd, pp, np.float32(V), F, pairs)]
+    assert len(pairs) > 50 and (vols[1][0] > 0).sum() > 10
+    assert np.array_equal(vols[1][0], vols[0][0]) and np.array_equal(vols[1][1], vols[0][1])
+
+
 def test_nms3d_flags_and_edges(refmods):
     from stardist_amd.lib import stardist3d as sd3
     rays = _rays(32)
