@@ -16,6 +16,15 @@ def test_conv_layout_emulation(tmp_path):
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
 
 
+def test_conv_bf16_layout_emulation(tmp_path):
+    """the split-bf16 kernel's element assignment (one owner per halo element, conflict-free LDS stores), its address rule on interior
+    and border tiles, the f32 -> 3 x bf16 split, the weight packer and a whole layer through the LDS layouts vs float64"""
+    exe = str(tmp_path / "conv_bf16_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "host", "conv_bf16_check.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
 def test_pack_weights_abi():
     from stardist_amd.lib import _native as N
     l = N.lib()
