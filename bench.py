@@ -309,6 +309,16 @@ def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, di
             "per_rank": per_rank}
 
 
+def guarded(fn, what):
+    """(result, None) or (None, message): an extra leg that fails is reported in the JSON line instead of losing the whole line"""
+    try:
+        return fn(), None
+    except Exception as e:                                          # noqa: BLE001 -- reported, not swallowed
+        import traceback
+        traceback.print_exc()
+        return None, "%s failed: %r" % (what, e)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -452,8 +462,10 @@ def main():
     if not args.no_sharded:
         rep = max(1, args.sharded_size // H)
         big = torch.from_numpy(synth.s2d_nuclei_image(H, W, seed=0)).to(dev).repeat(rep, rep)
-        r = run_sharded_leg(model, big, "YX", min(args.sharded_block, big.shape[0]), 128, 128, 2, world, dist_, rank)
-        if rank == 0:
+        r, err = guarded(lambda: run_sharded_leg(model, big, "YX", min(args.sharded_block, big.shape[0]), 128, 128, 2, world, dist_, rank), "sharded_2d")
+        if rank == 0 and err:
+            out["sharded_2d"] = {"error": err}                      # the headline stays the tile leg
+        elif rank == 0:
             r["unit"] = "Mpix/s"
             out["sharded_2d"] = r
             if world > 1:
@@ -527,8 +539,10 @@ def main():
         if not args.no_sharded and not args.skip_sharded_3d:
             rep = max(1, args.sharded_size3d // S)
             bigv = torch.from_numpy(synth.s3d_nuclei_image(S, seed=0)).to(dev).repeat(rep, rep, rep)
-            r = run_sharded_leg(m3, bigv, "ZYX", min(args.sharded_block3d, bigv.shape[0]), 32, 32, 1, world, dist_, rank)
-            if rank == 0:
+            r, err = guarded(lambda: run_sharded_leg(m3, bigv, "ZYX", min(args.sharded_block3d, bigv.shape[0]), 32, 32, 1, world, dist_, rank), "sharded_3d")
+            if rank == 0 and err:
+                out["sharded_3d"] = {"error": err}
+            elif rank == 0:
                 r["unit"] = "Mvox/s"
                 out["sharded_3d"] = r
             del bigv
