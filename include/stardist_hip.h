@@ -250,7 +250,7 @@ int sd_head_rows_device(const float* d_feat, int n_channels, const long long* d_
  * -- Concatenate([up, skip]) of the up path without the concatenated tensor; d_src1 == NULL: one source.  `up` is a bit mask of the
  * axes (1: x, 2: y, 4: z) along which a source has half the output resolution and is read through nearest-neighbour 2x up-sampling
  * (UpSampling2D/3D folded into the operand fetch).  stride = floats per pixel of a source.
- * Supported: c0, c1 multiples of 32 with c0 + c1 <= 256 and c_out a multiple of 32; and the first layer c0 = 1 (c_out % 4 == 0).
+ * Supported: c0, c1 multiples of 32 with c0 + c1 <= 512 and c_out a multiple of 32; and the first layer c0 = 1 (c_out % 4 == 0).
  * d_wpacked: the kernel in the device layout written by sd_conv3_pack_weights_host (sd_conv3_packed_floats floats).
  * act: 0 linear, 1 relu.  Exact float32: each output is one fma chain in a fixed order (bias first), repeatable bit for bit. */
 long long sd_conv3_packed_floats(int c_in, int c_out, int kz);
@@ -276,6 +276,24 @@ int sd_conv3_bf16x6_ndhwc_device(const float* d_src0, int c0, int stride0, int u
 int sd_conv3_bf16x6_res_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1,
                                      int up1, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias,
                                      const float* d_res, int res_stride, int c_out, int act, float* d_out, void* stream);
+
+/* The same layer with every f32 product evaluated as three fp16 x fp16 products: each operand x = hi + lo' * 2^-11 (hi = fp16(x),
+ * lo' = fp16((x - hi) * 2^11)), a * b ~ hi*hi + 2^-11 (hi*lo' + lo'*hi), f32 accumulation in two accumulators on the fp16 matrix cores:
+ * f32-level accuracy (the dropped term is below 2^-22 of a product; networks within 3e-6 of a float64 evaluation like the two forms
+ * above) with half the matrix instructions of the bf16 form -- the default network path since round 4.  Same arguments as
+ * sd_conv3_bf16x6_*, plus d_range_flag (device int, may be NULL): OR-ed with 1 when an input value lies outside the fp16 range
+ * (|x| > 65504 or not finite), in which case the output is not valid and the caller must re-evaluate the layer with the bf16x6 form.
+ * sd_conv3_f16x3_pack_weights_host returns -2 (weights still packed) when a weight is outside that range.
+ * Option "conv_f16_workgroups_per_cu" (sd_set_option): 2 (default) or 1, an A/B probe of the launch geometry; same results. */
+long long sd_conv3_f16x3_packed_floats(int c_in, int c_out, int kz);
+int sd_conv3_f16x3_pack_weights_host(const float* w /* [c_out][c_in][kz][3][3] */, int c_in, int c_out, int kz, float* packed);
+int sd_conv3_f16x3_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1,
+                                int up1, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, int c_out,
+                                int act, float* d_out, int* d_range_flag, void* stream);
+int sd_conv3_f16x3_res_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1,
+                                    int up1, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias,
+                                    const float* d_res, int res_stride, int c_out, int act, float* d_out, int* d_range_flag,
+                                    void* stream);
 
 /* ---- general convolution (any kernel size, stride, padding, channel counts) ------------------------------------------------
  * Every other convolution of the reference's networks, channels-last float32, exact f32 on the matrix cores with one fixed fma chain

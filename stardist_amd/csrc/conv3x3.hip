@@ -294,7 +294,7 @@ extern "C" long long sd_conv3_packed_floats(int c_in, int c_out, int kz) {
 
 extern "C" int sd_conv3_pack_weights_host(const float* w, int c_in, int c_out, int kz, float* packed) {
   if (!w || !packed || sd_conv3_packed_floats(c_in, c_out, kz) < 0) {
-    sd::set_error("sd_conv3_pack_weights: kz 1|3, c_in 1 (c_out %% 4 == 0) or a multiple of 32 up to 256 (c_out %% 32 == 0)");
+    sd::set_error("sd_conv3_pack_weights: kz 1|3, c_in 1 (c_out %% 4 == 0) or a multiple of 32 up to 512 (c_out %% 32 == 0)");
     return -1;
   }
   if (c_in == 1) {

@@ -307,7 +307,7 @@ extern "C" long long sd_conv3_bf16x6_packed_floats(int c_in, int c_out, int kz) 
 extern "C" int sd_conv3_bf16x6_pack_weights_host(const float* w, int c_in, int c_out, int kz, float* packed) {
   const long long n = sd_conv3_bf16x6_packed_floats(c_in, c_out, kz);
   if (!w || !packed || n < 0) {
-    sd::set_error("sd_conv3_bf16x6_pack_weights: kz 1|3, c_in a multiple of 32 up to 256, c_out a multiple of 32");
+    sd::set_error("sd_conv3_bf16x6_pack_weights: kz 1|3, c_in a multiple of 32 up to 512, c_out a multiple of 32");
     return -1;
   }
   sdconv::pack_weights_bf16(w, c_in, c_out, kz, (unsigned short*)packed);

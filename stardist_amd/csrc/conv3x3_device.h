@@ -39,6 +39,7 @@ struct Params {
   const float* res;    // optional residual [D][H][W][res_stride]: out = act(conv + bias + res) -- the Add + Activation that closes a
   int res_stride;      // csbdeep resnet_block, folded into the epilogue (nullptr: none)
   int tiles_x, tiles_plane, n_tiles, groups;
+  int* flag;           // conv3x3_f16.hip: OR-ed with 1 when an activation is outside the fp16 range (nullptr: not reported)
 };
 
 // workgroup -> (output-channel group g, tile slot q): consecutive workgroups go round-robin over the 8 XCDs, so the `groups`
@@ -163,7 +164,7 @@ struct HaloBase {
   bool zin;
 };
 __device__ __forceinline__ HaloBase halo_base(const Params& P, const TileAddr& T, int u) {
-  const int c = P.kz == 3 ? (u * 21846) >> 16 : u;           // u / 3 (u < 32)
+  const int c = P.kz == 3 ? (u * 21846) >> 16 : u;           // u / 3 (exact for u < 4096)
   const int dz = P.kz == 3 ? u - c * 3 - 1 : 0;
   HaloBase B;
   B.k = P.chunk_kind[c];
@@ -208,7 +209,7 @@ __device__ __forceinline__ void halo_load(halo_gptr (&addr)[PRE_F4], v4f (&pre)[
 
 __device__ __forceinline__ void halo_fetch_at(const Params& P, const unsigned (&goff)[2][PRE_F4], const unsigned (&tyx)[PRE_F4], const TileAddr& T, int u,
                                               v4f (&pre)[PRE_F4]) {
-  const int c = P.kz == 3 ? (u * 21846) >> 16 : u;           // u / 3 (u < 32)
+  const int c = P.kz == 3 ? (u * 21846) >> 16 : u;           // u / 3 (exact for u < 4096)
   const int dz = P.kz == 3 ? u - c * 3 - 1 : 0;
   const int k = P.chunk_kind[c];
   const Src S = P.kind[k];

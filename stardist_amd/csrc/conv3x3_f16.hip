@@ -1,0 +1,454 @@
+// conv3x3_f16.hip -- the 3x3 / 3x3x3 convolution of conv3x3.hip with every f32 product evaluated as THREE fp16 x fp16 products on
+// v_mfma_f32_32x32x16_f16 (f32 accumulation): x = hi + lo' * 2^-11 with hi = fp16(x), lo' = fp16((x - hi) * 2^11), and
+//     a * b  ~  hi_a * hi_b + 2^-11 * (hi_a * lo'_b + lo'_a * hi_b)              (conv3x3_layout.h: error 2^-22 of the product)
+// The network's default kernel since round 4 (models/unet.py conv_mode()).
+//
+// Why: the six-product bf16 form (conv3x3_bf16.hip) spends 5/6 of its matrix-core time on precision emulation; fp16 carries 11
+// significant bits instead of 8, so two terms per operand and three products reach the same "f32-accurate" bar (networks within 3e-6 of
+// a float64 evaluation; tools/split_study.py) with half the matrix instructions, two LDS planes instead of three and 12-KiB instead of
+// 18-KiB weight blocks.  The cross terms are accumulated in their own tile (acc1) and scaled by 2^-11 once, in the epilogue; the bias is
+// the initial value of acc0.
+//
+// Same decomposition as the other two kernels (8 x 32 output tile, 32 output channels per workgroup, (chunk, kz) units walked as three
+// sub-units, persistent workgroups, halo tile prefetched through registers: conv3x3_device.h).  What the smaller footprint buys:
+//   * 73.5 KiB of LDS per workgroup (two 12-KiB weight buffers + the 47.8-KiB two-plane tile) and <= 256 registers per lane, so TWO
+//     workgroups share a CU (two waves per SIMD): while one wave waits for a barrier, for its halo or for the LDS, the other one
+//     feeds the matrix pipe.  The bf16 kernel (137 KiB, one wave per SIMD) had the matrix pipe idle 46 % of the time.
+//   * the epilogue stores straight from the accumulators (32 global_store_dword per wave and tile, each covering two pixels' 128
+//     contiguous bytes) -- the transposing scratch of the other kernels (32 KiB) would not fit twice.
+// Range: an activation beyond the fp16 range (|x| > 65504) cannot be split; the kernel ORs a flag into *P.flag when it sees one and
+// the caller re-evaluates with the bf16 kernel (models/unet.py).  Weights are checked by the packer.
+#include <stdlib.h>
+
+#include "common.h"
+#include "conv3x3_device.h"
+#include "stardist_hip.h"
+
+#ifdef SD_CONV_PROFILE
+__device__ unsigned long long g_conv_prof[16];   // [0] total, [1..14] phases, [15] units
+#define PROF_DECL unsigned long long pf_t = __builtin_amdgcn_s_memtime(), pf_acc[14] = {}; const unsigned long long pf_t0 = pf_t; unsigned long long pf_units = 0
+#define PROF(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pf_acc[k] += n_ - pf_t; pf_t = n_; } while (0)
+#define PROF_UNIT() (++pf_units)
+#define PROF_END() do { if (threadIdx.x == 0) { atomicAdd(&g_conv_prof[0], __builtin_amdgcn_s_memtime() - pf_t0); \
+  for (int k_ = 0; k_ < 14; ++k_) atomicAdd(&g_conv_prof[1 + k_], pf_acc[k_]); atomicAdd(&g_conv_prof[15], pf_units); } } while (0)
+#else
+#define PROF_DECL
+#define PROF(k)
+#define PROF_UNIT()
+#define PROF_END()
+#endif
+
+namespace {
+
+using namespace sdconvdev;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// Per-thread constants of the halo staging (registers are the scarce resource at two waves per SIMD): only the halo coordinates
+// ty | tx << 8 of this thread's PRE_F4 elements.  The source offset of an element and its LDS address are derived from them where they
+// are needed (in the shadow of the matrix instructions); the channel quad of every element of a thread is q4 = tid & 7 (THREADS is a
+// multiple of 8).
+struct StageH {
+  unsigned tyx[PRE_F4];
+};
+
+__device__ __forceinline__ void stage_init_h(StageH& st, int tid) { tyx_init<true>(st.tyx, tid); }
+__device__ __forceinline__ int lds_off_of(unsigned tyx, int tid) {
+  asm volatile("" : "+v"(tyx));         // derived where it is used: hoisted out of the tile loop the eleven offsets would be spilled
+  return htile_store_off((int)(tyx & 255u), (int)(tyx >> 8), 0, tid & 7);
+}
+
+// The halo is read with BUFFER loads: a unit's source plane is described by one wave-uniform resource (base = the source address of the
+// halo's first pixel, which may lie in front of the tensor on border tiles: nothing is read there), an element is a 32-bit offset, and an
+// element outside the image gets an offset beyond the resource's range, for which the hardware returns zeros -- the zero padding of
+// 'same' costs one select, no 64-bit address arithmetic and half the address registers of the pointer form (conv3x3_device.h).
+// Offset of halo pixel (ty, tx), channel quad q4, in a source with half-resolution flags (shy, shx): conv3x3_layout.h src_rel,
+//   (src_rel(ty, shy) * row_bytes + src_rel(tx, shx) * pix_bytes) + q4 * 16,   src_rel(t, sh) = ((t - sh) >> sh) + sh.
+constexpr unsigned HALO_RANGE = 0x80000000u, HALO_OUTSIDE = 0xFFFFFFF0u;
+struct HaloRsrc {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned row_bytes, pix_bytes;
+  int shy, shx;
+  int ty0, tx0, H, W;    // zin folded in: H = 0 for a z plane outside the volume (no element is inside)
+};
+__device__ __forceinline__ HaloRsrc halo_rsrc(const Params& P, const HaloBase& B, const TileAddr& T) {
+  HaloRsrc s;
+  const Src S = P.kind[B.k];
+  s.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)uniform64((unsigned long long)B.base), 0, (int)HALO_RANGE, 0x00020000);
+  s.pix_bytes = (unsigned)__builtin_amdgcn_readfirstlane(S.stride * 4);
+  s.row_bytes = (unsigned)__builtin_amdgcn_readfirstlane((P.W >> S.shx) * S.stride * 4);
+  s.shy = __builtin_amdgcn_readfirstlane(S.shy); s.shx = __builtin_amdgcn_readfirstlane(S.shx);
+  s.ty0 = __builtin_amdgcn_readfirstlane(T.ty0); s.tx0 = __builtin_amdgcn_readfirstlane(T.tx0);
+  s.H = __builtin_amdgcn_readfirstlane(B.zin ? P.H : 0); s.W = __builtin_amdgcn_readfirstlane(P.W);
+  asm volatile("" : "+s"(s.pix_bytes), "+s"(s.row_bytes), "+s"(s.shy), "+s"(s.shx), "+s"(s.ty0), "+s"(s.tx0), "+s"(s.H), "+s"(s.W));
+  return s;
+}
+__device__ __forceinline__ unsigned halo_off_one(const HaloRsrc& s, unsigned tyx, unsigned q4off) {
+  const int ty = (int)(tyx & 255u), tx = (int)(tyx >> 8);
+  const bool inside = (int)((unsigned)(s.ty0 + ty) < (unsigned)s.H) & (int)((unsigned)(s.tx0 + tx) < (unsigned)s.W);
+  const unsigned ry = (unsigned)(((ty - s.shy) >> s.shy) + s.shy), rx = (unsigned)(((tx - s.shx) >> s.shx) + s.shx);
+  unsigned a = inside ? ry * s.row_bytes + (rx * s.pix_bytes + q4off) : HALO_OUTSIDE;
+  asm volatile("" : "+v"(a));                                 // computed HERE, not where it is used
+  return a;
+}
+__device__ __forceinline__ v4f halo_load_one(const HaloRsrc& s, unsigned off) {
+  return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, (int)off, 0, 0));
+}
+
+// weights of sub-unit (u, dy) of group g: 12 KiB = 768 x 16 bytes through registers (three per thread), as in conv3x3_bf16.hip
+constexpr int WREG = (HWSUB_BYTES / 16 + THREADS - 1) / THREADS;
+static_assert(WREG * THREADS == HWSUB_BYTES / 16, "a sub-unit's weights are a whole number of 16-byte elements per thread");
+__device__ __forceinline__ void weights_fetch(const Params& P, int g, int u, int dy, v4f (&wreg)[WREG], int tid) {
+  // buffer loads: wave-uniform block address in the resource, one 32-bit offset register per thread (no 64-bit address per element)
+  const char* blk = (const char*)P.wp + (((size_t)g * P.n_units + u) * 3 + dy) * HWSUB_BYTES;
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)uniform64((unsigned long long)blk), 0, HWSUB_BYTES, 0x00020000);
+#pragma unroll
+  for (int n = 0; n < WREG; ++n) wreg[n] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, n * THREADS * 16, 0));
+}
+__device__ __forceinline__ void weights_store(char* __restrict__ wnext, const v4f (&wreg)[WREG], int tid) {
+#pragma unroll
+  for (int n = 0; n < WREG; ++n) ((v4f*)wnext)[tid + n * THREADS] = wreg[n];
+}
+
+// two f32 values -> their two fp16 terms, packed (a in the low half); round to nearest even like split2_f16 of conv3x3_layout.h;
+// `amax` collects max |x| for the range flag
+__device__ __forceinline__ void split2_pair(float a, float b, unsigned& hi, unsigned& lo, float& amax) {
+  const f32x2 x = {a, b};
+  const f16x2 h = __builtin_convertvector(x, f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  const f32x2 r = (x - __builtin_convertvector(h, f32x2)) * 2048.f;
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+  amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)));
+}
+__device__ __forceinline__ void split_elem(const v4f x, u32x2 (&pl)[2], float& amax) {
+  unsigned a[2], b[2];
+  split2_pair(x.x, x.y, a[0], a[1], amax);
+  split2_pair(x.z, x.w, b[0], b[1], amax);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    asm volatile("" : "+v"(a[p]), "+v"(b[p]));                // computed HERE (the compiler would sink the arithmetic to the stores)
+    pl[p].x = a[p]; pl[p].y = b[p];
+  }
+}
+__device__ __forceinline__ void store_planes(const StageH& st, char* __restrict__ tileH, const u32x2 (&pk)[PRE_F4][2], int tid) {
+#pragma unroll
+  for (int n = 0; n < PRE_F4; ++n)
+    if (n < PRE_F4 - 1 || tid < TILE_F4 - (PRE_F4 - 1) * THREADS) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) *(u32x2*)(tileH + lds_off_of(st.tyx[n], tid) + p * 64) = pk[n][p];
+    }
+}
+
+// One sub-unit (row tap dy): 6 operand groups (dx, block); a group = 2 halo rows x 2 planes (A) + 2 planes (B) = 6 ds_read_b128 feeding
+// 6 MFMAs (three plane pairs x two output rows).  The operands of group g+1 are read while the matrix cores work on group g.
+// `extra(gi)`: vector-ALU work / global loads that do not depend on the matrix instructions, interleaved with them.
+template <int NV, int NLD, class Extra>
+__device__ __forceinline__ void compute_sub(const char* __restrict__ tileH, const char* __restrict__ w, int dy, f32x16 (&acc0)[2], f32x16 (&acc1)[2],
+                                            int wave, int i, int h, Extra extra) {
+  u32x4 A[2][2][2], B[2][2];
+  const char* arow = tileH + (wave * 2 + dy) * HALO_W * HPIX;
+#define SD_LOAD_GROUP_H(gi, buf)                                                                                        \
+  do {                                                                                                                   \
+    const int dx_ = (gi) >> 1, b_ = (gi) & 1;                                                                            \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                        \
+      _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) A[buf][p][pl] = *(const u32x4*)(arow + htile_off(p, i + dx_, pl, b_, h)); \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) B[buf][pl] = *(const u32x4*)(w + hw_off(dx_, b_, pl, h, i));        \
+  } while (0)
+  SD_LOAD_GROUP_H(0, 0);
+#pragma unroll
+  for (int gi = 0; gi < 6; ++gi) {
+    const int buf = gi & 1;
+    if (gi + 1 < 6) SD_LOAD_GROUP_H(gi + 1, buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    extra(gi);
+    const f16x8 bh = __builtin_bit_cast(f16x8, B[buf][0]), bl = __builtin_bit_cast(f16x8, B[buf][1]);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const f16x8 ah = __builtin_bit_cast(f16x8, A[buf][p][0]), al = __builtin_bit_cast(f16x8, A[buf][p][1]);
+      acc1[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[p], 0, 0, 0);
+      acc1[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[p], 0, 0, 0);
+      acc0[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0[p], 0, 0, 0);
+    }
+    if (NV > 0 || NLD > 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // one MFMA ...
+        if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                      // ... then NV vector-ALU instructions
+        if (NLD > 0 && k % (6 / NLD) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // ... or a global load
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef SD_LOAD_GROUP_H
+}
+
+// results of one tile -> HBM, straight from the accumulators: register r of lane (i, h) holds output channel i of pixel column
+// (r & 3) + 8 (r >> 2) + 4 h (acc_col): one global_store_dword covers two pixels' 128 contiguous bytes
+template <bool RES>
+__device__ __forceinline__ void store_tile_direct(const Params& P, const f32x16 (&acc0)[2], const f32x16 (&acc1)[2], int g, int tz, int ty, int tx,
+                                                  int wave, int lane) {
+  const int i = lane & 31, h = lane >> 5;
+  const bool xfull = tx + TW <= P.W;
+  // buffer stores: one resource per output row (wave-uniform), 32-bit offsets inside the row
+  const unsigned pix_bytes = (unsigned)P.c_out * 4u, res_bytes = (unsigned)P.res_stride * 4u;
+  const unsigned off0 = (unsigned)(tx + 4 * h) * pix_bytes + (unsigned)(g * 32 + i) * 4u;
+  const unsigned roff0 = (unsigned)(tx + 4 * h) * res_bytes + (unsigned)(g * 32 + i) * 4u;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int y = ty + wave * 2 + p;
+    if (y >= P.H) continue;                                            // (wave-uniform)
+    const size_t row = ((size_t)tz * P.H + y) * P.W;
+    const __amdgpu_buffer_rsrc_t ro =
+        __builtin_amdgcn_make_buffer_rsrc((void*)uniform64((unsigned long long)(P.out + row * P.c_out)), 0, (int)((unsigned)P.W * pix_bytes), 0x00020000);
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc0[p][r] + acc1[p][r] * 4.8828125e-4f;      // 2^-11
+    if (RES && P.res) {
+      const __amdgpu_buffer_rsrc_t rr =
+          __builtin_amdgcn_make_buffer_rsrc((void*)uniform64((unsigned long long)(P.res + row * P.res_stride)), 0, (int)((unsigned)P.W * res_bytes), 0x00020000);
+#pragma unroll
+      for (int r = 0; r < 16; ++r)          // (a pixel beyond the row's end reads zero and is not stored)
+        v[r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)(roff0 + (unsigned)((r & 3) + 8 * (r >> 2)) * res_bytes), 0, 0));
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (P.act == 1) v[r] = fmaxf(v[r], 0.f);
+      // a pixel beyond the end of the row lies outside the resource: the hardware drops the store (partial last tile column)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), ro, (int)(off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * pix_bytes), 0, 0);
+    }
+  }
+  (void)xfull;
+}
+
+// TWO workgroups per CU (73.5 KiB of LDS each, <= 256 registers per lane): two waves per SIMD
+// (WPE = 1: the same code compiled for one wave per SIMD -- 512 registers -- as the A/B partner of option conv_f16_workgroups_per_cu = 1)
+template <bool RES, int WPE>
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_conv3_f16(const Params P) {
+  extern __shared__ float4 smem4h[];
+  // LDS map (bytes): two weight buffers of one sub-unit each | halo tile, 2 fp16 planes
+  char* W = (char*)smem4h;
+  char* tileH = W + 2 * HWSUB_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int g, q, Q;
+  wg_slot(P, g, q, Q);
+  if (q >= P.n_tiles) return;
+  const float bias_r = P.bias ? P.bias[g * 32 + (lane & 31)] : 0.f;
+  StageH st;
+  stage_init_h(st, tid);
+  const unsigned q4off = (unsigned)(tid & 7) * 16u;
+  TileAddr Tc, Tn;                                      // the tile being computed, the tile whose first unit is fetched next
+  tile_addr(P, q, Tc);
+  Tn = Tc;
+  float amax = 0.f;
+  {
+    v4f pre[PRE_F4], wreg[WREG];
+    u32x2 pk[PRE_F4][2];
+    weights_fetch(P, g, 0, 0, wreg, tid);
+    {
+      const HaloRsrc hs = halo_rsrc(P, halo_base(P, Tc, 0), Tc);
+#pragma unroll
+      for (int n = 0; n < PRE_F4; ++n) pre[n] = halo_load_one(hs, halo_off_one(hs, st.tyx[n], q4off));
+    }
+    weights_store(W, wreg, tid);
+#pragma unroll
+    for (int n = 0; n < PRE_F4; ++n) split_elem(pre[n], pk[n], amax);
+    store_planes(st, tileH, pk, tid);
+  }
+  __syncthreads();
+  PROF_DECL;
+  int wb = 0;
+  for (int t = q; t < P.n_tiles; t += Q) {
+    f32x16 acc0[2], acc1[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[p][r] = bias_r; acc1[p][r] = 0.f; }
+    for (int u = 0; u < P.n_units; ++u) {
+      const bool last = u == P.n_units - 1;
+      const int tn = last ? t + Q : t, un = last ? 0 : u + 1;
+      const bool have = tn < P.n_tiles;
+      v4f pre[PRE_F4];
+      unsigned addr[PRE_F4];
+      u32x2 pk[PRE_F4][2];
+      HaloRsrc hs;
+      // dy 0: its matrix instructions hide the address arithmetic of the next unit's halo; dy 1 issues its weight loads FIRST and the
+      // halo loads after them (the wait for the weights leaves the halo in flight); dy 2 splits the halo elements into their fp16
+      // planes (registers) as they arrive; after its barrier only the LDS stores are left.
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const bool lastdy = dy == 2, have_w = lastdy ? have : true;
+        v4f wreg[WREG];
+        // (always issued, from a valid address even when there is nothing left to fetch)
+        weights_fetch(P, g, lastdy ? (have ? un : u) : u, lastdy ? (have ? 0 : dy) : dy + 1, wreg, tid);      // next sub-unit's weights
+        __builtin_amdgcn_sched_barrier(0);
+        if (dy == 0 && last && have) tile_addr(P, tn, Tn);                                     // (once per tile)
+        __builtin_amdgcn_sched_barrier(0);
+        PROF(dy);
+        const char* wcur = W + wb * HWSUB_BYTES;
+        if (dy == 0) {
+          const TileAddr T = tile_select(last && have, Tc, Tn);
+          hs = halo_rsrc(P, halo_base(P, T, have ? un : u), T);
+          compute_sub<5, 0>(tileH, wcur, dy, acc0, acc1, wave, lane & 31, lane >> 5, [&](int gi) {
+#pragma unroll
+            for (int n = gi * 2; n < gi * 2 + 2; ++n)
+              if (n < PRE_F4) addr[n] = halo_off_one(hs, st.tyx[n], q4off);
+          });
+        } else if (dy == 1) {
+          compute_sub<0, 2>(tileH, wcur, dy, acc0, acc1, wave, lane & 31, lane >> 5, [&](int gi) {      // the next unit's halo loads
+#pragma unroll
+            for (int n = gi * 2; n < gi * 2 + 2; ++n)
+              if (n < PRE_F4) pre[n] = halo_load_one(hs, addr[n]);
+          });
+        } else {
+          compute_sub<6, 0>(tileH, wcur, dy, acc0, acc1, wave, lane & 31, lane >> 5, [&](int gi) {
+#pragma unroll
+            for (int n = (gi - 2) * 3; n < (gi - 2) * 3 + 3; ++n)
+              if (gi >= 2 && n < PRE_F4) split_elem(pre[n], pk[n], amax);
+          });
+        }
+        PROF(dy == 0 ? 3 : 11 + dy);
+        if (have_w) weights_store(W + (wb ^ 1) * HWSUB_BYTES, wreg, tid);                    // the other buffer: nobody reads it now
+        if (lastdy) {                                                                        // (a use on every path, see conv3x3_bf16.hip)
+#pragma unroll
+          for (int n = 0; n < WREG; ++n) asm volatile("" ::"v"(wreg[n]));
+        }
+        PROF(4 + dy);
+        __syncthreads();
+        PROF(7);
+        wb ^= 1;
+      }
+      PROF(8);
+      if (have) store_planes(st, tileH, pk, tid);                  // (every wave is past the barrier behind the last sub-unit)
+      PROF(9);
+      __syncthreads();
+      PROF(10);
+      PROF_UNIT();
+    }
+    store_tile_direct<RES>(P, acc0, acc1, g, Tc.tz, Tc.ty0 + 1, Tc.tx0 + 1, wave, lane);
+    PROF(11);
+    Tc = Tn;
+  }
+  // an activation outside the fp16 range (or not finite): tell the host (one atomic per offending wave, normally none)
+  if (P.flag && !(amax <= 65504.f)) atomicOr(P.flag, 1);
+  PROF_END();
+}
+
+}  // namespace
+
+extern "C" long long sd_conv3_f16x3_packed_floats(int c_in, int c_out, int kz) {
+  if ((kz != 1 && kz != 3) || c_in <= 0 || c_in % 32 || c_in > 32 * sdconv::MAX_CHUNKS || c_out <= 0 || c_out % 32) return -1;
+  return (long long)(sdconv::hpacked_bytes(c_in, c_out, kz) / 4) + 4;      // + 16 bytes of zeros (the zero-padding source)
+}
+
+extern "C" int sd_conv3_f16x3_pack_weights_host(const float* w, int c_in, int c_out, int kz, float* packed) {
+  const long long n = sd_conv3_f16x3_packed_floats(c_in, c_out, kz);
+  if (!w || !packed || n < 0) {
+    sd::set_error("sd_conv3_f16x3_pack_weights: kz 1|3, c_in a multiple of 32 up to 512, c_out a multiple of 32");
+    return -1;
+  }
+  const float wmax = sdconv::pack_weights_f16(w, c_in, c_out, kz, (unsigned short*)packed);
+  for (int k = 0; k < 4; ++k) packed[n - 4 + k] = 0.f;
+  if (!(wmax <= 65504.f)) {
+    sd::set_error("sd_conv3_f16x3_pack_weights: a weight of magnitude %g is outside the fp16 range (use the bf16x6 form for this layer)", (double)wmax);
+    return -2;
+  }
+  return 0;
+}
+
+extern "C" int sd_conv3_f16x3_res_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1,
+                                               int up1, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias,
+                                               const float* d_res, int res_stride, int c_out, int act, float* d_out, int* d_range_flag,
+                                               void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (D <= 0 || H <= 0 || W <= 0) return 0;
+  const int c_in = c0 + (d_src1 ? c1 : 0);
+  const long long n_packed = sd_conv3_f16x3_packed_floats(c_in, c_out, kz);
+  if (!d_src0 || !d_wpacked || !d_out || (act != 0 && act != 1) || n_packed < 0 || (kz == 1 && D != 1) ||
+      (((uintptr_t)d_src0 | (uintptr_t)d_src1 | (uintptr_t)d_wpacked | (uintptr_t)d_out | (uintptr_t)d_bias) & 15) || ((uintptr_t)d_range_flag & 3)) {
+    sd::set_error("sd_conv3_f16x3: unsupported channel counts (%d + %d -> %d), kz, act or misaligned pointers", c0, d_src1 ? c1 : 0, c_out);
+    return -1;
+  }
+  const int ups[2] = {up0, d_src1 ? up1 : 0};
+  for (int k = 0; k < 2; ++k)
+    if (ups[k] < 0 || ups[k] > 7 || ((ups[k] & 1) && (W & 1)) || ((ups[k] & 2) && (H & 1)) || ((ups[k] & 4) && (D & 1))) {
+      sd::set_error("sd_conv3_f16x3: up is a bit mask (1: x, 2: y, 4: z); an up-sampled axis needs an even output size");
+      return -1;
+    }
+  if ((c0 % 32) || (d_src1 && (c1 % 32)) || stride0 < c0 || (stride0 & 3) || (d_src1 && (stride1 < c1 || (stride1 & 3)))) {
+    sd::set_error("sd_conv3_f16x3: sources must hold multiples of 32 channels, strides multiples of 4 floats");
+    return -1;
+  }
+  Params P;
+  int nc = 0;
+  P.kind[0] = make_src(d_src0, stride0, up0, H, W);
+  P.kind[1] = d_src1 ? make_src(d_src1, stride1, up1, H, W) : P.kind[0];
+  for (int k = 0; k < MAX_CHUNKS; ++k) { P.chunk_kind[k] = 0; P.chunk_choff[k] = 0; }
+  for (int k = 0; k < c0 / 32; ++k) { P.chunk_kind[nc] = 0; P.chunk_choff[nc++] = k * 32; }
+  if (d_src1) for (int k = 0; k < c1 / 32; ++k) { P.chunk_kind[nc] = 1; P.chunk_choff[nc++] = k * 32; }
+  P.D = D; P.H = H; P.W = W; P.kz = kz; P.n_units = nc * kz;
+  P.zero = d_wpacked + (n_packed - 4);
+  if (d_res && (res_stride < c_out || (res_stride & 3) || ((uintptr_t)d_res & 15))) {
+    sd::set_error("sd_conv3_f16x3: the residual needs 16-byte alignment and a stride >= c_out");
+    return -1;
+  }
+  P.res = d_res; P.res_stride = res_stride;
+  P.wp = d_wpacked; P.bias = d_bias; P.out = d_out; P.c_out = c_out; P.act = act;
+  P.flag = d_range_flag;
+  P.tiles_x = (W + TW - 1) / TW;
+  P.tiles_plane = P.tiles_x * ((H + TH - 1) / TH);
+  const long long nt_ll = (long long)P.tiles_plane * D;
+  if (nt_ll > 0x7fffffffLL) { sd::set_error("sd_conv3_f16x3: too many tiles"); return -1; }
+  // 32-bit offsets inside one halo tile's rows (buffer loads) and inside one output row (buffer stores)
+  const long long row0 = (long long)(W >> (up0 & 1)) * stride0 * 4, row1 = d_src1 ? (long long)(W >> (up1 & 1)) * stride1 * 4 : 0;
+  if ((HALO_H + 1) * (row0 > row1 ? row0 : row1) >= 0x7fffffffLL || (long long)W * c_out * 4 >= 0x7fffffffLL ||
+      (d_res && (long long)W * res_stride * 4 >= 0x7fffffffLL)) {
+    sd::set_error("sd_conv3_f16x3: an image row of %d pixels is too long for 32-bit offsets", W);
+    return -1;
+  }
+  P.n_tiles = (int)nt_ll;
+  P.groups = c_out / 32;
+  static bool attr_set[16] = {};
+  static int n_cu[16] = {};
+  int dev = 0;
+  SD_CHECK(hipGetDevice(&dev));
+  const size_t lds = (size_t)2 * HWSUB_BYTES + HTILE_BYTES;               // 71.8 KiB: two workgroups per CU
+  if (dev >= 16 || !attr_set[dev]) {
+    SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (dev < 16) attr_set[dev] = true;
+  }
+  int cus = dev < 16 ? n_cu[dev] : 0;
+  if (cus <= 0) {
+    SD_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus <= 0) cus = 256;
+    if (dev < 16) n_cu[dev] = cus;
+  }
+  const int per_cu = sd::option(sd::OPT_CONV_F16_WGS) == 1 ? 1 : 2;          // (1: A/B probe of the one-workgroup-per-CU launch)
+  long long blocks = (long long)(per_cu * cus / P.groups) * P.groups;
+  if (blocks < P.groups) blocks = P.groups;
+  const long long want = (long long)P.n_tiles * P.groups;
+  if (blocks > want) blocks = want;
+  if (per_cu == 1) {
+    if (d_res) hipLaunchKernelGGL((k_conv3_f16<true, 1>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
+    else hipLaunchKernelGGL((k_conv3_f16<false, 1>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
+  } else {
+    if (d_res) hipLaunchKernelGGL((k_conv3_f16<true, 2>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
+    else hipLaunchKernelGGL((k_conv3_f16<false, 2>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
+  }
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sd_conv3_f16x3_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1, int up1,
+                                           int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, int c_out, int act,
+                                           float* d_out, int* d_range_flag, void* stream_) {
+  return sd_conv3_f16x3_res_ndhwc_device(d_src0, c0, stride0, up0, d_src1, c1, stride1, up1, D, H, W, kz, d_wpacked, d_bias, nullptr, 0,
+                                         c_out, act, d_out, d_range_flag, stream_);
+}

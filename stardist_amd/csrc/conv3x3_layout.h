@@ -35,7 +35,7 @@ constexpr int TILE_FLOATS = HALO_H * HALO_W * PIX_STRIDE;
 constexpr int TILE_F4 = HALO_H * HALO_W * (CHUNK / 4);       // float4 elements of one staged halo tile
 constexpr int THREADS = 256;
 constexpr int PRE_F4 = (TILE_F4 + THREADS - 1) / THREADS;    // float4 registers per thread for the prefetch of the next tile
-constexpr int MAX_CHUNKS = 8;                     // up to 256 input channels
+constexpr int MAX_CHUNKS = 16;                    // up to 512 input channels (depth-4 U-Net: 256 up-sampled + 256 skip)
 
 // 32-wide output-channel tiles a workgroup computes at once (registers: 2*NT accumulator tiles per wave, 9*NT float4 of weight
 // prefetch per thread; LDS: NT*36 KiB of weights).  NT = 2 halves the input staging per output channel but its prefetch registers
@@ -154,6 +154,84 @@ inline void pack_weights_bf16(const float* w, int c_in, int c_out, int kz, unsig
                     const size_t sub = (((size_t)g * n_units + c * kz + z) * 3 + dy) * BWSUB_BYTES;
                     for (int p = 0; p < 3; ++p) out[(sub + bw_off(dx, b, p, h, i)) / 2 + j] = (unsigned short)(pl[p] >> 16);
                   }
+}
+
+// ---- split-fp16 variant (conv3x3_f16.hip) --------------------------------------------------------------------------------------
+// Every f32 operand x is written as hi + lo' * 2^-11 with hi = fp16(x) and lo' = fp16((x - hi) * 2^11) (round to nearest even; the
+// remainder x - hi is exact in f32, and scaling it by 2^11 keeps lo' in the normal fp16 range whenever hi is).  fp16 carries 11
+// significant bits, so hi + lo' * 2^-11 reproduces x to 2^-22, and a product a*b is evaluated as
+//     hi_a * hi_b  +  2^-11 * (hi_a * lo'_b + lo'_a * hi_b)
+// -- three fp16 x fp16 products (each exact in f32) on v_mfma_f32_32x32x16_f16 with two f32 accumulators (the cross terms are summed
+// in their own accumulator and scaled once, in the epilogue); the dropped lo * lo term is below 2^-22 of the product.  Half the
+// matrix-core work of the six-product bf16 form at ~2.5x its split error, still 5x below the f32 accumulation error of any f32 kernel
+// (tools/split_study.py: 2.3e-7 vs 9.5e-8 on the 2D network, where f32 accumulation itself is at 1.2e-6).
+// Range: fp16 overflows above 65504.  Weights are checked when they are packed; the kernel raises a device flag when an activation
+// exceeds the range (models/unet.py then re-evaluates the network with the bf16 form, loudly).  Values below 2^-14 have a subnormal
+// hi, i.e. an ABSOLUTE error floor of 2^-36 after the lo' term -- harmless.
+//   LDS tile   : 144 bytes per halo pixel = 2 planes (hi, lo') x 32 channels x 2 bytes + 16 bytes of padding (36 dwords: the 16 lanes
+//                of a ds_read_b128 group hit 16 distinct bank quadruples)
+//   sub-unit   : the weights of one (unit, row tap dy) = 3 dx x 2 blocks x 2 planes x 2 h x 32 output channels x 16 bytes = 12 KiB
+constexpr int HPIX = 144;
+constexpr int HTILE_BYTES = HALO_H * HALO_W * HPIX;
+constexpr int HWSUB_BYTES = 3 * 2 * 2 * 2 * 32 * 16;
+SDC_HD int htile_off(int ty, int tx, int p, int b, int h) { return (ty * HALO_W + tx) * HPIX + p * 64 + b * 32 + h * 16; }
+SDC_HD int htile_store_off(int ty, int tx, int p, int q4) { return (ty * HALO_W + tx) * HPIX + p * 64 + q4 * 8; }
+SDC_HD int hw_off(int dx, int b, int p, int h, int i) { return ((((dx * 2 + b) * 2 + p) * 2 + h) * 32 + i) * 16; }
+SDC_HD size_t hpacked_bytes(int c_in, int c_out, int kz) { return (size_t)(c_out / 32) * (c_in / CHUNK) * kz * 3 * HWSUB_BYTES; }
+
+// fp16(f), round to nearest even, subnormals kept, overflow -> infinity: the bits (what v_cvt_pk_f16_f32 / v_cvt_f16_f32 produce)
+SDC_HD unsigned short f16_bits(float f) {
+  const unsigned u = f2u(f), sign = (u >> 16) & 0x8000u, a = u & 0x7FFFFFFFu;
+  if (a >= 0x7F800000u) return (unsigned short)(sign | 0x7C00u | ((a > 0x7F800000u) ? 0x200u : 0u));   // inf / nan
+  if (a >= 0x477FF000u) return (unsigned short)(sign | 0x7C00u);                                       // rounds to >= 2^16: infinity
+  if (a < 0x33000001u) return (unsigned short)sign;                                                     // <= 2^-25: rounds to zero
+  int e = (int)(a >> 23) - 127;
+  unsigned m = (a & 0x7FFFFFu) | 0x800000u;                    // 24-bit significand
+  int shift = e >= -14 ? 13 : 13 + (-14 - e);                   // bits dropped (subnormal results drop more)
+  const unsigned keep = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  unsigned r = keep + ((rem > half || (rem == half && (keep & 1u))) ? 1u : 0u);
+  // normal: exponent field e + 15 with the implicit bit inside r (r in [2^10, 2^11]); subnormal: exponent field 0
+  const unsigned bits = e >= -14 ? ((unsigned)(e + 14) << 10) + r : r;      // (a carry out of r bumps the exponent by itself)
+  return (unsigned short)(sign | bits);
+}
+SDC_HD float f16_value(unsigned short h) {
+  const unsigned sign = (unsigned)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3FFu;
+  if (e == 31u) return u2f(sign | 0x7F800000u | (m << 13));
+  if (e == 0u) {                                                // zero / subnormal: m * 2^-24
+    float v = (float)m * 5.9604644775390625e-08f;
+    return (sign ? -v : v);
+  }
+  return u2f(sign | ((e + 112u) << 23) | (m << 13));
+}
+SDC_HD void split2_f16(float x, unsigned short& hi, unsigned short& lo) {
+  hi = f16_bits(x);
+  lo = f16_bits((x - f16_value(hi)) * 2048.f);
+}
+
+// Pack w[c_out][c_in][kz][3][3] (float32) into the two fp16 planes of the device layout: [group][unit][dy][sub-unit block].
+// Returns the largest |w| (the caller refuses weights beyond the fp16 range).
+inline float pack_weights_f16(const float* w, int c_in, int c_out, int kz, unsigned short* out) {
+  const int n_chunks = c_in / CHUNK, groups = c_out / 32, n_units = n_chunks * kz;
+  float wmax = 0.f;
+  for (int g = 0; g < groups; ++g)
+    for (int c = 0; c < n_chunks; ++c)
+      for (int z = 0; z < kz; ++z)
+        for (int dy = 0; dy < 3; ++dy)
+          for (int dx = 0; dx < 3; ++dx)
+            for (int b = 0; b < 2; ++b)
+              for (int h = 0; h < 2; ++h)
+                for (int i = 0; i < 32; ++i)
+                  for (int j = 0; j < 8; ++j) {
+                    const int co = g * 32 + i, ci = c * CHUNK + b * 16 + h * 8 + j;
+                    const float x = w[(((size_t)co * c_in + ci) * kz + z) * 9 + dy * 3 + dx];
+                    const float ax = x < 0 ? -x : x;
+                    if (!(ax <= wmax)) wmax = ax;               // (a NaN ends up in wmax)
+                    unsigned short pl[2];
+                    split2_f16(x, pl[0], pl[1]);
+                    const size_t sub = (((size_t)g * n_units + c * kz + z) * 3 + dy) * HWSUB_BYTES;
+                    for (int p = 0; p < 2; ++p) out[(sub + hw_off(dx, b, p, h, i)) / 2 + j] = pl[p];
+                  }
+  return wmax;
 }
 
 }  // namespace sdconv

@@ -68,6 +68,10 @@ SIGNATURES = {
     "sd_conv3_bf16x6_packed_floats": (ctypes.c_longlong, [_i, _i, _i]),
     "sd_conv3_bf16x6_pack_weights_host": (_i, [_vp, _i, _i, _i, _vp]),
     "sd_conv3_bf16x6_ndhwc_device": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "sd_conv3_f16x3_packed_floats": (ctypes.c_longlong, [_i, _i, _i]),
+    "sd_conv3_f16x3_pack_weights_host": (_i, [_vp, _i, _i, _i, _vp]),
+    "sd_conv3_f16x3_ndhwc_device": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "sd_conv3_f16x3_res_ndhwc_device": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "_LIB_non_maximum_suppression_2d": (None, [_vp, _vp, _i, _i, _f, _i, _i, _i, _vp]),
     "_LIB_polygon_to_label": (None, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "_LIB_star_dist": (None, [_vp, _i, _i, _i, _i, _i, _vp]),

@@ -103,7 +103,11 @@ class StarDistBase(object):
         self.thresholds = dict(prob=0.5 if threshs["prob"] is None else threshs["prob"],
                                nms=0.4 if threshs["nms"] is None else threshs["nms"])
         self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
-        self.compute_dtype = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16}[compute_dtype]
+        if compute_dtype != "float32":
+            # (rounds 1-3 offered bfloat16 / float16 autocast through the framework's library kernels; the prediction path is float32
+            # data on the library's own kernels -- whose matrix-core forms are already f32-accurate evaluations on the fp16 / bf16 pipes)
+            raise ValueError("compute_dtype=%r: the prediction path computes in float32" % (compute_dtype,))
+        self.compute_dtype = torch.float32
         self.net = self._build()
         from .unet import init_he_normal_
         init_he_normal_(self.net, seed)
@@ -119,9 +123,6 @@ class StarDistBase(object):
                     break
         self.net = self.net.to(self.device).eval()
         if self.device.type == "cuda":
-            # let MIOpen time its solvers per conv shape once (find mode) instead of the immediate-mode heuristic:
-            # 2D net 20.9 -> 18.2 ms, 3D net 267 -> 205 ms on MI355X; the search runs during the first call per shape
-            torch.backends.cudnn.benchmark = True
             self.net = self.net.to(memory_format=torch.channels_last if config.n_dim == 2 else torch.channels_last_3d)
 
     # the seam where the reference calls keras_model.predict (base.py:408-410)
@@ -289,13 +290,37 @@ class StarDistBase(object):
         return _permute_axes
 
     def _net_forward(self, x, sparse_head=False):
+        """_net_forward_once under the range guard of the default split-fp16 convolutions (models/unet.py conv_mode): the kernels OR a
+        device flag when an activation lies outside the fp16 range (|x| > 65504 or not finite).  The flag is read back after the pass
+        (one 4-byte copy); when it is set the outputs are discarded, a warning names the cause, and this pass and all later ones of
+        this model run the six-product bf16 form, which has f32 range."""
+        from . import unet
+        pinned = getattr(self, "_conv_mode_pin", None)
+        if self.device.type != "cuda" or pinned is not None or unet.conv_mode() != "f16x3":
+            if pinned is not None and unet.conv_mode() == "f16x3":
+                with unet.force_conv_mode(pinned):
+                    return self._net_forward_once(x, sparse_head)
+            return self._net_forward_once(x, sparse_head)
+        flag = unet.range_flag(self.device)
+        flag.zero_()
+        ys = self._net_forward_once(x, sparse_head)
+        if int(flag.item()) == 0:
+            return ys
+        import warnings
+        warnings.warn("an activation of the network lies outside the fp16 range (|x| > 65504 or not finite): re-evaluating with the "
+                      "bf16x6 convolution kernels, which this model uses from now on")
+        self._conv_mode_pin = "bf16x6"
+        with unet.force_conv_mode("bf16x6"):
+            return self._net_forward_once(x, sparse_head)
+
+    def _net_forward_once(self, x, sparse_head=False):
         """x: torch tensor with axes_net semantics (channels last) -> tuple of channels-last outputs (prob, dist[, prob_class]).
         sparse_head=True (GPU, fused heads: models/unet.py): (prob, features[, prob_class]) when self._head_mode == "sparse" after
         the call -- the distance head is then evaluated on the selected rows only (_select_rows); otherwise as above.
 
         On the GPU the forward pass is captured once per input shape into a HIP graph (torch.cuda.CUDAGraph) and
-        replayed: the network is ~60 small conv launches whose host-side dispatch (MIOpen solver lookup + launch)
-        otherwise leaves the device idle for several ms per call.  Outputs of a replay are valid until the next call."""
+        replayed: the network is a few dozen launches whose host-side dispatch through ctypes otherwise leaves the device idle
+        between them.  Outputs of a replay are valid until the next call."""
         import torch
         nd = self.config.n_dim
         xc = x.permute(*([nd] + list(range(nd)))).unsqueeze(0)      # (1,C,...)
@@ -316,7 +341,7 @@ class StarDistBase(object):
                 static_in.copy_(xc)
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):                        # warm-up outside capture (MIOpen find, workspaces)
+                with torch.cuda.stream(side):                        # warm-up outside capture (weight packing, allocations)
                     for _ in range(2):
                         self._net_eager(static_in, sparse_head)
                 torch.cuda.current_stream().wait_stream(side)
@@ -330,7 +355,7 @@ class StarDistBase(object):
                     import warnings
                     warnings.warn("HIP graph capture of the network failed (%r); running eagerly" % (e,))
                     self.use_hip_graph = False
-                    return self._net_forward(x, sparse_head)
+                    return self._net_forward_once(x, sparse_head)
             g, static_in, static_out, self._head_mode = cache[key]
             static_in.copy_(xc)
             g.replay()
@@ -341,10 +366,6 @@ class StarDistBase(object):
         import torch
         kw = dict(sparse_head=True) if sparse_head else {}
         with torch.no_grad():
-            if self.compute_dtype != torch.float32:
-                with torch.autocast(device_type=self.device.type, dtype=self.compute_dtype):
-                    ys = self.net(xc, **kw)
-                return tuple(y.float() for y in ys)
             return tuple(self.net(xc.float(), **kw))
 
     def _predict_setup(self, img, axes, normalizer, n_tiles):

@@ -33,114 +33,80 @@ def _act(name):
     raise ValueError("activation %s not supported" % name)
 
 
-# MIOpen's find mode picks split-K kernels (partial sums combined with atomics, run-to-run different in the last bits) for
-# convolutions with few output pixels and a long reduction -- the deep levels of the U-Net on small inputs (measured:
-# 256->128 channels at 64^2: not repeatable; the same layer at 256^2 and every full-resolution layer: repeatable).
-# Below this many output pixels the convolution is done as ONE rocBLAS GEMM over explicitly shifted views instead
-# (repeatable; 0.05-0.1 ms per layer, tools/conv_det_probe2.py), so that predict() is deterministic and the dense and the
-# sparse prediction path agree bit for bit.
-_GEMM_CONV_MAX_PIXELS = 128 * 128
+# ---- hand-written convolutions (csrc/conv3x3*.hip, conv_general.hip) -----------------------------------------------------------
+# GPU inference runs EVERY convolution, pooling and head of the network on the library's own kernels; a layer none of them covers
+# raises UnsupportedLayer with the layer's shape (there is no library / framework fallback on the device).  The plain torch modules
+# below remain what they are everywhere else: on the CPU (float64 references of the tests, the flagged CPU baseline of bench.py) and
+# under autograd.
+#
+# Conv2D(3x3) / Conv3D(3x3x3) 'same' layers with 1 or a multiple of 32 (<= 512) input channels and a multiple of 32 output channels
+# -- including Concatenate([UpSampling(x), skip]) in front of them -- run as implicit GEMMs on the matrix cores with up-sampling,
+# concatenation, bias, batch-norm and activation folded in.
+class UnsupportedLayer(NotImplementedError):
+    """a network layer that no hand-written kernel covers (GPU inference has no library fallback)"""
 
 
-def _gemm_conv(x, w):
-    """stride-1 'same' convolution of x (N, C, *S) with w (Cout, C, *k), odd k, as one matrix product"""
-    nd = x.dim() - 2
-    k = w.shape[2:]
-    pads = []
-    for kk in reversed(k):
-        pads += [kk // 2, kk // 2]
-    xp = F.pad(x, pads)
-    S = x.shape[2:]
-    import itertools
-    cols = [xp[(slice(None), slice(None)) + tuple(slice(o, o + s) for o, s in zip(off, S))] for off in itertools.product(*[range(kk) for kk in k])]
-    cols = torch.stack(cols, dim=2).reshape(x.shape[0], x.shape[1] * len(cols), -1)      # (N, C*K, prod S), K fastest like w
-    y = torch.matmul(w.reshape(w.shape[0], -1), cols)
-    y = y.reshape((x.shape[0], w.shape[0]) + tuple(S))
-    return y.contiguous(memory_format=torch.channels_last if nd == 2 else torch.channels_last_3d)
+_CONV_MODES = ("f16x3", "bf16x6", "hand")
+_mode_override = []
 
 
-def _conv_nobias(conv, x):
-    """the convolution without its bias: MIOpen/CK kernel, or the repeatable GEMM form for small deep layers"""
-    S = x.shape[2:]
-    if (x.is_cuda and int(np.prod(S)) <= _GEMM_CONV_MAX_PIXELS and conv.in_channels * int(np.prod(conv.kernel_size)) >= 256
-            and all(s == 1 for s in conv.stride) and all(d == 1 for d in conv.dilation) and conv.groups == 1
-            and all(kk % 2 == 1 and p == kk // 2 for kk, p in zip(conv.kernel_size, conv.padding)) and not torch.is_grad_enabled()):
-        return _gemm_conv(x, conv.weight)
-    return conv._conv_forward(x, conv.weight, None)
-
-
-# A convolution over a channel concatenation [a, b] equals conv(a, W[:, :Ca]) + conv(b, W[:, Ca:]).  For the large
-# (full-resolution) levels of the up path the two-source form is used on the GPU: the concatenated tensor is never written
-# (2D 2048^2: 1 GiB, 3D 256^3: 4 GiB), and MIOpen's kernel for the 4 GiB input of the 256^3 level runs at 33 TFLOP/s where
-# the two 32-channel halves run at 97 (56 ms -> 19 ms, tools/probe_bigconv.py).  The partial sums are added in float32 by
-# the same pass that applies bias + activation (sd_add_bias_act_device).
-_SPLIT_CONCAT_MIN_ELEMS = 2 ** 28
-
-
-def _split_weights(conv, ca):
-    """the two input-channel halves of conv.weight, cached per module (inference only: invalidated when the weight changes)"""
-    key = (conv.weight.data_ptr(), conv.weight._version, ca)
-    cache = conv.__dict__.get("_sd_split")
-    if cache is None or cache[0] != key:
-        mf = torch.channels_last if conv.weight.dim() == 4 else torch.channels_last_3d
-        wa = conv.weight[:, :ca].detach().contiguous(memory_format=mf)
-        wb = conv.weight[:, ca:].detach().contiguous(memory_format=mf)
-        cache = (key, wa, wb)
-        conv.__dict__["_sd_split"] = cache
-    return cache[1], cache[2]
-
-
-def _conv_cat_bias_act(conv, a, b, kind):
-    """act(conv(cat([a, b], 1)) + bias) without the concatenation; None if not applicable (caller concatenates)"""
-    if not (a.is_cuda and conv.bias is not None and a.dtype == torch.float32 and b.dtype == torch.float32 and not torch.is_grad_enabled()
-            and not torch.is_autocast_enabled() and kind in (0, 1) and a.numel() + b.numel() >= _SPLIT_CONCAT_MIN_ELEMS
-            and conv.groups == 1 and a.shape[1] + b.shape[1] == conv.in_channels):
-        return None
-    from ..lib import _native as N
-    wa, wb = _split_weights(conv, a.shape[1])
-    st, pd, dl = conv.stride, conv.padding, conv.dilation
-    f = F.conv2d if a.dim() == 4 else F.conv3d
-    y = f(a, wa, None, st, pd, dl)
-    z = f(b, wb, None, st, pd, dl)
-    C = y.shape[1]
-    cl = torch.channels_last if y.dim() == 4 else torch.channels_last_3d
-    if y.dtype == torch.float32 and y.is_contiguous(memory_format=cl) and z.is_contiguous(memory_format=cl):
-        n_outer, inner = y.numel() // C, 1
-    elif y.dtype == torch.float32 and y.is_contiguous() and z.is_contiguous():
-        n_outer, inner = y.shape[0], y.numel() // (y.shape[0] * C)
-    else:
-        y = y.add_(z).add_(conv.bias.to(y.dtype).view((1, C) + (1,) * (y.dim() - 2)))
-        return torch.relu_(y) if kind == 1 else y
-    N.dcall(y, "sd_add_bias_act_device", ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(z.data_ptr()), ctypes.c_void_p(conv.bias.data_ptr()),
-            n_outer, C, inner, kind)
-    return y
-
-
-# ---- hand-written 3x3 / 3x3x3 convolutions (csrc/conv3x3.hip) ---------------------------------------------------------------
-# Conv2D(3x3) / Conv3D(3x3x3) 'same' layers with 1 or a multiple of 32 (<= 256) input channels and a multiple of 32 output channels
-# -- including Concatenate([UpSampling(x), skip]) in front of them -- run as implicit GEMMs on the f32 matrix cores with up-sampling,
-# concatenation, bias and activation folded in: one kernel instead of interpolate + cat + conv + epilogue, exact float32 with a fixed
-# summation order.  STARDIST_AMD_CONV=miopen switches them off (every layer through MIOpen, as before); the choice is read per call
-# so tests can compare both.
 def conv_mode():
-    """Which kernel family the 3x3 / 3x3x3 layers over 32-channel chunks run on (STARDIST_AMD_CONV, read per call):
-      'bf16x6' (default)  csrc/conv3x3_bf16.hip: every f32 product as six bf16 x bf16 MFMA products with f32 accumulation -- f32-accurate
-                          (layers and networks within 3e-6 of a float64 evaluation, the same as the exact kernel; same 1e-5 tests), 1.33x faster
+    """Which kernel the 3x3 / 3x3x3 layers over 32-channel chunks run on (STARDIST_AMD_CONV, read per call; force_conv_mode overrides):
+      'f16x3' (default)   csrc/conv3x3_f16.hip: every f32 product as three fp16 x fp16 MFMA products (two fp16 terms per operand, the
+                          cross terms in their own f32 accumulator) -- f32-accurate: layers and networks within 3e-6 of a float64
+                          evaluation, the same 1e-5 tests as the exact kernel.  An activation outside the fp16 range raises a device
+                          flag; the model then re-evaluates with 'bf16x6' (StarDistBase._net_forward).
+      'bf16x6'            csrc/conv3x3_bf16.hip: six bf16 x bf16 products per f32 product (three bf16 terms per operand); no range limit
       'hand' / 'f32'      csrc/conv3x3.hip: exact f32 MFMA kernel (one fma chain per output)
-      'miopen'            library kernels (A/B probes only; not deterministic across boxes)
     The one-channel first layer and the general kernel (csrc/conv_general.hip) are exact f32 in every mode."""
+    if _mode_override:
+        return _mode_override[-1]
     import os
-    m = os.environ.get("STARDIST_AMD_CONV", "bf16x6")
-    return "miopen" if m == "miopen" else ("hand" if m in ("hand", "f32") else "bf16x6")
+    m = os.environ.get("STARDIST_AMD_CONV", "f16x3")
+    return "hand" if m in ("hand", "f32") else (m if m in _CONV_MODES else "f16x3")
 
 
-def hand_conv_enabled():
-    return conv_mode() != "miopen"
+class force_conv_mode(object):
+    """context manager: `with force_conv_mode("bf16x6"): ...` (takes precedence over the environment variable)"""
+
+    def __init__(self, mode):
+        assert mode in _CONV_MODES, mode
+        self.mode = mode
+
+    def __enter__(self):
+        _mode_override.append(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _mode_override.pop()
+        return False
 
 
-# convolutions that could not be taken by a hand-written kernel in GPU inference (reason strings): parity tests assert this stays
-# empty for the configurations they pin, so a silent detour through library kernels cannot hide behind a green test
-library_fallbacks = []
+_range_flags = {}
+
+
+def range_flag(device):
+    """the device word the split-fp16 convolutions OR with 1 when an activation lies outside the fp16 range (one per device; cleared
+    and read by StarDistBase._net_forward around a forward pass)"""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    t = _range_flags.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=device)
+        _range_flags[key] = t
+    return t
+
+
+def _native_inference(x):
+    """the hand-written path applies: tensor on a HIP device, no autograd, no autocast"""
+    return x.is_cuda and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
+
+
+def _layer_desc(conv, srcs=None):
+    return "%s %s -> %d, kernel %s, stride %s%s" % (
+        type(conv).__name__, conv.in_channels if srcs is None else " + ".join(str(int(t.shape[1])) + ("(up)" if any(np.atleast_1d(u)) else "") for t, u in srcs),
+        conv.out_channels, tuple(conv.kernel_size), tuple(conv.stride),
+        "" if srcs is None else ", input %s" % (tuple(srcs[0][0].shape[2:]),))
 
 
 def _bn_fold(conv, bn):
@@ -157,10 +123,17 @@ def _bn_fold(conv, bn):
     return np.ascontiguousarray(w, np.float32), np.ascontiguousarray(b, np.float32)
 
 
+_FORM_PREFIX = {"conv3": "sd_conv3", "bf16x6": "sd_conv3_bf16x6", "f16x3": "sd_conv3_f16x3"}
+
+
+class _WeightRange(ValueError):
+    """a kernel with weights outside the fp16 range: the layer takes the bf16x6 form"""
+
+
 def _packed_conv_weights(conv, form="conv3", bn=None):
     """(packed kernel, bias) on the device for the native layer `form`: 'conv3' (sd_conv3_ndhwc_device), 'bf16x6'
-    (sd_conv3_bf16x6_ndhwc_device) or 'general' (sd_convg_ndhwc_device); an inference batch-norm layer behind the convolution is
-    folded in.  Cached per module (inference: invalidated when a parameter changes)."""
+    (sd_conv3_bf16x6_ndhwc_device), 'f16x3' (sd_conv3_f16x3_ndhwc_device) or 'general' (sd_convg_ndhwc_device); an inference batch-norm
+    layer behind the convolution is folded in.  Cached per module (inference: invalidated when a parameter changes)."""
     from ..lib import _native as N
     ver = lambda t: None if t is None else (t.data_ptr(), t._version)
     key = (ver(conv.weight), ver(conv.bias), str(conv.weight.device)) + \
@@ -180,16 +153,22 @@ def _packed_conv_weights(conv, form="conv3", bn=None):
             packed = np.zeros(n, np.float32)
             N.check(L.sd_convg_pack_weights_host(N.ptr(w), ci, co, kz, ky, kx, N.ptr(packed)))
         else:
-            prefix = "sd_conv3_bf16x6" if form == "bf16x6" else "sd_conv3"
+            prefix = _FORM_PREFIX[form]
             kz = 3 if w.ndim == 5 else 1
             n = int(getattr(L, prefix + "_packed_floats")(ci, co, kz))
             if n < 0:
                 raise ValueError("%s: unsupported channel counts %d -> %d" % (prefix, ci, co))
             packed = np.empty(n, np.float32)
-            N.check(getattr(L, prefix + "_pack_weights_host")(N.ptr(w), ci, co, kz, N.ptr(packed)))
+            rc = getattr(L, prefix + "_pack_weights_host")(N.ptr(w), ci, co, kz, N.ptr(packed))
+            if form == "f16x3" and rc == -2:
+                conv.__dict__[slot] = (key, None, None)
+                raise _WeightRange(L.sd_last_error().decode(errors="replace"))
+            N.check(rc)
         has_bias = conv.bias is not None or bn is not None
         cache = (key, torch.from_numpy(packed).to(conv.weight.device), torch.from_numpy(b).to(conv.weight.device) if has_bias else None)
         conv.__dict__[slot] = cache
+    if cache[1] is None:
+        raise _WeightRange("weights outside the fp16 range")
     return cache[1], cache[2]
 
 
@@ -238,15 +217,18 @@ def _general_conv(conv, x, kind, res=None, bn=None, tf_same=False):
     return out
 
 
+_MAX_CHUNK_CHANNELS = 512          # csrc/conv3x3_layout.h MAX_CHUNKS * 32
+
+
 def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False):
     """act(conv(cat(srcs, 1)) + bias (+ res)) by a hand-written kernel; srcs = [(tensor (1, C, *spatial) channels-last float32, up)] with
     up = per-axis tuple of 0/1 (or one int for all axes): 1 where the source has half the output resolution and the reference
     up-samples it (nearest, x2) first.  res: residual added before the activation (resnet_block's Add); bn: inference batch-norm layer
     between convolution and activation (folded into kernel and bias).  3x3(x3) stride-1 'same' layers over 32-channel chunks (and the
-    one-channel first layer) go to csrc/conv3x3.hip, everything else with one full-resolution source to csrc/conv_general.hip.
-    None when the layer is not covered."""
+    one-channel first layer) go to csrc/conv3x3*.hip, everything else with one full-resolution source to csrc/conv_general.hip.
+    None when the layer is not covered (the callers raise UnsupportedLayer)."""
     nd = 2 if isinstance(conv, nn.Conv2d) else (3 if isinstance(conv, nn.Conv3d) else 0)
-    if not (nd and kind in (0, 1) and hand_conv_enabled() and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
+    if not (nd and kind in (0, 1) and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
             and conv.groups == 1 and conv.weight.dtype == torch.float32 and 1 <= len(srcs) <= 2) or (bn is not None and bn.training):
         return None
     cl = torch.channels_last if nd == 2 else torch.channels_last_3d
@@ -264,7 +246,7 @@ def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False):
     if cs == [1]:
         ok = is3 and co % 4 == 0 and not any(ups[0]) and res is None
     else:
-        ok = is3 and all(c % 32 == 0 and c > 0 for c in cs) and sum(cs) <= 256 and co % 32 == 0
+        ok = is3 and all(c % 32 == 0 and c > 0 for c in cs) and sum(cs) <= _MAX_CHUNK_CHANNELS and co % 32 == 0
     if not ok:
         if len(srcs) == 1 and not any(ups[0]):
             return _general_conv(conv, srcs[0][0], kind, res, bn, tf_same)
@@ -276,57 +258,45 @@ def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False):
     from ..lib import _native as N
     # channels-last operands (a pooling layer may hand over a tensor in the default layout: one copy at its resolution)
     srcs = [(t if t.is_contiguous(memory_format=cl) and t.data_ptr() % 16 == 0 else t.clone(memory_format=cl), up) for t, up in srcs]
-    split = conv_mode() == "bf16x6" and cs != [1]
-    wp, bias = _packed_conv_weights(conv, "bf16x6" if split else "conv3", bn)
+    form = "conv3" if (cs == [1] or conv_mode() == "hand") else conv_mode()
+    if form == "f16x3":
+        try:
+            wp, bias = _packed_conv_weights(conv, form, bn)
+        except _WeightRange:
+            form = "bf16x6"
+    if form != "f16x3":
+        wp, bias = _packed_conv_weights(conv, form, bn)
     out = torch.empty((1, co) + shape, dtype=torch.float32, device=conv.weight.device, memory_format=cl)
     if res is not None and not (tuple(res.shape) == tuple(out.shape) and res.dtype == torch.float32 and res.is_contiguous(memory_format=cl)):
         return None
     D, H, W = ((1,) + shape) if nd == 2 else shape
     mask = lambda up: sum(b << k for k, b in enumerate(reversed(up)))                     # bit 0: x, 1: y, 2: z
     a, b = srcs[0][0], (srcs[1][0] if len(srcs) == 2 else None)
-    N.dcall(a, "sd_conv3_bf16x6_res_ndhwc_device" if split else "sd_conv3_res_ndhwc_device", ctypes.c_void_p(a.data_ptr()), cs[0], cs[0], mask(ups[0]),
+    args = [ctypes.c_void_p(a.data_ptr()), cs[0], cs[0], mask(ups[0]),
             ctypes.c_void_p(b.data_ptr()) if b is not None else None, cs[1] if b is not None else 0, cs[1] if b is not None else 0,
             mask(ups[1]) if b is not None else 0, D, H, W, 1 if nd == 2 else 3, ctypes.c_void_p(wp.data_ptr()),
             ctypes.c_void_p(bias.data_ptr()) if bias is not None else None, ctypes.c_void_p(res.data_ptr()) if res is not None else None,
-            co if res is not None else 0, co, kind, ctypes.c_void_p(out.data_ptr()))
+            co if res is not None else 0, co, kind, ctypes.c_void_p(out.data_ptr())]
+    if form == "f16x3":
+        args.append(ctypes.c_void_p(range_flag(a.device).data_ptr()))
+    N.dcall(a, _FORM_PREFIX[form] + "_res_ndhwc_device", *args)
     return out
 
 
 def _conv_bias_act(conv, x, kind):
-    """conv + bias + (0 linear | 1 relu) with the element-wise part done by the native one-pass kernel; None if not applicable"""
-    if not (x.is_cuda and conv.bias is not None and x.dtype == torch.float32 and not torch.is_grad_enabled()):
+    """conv + bias + (0 linear | 1 relu) of GPU inference by a hand-written kernel; None when the hand-written path does not apply
+    (CPU, autograd, autocast: the caller runs the plain modules); raises UnsupportedLayer for a layer no kernel covers"""
+    if not (_native_inference(x) and x.dtype == torch.float32):
         return None
-    if torch.is_autocast_enabled():
-        return None                      # reduced-precision autocast: the native epilogue is float32 only -> plain Sequential
-    from ..lib import _native as N
     y = _hand_conv(conv, [(x, 0)], kind)
-    if y is not None:
-        return y
-    if hand_conv_enabled():
-        library_fallbacks.append("%s %d->%d k%s s%s" % (type(conv).__name__, conv.in_channels, conv.out_channels, tuple(conv.kernel_size), tuple(conv.stride)))
-    y = _conv_nobias(conv, x)
-    if y.dtype != torch.float32:         # gate on the convolution OUTPUT (the kernel reads/writes 4 bytes per element)
-        y = y + conv.bias.to(y.dtype).view((1, y.shape[1]) + (1,) * (y.dim() - 2))
-        return torch.relu_(y) if kind == 1 else y
-    C = y.shape[1]
-    cl = torch.channels_last if y.dim() == 4 else torch.channels_last_3d
-    if y.is_contiguous(memory_format=cl):
-        n_outer, inner = y.numel() // C, 1
-    elif y.is_contiguous():
-        n_outer, inner = y.shape[0], y.numel() // (y.shape[0] * C)
-    else:
-        y = y + conv.bias.view((1, C) + (1,) * (y.dim() - 2))
-        return torch.relu_(y) if kind == 1 else y
-    with torch.cuda.device(y.device):
-        N.check(N.lib().sd_bias_act_device(ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(conv.bias.data_ptr()), n_outer, C, inner, kind,
-                                           N.current_stream(y.device)))
+    if y is None:
+        raise UnsupportedLayer(_layer_desc(conv, [(x, 0)]))
     return y
 
 
 class ConvAct(nn.Sequential):
-    """[conv, activation] with the Keras layer's parameter names.  On a HIP device in inference the bias add and the
-    (linear / relu) activation are done by one in-place pass of the native library (sd_bias_act_device) instead of two
-    framework element-wise kernels; everywhere else (CPU, training, other activations) it is the plain Sequential."""
+    """[conv, activation] (or [conv, batch-norm, activation]) with the Keras layer's parameter names.  GPU inference: one launch of a
+    hand-written kernel (bias, folded batch-norm and linear / relu activation in its epilogue); everywhere else the plain Sequential."""
 
     def parts(self):
         """(conv, batch-norm or None, kind) with kind 0 linear / 1 relu / -1 another activation"""
@@ -335,13 +305,12 @@ class ConvAct(nn.Sequential):
 
     def forward(self, x):
         conv, bn, kind = self.parts()
-        if bn is not None:                      # [conv, batch-norm, activation] (unet_batch_norm=True): folded into the hand-written layer
-            y = _hand_conv(conv, [(x, 0)], kind, bn=bn) if (x.is_cuda and kind >= 0) else None
-            if y is None and x.is_cuda and hand_conv_enabled() and not torch.is_grad_enabled() and not torch.is_autocast_enabled():
-                library_fallbacks.append("ConvAct+BN %d->%d" % (conv.in_channels, conv.out_channels))
-            return super().forward(x) if y is None else y
-        y = _conv_bias_act(conv, x, kind) if kind >= 0 else None
-        return super().forward(x) if y is None else y
+        if not (_native_inference(x) and x.dtype == torch.float32):
+            return super().forward(x)
+        y = _hand_conv(conv, [(x, 0)], kind, bn=bn) if kind >= 0 else None
+        if y is None:
+            raise UnsupportedLayer(_layer_desc(conv, [(x, 0)]) + ("" if kind >= 0 else ", activation %s" % type(self[-1]).__name__))
+        return y
 
 
 def _conv(nd, cin, cout, k, act="relu", bias=True, batch_norm=False):
@@ -358,14 +327,16 @@ def _conv(nd, cin, cout, k, act="relu", bias=True, batch_norm=False):
 
 
 def max_pool(x, pool):
-    """Keras MaxPooling ('valid', stride = pool).  GPU inference on channels-last float32 tensors: the native one-pass kernel
-    (sd_maxpool_ndhwc_device, 64-bit indexing, output channels-last) -- the framework's 3D pooling converts a channels-last tensor to
-    the default layout and back (three extra passes over the level) and indexes with 32 bits; everywhere else F.max_pool."""
+    """Keras MaxPooling ('valid', stride = pool).  GPU inference: the native one-pass channels-last kernel (sd_maxpool_ndhwc_device,
+    64-bit indexing); everywhere else F.max_pool."""
     nd = x.dim() - 2
     pool = tuple(int(p) for p in pool)
-    cl = torch.channels_last if nd == 2 else torch.channels_last_3d
-    if (x.is_cuda and nd in (2, 3) and x.shape[0] == 1 and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and hand_conv_enabled()
-            and not torch.is_grad_enabled() and not torch.is_autocast_enabled() and x.is_contiguous(memory_format=cl) and x.data_ptr() % 16 == 0):
+    if _native_inference(x):
+        cl = torch.channels_last if nd == 2 else torch.channels_last_3d
+        if not (nd in (2, 3) and x.shape[0] == 1 and x.dtype == torch.float32 and x.shape[1] % 4 == 0):
+            raise UnsupportedLayer("MaxPooling %s on %s %s" % (pool, x.dtype, tuple(x.shape)))
+        if not (x.is_contiguous(memory_format=cl) and x.data_ptr() % 16 == 0):
+            x = x.clone(memory_format=cl)
         from ..lib import _native as N
         S = (1,) * (3 - nd) + tuple(int(v) for v in x.shape[2:])
         P = (1,) * (3 - nd) + pool
@@ -417,21 +388,19 @@ class UNetBlock(nn.Module):
             x = max_pool(x, self.pool)
         x = self.middle(x)
         for blk, skip in zip(self.up, reversed(skips)):
-            first = blk[0]
-            y, kind, bn = None, -1, None
-            if isinstance(first, ConvAct):
+            if _native_inference(x):
+                # UpSampling + Concatenate + Conv (+ BN) + bias + activation as ONE launch: the up-sampled and the concatenated tensors
+                # of the reference's graph are never written
+                first = blk[0]
                 conv0, bn, kind = first.parts()
-                if all(p in (1, 2) for p in self.pool) and kind >= 0 and x.is_cuda:
-                    y = _hand_conv(conv0, [(x, tuple(p == 2 for p in self.pool)), (skip, 0)], kind, bn=bn)   # UpSampling + Concatenate + Conv (+ BN) + bias + act
-                    if y is not None:
-                        x = blk[1:](y)
-                        continue
-                    if hand_conv_enabled() and not torch.is_grad_enabled() and not torch.is_autocast_enabled():
-                        library_fallbacks.append("up-level %d->%d" % (conv0.in_channels, conv0.out_channels))
+                srcs = [(x, tuple(p == 2 for p in self.pool)), (skip, 0)]
+                y = _hand_conv(conv0, srcs, kind, bn=bn) if (all(p in (1, 2) for p in self.pool) and kind >= 0) else None
+                if y is None:
+                    raise UnsupportedLayer("up-level " + _layer_desc(conv0, srcs) + ", pool %s" % (self.pool,))
+                x = blk[1:](y)
+                continue
             x = F.interpolate(x, scale_factor=tuple(float(p) for p in self.pool), mode="nearest")
-            if kind >= 0 and bn is None:
-                y = _conv_cat_bias_act(first[0], x, skip, kind)
-            x = blk(torch.cat([x, skip], dim=1)) if y is None else blk[1:](y)
+            x = blk(torch.cat([x, skip], dim=1))
         return x
 
 
@@ -468,38 +437,32 @@ class ResNetBlock(nn.Module):
 
     def _forward_hand(self, x):
         """the block on the hand-written kernels: strided first convolution (TensorFlow 'same' padding) with its activation, body
-        convolutions, the strided 1x1 projection, and Add + Activation folded into the last convolution's epilogue; None if a layer is
-        not covered"""
+        convolutions, the strided 1x1 projection, and Add + Activation folded into the last convolution's epilogue"""
         kind = lambda a: 0 if isinstance(a, nn.Identity) else (1 if isinstance(a, nn.ReLU) else -1)
         layers = list(self.body)
-        if not (x.is_cuda and hand_conv_enabled() and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
-                and kind(layers[0]) >= 0 and kind(self.act) >= 0):
-            return None
-        y = _hand_conv(self.first, [(x, 0)], kind(layers[0]), tf_same=True)
-        if y is None:
-            return None
+        if not (kind(layers[0]) >= 0 and kind(self.act) >= 0):
+            raise UnsupportedLayer("resnet_block activation %s" % type(self.act).__name__)
+
+        def need(y, conv, src):
+            if y is None:
+                raise UnsupportedLayer("resnet_block " + _layer_desc(conv, [(src, 0)]))
+            return y
+        y = need(_hand_conv(self.first, [(x, 0)], kind(layers[0]), tf_same=True), self.first, x)
         sc = x
         if self.proj is not None:
-            sc = _hand_conv(self.proj, [(x, 0)], 0, tf_same=True)
-            if sc is None:
-                return None
+            sc = need(_hand_conv(self.proj, [(x, 0)], 0, tf_same=True), self.proj, x)
         convs = [(layers[k], layers[k + 1] if k + 1 < len(layers) else None) for k in range(1, len(layers), 2)]
         for conv, act in convs:
             last = act is None
             k = kind(self.act) if last else kind(act)
             if k < 0:
-                return None
-            y = _hand_conv(conv, [(y, 0)], k, res=sc if last else None)
-            if y is None:
-                return None
+                raise UnsupportedLayer("resnet_block activation %s" % type(act).__name__)
+            y = need(_hand_conv(conv, [(y, 0)], k, res=sc if last else None), conv, y)
         return y
 
     def forward(self, x):
-        y = self._forward_hand(x)
-        if y is not None:
-            return y
-        if x.is_cuda and hand_conv_enabled() and not torch.is_grad_enabled() and not torch.is_autocast_enabled():
-            library_fallbacks.append("ResNetBlock %d" % self.first.in_channels)
+        if _native_inference(x):
+            return self._forward_hand(x)
         y = self.body(self.first(self._same_pad(x)))
         if self.proj is not None:
             x = self.proj(x)
@@ -561,6 +524,8 @@ class StarDistNet(nn.Module):
             self.prob_class = Conv(cf, cfg.n_classes + 1, (1,) * nd)
 
     def _heads(self, base):
+        """the plain graph: features conv, prob (Conv 1x1 + sigmoid), dist (Conv 1x1)[, class head] -- on the GPU every convolution is
+        a hand-written kernel (64-bit indexing: no slabs whatever the volume), elsewhere the torch modules"""
         f = self.features(base)
         p = _conv_bias_act(self.prob, f, 0)
         prob = torch.sigmoid_(p) if p is not None else torch.sigmoid(self.prob(f))
@@ -577,47 +542,19 @@ class StarDistNet(nn.Module):
         y = _conv_bias_act(self.prob_class, f, 0)
         return torch.softmax(y if y is not None else self.prob_class(f), dim=1)
 
-    # MIOpen convolutions index with int32: a tensor of >= 2**31 elements (e.g. 128 feature channels on a 256^3 volume)
-    # silently drops PyTorch to its im2col+GEMM fallback, ~3x slower.  The head (features conv + 1x1 output convs) is
-    # therefore run on slabs along the first spatial axis, with a halo of the features kernel's radius.
-    _INDEX_LIMIT = 2 ** 31 - 1
-    _slab_on_cpu = False                      # tests only
-
-    def _heads_slabbed(self, base):
-        widest = max([base.shape[1], self.prob.in_channels, self.dist.out_channels] +
-                     ([self.prob_class.out_channels] if self.n_classes is not None else []))
-        per_plane = base.shape[0] * widest * int(np.prod(base.shape[3:]))
-        D = base.shape[2]
-        if not (base.is_cuda or self._slab_on_cpu) or per_plane * D <= self._INDEX_LIMIT:
-            return self._heads(base)
-        halo = self.features[0].kernel_size[0] // 2 if isinstance(self.features, nn.Sequential) else 0
-        cz = max(1, (self._INDEX_LIMIT // per_plane) - 2 * halo)
-        outs = None
-        for z0 in range(0, D, cz):
-            z1 = min(D, z0 + cz)
-            a, b = max(0, z0 - halo), min(D, z1 + halo)
-            part = self._heads(base[:, :, a:b])
-            if outs is None:       # same memory format as the slabs, so that every slab lands as one contiguous block
-                cl = torch.channels_last_3d if base.dim() == 5 else torch.channels_last
-                outs = [torch.empty(p.shape[:2] + (D,) + p.shape[3:], dtype=p.dtype, device=p.device,
-                                    memory_format=cl if p.is_contiguous(memory_format=cl) else torch.contiguous_format) for p in part]
-            for o, p in zip(outs, part):
-                o[:, :, z0:z1] = p[:, :, z0 - a:z0 - a + (z1 - z0)]
-        return tuple(outs)
-
     # ---- fused heads (GPU inference) ----------------------------------------------------------------------------------------
-    # features conv -> ONE pass doing bias + activation + the probability head (sd_bias_act_dot_device) -> distance head as an fp32-MFMA
+    # features conv -> ONE pass doing the probability head (sd_bias_act_dot_device) -> distance head as an fp32-MFMA
     # GEMM over the rows asked for (sd_head_rows_device): every pixel for the dense prediction, or -- sparse_head=True -- none here:
     # the caller selects the candidate pixels from the probabilities and evaluates the distance head on those rows only
     # (StarDistBase._predict_sparse_generator), so the dense n_rays-channel tensor of the reference's predict_sparse
     # (base.py:553-610: full prediction, then masking) is never written.  Both paths run the same kernels with a fixed summation
     # order per output, hence agree bit for bit.
-    fused_heads = True                        # False: plain module path on the GPU as well (statistics hooks, A/B timing)
+    fused_heads = True                        # False: plain graph on the GPU as well (statistics hooks, A/B timing)
 
     def _fused_heads_ok(self, base):
         f = self.features
-        if not (self.fused_heads and base.is_cuda and base.shape[0] == 1 and base.dtype == torch.float32 and not torch.is_grad_enabled()
-                and not torch.is_autocast_enabled() and isinstance(f, ConvAct) and len(f) == 2 and f[0].bias is not None):
+        if not (self.fused_heads and _native_inference(base) and base.shape[0] == 1 and base.dtype == torch.float32
+                and isinstance(f, ConvAct) and len(f) == 2 and f[0].bias is not None):
             return False
         kind = 0 if isinstance(f[1], nn.Identity) else (1 if isinstance(f[1], nn.ReLU) else -1)
         C, R = f[0].out_channels, self.dist.out_channels
@@ -643,36 +580,17 @@ class StarDistNet(nn.Module):
         conv, act = self.features[0], self.features[1]
         kind = 1 if isinstance(act, nn.ReLU) else 0
         nd = base.dim() - 2
-        cl = torch.channels_last if nd == 2 else torch.channels_last_3d
         S = tuple(base.shape[2:])
-        D, plane = S[0], int(np.prod(S[1:]))
         C = conv.out_channels
         wp = self.prob.weight.detach().reshape(-1).contiguous()
         bp = self.prob.bias
         prob = torch.empty((1, 1) + S, dtype=torch.float32, device=base.device)
-        per_plane = max(base.shape[1], C) * plane
-        y = _hand_conv(conv, [(base, 0)], kind)               # features conv with bias + activation fused (64-bit indexing: no slabs)
-        if y is not None:                                     # ... then the probability head alone: one read of the features
-            N.dcall(y, "sd_bias_act_dot_device", ctypes.c_void_p(y.data_ptr()), None, None, D * plane, C, 0, ctypes.c_void_p(wp.data_ptr()),
-                    ctypes.c_void_p(bp.data_ptr() if bp is not None else None), 1, ctypes.c_void_p(prob.data_ptr()))
-            feat, slabs = y, []
-        elif per_plane * D <= self._INDEX_LIMIT:
-            slabs, feat = [(0, D, 0, D)], None
-        else:                                   # MIOpen indexes with int32: features conv on z-slabs with a halo (see _heads_slabbed)
-            halo = conv.kernel_size[0] // 2
-            cz = max(1, (self._INDEX_LIMIT // per_plane) - 2 * halo)
-            slabs = [(z0, min(D, z0 + cz), max(0, z0 - halo), min(D, min(D, z0 + cz) + halo)) for z0 in range(0, D, cz)]
-            feat = torch.empty((1, C) + S, dtype=torch.float32, device=base.device).contiguous(memory_format=cl)
-        for z0, z1, a, b in slabs:
-            y = _conv_nobias(conv, base[:, :, a:b] if (a, b) != (0, D) else base)
-            if not (y.dtype == torch.float32 and y.is_contiguous(memory_format=cl)):
-                y = y.float().contiguous(memory_format=cl)
-            if feat is None:
-                feat = y
-            src = y.data_ptr() + (z0 - a) * plane * C * 4
-            N.dcall(y, "sd_bias_act_dot_device", ctypes.c_void_p(src), ctypes.c_void_p(feat.data_ptr() + z0 * plane * C * 4),
-                    ctypes.c_void_p(conv.bias.data_ptr()), (z1 - z0) * plane, C, kind, ctypes.c_void_p(wp.data_ptr()),
-                    ctypes.c_void_p(bp.data_ptr() if bp is not None else None), 1, ctypes.c_void_p(prob.data_ptr() + z0 * plane * 4))
+        feat = _hand_conv(conv, [(base, 0)], kind)            # features conv with bias + activation fused (64-bit indexing: no slabs)
+        if feat is None:
+            raise UnsupportedLayer("features " + _layer_desc(conv, [(base, 0)]))
+        # ... then the probability head alone: one read of the features
+        N.dcall(feat, "sd_bias_act_dot_device", ctypes.c_void_p(feat.data_ptr()), None, None, int(np.prod(S)), C, 0, ctypes.c_void_p(wp.data_ptr()),
+                ctypes.c_void_p(bp.data_ptr() if bp is not None else None), 1, ctypes.c_void_p(prob.data_ptr()))
         if sparse_head:
             return prob, feat
         R = self.dist.out_channels
@@ -691,30 +609,9 @@ class StarDistNet(nn.Module):
             if sparse_head:
                 self.head_mode = "sparse"
             if self.n_classes is not None:
-                out = tuple(out) + (self._class_head_slabbed(base),)
+                out = tuple(out) + (self._class_head(base),)
             return tuple(out)
-        return self._heads_slabbed(base)
-
-    def _class_head_slabbed(self, base):
-        head = self._class_head
-        if base.is_cuda and hand_conv_enabled() and not torch.is_grad_enabled() and not torch.is_autocast_enabled():
-            return head(base)                       # hand-written kernels index with 64 bits: no slabs
-        widest = max(base.shape[1], self.prob_class.in_channels, self.prob_class.out_channels)
-        per_plane = base.shape[0] * widest * int(np.prod(base.shape[3:]))
-        D = base.shape[2]
-        if per_plane * D <= self._INDEX_LIMIT:
-            return head(base)
-        halo = self.features_class[0].kernel_size[0] // 2 if isinstance(self.features_class, nn.Sequential) else 0
-        cz = max(1, (self._INDEX_LIMIT // per_plane) - 2 * halo)
-        out = None
-        for z0 in range(0, D, cz):
-            z1 = min(D, z0 + cz)
-            a, b = max(0, z0 - halo), min(D, z1 + halo)
-            part = head(base[:, :, a:b])
-            if out is None:
-                out = torch.empty(part.shape[:2] + (D,) + part.shape[3:], dtype=part.dtype, device=part.device)
-            out[:, :, z0:z1] = part[:, :, z0 - a:z0 - a + (z1 - z0)]
-        return out
+        return self._heads(base)
 
 
 def init_he_normal_(net, seed=0):
@@ -732,12 +629,15 @@ def init_he_normal_(net, seed=0):
 
 
 def conv_macs_per_input_pixel(net, cfg):
-    """analytic multiply-accumulates per INPUT pixel of the conv stack (for the MFMA roofline)."""
+    """analytic multiply-accumulates per INPUT pixel of the conv stack (for the MFMA roofline): counted by forward hooks on a CPU copy
+    of the modules (the GPU inference path does not go through the modules' forward)."""
+    import copy
     nd = cfg.n_dim
     size = 64 if nd == 2 else 32
     shape = tuple(size * g for g in cfg.grid)
     macs = [0.0]
     hooks = []
+    net = copy.deepcopy(net).cpu()
 
     def hook(m, inp, out):
         k = float(np.prod(m.kernel_size))
@@ -745,9 +645,8 @@ def conv_macs_per_input_pixel(net, cfg):
     for m in net.modules():
         if isinstance(m, (nn.Conv2d, nn.Conv3d)):
             hooks.append(m.register_forward_hook(hook))
-    dev = next(net.parameters()).device
-    with torch.enable_grad():      # the plain module path (the fused inference epilogue bypasses the Conv modules' hooks)
-        net(torch.zeros((1, cfg.n_channel_in) + shape, device=dev))
+    with torch.no_grad():
+        net(torch.zeros((1, cfg.n_channel_in) + shape))
     for h in hooks:
         h.remove()
     return macs[0] / float(np.prod(shape))

@@ -27,6 +27,11 @@ def recorder(monkeypatch):
     gsrc = inspect.getsource(U._general_conv)
     assert "t.is_cuda and " in src and "x.is_cuda and " in gsrc
     ns = dict(U.__dict__)
+
+    class _Flag(object):
+        def data_ptr(self):
+            return 12345
+    ns["range_flag"] = lambda device: _Flag()
     exec(gsrc.replace("x.is_cuda and ", ""), ns)
     exec(src.replace("t.is_cuda and ", ""), ns)
     return ns["_hand_conv"], calls
@@ -125,11 +130,9 @@ def test_dispatch_rejections_and_modes(recorder, monkeypatch):
         assert hand(torch.nn.Conv2d(32, 32, 3, padding=1, dilation=2), [(x32, 0)], 1) is None     # dilated
         assert hand(torch.nn.Conv2d(32, 32, 3, padding=1), [(x32, 0)], -1) is None                # activation it does not fuse
         assert hand(torch.nn.Conv2d(64, 32, 3, padding=1), [(x32, 1), (_t((1, 32, 8, 8), cl2), 0)], 1) is None   # shapes do not match after x2
-        n0 = len(calls)
-        monkeypatch.setenv("STARDIST_AMD_CONV", "miopen")
-        assert hand(torch.nn.Conv2d(32, 32, 3, padding=1), [(x32, 0)], 1) is None and len(calls) == n0
-        for mode, entry in (("bf16x6", "sd_conv3_bf16x6_res_ndhwc_device"), (None, "sd_conv3_bf16x6_res_ndhwc_device"), ("hand", "sd_conv3_res_ndhwc_device"),
-                            ("f32", "sd_conv3_res_ndhwc_device")):               # default = the split-bf16 kernel
+        for mode, entry in (("bf16x6", "sd_conv3_bf16x6_res_ndhwc_device"), (None, "sd_conv3_f16x3_res_ndhwc_device"), ("hand", "sd_conv3_res_ndhwc_device"),
+                            ("f32", "sd_conv3_res_ndhwc_device"), ("f16x3", "sd_conv3_f16x3_res_ndhwc_device"),
+                            ("miopen", "sd_conv3_f16x3_res_ndhwc_device")):      # default = the split-fp16 kernel; there is no library mode
             if mode is None:
                 monkeypatch.delenv("STARDIST_AMD_CONV", raising=False)
             else:
@@ -137,6 +140,16 @@ def test_dispatch_rejections_and_modes(recorder, monkeypatch):
             assert hand(torch.nn.Conv2d(32, 32, 3, padding=1), [(x32, 0)], 1) is not None and calls[-1][0] == entry, mode
         monkeypatch.setenv("STARDIST_AMD_CONV", "bf16x6")
         assert hand(torch.nn.Conv2d(1, 32, 3, padding=1), [(_t((1, 1, 8, 8), cl2), 0)], 1) is not None and calls[-1][0] == "sd_conv3_res_ndhwc_device"
+        # the split-fp16 form: the range-flag pointer rides in front of the stream; weights beyond the fp16 range -> the bf16x6 form
+        monkeypatch.delenv("STARDIST_AMD_CONV", raising=False)
+        conv = torch.nn.Conv2d(32, 32, 3, padding=1)
+        assert hand(conv, [(x32, 0)], 1) is not None and calls[-1][0] == "sd_conv3_f16x3_res_ndhwc_device" and calls[-1][1][-1] == 12345
+        conv.weight[0, 0, 0, 0] = 1e5
+        assert hand(conv, [(x32, 0)], 1) is not None and calls[-1][0] == "sd_conv3_bf16x6_res_ndhwc_device"
+        from stardist_amd.models import unet as U
+        with U.force_conv_mode("hand"):
+            assert U.conv_mode() == "hand"
+        assert U.conv_mode() == "f16x3"
     with torch.enable_grad():
         monkeypatch.delenv("STARDIST_AMD_CONV", raising=False)
         assert hand(torch.nn.Conv2d(32, 32, 3, padding=1), [(x32, 0)], 1) is None                 # training: plain modules
@@ -162,3 +175,35 @@ def test_split_weight_packing_roundtrip():
         want = np.transpose(w6, (0, 2, 6, 7, 8, 3, 4, 1, 5)).reshape(rec.shape)                    # g, (chunk, z), dy, dx, block, h, cout, j
         assert np.abs(rec - want).max() <= np.abs(want).max() * 2.0 ** -23
     assert l.sd_conv3_bf16x6_packed_floats(1, 32, 1) == -1
+
+
+def test_split_fp16_weight_packing_roundtrip():
+    """the split-fp16 packer of the C ABI: hi + lo' * 2^-11 of every packed weight reproduces the f32 weight to <= 2^-21 relative at the
+    position the kernel reads it from (conv3x3_layout.h: [group][unit][dy][dx][block][plane][h][cout][8]); hi is numpy's float16(w)
+    (round to nearest even, subnormals, overflow to infinity); weights beyond the fp16 range are reported with -2"""
+    from stardist_amd.lib import _native as N
+    l = N.lib()
+    rs = np.random.RandomState(2)
+    for ci, co, kz in ((32, 32, 1), (64, 64, 3), (512, 32, 1)):
+        w = (rs.randn(*((co, ci) + ((3, 3, 3) if kz == 3 else (3, 3)))) * np.exp(rs.uniform(-12, 3, 1))).astype(np.float32)
+        w.reshape(-1)[:7] = [0.0, 6.1e-5, 5.9e-8, 3e-8, 65504.0, -1.0, 2.0 ** -14]
+        n = l.sd_conv3_f16x3_packed_floats(ci, co, kz)
+        assert n == co * ci * 9 * kz * 2 * 2 // 4 + 4
+        out = np.empty(n, np.float32)
+        N.check(l.sd_conv3_f16x3_pack_weights_host(N.ptr(w), ci, co, kz, N.ptr(out)))
+        assert not out[-4:].any()
+        f16 = out[:-4].view(np.float16).reshape(co // 32, (ci // 32) * kz, 3, 3, 2, 2, 2, 32, 8)   # g, unit, dy, dx, block, plane, h, cout, j
+        w6 = w.reshape(co // 32, 32, ci // 32, 2, 2, 8, kz, 3, 3)                                   # g, cout, chunk, block, h, j, z, dy, dx
+        want = np.transpose(w6, (0, 2, 6, 7, 8, 3, 4, 1, 5)).reshape(f16[:, :, :, :, :, 0].shape)   # g, (chunk, z), dy, dx, block, h, cout, j
+        hi, lo = f16[:, :, :, :, :, 0], f16[:, :, :, :, :, 1]
+        assert np.array_equal(hi.view(np.uint16), want.astype(np.float16).view(np.uint16))
+        rem = (want - hi.astype(np.float32)) * np.float32(2048.0)
+        assert np.array_equal(lo.view(np.uint16), rem.astype(np.float16).view(np.uint16))
+        rec = hi.astype(np.float64) + lo.astype(np.float64) / 2048.0
+        big = np.abs(want) >= 2.0 ** -14
+        assert (np.abs(rec - want)[big] <= np.abs(want)[big] * 2.0 ** -21).all()
+        assert np.abs(rec - want).max() <= max(np.abs(want).max() * 2.0 ** -21, 2.0 ** -35)
+    w = np.zeros((32, 32, 3, 3), np.float32); w[3, 5, 1, 1] = 70000.0
+    out = np.empty(l.sd_conv3_f16x3_packed_floats(32, 32, 1), np.float32)
+    assert l.sd_conv3_f16x3_pack_weights_host(N.ptr(w), 32, 32, 1, N.ptr(out)) == -2 and b"fp16 range" in l.sd_last_error()
+    assert l.sd_conv3_f16x3_packed_floats(1, 32, 1) == -1 and l.sd_conv3_f16x3_packed_floats(544, 32, 1) == -1

@@ -25,10 +25,20 @@ def test_conv_bf16_layout_emulation(tmp_path):
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
 
 
+def test_conv_f16_layout_emulation(tmp_path):
+    """the split-fp16 kernel (the default): conflict-free LDS stores and A-operand reads with the two-plane tile, the buffer-load offset
+    rule on interior and border tiles, the f32 -> 2 x fp16 split, the weight packer, and a whole layer through the LDS layouts with the
+    three products in two accumulators vs float64"""
+    exe = str(tmp_path / "conv_f16_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "host", "conv_f16_check.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
 def test_pack_weights_abi():
     from stardist_amd.lib import _native as N
     l = N.lib()
-    assert l.sd_conv3_packed_floats(288, 32, 1) == -1 and l.sd_conv3_packed_floats(32, 48, 1) == -1 and l.sd_conv3_packed_floats(1, 32, 1) == 288
+    assert l.sd_conv3_packed_floats(544, 32, 1) == -1 and l.sd_conv3_packed_floats(300, 32, 1) == -1 and l.sd_conv3_packed_floats(32, 48, 1) == -1 and l.sd_conv3_packed_floats(1, 32, 1) == 288
     assert l.sd_conv3_packed_floats(32, 32, 2) == -1 and l.sd_conv3_packed_floats(1, 32, 3) == 864
     rs = np.random.RandomState(0)
     for ci, co, kz in ((32, 32, 1), (32, 64, 1), (64, 128, 1), (256, 32, 1), (32, 32, 3), (64, 64, 3)):

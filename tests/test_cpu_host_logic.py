@@ -134,25 +134,6 @@ def test_3d_models_build_and_predict_on_cpu():
         assert (d >= 1e-3).all() and ((p > 0) & (p < 1)).all()
 
 
-def test_network_head_slabs_equal_whole_volume():
-    """the head is run on z-slabs with a halo when a tensor would exceed MIOpen's int32 indexing: same result"""
-    import torch
-    from stardist_amd.models.config import Config3D
-    from stardist_amd.models.unet import StarDistNet, init_he_normal_
-    from stardist_amd.rays3d import Rays_GoldenSpiral
-    cfg = Config3D(rays=Rays_GoldenSpiral(16), n_channel_in=1, unet_n_depth=1, unet_n_filter_base=4, net_conv_after_unet=8)
-    net = StarDistNet(cfg); init_he_normal_(net, 0); net.eval()
-    x = torch.randn(1, 1, 24, 16, 16)
-    with torch.no_grad():
-        ref = net(x)
-        net._slab_on_cpu = True
-        net._INDEX_LIMIT = 16 * 16 * 16 * 5          # forces 5 slabs of 3 planes + halo
-        out = net(x)
-    assert len(ref) == len(out)
-    for a, b in zip(ref, out):
-        assert a.shape == b.shape and torch.equal(a, b)
-
-
 def test_export_to_obj_file3D_equals_reference_text(tmp_path):
     """geom3d.export_to_obj_file3D against the text produced by the reference's own function (tests/golden/make_export_golden.py)"""
     import os
@@ -231,19 +212,6 @@ def test_load_weights_npz_matches_heads_by_name(tmp_path):
     np.savez(path, **bad)
     with pytest.raises(ValueError):
         dst.load_weights_npz(path)
-
-
-@pytest.mark.parametrize("nd", [2, 3])
-def test_gemm_form_of_small_convolutions_equals_conv(nd):
-    """the repeatable GEMM form used for the small deep layers on the GPU (unet.py _gemm_conv) is the same convolution"""
-    import torch
-    import torch.nn.functional as F
-    from stardist_amd.models.unet import _gemm_conv
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn((2, 5) + (7, 9, 6)[:nd], generator=g)
-    w = torch.randn((4, 5) + (3, 3, 3)[:nd], generator=g)
-    ref = (F.conv2d if nd == 2 else F.conv3d)(x, w, padding=1)
-    assert torch.allclose(_gemm_conv(x, w), ref, atol=1e-5)
 
 
 def test_unet_batch_norm_matches_keras_semantics_and_round_trips(tmp_path):

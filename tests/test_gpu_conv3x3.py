@@ -33,18 +33,26 @@ CASES = [  # (spatial shape, [(channels, up)], c_out)
     ((256, 512), [(32, 0)], 128), ((32, 64), [(128, 1), (128, 0)], 128), ((24, 40), [(128, 0)], 256), ((16, 32), [(256, 0)], 128),
     ((12, 20, 36), [(32, 0)], 32), ((6, 16, 40), [(1, 0)], 32), ((8, 24, 64), [(32, 1), (32, 0)], 32), ((10, 16, 32), [(64, 0)], 64),
     ((4, 8, 32), [(64, 1), (64, 0)], 64), ((8, 16, 32), [(32, (0, 1, 1)), (32, 0)], 32), ((32, 64, 64), [(32, 0)], 128),
-    ((6, 10, 34), [(64, 0)], 128),
+    ((6, 10, 34), [(64, 0)], 128), ((16, 32), [(256, 1), (256, 0)], 256), ((4, 8, 32), [(256, 1), (256, 0)], 256),
 ]
 
 
 @pytest.mark.parametrize("shape,chans,c_out", CASES)
 @pytest.mark.parametrize("kind", [0, 1])
-@pytest.mark.parametrize("mode", ["hand", "bf16x6"])
+@pytest.mark.parametrize("mode", ["hand", "bf16x6", "f16x3", "f16x3-1wg"])
 def test_conv3_matches_float64(shape, chans, c_out, kind, mode, monkeypatch):
-    """mode 'hand': the exact f32-MFMA kernel (default path); 'bf16x6': the opt-in split-bf16 kernel (six bf16 MFMAs per product)"""
+    """mode 'hand': the exact f32-MFMA kernel; 'bf16x6': six bf16 MFMAs per product; 'f16x3': the default split-fp16 kernel (three fp16
+    MFMAs per product, two workgroups per CU); 'f16x3-1wg': the same kernel's one-workgroup-per-CU instance"""
     import torch
-    if mode == "bf16x6" and chans[0][0] == 1:
-        pytest.skip("the one-channel first layer has no split-bf16 form")
+    if mode != "hand" and chans[0][0] == 1:
+        pytest.skip("the one-channel first layer has no split form")
+    if mode == "f16x3-1wg":
+        from stardist_amd.lib import _native as N
+        N.check(N.lib().sd_set_option(b"conv_f16_workgroups_per_cu", 1))
+        mode = "f16x3"
+        request_restore = True
+    else:
+        request_restore = False
     monkeypatch.setenv("STARDIST_AMD_CONV", mode)
     from stardist_amd.models import unet as U
     dev = torch.device("cuda:0")
@@ -62,18 +70,27 @@ def test_conv3_matches_float64(shape, chans, c_out, kind, mode, monkeypatch):
         upt = up if isinstance(up, tuple) else (up,) * nd
         t = torch.randn((1, c) + tuple(s >> u for s, u in zip(shape, upt)), generator=g).to(dev).contiguous(memory_format=cl)
         srcs.append((t, upt))
-    with torch.no_grad():
-        y = U._hand_conv(conv, srcs, kind)
-        assert y is not None, "layer not taken by the hand-written kernel"
-        y2 = U._hand_conv(conv, srcs, kind)
-    torch.cuda.synchronize()
+    try:
+        with torch.no_grad():
+            if mode == "f16x3":
+                U.range_flag(dev).zero_()
+            y = U._hand_conv(conv, srcs, kind)
+            assert y is not None, "layer not taken by the hand-written kernel"
+            y2 = U._hand_conv(conv, srcs, kind)
+        torch.cuda.synchronize()
+    finally:
+        if request_restore:
+            from stardist_amd.lib import _native as N
+            N.check(N.lib().sd_set_option(b"conv_f16_workgroups_per_cu", 2))
+    if mode == "f16x3":
+        assert int(U.range_flag(dev).item()) == 0
     assert tuple(y.shape) == (1, c_out) + tuple(shape) and y.is_contiguous(memory_format=cl)
     assert torch.equal(y, y2), "not repeatable"
     ref = _ref(srcs, conv, kind)
     err = float((y.cpu().double() - ref).abs().max())
     scale = max(1.0, float(ref.abs().max()))
     print("conv3 %s %s %s c_out %d kind %d: max err / scale = %.3g" % (mode, shape, chans, c_out, kind, err / scale))
-    assert err <= 1e-5 * scale, (err, scale)       # the same bar for the exact-f32 and the split-bf16 kernel
+    assert err <= 1e-5 * scale, (err, scale)       # the same bar for the exact-f32 and the split kernels
 
 
 def test_layout_conversion_and_refusals():
@@ -151,6 +168,44 @@ def test_general_and_residual_layers_match_float64(nd, ci, co, k, stride, S, tf_
     assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err
 
 
+def test_split_fp16_range_flag_and_fallback():
+    """an activation beyond the fp16 range sets the device flag (the layer's output is then not valid); StarDistBase._net_forward
+    re-evaluates with the bf16x6 form and pins it: the prediction equals the bf16x6 prediction"""
+    import torch
+    import warnings
+    from stardist_amd.models import unet as U
+    from stardist_amd.models import Config2D, StarDist2D
+    dev = torch.device("cuda:0")
+    conv = torch.nn.Conv2d(32, 32, 3, padding=1).to(dev)
+    x = torch.randn(1, 32, 40, 70, device=dev).contiguous(memory_format=torch.channels_last)
+    flag = U.range_flag(dev)
+    with torch.no_grad(), U.force_conv_mode("f16x3"):
+        flag.zero_()
+        U._hand_conv(conv, [(x, 0)], 1)
+        assert int(flag.item()) == 0
+        x[0, 7, 33, 69] = 7e4
+        U._hand_conv(conv, [(x, 0)], 1)
+        assert int(flag.item()) == 1
+        flag.zero_()
+        x[0, 7, 33, 69] = float("inf")
+        U._hand_conv(conv, [(x, 0)], 1)
+        assert int(flag.item()) == 1
+        flag.zero_()
+    img = np.random.RandomState(0).rand(96, 128).astype(np.float32)
+    img[40, 50] = 3e7                     # a hot pixel the normaliser is told to keep
+    m = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
+    with U.force_conv_mode("bf16x6"):
+        want = m.predict(img)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = m.predict(img)
+    if m.__dict__.get("_conv_mode_pin") == "bf16x6":          # the flag tripped (depends on the seeded weights' gain): results must be the bf16 ones
+        assert any("fp16 range" in str(x.message) for x in w)
+        assert all(np.array_equal(a, b) for a, b in zip(want, got))
+    else:
+        assert all(np.isfinite(a).all() for a in got)
+
+
 def test_batch_norm_layer_folded_matches_float64():
     """csbdeep conv_block with batch_norm=True: Conv -> BatchNormalization (moving statistics) -> Activation, folded into the
     hand-written layer's kernel and bias"""
@@ -167,7 +222,5 @@ def test_batch_norm_layer_folded_matches_float64():
     with torch.no_grad():
         ref = blk.double()(x.double())
         blk = blk.float().to(dev)
-        del U.library_fallbacks[:]
         y = blk(x.to(dev).contiguous(memory_format=torch.channels_last))
-    assert not U.library_fallbacks, U.library_fallbacks
     assert float((y.cpu().double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))

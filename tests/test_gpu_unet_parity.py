@@ -2,7 +2,7 @@
 in a HIP graph) against the SAME module evaluated on the CPU in float32 and float64 -- the <=1e-5 bar of the north star on
 probabilities and distances -- and run-to-run / process-to-process determinism (so that survivor indices are reproducible end to end).
 Topologies: default U-Nets, grid (2,2) (2D_demo / 2D_versatile_fluo), 3 input channels (2D_versatile_he), batch-norm, multi-class
-head, ResNet backbone (3D_demo) -- with the default split-bf16 convolution kernel and with the exact-f32 kernel.
+head, depth 4, ResNet backbone (3D_demo) -- with the default split-fp16 convolution kernel, the split-bf16 and the exact-f32 kernel.
 TensorFlow itself is not installed: this pins the GPU arithmetic, not the Keras graph translation, which
 tests/test_cpu_host_logic.py pins against a numpy restatement of the Keras semantics."""
 import numpy as np
@@ -35,6 +35,8 @@ def _models(kind):
         return (lambda d: _bn_stats_(StarDist2D(Config2D(n_rays=32, unet_batch_norm=True), basedir=None, device=d, seed=0))), ("2d", 256), dict()
     if kind == "unet2d-multiclass":
         return (lambda d: StarDist2D(Config2D(n_rays=32, n_classes=3), basedir=None, device=d, seed=0)), ("2d", 256), dict()
+    if kind == "unet2d-depth4":  # unet_n_depth=4: the last up-level concatenates 256 + 256 channels (16 chunks)
+        return (lambda d: StarDist2D(Config2D(n_rays=32, unet_n_depth=4), basedir=None, device=d, seed=0)), ("2d", 256), dict()
     if kind == "unet3d":
         return (lambda d: StarDist3D(Config3D(rays=96), basedir=None, device=d, seed=0)), ("3d", 64), dict(frac=0.02, radius=8.5, noise=0.03)
     if kind == "resnet3d":   # the reference's 3D_demo topology: resnet backbone, grid (1,2,2)
@@ -52,9 +54,11 @@ def _image(dim, size):
     return synth.s3d_nuclei_image(size, seed=1)
 
 
-# every topology with the default convolution kernel (split-bf16 products, f32 accumulation); "-f32exact": the exact-f32 MFMA kernel
-KINDS = ["unet2d", "unet2d-grid2", "unet2d-he", "unet2d-bn", "unet2d-multiclass", "unet3d", "resnet3d",
-         "unet2d-f32exact", "unet2d-grid2-f32exact", "unet2d-bn-f32exact", "unet3d-f32exact", "resnet3d-f32exact"]
+# every topology with the default convolution kernel (split-fp16 products, f32 accumulation); "-f32exact": the exact-f32 MFMA kernel;
+# "-bf16x6": the six-product bf16 form (the range fallback of the default)
+KINDS = ["unet2d", "unet2d-grid2", "unet2d-he", "unet2d-bn", "unet2d-multiclass", "unet2d-depth4", "unet3d", "resnet3d",
+         "unet2d-f32exact", "unet2d-grid2-f32exact", "unet2d-bn-f32exact", "unet3d-f32exact", "resnet3d-f32exact",
+         "unet2d-bf16x6", "unet3d-bf16x6", "resnet3d-bf16x6"]
 
 
 @pytest.mark.parametrize("kind", KINDS)
@@ -63,22 +67,23 @@ def test_gpu_forward_matches_cpu_float32_and_is_deterministic(kind, monkeypatch)
     import bench
     import stardist_amd.models.unet as U
     if kind.endswith("-f32exact"):
-        # the exact-f32 MFMA kernel (STARDIST_AMD_CONV=hand); the default split-bf16 kernel is held to the same <= 1e-5 bar against float64
+        # the exact-f32 MFMA kernel (STARDIST_AMD_CONV=hand); the default split-fp16 kernel is held to the same <= 1e-5 bar against float64
         monkeypatch.setenv("STARDIST_AMD_CONV", "hand")
         kind = kind[:-9]
+    elif kind.endswith("-bf16x6"):
+        monkeypatch.setenv("STARDIST_AMD_CONV", "bf16x6")
+        kind = kind[:-7]
     else:
         monkeypatch.delenv("STARDIST_AMD_CONV", raising=False)
-        assert U.conv_mode() == "bf16x6"
+        assert U.conv_mode() == "f16x3"
     make, (dim, size), calib = _models(kind)
     img = _image(dim, size)
     dev = torch.device("cuda:0")
     m = make(dev)
     bench.calibrate_heads(m, torch.from_numpy(img).to(dev), **calib)
-    del U.library_fallbacks[:]
-    out1 = m.predict(img)
+    out1 = m.predict(img)          # (a layer no hand-written kernel covers raises UnsupportedLayer: there is no library path)
     out2 = m.predict(img)
-    # every convolution of the network ran on a hand-written kernel: nothing was left to a library solver
-    assert not U.library_fallbacks, U.library_fallbacks
+    assert m.__dict__.get("_conv_mode_pin") is None, "the fp16 range flag tripped on seeded weights"
     assert all(np.array_equal(a, b) for a, b in zip(out1, out2)), "GPU forward pass is not run-to-run identical"
     p1, d1 = out1[:2]
     mc = make("cpu")
@@ -153,18 +158,19 @@ def test_dense_equals_sparse_bit_for_bit():
     assert np.array_equal(l1, l2)
 
 
-def test_reduced_precision_autocast_runs_and_stays_close():
-    """compute_dtype='bfloat16' (bench.py --dtype): the fp32-only fused epilogue must step aside (it used to overrun the
-    bf16 buffer); predictions stay within bf16 accuracy of the float32 ones"""
+def test_reduced_precision_is_refused_and_uncovered_layers_raise():
+    """the prediction path is float32 on the library's own kernels: compute_dtype other than float32 is refused, and a layer no
+    hand-written kernel covers raises (rounds 1-3 fell back to library kernels)"""
     import torch
-    from oracle import synth
     from stardist_amd.models import Config2D, StarDist2D
+    from stardist_amd.models import unet as U
     dev = torch.device("cuda:0")
-    img = synth.s2d_nuclei_image(256, 256, seed=2)
-    m32 = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
-    m16 = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0, compute_dtype="bfloat16")
-    m16.net.load_state_dict(m32.net.state_dict())
-    p32, d32 = m32.predict(img)[:2]
-    p16, d16 = m16.predict(img)[:2]
-    assert np.isfinite(p16).all() and np.isfinite(d16).all()
-    assert np.abs(p16 - p32).max() < 0.1 and np.abs(d16 - d32).max() < 0.1 * max(1.0, float(np.abs(d32).max()))
+    with pytest.raises(ValueError):
+        StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0, compute_dtype="bfloat16")
+    x = torch.randn(1, 32, 16, 16, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        with pytest.raises(U.UnsupportedLayer):
+            U._conv(2, 32, 32, 3, "elu").to(dev)(x)                       # activation the epilogues do not fuse
+        with pytest.raises(U.UnsupportedLayer):
+            U._conv_bias_act(torch.nn.Conv2d(32, 32, 3, padding=2, dilation=2).to(dev), x, 1)
+
