@@ -38,7 +38,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak
-MFMA_BF16_PEAK_TFLOPS = 2500.0
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak (same rate on gfx950)
+# the matrix instructions a kernel family executes per algorithmic multiply-accumulate, and the pipe they run on
+CONV_FORMS = {"f16x3": (3.0, MFMA_BF16_PEAK_TFLOPS, "f16"), "bf16x6": (6.0, MFMA_BF16_PEAK_TFLOPS, "bf16"), "hand": (1.0, MFMA_F32_PEAK_TFLOPS, "f32")}
 # HBM bytes per pair-kernel launch are NOT a constant in this file: tools/profile_traffic.py (run under rocprofv3 --pmc FETCH_SIZE /
 # WRITE_SIZE in separate passes) writes them, together with the pair count of the profiled workload, to this json; bench.py
 # reports them as roofline.traffic only when its own pair count matches the profiled one.
@@ -52,12 +54,9 @@ def calibrate_heads(model, img, frac=0.10, radius=10.0, noise=0.1):
     net = model.net
     feats = {}
     h = net.features.register_forward_hook(lambda m, i, o: feats.__setitem__("f", o))
-    limit = net._INDEX_LIMIT
-    net._INDEX_LIMIT = 2 ** 62          # whole-volume head for the statistics (the timed path runs it in slabs)
-    net.fused_heads = False             # ... through the plain modules, so that the hook sees the features
+    net.fused_heads = False             # the plain graph, so that the hook sees the features
     with torch.no_grad():
         model.predict(img)
-    net._INDEX_LIMIT = limit
     del net.fused_heads
     model.__dict__.pop("_graphs", None)   # the captured HIP graph of this pass has the whole-volume head baked in
     h.remove()
@@ -77,17 +76,43 @@ def calibrate_heads(model, img, frac=0.10, radius=10.0, noise=0.1):
     del feats, f
 
 
+def _gpu_candidates(model, x_np):
+    """the candidates the GPU path's own network + selection produce for x (score-sorted, as the NMS natives take them) and the
+    keep flags of the HIP NMS on them"""
+    import torch
+    from stardist_amd.nms import _argsort_desc
+    with torch.no_grad():
+        r = model.predict_sparse_device(torch.from_numpy(np.ascontiguousarray(x_np)).to(model.device))
+    prob, dist, points = r[0], r[1], r[-1]
+    ind = _argsort_desc(prob)
+    prob, dist, points = prob[ind].contiguous(), dist[ind].contiguous(), points[ind].contiguous()
+    from stardist_amd import nms as sd_nms
+    if model.config.n_dim == 2:
+        keep = sd_nms.non_maximum_suppression_inds(dist, points, prob, thresh=model.thresholds.nms, verbose=0)
+    else:
+        from stardist_amd.lib.stardist3d import c_non_max_suppression_inds       # (the *_3d_inds wrapper would sort again)
+        from stardist_amd.rays3d import rays_from_json
+        rays = rays_from_json(model.config.rays_json)
+        verts = torch.as_tensor(np.ascontiguousarray(rays.vertices, np.float32), device=dist.device)
+        faces = torch.as_tensor(np.ascontiguousarray(rays.faces, np.int32), device=dist.device)
+        keep = c_non_max_suppression_inds(dist.float().contiguous(), points.float().contiguous(), verts, faces, prob.float().contiguous(), 1, 1, 0,
+                                          np.float32(model.thresholds.nms))
+    keep = (keep.cpu().numpy() if torch.is_tensor(keep) else np.asarray(keep)).astype(bool)
+    return dist.cpu().numpy().astype(np.float32), prob.cpu().numpy().astype(np.float32), points.cpu().numpy().astype(np.float32), keep
+
+
 def cpu_baseline_2d(img_np, model, sample, threads):
-    """Reference CPU path on a bounded sample: U-Net = the same PyTorch module on CPU (stand-in for
-    TF-CPU, which is not installed -- flagged deviation); post-processing = the COMPILED REFERENCE
-    natives (oracle/_ref: stardist2d.cpp + Clipper + nanoflann, OpenMP) + the numpy restatement of
-    the reference's Python rasteriser loop."""
+    """Reference CPU path on a bounded sample: U-Net = the same PyTorch module on CPU (stand-in for TF-CPU, which is not installed --
+    flagged deviation) + threshold / sort on its output; post-processing = the COMPILED REFERENCE natives (oracle/_ref: stardist2d.cpp +
+    Clipper + nanoflann, OpenMP) + the numpy restatement of the reference's Python rasteriser loop, run on the candidates the GPU
+    path's network produced for the same sample -- so that the reference's keep flags can be compared ONE BY ONE with the HIP NMS's
+    (`parity_checked`); the candidate statistics are those of the timed workload either way."""
     import copy
     import torch
     from oracle import port, ref
     torch.set_num_threads(threads)
     ref.stardist2d(); ref.set_threads(threads)
-    x = img_np[:sample, :sample]
+    x = np.ascontiguousarray(img_np[:sample, :sample])
     net_cpu = copy.deepcopy(model.net).to("cpu").float()
     t0 = time.time()
     with torch.no_grad():
@@ -97,32 +122,35 @@ def cpu_baseline_2d(img_np, model, sample, threads):
     t_net = time.time() - t0
     t0 = time.time()
     mask = port.ind_prob_thresh(prob, model.thresholds.prob, b=2)
-    pts = np.stack(np.where(mask), 1)
-    d, s = dist[mask], prob[mask]
-    ind = np.argsort(s)[::-1]
-    d, s, pts = d[ind], s[ind], pts[ind]
-    keep = ref.stardist2d().c_non_max_suppression_inds(np.ascontiguousarray(d, np.float32), np.ascontiguousarray(pts.astype(np.float32)),
-                                                       1, 1, 0, np.float32(model.thresholds.nms))
+    pts_c = np.stack(np.where(mask), 1)
+    ind = np.argsort(prob[mask])[::-1]
+    d_c = dist[mask][ind]
+    t_sel = time.time() - t0
+    d, s, pts, keep_gpu = _gpu_candidates(model, x)
+    t0 = time.time()
+    keep = ref.stardist2d().c_non_max_suppression_inds(d, pts, 1, 1, 0, np.float32(model.thresholds.nms))
     t_nms = time.time() - t0
     t0 = time.time()
     port.polygons_to_label(d[keep], pts[keep], prob=s[keep], shape=x.shape)
     t_ras = time.time() - t0
-    tot = t_net + t_nms + t_ras
+    tot = t_net + t_sel + t_nms + t_ras
     # BASELINE.md 3.1 asks for the native post-processing at cpu_count AND at one thread: the first quarter of the candidates
     # (bounded sample) through the compiled reference NMS with a single OpenMP thread
     n1 = max(1, len(d) // 4)
     ref.set_threads(1)
     t0 = time.time()
-    k1 = ref.stardist2d().c_non_max_suppression_inds(np.ascontiguousarray(d[:n1], np.float32), np.ascontiguousarray(pts[:n1].astype(np.float32)),
-                                                     1, 1, 0, np.float32(model.thresholds.nms))
+    k1 = ref.stardist2d().c_non_max_suppression_inds(np.ascontiguousarray(d[:n1]), np.ascontiguousarray(pts[:n1]), 1, 1, 0, np.float32(model.thresholds.nms))
     t_nms1 = time.time() - t0
     ref.set_threads(threads)
+    same = bool(np.array_equal(keep.astype(bool), keep_gpu))
     return dict(value=round(x.size / tot / 1e6, 4), unit="Mpix/s", cores=threads, kind="reference",
+                parity_checked=same, parity="keep flags of the compiled reference NMS %s the HIP NMS on the %d candidates of the GPU path (%d survivors)"
+                                            % ("==" if same else "DIFFER FROM (%d flags)" % int((keep.astype(bool) != keep_gpu).sum()), len(d), int(keep.sum())),
                 nms_only={"threads_%d" % threads: {"candidates": int(len(d)), "seconds": round(t_nms, 3), "cand_per_s": round(len(d) / t_nms)},
                           "threads_1": {"candidates": int(n1), "seconds": round(t_nms1, 3), "cand_per_s": round(n1 / t_nms1), "survivors": int(k1.sum())}},
-                sample="%dx%d crop of the bench image: torch-CPU U-Net %.2fs (TF-CPU stand-in) + compiled reference NMS "
-                       "(oracle/_ref, %d candidates -> %d) %.2fs + numpy restatement of the Python rasteriser loop %.2fs"
-                       % (sample, sample, t_net, len(d), int(keep.sum()), t_nms, t_ras))
+                sample="%dx%d crop of the bench image: torch-CPU U-Net %.2fs (TF-CPU stand-in; its own %d candidates thresholded + sorted in %.2fs) + "
+                       "compiled reference NMS (oracle/_ref) on the GPU path's %d candidates -> %d: %.2fs + numpy restatement of the Python "
+                       "rasteriser loop %.2fs" % (sample, sample, t_net, len(d_c), t_sel, len(d), int(keep.sum()), t_nms, t_ras))
 
 
 def cpu_baseline_3d(vol_np, model, sample, threads):
@@ -133,7 +161,7 @@ def cpu_baseline_3d(vol_np, model, sample, threads):
     torch.set_num_threads(threads)
     m3 = ref.stardist3d(); ref.set_threads(threads)
     rays = rays_from_json(model.config.rays_json)
-    x = vol_np[:sample, :sample, :sample]
+    x = np.ascontiguousarray(vol_np[:sample, :sample, :sample])
     net_cpu = copy.deepcopy(model.net).to("cpu").float()
     t0 = time.time()
     with torch.no_grad():
@@ -143,25 +171,32 @@ def cpu_baseline_3d(vol_np, model, sample, threads):
     t_net = time.time() - t0
     t0 = time.time()
     mask = port.ind_prob_thresh(prob, model.thresholds.prob, b=2)
-    pts = np.stack(np.where(mask), 1)
-    d, s = dist[mask], prob[mask]
-    ind = np.argsort(s)[::-1]
-    d, s, pts = np.ascontiguousarray(d[ind], np.float32), np.ascontiguousarray(s[ind], np.float32), np.ascontiguousarray(pts[ind].astype(np.float32))
+    n_c = int(mask.sum())
+    ind = np.argsort(prob[mask])[::-1]
+    d_c = dist[mask][ind]
+    t_sel = time.time() - t0
+    del d_c, dist
+    # the reference natives on the candidates of the GPU path's network (see cpu_baseline_2d): keep flags compared one by one
+    d, s, pts, keep_gpu = _gpu_candidates(model, x)
     V, F = rays.vertices, rays.faces.astype(np.int32)
+    t0 = time.time()
     keep = m3.c_non_max_suppression_inds(d, pts, V, F, s, 1, 1, 0, np.float32(model.thresholds.nms))
     t_nms = time.time() - t0
     t0 = time.time()
     m3.c_polyhedron_to_label(d[keep], pts[keep], V, F, np.arange(1, keep.sum() + 1, dtype=np.int32), 0, 0, 0, 0, x.shape)
     t_ras = time.time() - t0
-    tot = t_net + t_nms + t_ras
+    tot = t_net + t_sel + t_nms + t_ras
     full = sample >= vol_np.shape[0]
+    same = bool(np.array_equal(keep.astype(bool), keep_gpu))
     return dict(value=round(x.size / tot / 1e6, 4), unit="Mvox/s", cores=threads, kind="reference", seconds=round(tot, 2), same_size=bool(full),
+                parity_checked=same, parity="keep flags of the compiled reference 3D NMS %s the HIP NMS on the %d candidates of the GPU path (%d survivors)"
+                                            % ("==" if same else "DIFFER FROM (%d flags)" % int((keep.astype(bool) != keep_gpu).sum()), len(d), int(keep.sum())),
                 note=("the whole bench volume: a same-size comparison with value_3d" if full else
                       "measured on a crop (the full-size reference run was predicted to exceed --cpu-budget3d): any GPU/CPU ratio formed with "
                       "value_3d is an extrapolation from this crop, not a same-size comparison"),
-                sample="%s of the bench volume: torch-CPU U-Net %.2fs (TF-CPU stand-in) + compiled reference 3D NMS "
-                       "(oracle/_ref incl. Qhull, %d candidates -> %d) %.2fs + compiled reference rasteriser %.2fs"
-                       % ("all %d^3 voxels" % sample if full else "%d^3 crop" % sample, t_net, len(d), int(keep.sum()), t_nms, t_ras))
+                sample="%s of the bench volume: torch-CPU U-Net %.2fs (TF-CPU stand-in; its own %d candidates thresholded + sorted in %.2fs) + compiled "
+                       "reference 3D NMS (oracle/_ref incl. Qhull) on the GPU path's %d candidates -> %d: %.2fs + compiled reference rasteriser %.2fs"
+                       % ("all %d^3 voxels" % sample if full else "%d^3 crop" % sample, t_net, n_c, t_sel, len(d), int(keep.sum()), t_nms, t_ras))
 
 
 def net_macs(model, macs):
@@ -212,65 +247,60 @@ def run_leg(model, img, steps, warmup, world, dist_):
     return elapsed, net_ms, res, stats
 
 
-def run_exact_leg(model, img, steps, warmup, world, dist_):
-    """The same steps with the exact-f32 convolution kernel (csrc/conv3x3.hip, STARDIST_AMD_CONV=hand: one f32 fma chain per output)
-    instead of the default split-bf16 kernel (csrc/conv3x3_bf16.hip: six bf16 MFMA products per f32 product, f32 accumulation; both are
-    held to the same 1e-5 bar against float64 by tests/test_gpu_unet_parity.py and tests/test_gpu_conv3x3.py).  Reported NEXT TO `value`.
+def run_mode_leg(model, img, steps, warmup, world, dist_, mode):
+    """The same steps with another form of the 3x3 convolutions (models/unet.py conv_mode): 'hand' = the exact-f32 MFMA kernel
+    (csrc/conv3x3.hip, one f32 fma chain per output), 'bf16x6' = six bf16 products per f32 product (csrc/conv3x3_bf16.hip, the round-3
+    default and the range fallback of the default).  All forms are held to the same 1e-5 bar against float64 by
+    tests/test_gpu_unet_parity.py and tests/test_gpu_conv3x3.py.  Reported NEXT TO `value`.
     Returns a dict, or an error note (this leg must never take the bench down)."""
-    old = os.environ.get("STARDIST_AMD_CONV")
+    from stardist_amd.models.unet import force_conv_mode
     graphs = model.__dict__.pop("_graphs", None)
-    os.environ["STARDIST_AMD_CONV"] = "hand"
     try:
-        elapsed, net_ms, res, _ = run_leg(model, img, steps, warmup, world, dist_)
+        with force_conv_mode(mode):
+            elapsed, net_ms, res, _ = run_leg(model, img, steps, warmup, world, dist_)
         n = int(np.prod(img.shape))
         return {"value": round(world * n * steps / elapsed / 1e6, 3), "ms_per_step": round(1e3 * elapsed / steps, 3), "unet_forward_ms": round(net_ms, 3),
                 "instances": len(res[1]["prob"]), "steps": steps,
-                "arithmetic": "exact f32 MFMA (v_mfma_f32_32x32x2_f32), one fma chain per output (STARDIST_AMD_CONV=hand)"}
+                "arithmetic": {"hand": "exact f32 MFMA (v_mfma_f32_32x32x2_f32), one fma chain per output (STARDIST_AMD_CONV=hand)",
+                               "bf16x6": "six bf16 x bf16 MFMA products per f32 product, f32 accumulation (STARDIST_AMD_CONV=bf16x6)"}[mode]}
     except Exception as e:                       # pragma: no cover
         return {"value": None, "error": repr(e)[:200]}
     finally:
-        if old is None:
-            os.environ.pop("STARDIST_AMD_CONV", None)
-        else:
-            os.environ["STARDIST_AMD_CONV"] = old
         model.__dict__.pop("_graphs", None)
         if graphs is not None:
             model._graphs = graphs
 
 
-def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, dist_, rank, pipeline=True):
+def predicted_scaling(per_block, t_exchange, t_final_nms, t_raster_local, s_pass_n1):
+    """From the N = 1 per-block times: the per-rank critical path max_r sum_{b % N == r} (t_predict + t_local_nms) for N = 2, 4, 8 with the
+    round-robin deal of predict_instances_sharded, plus the serial tail on rank 0 (exchange + cross-tile NMS; measured at N = 1, the
+    gather over xGMI is not modelled) and the owner-side rasters (the N = 1 total / N)."""
+    out = {}
+    for n in (2, 4, 8):
+        loads = [sum(tp + tn for bi, tp, tn in per_block if bi % n == r) for r in range(n)]
+        t = max(loads) + t_exchange + t_final_nms + t_raster_local / n
+        out[str(n)] = {"critical_path_s": round(max(loads), 4), "pass_s": round(t, 4), "serial_tail_share": round((t_exchange + t_final_nms) / t, 4),
+                       "strong_scaling_efficiency": round(s_pass_n1 / (n * t), 4)}
+    return out
+
+
+def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, dist_, rank):
     """BASELINE.json configs 4/5: ONE large input, its blocks dealt round-robin to the ranks; per block network + selection + local NMS on
     the device; one gather of the surviving records to rank 0; cross-tile NMS over the band survivors only; final instances broadcast and
     every rank renders the write regions of its blocks (stardist_amd/big.py, design A of SURVEY.md 8e).  Strong scaling: the input is
     the same for every N.  N = 1: the label image comes back as ONE host array (as predict_instances returns it); N > 1: the tiles stay on
-    the ranks that rendered them (labels_out="local"), as the reference's block.write leaves them in the shared output.
-    pipeline: the network of block k+1 runs on the main stream while the NMS of block k runs on a second one; the warm-up runs a
-    two-block input through both loops and the pipelined one is used only if it returns bit-identical instances and labels.
+    the ranks that rendered them (labels_out="local": owner-side window rasters, no whole-volume raster and no label gather on rank 0),
+    as the reference's block.write leaves them in the shared output.  At N = 1 one extra pass in that owner-side form is timed as well
+    and, from the per-block times, the per-rank critical path and strong-scaling efficiency at N = 2, 4, 8 are predicted.
     Returns a dict (rank 0) or None."""
     import torch
-    # warm-up on TWO blocks' worth of the input (HIP graph of the block shape, arena growth): a full pass of the 1024^3 volume is ~10 s
-    warm = big[tuple(slice(0, block) for _ in range(big.dim() - 1)) + (slice(0, min(big.shape[-1], 2 * block - overlap - 2 * context)),)]
-    wkw = dict(block_size=block, min_overlap=overlap, context=context, distributed=False)
-    l0, r0_ = model.predict_instances_sharded(warm, axes, pipeline=False, **wkw)
-    check = "serial loop"
-    if pipeline:
-        l1, r1_ = model.predict_instances_sharded(warm, axes, pipeline=True, **wkw)
-        same = (bool(model._last_sharded_stats["pipelined"]) and np.array_equal(np.asarray(l0), np.asarray(l1))
-                and all(np.array_equal(np.asarray(r0_[k]), np.asarray(r1_[k])) for k in ("points", "prob")))
-        check = "two-block warm-up: pipelined == serial (labels, points, prob bit-identical)" if same else "two-block warm-up DISAGREED: serial loop used"
-        pipeline = same
-        del l1, r1_
-    if world > 1:                          # one decision for all ranks
-        flag = torch.tensor([int(pipeline)], device=big.device)
-        dist_.all_reduce(flag, op=dist_.ReduceOp.MIN)
-        if pipeline and not flag.item():
-            check = "another rank's two-block warm-up disagreed: serial loop used"
-        pipeline = bool(flag.item())
-    del warm, l0, r0_
-    kw = dict(block_size=block, min_overlap=overlap, context=context, broadcast_result=False, pipeline=pipeline)
+    # warm-up on one block's worth of the input (HIP graph of the block shape, weight packing, arena growth)
+    warm = big[tuple(slice(0, block) for _ in range(big.dim()))]
+    model.predict_instances_sharded(warm, axes, block_size=block, min_overlap=overlap, context=context, distributed=False)
+    del warm
+    kw = dict(block_size=block, min_overlap=overlap, context=context, broadcast_result=False)
     if world > 1:
         kw["labels_out"] = "local"
-    if world > 1:
         dist_.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -278,12 +308,13 @@ def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, di
     for _ in range(passes):
         labels, res = model.predict_instances_sharded(big, axes, **kw)
         for k, v in model._last_sharded_stats.items():
-            acc[k] = acc.get(k, 0) + v
+            acc[k] = (acc.get(k, 0) + v) if not isinstance(v, list) else v
     torch.cuda.synchronize()
     if world > 1:
         dist_.barrier()
     elapsed = time.perf_counter() - t0
-    mean = {k: (round(v / passes, 4) if isinstance(v, float) else v // passes) for k, v in acc.items()}
+    del labels
+    mean = {k: (v if isinstance(v, list) else (round(v / passes, 4) if isinstance(v, float) else v // passes)) for k, v in acc.items()}
     per_rank = [None] * world
     if world > 1:
         tt = torch.tensor([elapsed], device=big.device, dtype=torch.float64)
@@ -292,21 +323,36 @@ def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, di
         dist_.all_gather_object(per_rank, mean)
     else:
         per_rank = [mean]
+    local_form = None
+    if world == 1:                         # the owner-side form of N > 1, once, on one GPU: its raster time feeds the prediction
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        model.predict_instances_sharded(big, axes, labels_out="local", **kw)
+        torch.cuda.synchronize()
+        local_form = {"s_per_pass": round(time.perf_counter() - t1, 4), "t_raster": round(model._last_sharded_stats["t_raster"], 4),
+                      "t_final": round(model._last_sharded_stats["t_final"], 4)}
     if rank != 0:
         return None
     n = int(np.prod(big.shape))
     r0 = per_rank[0]
     s_pass = elapsed / passes
-    return {"value": round(n * passes / elapsed / 1e6, 3), "s_per_pass": round(s_pass, 4), "passes": passes, "scaling": "strong",
-            "input_shape": list(big.shape), "block_size": block, "min_overlap": overlap, "context": context, "blocks": sum(p["blocks"] for p in per_rank),
-            "instances": r0["instances"], "candidates": sum(p["candidates"] for p in per_rank),
-            "gathered_survivors": r0["gathered"], "gathered_bytes": r0["gathered_bytes"], "band_survivors": r0["band"], "interior_survivors": r0["interior"],
-            "pipelined": bool(r0["pipelined"]), "pipeline_check": check, "t_phase1": max(p["t_phase1"] for p in per_rank),
-            "t_predict": max(p["t_predict"] for p in per_rank), "t_local_nms": max(p["t_local_nms"] for p in per_rank), "t_exchange": r0["t_exchange"],
-            "t_final": r0["t_final"], "t_final_nms": r0["t_final_nms"], "t_raster": max(p["t_raster"] for p in per_rank),
-            "t_final_frac": round(r0["t_final"] / s_pass, 4),
-            "labels": "one host array on rank 0" if world == 1 else "rank-local tiles of the owned write regions (not gathered)",
-            "per_rank": per_rank}
+    out = {"value": round(n * passes / elapsed / 1e6, 3), "s_per_pass": round(s_pass, 4), "passes": passes, "scaling": "strong",
+           "input_shape": list(big.shape), "block_size": block, "min_overlap": overlap, "context": context, "blocks": sum(p["blocks"] for p in per_rank),
+           "redundancy": round(sum(p["blocks"] for p in per_rank) * float(block) ** big.dim() / n, 3),
+           "instances": r0["instances"], "candidates": sum(p["candidates"] for p in per_rank),
+           "gathered_survivors": r0["gathered"], "gathered_bytes": r0["gathered_bytes"], "band_survivors": r0["band"], "interior_survivors": r0["interior"],
+           "t_phase1": max(p["t_phase1"] for p in per_rank),
+           "t_predict": max(p["t_predict"] for p in per_rank), "t_local_nms": max(p["t_local_nms"] for p in per_rank), "t_exchange": r0["t_exchange"],
+           "t_final": r0["t_final"], "t_final_nms": r0["t_final_nms"], "t_raster": max(p["t_raster"] for p in per_rank),
+           "t_final_frac": round(r0["t_final"] / s_pass, 4),
+           "labels": "one host array on rank 0" if world == 1 else "rank-local tiles of the owned write regions (owner-side window rasters, not gathered)",
+           "per_rank": [{k: v for k, v in p.items() if k != "per_block"} for p in per_rank]}
+    if world == 1:
+        out["owner_side_form"] = local_form
+        # the N = 1 pass in the owner-side form is the numerator: the same work, the same output form as N > 1
+        out["predicted_scaling"] = predicted_scaling(r0["per_block"], r0["t_exchange"], r0["t_final_nms"], local_form["t_raster"], local_form["s_per_pass"])
+        out["predicted_scaling"]["basis"] = ("per-block (t_predict + t_local_nms) of this N = 1 run dealt round-robin, + exchange + cross-tile NMS "
+                                             "on rank 0 (serial tail) + owner-side rasters / N; numerator = the N = 1 pass in the owner-side form")
+    return out
 
 
 def guarded(fn, what):
@@ -326,7 +372,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--size3d", type=int, default=256)
-    ap.add_argument("--dtype", default="float32", choices=["float32", "bfloat16", "float16"])
     ap.add_argument("--skip-3d", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048)
@@ -336,14 +381,16 @@ def main():
     ap.add_argument("--no-sharded", action="store_true", help="skip the block-sharded big-input legs (configs 4/5; run by default at every N)")
     ap.add_argument("--sharded-size", type=int, default=16384)
     ap.add_argument("--sharded-size3d", type=int, default=1024)
-    # block sizes (read size incl. context, as in the reference's BlockND.cover): 4480 -> 16 blocks of the 16384^2 slide (1.20x the slide's
-    # pixels, an equal number per rank at N = 1, 2, 4, 8); 416 -> 27 blocks of the 1024^3 volume (1.81x; a 32-channel level of one block is
-    # 9.2 GB, the 128-channel features 37 GB)
+    # block sizes (read size incl. context, as in the reference's BlockND.cover), chosen so that the block count divides by 8:
+    # 4480 -> 16 blocks of the 16384^2 slide (1.20x the slide's pixels); 544 -> 8 blocks of the 1024^3 volume (1.20x its voxels; the
+    # 128-channel features of one block are 82 GB of the 288 GB) -- round 3 used 27 blocks of 416^3 (1.81x, 4/3/3/.. blocks per rank at N = 8).
+    # Should the 544^3 block not fit, the leg falls back to 64 blocks of 288^3 (1.42x) and says so.
     ap.add_argument("--sharded-block", type=int, default=4480)
-    ap.add_argument("--sharded-block3d", type=int, default=416)
+    ap.add_argument("--sharded-block3d", type=int, default=544)
+    ap.add_argument("--sharded-block3d-fallback", type=int, default=288)
     ap.add_argument("--skip-sharded-3d", action="store_true")
     ap.add_argument("--no-split-leg", "--no-exact-leg", dest="no_split_leg", action="store_true",
-                    help="skip the extra legs with the exact-f32 convolution kernel")
+                    help="skip the extra legs with the exact-f32 and the six-product bf16 convolution kernels")
     args = ap.parse_args()
 
     import torch
@@ -363,21 +410,23 @@ def main():
     from oracle import synth                       # input generators only (numpy), shared with the tests
     from stardist_amd.models import Config2D, Config3D, StarDist2D, StarDist3D
     from stardist_amd.models.unet import conv_macs_per_input_pixel
-    peak = MFMA_F32_PEAK_TFLOPS if args.dtype == "float32" else MFMA_BF16_PEAK_TFLOPS
-    dt = {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[args.dtype]
+    from stardist_amd.models.unet import conv_mode
+    mode = conv_mode()
+    mult, cpeak, pipe = CONV_FORMS[mode]
 
     # ------------------------------------------------------------------ 2D leg (headline)
     H = W = args.size
     img_np = synth.s2d_nuclei_image(H, W, seed=rank)
     img = torch.from_numpy(img_np).to(dev)
-    model = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0, compute_dtype=args.dtype)
+    model = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
     # every rank calibrates on the SAME image (seed 0), so that all ranks run identical weights -- the sharded legs deal the blocks of one
     # input over the ranks and must see one model; the timed tile of a rank is its own (seed = rank)
     calibrate_heads(model, img if rank == 0 else torch.from_numpy(synth.s2d_nuclei_image(H, W, seed=0)).to(dev))
     macs = conv_macs_per_input_pixel(model.net, model.config)
     elapsed, net_ms, res, st = run_leg(model, img, args.steps, args.warmup, world, dist_)
     # second number (SURVEY.md 8d defines the metric host-array-in): the same steps with the image handed over as a host numpy array,
-    # i.e. including the 16.8 MB H2D copy; `value` stays the HBM-resident figure the contract asks for
+    # i.e. including the 16.8 MB H2D copy (staged through page-locked memory, stardist_amd/utils.py to_device); `value` stays the
+    # HBM-resident figure the bench contract asks for
     torch.cuda.synchronize(); t0h = time.perf_counter()
     for _ in range(args.steps):
         model.predict_instances(img_np)
@@ -397,23 +446,25 @@ def main():
         stages = {"unet_forward": round(net_ms, 3), "nms_pair_kernel": round(float(pair_ms), 3),
                   "nms_exact_join_kernel": round(float(s2[6] / 1e6), 3), "nms_build_bin_neighbours": round(float(s2[7] / 1e6), 3),
                   "other(select,sort,greedy-scan,raster,d2h)": round(ms_per_step - net_ms - float(pair_ms + s2[6] / 1e6 + s2[7] / 1e6), 3)}
-        from stardist_amd.models.unet import conv_mode
-        mode = conv_mode() if args.dtype == "float32" else "miopen"
-        # roofline of the convolutions.  Split kernel (default): every f32 multiply-accumulate is six bf16 x bf16 MFMA products, so the
-        # matrix cores execute 6x the algorithmic FLOPs, on the bf16 pipe (dense peak 2.5 PFLOP/s); exact kernel: the FLOPs themselves on
-        # the f32 pipe (157.3 TFLOP/s).  `achieved` / `peak` / `frac` are those of the pipe the kernel runs on; `f32_equivalent_tflops` is
-        # the algorithmic rate either way.
-        mult, cpeak, pipe = (6.0, MFMA_BF16_PEAK_TFLOPS, "bf16") if mode == "bf16x6" else (1.0, peak, "f32" if args.dtype == "float32" else args.dtype)
-        conv_kernel = {"bf16x6": "network forward = one HIP graph: k_conv3_bf16 (hand-written split-bf16 implicit GEMM, csrc/conv3x3_bf16.hip: every 3x3 layer incl. "
-                                 "folded up-sampling / concatenation / bias / ReLU; v_mfma_f32_32x32x16_bf16, six products per f32 product, f32 accumulate) + "
-                                 "k_conv3_c1x32 + k_maxpool_cl4 + probability-head pass",
+        # Roofline of the convolutions, SURVEY.md 8(d): ALGORITHMIC flops (2 x MACs of the instantiated module) / HIP-event time of the forward
+        # pass / dense peak of the pipe the kernel runs on.  A split form executes `mult` matrix products per algorithmic one (f16x3: 3 on
+        # the fp16 pipe, bf16x6: 6 on the bf16 pipe, both 2.5 PFLOP/s dense; exact: 1 on the f32 pipe, 157.3 TFLOP/s): `executed_frac` is
+        # the pipe occupancy, `frac` the roofline fraction.
+        conv_kernel = {"f16x3": "network forward = one HIP graph: k_conv3_f16 (hand-written split-fp16 implicit GEMM, csrc/conv3x3_f16.hip: every 3x3 layer incl. "
+                                "folded up-sampling / concatenation / bias / ReLU; v_mfma_f32_32x32x16_f16, three products per f32 product in two f32 "
+                                "accumulators, two workgroups per CU) + k_conv3_c1x32 + k_maxpool_cl4 + probability-head pass",
+                       "bf16x6": "network forward = one HIP graph: k_conv3_bf16 (csrc/conv3x3_bf16.hip, six bf16 products per f32 product) + k_conv3_c1x32 + "
+                                 "k_maxpool_cl4 + probability-head pass",
                        "hand": "network forward = one HIP graph: k_conv3<1> (hand-written exact-f32 MFMA implicit GEMM, csrc/conv3x3.hip) + k_conv3_c1x32 + "
-                               "k_maxpool_cl4 + probability-head pass"}.get(mode, "network forward (MIOpen / CK convolution kernels, NHWC) + epilogue passes")
-        roof_conv = {"bound": "mfma", "pipe": pipe, "kernel": conv_kernel, "achieved": round(conv_tf * mult, 3), "peak": cpeak,
-                     "unit": "TFLOP/s", "frac": round(conv_tf * mult / cpeak, 4), "traffic": None, "flops_per_launch": flops * mult,
-                     "f32_equivalent_tflops": round(conv_tf, 3), "frac_of_f32_peak_equivalent": round(conv_tf / MFMA_F32_PEAK_TFLOPS, 4), "avg_ms": round(net_ms, 3),
-                     "note": "algorithmic FLOPs of the convolutions (2 x MACs, recomputed from the instantiated module; x6 executed products for the split "
-                             "kernel) / HIP-event time of the whole forward pass on the caller's stream; per-kernel durations: profiles/r03_bench_kernel_stats.md"}
+                               "k_maxpool_cl4 + probability-head pass"}[mode]
+        roof_conv = {"bound": "mfma", "pipe": pipe, "kernel": conv_kernel, "achieved": round(conv_tf, 3), "peak": cpeak,
+                     "unit": "TFLOP/s", "frac": round(conv_tf / cpeak, 4), "traffic": None, "flops_per_launch": flops,
+                     "executed_products_per_mac": mult, "executed_tflops": round(conv_tf * mult, 3), "executed_frac": round(conv_tf * mult / cpeak, 4),
+                     "avg_ms": round(net_ms, 3),
+                     "note": "achieved = algorithmic FLOPs of the convolutions (2 x MACs, recomputed from the instantiated module) / HIP-event time of the "
+                             "whole forward pass (14 conv launches + pools + head) on the caller's stream; executed_* = x%d matrix products per MAC; "
+                             "for reference the f32-MFMA peak is %.1f TFLOP/s; per-kernel durations and the MFMA-busy counter: profiles/r04_*"
+                             % (int(mult), MFMA_F32_PEAK_TFLOPS)}
         roof_pair = {"bound": "hbm", "kernel": "k_pairs_beam<32,8,6,4,64> (bound-slot scan-beam polygon intersection, one pair per lane, state in LDS)", "achieved": round(pair_gbs, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pair_gbs / HBM_PEAK_GBS, 6), "traffic": None,
                      "bytes_per_launch": round(pair_bytes_per_launch), "avg_launch_ms": round(float(pair_ms / pair_launches), 4),
@@ -433,11 +484,12 @@ def main():
             "metric": "predict_instances() Mpix/s (2D) + Mvox/s (3D) end-to-end at 1/2/4/8 GPU",
             "value": round(world * H * W * args.steps / elapsed / 1e6, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": dt, "data": "synthetic",
+            "dtype": "f32", "data": "synthetic",
             "arithmetic": ("float32 data, float32 accumulation; 3x3 convolution products " +
-                           ("as six bf16 x bf16 terms of operands split into three bf16 parts (f32-accurate: layers and networks within 3e-6 of a float64 "
-                            "evaluation, tests/test_gpu_conv3x3.py, test_gpu_unet_parity.py; `exact_f32` = the same step with the exact-f32 MFMA kernel)"
-                            if args.dtype == "float32" and conv_mode() == "bf16x6" else "in the named dtype") +
+                           {"f16x3": "as three fp16 x fp16 terms of operands split into two fp16 parts (hi + lo * 2^-11)",
+                            "bf16x6": "as six bf16 x bf16 terms of operands split into three bf16 parts", "hand": "exact in f32"}[mode] +
+                           " (f32-accurate: layers and networks within 3e-6 of a float64 evaluation, tests/test_gpu_conv3x3.py, "
+                           "test_gpu_unet_parity.py; `exact_f32` / `split_bf16x6` = the same step with the other kernel forms)"
                            "; NMS / rasteriser in the reference's own int64 / float32 / float64 arithmetic"),
             "config": {"workload": "StarDist2D 32-ray U-Net (depth 3, 32 base filters), %dx%d synthetic fluo tile per GPU, predict_instances "
                                    "(U-Net + select + 2D NMS + polygon raster), seeded random weights, heads calibrated to ~10%% candidates "
@@ -453,11 +505,14 @@ def main():
                 out["cpu_baseline"] = cpu_baseline_2d(img_np, model, min(args.cpu_sample, H), threads)
             except Exception as e:   # oracle/_ref must have travelled with the tree
                 out["cpu_baseline"] = {"value": None, "unit": "Mpix/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
-    if args.dtype == "float32" and not args.no_split_leg:
-        r = run_exact_leg(model, img, max(1, min(args.steps, 10)), 2, world, dist_)
-        if rank == 0:
-            r["unit"] = "Mpix/s"
-            out["exact_f32"] = r
+    if not args.no_split_leg:
+        for key, md in (("exact_f32", "hand"), ("split_bf16x6", "bf16x6")):
+            if md == mode:
+                continue
+            r = run_mode_leg(model, img, max(1, min(args.steps, 10)), 2, world, dist_, md)
+            if rank == 0:
+                r["unit"] = "Mpix/s"
+                out[key] = r
     # ---- config 4: one 16384^2 slide (the 2048^2 synthetic tile repeated), blocks 4480 / overlap 128 / context 128, sharded over the ranks
     if not args.no_sharded:
         rep = max(1, args.sharded_size // H)
@@ -489,7 +544,7 @@ def main():
         S = args.size3d
         vol_np = synth.s3d_nuclei_image(S, seed=rank)
         vol = torch.from_numpy(vol_np).to(dev)
-        m3 = StarDist3D(Config3D(rays=96), basedir=None, device=dev, seed=0, compute_dtype=args.dtype)
+        m3 = StarDist3D(Config3D(rays=96), basedir=None, device=dev, seed=0)
         m3.thresholds = dict(prob=0.5, nms=0.3)
         calibrate_heads(m3, vol if rank == 0 else torch.from_numpy(synth.s3d_nuclei_image(S, seed=0)).to(dev),
                         frac=0.009, radius=8.5, noise=0.03)   # near-spherical objects; same image on every rank
@@ -515,10 +570,9 @@ def main():
                                    "nms_stage4_hull_volume": round(float(s3[9] / 1e6), 3), "nms_stage5_render": round(float(s3[10] / 1e6), 3),
                                    "other": round(ms3 - net3_ms - float((s3[8] + s3[9] + s3[10]) / 1e6), 3)}
             out["roofline_convs_3d"] = {"bound": "mfma", "pipe": pipe, "kernel": "network forward (3x3x3 layers as three z-plane units per 32-channel chunk; kernel family as `roofline_convs`)",
-                                        "achieved": round(conv3_tf * mult, 3), "peak": cpeak, "unit": "TFLOP/s",
-                                        "frac": round(conv3_tf * mult / cpeak, 4), "flops_per_launch": flops3 * mult,
-                                        "f32_equivalent_tflops": round(conv3_tf, 3), "frac_of_f32_peak_equivalent": round(conv3_tf / MFMA_F32_PEAK_TFLOPS, 4),
-                                        "avg_ms": round(net3_ms, 3)}
+                                        "achieved": round(conv3_tf, 3), "peak": cpeak, "unit": "TFLOP/s", "frac": round(conv3_tf / cpeak, 4),
+                                        "traffic": None, "flops_per_launch": flops3, "executed_products_per_mac": mult,
+                                        "executed_tflops": round(conv3_tf * mult, 3), "executed_frac": round(conv3_tf * mult / cpeak, 4), "avg_ms": round(net3_ms, 3)}
             if not args.no_cpu_baseline and world == 1:
                 try:
                     cb = cpu_baseline_3d(vol_np, m3, min(args.cpu_sample3d, S), threads)
@@ -530,16 +584,27 @@ def main():
                     out["cpu_baseline_3d"] = cb
                 except Exception as e:
                     out["cpu_baseline_3d"] = {"value": None, "unit": "Mvox/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
-        if args.dtype == "float32" and not args.no_split_leg:
-            r = run_exact_leg(m3, vol, steps3, 1, world, dist_)
-            if rank == 0:
-                r["unit"] = "Mvox/s"
-                out["exact_f32_3d"] = r
+        if not args.no_split_leg:
+            for key, md in (("exact_f32_3d", "hand"), ("split_bf16x6_3d", "bf16x6")):
+                if md == mode:
+                    continue
+                r = run_mode_leg(m3, vol, steps3, 1, world, dist_, md)
+                if rank == 0:
+                    r["unit"] = "Mvox/s"
+                    out[key] = r
         # ---- config 5: one 1024^3 volume (the 256^3 synthetic volume repeated), 416^3 blocks / overlap 32 / context 32, sharded
         if not args.no_sharded and not args.skip_sharded_3d:
             rep = max(1, args.sharded_size3d // S)
             bigv = torch.from_numpy(synth.s3d_nuclei_image(S, seed=0)).to(dev).repeat(rep, rep, rep)
             r, err = guarded(lambda: run_sharded_leg(m3, bigv, "ZYX", min(args.sharded_block3d, bigv.shape[0]), 32, 32, 1, world, dist_, rank), "sharded_3d")
+            if err and args.sharded_block3d_fallback and args.sharded_block3d_fallback < args.sharded_block3d:      # (every rank fails alike: same shapes)
+                m3.__dict__.pop("_graphs", None)
+                torch.cuda.empty_cache()
+                first_err = err
+                r, err = guarded(lambda: run_sharded_leg(m3, bigv, "ZYX", min(args.sharded_block3d_fallback, bigv.shape[0]), 32, 32, 1, world, dist_, rank),
+                                 "sharded_3d (fallback block)")
+                if rank == 0 and r is not None:
+                    r["fallback_from"] = {"block_size": args.sharded_block3d, "error": first_err[:300]}
             if rank == 0 and err:
                 out["sharded_3d"] = {"error": err}
             elif rank == 0:

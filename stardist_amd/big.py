@@ -445,7 +445,7 @@ def _exclusive_intervals(blocks, axes_out):
 
 def predict_instances_sharded(model, img, axes, block_size, min_overlap, context=None, prob_thresh=None, nms_thresh=None,
                               return_labels=True, labels_out=None, show_progress=False, distributed=None, predict_kwargs=None,
-                              nms_kwargs=None, broadcast_result=True, pipeline=False):
+                              nms_kwargs=None, broadcast_result=True, keep_debug=False):
     """Block-sharded prediction with a final cross-tile NMS (SURVEY.md 8e design A, the north-star's multi-GPU path).
 
     The blocks of `BlockND.cover` (big.py:426-450) are dealt round-robin to the ranks of the default torch.distributed group
@@ -468,9 +468,8 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
     Unlike `predict_instances_big` (design B, the reference's own semantics: per-block NMS + bbox responsibility rule, no
     cross-tile NMS) label ids follow the global score order.  Per-stage wall times and counters: model._last_sharded_stats.
 
-    pipeline=True (device path, EXPERIMENTAL, off by default): the network of block k+1 runs on the main HIP stream while the local NMS of
-    block k runs on a second stream (see phase 1); measured gain 8-11 % (the two contend for the same CUs), and one of four test
-    processes returned a label image that differed from the serialised pass -- unexplained, hence not the default and not benchmarked.
+    keep_debug=True: rank 0 leaves the unique gathered records, the interior / band split and the keep mask in model._last_sharded_debug
+    (the full-size parity tests compare them with the reference NMS over the same records).
 
     Returns (labels, dict) on rank 0; (labels-or-None, dict) on the other ranks (dict None there with broadcast_result=False)."""
     import time
@@ -520,7 +519,7 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
     W = R + 1 + nd + 1 + n_cls                                      # record width
     c_prob, c_pts, c_blk, c_cls = R, R + 1, R + 1 + nd, R + 2 + nd
     st = dict(blocks=0, candidates=0, local_survivors=0, t_phase1=0.0, t_predict=0.0, t_local_nms=0.0, t_exchange=0.0, t_final=0.0, t_final_nms=0.0,
-              t_raster=0.0, gathered=0, gathered_bytes=0, unique=0, band=0, interior=0, instances=0)
+              t_raster=0.0, gathered=0, gathered_bytes=0, unique=0, band=0, interior=0, instances=0, per_block=[])
 
     def tick():
         if on_dev:
@@ -558,57 +557,24 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
         return rec
 
     mine = [bi for bi in range(len(blocks)) if bi % world == rank]
-    pipelined = bool(pipeline) and on_dev and hasattr(model, "predict_sparse_begin") and set(predict_kwargs) <= {"normalizer"} and len(mine) > 1
-    st["pipelined"] = int(pipelined)
-    if pipelined:
-        # Software pipeline over two HIP streams: while the NMS of block k runs (latency-bound integer / fp64 kernels driven by a host
-        # round loop, on `side`), the network of block k+1 (MFMA-bound, one graph replay) is already running on the main stream.
-        # t_predict / t_local_nms are then the times the HOST waited for each (they overlap on the device).
-        main = torch.cuda.current_stream(dev)
-        side = torch.cuda.Stream(device=dev)
-        t_begin = time.perf_counter()
-        fin = model.predict_sparse_begin(blocks[mine[0]].read(img, axes=axes), axes=axes, prob_thresh=prob_thresh, **predict_kwargs)
-        for k, bi in enumerate(mine):
-            t0 = time.perf_counter()
-            res = fin()                                            # selection of block k (waits for its forward pass)
-            prob, dist, points = res[0], res[1], res[-1]
-            pcls = res[2] if n_cls else None
-            ready = torch.cuda.Event()
-            ready.record(main)
-            if k + 1 < len(mine):                                   # forward pass of block k+1: enqueued, not waited for
-                fin = model.predict_sparse_begin(blocks[mine[k + 1]].read(img, axes=axes), axes=axes, prob_thresh=prob_thresh, **predict_kwargs)
-            t1 = time.perf_counter()
-            st["blocks"] += 1; st["candidates"] += int(prob.numel()); st["t_predict"] += t1 - t0
-            if prob.numel():
-                side.wait_event(ready)
-                for t in (prob, dist, points, pcls):
-                    if t is not None:
-                        t.record_stream(side)
-                with torch.cuda.stream(side):
-                    rec = block_record(bi, blocks[bi], prob, dist, points, pcls)
-                recs.append(rec)
-                st["local_survivors"] += int(rec.shape[0])
-            st["t_local_nms"] += time.perf_counter() - t1
-        main.wait_stream(side)
-        for r_ in recs:
-            r_.record_stream(main)
-        st["t_phase1"] = tick() - t_begin
-    else:
-        for bi in mine:
-            block = blocks[bi]
-            t0 = tick()
-            x = block.read(img, axes=axes)
-            res = (model.predict_sparse_device if on_dev else model.predict_sparse)(x, axes=axes, prob_thresh=prob_thresh, **predict_kwargs)
-            prob, dist, points = as_t(res[0]), as_t(res[1]), as_t(res[-1])
-            pcls = as_t(res[2]) if n_cls else None
-            t1 = tick()
-            st["blocks"] += 1; st["candidates"] += int(prob.numel()); st["t_predict"] += t1 - t0
-            if prob.numel() == 0:
-                continue
-            rec = block_record(bi, block, prob, dist, points, pcls)
-            recs.append(rec)
-            st["local_survivors"] += int(rec.shape[0]); st["t_local_nms"] += tick() - t1
-        st["t_phase1"] = st["t_predict"] + st["t_local_nms"]
+    for bi in mine:
+        block = blocks[bi]
+        t0 = tick()
+        x = block.read(img, axes=axes)
+        res = (model.predict_sparse_device if on_dev else model.predict_sparse)(x, axes=axes, prob_thresh=prob_thresh, **predict_kwargs)
+        prob, dist, points = as_t(res[0]), as_t(res[1]), as_t(res[-1])
+        pcls = as_t(res[2]) if n_cls else None
+        t1 = tick()
+        st["blocks"] += 1; st["candidates"] += int(prob.numel()); st["t_predict"] += t1 - t0
+        if prob.numel() == 0:
+            st["per_block"].append((bi, round(t1 - t0, 5), 0.0))
+            continue
+        rec = block_record(bi, block, prob, dist, points, pcls)
+        recs.append(rec)
+        t2 = tick()
+        st["local_survivors"] += int(rec.shape[0]); st["t_local_nms"] += t2 - t1
+        st["per_block"].append((bi, round(t1 - t0, 5), round(t2 - t1, 5)))
+    st["t_phase1"] = st["t_predict"] + st["t_local_nms"]
     rec = torch.cat(recs) if recs else torch.zeros((0, W), dtype=torch.float32, device=dev)
 
     # ---- phase 2: one gather of the records to rank 0 (counts first; padded to the largest rank)
@@ -675,6 +641,9 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
         so = _argsort_desc(rec[:, c_prob])                          # the order predict_instances' NMS works in and returns
         final = rec[so[keep_mask[so]]].contiguous()
         st["instances"] = int(final.shape[0])
+        if keep_debug:                                              # the parity tests' view of the exchange: the unique gathered records
+            model._last_sharded_debug = dict(dist=rec[:, :R], prob=rec[:, c_prob], points=pts, block=rec[:, c_blk], interior=interior,
+                                             keep=keep_mask, order=so)
     if multi and (return_labels or broadcast_result):               # the final instances to every rank (M x record)
         m = torch.tensor([final.shape[0] if rank == 0 else 0], dtype=torch.int64, device=cdev)
         dist_.broadcast(m, src=0)

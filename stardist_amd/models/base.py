@@ -20,6 +20,7 @@ import numpy as np
 
 from ..lib import _native as N
 from ..nms import _ind_prob_thresh
+from ..utils import to_device
 
 
 def axes_check_and_normalize(axes, length=None):
@@ -392,9 +393,9 @@ class StarDistBase(object):
             # csbdeep Normalizer protocol: .before(x, axes) on the host array
             x_host = _permute_axes(np.asarray(img))
             x_host = normalizer.before(x_host, axes_net)
-            x = torch.as_tensor(np.ascontiguousarray(x_host), device=self.device)
+            x = to_device(x_host, self.device)
         else:
-            x = img if N.is_torch(img) else torch.as_tensor(np.ascontiguousarray(img), device=self.device)
+            x = img if N.is_torch(img) else to_device(img, self.device)
             x = _permute_axes(x.to(self.device))
         channel = axes_dict(axes_net)["C"]
         if self.config.n_channel_in != x.shape[channel]:
@@ -622,18 +623,6 @@ class StarDistBase(object):
         if self._is_multiclass():
             return proba, dista, prob_classa[idx], pointsa
         return proba, dista, pointsa
-
-    def predict_sparse_begin(self, img, prob_thresh=None, axes=None, normalizer=None, b=2):
-        """Two-phase predict_sparse_device for software pipelining (stardist_amd/big.py): ENQUEUES normalisation, padding and the
-        network's forward pass (one HIP graph replay) on torch's current stream without waiting for it, and returns `finish`;
-        finish() does the candidate selection (its candidate count is the first host synchronisation) and returns what
-        predict_sparse_device returns.  The forward pass writes into the graph's static output buffers: call finish() before the
-        next predict_sparse_begin / predict* on this model."""
-        if prob_thresh is None: prob_thresh = self.thresholds.prob
-        x, axes, axes_net, axes_net_div_by, resizer, n_tiles, grid, grid_dict, channel = self._predict_setup(img, axes, normalizer, None)
-        res = self._net_forward(x, sparse_head=True)
-        head_mode = self._head_mode
-        return lambda: self._sparse_finish(res, head_mode, x, resizer, axes_net, prob_thresh, b)
 
     def predict_sparse(self, *args, **kwargs):
         r = None
