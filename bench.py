@@ -382,12 +382,12 @@ def main():
     ap.add_argument("--sharded-size", type=int, default=16384)
     ap.add_argument("--sharded-size3d", type=int, default=1024)
     # block sizes (read size incl. context, as in the reference's BlockND.cover), chosen so that the block count divides by 8:
-    # 4480 -> 16 blocks of the 16384^2 slide (1.20x the slide's pixels); 544 -> 8 blocks of the 1024^3 volume (1.20x its voxels; the
-    # 128-channel features of one block are 82 GB of the 288 GB) -- round 3 used 27 blocks of 416^3 (1.81x, 4/3/3/.. blocks per rank at N = 8).
-    # Should the 544^3 block not fit, the leg falls back to 64 blocks of 288^3 (1.42x) and says so.
-    ap.add_argument("--sharded-block", type=int, default=4480)
-    ap.add_argument("--sharded-block3d", type=int, default=544)
-    ap.add_argument("--sharded-block3d-fallback", type=int, default=288)
+    # 4416 -> 16 blocks of the 16384^2 slide (1.16x the slide's pixels, the smallest 4 x 4 cover); 560 -> 8 blocks of the 1024^3 volume
+    # (1.31x its voxels, the smallest 2 x 2 x 2 cover; the 128-channel features of one block are 90 GB of the 288 GB) -- round 3 used 27
+    # blocks of 416^3 (1.81x, 4/3/3/.. blocks per rank at N = 8).  Should the 560^3 block not fit, the leg falls back to those and says so.
+    ap.add_argument("--sharded-block", type=int, default=4416)
+    ap.add_argument("--sharded-block3d", type=int, default=560)
+    ap.add_argument("--sharded-block3d-fallback", type=int, default=416)
     ap.add_argument("--skip-sharded-3d", action="store_true")
     ap.add_argument("--no-split-leg", "--no-exact-leg", dest="no_split_leg", action="store_true",
                     help="skip the extra legs with the exact-f32 and the six-product bf16 convolution kernels")

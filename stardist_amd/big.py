@@ -613,7 +613,9 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
             ks, ki = torch.sort(key, stable=True)
             first = torch.ones_like(ks, dtype=torch.bool)
             first[1:] = ks[1:] != ks[:-1]
-            sel = torch.sort(ki[first])[0]
+            # ... and the records in row-major pixel order: candidates of EQUAL score are then taken by every later sort (stable
+            # ascending, reversed: nms._argsort_desc) in the order predict_instances on the whole image takes them, whatever the blocks
+            sel = ki[first]
             rec, pts = rec[sel], pts[sel]
         nU = int(rec.shape[0])
         st["unique"] = nU

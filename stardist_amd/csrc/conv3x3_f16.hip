@@ -11,11 +11,11 @@
 //
 // Same decomposition as the other two kernels (8 x 32 output tile, 32 output channels per workgroup, (chunk, kz) units walked as three
 // sub-units, persistent workgroups, halo tile prefetched through registers: conv3x3_device.h).  What the smaller footprint buys:
-//   * 73.5 KiB of LDS per workgroup (two 12-KiB weight buffers + the 47.8-KiB two-plane tile) and <= 256 registers per lane, so TWO
+//   * 79.8 KiB of LDS per workgroup (two 12-KiB weight buffers + the 47.8-KiB two-plane tile + 8 KiB) and <= 256 registers per lane, so TWO
 //     workgroups share a CU (two waves per SIMD): while one wave waits for a barrier, for its halo or for the LDS, the other one
 //     feeds the matrix pipe.  The bf16 kernel (137 KiB, one wave per SIMD) had the matrix pipe idle 46 % of the time.
-//   * the epilogue stores straight from the accumulators (32 global_store_dword per wave and tile, each covering two pixels' 128
-//     contiguous bytes) -- the transposing scratch of the other kernels (32 KiB) would not fit twice.
+//   * the epilogue transposes a tile through a wave-private 2-KiB scratch in four rounds (the other kernels' 32-KiB scratch would not
+//     fit twice), so that a lane stores 16 bytes of one pixel's channels.
 // Range: an activation beyond the fp16 range (|x| > 65504) cannot be split; the kernel ORs a flag into *P.flag when it sees one and
 // the caller re-evaluates with the bf16 kernel (models/unet.py).  Weights are checked by the packer.
 #include <stdlib.h>
@@ -186,54 +186,62 @@ __device__ __forceinline__ void compute_sub(const char* __restrict__ tileH, cons
 #undef SD_LOAD_GROUP_H
 }
 
-// results of one tile -> HBM, straight from the accumulators: register r of lane (i, h) holds output channel i of pixel column
-// (r & 3) + 8 (r >> 2) + 4 h (acc_col): one global_store_dword covers two pixels' 128 contiguous bytes
+// Results of one tile -> HBM.  An accumulator register holds ONE channel (i) of 16 pixels (register r of lane (i, h): tile column
+// (r & 3) + 8 (r >> 2) + 4 h, conv3x3_layout.h acc_col); channels-last memory wants the 32 channels of a pixel together, and a store
+// instruction costs the memory pipeline per LANE ADDRESS, not per byte: 32 global_store_dword per wave (two pixels' 128 bytes each) took
+// 19 % of the 2D 32 -> 32 layer.  So the tile is transposed through a wave-private 2-KiB LDS scratch in four rounds of 16 pixels
+// (8 ds_write_b32 + 2 ds_read_b128 + 2 buffer_store_dwordx4 each: a lane stores 4 channels of one pixel); LDS operations of one wave
+// execute in order, so the rounds need no barrier and no wait between a round's reads and the next round's writes.
 template <bool RES>
-__device__ __forceinline__ void store_tile_direct(const Params& P, const f32x16 (&acc0)[2], const f32x16 (&acc1)[2], int g, int tz, int ty, int tx,
-                                                  int wave, int lane) {
+__device__ __forceinline__ void store_tile(const Params& P, const f32x16 (&acc0)[2], const f32x16 (&acc1)[2], float* __restrict__ scr, int g, int tz,
+                                           int ty, int tx, int wave, int lane) {
   const int i = lane & 31, h = lane >> 5;
-  const bool xfull = tx + TW <= P.W;
-  // buffer stores: one resource per output row (wave-uniform), 32-bit offsets inside the row
+  const int px = lane >> 3, c4 = lane & 7;                      // as a reader: this lane's pixel within a chunk's 8, its channel quad
   const unsigned pix_bytes = (unsigned)P.c_out * 4u, res_bytes = (unsigned)P.res_stride * 4u;
-  const unsigned off0 = (unsigned)(tx + 4 * h) * pix_bytes + (unsigned)(g * 32 + i) * 4u;
-  const unsigned roff0 = (unsigned)(tx + 4 * h) * res_bytes + (unsigned)(g * 32 + i) * 4u;
+  const unsigned chan_off = (unsigned)(g * 32 + c4 * 4) * 4u;
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const int y = ty + wave * 2 + p;
     if (y >= P.H) continue;                                            // (wave-uniform)
     const size_t row = ((size_t)tz * P.H + y) * P.W;
+    // buffer stores: one resource per output row (wave-uniform), 32-bit offsets inside the row; a pixel beyond the end of the row lies
+    // outside the resource and the hardware drops the store (partial last tile column)
     const __amdgpu_buffer_rsrc_t ro =
         __builtin_amdgcn_make_buffer_rsrc((void*)uniform64((unsigned long long)(P.out + row * P.c_out)), 0, (int)((unsigned)P.W * pix_bytes), 0x00020000);
-    float v[16];
+    __amdgpu_buffer_rsrc_t rr = ro;
+    if (RES && P.res)
+      rr = __builtin_amdgcn_make_buffer_rsrc((void*)uniform64((unsigned long long)(P.res + row * P.res_stride)), 0, (int)((unsigned)P.W * res_bytes), 0x00020000);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = acc0[p][r] + acc1[p][r] * 4.8828125e-4f;      // 2^-11
-    if (RES && P.res) {
-      const __amdgpu_buffer_rsrc_t rr =
-          __builtin_amdgcn_make_buffer_rsrc((void*)uniform64((unsigned long long)(P.res + row * P.res_stride)), 0, (int)((unsigned)P.W * res_bytes), 0x00020000);
+    for (int q = 0; q < 2; ++q) {                                      // columns 16 q .. 16 q + 15
 #pragma unroll
-      for (int r = 0; r < 16; ++r)          // (a pixel beyond the row's end reads zero and is not stored)
-        v[r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)(roff0 + (unsigned)((r & 3) + 8 * (r >> 2)) * res_bytes), 0, 0));
-    }
+      for (int r8 = 0; r8 < 8; ++r8) {
+        const int r = q * 8 + r8;
+        const int pl = (r8 & 3) + 8 * (r8 >> 2) + 4 * h;               // pixel within the round's 16
+        scr[pl * 32 + i] = acc0[p][r] + acc1[p][r] * 4.8828125e-4f;    // 2^-11
+      }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (P.act == 1) v[r] = fmaxf(v[r], 0.f);
-      // a pixel beyond the end of the row lies outside the resource: the hardware drops the store (partial last tile column)
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), ro, (int)(off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * pix_bytes), 0, 0);
+      for (int n = 0; n < 2; ++n) {
+        v4f v = *(const v4f*)(scr + n * 256 + lane * 4);
+        const unsigned x = (unsigned)(tx + q * 16 + n * 8 + px);
+        if (RES && P.res) v += __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(x * res_bytes + chan_off), 0, 0));
+        if (P.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, (int)(x * pix_bytes + chan_off), 0, 0);
+      }
     }
   }
-  (void)xfull;
 }
 
-// TWO workgroups per CU (73.5 KiB of LDS each, <= 256 registers per lane): two waves per SIMD
+// TWO workgroups per CU (79.8 KiB of LDS each, <= 256 registers per lane): two waves per SIMD
 // (WPE = 1: the same code compiled for one wave per SIMD -- 512 registers -- as the A/B partner of option conv_f16_workgroups_per_cu = 1)
 template <bool RES, int WPE>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_conv3_f16(const Params P) {
   extern __shared__ float4 smem4h[];
-  // LDS map (bytes): two weight buffers of one sub-unit each | halo tile, 2 fp16 planes
+  // LDS map (bytes): two weight buffers of one sub-unit each | halo tile, 2 fp16 planes | 4 x 2 KiB wave-private epilogue scratch
   char* W = (char*)smem4h;
   char* tileH = W + 2 * HWSUB_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* scr = (float*)(tileH + HTILE_BYTES) + wave * 512;
   int g, q, Q;
   wg_slot(P, g, q, Q);
   if (q >= P.n_tiles) return;
@@ -329,7 +337,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WP
       PROF(10);
       PROF_UNIT();
     }
-    store_tile_direct<RES>(P, acc0, acc1, g, Tc.tz, Tc.ty0 + 1, Tc.tx0 + 1, wave, lane);
+    store_tile<RES>(P, acc0, acc1, scr, g, Tc.tz, Tc.ty0 + 1, Tc.tx0 + 1, wave, lane);
     PROF(11);
     Tc = Tn;
   }
@@ -416,7 +424,7 @@ extern "C" int sd_conv3_f16x3_res_ndhwc_device(const float* d_src0, int c0, int 
   static int n_cu[16] = {};
   int dev = 0;
   SD_CHECK(hipGetDevice(&dev));
-  const size_t lds = (size_t)2 * HWSUB_BYTES + HTILE_BYTES;               // 71.8 KiB: two workgroups per CU
+  const size_t lds = (size_t)2 * HWSUB_BYTES + HTILE_BYTES + 4 * 2048;    // 79.8 KiB: two workgroups per CU
   if (dev >= 16 || !attr_set[dev]) {
     SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -26,10 +26,18 @@ def polyhedron_to_label(dist, points, rays, shape, prob=None, thr=-np.inf, label
     """geom3d.py:100-198: filters prob >= thr, sorts by descending prob, paints first-writer-wins.
     window = ((z0, y0, x0), (nz, ny, nx)) (device tensors): only that part of the volume is rendered and returned."""
     from ..lib.stardist3d import c_polyhedron_to_label
+
+    def _empty():
+        """geom3d.py:128-131: a background-only uint16 image -- of the WINDOW (device tensor, like every windowed result) when one is asked for"""
+        if window is None:
+            return np.zeros(shape, np.uint16)
+        import torch
+        dev = dist.device if N.is_torch(dist) else (points.device if N.is_torch(points) else "cpu")
+        return torch.zeros(tuple(int(v) for v in window[1]), dtype=torch.int32, device=dev)
     if len(points) == 0:
         if verbose:
             print("warning: empty list of points (returning background-only image)")
-        return np.zeros(shape, np.uint16)
+        return _empty()
     modes = {"full": 0, "kernel": 1, "hull": 2, "bbox": 3, "debug": 4}
     if mode not in modes:
         raise KeyError("Unknown render mode '%s' , allowed:  %s" % (mode, tuple(modes.keys())))
@@ -48,7 +56,7 @@ def polyhedron_to_label(dist, points, rays, shape, prob=None, thr=-np.inf, label
         ind = torch.where(prob >= thr)[0]
         if len(ind) == 0:
             if verbose: print("warning: no points found with probability>= {thr:.4f} (returning background-only image)".format(thr=thr))
-            return np.zeros(shape, np.uint16)
+            return _empty()
         prob, points, dist, labels = prob[ind], points[ind], dist[ind], labels[ind]
         ind = torch.flip(torch.sort(prob, stable=True)[1], dims=(0,))
         points, dist, labels = points[ind], dist[ind], labels[ind]

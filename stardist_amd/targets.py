@@ -4,7 +4,8 @@ call per sample -- `edt_prob` and `star_dist` / `star_dist3D` -- as HIP kernels 
 Mirror of the target part of StarDistData2D.__getitem__ / StarDistData3D.__getitem__ (stardist/models/model2d.py:63-104,
 model3d.py:66-104) without shape completion:
     negative labels -> background, remembered in `mask_neg_labels` (loss disabled there: prob = -1)
-    prob          = edt_prob(lbl[b][::grid])                       (object probability, ..., 1)
+    prob          = edt_prob(lbl[b][::grid])  in 2D                (model2d.py:86: subsampled first, then the distance transform)
+                    edt_prob(lbl, anisotropy)[b][::grid]  in 3D    (model3d.py:88: the distance transform at FULL resolution, then subsampled)
     dist          = star_dist(lbl, n_rays, grid=grid)              (radial distances, ..., n_rays)
     dist_and_mask = [dist | prob]                                  (..., n_rays + 1: the mask channel weights the distance loss)
 The training loop itself (losses, optimiser, augmentation, patch sampling) is out of scope."""
@@ -30,7 +31,10 @@ def stardist_targets(labels, n_rays=32, grid=None, rays=None, b=None, anisotropy
     neg = np.stack([y[b][ss] < 0 for y in Y])
     if neg.any():
         Y = [np.maximum(y, 0) for y in Y]
-    prob = np.stack([edt_prob(y[b][ss], anisotropy=anisotropy) for y in Y])
+    if nd == 2:
+        prob = np.stack([edt_prob(y[b][ss], anisotropy=anisotropy) for y in Y])
+    else:                       # StarDistData3D: EDT of the whole volume first, border crop and grid subsampling second (model3d.py:88)
+        prob = np.stack([edt_prob(y, anisotropy=anisotropy)[b][ss] for y in Y])
     if nd == 2:
         dist = np.stack([star_dist(y, n_rays, grid=grid, mode="hip")[b] for y in Y]) if b == (slice(None),) * nd else \
             np.stack([star_dist(y, n_rays, mode="hip")[b + (slice(None),)][ss] for y in Y])

@@ -249,6 +249,51 @@ def test_sharded_cross_tile_nms_equals_whole_image(refmods, tmp_path):
     assert np.array_equal(np.load(mm_path), ref_labels)
 
 
+def _sharded_worker4(rank, world, port_, q, block):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port_)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stardist_amd.big import predict_instances_sharded
+    from test_cpu_big import _FieldModel, _field
+    x, _ = _field()
+    m = _FieldModel()
+    tiles, res = predict_instances_sharded(m, x, "YXC", block, 32, context=16, labels_out="local", broadcast_result=False)
+    st = dict(m._last_sharded_stats)
+    q.put((rank, None if res is None else (res["points"], res["prob"]), [(bi, tuple((s.start, s.stop) for s in sl), t.numpy()) for bi, sl, t in tiles], st))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("block,n_blocks", [(120, 9), (128, 6)])
+def test_sharded_gloo_world4_uneven_block_counts(refmods, block, n_blocks):
+    """four ranks, block counts that do not divide by four (9 -> 3/2/2/2, 6 -> 2/2/1/1): the form bench.py runs at N > 1 (owner-side
+    tiles, result dict on rank 0 only) equals predict_instances on the whole image, and every block is rendered by exactly its owner"""
+    import torch.multiprocessing as mp
+    m = _FieldModel()
+    x, lbl = _field()
+    p, d, pts = m.predict_sparse(x)
+    ref_labels, ref_res = m._instances_from_prediction(x.shape[:2], p, d, points=pts)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port_ = 29850 + (os.getpid() + block) % 60
+    procs = [ctx.Process(target=_sharded_worker4, args=(r, 4, port_, q, block)) for r in range(4)]
+    for pr in procs: pr.start()
+    out = [q.get(timeout=300) for _ in range(4)]
+    for pr in procs: pr.join(60)
+    seen = {}
+    for rank, res, tiles, st in out:
+        assert (res is None) == (rank != 0)
+        if rank == 0:
+            assert np.array_equal(res[0], ref_res["points"]) and np.allclose(res[1], ref_res["prob"])
+            assert st["instances"] == len(ref_res["prob"]) and st["band"] + st["interior"] == st["unique"]
+        assert st["blocks"] == len([b for b in range(n_blocks) if b % 4 == rank]) == len(tiles)
+        for bi, sl, t in tiles:
+            assert bi % 4 == rank and bi not in seen and np.array_equal(t, ref_labels[tuple(slice(a, b) for a, b in sl)])
+            seen[bi] = rank
+    assert sorted(seen) == list(range(n_blocks))
+
+
 @pytest.mark.parametrize("name,axes", [("2d", "YX"), ("2dg", "YX"), ("3d", "ZYX")])
 def test_cover_crop_filter_objects_equal_reference_golden(name, axes):
     """BlockND.cover + read + crop_context + filter_objects (responsibility rule, coordinate translation) against outputs of the

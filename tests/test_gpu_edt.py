@@ -68,4 +68,10 @@ def test_training_targets_equal_reference_composition(refmods):
     lab3 = [_blobs((12, 32, 36), 6, seed=7)]
     prob, dm = stardist_targets(lab3, rays=rays, grid=(1, 2, 2), anisotropy=(2.0, 1.0, 1.0))
     assert np.array_equal(dm[0, ..., :-1], port.star_dist3D(lab3[0], rays.vertices, grid=(1, 2, 2)))
-    assert np.array_equal(prob[0, ..., 0], port.edt_prob(lab3[0][:, ::2, ::2], anisotropy=(2.0, 1.0, 1.0)))
+    # StarDistData3D computes the distance transform at FULL resolution and subsamples afterwards (model3d.py:88) -- unlike the 2D
+    # generator (model2d.py:86); the two orders differ (this used to subsample first in 3D as well)
+    want3 = port.edt_prob(lab3[0], anisotropy=(2.0, 1.0, 1.0))[:, ::2, ::2]
+    assert np.array_equal(prob[0, ..., 0], want3) and np.array_equal(dm[0, ..., -1], want3)
+    assert not np.array_equal(want3, port.edt_prob(lab3[0][:, ::2, ::2], anisotropy=(2.0, 1.0, 1.0)))
+    prob2, dm2 = stardist_targets(lab3, rays=rays, grid=(2, 2, 2))
+    assert np.array_equal(prob2[0, ..., 0], port.edt_prob(lab3[0])[::2, ::2, ::2])

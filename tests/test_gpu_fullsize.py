@@ -175,3 +175,28 @@ def test_sharded_window_tiles_equal_whole_image_raster_and_band_nms_equals_union
     finally:
         B._exclusive_intervals = orig
     assert np.array_equal(res_u["points"], res["points"]) and np.array_equal(res_u["prob"], res["prob"]) and np.array_equal(labels_u, labels)
+
+
+@pytest.mark.parametrize("dim", ["2d", "3d"])
+def test_sharded_prediction_without_detections(dim):
+    """an input on which nothing passes the probability threshold: every form of the label output is background of the right shape
+    (the windowed 3D rasteriser used to return a host array of the WHOLE volume on its empty paths)"""
+    import torch
+    from stardist_amd.models import Config2D, Config3D, StarDist2D, StarDist3D
+    dev = torch.device("cuda:0")
+    if dim == "3d":
+        model = StarDist3D(Config3D(rays=96), basedir=None, device=dev, seed=0)
+        img = np.zeros((64, 64, 96), np.float32)
+        args = dict(axes="ZYX", block_size=48, min_overlap=16, context=8)
+    else:
+        model = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
+        img = np.zeros((256, 384), np.float32)
+        args = dict(axes="YX", block_size=128, min_overlap=32, context=32)
+    with torch.no_grad():
+        model.net.prob.bias.fill_(-20.0)                 # sigmoid(-20): nothing above any threshold
+    labels, res = model.predict_instances_sharded(img, **args)
+    assert labels.shape == img.shape and not np.asarray(labels).any() and len(res["prob"]) == 0
+    tiles, res2 = model.predict_instances_sharded(img, labels_out="local", **args)
+    assert len(res2["prob"]) == 0 and len(tiles) == model._last_sharded_stats["blocks"]
+    for bi, sl, t in tiles:
+        assert torch.is_tensor(t) and tuple(t.shape) == tuple(s.stop - s.start for s in sl) and not bool(t.any())

@@ -16,14 +16,14 @@ def test_conv_bias_act_fused_equals_plain(nd, act, cl):
     m = _conv(nd, 5, 12, 3, act).to(dev)
     with torch.no_grad():
         m[0].bias.normal_()
-        x = torch.randn((2, 5, 33, 47) if nd == 2 else (1, 5, 9, 17, 21), device=dev)
+        x = torch.randn((1, 5, 33, 47) if nd == 2 else (1, 5, 9, 17, 21), device=dev)
         if cl:
             fmt = torch.channels_last if nd == 2 else torch.channels_last_3d
             x = x.contiguous(memory_format=fmt); m = m.to(memory_format=fmt)
         y_fused = m(x)
         y_plain = nn.Sequential.forward(m, x)
     assert y_fused.shape == y_plain.shape
-    # two separate convolution launches (MIOpen may pick an atomics-based solver): identical up to float summation order
+    # hand-written layer (general kernel: 5 -> 12 channels) against the framework's convolution + bias + activation (test-side comparator)
     assert torch.allclose(y_fused, y_plain, rtol=1e-5, atol=1e-5)
     if act == "relu":
         assert float(y_fused.min()) >= 0.0
