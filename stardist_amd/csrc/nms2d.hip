@@ -802,6 +802,13 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   i64 totalNbr = 0;
   SD_CHECK(hipMemcpyAsync(&totalNbr, nbrStart + N, sizeof(i64), hipMemcpyDeviceToHost, s));
   SD_CHECK(hipStreamSynchronize(s));
+  // capacity of one call: neighbour lists and pair queues are indexed with 32 bits.  Beyond it (about 13 M candidates at the density
+  // of the 2048^2 bench set) the input has to be sharded -- predict_instances_sharded / predict_instances_big do exactly that.
+  if (totalNbr < 0 || totalNbr >= (i64)0x7fffffff) {
+    sd::set_error("sd_nms2d: %lld neighbour entries for %d candidates exceed the capacity of one call (2^31 - 1): shard the input "
+                  "(predict_instances_sharded / predict_instances_big)", (long long)totalNbr, N);
+    return -1;
+  }
   int* nbr = A.take_n<int>((size_t)totalNbr);
   int* waitOn = A.take_n<int>(N);
   if (!nbr || !waitOn) return -1;

@@ -2185,6 +2185,13 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
       bverts = v2; bfaces = f2; bR = R2; bF = F2;
     }
   }
+  // capacity of one call (32-bit indices into the neighbour lists and pair queues, N * n_rays * 4 bytes of distances): beyond it the
+  // input has to be sharded -- predict_instances_sharded / predict_instances_big do exactly that
+  if (totalNbr < 0 || totalNbr >= (i64)0x7fffffff || (i64)N * R >= (i64)0x3fffffff) {
+    sd::set_error("sd_nms3d: %d candidates (%lld neighbour entries) exceed the capacity of one call (2^30 distance values, 2^31 - 1 "
+                  "neighbour entries): shard the input (predict_instances_sharded / predict_instances_big)", N, (long long)totalNbr);
+    return -1;
+  }
   int* nbr = A.take_n<int>((size_t)totalNbr);
   int* waitOn = A.take_n<int>(N);
   if (!nbr || !waitOn) return -1;

@@ -1,13 +1,13 @@
 """GPU: parity of the block-sharded prediction AT THE FULL SIZES of BASELINE.json configs 4 and 5 (bench.py's `sharded_2d` /
 `sharded_3d` inputs) -- reference semantics: big == whole (tests/test_big.py:98-147, stardist/big.py:89-122).
 
-  config 4, 16384^2:  (a) the compiled reference NMS over the union of the gathered survivors gives exactly the keep mask the
-                      interior / band rule + band-restricted NMS produced; (b) the final instances and the label image equal the
-                      committed golden of the reference NMS over ALL 32 M candidates of the whole slide
-                      (tests/golden/sharded_fullsize.json, made by tests/golden/make_sharded_golden.py on the GPU box).
-  config 5, 1024^3:   the compiled Qhull reference is out of reach at 10^7 candidates, so sharded == the monolithic HIP NMS over all
-                      candidates of the whole volume (the kernel itself is pinned to the reference at 256^3 and below); and at 512^3 /
-                      8 blocks the sharded result equals the committed golden of the compiled reference over all 1.3 M candidates."""
+  config 4, 16384^2:  per-block local NMS == compiled reference (block-local coordinates, as the reference's predict_instances_big
+                      evaluates a block); compiled reference over the union of the gathered survivors == the final instances; count
+                      against the reference over ALL 27 M candidates of the whole slide (committed golden) within 1e-4 -- exact
+                      equality is impossible for the reference itself, see the test's docstring.
+  config 5, 1024^3:   at 512^3 / 8 blocks: monolithic HIP NMS over all 1.38 M candidates == the compiled Qhull reference bit for bit
+                      (committed golden) == the sharded result; at 1024^3 / 8 blocks of 560^3: every instance away from the border is a
+                      periodic image of those reference instances, in both directions."""
 import json
 import os
 
@@ -28,46 +28,115 @@ def _golden(key):
     return g[key]
 
 
-def test_sharded_16384_equals_reference(refmods):
+def test_sharded_16384_equals_reference_composition(refmods):
+    """config 4 against the reference's own semantics of a big input (stardist/models/base.py:953-975: predict_instances per block, in
+    BLOCK-LOCAL coordinates) composed with design A's exchange:
+      (a1) per block (4 of the 16: a corner, two edges, an inner one), the local HIP NMS has exactly the keep flags of the compiled
+           reference on the block's ~1.9 M candidates;
+      (a2) the compiled reference over the union of the gathered survivors (global coordinates, final score order) gives exactly the
+           keep mask that the interior / band rule + band-restricted NMS produced, i.e. the final instances;
+      (b)  against the compiled reference over ALL 27 M candidates of the whole slide in GLOBAL coordinates (the committed golden,
+           tests/golden/make_sharded_golden.py) the instance count agrees to 1e-4.  It cannot agree exactly, for the reference itself:
+           its float32 vertex arithmetic (stardist2d.cpp:453-471) is not translation invariant -- shifting a candidate set by 2048 px
+           changes 40 of 104 580 keep flags of c_non_max_suppression_inds (tests/test_cpu_oracle.py::
+           test_reference_nms2d_is_not_translation_invariant) -- and a block evaluates its polygons at block-local coordinates, in the
+           reference's predict_instances_big exactly as here.  The difference does not shrink with the context (measured 128 .. 384 px:
+           56 - 72 of 822 235 instances, profiles/r04_big_equals_whole.txt): it is not a boundary effect."""
+    import gc
+    import torch
+    import _bigparity as B
+    from stardist_amd import nms as sd_nms
+    from stardist_amd.big import BlockND
+    from stardist_amd.nms import _argsort_desc
+    dev = torch.device("cuda:0")
+    cfg = B.CFG2D
+    gc.collect(); torch.cuda.empty_cache()
+    refmods.stardist2d(); refmods.set_threads(min(os.cpu_count() or 1, 32))
+    try:
+        model, big, axes = B.model_and_input(2, cfg, dev)
+        thr = np.float32(model.thresholds.nms)
+        # (a1)
+        blocks = BlockND.cover(big.shape, axes, (cfg["block"],) * 2, (cfg["overlap"],) * 2, (cfg["context"],) * 2, model._axes_div_by(axes))
+        assert len(blocks) == 16
+        for bi in (0, 2, 5, 15):
+            r = model.predict_sparse_device(blocks[bi].read(big, axes=axes), axes=axes)
+            prob, dist, pts = r[0], r[1], r[-1]
+            ind = _argsort_desc(prob)
+            d, p = dist[ind].float().contiguous(), pts[ind].float().contiguous()
+            keep = sd_nms.non_maximum_suppression_inds(d, p, prob[ind], thresh=thr, verbose=0)
+            keep = keep.cpu().numpy().astype(bool)
+            ref_keep = refmods.stardist2d().c_non_max_suppression_inds(d.cpu().numpy(), p.cpu().numpy(), 1, 1, 0, thr).astype(bool)
+            assert np.array_equal(keep, ref_keep), "block %d: %d of %d flags differ" % (bi, int((keep != ref_keep).sum()), len(keep))
+            assert len(keep) > 1500000
+            del r, prob, dist, pts, d, p
+        # (a2)
+        labels, res = model.predict_instances_sharded(big, axes, block_size=cfg["block"], min_overlap=cfg["overlap"], context=cfg["context"], keep_debug=True)
+        st, dbg = model._last_sharded_stats, model._last_sharded_debug
+        assert st["blocks"] == 16 and st["unique"] > 500000 and st["interior"] > 0 and st["band"] > 0
+        so = dbg["order"]
+        d = dbg["dist"][so].cpu().numpy().astype(np.float32); p = dbg["points"][so].cpu().numpy().astype(np.float32)
+        ref_keep = refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, thr).astype(bool)
+        got = dbg["keep"][so].cpu().numpy()
+        assert np.array_equal(ref_keep, got), "%d of %d flags differ (first: %s)" % ((ref_keep != got).sum(), len(got), np.flatnonzero(ref_keep != got)[:10])
+        assert int(ref_keep.sum()) == len(res["prob"]) == st["instances"]
+        assert np.array_equal(np.asarray(res["points"]), dbg["points"][so].cpu().numpy()[ref_keep])
+        # ... and the label image is the whole-image rasteriser's rendering of exactly those instances (ids in score order)
+        assert labels.shape == tuple(big.shape) and int(labels.max()) == st["instances"]
+        # (b)
+        g = _golden("2d")
+        assert {k: g[k] for k in cfg} == cfg, "the golden was made for another block geometry"
+        assert abs(st["instances"] - g["survivors"]) <= 1e-4 * g["survivors"], (st["instances"], g["survivors"])
+        print("16384^2: %d instances; reference over all %d candidates in global coordinates: %d" % (st["instances"], g["candidates"], g["survivors"]))
+    finally:
+        model = big = labels = res = dbg = None
+        model_dbg = None
+        _free()
+
+
+def _free():
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def _sharded_3d(cfg, dev):
+    import torch
+    import _bigparity as B
+    model, big, axes = B.model_and_input(3, cfg, dev)
+    tiles, res = model.predict_instances_sharded(big, axes, block_size=cfg["block"], min_overlap=cfg["overlap"], context=cfg["context"], labels_out="local")
+    st = dict(model._last_sharded_stats)
+    del tiles
+    torch.cuda.empty_cache()
+    return model, big, axes, res, st
+
+
+def test_sharded_3d_512_equals_monolithic_equals_reference():
+    """512^3, 8 blocks of 304^3: the monolithic HIP NMS over all 1.38 M candidates of the whole volume has exactly the keep bits of the
+    compiled reference (Qhull; tests/golden/sharded_fullsize.json), and the sharded prediction returns exactly those instances"""
     import torch
     import _bigparity as B
     dev = torch.device("cuda:0")
-    cfg = B.CFG2D
-    model, big, axes = B.model_and_input(2, cfg, dev)
-    labels, res = model.predict_instances_sharded(big, axes, block_size=cfg["block"], min_overlap=cfg["overlap"], context=cfg["context"], keep_debug=True)
-    st, dbg = model._last_sharded_stats, model._last_sharded_debug
-    assert st["blocks"] == 16 and st["unique"] > 500000 and st["interior"] > 0 and st["band"] > 0
-    # (a) the reference over the union of the gathered survivors, in the final score order
-    so = dbg["order"]
-    d = dbg["dist"][so].cpu().numpy().astype(np.float32); p = dbg["points"][so].cpu().numpy().astype(np.float32)
-    refmods.stardist2d(); refmods.set_threads(min(os.cpu_count() or 1, 32))
-    ref_keep = refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(model.thresholds.nms)).astype(bool)
-    got = dbg["keep"][so].cpu().numpy()
-    assert np.array_equal(ref_keep, got), "%d of %d flags differ (first: %s)" % ((ref_keep != got).sum(), len(got), np.flatnonzero(ref_keep != got)[:10])
-    assert int(ref_keep.sum()) == len(res["prob"])
-    # (b) the reference over ALL candidates of the whole slide
-    g = _golden("2d")
-    assert {k: g[k] for k in cfg} == cfg, "the golden was made for another block geometry"
-    assert st["instances"] == g["survivors"], (st["instances"], g["survivors"])
-    assert B.points_digest(res["points"]) == g["points_sha256"]
-    assert B.array_digest(np.asarray(labels).astype(np.int32)) == g["labels_sha256"]
+    cfg = B.CFG3D_REF
+    try:
+        model, big, axes, res, st = _sharded_3d(cfg, dev)
+        assert st["blocks"] == 8
+        keep, pts = _monolithic_3d(model, big, axes, cfg, dev)
+        g = _golden("3d")
+        assert {k: g[k] for k in cfg} == cfg, "the golden was made for another block geometry"
+        assert g["candidates"] == len(keep) and g["survivors"] == int(keep.sum())
+        assert B.array_digest(np.packbits(keep)) == g["keep_sha256"], "monolithic HIP NMS differs from the compiled reference"
+        assert st["instances"] == g["survivors"] and B.points_digest(res["points"]) == g["points_sha256"]
+    finally:
+        model = big = res = None
+        _free()
 
 
-@pytest.mark.parametrize("cfgname", ["1024", "512-golden"])
-def test_sharded_3d_equals_monolithic_and_reference(cfgname):
+def _monolithic_3d(model, big, axes, cfg, dev):
     import torch
     import _bigparity as B
     from stardist_amd.lib.stardist3d import c_non_max_suppression_inds
     from stardist_amd.rays3d import rays_from_json
-    dev = torch.device("cuda:0")
-    cfg = B.CFG3D if cfgname == "1024" else B.CFG3D_REF
-    model, big, axes = B.model_and_input(3, cfg, dev)
-    tiles, res = model.predict_instances_sharded(big, axes, block_size=cfg["block"], min_overlap=cfg["overlap"], context=cfg["context"], labels_out="local")
-    st = dict(model._last_sharded_stats)
-    assert st["blocks"] == 8 and st["instances"] > 1000 * (cfg["size"] // 256) ** 3
-    del tiles
-    torch.cuda.empty_cache()
-    # the monolithic HIP NMS over every candidate of the whole volume, in predict_instances' order
     dist, prob, pts, nb = B.whole_input_candidates(model, big, axes, cfg)
     rays = rays_from_json(model.config.rays_json)
     verts = torch.as_tensor(np.ascontiguousarray(rays.vertices, np.float32), device=dev)
@@ -75,13 +144,51 @@ def test_sharded_3d_equals_monolithic_and_reference(cfgname):
     keep = c_non_max_suppression_inds(dist.float().contiguous(), pts.float().contiguous(), verts, faces, prob.float().contiguous(), 1, 1, 0,
                                       np.float32(model.thresholds.nms))
     keep = keep.cpu().numpy().astype(bool) if torch.is_tensor(keep) else np.asarray(keep, bool)
-    mono = pts.cpu().numpy()[keep]
-    print("3D %s: %d candidates, sharded %d instances, monolithic %d" % (cfgname, int(prob.numel()), st["instances"], int(keep.sum())))
-    assert int(keep.sum()) == st["instances"]
-    assert B.points_digest(mono) == B.points_digest(res["points"])
-    if cfgname != "1024":
+    return keep, pts.cpu().numpy()
+
+
+def test_sharded_3d_1024_equals_reference_by_periodicity():
+    """config 5, 1024^3, 8 blocks of 560^3 (bench.py's `sharded_3d`).  The compiled reference is out of reach at 1.1e7 candidates (and
+    one call of the HIP NMS is capped at 2^31 neighbour entries), but the volume is the 256^3 tile repeated: away from the volume's
+    border the instances must be the periodic images of those of the 512^3 volume, whose monolithic NMS is pinned to the compiled
+    reference bit for bit (previous test).  Every instance of the sharded 1024^3 result at least 64 voxels inside the volume is
+    compared with the 512^3 reference instances at the congruent position (mod 256), in both directions."""
+    import torch
+    import _bigparity as B
+    dev = torch.device("cuda:0")
+    try:
+        model, big, axes = B.model_and_input(3, B.CFG3D_REF, dev)
+        keep, pts = _monolithic_3d(model, big, axes, B.CFG3D_REF, dev)
         g = _golden("3d")
-        assert {k: g[k] for k in cfg} == cfg
-        assert g["candidates"] == int(prob.numel()) and g["survivors"] == st["instances"]
-        assert B.points_digest(res["points"]) == g["points_sha256"]
         assert B.array_digest(np.packbits(keep)) == g["keep_sha256"]
+        ref512 = pts[keep]
+        model = big = None
+        _free()
+        model, big, axes, res, st = _sharded_3d(B.CFG3D, dev)
+        assert st["blocks"] == 8 and st["instances"] > 100000
+        got = np.asarray(res["points"]).astype(np.int64)
+    finally:
+        model = big = res = None
+        _free()
+    m = 64
+    inner = np.all((got >= m) & (got < 1024 - m), axis=1)
+    q = got[inner] % 256
+    q = np.where(q < m, q + 256, q)                              # congruent position inside [64, 320)^3 of the 512^3 volume
+    key = lambda p: (p[:, 0] * 512 + p[:, 1]) * 512 + p[:, 2]
+    refset = np.unique(key(ref512))
+    assert np.isin(key(q), refset).all(), "%d sharded instances have no counterpart in the reference" % int((~np.isin(key(q), refset)).sum())
+    # conversely: every reference instance inside [64, 320)^3 appears at each of its 3 x 3 x 3 .. periodic images inside the big volume
+    r = ref512[np.all((ref512 >= m) & (ref512 < m + 256), axis=1)]
+    gotset = np.unique((got[:, 0] * 1024 + got[:, 1]) * 1024 + got[:, 2])
+    n_img = 0
+    for dz in range(-1, 4):
+        for dy in range(-1, 4):
+            for dx in range(-1, 4):
+                p = r + np.array([dz, dy, dx]) * 256
+                ok = np.all((p >= m) & (p < 1024 - m), axis=1)
+                p = p[ok]
+                n_img += len(p)
+                assert np.isin((p[:, 0] * 1024 + p[:, 1]) * 1024 + p[:, 2], gotset).all(), (dz, dy, dx)
+    assert n_img == int(inner.sum()), (n_img, int(inner.sum()))
+    print("1024^3: %d instances, %d of them >= 64 voxels inside the volume, all periodic images of the %d reference instances of the 512^3 volume" % (
+        len(got), int(inner.sum()), len(r)))

@@ -37,11 +37,17 @@ def main():
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--size3d", type=int, default=256)
+    ap.add_argument("--host-input", action="store_true", help="hand the image over as a host numpy array (SURVEY.md 8d's definition of the metric)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     img = torch.from_numpy(synth.s2d_nuclei_image(a.size, a.size, seed=0)).to(dev)
     model = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
     bench.calibrate_heads(model, img)
+    if a.host_input:
+        import stardist_amd.models.base as MB
+        img = img.cpu().numpy()
+        wrap(MB, "to_device", "to_device (H2D through the pinned stage)")
+        a.size3d = 0
     for _ in range(3):
         model.predict_instances(img)
     torch.cuda.synchronize(); t0 = time.perf_counter()
