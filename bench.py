@@ -45,6 +45,20 @@ CONV_FORMS = {"f16x3": (3.0, MFMA_BF16_PEAK_TFLOPS, "f16"), "bf16x6": (6.0, MFMA
 # WRITE_SIZE in separate passes) writes them, together with the pair count of the profiled workload, to this json; bench.py
 # reports them as roofline.traffic only when its own pair count matches the profiled one.
 PAIR_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pair_kernel_traffic.json")
+# the same for the convolution kernel, per forward pass (tools/pmc_forward.py + tools/conv_traffic.py, profiles/r04_conv_forward.md)
+CONV_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "conv_kernel_traffic.json")
+
+
+def conv_traffic(which, mode, size, full):
+    """HBM bytes per forward pass of the convolution kernel as profiled (None when the profile is of another kernel form / size)"""
+    try:
+        with open(CONV_TRAFFIC_JSON) as fh:
+            tj = json.load(fh)[which]
+        if mode == "f16x3" and size == full:
+            return tj
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def calibrate_heads(model, img, frac=0.10, radius=10.0, noise=0.1):
@@ -465,12 +479,18 @@ def main():
                              "whole forward pass (14 conv launches + pools + head) on the caller's stream; executed_* = x%d matrix products per MAC; "
                              "for reference the f32-MFMA peak is %.1f TFLOP/s; per-kernel durations and the MFMA-busy counter: profiles/r04_*"
                              % (int(mult), MFMA_F32_PEAK_TFLOPS)}
+        ct = conv_traffic("2d", mode, H, 2048)
+        if ct:
+            roof_conv["traffic"] = ct["bytes_per_forward"]
+            roof_conv["traffic_source"] = ct["source"]
+            roof_conv["kernel_ms_per_forward_rocprof"] = ct["kernel_ms_per_forward"]
         roof_pair = {"bound": "hbm", "kernel": "k_pairs_beam<32,8,6,4,64> (bound-slot scan-beam polygon intersection, one pair per lane, state in LDS)", "achieved": round(pair_gbs, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pair_gbs / HBM_PEAK_GBS, 6), "traffic": None,
                      "bytes_per_launch": round(pair_bytes_per_launch), "avg_launch_ms": round(float(pair_ms / pair_launches), 4),
                      "launches_per_step": float(pair_launches), "pairs_per_step": float(n_pairs),
-                     "note": "integer scan-beam sweep, one pair per lane, per-pair state lane-interleaved in LDS: bound by instruction issue under lane "
-                             "divergence and by one sweep's serial latency, not by HBM; algorithmic bytes = 272 B/pair (SURVEY.md 8d)"}
+                     "note": "integer scan-beam sweep, one pair per lane, per-pair state (636 B) lane-interleaved in LDS: LATENCY-bound -- VALU issue 12.5 %, "
+                             "LDS capacity limits a CU to 256 pairs in flight (4 x 64 or 7 x 32 lanes, same time either way: option nms2d_pair_lanes) and a "
+                             "launch costs ceil(pairs / 65536) sweeps of ~0.6 ms; not HBM-bound; algorithmic bytes = 272 B/pair (SURVEY.md 8d)"}
         try:
             with open(PAIR_TRAFFIC_JSON) as fh:
                 tj = json.load(fh)
@@ -573,6 +593,10 @@ def main():
                                         "achieved": round(conv3_tf, 3), "peak": cpeak, "unit": "TFLOP/s", "frac": round(conv3_tf / cpeak, 4),
                                         "traffic": None, "flops_per_launch": flops3, "executed_products_per_mac": mult,
                                         "executed_tflops": round(conv3_tf * mult, 3), "executed_frac": round(conv3_tf * mult / cpeak, 4), "avg_ms": round(net3_ms, 3)}
+            ct3 = conv_traffic("3d", mode, S, 256)
+            if ct3:
+                out["roofline_convs_3d"]["traffic"] = ct3["bytes_per_forward"]
+                out["roofline_convs_3d"]["kernel_ms_per_forward_rocprof"] = ct3["kernel_ms_per_forward"]
             if not args.no_cpu_baseline and world == 1:
                 try:
                     cb = cpu_baseline_3d(vol_np, m3, min(args.cpu_sample3d, S), threads)

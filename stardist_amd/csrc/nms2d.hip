@@ -613,6 +613,7 @@ __global__ void __launch_bounds__(256) k_pair_bucket_scatter(const int2* __restr
   }
 }
 
+__global__ void k_count_after(unsigned int* out, const unsigned int* total, const unsigned int* first) { *out = *total > *first ? *total - *first : 0u; }
 __global__ void k_iota(int* a, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = i; }
 __global__ void k_keep(const unsigned char* __restrict__ state, unsigned char* __restrict__ keep, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -644,8 +645,18 @@ struct BeamPath {
   // tier 1 (K = 8): all pairs of the round; capacity spills -> q.spill
   static int tier1(const int2* pairs, const unsigned int* idx, const unsigned long long* nPairs, const unsigned int* first, const void* prep, const float* area,
                    float thr, unsigned char* state, unsigned char* supp, PairQueues q, hipStream_t s) {
-    static const size_t lds = beam_lds_bytes<MAXV, 8, 6, 4, 64>();
-    hipLaunchKernelGGL((k_pairs_beam<MAXV, 8, 6, 4, 64, unsigned long long>), dim3(256 * 4), dim3(64), lds, s, pairs, idx, nPairs, first, (const Prep*)prep, area, thr, state, supp, q);
+    // One pair per lane, the pair's whole sweep state (636 bytes) in LDS.  The kernel is latency-bound under lane divergence (VALU
+    // issue 12.5 % at one wave per SIMD, profiles/r03_pmc_mfma.md), and LDS capacity sets the occupancy: 64-lane workgroups hold
+    // 40.7 KB -> four waves per CU; 32-lane workgroups (the upper half of a wave stays empty) hold 20.4 KB -> eight waves per CU, two per
+    // SIMD, the same 256 pairs in flight per CU but each wave diverges over 32 sweeps instead of 64 and has a partner to overlap its
+    // LDS round trips with.  Option "nms2d_pair_lanes" (64 | 32) selects; same results.
+    if (sd::option(sd::OPT_NMS2D_PAIR_LANES) == 32) {
+      static const size_t lds32 = beam_lds_bytes<MAXV, 8, 6, 4, 32>();
+      hipLaunchKernelGGL((k_pairs_beam<MAXV, 8, 6, 4, 32, unsigned long long>), dim3(256 * 8), dim3(32), lds32, s, pairs, idx, nPairs, first, (const Prep*)prep, area, thr, state, supp, q);
+    } else {
+      static const size_t lds = beam_lds_bytes<MAXV, 8, 6, 4, 64>();
+      hipLaunchKernelGGL((k_pairs_beam<MAXV, 8, 6, 4, 64, unsigned long long>), dim3(256 * 4), dim3(64), lds, s, pairs, idx, nPairs, first, (const Prep*)prep, area, thr, state, supp, q);
+    }
     SD_LAUNCH_CHECK();
     return 0;
   }
@@ -868,6 +879,9 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
     if (!dfr.pairs || !dfr.next) return -1;
   }
   i64 nDeferred = 0;
+  bool sideGeneral = false;                   // tail batch: the deferred pairs' general-path launch runs on the helper stream
+  unsigned int* nNewExact = A.take_n<unsigned int>(1);
+  if (!nNewExact) return -1;
   // one beam-path pass over the current pair list (tier 1, tier 2, then the general path -- or its deferral); suppOut == nullptr
   // applies decisions to state (normal round), else records them per pair (tail batch, whose first *firstNew entries are the
   // deferred pairs, already queued for the general path)
@@ -907,6 +921,13 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
     if (!suppOut && deferOn) {
       hipLaunchKernelGGL(k_defer, dim3(64), dim3(256), 0, s, pairs, exactPairs, &d_cnt->nExact, qCap, dfr);
       SD_LAUNCH_CHECK();
+    } else if (suppOut && sideGeneral) {
+      // tail batch: the deferred pairs (the first nDeferred queue entries) are being evaluated on the helper stream since the batch
+      // began; here only what the two tiers added behind them, then join
+      hipLaunchKernelGGL(k_count_after, dim3(1), dim3(1), 0, s, nNewExact, &d_cnt->nExact, firstNew);
+      SD_LAUNCH_CHECK();
+      if (sd::clip_full_pairs(pairs, exactPairs + nDeferred, nNewExact, qCap - (unsigned int)nDeferred, R, vx, vy, area, threshold, state, suppOut, &d_cnt->nErr, s)) return -1;
+      SD_CHECK(hipStreamWaitEvent(s, evJoin, 0));
     } else if (sd::clip_full_pairs(pairs, exactPairs, &d_cnt->nExact, qCap, R, vx, vy, area, threshold, state, suppOut, &d_cnt->nErr, s)) return -1;
     if (stats) SD_CHECK(hipEventRecord(ev3, s));
     return 0;
@@ -935,6 +956,16 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
       SD_CHECK(hipMemsetAsync(supp, 0, pairCap, s));
       const int wg = sd::div_up(nU, 4) < 2048 ? sd::div_up(nU, 4) : 2048;
       hipLaunchKernelGGL(k_tail_init, dim3(64), dim3(256), 0, s, dfr, pairs, exactPairs, &d_cnt->nPairs, &d_cnt->nExact, firstNew);
+      // The deferred pairs all need the general path (a latency-bound launch of ~1 ms over a few thousand pairs, a fraction of the
+      // chip): it starts NOW on the helper stream, next to the emission of the remaining pairs and the two bound-slot tiers; decisions
+      // are recorded per pair (supp[]), so the two streams write disjoint bytes.  Joined in run_pairs.
+      sideGeneral = deferOn && nDeferred > 0 && nDeferred < (i64)qCap && side != nullptr;
+      if (sideGeneral) {
+        SD_CHECK(hipEventRecord(evFork, s));
+        SD_CHECK(hipStreamWaitEvent(side, evFork, 0));
+        if (sd::clip_full_pairs(pairs, exactPairs, firstNew, qCap, R, vx, vy, area, threshold, state, supp, &d_cnt->nErr, side)) return -1;
+        SD_CHECK(hipEventRecord(evJoin, side));
+      }
       hipLaunchKernelGGL(k_tail_emit, dim3(wg), dim3(256), 0, s, Ucur, nU, state, nbrStart, nbrLow, nbr, f, d_points, bbox, radius, area, pairs,
                          &d_cnt->nPairs, pairCap, segStart, segCnt);
       SD_LAUNCH_CHECK();

@@ -8,6 +8,9 @@ from stardist_amd import nms
 from stardist_amd.lib import _native, stardist2d as sd2
 from stardist_amd.models import Config2D, StarDist2D
 dev = torch.device("cuda:0")
+if os.environ.get("SD_PAIR_LANES"):
+    _native.check(_native.lib().sd_set_option(b"nms2d_pair_lanes", int(os.environ["SD_PAIR_LANES"])))
+    print("nms2d_pair_lanes =", _native.lib().sd_get_option(b"nms2d_pair_lanes"))
 if os.environ.get("SD_TRACE"):
     _native.lib().sd_set_option(b"trace", 1)      # per-round counters on stdout
 img = torch.from_numpy(synth.s2d_nuclei_image(2048, 2048, seed=0)).to(dev)
