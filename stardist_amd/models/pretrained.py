@@ -5,8 +5,8 @@ The reference downloads and unpacks `<url>` into Keras' cache (`~/.keras/models/
 `keras.utils.get_file` and then constructs `cls(config=None, name=key, basedir=<cache>/<ClassName>)`.  Here the same folder
 layout is used; the folder is looked up in, in order: $STARDIST_AMD_MODELS/<ClassName>/<key>, ~/.keras/models/<ClassName>/<key>.
 If it is missing a download is attempted (urllib + md5 check + unzip); without network that fails with a message that says
-where to put the unpacked folder.  Weights: `weights.npz` / `weights_best.npz` (tools/keras_to_npz.py output) or, when h5py is
-importable, the Keras `weights_best.h5` itself.
+where to put the unpacked folder.  Weights: `weights.npz` / `weights_best.npz` (tools/keras_to_npz.py output) or the Keras
+`weights_best.h5` itself (h5py if importable, else the package's own minimal HDF5 reader, models/hdf5_min.py).
 """
 import hashlib
 import os
@@ -105,26 +105,32 @@ def get_model_folder(cls_name, key_or_alias):
 def keras_h5_to_npz(src, dst):
     """Keras HDF5 weight file (weights_best.h5 / weights_last.h5 of a csbdeep model folder, or the folder itself) -> the .npz that
     StarDistBase.load_weights_npz reads: one entry per variable, named "<layer>/<variable>" ("conv2d_1/kernel:0"), in the order of the
-    file's `layer_names` attribute (= Keras graph order); kernels stay in Keras layout (k..., cin, cout).  Needs h5py."""
-    try:
-        import h5py
-    except ImportError:
-        raise ImportError("reading %s needs h5py; convert it once with tools/keras_to_npz.py on a machine that has it" % (src,))
+    file's `layer_names` attribute (= Keras graph order); kernels stay in Keras layout (k..., cin, cout).  Read with h5py when it is
+    importable, else with the package's own minimal HDF5 reader (models/hdf5_min.py: superblock 0-3, old- and new-style groups,
+    contiguous / compact / unfiltered chunked float datasets -- everything keras.Model.save_weights writes)."""
     import numpy as np
-    if os.path.isdir(src):
+    if not hasattr(src, "read") and os.path.isdir(src):
         for name in ("weights_best.h5", "weights_last.h5", "weights_now.h5"):
             if os.path.exists(os.path.join(src, name)):
                 src = os.path.join(src, name)
                 break
         else:
             raise FileNotFoundError("no weights_*.h5 in %s" % src)
-    out = {}
-    text = lambda n: n.decode() if isinstance(n, bytes) else n
-    with h5py.File(src, "r") as f:
-        g = f["model_weights"] if "model_weights" in f else f
-        for ln in map(text, g.attrs["layer_names"]):
-            lg = g[ln]
-            for wn in map(text, lg.attrs.get("weight_names", [])):
-                out[wn if wn.startswith(ln) else ln + "/" + wn.split("/")[-1]] = np.asarray(lg[wn])
+    try:
+        import h5py
+    except ImportError:
+        h5py = None
+    if h5py is None:
+        from .hdf5_min import read_keras_weights
+        out = read_keras_weights(src)
+    else:
+        out = {}
+        text = lambda n: n.decode() if isinstance(n, bytes) else n
+        with h5py.File(src, "r") as f:
+            g = f["model_weights"] if "model_weights" in f else f
+            for ln in map(text, g.attrs["layer_names"]):
+                lg = g[ln]
+                for wn in map(text, lg.attrs.get("weight_names", [])):
+                    out[wn if wn.startswith(ln) else ln + "/" + wn.split("/")[-1]] = np.asarray(lg[wn])
     np.savez(dst, **out)
     return list(out)

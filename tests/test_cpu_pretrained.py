@@ -76,3 +76,35 @@ def test_keras_layout_fixture_written_by_an_independent_script_loads_and_predict
     assert prob.shape == e["prob"].shape and dist.shape == e["dist"].shape
     assert np.abs(prob - e["prob"]).max() <= 2e-6
     assert np.abs(dist - np.maximum(e["dist"], 1e-3)).max() <= 2e-5 * max(1.0, float(np.abs(e["dist"]).max()))
+
+
+@pytest.mark.parametrize("cls_name,key", [("StarDist2D", "fixture2d"), ("StarDist3D", "fixture3d")])
+def test_keras_h5_weights_read_without_h5py(cls_name, key, tmp_path):
+    """the Keras HDF5 weight files themselves (tests/golden/make_keras_h5_fixture.py: written by the real HDF5 library, h5py 3.3, in
+    keras.Model.save_weights' layout -- and a model.save()-style file with /model_weights and a chunked dataset) through the package's
+    own minimal HDF5 reader (models/hdf5_min.py): every variable bit-identical to the .npz, in Keras' order; a model folder that holds
+    ONLY weights_best.h5 loads and reproduces the independent evaluation (csbdeep _find_and_load_weights, stardist/models/base.py:232-252)"""
+    import stardist_amd.models as M
+    from stardist_amd.models import hdf5_min
+    src = os.path.join(ROOT, "tests", "golden", "keras_fixture", cls_name, key)
+    z = np.load(os.path.join(src, "weights_best.npz"))
+    for fn in ("weights_best.h5", "model_saved.h5"):
+        w = hdf5_min.read_keras_weights(os.path.join(src, fn))
+        assert list(w) == list(z.files)
+        assert all(w[k].dtype == z[k].dtype and np.array_equal(w[k], z[k]) for k in z.files)
+    f = hdf5_min.File(os.path.join(src, "model_saved.h5"))
+    assert np.array_equal(f.root["model_weights"]["chunked_copy"].read(), z[z.files[0]])            # unfiltered chunks, v1 B-tree
+    assert bytes(f.root["model_weights"].attrs["backend"]) == b"tensorflow"
+    with pytest.raises(KeyError):
+        f.root["model_weights"]["no_such_layer"]
+    with pytest.raises(hdf5_min.HDF5Error):
+        hdf5_min.File(b"not an hdf5 file" * 100)
+    folder = tmp_path / cls_name / key
+    os.makedirs(str(folder))
+    for fn in ("config.json", "thresholds.json", "weights_best.h5"):
+        shutil.copy(os.path.join(src, fn), str(folder / fn))
+    m = getattr(M, cls_name)(config=None, name=key, basedir=str(tmp_path / cls_name), device="cpu")
+    e = np.load(os.path.join(src, "expected.npz"))
+    prob, dist = m.predict(e["x"])[:2]
+    assert np.abs(prob - e["prob"]).max() <= 2e-6
+    assert np.abs(dist - np.maximum(e["dist"], 1e-3)).max() <= 2e-5 * max(1.0, float(np.abs(e["dist"]).max()))
