@@ -585,7 +585,8 @@ def main():
                                             "(U-Net + select + 3D NMS cascade + polyhedron raster + relabel)" % S,
                                 "survivors": len(res3[1]["prob"]), "steps": steps3, "nms_thresh": 0.3,
                                 "cascade_calls": {"upper": float(s3[0]), "lower": float(s3[1]), "kernel_volume": float(s3[2]),
-                                                  "hull_volume": float(s3[11]), "render": float(s3[3])}}
+                                                  "hull_volume": float(s3[11]), "render": float(s3[3])},
+                                "near_threshold_volume_decisions": float(s3[13])}
             out["stages_ms_3d"] = {"unet_forward": round(net3_ms, 3), "nms_stage3_kernel_volume": round(float(s3[8] / 1e6), 3),
                                    "nms_stage4_hull_volume": round(float(s3[9] / 1e6), 3), "nms_stage5_render": round(float(s3[10] / 1e6), 3),
                                    "other": round(ms3 - net3_ms - float((s3[8] + s3[9] + s3[10]) / 1e6), 3)}

@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(256) k_round_decide3(const int* __restrict__ U
   flush();
 }
 
-struct Stats { unsigned long long upper, lower, kernel, render, kept_pre, sup_pre, sup_kernel, sup_render, convex, kept_convex, overflow, hiv_faces, hiv_fallback, hiv_list, hiv_clips, hiv_rest, lb_decided, ub_decided;
+struct Stats { unsigned long long upper, lower, kernel, render, kept_pre, sup_pre, sup_kernel, sup_render, convex, kept_convex, overflow, hiv_faces, hiv_fallback, hiv_list, hiv_clips, hiv_rest, lb_decided, ub_decided, near_thr;
                unsigned long long cyc[6]; };   // SD_TRACE: stage-3 wave cycles spent in load+half-spaces / cull / bounds / exact volume / total
 #define SD_PROF_BIT 0x40000000u
 
@@ -1074,6 +1074,7 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
       const float A_inter_kernel = (float)vol;                                  // function returns float :679
       const float A_min = fminf(volume[ij.x], volume[ij.y]);
       const float iou = (float)((double)A_inter_kernel / ((double)A_min + 1e-10));   // :1269
+      if (fabsf(iou - thr) < 1e-6f) atomicAdd(&st->near_thr, 1ull);      // (a flip by the <= 1e-9 volume deviation from Qhull would need |iou - thr| ~ 1e-9)
       if (iou > thr) { sink.suppress(ij.x, ij.y); atomicAdd(&st->sup_kernel, 1ull); }
       else pairs5[atomicAdd(pair5Count, 1u)] = ij;
     }
@@ -1171,7 +1172,8 @@ __global__ void __launch_bounds__(64 * NW) k_stage3x(const int2* __restrict__ pa
         const float A_inter_kernel = (float)vol;                                  // function returns float :679
         const float A_min = fminf(volume[ij.x], volume[ij.y]);
         const float iou = (float)((double)A_inter_kernel / ((double)A_min + 1e-10));   // :1269
-        if (iou > thr) { sink.suppress(ij.x, ij.y); atomicAdd(&st->sup_kernel, 1ull); }
+        if (fabsf(iou - thr) < 1e-6f) atomicAdd(&st->near_thr, 1ull);      // (a flip by the <= 1e-9 volume deviation from Qhull would need |iou - thr| ~ 1e-9)
+      if (iou > thr) { sink.suppress(ij.x, ij.y); atomicAdd(&st->sup_kernel, 1ull); }
         else pairs5[atomicAdd(pair5Count, 1u)] = ij;
       }
     }
@@ -1653,6 +1655,7 @@ __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, u
       const float A_inter_convex = (float)vol;
       const float A_min = fminf(volume[ij.x], volume[ij.y]);
       const float iou = (float)((double)A_inter_convex / ((double)A_min + 1e-10));     // :1289
+      if (fabsf(iou - thr) < 1e-6f) atomicAdd(&st->near_thr, 1ull);
       if (iou <= thr) atomicAdd(&st->kept_convex, 1ull);                                // :1291-1295
       else pairs5[atomicAdd(pair5Count, 1u)] = ij;
     }
@@ -1738,7 +1741,8 @@ __global__ void __launch_bounds__(64 * NW) k_stage4x(const int2* __restrict__ pa
         const float A_inter_convex = (float)vol;
         const float A_min = fminf(volume[ij.x], volume[ij.y]);
         const float iou = (float)((double)A_inter_convex / ((double)A_min + 1e-10));     // :1289
-        if (iou <= thr) atomicAdd(&st->kept_convex, 1ull);                                // :1291-1295
+        if (fabsf(iou - thr) < 1e-6f) atomicAdd(&st->near_thr, 1ull);
+      if (iou <= thr) atomicAdd(&st->kept_convex, 1ull);                                // :1291-1295
         else pairs5[atomicAdd(pair5Count, 1u)] = ij;
       }
     }
@@ -2367,7 +2371,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
     stats[0] = (int64_t)hs_.upper; stats[1] = (int64_t)hs_.lower; stats[2] = (int64_t)hs_.kernel; stats[3] = (int64_t)hs_.render;
     stats[4] = rounds; stats[5] = totalNbr; stats[6] = (int64_t)hs_.sup_kernel; stats[7] = (int64_t)hs_.sup_render;
     stats[8] = (int64_t)ns3; stats[9] = (int64_t)ns4; stats[10] = (int64_t)ns5; stats[11] = (int64_t)hs_.convex; stats[12] = (int64_t)hs_.kept_convex;
-    stats[13] = (int64_t)hs_.hiv_faces; stats[14] = (int64_t)hs_.hiv_fallback;
+    stats[13] = (int64_t)hs_.near_thr; stats[14] = (int64_t)hs_.hiv_fallback;
     { float msb = 0; SD_CHECK(hipEventElapsedTime(&msb, evb0, evb1)); stats[15] = (int64_t)(msb * 1e6); }
     if (trace) printf("hiv: faces %llu list entries %llu clips %llu list overflows %llu fallbacks %llu\n", hs_.hiv_faces, hs_.hiv_list, hs_.hiv_clips, hs_.hiv_rest, hs_.hiv_fallback);
     if (trace && hs_.cyc[5]) printf("stage 3 wave cycles per pair (clock64): load+half-spaces %.0f, cull %.0f, bounds %.0f, decide/exact %.0f, total %.0f (%llu pairs)\n",
