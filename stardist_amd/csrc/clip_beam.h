@@ -302,10 +302,10 @@ struct BeamCore {
   enum { ORD_BITS = (K > 8) ? 64 : 32 };
   enum { GJ = (K <= 8 ? 3 : 4), NX = (K <= 8 ? 2 : 4), EID_POLY = 4096 };
   SD_HD D& self() { return *static_cast<D*>(this); }
-  static constexpr unsigned RI = P::template region<int, K>(), RD = P::template region<double, K>(),
+  static constexpr unsigned RI = P::template coord_region<K>(), RD = P::template slope_region<K>(),
                             RS = P::template region<short, K>(), RB = P::template region<signed char, K>(),
-                            RIL = P::template region<int, MAXIL>(), RILB = P::template region<signed char, MAXIL>(),
-                            RG = P::template region<int, GJ>(), RGF = P::template region<int, (FULLGJ ? GJ : 1)>(), R1 = P::template region<int, 1>(), R8 = P::template region<u64, 1>(), RO = P::template region<ord_t, 1>();
+                            RIL = P::template coord_region<MAXIL>(), RILB = P::template region<signed char, MAXIL>(),
+                            RG = P::template coord_region<GJ>(), RGF = P::template region<int, (FULLGJ ? GJ : 1)>(), R1 = P::template region<int, 1>(), R8 = P::template region<u64, 1>(), RO = P::template region<ord_t, 1>();
   static constexpr unsigned O_BOTX = 0, O_BOTY = O_BOTX + RI, O_TOPX = O_BOTY + RI, O_TOPY = O_TOPX + RI, O_CURX = O_TOPY + RI,
                             O_CURY = O_CURX + RI, O_DX = O_CURY + RI, O_EID = O_DX + RD, O_WCNT = O_EID + RS, O_WCNT2 = O_WCNT + RB,
                             O_OUTIDX = O_WCNT2 + RB, O_LMLC = O_OUTIDX + RB, O_WDELTA = O_LMLC + RB, O_PTYP = O_WDELTA + RB,
@@ -315,12 +315,13 @@ struct BeamCore {
                             O_PA = O_MLM + P::template region<unsigned char, 16>(),
                             O_ORD = O_PA + 2 * R8, O_HSEL = O_ORD + RO, O_AFTER_ORD = O_HSEL + RO, O_PB = O_PA + R8, O_NAEL = O_AFTER_ORD, O_FREE = O_NAEL + R1, O_NLM = O_FREE + R1,
                             O_CURLM = O_NLM + R1, O_NIL = O_CURLM + R1, O_STATUS = O_NIL + R1, O_NJOINS = O_STATUS + R1,
-                            O_NGJ = O_NJOINS + R1, O_NXTRA = O_NGJ + R1, O_LMY = O_NXTRA + R1, O_CORE_END = O_LMY + R1;
+                            O_NGJ = O_NJOINS + R1, O_NXTRA = O_NGJ + R1, O_LMY = O_NXTRA + R1, O_ORGX = O_LMY + R1, O_ORGY = O_ORGX + R1, O_CORE_END = O_ORGY + R1;
   // ---- bound slots
-  typename P::template Arr<int, K, O_BOTX> botx; typename P::template Arr<int, K, O_BOTY> boty;
-  typename P::template Arr<int, K, O_TOPX> topx; typename P::template Arr<int, K, O_TOPY> topy;
-  typename P::template Arr<int, K, O_CURX> curx; typename P::template Arr<int, K, O_CURY> cury;
-  typename P::template Arr<double, K, O_DX> dx;
+  // (coordinates: plain ints, or 16-bit offsets from the pair's origin (orgx, orgy) with LdsStorage16; slopes: stored, or recomputed)
+  typename P::template CoordArr<K, O_BOTX, O_ORGX, O_STATUS> botx; typename P::template CoordArr<K, O_BOTY, O_ORGY, O_STATUS> boty;
+  typename P::template CoordArr<K, O_TOPX, O_ORGX, O_STATUS> topx; typename P::template CoordArr<K, O_TOPY, O_ORGY, O_STATUS> topy;
+  typename P::template CoordArr<K, O_CURX, O_ORGX, O_STATUS> curx; typename P::template CoordArr<K, O_CURY, O_ORGY, O_STATUS> cury;
+  typename P::template SlopeArr<K, O_DX, O_BOTX, O_BOTY, O_TOPX, O_TOPY> dx;
   typename P::template Arr<short, K, O_EID> eid;                 // current edge: poly * EID_POLY + index in that polygon's ring
   typename P::template Arr<signed char, K, O_WCNT> wcnt; typename P::template Arr<signed char, K, O_WCNT2> wcnt2;   // |winding| <= n_lm <= 16
   typename P::template Arr<signed char, K, O_OUTIDX> outidx;
@@ -328,11 +329,11 @@ struct BeamCore {
   typename P::template Arr<signed char, K, O_WDELTA> wdelta; typename P::template Arr<signed char, K, O_PTYP> ptyp;
   typename P::template Arr<signed char, K, O_SIDE> side;
   // ---- intersections of the current scan-beam
-  typename P::template Arr<int, MAXIL, O_ILX> ilx; typename P::template Arr<int, MAXIL, O_ILY> ily;
+  typename P::template CoordArr<MAXIL, O_ILX, O_ORGX, O_STATUS> ilx; typename P::template CoordArr<MAXIL, O_ILY, O_ORGY, O_STATUS> ily;
   typename P::template Arr<signed char, MAXIL, O_ILE1> ile1; typename P::template Arr<signed char, MAXIL, O_ILE2> ile2;
   // ---- ghost joins of the current scan-line (:1968-1975), extra scan-beam Ys, merged local minima
-  typename P::template Arr<int, (FULLGJ ? GJ : 1), O_GJOP> gjop; typename P::template Arr<int, GJ, O_GJX1> gjx1;
-  typename P::template Arr<int, GJ, O_GJX2> gjx2; typename P::template Arr<int, (FULLGJ ? GJ : 1), O_GJY2> gjy2;
+  typename P::template Arr<int, (FULLGJ ? GJ : 1), O_GJOP> gjop; typename P::template CoordArr<GJ, O_GJX1, O_ORGX, O_STATUS> gjx1;
+  typename P::template CoordArr<GJ, O_GJX2, O_ORGX, O_STATUS> gjx2; typename P::template Arr<int, (FULLGJ ? GJ : 1), O_GJY2> gjy2;
   typename P::template Arr<int, NX, O_XTRA> xtra;
   typename P::template Arr<unsigned char, 16, O_MLM> mlm;       // poly * 128 + index into that polygon's lm list
   // ---- scalars
@@ -345,6 +346,7 @@ struct BeamCore {
   typename P::template Scalar<int, O_NJOINS> n_joins; typename P::template Scalar<int, O_NGJ> n_gj;
   typename P::template Scalar<int, O_NXTRA> n_xtra;
   typename P::template Scalar<int, O_LMY> next_lm_y;             // Y of local minimum cur_lm (valid while cur_lm < n_lm)
+  typename P::template Scalar<int, O_ORGX> orgx; typename P::template Scalar<int, O_ORGY> orgy;   // origin of the 16-bit coordinate arrays
 
   static constexpr ord_t ALLF = (ord_t)~(ord_t)0;
   static constexpr ord_t ONES = (ord_t)0x1111111111111111ull, HIGHS = (ord_t)0x8888888888888888ull;
@@ -1028,6 +1030,7 @@ struct BeamCore {
   // ------------------------------------------------------------------ Execute  :1560-1621, 1247-1276
   SD_HD void reset_core(const Prep* a, const Prep* b) {
     prepA = a; prepB = b;
+    orgx = a->n ? a->v[0].x : (b->n ? b->v[0].x : 0); orgy = a->n ? a->v[0].y : (b->n ? b->v[0].y : 0);      // (before any coordinate is stored)
     ord = ALLF; hsel = ALLF; n_ael = 0; freemask = (1 << K) - 1;
     n_lm = 0; cur_lm = 0; n_il = 0; status = ST_OK; n_joins = 0; n_gj = 0; n_xtra = 0;
   }
@@ -1083,13 +1086,13 @@ template <int MAXV, int K, int MAXIL, int MAXREC, class P = PlainStorage>
 struct Beam : BeamCore<Beam<MAXV, K, MAXIL, MAXREC, P>, P, MAXV, K, MAXIL> {
   typedef BeamCore<Beam<MAXV, K, MAXIL, MAXREC, P>, P, MAXV, K, MAXIL> B;
   using B::outidx; using B::side; using B::status; using B::ord; using B::n_ael;
-  static constexpr unsigned RR = P::template region<int, MAXREC>();
+  static constexpr unsigned RR = P::template coord_region<MAXREC>();
   static constexpr unsigned O_RFX = B::O_CORE_END, O_RFY = O_RFX + RR, O_RLX = O_RFY + RR, O_RLY = O_RLX + RR, O_RSUM = O_RLY + RR,
                             O_RSER = O_RSUM + P::template region<i64, MAXREC>(), O_NREC = O_RSER + P::template region<unsigned char, MAXREC>(),
                             O_RFREE = O_NREC + P::template region<int, 1>(), O_TWICE = O_RFREE + P::template region<int, 1>(),
                             O_SABS = O_TWICE + P::template region<i64, 1>(), O_END = O_SABS + P::template region<i64, 1>();
-  typename P::template Arr<int, MAXREC, O_RFX> rfx; typename P::template Arr<int, MAXREC, O_RFY> rfy;
-  typename P::template Arr<int, MAXREC, O_RLX> rlx; typename P::template Arr<int, MAXREC, O_RLY> rly;
+  typename P::template CoordArr<MAXREC, O_RFX, B::O_ORGX, B::O_STATUS> rfx; typename P::template CoordArr<MAXREC, O_RFY, B::O_ORGY, B::O_STATUS> rfy;
+  typename P::template CoordArr<MAXREC, O_RLX, B::O_ORGX, B::O_STATUS> rlx; typename P::template CoordArr<MAXREC, O_RLY, B::O_ORGY, B::O_STATUS> rly;
   typename P::template Arr<i64, MAXREC, O_RSUM> rsum;
   static constexpr unsigned lds_bytes() { return O_END; }
   typename P::template Arr<unsigned char, MAXREC, O_RSER> rser;   // creation order of the ring held in a slot (Clipper's OutRec index)

@@ -170,6 +170,11 @@ struct PlainStorage {
   };
   template <int N, unsigned OBX, unsigned OBY, unsigned OTX, unsigned OTY> struct DxArr : Arr<double, N, 0> {};
   template <class T, unsigned OFF> using Scalar = T;
+  // clip_beam.h: coordinate arrays (may be stored relative to a per-pair origin, see LdsStorage16) and the slot slopes
+  template <int N> static constexpr unsigned coord_region() { return 0; }
+  template <int N> static constexpr unsigned slope_region() { return 0; }
+  template <int N, unsigned OFF, unsigned OORG, unsigned OST> using CoordArr = Arr<int, N, OFF>;
+  template <int N, unsigned OFF, unsigned OBX, unsigned OBY, unsigned OTX, unsigned OTY> using SlopeArr = Arr<double, N, OFF>;
 };
 
 // LDS-interleaved storage: element i of thread t of array A lives at  lds_base + OFF_A + (i*STRIDE + t)*sizeof(T).
@@ -217,6 +222,55 @@ struct LdsStorage {
     SD_HD T operator++(int) const { return ref()++; }
     SD_HD T operator--() const { return --ref(); }
     SD_HD T operator--(int) const { return ref()--; }
+  };
+  template <int N> static constexpr unsigned coord_region() { return region<int, N>(); }
+  template <int N> static constexpr unsigned slope_region() { return region<double, N>(); }
+  template <int N, unsigned OFF, unsigned OORG, unsigned OST> using CoordArr = Arr<int, N, OFF>;
+  template <int N, unsigned OFF, unsigned OBX, unsigned OBY, unsigned OTX, unsigned OTY> using SlopeArr = Arr<double, N, OFF>;
+};
+
+// LdsStorage with the bound-slot sweep's COORDINATES held as 16-bit offsets from a per-pair origin and its slopes recomputed instead of
+// stored (clip_beam.h).  The pair kernel is latency-bound and LDS capacity decides how many pairs a CU has in flight: 636 bytes per
+// pair = four waves per CU; with 16-bit coordinates (bot / top / cur of the K slots, intersection points, ring end points: 152 bytes
+// less) and no stored slopes (64 bytes less) it is 420 bytes = six waves.  The arithmetic is unchanged: a coordinate reads as
+// origin + offset (exact), a slope as the same double quotient of the same integer differences that the stored value was computed
+// from (es_dx).  A value that does not fit 16 bits raises `ST_OVERFLOW_AEL` through the status word at OST: the pair is then
+// re-run by the next tier, which keeps 32-bit coordinates.
+enum { ST_REL16_OVERFLOW = 32 };      // = ST_OVERFLOW_AEL of clip_beam.h (a capacity flag: the pair spills to tier 2)
+template <int STRIDE>
+struct LdsStorage16 : LdsStorage<STRIDE> {
+  typedef LdsStorage<STRIDE> Base;
+  template <int N> static constexpr unsigned coord_region() { return Base::template region<short, N>(); }
+  template <int N> static constexpr unsigned slope_region() { return 0; }
+  template <int N, unsigned OFF, unsigned OORG, unsigned OST> struct CoordArr {
+    struct Ref {
+      int i;
+      SD_HD short& raw() const { return *(short*)(sd_lds_base() + OFF + (unsigned)(i * STRIDE + sd_lds_tid()) * 2u); }
+      SD_HD int org() const { return *(const int*)(sd_lds_base() + OORG + (unsigned)sd_lds_tid() * 4u); }
+      SD_HD operator int() const { return org() + (int)raw(); }
+      SD_HD int operator=(int v) const {
+        const int r = v - org();
+        if (r != (int)(short)r) *(int*)(sd_lds_base() + OST + (unsigned)sd_lds_tid() * 4u) |= ST_REL16_OVERFLOW;
+        raw() = (short)r;
+        return v;
+      }
+      SD_HD int operator=(const Ref& o) const { return *this = (int)o; }
+    };
+    SD_HD Ref operator[](int i) const { Ref r; r.i = i; return r; }
+    SD_HD static int rel(int i) { return (int)*(const short*)(sd_lds_base() + OFF + (unsigned)(i * STRIDE + sd_lds_tid()) * 2u); }
+  };
+  template <int N, unsigned OFF, unsigned OBX, unsigned OBY, unsigned OTX, unsigned OTY> struct SlopeArr {   // slope = f(bot, top): recomputed, never stored
+    struct Ref {
+      int e;
+      SD_HD operator double() const {
+        // differences of the stored 16-bit offsets = differences of the coordinates (same origin)
+        const long long dy = (long long)CoordArr<N, OTY, 0, 0>::rel(e) - CoordArr<N, OBY, 0, 0>::rel(e);
+        if (dy == 0) return SD_HORIZONTAL;
+        return (double)((long long)CoordArr<N, OTX, 0, 0>::rel(e) - CoordArr<N, OBX, 0, 0>::rel(e)) / (double)dy;
+      }
+      SD_HD void operator=(double) const {}
+    };
+    SD_HD Ref operator[](int e) const { Ref r; r.e = e; return r; }
   };
 };
 

@@ -21,6 +21,8 @@
 //   The fixed point of the rounds is the reference's sequential greedy result: j is
 //   suppressed iff some survivor i < j has overlap(i,j) > threshold, and a candidate is only
 //   promoted to survivor after all of its possible suppressors are final.
+#include <type_traits>
+
 #include "common.h"
 #include "clip_sweep.h"
 #include "clip_beam.h"
@@ -366,12 +368,15 @@ struct PairQueues { unsigned int* spill; unsigned int* spillCount; unsigned int*
 enum { BEAM_CAPFLAGS = sdclip::ST_OVERFLOW_IL | sdclip::ST_OVERFLOW_REC | sdclip::ST_OVERFLOW_AEL | sdclip::ST_OVERFLOW_LM | sdclip::ST_OVERFLOW_GJ };
 // idx == nullptr: pairs[0 .. *nPtr);  else pairs[idx[0 .. *nPtr)].   supp == nullptr: a suppressing pair marks state[j]
 // (greedy round, i is a survivor); else supp[pair index] = 1 (tail batch: i is still undecided, the result is kept per edge).
-template <int MAXV, int K, int MAXIL, int MAXREC, int S, typename CNT>
+// REL16: the sweep state with 16-bit coordinates relative to the pair's origin and recomputed slopes (clip_sweep.h LdsStorage16): 420
+// instead of 636 bytes per pair; a pair whose coordinates do not fit raises a capacity flag and spills to the next tier like any other
+template <int MAXV, int K, int MAXIL, int MAXREC, int S, typename CNT, bool REL16 = false>
 __global__ void __launch_bounds__(S) k_pairs_beam(const int2* __restrict__ pairs, const unsigned int* __restrict__ idx, const CNT* __restrict__ nPtr,
                                                   const unsigned int* __restrict__ firstPtr, const sdclip::PolyPrep<MAXV>* __restrict__ prep,
                                                   const float* __restrict__ area, float thr, unsigned char* __restrict__ state,
                                                   unsigned char* __restrict__ supp, PairQueues q) {
-  typedef sdclip::Beam<MAXV, K, MAXIL, MAXREC, sdclip::LdsStorage<S>> BeamT;
+  typedef typename std::conditional<REL16, sdclip::LdsStorage16<S>, sdclip::LdsStorage<S>>::type Storage;
+  typedef sdclip::Beam<MAXV, K, MAXIL, MAXREC, Storage> BeamT;
   const unsigned long long n = (unsigned long long)*nPtr;
   const unsigned long long first = firstPtr ? (unsigned long long)*firstPtr : 0ull;      // entries before `first` are already queued for the general path
   for (unsigned long long t = first + (unsigned long long)blockIdx.x * S + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * S) {
@@ -396,8 +401,11 @@ __global__ void __launch_bounds__(S) k_pairs_beam(const int2* __restrict__ pairs
     if (overlap > thr) { if (supp) supp[p] = 1; else state[ij.y] = ST_SUPPRESSED; }                // :581-585
   }
 }
-template <int MAXV, int K, int MAXIL, int MAXREC, int S>
-size_t beam_lds_bytes() { return (size_t)sdclip::Beam<MAXV, K, MAXIL, MAXREC, sdclip::LdsStorage<S>>::lds_bytes() + 64; }
+template <int MAXV, int K, int MAXIL, int MAXREC, int S, bool REL16 = false>
+size_t beam_lds_bytes() {
+  typedef typename std::conditional<REL16, sdclip::LdsStorage16<S>, sdclip::LdsStorage<S>>::type Storage;
+  return (size_t)sdclip::Beam<MAXV, K, MAXIL, MAXREC, Storage>::lds_bytes() + 64;
+}
 
 // ---- tail batch.  Late greedy rounds hold few pairs but each costs one sweep's serial latency; once few candidates are
 // undecided, ALL pairs (i < j, both undecided) the reference could still evaluate are emitted at once, their overlap decisions
@@ -645,17 +653,23 @@ struct BeamPath {
   // tier 1 (K = 8): all pairs of the round; capacity spills -> q.spill
   static int tier1(const int2* pairs, const unsigned int* idx, const unsigned long long* nPairs, const unsigned int* first, const void* prep, const float* area,
                    float thr, unsigned char* state, unsigned char* supp, PairQueues q, hipStream_t s) {
-    // One pair per lane, the pair's whole sweep state (636 bytes) in LDS.  The kernel is latency-bound under lane divergence (VALU
-    // issue 12.5 % at one wave per SIMD, profiles/r03_pmc_mfma.md), and LDS capacity sets the occupancy: 64-lane workgroups hold
-    // 40.7 KB -> four waves per CU; 32-lane workgroups (the upper half of a wave stays empty) hold 20.4 KB -> eight waves per CU, two per
-    // SIMD, the same 256 pairs in flight per CU but each wave diverges over 32 sweeps instead of 64 and has a partner to overlap its
-    // LDS round trips with.  Option "nms2d_pair_lanes" (64 | 32) selects; same results.
-    if (sd::option(sd::OPT_NMS2D_PAIR_LANES) == 32) {
+    // One pair per lane, the pair's whole sweep state in LDS.  The kernel is latency-bound under lane divergence (VALU issue 12.5 % at
+    // one wave per SIMD, profiles/r03_pmc_mfma.md) and LDS capacity sets how many pairs a CU has in flight: with 32-bit coordinates and
+    // stored slopes a pair takes 636 bytes -> 40.7 KB per wave -> FOUR waves per CU; with 16-bit coordinates relative to the pair's origin
+    // and recomputed slopes (LdsStorage16, the default since round 4) 420 bytes -> 26.9 KB -> SIX waves per CU, 1.5x the pairs in flight.
+    // Same arithmetic (tests/host/beam_check.cpp: 0 mismatches against Clipper in either form); pairs whose coordinates do not fit 16 bits
+    // spill to tier 2.  Option "nms2d_pair_lanes": 64 (default) | 32 (half-filled waves: measured no gain) | 6464 (the 32-bit form).
+    const int lanes = sd::option(sd::OPT_NMS2D_PAIR_LANES);
+    if (lanes == 32) {
       static const size_t lds32 = beam_lds_bytes<MAXV, 8, 6, 4, 32>();
       hipLaunchKernelGGL((k_pairs_beam<MAXV, 8, 6, 4, 32, unsigned long long>), dim3(256 * 8), dim3(32), lds32, s, pairs, idx, nPairs, first, (const Prep*)prep, area, thr, state, supp, q);
-    } else {
+    } else if (lanes == 6464) {
       static const size_t lds = beam_lds_bytes<MAXV, 8, 6, 4, 64>();
       hipLaunchKernelGGL((k_pairs_beam<MAXV, 8, 6, 4, 64, unsigned long long>), dim3(256 * 4), dim3(64), lds, s, pairs, idx, nPairs, first, (const Prep*)prep, area, thr, state, supp, q);
+    } else {
+      static const size_t lds16 = beam_lds_bytes<MAXV, 8, 6, 4, 64, true>();
+      static const int per_cu = (int)((160 * 1024) / lds16);
+      hipLaunchKernelGGL((k_pairs_beam<MAXV, 8, 6, 4, 64, unsigned long long, true>), dim3(256 * per_cu), dim3(64), lds16, s, pairs, idx, nPairs, first, (const Prep*)prep, area, thr, state, supp, q);
     }
     SD_LAUNCH_CHECK();
     return 0;

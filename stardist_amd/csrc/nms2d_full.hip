@@ -3,6 +3,8 @@
 // The fast pair kernel (nms2d.hip, k_pairs) is exact whenever Clipper records no joins for the
 // pair.  Pairs with joins are re-evaluated here with the full ring bookkeeping
 // (clip_sweep_full.h), which also restates JoinCommonEdges.
+#include <type_traits>
+
 #include "common.h"
 #include "clip_sweep.h"
 #include "clip_sweep_full.h"
@@ -69,7 +71,7 @@ size_t lds_full_bytes() {
 // probe: explicit vertex arrays per pair, evaluated the way the NMS does: prepared polygons + bound-slot sweep
 // (clip_beam.h, tier capacities K/BIL/BREC); the general sweep when that flags a capacity or records joins.
 // flags: sweep status | 256 (general path used) | 512 (bound-slot result used)
-template <int MAXV, int K, int BIL, int BREC, int S, int MAXIL, int MAXREC, int MAXPT, int MAXJ>
+template <int MAXV, int K, int BIL, int BREC, int S, int MAXIL, int MAXREC, int MAXPT, int MAXJ, bool REL16 = false>
 __global__ void __launch_bounds__(S) k_probe(const int* __restrict__ xa, const int* __restrict__ ya,
                                              const int* __restrict__ xb, const int* __restrict__ yb, int n, int R,
                                              sdclip::PolyPrep<MAXV>* __restrict__ prepbuf,
@@ -88,7 +90,8 @@ __global__ void __launch_bounds__(S) k_probe(const int* __restrict__ xa, const i
   int fl;
   bool need_full;
   {
-    sdclip::Beam<MAXV, K, BIL, BREC, LP> bm;
+    typedef typename std::conditional<REL16, sdclip::LdsStorage16<S>, LP>::type BP;      // REL16: the NMS's tier-1 form (16-bit coordinates)
+    sdclip::Beam<MAXV, K, BIL, BREC, BP> bm;
     bm.reset_state(pa, pb);
     t = bm.execute();
     fl = bm.status | 512;
@@ -105,7 +108,7 @@ __global__ void __launch_bounds__(S) k_probe(const int* __restrict__ xa, const i
   twice[p] = t;
   flags[p] = fl;
 }
-template <int MAXV, int K, int BIL, int BREC, int S, int MAXIL, int MAXREC, int MAXPT, int MAXJ>
+template <int MAXV, int K, int BIL, int BREC, int S, int MAXIL, int MAXREC, int MAXPT, int MAXJ, bool REL16 = false>
 int launch_probe(const int* xa, const int* ya, const int* xb, const int* yb, int n, int R, i64* out, int* flags, hipStream_t s) {
   typedef sdclip::LdsStorage<S> LP;
   sd::Arena& A = sd::arena();
@@ -116,7 +119,7 @@ int launch_probe(const int* xa, const int* ya, const int* xb, const int* yb, int
   const size_t lds2 = sdclip::PrepWork<LP, MAXV>::lds_bytes();
   if (lds2 > lds) lds = lds2;
   lds += 64;
-  hipLaunchKernelGGL((k_probe<MAXV, K, BIL, BREC, S, MAXIL, MAXREC, MAXPT, MAXJ>), dim3((n + S - 1) / S), dim3(S), lds, s, xa, ya, xb, yb, n, R, prepbuf, out, flags,
+  hipLaunchKernelGGL((k_probe<MAXV, K, BIL, BREC, S, MAXIL, MAXREC, MAXPT, MAXJ, REL16>), dim3((n + S - 1) / S), dim3(S), lds, s, xa, ya, xb, yb, n, R, prepbuf, out, flags,
                      sd::option(sd::OPT_PROBE_NO_GENERAL) ? 1 : 0);
   SD_LAUNCH_CHECK();
   return 0;
@@ -181,8 +184,9 @@ extern "C" int sd_clip_pairs_device(const int32_t* d_xa, const int32_t* d_ya, co
   const int R = n_verts;
   if (R < 1 || R > 256) { sd::set_error("sd_clip_pairs: n_verts=%d unsupported (1..256)", R); return -1; }
   i64* out = (i64*)d_out_twice_area;
-  const int tier = sd::option(sd::OPT_PROBE_TIER);   // 1: K = 8 capacities (as the NMS's first tier), 2: K = 15
-  if (R <= 32 && tier == 1) return launch_probe<32, 8, 6, 4, 64, 64, 32, 192, 64>(d_xa, d_ya, d_xb, d_yb, n_pairs, R, out, d_out_flags, s);
+  const int tier = sd::option(sd::OPT_PROBE_TIER);   // 1: K = 8 capacities, 16-bit coordinates (the NMS's first tier), 3: the same with 32-bit coordinates, 2: K = 15
+  if (R <= 32 && tier == 1) return launch_probe<32, 8, 6, 4, 64, 64, 32, 192, 64, true>(d_xa, d_ya, d_xb, d_yb, n_pairs, R, out, d_out_flags, s);
+  if (R <= 32 && tier == 3) return launch_probe<32, 8, 6, 4, 64, 64, 32, 192, 64>(d_xa, d_ya, d_xb, d_yb, n_pairs, R, out, d_out_flags, s);
   if (R <= 32) return launch_probe<32, 15, 16, 8, 32, 64, 32, 192, 64>(d_xa, d_ya, d_xb, d_yb, n_pairs, R, out, d_out_flags, s);
   if (R <= 64) return launch_probe<64, 15, 16, 8, 32, 96, 48, 384, 96>(d_xa, d_ya, d_xb, d_yb, n_pairs, R, out, d_out_flags, s);
   if (R <= 128) return launch_probe<128, 15, 16, 8, 32, 128, 64, 768, 128>(d_xa, d_ya, d_xb, d_yb, n_pairs, R, out, d_out_flags, s);

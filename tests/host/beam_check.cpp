@@ -37,6 +37,8 @@ typedef sdclip::Beam<BEAM_MAXV, BEAM_K, BEAM_MAXIL, BEAM_MAXREC> BeamT;
 typedef sdclip::LdsStorage<4> LdsP;
 typedef sdclip::PrepWork<LdsP, BEAM_MAXV> PrepWL;
 typedef sdclip::Beam<BEAM_MAXV, BEAM_K, BEAM_MAXIL, BEAM_MAXREC, LdsP> BeamL;
+typedef sdclip::LdsStorage16<4> Lds16P;                 // 16-bit coordinates relative to the pair's origin, slopes recomputed (tier 1 on the GPU)
+typedef sdclip::Beam<BEAM_MAXV, BEAM_K, BEAM_MAXIL, BEAM_MAXREC, Lds16P> BeamL16;
 
 static void make_poly(std::mt19937& rng, int n_rays, float radius, float noise, float cy, float cx,
                       std::vector<int64_t>& xs, std::vector<int64_t>& ys) {
@@ -102,6 +104,15 @@ int main(int argc, char** argv) {
       BeamT bm;
       bm.reset_state(&pa, &pb);
       t_new = bm.execute(); st_new = bm.status; nj_new = bm.n_joins;
+    } else if (lds_mode == 2) {
+      sdclip::HostLds::base() = lds_buf; sdclip::HostLds::tid() = (int)(p & 3);
+      PrepWL w;
+      w.prepare(xa.data(), ya.data(), n_rays, &pa);
+      w.prepare(xb.data(), yb.data(), n_rays, &pb);
+      BeamL16 bm;
+      bm.reset_state(&pa, &pb);
+      t_new = bm.execute(); st_new = bm.status; nj_new = bm.n_joins;
+      if (p == 0) printf("LdsStorage16<4>: beam %u bytes per 4 threads (32-bit form: %u)\n", BeamL16::lds_bytes(), BeamL::lds_bytes());
     } else {
       sdclip::HostLds::base() = lds_buf; sdclip::HostLds::tid() = (int)(p & 3);
       if (BeamL::lds_bytes() > sizeof(lds_buf) || PrepWL::lds_bytes() > sizeof(lds_buf)) { printf("lds_buf too small\n"); return 2; }

@@ -139,3 +139,23 @@ def test_raster2d_lattice_and_degenerate_cases_vs_skimage():
     for i in range(len(coord)):
         one = sd2.c_polygons_to_label(coord[i:i + 1], np.zeros(1, np.int32), shape)
         assert np.array_equal(one > 0, g["explicit_mask%d" % i]), i
+
+
+def test_nms2d_pair_kernel_forms_agree(refmods):
+    """tier 1 of the pair kernel in its three launch forms -- 16-bit coordinates relative to the pair's origin with recomputed slopes
+    (the default: six waves per CU), 32-bit coordinates with stored slopes (four waves), half-filled 32-lane waves -- returns the
+    reference's survivors; large absolute coordinates (a candidate set far from the image origin) do not disturb the relative form"""
+    from oracle import synth
+    from stardist_amd.lib import _native as N, stardist2d as sd2
+    d, p, s = synth.s2d_uniform(512, 512)
+    p_far = (p + np.float32(12000)).astype(np.float32)
+    refmods.set_threads(8)
+    want = refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4))
+    want_far = refmods.stardist2d().c_non_max_suppression_inds(d, p_far, 1, 1, 0, np.float32(0.4))
+    try:
+        for lanes in (64, 6464, 32):
+            N.check(N.lib().sd_set_option(b"nms2d_pair_lanes", lanes))
+            assert np.array_equal(sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4)), want), lanes
+            assert np.array_equal(sd2.c_non_max_suppression_inds(d, p_far, 1, 1, 0, np.float32(0.4)), want_far), lanes
+    finally:
+        N.check(N.lib().sd_set_option(b"nms2d_pair_lanes", 64))
