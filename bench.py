@@ -77,13 +77,18 @@ def calibrate_heads(model, img, frac=0.10, radius=10.0, noise=0.1):
     f = feats["f"].float()
     with torch.no_grad():
         bshape = (1, -1) + (1,) * (f.dim() - 2)
-        z = net.prob(f) - net.prob.bias.reshape(bshape)
+        if f.is_cuda:                       # the 1x1 heads through the library's own kernels here as well (no framework convolution on the device)
+            from stardist_amd.models.unet import _conv_bias_act
+            head = lambda conv: _conv_bias_act(conv, f, 0)
+        else:
+            head = lambda conv: conv(f)
+        z = head(net.prob) - net.prob.bias.reshape(bshape)
         zs = z.flatten()
         if zs.numel() > 4_000_000:
             zs = zs[:: zs.numel() // 4_000_000]
         q = torch.quantile(zs, 1.0 - frac)
         net.prob.bias.fill_(float(-q))
-        d = net.dist(f) - net.dist.bias.reshape(bshape)
+        d = head(net.dist) - net.dist.bias.reshape(bshape)
         sd = float(d[:, :, ::2].std())
         net.dist.weight.mul_(radius * noise * 0.58 / max(sd, 1e-12))
         net.dist.bias.fill_(radius)
