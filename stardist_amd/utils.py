@@ -76,7 +76,22 @@ def edt_prob(lbl_img, anisotropy=None):
     from .lib import _native as N
     N.require_device()
     as_np = not N.is_torch(lbl_img)
-    lab = torch.from_numpy(np.ascontiguousarray(lbl_img).astype(np.int32, copy=False)).cuda() if as_np else lbl_img.to(torch.int32).contiguous()
+    # label ids: the kernel keeps one table entry per id up to the largest, in int32.  Ids beyond int32, or sparse huge ids (hash-like
+    # labels), are first compacted to 1..n -- the result depends on which pixels share a label, not on the ids
+    if as_np:
+        a = np.ascontiguousarray(lbl_img)
+        if a.size and (int(a.max()) >= 2 ** 31 or int(a.max()) > 4 * a.size + 1024):
+            u, inv = np.unique(a, return_inverse=True)
+            a = inv.reshape(a.shape).astype(np.int64) + (0 if (len(u) and u[0] == 0) else 1)
+            if len(u) and u[0] < 0:
+                raise ValueError("edt_prob: negative labels")
+        lab = torch.from_numpy(a.astype(np.int32, copy=False)).cuda()
+    else:
+        t = lbl_img
+        if t.numel() and (int(t.max()) >= 2 ** 31 or int(t.max()) > 4 * t.numel() + 1024):
+            u, inv = torch.unique(t, return_inverse=True)
+            t = inv.reshape(t.shape) + (0 if int(u[0]) == 0 else 1)
+        lab = t.to(torch.int32).contiguous()
     nd = lab.dim()
     if nd not in (2, 3):
         raise ValueError("edt_prob: label image must be 2D or 3D")

@@ -75,3 +75,14 @@ def test_training_targets_equal_reference_composition(refmods):
     assert not np.array_equal(want3, port.edt_prob(lab3[0][:, ::2, ::2], anisotropy=(2.0, 1.0, 1.0)))
     prob2, dm2 = stardist_targets(lab3, rays=rays, grid=(2, 2, 2))
     assert np.array_equal(prob2[0, ..., 0], port.edt_prob(lab3[0])[::2, ::2, ::2])
+
+
+def test_edt_prob_huge_and_sparse_label_ids():
+    """ids beyond int32 / hash-like sparse ids are compacted first: same result as with small consecutive ids"""
+    from stardist_amd import utils
+    lab = _blobs((40, 56), 7, seed=4).astype(np.int64)
+    want = utils.edt_prob(lab)
+    big = np.where(lab > 0, lab * 7919 + 2 ** 33, 0)
+    assert np.array_equal(utils.edt_prob(big), want)
+    sparse = np.where(lab > 0, lab * 1000003, 0)
+    assert np.array_equal(utils.edt_prob(sparse), want)
