@@ -24,6 +24,8 @@
 //           convex hulls by exhaustive facet search (one wave per polyhedron: every vertex triple whose
 //           plane has all other vertices on one side), then the same half-space volume routine.
 //       (5) voxel rendering: count lattice points inside both polyhedra -> suppress :1305-1330
+#include <algorithm>
+
 #include "common.h"
 #include "geom3d.h"
 #include "../../include/stardist_hip.h"
@@ -1567,11 +1569,13 @@ __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, u
                                                int2* __restrict__ pairs5, unsigned int* pair5Count, Stats* st, int no_lb,
                                                const float* __restrict__ bverts, const int* __restrict__ bfaces, int bR, int bF,
                                                double* __restrict__ volOut = nullptr, int2* __restrict__ pairsX = nullptr,
-                                               unsigned int* __restrict__ nX = nullptr) {
-  // pairsX != nullptr: undecided pairs are queued for k_stage4x (as in k_stage3)
+                                               unsigned int* __restrict__ nX = nullptr, unsigned int wsBytes = 0) {
+  // pairsX != nullptr: undecided pairs are queued for k_stage4x (as in k_stage3).  wsBytes != 0: the workspace between the half-spaces
+  // and the seed / pos / orig lists is only that large (a bounds-only launch: the polygon workspace of the exact routine is not needed,
+  // the smaller footprint lets six waves share a CU instead of four)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* hs = (double*)smem;                   // 2*cap*4
-  unsigned short* seed = (unsigned short*)(smem + (size_t)8 * cap * sizeof(double) + hiv_poly_bytes_dev());   // 2*cap*3
+  unsigned short* seed = (unsigned short*)(smem + (size_t)8 * cap * sizeof(double) + (wsBytes ? (size_t)wsBytes : hiv_poly_bytes_dev()));   // 2*cap*3
   unsigned short* pos = seed + 6 * cap;         // 2*cap
   unsigned short* orig = pos + 2 * cap;         // 2*cap
   HivLds W;
@@ -2036,9 +2040,15 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   // (the launches of the later rounds hold few pairs and lasted as long as their slowest pair, an exact volume of ~1 ms by one wave;
   // in the first round the one-wave form is faster: thousands of exact volumes keep every SIMD busy either way)
   const size_t lds3x = stage3x_lds(F, ws3, 4), lds4x = stage4x_lds(2 * R, 4);
-  const bool split3 = sd::option(sd::OPT_NMS3D_SPLIT_EXACT) && lds3x <= 150 * 1024;
-  const bool split4 = sd::option(sd::OPT_NMS3D_SPLIT_EXACT) && lds4x <= 150 * 1024;
-  const unsigned int split3Max = 32768u, split4Max = 16384u;           // pairs per launch up to which the second pass pays
+  // option nms3d_split_exact: 0 exact volumes in place; 1 second pass (k_stage3x / k_stage4x: four waves per pair) for the smaller launches
+  // (round 3); 2 (default): stage 3 ALWAYS splits, and a bounds-only first pass is launched with the small LDS footprint (no polygon
+  // workspace: 25.6 instead of 39.3 KB per wave = six waves per CU instead of four) -- measured on the 256^3 bench set: stage 3
+  // 12.9 -> 10.7 ms; stage 4 keeps its threshold (always splitting it: 12.6 -> 13.1 ms, the hull construction dominates there);
+  // 3: both stages always split
+  const int splitOpt = sd::option(sd::OPT_NMS3D_SPLIT_EXACT);
+  const bool split3 = splitOpt && lds3x <= 150 * 1024;
+  const bool split4 = splitOpt && lds4x <= 150 * 1024;
+  const unsigned int split3Max = splitOpt >= 2 ? 0x7fffffffu : 32768u, split4Max = splitOpt >= 3 ? 0x7fffffffu : 16384u;   // pairs per launch up to which the second pass pays
   if (split3 && lds3x > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_stage3x<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3x));
   if (split4 && lds4x > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_stage4x<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4x));
   if (ldsH > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_hull, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsH));
@@ -2284,9 +2294,15 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
       if (h.nP3 > 0) {
         const unsigned int b3 = h.nP3 < 16384u ? h.nP3 : 16384u;
         if (stats) SD_CHECK(hipEventRecord(ev0, s));
-        hipLaunchKernelGGL(k_stage3, dim3(b3), dim3(64), lds3, s, pairs3, h.nP3, d_dist, d_points, d_verts, d_faces, faceAdj, R, F, volume,
-                           threshold, sink, pairs4, &d_cnt->nP4, d_st, (unsigned int)ws3 | (use_bounds ? 0u : 0x80000000u) | (trace ? SD_PROF_BIT : 0u), bverts, bfaces, bR, bF,
-                           (double*)nullptr, (split3 && h.nP3 <= split3Max) ? pairsX : (int2*)nullptr, &d_cnt->nX3);
+        const bool sp3 = split3 && h.nP3 <= split3Max;
+        // bounds-only pass: the workspace only holds the ray-cast vectors (3 bR doubles + bR shorts; at least the 6 R floats of the vertex staging)
+        const size_t ws3s = (std::max((size_t)6 * R * sizeof(float), (size_t)3 * bR * sizeof(double) + (size_t)2 * bR) + 15) & ~(size_t)15;
+        const bool small3 = sp3 && splitOpt >= 2 && ws3s < ws3;
+        const size_t ws3l = small3 ? ws3s : ws3;
+        const size_t lds3l = (size_t)8 * F * sizeof(double) + ws3l + (size_t)10 * F * sizeof(unsigned short);
+        hipLaunchKernelGGL(k_stage3, dim3(b3), dim3(64), lds3l, s, pairs3, h.nP3, d_dist, d_points, d_verts, d_faces, faceAdj, R, F, volume,
+                           threshold, sink, pairs4, &d_cnt->nP4, d_st, (unsigned int)ws3l | (use_bounds ? 0u : 0x80000000u) | (trace ? SD_PROF_BIT : 0u), bverts, bfaces, bR, bF,
+                           (double*)nullptr, sp3 ? pairsX : (int2*)nullptr, &d_cnt->nX3);
         if (split3 && h.nP3 <= split3Max)
           hipLaunchKernelGGL(k_stage3x<4>, dim3(h.nP3 < 256u ? h.nP3 : 256u), dim3(256), lds3x, s, pairsX, &d_cnt->nX3, 0u, d_dist, d_points, d_verts, d_faces, faceAdj,
                              R, F, volume, threshold, sink, pairs4, &d_cnt->nP4, d_st, (unsigned int)ws3, (double*)nullptr);
@@ -2314,9 +2330,13 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
                                h.nHull, d_dist, d_points, d_verts, R, hullCap, hullPlanes, hullAdj, hullCount);
             SD_LAUNCH_CHECK();
           }
-          hipLaunchKernelGGL(k_stage4, dim3(b4), dim3(64), lds4, s, pairs4, h.nP4, d_dist, d_points, d_verts, d_faces, R, F, hullCap, hullPlanes, hullAdj, hullCount,
+          const bool sp4 = split4 && h.nP4 <= split4Max;
+          const size_t ws4s = (((size_t)3 * bR * sizeof(double) + (size_t)2 * bR) + 15) & ~(size_t)15;
+          const bool small4 = sp4 && splitOpt >= 2 && ws4s < hivBytes;
+          const size_t lds4l = small4 ? (size_t)16 * R * sizeof(double) + ws4s + (size_t)20 * R * sizeof(unsigned short) : lds4;
+          hipLaunchKernelGGL(k_stage4, dim3(b4), dim3(64), lds4l, s, pairs4, h.nP4, d_dist, d_points, d_verts, d_faces, R, F, hullCap, hullPlanes, hullAdj, hullCount,
                              volume, threshold, pairs5, &d_cnt->nP5, d_st, use_bounds ? 0 : 1, bverts, bfaces, bR, bF, (double*)nullptr,
-                             (split4 && h.nP4 <= split4Max) ? pairsX : (int2*)nullptr, &d_cnt->nX4);
+                             sp4 ? pairsX : (int2*)nullptr, &d_cnt->nX4, small4 ? (unsigned int)ws4s : 0u);
           if (split4 && h.nP4 <= split4Max)
             hipLaunchKernelGGL(k_stage4x<4>, dim3(h.nP4 < 256u ? h.nP4 : 256u), dim3(256), lds4x, s, pairsX, &d_cnt->nX4, 0u, d_dist, d_points, R, hullCap, hullPlanes, hullAdj,
                                hullCount, volume, threshold, pairs5, &d_cnt->nP5, d_st, (double*)nullptr);

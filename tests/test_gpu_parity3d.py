@@ -151,7 +151,7 @@ def test_nms3d_split_exact_does_not_change_survivors_or_volumes(refmods):
     refmods.stardist3d(); refmods.set_threads(1)
     ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(0.3))
     keeps = {}
-    for split in (1, 0):
+    for split in (2, 3, 1, 0):          # 2 (default): second pass for small launches + small-footprint bounds pass; 3: for every launch
         for bounds in (1, 0):
             with N.option("nms3d_split_exact", split), N.option("nms3d_volume_bounds", bounds):
                 keeps[split, bounds] = sd3.c_non_max_suppression_inds(*args).cpu().numpy()
@@ -165,9 +165,10 @@ def test_nms3d_split_exact_does_not_change_survivors_or_volumes(refmods):
     close = np.linalg.norm(pp[pairs[:, 0]] - pp[pairs[:, 1]], axis=1) < 14
     pairs = np.ascontiguousarray(pairs[close][:600])
     vols = {}
-    for split in (1, 0):
+    for split in (1, 0, 2):
         with N.option("nms3d_split_exact", split):
             vols[split] = [np.asarray(v) for v in sd3.hiv_pair_volumes(dd, pp, np.float32(V), F, pairs)]
+    assert np.array_equal(vols[2][0], vols[0][0]) and np.array_equal(vols[2][1], vols[0][1])
     assert len(pairs) > 50 and (vols[1][0] > 0).sum() > 10
     assert np.array_equal(vols[1][0], vols[0][0]) and np.array_equal(vols[1][1], vols[0][1])
 

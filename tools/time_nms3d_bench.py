@@ -10,6 +10,9 @@ from stardist_amd.lib import _native, stardist3d as sd3
 from stardist_amd.models import Config3D, StarDist3D
 from stardist_amd.rays3d import rays_from_json
 dev = torch.device("cuda:0")
+if os.environ.get("SD_SPLIT_EXACT"):
+    _native.check(_native.lib().sd_set_option(b"nms3d_split_exact", int(os.environ["SD_SPLIT_EXACT"])))
+    print("nms3d_split_exact =", _native.lib().sd_get_option(b"nms3d_split_exact"))
 if os.environ.get("SD_TRACE"):
     _native.lib().sd_set_option(b"trace", 1)      # per-round counters on stdout
 S = int(os.environ.get("SD_SIZE3D", "256"))
