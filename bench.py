@@ -260,7 +260,7 @@ def run_leg(model, img, steps, warmup, world, dist_):
     net_ms = sum(a.elapsed_time(b) for a, b in pairs) / max(1, len(pairs))
     model._net_forward = orig_forward
     if world > 1:
-        tt = torch.tensor([elapsed], device=img.device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=img.device if dist_.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist_.all_reduce(tt, op=dist_.ReduceOp.MAX)
         elapsed = float(tt.item())
     return elapsed, net_ms, res, stats
@@ -336,7 +336,7 @@ def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, di
     mean = {k: (v if isinstance(v, list) else (round(v / passes, 4) if isinstance(v, float) else v // passes)) for k, v in acc.items()}
     per_rank = [None] * world
     if world > 1:
-        tt = torch.tensor([elapsed], device=big.device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=big.device if dist_.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist_.all_reduce(tt, op=dist_.ReduceOp.MAX)
         elapsed = float(tt.item())
         dist_.all_gather_object(per_rank, mean)
@@ -420,8 +420,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # plumbing check on a one-GPU box: STARDIST_AMD_BENCH_BACKEND=gloo runs the N ranks on ONE device with gloo collectives (every
+        # code path of the N > 1 legs except the RCCL transport; the numbers of such a run mean nothing)
+        backend = os.environ.get("STARDIST_AMD_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist_.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" IS RCCL on ROCm
+        dist_.init_process_group(backend, rank=rank, world_size=world)   # "nccl" IS RCCL on ROCm
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
     threads = args.cpu_threads or min(os.cpu_count() or 1, 32)
