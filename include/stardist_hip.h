@@ -297,6 +297,12 @@ int sd_conv3_f16x3_res_ndhwc_device(const float* d_src0, int c0, int stride0, in
                                     const float* d_res, int res_stride, int c_out, int act, float* d_out, int* d_range_flag,
                                     void* stream);
 
+/* UpSampling2D/3D (nearest, x2 along the axes of `up`: bit 0 x, 1 y, 2 z) + Concatenate([up-sampled a, b]) of a csbdeep unet_block up
+ * level as one channels-last tensor [D][H][W][ca + cb] (a: [D >> z][H >> y][W >> x][ca]).  Only the coverage path needs it -- up
+ * levels whose channel counts are not multiples of 32 (e.g. n_filter_base = 48) run this + sd_convg_ndhwc_device; the fused 3x3 kernels
+ * above never materialise the concatenation.  ca, cb multiples of 4. */
+int sd_upcat_ndhwc_device(const float* d_a, int ca, int up, const float* d_b, int cb, int D, int H, int W, float* d_out, void* stream);
+
 /* ---- general convolution (any kernel size, stride, padding, channel counts) ------------------------------------------------
  * Every other convolution of the reference's networks, channels-last float32, exact f32 on the matrix cores with one fixed fma chain
  * per output (bias first, residual last): the 7x7x7 stem, the strided first convolution and the strided 1x1x1 shortcut projection of

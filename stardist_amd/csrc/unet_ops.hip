@@ -159,7 +159,43 @@ __global__ void __launch_bounds__(256) k_maxpool_cl4(const float4* __restrict__ 
   }
 }
 
+// UpSampling (nearest, x2 along the axes of `up`) + Concatenate([up-sampled a, b]) as ONE channels-last tensor: the coverage path of an
+// up level whose channel counts the fused 3x3 kernels do not take (csbdeep unet_block, e.g. n_filter_base = 48); thread per
+// (output pixel, channel quad)
+__global__ void __launch_bounds__(256) k_upcat_cl4(const float4* __restrict__ a, int ca4, int shz, int shy, int shx, const float4* __restrict__ b, int cb4,
+                                                   int H, int W, long long n_out4, float4* __restrict__ out) {
+  const int C4 = ca4 + cb4;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int Ha = H >> shy, Wa = W >> shx;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n_out4; idx += stride) {
+    const int q = (int)(idx % C4);
+    long long pix = idx / C4;
+    const int x = (int)(pix % W); pix /= W;
+    const int y = (int)(pix % H);
+    const long long z = pix / H;
+    if (q < ca4) out[idx] = a[(((z >> shz) * Ha + (y >> shy)) * (long long)Wa + (x >> shx)) * ca4 + q];
+    else out[idx] = b[((z * H + y) * (long long)W + x) * cb4 + (q - ca4)];
+  }
+}
+
 }  // namespace
+
+extern "C" int sd_upcat_ndhwc_device(const float* d_a, int ca, int up, const float* d_b, int cb, int D, int H, int W, float* d_out, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (D <= 0 || H <= 0 || W <= 0) return 0;
+  if (!d_a || !d_b || !d_out || ca <= 0 || cb <= 0 || (ca % 4) || (cb % 4) || up < 0 || up > 7 || ((up & 1) && (W & 1)) || ((up & 2) && (H & 1)) || ((up & 4) && (D & 1)) ||
+      (((uintptr_t)d_a | (uintptr_t)d_b | (uintptr_t)d_out) & 15)) {
+    sd::set_error("sd_upcat_ndhwc: channel counts must be multiples of 4, pointers 16-byte aligned, up a bit mask (1: x, 2: y, 4: z) over even output sizes");
+    return -1;
+  }
+  const long long n4 = (long long)D * H * W * ((ca + cb) / 4);
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 262144) blocks = 262144;
+  hipLaunchKernelGGL(k_upcat_cl4, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)d_a, ca / 4, (up >> 2) & 1, (up >> 1) & 1, up & 1, (const float4*)d_b, cb / 4, H, W, n4,
+                     (float4*)d_out);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int sd_maxpool_ndhwc_device(const float* d_in, int n_channels, int D, int H, int W, int pz, int py, int px, float* d_out, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;

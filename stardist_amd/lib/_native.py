@@ -54,6 +54,7 @@ SIGNATURES = {
     "sd_bias_act_device": (_i, [_vp, _vp, ctypes.c_longlong, _i, ctypes.c_longlong, _i, _vp]),
     "sd_add_bias_act_device": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, ctypes.c_longlong, _i, _vp]),
     "sd_maxpool_ndhwc_device": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sd_upcat_ndhwc_device": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sd_inside_polyhedron_device": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp]),
     "sd_bias_act_dot_device": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "sd_head_rows_device": (_i, [_vp, _i, _vp, ctypes.c_longlong, _vp, _vp, _i, ctypes.c_float, _vp, _vp]),

@@ -283,6 +283,27 @@ def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False):
     return out
 
 
+def _upcat_general(conv, x, skip, pool, kind, bn=None):
+    """coverage path of an up level the fused kernels do not take (e.g. n_filter_base = 48: 96 + 96 input channels): UpSampling +
+    Concatenate materialised by the native one-pass kernel (sd_upcat_ndhwc_device), then the general convolution kernel.  None when
+    not applicable."""
+    nd = x.dim() - 2
+    if not (nd in (2, 3) and all(p in (1, 2) for p in pool) and x.shape[0] == 1 and x.dtype == torch.float32 and skip.dtype == torch.float32
+            and x.shape[1] % 4 == 0 and skip.shape[1] % 4 == 0 and x.shape[1] + skip.shape[1] == conv.in_channels
+            and tuple(int(s) * int(p) for s, p in zip(x.shape[2:], pool)) == tuple(int(s) for s in skip.shape[2:])):
+        return None
+    from ..lib import _native as N
+    cl = torch.channels_last if nd == 2 else torch.channels_last_3d
+    a = x if x.is_contiguous(memory_format=cl) and x.data_ptr() % 16 == 0 else x.clone(memory_format=cl)
+    b = skip if skip.is_contiguous(memory_format=cl) and skip.data_ptr() % 16 == 0 else skip.clone(memory_format=cl)
+    S = (1,) * (3 - nd) + tuple(int(v) for v in skip.shape[2:])
+    up = sum((1 << k) for k, p in enumerate(reversed(pool)) if p == 2)                    # bit 0: x, 1: y, 2: z
+    cat = torch.empty((1, a.shape[1] + b.shape[1]) + tuple(skip.shape[2:]), dtype=torch.float32, device=x.device, memory_format=cl)
+    N.dcall(a, "sd_upcat_ndhwc_device", ctypes.c_void_p(a.data_ptr()), int(a.shape[1]), up, ctypes.c_void_p(b.data_ptr()), int(b.shape[1]), *S,
+            ctypes.c_void_p(cat.data_ptr()))
+    return _general_conv(conv, cat, kind, None, bn)
+
+
 def _conv_bias_act(conv, x, kind):
     """conv + bias + (0 linear | 1 relu) of GPU inference by a hand-written kernel; None when the hand-written path does not apply
     (CPU, autograd, autocast: the caller runs the plain modules); raises UnsupportedLayer for a layer no kernel covers"""
@@ -395,6 +416,8 @@ class UNetBlock(nn.Module):
                 conv0, bn, kind = first.parts()
                 srcs = [(x, tuple(p == 2 for p in self.pool)), (skip, 0)]
                 y = _hand_conv(conv0, srcs, kind, bn=bn) if (all(p in (1, 2) for p in self.pool) and kind >= 0) else None
+                if y is None and kind >= 0:
+                    y = _upcat_general(conv0, x, skip, self.pool, kind, bn)      # coverage path (channel counts not in 32-chunks)
                 if y is None:
                     raise UnsupportedLayer("up-level " + _layer_desc(conv0, srcs) + ", pool %s" % (self.pool,))
                 x = blk[1:](y)

@@ -37,6 +37,11 @@ def _models(kind):
         return (lambda d: StarDist2D(Config2D(n_rays=32, n_classes=3), basedir=None, device=d, seed=0)), ("2d", 256), dict()
     if kind == "unet2d-depth4":  # unet_n_depth=4: the last up-level concatenates 256 + 256 channels (16 chunks)
         return (lambda d: StarDist2D(Config2D(n_rays=32, unet_n_depth=4), basedir=None, device=d, seed=0)), ("2d", 256), dict()
+    if kind == "unet2d-base48":  # channel counts that are no multiples of 32: every layer on the general kernel, up levels through sd_upcat_ndhwc_device
+        return (lambda d: StarDist2D(Config2D(n_rays=32, unet_n_filter_base=48, unet_n_depth=2), basedir=None, device=d, seed=0)), ("2d", 256), dict()
+    if kind == "unet3d-base48":
+        return (lambda d: StarDist3D(Config3D(rays=96, unet_n_filter_base=48, unet_n_depth=1), basedir=None, device=d, seed=0)), ("3d", 48), \
+            dict(frac=0.02, radius=8.5, noise=0.03)
     if kind == "unet3d":
         return (lambda d: StarDist3D(Config3D(rays=96), basedir=None, device=d, seed=0)), ("3d", 64), dict(frac=0.02, radius=8.5, noise=0.03)
     if kind == "resnet3d":   # the reference's 3D_demo topology: resnet backbone, grid (1,2,2)
@@ -56,7 +61,7 @@ def _image(dim, size):
 
 # every topology with the default convolution kernel (split-fp16 products, f32 accumulation); "-f32exact": the exact-f32 MFMA kernel;
 # "-bf16x6": the six-product bf16 form (the range fallback of the default)
-KINDS = ["unet2d", "unet2d-grid2", "unet2d-he", "unet2d-bn", "unet2d-multiclass", "unet2d-depth4", "unet3d", "resnet3d",
+KINDS = ["unet2d", "unet2d-grid2", "unet2d-he", "unet2d-bn", "unet2d-multiclass", "unet2d-depth4", "unet2d-base48", "unet3d-base48", "unet3d", "resnet3d",
          "unet2d-f32exact", "unet2d-grid2-f32exact", "unet2d-bn-f32exact", "unet3d-f32exact", "resnet3d-f32exact",
          "unet2d-bf16x6", "unet3d-bf16x6", "resnet3d-bf16x6"]
 
