@@ -72,9 +72,26 @@ class Rays_Base(object):
         return res
 
 
+_RAYS_CACHE = {}
+
+
 def rays_from_json(d):
+    """rays3d.py:156.  The objects are immutable in use (`copy(scale)` returns a new one), so one instance per description is kept:
+    building Rays_GoldenSpiral(96) runs scipy's ConvexHull (1.4 ms), and the reference's call sites ask for it on every
+    predict_instances (model3d.py:600)."""
+    import json
     cls = {c.__name__: c for c in (Rays_Explicit, Rays_Cartesian, Rays_Tetra, Rays_Octo, Rays_GoldenSpiral)}
-    return cls[d["name"]](**d["kwargs"])
+    try:
+        key = json.dumps(d, sort_keys=True)
+    except TypeError:
+        return cls[d["name"]](**d["kwargs"])
+    r = _RAYS_CACHE.get(key)
+    if r is None:
+        if len(_RAYS_CACHE) >= 16:
+            _RAYS_CACHE.clear()
+        r = cls[d["name"]](**d["kwargs"])
+        _RAYS_CACHE[key] = r
+    return r
 
 
 class Rays_Explicit(Rays_Base):
