@@ -1224,12 +1224,17 @@ __device__ __forceinline__ PivotFrame hull_pivot_frame(const double u[3], const 
 }
 __device__ __forceinline__ void hull_pivot_part(const double* __restrict__ pv, int R, int iu, int iv, int it, const PivotFrame& F, int q0, int qstep,
                                                 int& best, double& bx, double& by) {
+  // Branch-free and unrolled: the loop is a chain of LDS reads and dependent f64 operations, and its only product is the CHOICE of a
+  // vertex (the facet is verified afterwards with the exhaustive search's arithmetic), so the projections may be fused.
   best = -1; bx = 0; by = 0;
+  const double ux = F.u[0] * F.x[0] + F.u[1] * F.x[1] + F.u[2] * F.x[2], uy = F.u[0] * F.y[0] + F.u[1] * F.y[1] + F.u[2] * F.y[2];
+#pragma unroll 4
   for (int q = q0; q < R; q += qstep) {
-    if (q == iu || q == iv || q == it) continue;
-    const double d0 = pv[3 * q] - F.u[0], d1 = pv[3 * q + 1] - F.u[1], d2 = pv[3 * q + 2] - F.u[2];
-    const double xq = d0 * F.x[0] + d1 * F.x[1] + d2 * F.x[2], yq = d0 * F.y[0] + d1 * F.y[1] + d2 * F.y[2];
-    if (best < 0 || bx * yq - by * xq > 0) { best = q; bx = xq; by = yq; }     // q is counter-clockwise of the current extreme
+    const double p0 = pv[3 * q], p1 = pv[3 * q + 1], p2 = pv[3 * q + 2];
+    const double xq = __builtin_fma(p0, F.x[0], __builtin_fma(p1, F.x[1], __builtin_fma(p2, F.x[2], -ux)));
+    const double yq = __builtin_fma(p0, F.y[0], __builtin_fma(p1, F.y[1], __builtin_fma(p2, F.y[2], -uy)));
+    const bool take = (q != iu) & (q != iv) & (q != it) & ((best < 0) | (bx * yq > by * xq));     // q is counter-clockwise of the current extreme
+    best = take ? q : best; bx = take ? xq : bx; by = take ? yq : by;
   }
 }
 __device__ __forceinline__ void hull_pivot_merge(int& best, double& bx, double& by, int obest, double obx, double oby) {
@@ -1250,10 +1255,26 @@ __device__ __forceinline__ int hull_pivot_group(const double* __restrict__ pv, i
   return best;
 }
 
-// tri: facets packed a << 20 | b << 10 | c with a < b < c, bit 30 = flip the normal; returns the facet count or -1
-__device__ int hull_giftwrap(const double* __restrict__ pv, int R, int cap, int p0, double ext, unsigned int* tri, unsigned char* cnt,
+// Edge use counts of the wrap: two bits per vertex pair lo * R + hi, sixteen to a word, incremented with a word atomic.  A field
+// that would pass 2 makes the increment that sees 2 report it and the construction is abandoned before anything reads the
+// (then possibly carried-into) neighbouring fields.  R * R / 4 bytes instead of R * R: 10 instead of 17 KB of LDS per polyhedron.
+__device__ __forceinline__ unsigned int hull_cnt_get(const unsigned int* cntw, int idx) { return (cntw[idx >> 4] >> ((idx & 15) * 2)) & 3u; }
+__device__ __forceinline__ unsigned int hull_cnt_inc(unsigned int* cntw, int idx) {
+  const unsigned int sh = (unsigned int)(idx & 15) * 2u;
+  return (atomicAdd(&cntw[idx >> 4], 1u << sh) >> sh) & 3u;
+}
+
+// tri: facets packed a << 20 | b << 10 | c with a < b < c, bit 30 = flip the normal; returns the facet count or -1.
+// One batch = up to 64 open edges, `grp` lanes each: the group pivots its edge, VERIFIES the facet it found against all R points
+// (criterion and arithmetic of the exhaustive search) and its first lane inserts it -- every step of a batch runs on all edges at
+// once (round 3 verified and inserted the facets one after the other with the whole wave: 2 R-point passes, a square root and a
+// barrier per facet, ~190 times per polyhedron).  A facet is reached from each of its open edges; the proposal through the
+// SMALLEST open edge inserts it (all open edges are in the frontier, so that edge is pivoted in this round too; its batch may be a
+// later one -- then the facet is inserted there).  If the point set is degenerate the proposals disagree: an edge gets a third
+// facet or stays open, both are detected (use counts) and the caller falls back to the exhaustive search.
+__device__ int hull_giftwrap(const double* __restrict__ pv, int R, int cap, int p0, double ext, unsigned int* tri, unsigned int* cntw,
                              unsigned int* frA, unsigned int* frB, int* s_cnt, int lane) {
-  for (int k = lane; k < (R * R + 3) / 4; k += 64) ((unsigned int*)cnt)[k] = 0u;
+  for (int k = lane; k < (R * R + 15) / 16; k += 64) cntw[k] = 0u;
   double g[3] = {0, 0, 0};
   for (int k = lane; k < R; k += 64) { g[0] += pv[3 * k]; g[1] += pv[3 * k + 1]; g[2] += pv[3 * k + 2]; }
   for (int o = 32; o; o >>= 1) { g[0] += __shfl_xor(g[0], o); g[1] += __shfl_xor(g[1], o); g[2] += __shfl_xor(g[2], o); }
@@ -1278,79 +1299,89 @@ __device__ int hull_giftwrap(const double* __restrict__ pv, int R, int cap, int 
   }
   int nfr = 0;            // entries in the current frontier (uniform)
   unsigned int* frCur = frA; unsigned int* frNext = frB;
-  int nf = 0;             // facets so far (uniform, mirrored in s_cnt[0])
+  int nf = 0;             // facets so far (uniform, mirror of s_cnt[0])
   bool failed = false;
-  // the insertion routine is used for the first facet as well: a "batch" with one proposal
-  int prop_u = p0, prop_v = p1, prop_w = (lane == 0) ? p2 : -1;
   int round_start = 0;
   for (int round = 0; round < 8 * R && !failed; ++round) {
-    // the open edges of the frontier are pivoted `per` at a time; the 64 / per lanes of an edge's group split the R points among them
-    // (a small frontier -- the first and the last rounds of the breadth-first wrap -- costs R / grp steps instead of R)
+    // round 0 is a "batch" with the first facet as its only proposal, verified by the whole wave.  Later: the open edges of the
+    // frontier, `per` at a time; the 64 / per lanes of an edge's group split the R points among them (a small frontier -- the first
+    // and the last rounds of the breadth-first wrap -- costs R / grp steps instead of R)
+    const int nitems = round == 0 ? 1 : nfr;
     int per = 64, grp = 1;
-    if (round > 0) { while (per > 1 && (per >> 1) >= nfr) { per >>= 1; grp <<= 1; } }
-    for (int base = 0; (round == 0 ? base == 0 : base < nfr) && !failed; base += per) {
-      if (round > 0) {
-        prop_w = -1;
-        const int slot = lane / grp, sub = lane - slot * grp;
-        bool bad = false;
-        int cand_w = -1;
-        // (every lane of a group takes the same branch: the condition depends on the edge only)
-        if (base + slot < nfr) {
-          const unsigned int item = frCur[base + slot];
-          prop_u = (int)(item & 1023u); prop_v = (int)((item >> 10) & 1023u);
-          const int t = (int)((item >> 20) & 1023u);
-          const int lo = prop_u < prop_v ? prop_u : prop_v, hi = prop_u < prop_v ? prop_v : prop_u;
-          if (cnt[lo * R + hi] == 1) {
-            const double u[3] = {pv[3 * prop_u], pv[3 * prop_u + 1], pv[3 * prop_u + 2]};
-            const double e[3] = {pv[3 * prop_v] - u[0], pv[3 * prop_v + 1] - u[1], pv[3 * prop_v + 2] - u[2]};
-            const double dref[3] = {pv[3 * t] - u[0], pv[3 * t + 1] - u[1], pv[3 * t + 2] - u[2]};
-            const PivotFrame F = hull_pivot_frame(u, e, dref, g);
-            if (!F.ok) bad = true;
-            else {
-              cand_w = hull_pivot_group(pv, R, prop_u, prop_v, t, F, sub, grp);
-              if (cand_w < 0) bad = true;
-            }
+    while (per > 1 && (per >> 1) >= nitems) { per >>= 1; grp <<= 1; }
+    for (int base = 0; base < nitems && !failed; base += per) {
+      const int slot = lane / grp, sub = lane - slot * grp;
+      int eu = -1, ev = -1, w = -1;
+      bool bad = false;
+      // (every lane of a group takes the same branches: the conditions depend on the edge only)
+      if (round == 0) { eu = p0; ev = p1; w = p2; }
+      else if (base + slot < nitems) {
+        const unsigned int item = frCur[base + slot];
+        eu = (int)(item & 1023u); ev = (int)((item >> 10) & 1023u);
+        const int t = (int)((item >> 20) & 1023u);
+        const int lo = eu < ev ? eu : ev, hi = eu < ev ? ev : eu;
+        if (hull_cnt_get(cntw, lo * R + hi) == 1u) {               // still open (not closed by an earlier batch of this round)
+          const double u[3] = {pv[3 * eu], pv[3 * eu + 1], pv[3 * eu + 2]};
+          const double e[3] = {pv[3 * ev] - u[0], pv[3 * ev + 1] - u[1], pv[3 * ev + 2] - u[2]};
+          const double dref[3] = {pv[3 * t] - u[0], pv[3 * t + 1] - u[1], pv[3 * t + 2] - u[2]};
+          const PivotFrame F = hull_pivot_frame(u, e, dref, g);
+          if (!F.ok) bad = true;
+          else {
+            w = hull_pivot_group(pv, R, eu, ev, t, F, sub, grp);
+            if (w < 0) bad = true;
           }
         }
-        if (bad) failed = true;
-        if (sub == 0) prop_w = cand_w;                 // one proposal per edge, on the first lane of its group
       }
-      failed = __any(failed);
-      unsigned long long mask = __ballot(prop_w >= 0);
-      while (mask && !failed) {
-        const int src = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        int a = __shfl(prop_u, src), b = __shfl(prop_v, src), c = __shfl(prop_w, src);
-        { const int lo = a < b ? a : b, hi = a < b ? b : a; if (round > 0 && cnt[lo * R + hi] != 1) continue; }   // closed meanwhile
+      // verification by the edge's group (same arithmetic and tolerance as the exhaustive search)
+      int a = eu, b = ev, c = w;
+      unsigned int key = 0u;
+      bool okf = false;
+      if (w >= 0) {
         if (a > b) { const int t_ = a; a = b; b = t_; }
         if (b > c) { const int t_ = b; b = c; c = t_; }
         if (a > b) { const int t_ = a; a = b; b = t_; }
-        if (a == b || b == c) { failed = true; break; }
-        // verification (same arithmetic and tolerance as the exhaustive search)
-        const double az = pv[3 * a], ay = pv[3 * a + 1], ax = pv[3 * a + 2];
-        const double ez = pv[3 * b] - az, ey_ = pv[3 * b + 1] - ay, ex_ = pv[3 * b + 2] - ax;
-        const double fz = pv[3 * c] - az, fy = pv[3 * c + 1] - ay, fx = pv[3 * c + 2] - ax;
-        const double nz = ey_ * fx - ex_ * fy, ny = ex_ * fz - ez * fx, nx = ez * fy - ey_ * fz;
-        const double nn = sqrt(nz * nz + ny * ny + nx * nx);
-        const double te = 1e-10 * nn * (ext + 1e-30);
-        if (!(nn > 1e-12 * ext * ext)) { failed = true; break; }
-        bool pos = false, neg = false, flat = false;
-        for (int q = lane; q < R; q += 64) {
-          if (q == a || q == b || q == c) continue;
-          const double sd_ = nz * (pv[3 * q] - az) + ny * (pv[3 * q + 1] - ay) + nx * (pv[3 * q + 2] - ax);
-          if (sd_ > te) pos = true; else if (sd_ < -te) neg = true; else flat = true;
+        if (a == b || b == c) bad = true;
+        else {
+          const double az = pv[3 * a], ay = pv[3 * a + 1], ax = pv[3 * a + 2];
+          const double ez = pv[3 * b] - az, ey_ = pv[3 * b + 1] - ay, ex_ = pv[3 * b + 2] - ax;
+          const double fz = pv[3 * c] - az, fy = pv[3 * c + 1] - ay, fx = pv[3 * c + 2] - ax;
+          const double nz = ey_ * fx - ex_ * fy, ny = ex_ * fz - ez * fx, nx = ez * fy - ey_ * fz;
+          const double nn = sqrt(nz * nz + ny * ny + nx * nx);
+          const double te = 1e-10 * nn * (ext + 1e-30);
+          if (!(nn > 1e-12 * ext * ext)) bad = true;
+          else {
+            int fl = 0;                                            // 1: a point above, 2: below, 4: on the plane
+#pragma unroll 4
+            for (int q = sub; q < R; q += grp) {
+              const double sd_ = nz * (pv[3 * q] - az) + ny * (pv[3 * q + 1] - ay) + nx * (pv[3 * q + 2] - ax);
+              const int f = sd_ > te ? 1 : (sd_ < -te ? 2 : 4);
+              fl |= ((q == a) | (q == b) | (q == c)) ? 0 : f;
+            }
+            for (int o = grp >> 1; o; o >>= 1) fl |= __shfl_xor(fl, o);
+            if ((fl & 3) == 3 || (fl & 4)) bad = true;
+            else { okf = true; key = ((unsigned int)a << 20) | ((unsigned int)b << 10) | (unsigned int)c | ((fl & 1) ? (1u << 30) : 0u); }
+          }
         }
-        const bool anyp = __any(pos), anyn = __any(neg), anyf = __any(flat);
-        if ((anyp && anyn) || anyf || nf >= cap) { failed = true; break; }
-        if (lane == 0) {
-          tri[nf] = ((unsigned int)a << 20) | ((unsigned int)b << 10) | (unsigned int)c | (anyp ? (1u << 30) : 0u);
-          const unsigned char c0 = ++cnt[a * R + b], c1 = ++cnt[b * R + c], c2 = ++cnt[a * R + c];
-          if (c0 > 2 || c1 > 2 || c2 > 2) s_cnt[2] = 1;
-        }
-        ++nf;
-        __syncthreads();
-        if (s_cnt[2]) failed = true;
       }
+      if (__any(bad)) { failed = true; break; }
+      // insertion: one lane per facet
+      const int iab = a * R + b, iac = a * R + c, ibc = b * R + c;     // iab < iac < ibc
+      bool win = okf && sub == 0;
+      if (win && round > 0) {
+        const int my = (eu < ev ? eu : ev) * R + (eu < ev ? ev : eu);
+        if (iab < my && hull_cnt_get(cntw, iab) == 1u) win = false;
+        if (iac < my && hull_cnt_get(cntw, iac) == 1u) win = false;
+      }
+      __builtin_amdgcn_wave_barrier();                               // every lane has read the counts of the batch's start
+      if (win) {
+        const int pos = atomicAdd(&s_cnt[0], 1);
+        if (pos < cap) tri[pos] = key;
+        const unsigned int o0 = hull_cnt_inc(cntw, iab), o1 = hull_cnt_inc(cntw, ibc), o2 = hull_cnt_inc(cntw, iac);
+        if (pos >= cap || o0 >= 2u || o1 >= 2u || o2 >= 2u) s_cnt[2] = 1;
+      }
+      __syncthreads();
+      if (s_cnt[2]) failed = true;
+      nf = s_cnt[0];
     }
     if (failed) break;
     // next frontier: edges of this round's facets that are still used once
@@ -1359,9 +1390,9 @@ __device__ int hull_giftwrap(const double* __restrict__ pv, int R, int cap, int 
     for (int t = round_start + lane; t < nf; t += 64) {
       const unsigned int key = tri[t];
       const int a = (int)((key >> 20) & 1023u), b = (int)((key >> 10) & 1023u), c = (int)(key & 1023u);
-      if (cnt[a * R + b] == 1) frNext[atomicAdd(&s_cnt[1], 1)] = (unsigned int)a | ((unsigned int)b << 10) | ((unsigned int)c << 20);
-      if (cnt[b * R + c] == 1) frNext[atomicAdd(&s_cnt[1], 1)] = (unsigned int)b | ((unsigned int)c << 10) | ((unsigned int)a << 20);
-      if (cnt[a * R + c] == 1) frNext[atomicAdd(&s_cnt[1], 1)] = (unsigned int)a | ((unsigned int)c << 10) | ((unsigned int)b << 20);
+      if (hull_cnt_get(cntw, a * R + b) == 1u) frNext[atomicAdd(&s_cnt[1], 1)] = (unsigned int)a | ((unsigned int)b << 10) | ((unsigned int)c << 20);
+      if (hull_cnt_get(cntw, b * R + c) == 1u) frNext[atomicAdd(&s_cnt[1], 1)] = (unsigned int)b | ((unsigned int)c << 10) | ((unsigned int)a << 20);
+      if (hull_cnt_get(cntw, a * R + c) == 1u) frNext[atomicAdd(&s_cnt[1], 1)] = (unsigned int)a | ((unsigned int)c << 10) | ((unsigned int)b << 20);
     }
     __syncthreads();
     nfr = s_cnt[1];
@@ -1372,6 +1403,17 @@ __device__ int hull_giftwrap(const double* __restrict__ pv, int R, int cap, int 
   }
   __syncthreads();
   if (failed || nfr != 0 || nf < 4) return -1;
+  // a closed surface: every edge of every facet is used exactly twice (an edge whose proposal was left to a smaller edge that then
+  // found another facet would still be open)
+  {
+    bool open = false;
+    for (int t = lane; t < nf; t += 64) {
+      const unsigned int key = tri[t];
+      const int a = (int)((key >> 20) & 1023u), b = (int)((key >> 10) & 1023u), c = (int)(key & 1023u);
+      if (hull_cnt_get(cntw, a * R + b) != 2u || hull_cnt_get(cntw, b * R + c) != 2u || hull_cnt_get(cntw, a * R + c) != 2u) open = true;
+    }
+    if (__any(open)) return -1;
+  }
   // sort the facets lexicographically by (a, b, c) (rank sort; keys are distinct)
   for (int t = lane; t < nf; t += 64) {
     const unsigned int key = tri[t] & 0x3FFFFFFFu;
@@ -1385,6 +1427,23 @@ __device__ int hull_giftwrap(const double* __restrict__ pv, int R, int cap, int 
   return nf;
 }
 
+// arg-extreme vertices along the probe directions d0 <= d < d1 (lowest index among equals) -> s_probe[d]
+__device__ __forceinline__ void hull_probes(const double* __restrict__ pv, int R, int lane, int* s_probe, int d0, int d1) {
+  const double dirs[8][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}, {1, 1, 1}, {-1, -1, -1}};
+  for (int d = d0; d < d1; ++d) {
+    double best = -1e300; int bi = 0;
+    for (int k = lane; k < R; k += 64) {
+      const double v = dirs[d][0] * pv[3 * k] + dirs[d][1] * pv[3 * k + 1] + dirs[d][2] * pv[3 * k + 2];
+      if (v > best) { best = v; bi = k; }
+    }
+    for (int o = 32; o; o >>= 1) {
+      const double ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) s_probe[d] = bi;
+  }
+}
+
 __global__ void __launch_bounds__(64) k_hull(const int* __restrict__ hullList, unsigned int nList, const float* __restrict__ dist,
                                              const float* __restrict__ pts, const float* __restrict__ verts, int R, int cap,
                                              double* __restrict__ hullPlanes, unsigned short* __restrict__ hullAdj, int* __restrict__ hullCount) {
@@ -1393,7 +1452,7 @@ __global__ void __launch_bounds__(64) k_hull(const int* __restrict__ hullList, u
   unsigned int* tri = (unsigned int*)(pv + 3 * R);   // cap packed facets a | b << 10 | c << 20
   unsigned int* frA = tri + cap;                     // fast path only: 6R + 6R open edges, R*R edge use counts
   unsigned int* frB = frA + 6 * R;
-  unsigned char* cnt = (unsigned char*)(frB + 6 * R);
+  unsigned int* cnt = frB + 6 * R;                   // R*R edge use counts, two bits each
   __shared__ int s_probe[8];
   __shared__ int s_n;
   __shared__ int s_cnt[3];
@@ -1408,25 +1467,12 @@ __global__ void __launch_bounds__(64) k_hull(const int* __restrict__ hullList, u
     }
     if (lane == 0) s_n = 0;
     __syncthreads();
-    // probes: arg-extremes along 8 directions (all are hull vertices)
+    // probes: arg-extremes along 8 directions (all are hull vertices).  The gift wrapping starts from probe 1 (lowest z); the other
+    // seven are the exhaustive search's quick rejection and are only computed when it runs.
     double ext = 0;
-    {
-      const double dirs[8][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}, {1, 1, 1}, {-1, -1, -1}};
-      for (int d = 0; d < 8; ++d) {
-        double best = -1e300; int bi = 0;
-        for (int k = lane; k < R; k += 64) {
-          const double v = dirs[d][0] * pv[3 * k] + dirs[d][1] * pv[3 * k + 1] + dirs[d][2] * pv[3 * k + 2];
-          if (v > best) { best = v; bi = k; }
-        }
-        for (int o = 32; o; o >>= 1) {
-          const double ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
-          if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
-        if (lane == 0) s_probe[d] = bi;
-      }
-      for (int k = lane; k < R; k += 64) ext = fmax(ext, fmax(fabs(pv[3 * k] - pv[0]), fmax(fabs(pv[3 * k + 1] - pv[1]), fabs(pv[3 * k + 2] - pv[2]))));
-      for (int o = 32; o; o >>= 1) ext = fmax(ext, __shfl_xor(ext, o));
-    }
+    hull_probes(pv, R, lane, s_probe, 1, 2);
+    for (int k = lane; k < R; k += 64) ext = fmax(ext, fmax(fabs(pv[3 * k] - pv[0]), fmax(fabs(pv[3 * k + 1] - pv[1]), fabs(pv[3 * k + 2] - pv[2]))));
+    for (int o = 32; o; o >>= 1) ext = fmax(ext, __shfl_xor(ext, o));
     __syncthreads();
     double* out = hullPlanes + (size_t)cand * cap * 4;
     int nfast = -1;
@@ -1449,7 +1495,9 @@ __global__ void __launch_bounds__(64) k_hull(const int* __restrict__ hullList, u
         tri[t] = ((key >> 20) & 1023u) | (((key >> 10) & 1023u) << 10) | ((key & 1023u) << 20);
       }
       if (lane == 0) s_n = nfast;
-    } else
+    } else {
+    hull_probes(pv, R, lane, s_probe, 0, 8);
+    __syncthreads();
     for (int a = 0; a < R - 2; ++a) {
       const double az = pv[3 * a], ay = pv[3 * a + 1], ax = pv[3 * a + 2];
       for (int b = a + 1; b < R - 1; ++b) {
@@ -1498,6 +1546,7 @@ __global__ void __launch_bounds__(64) k_hull(const int* __restrict__ hullList, u
           }
         }
       }
+    }
     }
     __syncthreads();
     // edge adjacency of the facets (seeds of the intersection-volume routine; a hint, not needed for correctness)
@@ -1864,7 +1913,7 @@ int hull_planes(const float* d_dist, const float* d_points, const float* d_verts
   if (R < 4 || R > 800) { sd::set_error("hull_planes: n_rays=%d unsupported (4..800)", R); return -1; }
   const int cap = 2 * R;
   const size_t ldsH = (size_t)3 * R * sizeof(double) + (size_t)2 * R * sizeof(unsigned int) +
-                      (R <= HULL_FAST_MAXR ? (size_t)12 * R * sizeof(unsigned int) + (size_t)R * R + 4 : 0);
+                      (R <= HULL_FAST_MAXR ? (size_t)12 * R * sizeof(unsigned int) + (size_t)((R * R + 15) / 16) * 4 : 0);
   if (ldsH > 150 * 1024) { sd::set_error("hull_planes: n_rays too large for LDS staging"); return -1; }
   if (ldsH > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_hull, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsH));
   sd::Arena& A = sd::arena();
@@ -2031,7 +2080,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   const size_t lds4 = (size_t)16 * R * sizeof(double) + hivBytes + (size_t)20 * R * sizeof(unsigned short);   // cap = 2R
   if (lds3 > 150 * 1024 || lds5 > 150 * 1024 || lds4 > 150 * 1024) { sd::set_error("sd_nms3d: n_rays/n_faces too large for LDS staging"); return -1; }
   const size_t ldsH = (size_t)3 * R * sizeof(double) + (size_t)2 * R * sizeof(unsigned int) +
-                      (R <= HULL_FAST_MAXR ? (size_t)12 * R * sizeof(unsigned int) + (size_t)R * R + 4 : 0);
+                      (R <= HULL_FAST_MAXR ? (size_t)12 * R * sizeof(unsigned int) + (size_t)((R * R + 15) / 16) * 4 : 0);
   // more than 64 KiB of dynamic LDS needs an explicit opt-in (only reached with several hundred rays)
   if (lds3 > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_stage3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
   if (lds4 > 64 * 1024) SD_CHECK(hipFuncSetAttribute((const void*)k_stage4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
