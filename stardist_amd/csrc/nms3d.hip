@@ -1204,19 +1204,19 @@ static inline size_t stage3x_lds(int F, size_t ws3, int nw) {
 // hull edge, so the cross-product order is a total order there and the combination is associative (exact ties = four coplanar
 // points, which the facet verification turns into the exhaustive search anyway).
 struct PivotFrame { double u[3], x[3], y[3]; bool ok; };
+// (x, y): axes of the plane normal to the edge direction e, x towards dref, y towards the side of the interior point g.  Only the
+// SIGN of a 2D cross product in this frame is ever used, and that is invariant under a positive scaling of either axis: nothing is
+// normalised (no square root, no division -- the f64 forms of both are long dependent instruction chains).
 __device__ __forceinline__ PivotFrame hull_pivot_frame(const double u[3], const double e[3], const double dref[3], const double g[3]) {
   PivotFrame F;
   F.ok = false;
   F.u[0] = u[0]; F.u[1] = u[1]; F.u[2] = u[2];
-  const double en = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
-  if (!(en > 0)) return F;
-  const double e0 = e[0] / en, e1 = e[1] / en, e2 = e[2] / en;
-  const double dr = dref[0] * e0 + dref[1] * e1 + dref[2] * e2;
-  double x0 = dref[0] - dr * e0, x1 = dref[1] - dr * e1, x2 = dref[2] - dr * e2;
-  const double xn = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
-  if (!(xn > 0)) return F;
-  x0 /= xn; x1 /= xn; x2 /= xn;
-  double y0 = e1 * x2 - e2 * x1, y1 = e2 * x0 - e0 * x2, y2 = e0 * x1 - e1 * x0;
+  const double ee = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+  if (!(ee > 0)) return F;
+  const double dr = dref[0] * e[0] + dref[1] * e[1] + dref[2] * e[2];
+  const double x0 = ee * dref[0] - dr * e[0], x1 = ee * dref[1] - dr * e[1], x2 = ee * dref[2] - dr * e[2];     // |e|^2 (dref - its part along e)
+  if (!(x0 * x0 + x1 * x1 + x2 * x2 > 0)) return F;
+  double y0 = e[1] * x2 - e[2] * x1, y1 = e[2] * x0 - e[0] * x2, y2 = e[0] * x1 - e[1] * x0;
   if ((g[0] - u[0]) * y0 + (g[1] - u[1]) * y1 + (g[2] - u[2]) * y2 < 0) { y0 = -y0; y1 = -y1; y2 = -y2; }
   F.x[0] = x0; F.x[1] = x1; F.x[2] = x2; F.y[0] = y0; F.y[1] = y1; F.y[2] = y2;
   F.ok = true;
@@ -1224,16 +1224,20 @@ __device__ __forceinline__ PivotFrame hull_pivot_frame(const double u[3], const 
 }
 __device__ __forceinline__ void hull_pivot_part(const double* __restrict__ pv, int R, int iu, int iv, int it, const PivotFrame& F, int q0, int qstep,
                                                 int& best, double& bx, double& by) {
-  // Branch-free and unrolled: the loop is a chain of LDS reads and dependent f64 operations, and its only product is the CHOICE of a
-  // vertex (the facet is verified afterwards with the exhaustive search's arithmetic), so the projections may be fused.
+  // Branch-free, with a wave-uniform trip count (a lane past the end re-reads the last point and discards it) so that the unrolled
+  // body's LDS reads are issued together: the loop is a chain of LDS reads and dependent f64 operations, and its only product is
+  // the CHOICE of a vertex (the facet is verified afterwards with the exhaustive search's arithmetic), so the projections may be fused.
   best = -1; bx = 0; by = 0;
   const double ux = F.u[0] * F.x[0] + F.u[1] * F.x[1] + F.u[2] * F.x[2], uy = F.u[0] * F.y[0] + F.u[1] * F.y[1] + F.u[2] * F.y[2];
+  const int niter = (R + qstep - 1) / qstep;
+  int q = q0;
 #pragma unroll 4
-  for (int q = q0; q < R; q += qstep) {
-    const double p0 = pv[3 * q], p1 = pv[3 * q + 1], p2 = pv[3 * q + 2];
+  for (int k = 0; k < niter; ++k, q += qstep) {
+    const int qq = q < R ? q : R - 1;
+    const double p0 = pv[3 * qq], p1 = pv[3 * qq + 1], p2 = pv[3 * qq + 2];
     const double xq = __builtin_fma(p0, F.x[0], __builtin_fma(p1, F.x[1], __builtin_fma(p2, F.x[2], -ux)));
     const double yq = __builtin_fma(p0, F.y[0], __builtin_fma(p1, F.y[1], __builtin_fma(p2, F.y[2], -uy)));
-    const bool take = (q != iu) & (q != iv) & (q != it) & ((best < 0) | (bx * yq > by * xq));     // q is counter-clockwise of the current extreme
+    const bool take = (q < R) & (q != iu) & (q != iv) & (q != it) & ((best < 0) | (bx * yq > by * xq));     // q is counter-clockwise of the current extreme
     best = take ? q : best; bx = take ? xq : bx; by = take ? yq : by;
   }
 }
@@ -1351,11 +1355,14 @@ __device__ int hull_giftwrap(const double* __restrict__ pv, int R, int cap, int 
           if (!(nn > 1e-12 * ext * ext)) bad = true;
           else {
             int fl = 0;                                            // 1: a point above, 2: below, 4: on the plane
+            const int niter = (R + grp - 1) / grp;
+            int q = sub;
 #pragma unroll 4
-            for (int q = sub; q < R; q += grp) {
-              const double sd_ = nz * (pv[3 * q] - az) + ny * (pv[3 * q + 1] - ay) + nx * (pv[3 * q + 2] - ax);
+            for (int k = 0; k < niter; ++k, q += grp) {
+              const int qq = q < R ? q : R - 1;
+              const double sd_ = nz * (pv[3 * qq] - az) + ny * (pv[3 * qq + 1] - ay) + nx * (pv[3 * qq + 2] - ax);
               const int f = sd_ > te ? 1 : (sd_ < -te ? 2 : 4);
-              fl |= ((q == a) | (q == b) | (q == c)) ? 0 : f;
+              fl |= ((q >= R) | (q == a) | (q == b) | (q == c)) ? 0 : f;
             }
             for (int o = grp >> 1; o; o >>= 1) fl |= __shfl_xor(fl, o);
             if ((fl & 3) == 3 || (fl & 4)) bad = true;
