@@ -36,7 +36,8 @@ int sd_release_workspace(void);           /* free the cached device workspace   
 /* Switches between EQUIVALENT formulations (same results; the parity suite runs both settings against the reference):
  *   "nms3d_volume_bounds" 1|0  decide 3D pairs from rigorous volume bounds where possible / always compute the exact volume
  *   "nms3d_cone_map"      1|0  stage-5 voxel tests through the cone map / over every face as the reference does
- *   "nms3d_refine_mesh"   1|0  refined direction mesh for the volume bounds
+ *   "nms3d_refine_mesh"   2|1|0  direction meshes of the volume bounds: the ray mesh only (0); refined once for the pairs it leaves
+ *                              undecided (1); refined twice for the pairs that reach the exact-volume kernels (2, default)
  *   "nms3d_tail_batch"    1|0  late greedy rounds of the 3D NMS as one speculative batch + replay on the device / as plain rounds
  *   "nms3d_split_exact"   1|0  exact volumes of the pairs the bounds leave undecided by four waves per pair in a second pass / by the
  *                              wave that evaluated the bounds (bit-identical volumes)

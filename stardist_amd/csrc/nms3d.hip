@@ -874,20 +874,107 @@ __device__ __forceinline__ void hiv_bounds_wave(const double* __restrict__ hs, i
   ub = bad ? 1e300 : accu / 6.0;
 }
 
-// edge adjacency of the ray mesh: adj[3f + e] = face sharing edge e = (v_e, v_{e+1}) of face f, or -1
-__global__ void k_face_adj(const int* __restrict__ faces, int F, int* __restrict__ adj) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+// The same bounds by the NW waves of a workgroup over a finer direction mesh (k_stage3x / k_stage4x, before they integrate: the
+// mesh refined twice has 16x the triangles of the ray mesh, its gap between the bounds is ~1/4 of the once-refined mesh's, and a ray
+// cast over it costs ~1/10 of the exact volume it makes unnecessary for most of the pairs that reach these kernels).  Any summation
+// order gives rigorous bounds (the callers' 1e-9 margins cover the rounding).  red: 2 NW doubles of LDS.  Workgroup barriers inside.
+template <int NW, int NB>
+__device__ __forceinline__ void hiv_bounds_block(const double* __restrict__ hs, int M, const float* __restrict__ verts,
+                                                 const int* __restrict__ faces, int R, int F, double* wv, unsigned short* hit, double* red,
+                                                 int tid, double& lb, double& ub) {
+#pragma clang fp contract(fast)
+  constexpr int NT = 64 * NW;
+  for (int k0 = 0; k0 < R; k0 += NT * NB) {
+    double dz[NB], dy[NB], dx[NB], ne_b[NB], q_b[NB];
+    int m_b[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int k = k0 + j * NT + tid;
+      const bool v = k < R;
+      dz[j] = v ? (double)verts[3 * k] : 0.0; dy[j] = v ? (double)verts[3 * k + 1] : 0.0; dx[j] = v ? (double)verts[3 * k + 2] : 0.0;
+      ne_b[j] = 1.0; q_b[j] = 0.0; m_b[j] = 0;
+    }
+#pragma unroll 2
+    for (int m = 0; m < M; ++m) {
+      const double h0 = hs[4 * m], h1 = hs[4 * m + 1], h2 = hs[4 * m + 2], ne = -hs[4 * m + 3];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const double q = h0 * dz[j] + h1 * dy[j] + h2 * dx[j];
+        if (q > 0 && ne * q_b[j] < ne_b[j] * q) { ne_b[j] = ne; q_b[j] = q; m_b[j] = m; }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int k = k0 + j * NT + tid;
+      if (k < R) {
+        const double t = (q_b[j] > 0) ? ne_b[j] / q_b[j] : 0.0;
+        wv[3 * k] = t * dz[j]; wv[3 * k + 1] = t * dy[j]; wv[3 * k + 2] = t * dx[j];
+        hit[k] = (unsigned short)((q_b[j] > 0) ? m_b[j] : HIV_NONE);
+      }
+    }
+  }
+  __syncthreads();
+  double accl = 0, accu = 0;
+  int bad = 0;
+  for (int f = tid; f < F; f += NT) {
+    const int iv[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
+    double w[3][3];
+#pragma unroll
+    for (int y = 0; y < 3; ++y) { w[y][0] = wv[3 * iv[y]]; w[y][1] = wv[3 * iv[y] + 1]; w[y][2] = wv[3 * iv[y] + 2]; }
+    const double det = fabs(w[0][0] * (w[1][1] * w[2][2] - w[1][2] * w[2][1]) + w[0][1] * (w[1][2] * w[2][0] - w[1][0] * w[2][2]) +
+                            w[0][2] * (w[1][0] * w[2][1] - w[1][1] * w[2][0]));
+    accl += det;
+    double best = 1e300;
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      const unsigned int m = hit[iv[x]];
+      if (m == HIV_NONE) continue;
+      const double nz = hs[4 * m], ny = hs[4 * m + 1], nx = hs[4 * m + 2], ne = -hs[4 * m + 3];
+      double qp = 1.0;
+      bool ok = true;
+#pragma unroll
+      for (int y = 0; y < 3; ++y) {
+        const double q = nz * w[y][0] + ny * w[y][1] + nx * w[y][2];
+        if (!(q > 0)) ok = false;
+        qp *= q;
+      }
+      if (ok) best = fmin(best, (ne * ne * ne) / qp);
+    }
+    if (best >= 1e300) bad = 1;
+    accu += det * fmax(best, 1.0);
+  }
+  for (int o = 32; o; o >>= 1) { accl += __shfl_xor(accl, o); accu += __shfl_xor(accu, o); }
+  if ((tid & 63) == 0) { red[2 * (tid >> 6)] = accl; red[2 * (tid >> 6) + 1] = accu; }
+  const bool anybad = __syncthreads_or(bad) != 0;
+  accl = 0; accu = 0;
+#pragma unroll
+  for (int w_ = 0; w_ < NW; ++w_) { accl += red[2 * w_]; accu += red[2 * w_ + 1]; }
+  __syncthreads();
+  lb = accl / 6.0;
+  ub = anybad ? 1e300 : accu / 6.0;
+}
+
+// edge adjacency of the ray mesh: adj[3f + e] = face sharing edge e = (v_e, v_{e+1}) of face f (the lowest-numbered one), or -1.
+// One wave per face, the lanes share the scan over the other faces (the meshes of the finer bounds have 4 F and 16 F faces).
+__global__ void __launch_bounds__(64) k_face_adj(const int* __restrict__ faces, int F, int* __restrict__ adj) {
+  const int f = blockIdx.x, lane = threadIdx.x;
   if (f >= F) return;
   const int v[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
-  for (int e = 0; e < 3; ++e) {
-    const int x = v[e], y = v[(e + 1) % 3];
-    int found = -1;
-    for (int g = 0; g < F && found < 0; ++g) {
-      if (g == f) continue;
-      const int a = faces[3 * g], b = faces[3 * g + 1], c = faces[3 * g + 2];
-      if ((a == x || b == x || c == x) && (a == y || b == y || c == y)) found = g;
+  int found[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+  for (int g = lane; g < F; g += 64) {
+    if (g == f) continue;
+    const int a = faces[3 * g], b = faces[3 * g + 1], c = faces[3 * g + 2];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const int x = v[e], y = v[(e + 1) % 3];
+      if ((a == x || b == x || c == x) && (a == y || b == y || c == y) && g < found[e]) found[e] = g;
     }
-    adj[3 * f + e] = found;
+  }
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    int m = found[e];
+    for (int o = 32; o; o >>= 1) { const int t = __shfl_xor(m, o); m = t < m ? t : m; }
+    if (lane == 0) adj[3 * f + e] = m == 0x7fffffff ? -1 : m;
   }
 }
 
@@ -1094,7 +1181,10 @@ __global__ void __launch_bounds__(64 * NW) k_stage3x(const int2* __restrict__ pa
                                                      const float* __restrict__ dist, const float* __restrict__ pts, const float* __restrict__ verts,
                                                      const int* __restrict__ faces, const int* __restrict__ faceAdj, int R, int F,
                                                      const float* __restrict__ volume, float thr, SuppSink sink, int2* __restrict__ pairs5,
-                                                     unsigned int* pair5Count, Stats* st, unsigned int wsBytes, double* __restrict__ volOut) {
+                                                     unsigned int* pair5Count, Stats* st, unsigned int wsBytes, double* __restrict__ volOut,
+                                                     const float* __restrict__ b3verts = nullptr, const int* __restrict__ b3faces = nullptr,
+                                                     int b3R = 0, int b3F = 0) {
+  // b3R != 0: direction mesh (refined twice) of one more pair of volume bounds, evaluated by the whole workgroup before the exact volume
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* hs = (double*)smem;
   float* pv1 = (float*)(hs + 8 * F);
@@ -1164,7 +1254,16 @@ __global__ void __launch_bounds__(64 * NW) k_stage3x(const int2* __restrict__ pa
       const double L = 4.0 * (2.0 * ext + sep + 1.0);
       const double balls[8] = {(double)c1[0] - c[0], (double)c1[1] - c[1], (double)c1[2] - c[2], ext1 * (1.0 + 1e-6) + 1e-6,
                                (double)c2[0] - c[0], (double)c2[1] - c[1], (double)c2[2] - c[2], ext2 * (1.0 + 1e-6) + 1e-6};
-      vol = hiv_volume_block<NW>(hs, Mc, zero3, L, W, lane, wave, terms, st, balls);
+      bool decided = false;
+      if (b3R > 0 && !volOut) {
+        const double A_min_d = (double)fminf(volume[ij.x], volume[ij.y]) + 1e-10;
+        const double thr_hi = (double)thr + 1e-5 * fabs((double)thr) + 1e-7, thr_lo = (double)thr - 1e-5 * fabs((double)thr) - 1e-7;
+        double lb, ub;
+        hiv_bounds_block<NW, 6>(hs, Mc, b3verts, b3faces, b3R, b3F, (double*)extra, (unsigned short*)((double*)extra + 3 * b3R), terms, tid, lb, ub);
+        if (lb * (1.0 - 1e-9) / A_min_d > thr_hi) { vol = lb; decided = true; if (tid == 0) atomicAdd(&st->lb_decided, 1ull); }            // as in k_stage3
+        else if (ub * (1.0 + 1e-9) / A_min_d < thr_lo) { vol = ub; decided = true; if (tid == 0) atomicAdd(&st->ub_decided, 1ull); }
+      }
+      if (!decided) vol = hiv_volume_block<NW>(hs, Mc, zero3, L, W, lane, wave, terms, st, balls);
     }
     if (tid == 0) {
       if (volOut) volOut[p] = vol;
@@ -1730,7 +1829,9 @@ __global__ void __launch_bounds__(64 * NW) k_stage4x(const int2* __restrict__ pa
                                                      const float* __restrict__ dist, const float* __restrict__ pts, int R, int cap,
                                                      const double* __restrict__ hullPlanes, const unsigned short* __restrict__ hullAdj,
                                                      const int* __restrict__ hullCount, const float* __restrict__ volume, float thr,
-                                                     int2* __restrict__ pairs5, unsigned int* pair5Count, Stats* st, double* __restrict__ volOut) {
+                                                     int2* __restrict__ pairs5, unsigned int* pair5Count, Stats* st, double* __restrict__ volOut,
+                                                     const float* __restrict__ b3verts = nullptr, const int* __restrict__ b3faces = nullptr,
+                                                     int b3R = 0, int b3F = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* hs = (double*)smem;
   unsigned short* seed = (unsigned short*)(smem + (size_t)8 * cap * sizeof(double) + hiv_poly_bytes_dev());
@@ -1791,7 +1892,16 @@ __global__ void __launch_bounds__(64 * NW) k_stage4x(const int2* __restrict__ pa
       const double zero3[3] = {0, 0, 0};
       const double balls[8] = {(double)c1[0] - c[0], (double)c1[1] - c[1], (double)c1[2] - c[2], ext1 * (1.0 + 1e-6) + 1e-6,
                                (double)c2[0] - c[0], (double)c2[1] - c[1], (double)c2[2] - c[2], ext2 * (1.0 + 1e-6) + 1e-6};
-      vol = hiv_volume_block<NW>(hs, Mc, zero3, L, W, lane, wave, terms, st, balls);
+      bool decided = false;
+      if (b3R > 0 && !volOut) {
+        const double A_min_d = (double)fminf(volume[ij.x], volume[ij.y]) + 1e-10;
+        const double thr_hi = (double)thr + 1e-5 * fabs((double)thr) + 1e-7, thr_lo = (double)thr - 1e-5 * fabs((double)thr) - 1e-7;
+        double lb, ub;
+        hiv_bounds_block<NW, 6>(hs, Mc, b3verts, b3faces, b3R, b3F, (double*)extra, (unsigned short*)((double*)extra + 3 * b3R), terms, tid, lb, ub);
+        if (lb * (1.0 - 1e-9) / A_min_d > thr_hi) { vol = lb; decided = true; if (tid == 0) atomicAdd(&st->lb_decided, 1ull); }            // as in k_stage4
+        else if (ub * (1.0 + 1e-9) / A_min_d < thr_lo) { vol = ub; decided = true; if (tid == 0) atomicAdd(&st->ub_decided, 1ull); }
+      }
+      if (!decided) vol = hiv_volume_block<NW>(hs, Mc, zero3, L, W, lane, wave, terms, st, balls);
     }
     if (tid == 0) {
       if (volOut) volOut[p] = vol;
@@ -1978,7 +2088,7 @@ extern "C" int sd_hiv_pairs_device(const float* d_dist, const float* d_points, i
   if (!volume || !faceAdj || !d_st || !dummyCount || !state) return -1;
   SD_CHECK(hipMemsetAsync(volume, 0, (size_t)N * sizeof(float), s));
   SD_CHECK(hipMemsetAsync(d_st, 0, sizeof(Stats), s));
-  hipLaunchKernelGGL(k_face_adj, dim3(sd::div_up(F, 64)), dim3(64), 0, s, d_faces, F, faceAdj);
+  hipLaunchKernelGGL(k_face_adj, dim3(F), dim3(64), 0, s, d_faces, F, faceAdj);
   const int2* pairs = (const int2*)d_pairs;
   const unsigned int nb = (unsigned int)n_pairs < 16384u ? (unsigned int)n_pairs : 16384u;
   const size_t lds3x = stage3x_lds(F, ws3, 4);
@@ -2226,7 +2336,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   if (!faceAdj || !d_mesh || !d_mesh_sa) return -1;
   SD_CHECK(hipMemsetAsync(d_mesh, 0, 4 * sizeof(int), s));
   SD_CHECK(hipMemsetAsync(d_mesh_sa, 0, sizeof(double), s));
-  hipLaunchKernelGGL(k_face_adj, dim3(sd::div_up(F, 64)), dim3(64), 0, s, d_faces, F, faceAdj);
+  hipLaunchKernelGGL(k_face_adj, dim3(F), dim3(64), 0, s, d_faces, F, faceAdj);
   hipLaunchKernelGGL(k_mesh_check, dim3(sd::div_up(F, 64)), dim3(64), 0, s, d_verts, d_faces, faceAdj, F, d_mesh, d_mesh_sa);
   SD_LAUNCH_CHECK();
   int h_mesh[4]; double h_mesh_sa = 0;
@@ -2253,6 +2363,27 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
       hipLaunchKernelGGL(k_refine_mesh, dim3(sd::div_up(F > R ? F : R, 64)), dim3(64), 0, s, d_verts, d_faces, faceAdj, R, F, edgeId, v2, f2);
       SD_LAUNCH_CHECK();
       bverts = v2; bfaces = f2; bR = R2; bF = F2;
+    }
+  }
+  // refined once more for the pairs that reach the exact-volume kernels (k_stage3x / k_stage4x evaluate it with the whole workgroup;
+  // its ray-cast vectors live in the polygon workspaces of waves 1..3, which are idle until the integration starts)
+  const float* b3verts = nullptr; const int* b3faces = nullptr; int b3R = 0, b3F = 0;
+  if (bR != R && splitOpt && sd::option(sd::OPT_NMS3D_REFINE_MESH) >= 2) {
+    const int R3 = bR + 3 * bF / 2, F3 = 4 * bF;
+    const size_t need = (size_t)3 * R3 * sizeof(double) + (size_t)2 * R3;
+    if (need <= (size_t)3 * hivBytes && R3 < 65535) {
+      int* adj2 = A.take_n<int>((size_t)3 * bF);
+      float* v3 = A.take_n<float>((size_t)3 * R3);
+      int* f3 = A.take_n<int>((size_t)3 * F3);
+      int* edgeId = A.take_n<int>((size_t)3 * bF);
+      int* ecount = A.take_n<int>(1);
+      if (!adj2 || !v3 || !f3 || !edgeId || !ecount) return -1;
+      SD_CHECK(hipMemsetAsync(ecount, 0, sizeof(int), s));
+      hipLaunchKernelGGL(k_face_adj, dim3(bF), dim3(64), 0, s, bfaces, bF, adj2);
+      hipLaunchKernelGGL(k_refine_edges, dim3(sd::div_up(3 * bF, 64)), dim3(64), 0, s, bfaces, adj2, bF, edgeId, ecount);
+      hipLaunchKernelGGL(k_refine_mesh, dim3(sd::div_up(bF > bR ? bF : bR, 64)), dim3(64), 0, s, bverts, bfaces, adj2, bR, bF, edgeId, v3, f3);
+      SD_LAUNCH_CHECK();
+      b3verts = v3; b3faces = f3; b3R = R3; b3F = F3;
     }
   }
   // capacity of one call (32-bit indices into the neighbour lists and pair queues, N * n_rays * 4 bytes of distances): beyond it the
@@ -2361,7 +2492,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
                            (double*)nullptr, sp3 ? pairsX : (int2*)nullptr, &d_cnt->nX3);
         if (split3 && h.nP3 <= split3Max)
           hipLaunchKernelGGL(k_stage3x<4>, dim3(h.nP3 < 256u ? h.nP3 : 256u), dim3(256), lds3x, s, pairsX, &d_cnt->nX3, 0u, d_dist, d_points, d_verts, d_faces, faceAdj,
-                             R, F, volume, threshold, sink, pairs4, &d_cnt->nP4, d_st, (unsigned int)ws3, (double*)nullptr);
+                             R, F, volume, threshold, sink, pairs4, &d_cnt->nP4, d_st, (unsigned int)ws3, (double*)nullptr, b3verts, b3faces, b3R, b3F);
         SD_LAUNCH_CHECK();
         if (stats) SD_CHECK(hipEventRecord(ev1, s));
         SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -2395,7 +2526,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
                              sp4 ? pairsX : (int2*)nullptr, &d_cnt->nX4, small4 ? (unsigned int)ws4s : 0u);
           if (split4 && h.nP4 <= split4Max)
             hipLaunchKernelGGL(k_stage4x<4>, dim3(h.nP4 < 256u ? h.nP4 : 256u), dim3(256), lds4x, s, pairsX, &d_cnt->nX4, 0u, d_dist, d_points, R, hullCap, hullPlanes, hullAdj,
-                               hullCount, volume, threshold, pairs5, &d_cnt->nP5, d_st, (double*)nullptr);
+                               hullCount, volume, threshold, pairs5, &d_cnt->nP5, d_st, (double*)nullptr, b3verts, b3faces, b3R, b3F);
           SD_LAUNCH_CHECK();
           if (stats) SD_CHECK(hipEventRecord(ev1, s));
           SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
