@@ -2446,7 +2446,8 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   // pair count grows quickly with them (measured on the 256^3 bench set: at N/8 = 16 404 undecided candidates 71 674 stage-3 pairs
   // instead of the 2 397 the plain rounds evaluate -- slower than the rounds it replaces; at N/128 the three last rounds, ~7 ms of
   // launch latency, become one pass).  sd_set_option("nms3d_tail_batch", 0) keeps the plain rounds (the parity suite runs both).
-  const int tailT = sd::option(sd::OPT_NMS3D_TAIL_BATCH) ? (N / 128 > 512 ? N / 128 : 512) : -1;
+  const int tailOpt = sd::option(sd::OPT_NMS3D_TAIL_BATCH), tailDiv = tailOpt >= 2 ? tailOpt : 32;       // option value >= 2: the divisor itself (tuning)
+  const int tailT = tailOpt ? (N / tailDiv > 512 ? N / tailDiv : 512) : -1;
   int2* supEdges = nullptr; unsigned int* supCount = nullptr; unsigned char* blocked = nullptr; int* d_left = nullptr;
   while (nU > 0) {
     ++rounds;

@@ -13,6 +13,8 @@ dev = torch.device("cuda:0")
 if os.environ.get("SD_SPLIT_EXACT"):
     _native.check(_native.lib().sd_set_option(b"nms3d_split_exact", int(os.environ["SD_SPLIT_EXACT"])))
     print("nms3d_split_exact =", _native.lib().sd_get_option(b"nms3d_split_exact"))
+if os.environ.get("SD_TAIL"):
+    _native.check(_native.lib().sd_set_option(b"nms3d_tail_batch", int(os.environ["SD_TAIL"])))
 if os.environ.get("SD_TRACE"):
     _native.lib().sd_set_option(b"trace", 1)      # per-round counters on stdout
 S = int(os.environ.get("SD_SIZE3D", "256"))
