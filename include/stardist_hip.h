@@ -41,6 +41,8 @@ int sd_release_workspace(void);           /* free the cached device workspace   
  *   "nms3d_tail_batch"    1|0  late greedy rounds of the 3D NMS as one speculative batch + replay on the device / as plain rounds
  *   "nms3d_split_exact"   1|0  exact volumes of the pairs the bounds leave undecided by four waves per pair in a second pass / by the
  *                              wave that evaluated the bounds (bit-identical volumes)
+ *   "nms2d_area_bounds"   1|0  2D pairs far from the threshold are decided from an enclosure of the intersection area (regular arithmetic,
+ *                              area_bounds.h) / every pair runs the Clipper-exact sweep
  *   "probe_tier"          1|2  capacity tier sd_clip_pairs_device runs first;  "probe_no_general" 1: do not fall back to the general path
  *   "trace"               1    print per-round counters to stdout
  * Nothing in the library reads the process environment.  sd_get_option returns -1 for an unknown name. */
@@ -55,7 +57,8 @@ int sd_get_option(const char* name);
  * keep   (n_polys,) bytes: 1 = survivor, 0 = suppressed (the reference returns NPY_BOOL).
  * stats  optional int64[16] (may be NULL): {0 pairs evaluated, 1 pairs re-run on the exact-join path,
  *        2 greedy rounds, 3 neighbour entries, 4 pair-kernel time ns (HIP events on `stream`),
- *        5 pair-kernel launches, 6 exact-join kernel ns, 7 build+bin+neighbour kernels ns, 8.. 0}.
+ *        5 pair-kernel launches, 6 exact-join kernel ns, 7 build+bin+neighbour kernels ns, 8 capacity spills,
+ *        9 pairs decided by the area enclosure (counted in 0 as well), 10.. 0}.
  */
 int sd_nms2d_host(const float* dist, const float* points, int n_polys, int n_rays,
                   int use_kdtree, int use_bbox, int verbose, float threshold,
@@ -76,6 +79,14 @@ int sd_prepare_polys_device(const int32_t* d_x, const int32_t* d_y, int n_polys,
 int sd_clip_pairs_device(const int32_t* d_xa, const int32_t* d_ya, const int32_t* d_xb,
                          const int32_t* d_yb, int n_pairs, int n_verts,
                          int64_t* d_out_twice_area, int32_t* d_out_flags, void* stream);
+
+/* Test probe of the decision shortcut of the 2D NMS (stardist_amd/csrc/area_bounds.h): for the same inputs as sd_clip_pairs_device
+ * (n_verts 3..32) the exact area of the intersection by boundary integration (float32), the half-width of the band that encloses
+ * the area ClipperLib returns for the pair, and info = bit 0: the enclosure may be used for a decision (both polygons simple, equally
+ * oriented, small enough for exact float predicates), bits 8..17: number of boundary crossings, bits 18..28: number of edge pairs
+ * closer than one lattice step. */
+int sd_area_bounds_pairs_device(const int32_t* d_xa, const int32_t* d_ya, const int32_t* d_xb, const int32_t* d_yb, int n_pairs,
+                                int n_verts, float* d_out_area, float* d_out_band, int32_t* d_out_info, void* stream);
 
 /* ---- star-convex distances (training targets; same native module) --------------------------
  * replaces stardist.lib.stardist2d.c_star_dist (stardist2d.cpp:55-124)

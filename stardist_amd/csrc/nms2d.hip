@@ -26,6 +26,7 @@
 #include "common.h"
 #include "clip_sweep.h"
 #include "clip_beam.h"
+#include "area_bounds.h"
 #include "../../include/stardist_hip.h"
 #include <hipcub/hipcub.hpp>
 #include <math.h>
@@ -407,6 +408,37 @@ size_t beam_lds_bytes() {
   return (size_t)sdclip::Beam<MAXV, K, MAXIL, MAXREC, Storage>::lds_bytes() + 64;
 }
 
+// Round kernel C0 (area_bounds.h): the pairs whose decision follows from an enclosure of the intersection area -- regular arithmetic,
+// 32 lanes per pair -- are decided here; decided[t] != 0 removes a pair from the sweep kernels' work list (k_pair_bucket_*).
+__global__ void __launch_bounds__(256) k_pairs_decide(const int2* __restrict__ pairs, const unsigned long long* __restrict__ nPtr,
+                                                      const unsigned int* __restrict__ firstPtr, const int* __restrict__ vx, const int* __restrict__ vy, int R,
+                                                      const sdarea::PolyProps* __restrict__ props, const float* __restrict__ area, float thr,
+                                                      unsigned char* __restrict__ state, unsigned char* __restrict__ supp,
+                                                      unsigned char* __restrict__ decided, unsigned int* __restrict__ nDecided) {
+  __shared__ float2 sq[4][2][32];
+  const int lane = threadIdx.x & 63, half = lane >> 5, l = lane & 31, wv = threadIdx.x >> 6;
+  const unsigned long long n = *nPtr, first = firstPtr ? (unsigned long long)*firstPtr : 0ull;
+  const unsigned long long nw = (unsigned long long)gridDim.x * 4;
+  unsigned int mine = 0;
+  for (unsigned long long base = first + 2ull * ((unsigned long long)blockIdx.x * 4 + wv); base < n; base += 2ull * nw) {
+    const unsigned long long t = base + half;
+    const bool active = t < n;
+    const int2 ij = active ? pairs[t] : make_int2(0, 0);
+    const sdarea::PolyProps pp = props[ij.x], pq = props[ij.y];
+    const sdarea::Enclosure E = sdarea::pair_enclosure(vx + (size_t)ij.x * R, vy + (size_t)ij.x * R, vx + (size_t)ij.y * R, vy + (size_t)ij.y * R, R, pp, pq,
+                                                       active, sq[wv][half], l, half);             // clip = i, subject = j (:157-158)
+    if (active && l == 0) {
+      const int dec = sdarea::decide(E, area[ij.x], area[ij.y], thr);
+      decided[t] = (unsigned char)dec;
+      if (dec == 2) { if (supp) supp[t] = 1; else state[ij.y] = ST_SUPPRESSED; }                  // :581-585
+      if (dec) ++mine;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  mine += __shfl_xor(mine, 32);
+  if (lane == 0 && mine) atomicAdd(nDecided, mine);
+}
+
 // ---- tail batch.  Late greedy rounds hold few pairs but each costs one sweep's serial latency; once few candidates are
 // undecided, ALL pairs (i < j, both undecided) the reference could still evaluate are emitted at once, their overlap decisions
 // are computed speculatively (supp[edge]), and one workgroup then replays the remaining greedy rounds on the device:
@@ -581,13 +613,13 @@ __device__ __forceinline__ int pair_bucket(const float* __restrict__ pts, int2 i
 }
 __global__ void __launch_bounds__(256) k_pair_bucket_count(const int2* __restrict__ pairs, const unsigned long long* __restrict__ nPtr,
                                                            const unsigned int* __restrict__ firstPtr, const float* __restrict__ pts, PairKey key,
-                                                           unsigned int* __restrict__ hist) {
+                                                           unsigned int* __restrict__ hist, const unsigned char* __restrict__ decided) {
   __shared__ unsigned int h[PAIR_BUCKETS];
   for (int b = threadIdx.x; b < PAIR_BUCKETS; b += 256) h[b] = 0;
   __syncthreads();
   const unsigned long long n = *nPtr, first = firstPtr ? *firstPtr : 0u;
   for (unsigned long long t = first + (unsigned long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * 256)
-    atomicAdd(&h[pair_bucket(pts, pairs[t], key)], 1u);
+    if (!decided || !decided[t]) atomicAdd(&h[pair_bucket(pts, pairs[t], key)], 1u);
   __syncthreads();
   for (int b = threadIdx.x; b < PAIR_BUCKETS; b += 256) if (h[b]) atomicAdd(&hist[b], h[b]);
 }
@@ -613,9 +645,11 @@ __global__ void __launch_bounds__(1024) k_pair_bucket_scan(const unsigned int* _
 }
 __global__ void __launch_bounds__(256) k_pair_bucket_scatter(const int2* __restrict__ pairs, const unsigned long long* __restrict__ nPtr,
                                                              const unsigned int* __restrict__ firstPtr, const float* __restrict__ pts, PairKey key,
-                                                             unsigned int* __restrict__ cursor, unsigned int* __restrict__ order, unsigned int cap) {
+                                                             unsigned int* __restrict__ cursor, unsigned int* __restrict__ order, unsigned int cap,
+                                                             const unsigned char* __restrict__ decided) {
   const unsigned long long n = *nPtr, first = firstPtr ? *firstPtr : 0u;
   for (unsigned long long t = first + (unsigned long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * 256) {
+    if (decided && decided[t]) continue;
     const unsigned int k = atomicAdd(&cursor[pair_bucket(pts, pairs[t], key)], 1u);
     if (k < cap) order[k] = (unsigned int)t;
   }
@@ -638,7 +672,7 @@ int clip_full_pairs(const int2* d_pairs, const unsigned int* d_idx, const unsign
 }
 
 namespace {
-struct Counters { int nU, nK, nS, left; unsigned long long nPairs; unsigned int nSpill, nExact, nErr, pad2; };
+struct Counters { int nU, nK, nS, left; unsigned long long nPairs; unsigned int nSpill, nExact, nErr, nDecided; };
 
 // prepared polygons + the two tiers of the bound-slot pair kernel for one vertex capacity
 template <int MAXV, int SPREP>
@@ -772,6 +806,15 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
     else rc = BeamPath<256, 16>::prepare(vx, vy, N, R, prep, side);
     if (rc) return -1;
   }
+  // polygon properties of the decision shortcut (area_bounds.h), same stream: they also depend on the integer vertices only
+  const bool areaBounds = R <= 32 && R >= 3 && sd::option(sd::OPT_NMS2D_AREA_BOUNDS) != 0;
+  sdarea::PolyProps* props = nullptr;
+  if (areaBounds) {
+    props = (sdarea::PolyProps*)A.take((size_t)N * sizeof(sdarea::PolyProps));
+    if (!props) return -1;
+    hipLaunchKernelGGL(sdarea::k_poly_props, dim3(sd::div_up(N, 8)), dim3(256), 0, side, vx, vy, N, R, props);
+    SD_LAUNCH_CHECK();
+  }
   SD_CHECK(hipEventRecord(evJoin, side));
   int gs[8];
   SD_CHECK(hipMemcpyAsync(gs, gstats, sizeof(gs), hipMemcpyDeviceToHost, s));
@@ -862,6 +905,9 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   unsigned int* bucketHist = A.take_n<unsigned int>(2 * PAIR_BUCKETS);
   unsigned long long* nOrdered = A.take_n<unsigned long long>(1);
   if (!U0 || !U1 || !K || !pairs || !spillPairs || !exactPairs || !Sl || !d_cnt || !bucketHist || !nOrdered || (pairSort && R <= 32 && !pairOrder)) return -1;
+  unsigned char* decided = (areaBounds && pairOrder) ? A.take_n<unsigned char>(pairCap) : nullptr;       // (the shortcut filters through the ordered index list)
+  if (areaBounds && pairOrder && !decided) return -1;
+  i64 totalDecided = 0;
   hipLaunchKernelGGL(k_iota, dim3(sd::div_up(N, 256)), dim3(256), 0, s, U0, N);
   int nU = N, rounds = 0;
   i64 totalPairs = 0, totalExact = 0, totalSpill = 0;
@@ -914,10 +960,13 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
         const int* md = modes[keyMode >= 0 && keyMode < 6 ? keyMode : 2];
         const PairKey key{(const char*)prep, prepStride, 1.f / (4.f * (max_dist + 1.f)), md[0], md[1], md[2]};   // offsets lie in (-2 max_dist, 2 max_dist)
         SD_CHECK(hipMemsetAsync(bucketHist, 0, PAIR_BUCKETS * sizeof(unsigned int), s));
-        hipLaunchKernelGGL(k_pair_bucket_count, dim3(512), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, d_points, key, bucketHist);
+        if (decided)
+          hipLaunchKernelGGL(k_pairs_decide, dim3(256 * 8), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, vx, vy, R, props, area, threshold, state, suppOut,
+                             decided, &d_cnt->nDecided);
+        hipLaunchKernelGGL(k_pair_bucket_count, dim3(512), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, d_points, key, bucketHist, decided);
         hipLaunchKernelGGL(k_pair_bucket_scan, dim3(1), dim3(1024), 0, s, bucketHist, bucketHist + PAIR_BUCKETS, nOrdered);
         hipLaunchKernelGGL(k_pair_bucket_scatter, dim3(512), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, d_points, key, bucketHist + PAIR_BUCKETS,
-                           pairOrder, qCap);
+                           pairOrder, qCap, decided);
         SD_LAUNCH_CHECK();
         rc = BeamPath<32, 64>::tier1(pairs, pairOrder, nOrdered, (const unsigned int*)nullptr, prep, area, threshold, state, suppOut, q1, s);
       } else
@@ -949,13 +998,13 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   auto account = [&](const char* what) -> int {
     if (h.nPairs > pairCap || h.nSpill > qCap || h.nExact > qCap) { sd::set_error("sd_nms2d: pair queue overflow (internal error)"); return -1; }
     if (h.nErr) { sd::set_error("sd_nms2d: %u pairs exceeded the general path's fixed capacities", h.nErr); return -1; }
-    totalPairs += (i64)h.nPairs; totalExact += h.nExact; totalSpill += h.nSpill;
+    totalPairs += (i64)h.nPairs; totalExact += h.nExact; totalSpill += h.nSpill; totalDecided += h.nDecided;
     if (stats) {
       float ms = 0, ms2 = 0;
       SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); SD_CHECK(hipEventElapsedTime(&ms2, ev2, ev3));
       if (h.nPairs) { ns_pairs += ms * 1e6; ++n_pair_launches; }
       ns_full += ms2 * 1e6;
-      if (sd::option(sd::OPT_TRACE)) printf("%s %d: nU=%d nK=%d pairs=%llu spill=%u exact=%u pair_kernel=%.3f ms general_path=%.3f ms\n", what, rounds, h.nU, h.nK, h.nPairs, h.nSpill, h.nExact, ms, ms2);
+      if (sd::option(sd::OPT_TRACE)) printf("%s %d: nU=%d nK=%d pairs=%llu decided by the area enclosure=%u spill=%u exact=%u pair_kernel=%.3f ms general_path=%.3f ms\n", what, rounds, h.nU, h.nK, h.nPairs, h.nDecided, h.nSpill, h.nExact, ms, ms2);
     }
     return 0;
   };
@@ -1027,7 +1076,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   SD_CHECK(hipStreamSynchronize(s));
   if (stats) { stats[0] = totalPairs; stats[1] = totalExact; stats[2] = rounds; stats[3] = totalNbr;
                stats[4] = (int64_t)ns_pairs; stats[5] = n_pair_launches; stats[6] = (int64_t)ns_full; stats[7] = (int64_t)ns_pre;
-               stats[8] = totalSpill; }
+               stats[8] = totalSpill; stats[9] = totalDecided; }
   if (verbose) {
     printf("NMS: %lld pair intersections (%lld on the exact-join path), %d greedy rounds, %lld neighbour entries\n",
            (long long)totalPairs, (long long)totalExact, rounds, (long long)totalNbr);

@@ -35,6 +35,7 @@ SIGNATURES = {
     "sd_nms2d_host": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "sd_nms2d_device": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "sd_clip_pairs_device": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "sd_area_bounds_pairs_device": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sd_prepare_polys_device": (_i, [_vp, _vp, _i, _i, _vp, ctypes.c_int64, _vp]),
     "sd_star_dist2d_host": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
     "sd_star_dist2d_device": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

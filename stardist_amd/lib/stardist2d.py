@@ -100,3 +100,19 @@ def clip_pairs(xa, ya, xb, yb):
                                          N.tptr(out), N.tptr(fl))
     torch.cuda.synchronize()
     return out.cpu().numpy(), fl.cpu().numpy()
+
+
+def area_bounds_pairs(xa, ya, xb, yb):
+    """Pair-level probe (tests) of the 2D NMS's decision shortcut (csrc/area_bounds.h): (exact intersection area float32, half-width of the
+    band enclosing Clipper's area, usable bool, number of boundary crossings, number of near edge pairs) per pair.  xa..yb int32 (n_pairs, n_verts <= 32)."""
+    import torch
+    N.require_device()
+    dev = torch.device("cuda")
+    t = [torch.from_numpy(np.ascontiguousarray(v, np.int32)).to(dev) for v in (xa, ya, xb, yb)]
+    n, R = t[0].shape
+    area = torch.zeros(n, dtype=torch.float32, device=dev); band = torch.zeros(n, dtype=torch.float32, device=dev)
+    info = torch.zeros(n, dtype=torch.int32, device=dev)
+    N.dcall(t[0], "sd_area_bounds_pairs_device", N.tptr(t[0]), N.tptr(t[1]), N.tptr(t[2]), N.tptr(t[3]), n, R, N.tptr(area), N.tptr(band), N.tptr(info))
+    torch.cuda.synchronize()
+    info = info.cpu().numpy()
+    return area.cpu().numpy(), band.cpu().numpy(), (info & 1).astype(bool), (info >> 8) & 0x3FF, (info >> 18) & 0x7FF

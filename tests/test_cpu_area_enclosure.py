@@ -1,0 +1,64 @@
+"""CPU: the statement of the 2D NMS's decision shortcut (tests/_area_exact.py, the arithmetic of csrc/area_bounds.h) against the vendored
+Clipper (oracle/_ref): the band around the exact intersection area contains Clipper's area for every usable pair, degenerate
+configurations included (shared edges, touching vertices, identical polygons)."""
+import numpy as np
+import pytest
+
+from _area_exact import band, edge_stats, exact_area, near_pairs, plain
+
+
+def _star_polys(rng, n, R, radius, noise, spread):
+    ang = np.float32(2 * np.pi / R)
+    k = np.arange(R, dtype=np.int32)
+    s = np.sin((ang * k).astype(np.float32)).astype(np.float32)
+    c = np.cos((ang * k).astype(np.float32)).astype(np.float32)
+    d = np.maximum((radius * (1 + noise * rng.uniform(-1, 1, (n, R)))).astype(np.float32), np.float32(1e-3))
+    p = np.floor(rng.uniform(50, 50 + spread, (n, 2))).astype(np.float32)
+    return (p[:, 1:] + d * c).astype(np.float32).astype(np.int64), (p[:, :1] + d * s).astype(np.float32).astype(np.int64)
+
+
+def _check(refmods, xa, ya, xb, yb):
+    A, K, ok, _, _ = exact_area(xa, ya, xb, yb)
+    usable = ok & plain(xa, ya) & plain(xb, yb)
+    la, pa = edge_stats(xa, ya); lb, pb = edge_stats(xb, yb)
+    B = band(K, near_pairs(xa, ya, xb, yb), la, lb, 64.0, pa, pb)
+    C = np.array([refmods.clipper_area(xa[i], ya[i], xb[i], yb[i]) for i in range(len(xa))], np.float64)
+    d = np.abs(C - A)
+    assert np.all(d[usable] <= B[usable]), (np.flatnonzero(usable & (d > B))[:5], d[usable].max())
+    return usable, d, B, K
+
+
+@pytest.mark.parametrize("R,radius,noise,spread", [(32, 10, 0.1, 12), (32, 10, 0.03, 5), (32, 10, 0.3, 25), (32, 4, 0.3, 6), (16, 25, 0.2, 30), (32, 10, 0.9, 12)])
+def test_band_contains_clipper_area(refmods, R, radius, noise, spread):
+    rng = np.random.RandomState(R + int(radius * 10) + int(noise * 100))
+    n = 1500
+    xa, ya = _star_polys(rng, n, R, radius, noise, spread)
+    xb, yb = _star_polys(rng, n, R, radius * 0.8, noise, spread)
+    usable, d, B, K = _check(refmods, xa, ya, xb, yb)
+    if noise <= 0.3 and radius >= 10:
+        assert usable.mean() > 0.95
+        assert (d[usable] / B[usable]).max() < 0.5          # measured < 0.3: the band is a bound, not a fit
+
+
+def test_degenerate_configurations(refmods):
+    sq = lambda x0, y0, w, h: (np.array([x0, x0 + w, x0 + w, x0]), np.array([y0, y0, y0 + h, y0 + h]))
+    cases = [(sq(0, 0, 10, 10), sq(0, 0, 10, 10)),        # identical
+             (sq(0, 0, 10, 10), sq(10, 0, 10, 10)),       # sharing an edge from outside
+             (sq(0, 0, 10, 10), sq(0, 0, 5, 10)),         # sharing three edges from inside
+             (sq(0, 0, 10, 10), sq(10, 10, 5, 5)),        # touching at a corner
+             (sq(0, 0, 10, 10), sq(5, 0, 10, 10)),        # collinear overlapping edges
+             (sq(0, 0, 10, 10), sq(2, 2, 3, 3)),          # nested
+             (sq(0, 0, 10, 10), sq(20, 0, 3, 3)),         # disjoint
+             ((np.array([0, 10, 5]), np.array([0, 0, 10])), (np.array([5, 10, 0]), np.array([0, 10, 10]))),   # vertex on an edge
+             ((np.array([0, 10, 10, 5, 0]), np.array([0, 0, 10, 10, 10])), sq(5, 5, 10, 10))]                 # collinear vertex = corner of the other
+    for (ax, ay), (bx, by) in cases:
+        for flip_a in (False, True):
+            for flip_b in (False, True):
+                if flip_a != flip_b: continue                                         # opposite orientations are not usable
+                xa, ya = (ax[::-1], ay[::-1]) if flip_a else (ax, ay)
+                xb, yb = (bx[::-1], by[::-1]) if flip_b else (bx, by)
+                n = max(len(xa), len(xb))
+                pad = lambda v: np.concatenate([v, np.repeat(v[-1:], n - len(v))])[None].astype(np.int64)      # repeated vertices = zero-length edges
+                A, K, ok, _, _ = exact_area(pad(xa), pad(ya), pad(xb), pad(yb))
+                C = refmods.clipper_area(pad(xa)[0], pad(ya)[0], pad(xb)[0], pad(yb)[0])
+                assert ok[0] and abs(A[0] - C) < 1e-9, (xa, ya, xb, yb, A[0], C)

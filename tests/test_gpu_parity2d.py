@@ -159,3 +159,56 @@ def test_nms2d_pair_kernel_forms_agree(refmods):
             assert np.array_equal(sd2.c_non_max_suppression_inds(d, p_far, 1, 1, 0, np.float32(0.4)), want_far), lanes
     finally:
         N.check(N.lib().sd_set_option(b"nms2d_pair_lanes", 64))
+
+
+# ---- the decision shortcut (csrc/area_bounds.h): enclosure of Clipper's area from regular arithmetic
+@pytest.mark.parametrize("R,radius,noise,spread", [(32, 10, 0.1, 12), (32, 10, 0.3, 25), (32, 4, 0.3, 6), (16, 25, 0.2, 30), (32, 10, 0.9, 12), (7, 12, 0.2, 14)])
+def test_area_enclosure_probe_matches_statement(R, radius, noise, spread):
+    """the GPU probe against the numpy statement of the same arithmetic (tests/_area_exact.py): area, crossing count, usability"""
+    from _area_exact import exact_area, near_pairs, plain
+    from stardist_amd.lib import stardist2d as sd2
+    rng = np.random.RandomState(R * 7 + int(radius))
+    n = 3000
+    xa, ya = _star_polys(rng, n, R, radius, noise, spread)
+    xb, yb = _star_polys(rng, n, R, radius * 0.8, noise, spread)
+    area, band, usable, K, T = sd2.area_bounds_pairs(xa, ya, xb, yb)
+    A, Ks, ok, _, _ = exact_area(*(v.astype(np.int64) for v in (xa, ya, xb, yb)))
+    want = ok & plain(xa.astype(np.int64), ya.astype(np.int64)) & plain(xb.astype(np.int64), yb.astype(np.int64))
+    assert np.array_equal(usable, want), (np.flatnonzero(usable != want)[:10], usable.mean(), want.mean())
+    assert np.array_equal(K[usable], Ks[usable])
+    assert np.array_equal(T[usable], near_pairs(*(v.astype(np.int64) for v in (xa, ya, xb, yb)))[usable])
+    assert np.all(np.abs(area[usable] - A[usable]) <= 2e-3 + 1e-6 * A[usable]), np.abs(area[usable] - A[usable]).max()
+
+
+@pytest.mark.parametrize("R,radius,noise,spread,scale", [(32, 10, 0.1, 12, 0.8), (32, 10, 0.03, 6, 1.0), (32, 10, 0.03, 3, 0.97), (32, 20, 0.05, 6, 0.95),
+                                                         (32, 10, 0.3, 25, 0.8), (32, 4, 0.3, 6, 0.8), (32, 2.5, 0.3, 4, 1.0), (16, 25, 0.2, 30, 0.8),
+                                                         (32, 40, 0.1, 60, 0.9), (32, 10, 0.9, 12, 0.8), (24, 200, 0.2, 300, 0.8)])
+def test_area_enclosure_contains_clipper_area(R, radius, noise, spread, scale):
+    """for every pair the shortcut may use, the area of the Clipper-exact sweep lies inside the band (400 k pairs per family)"""
+    from stardist_amd.lib import stardist2d as sd2
+    rng = np.random.RandomState(R * 13 + int(radius * 10) + int(noise * 100))
+    n = 400000
+    xa, ya = _star_polys(rng, n, R, radius, noise, spread)
+    xb, yb = _star_polys(rng, n, R, radius * scale, noise, spread)
+    twice, flags = sd2.clip_pairs(xa, ya, xb, yb)
+    assert not np.any(flags & 0xFF)
+    area, band, usable, K, T = sd2.area_bounds_pairs(xa, ya, xb, yb)
+    d = np.abs(0.5 * twice.astype(np.float64) - area.astype(np.float64))
+    worst = (d[usable] / band[usable]).max() if usable.any() else 0.0
+    print("R=%d radius=%g noise=%g spread=%g scale=%g: usable %.4f, crossings mean %.1f, near pairs mean %.1f, max |A_clipper - A| / band %.3f (max |d| %.2f)"
+          % (R, radius, noise, spread, scale, usable.mean(), K[usable].mean() if usable.any() else 0, T[usable].mean() if usable.any() else 0, worst,
+             d[usable].max() if usable.any() else 0))
+    assert worst <= 0.5, worst                               # a bound with room to spare, not a fit
+
+
+@pytest.mark.parametrize("thr", [0.3, 0.5])
+def test_nms2d_area_bounds_on_off(refmods, thr):
+    from oracle import synth
+    from stardist_amd.lib import _native as N, stardist2d as sd2
+    d, p, s = synth.s2d_uniform(384, 384, n_rays=32, prob_thresh=0.85)
+    ref_keep = refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(thr))
+    for on in (1, 0):
+        with N.option("nms2d_area_bounds", on):
+            keep, stats = sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(thr), return_stats=True)
+        assert np.array_equal(keep, ref_keep), (on, np.flatnonzero(keep != ref_keep)[:10])
+        assert (stats[9] > 0) == bool(on), stats[:10]

@@ -8,6 +8,10 @@ from stardist_amd import nms
 from stardist_amd.lib import _native, stardist2d as sd2
 from stardist_amd.models import Config2D, StarDist2D
 dev = torch.device("cuda:0")
+if os.environ.get("SD_LIB"):                      # a probe build of the library (SD_BUILD_DEBUG_SWITCHES=1: tuning knobs read from the environment)
+    _native.LIB_PATH = os.environ["SD_LIB"]
+if os.environ.get("SD_AREA_BOUNDS"):
+    _native.check(_native.lib().sd_set_option(b"nms2d_area_bounds", int(os.environ["SD_AREA_BOUNDS"])))
 if os.environ.get("SD_PAIR_LANES"):
     _native.check(_native.lib().sd_set_option(b"nms2d_pair_lanes", int(os.environ["SD_PAIR_LANES"])))
     print("nms2d_pair_lanes =", _native.lib().sd_get_option(b"nms2d_pair_lanes"))
