@@ -38,8 +38,6 @@ enum { PP_PLAIN = 1, PP_POS = 2, PP_NEG = 4 };
 struct PolyProps { float lmax, perim; int flags; int xmin, xmax, ymin, ymax; int pad; };   // integer bounding box of the vertices
 
 __device__ __forceinline__ float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
-// sign of cross(g, (eps, eps^2)) for a direction g != 0 and eps -> 0+
-__device__ __forceinline__ float tie_of(float gx, float gy) { return gy != 0.f ? -sgnf(gy) : sgnf(gx); }
 __device__ __forceinline__ float half_sum(float v) { for (int o = 16; o; o >>= 1) v += __shfl_xor(v, o); return v; }
 __device__ __forceinline__ float half_max(float v) { for (int o = 16; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
 __device__ __forceinline__ int half_sum_i(int v) { for (int o = 16; o; o >>= 1) v += __shfl_xor(v, o); return v; }
@@ -139,8 +137,12 @@ __device__ __forceinline__ Enclosure pair_enclosure(const int* __restrict__ px, 
   __builtin_amdgcn_wave_barrier();                  // (a wave's LDS accesses are processed in order)
   const float ex = bx - ax, ey = by - ay;
   const bool oke = lv && (ex != 0.f || ey != 0.f);
-  const float tie_e = tie_of(ex, ey);
-  const float sP = (pp.flags & PP_POS) ? 1.f : -1.f, sQ = (pq.flags & PP_POS) ? 1.f : -1.f;
+  // sides as booleans ("on the positive side"); a zero orientation takes the sign of the perturbation term:
+  //   Q's vertex against my edge e:      cross(e, (eps, eps^2)) > 0  <=>  ey != 0 ? ey < 0 : ex > 0
+  //   my vertex against Q's edge f:     -cross(f, (eps, eps^2)) > 0  <=>  fy != 0 ? fy > 0 : fx < 0
+  const bool tie_e_pos = ey != 0.f ? ey < 0.f : ex > 0.f;
+  const bool e_up = by > ay;
+  const bool sPpos = (pp.flags & PP_POS) != 0, sQpos = (pq.flags & PP_POS) != 0;
   const float exlo = fminf(ax, bx) - 1.f, exhi = fmaxf(ax, bx) + 1.f, eylo = fminf(ay, by) - 1.f, eyhi = fmaxf(ay, by) + 1.f;
   float accP = 0.f, accQ = 0.f;
   int K = 0, T = 0, parA = 0;
@@ -148,29 +150,31 @@ __device__ __forceinline__ Enclosure pair_enclosure(const int* __restrict__ px, 
   float o_ec = ex * (c.y - ay) - ey * (c.x - ax);
   const int Rw = __any(use) ? R : 0;                // (`use` is uniform within a half; the ballot in the loop is wave-wide)
   for (int k = 0; k < Rw; ++k) {
-    const bool kv = use;
     const int kn = (k + 1 >= R) ? 0 : k + 1;
     const float2 d = sq[kn];
     const float fx = d.x - c.x, fy = d.y - c.y;
-    const bool okf = kv && (fx != 0.f || fy != 0.f);
-    const float tie_f = -tie_of(fx, fy);
+    const bool okf = use & ((fx != 0.f) | (fy != 0.f));
+    const bool tie_f_pos = fy != 0.f ? fy > 0.f : fx < 0.f;
     const float o_ed = ex * (d.y - ay) - ey * (d.x - ax);
     const float o_fa = fx * (ay - c.y) - fy * (ax - c.x), o_fb = fx * (by - c.y) - fy * (bx - c.x);
-    const float s_c = o_ec != 0.f ? sgnf(o_ec) : tie_e, s_d = o_ed != 0.f ? sgnf(o_ed) : tie_e;
-    const float s_a = o_fa != 0.f ? sgnf(o_fa) : tie_f, s_b = o_fb != 0.f ? sgnf(o_fb) : tie_f;
+    const bool pos_c = (o_ec > 0.f) | ((o_ec == 0.f) & tie_e_pos), pos_d = (o_ed > 0.f) | ((o_ed == 0.f) & tie_e_pos);
+    const bool pos_a = (o_fa > 0.f) | ((o_fa == 0.f) & tie_f_pos), pos_b = (o_fb > 0.f) | ((o_fb == 0.f) & tie_f_pos);
     const float ccd = c.x * d.y - c.y * d.x;
-    if (oke && okf && fminf(c.x, d.x) <= exhi && fmaxf(c.x, d.x) >= exlo && fminf(c.y, d.y) <= eyhi && fmaxf(c.y, d.y) >= eylo) ++T;
-    if (oke && okf && s_c != s_d && s_a != s_b) {
-      const float t = o_fa / (o_fa - o_fb), u = o_ec / (o_ec - o_ed);
-      accP += sQ * s_b * (1.f - t);
-      accQ += ccd * (sP * s_d * (1.f - u));
+    const bool both = oke & okf;
+    // edge pairs closer than one lattice step (bounding boxes)
+    T += (both & ((c.x <= exhi) | (d.x <= exhi)) & ((c.x >= exlo) | (d.x >= exlo)) & ((c.y <= eyhi) | (d.y <= eyhi)) & ((c.y >= eylo) | (d.y >= eylo))) ? 1 : 0;
+    if (both & (pos_c != pos_d) & (pos_a != pos_b)) {                                         // e and f cross
+      const float t = o_fa * __builtin_amdgcn_rcpf(o_fa - o_fb), u = o_ec * __builtin_amdgcn_rcpf(o_ec - o_ed);   // (1 ulp: far inside the band)
+      const float wt = 1.f - t, wu = 1.f - u;
+      accP += (pos_b == sQpos) ? wt : -wt;                                                    // e enters Q: + (1 - t)
+      accQ += ccd * ((pos_d == sPpos) ? wu : -wu);
       ++K;
     }
-    if (okf && ((c.y < ay) != (d.y < ay)) && ((s_a > 0.f) == (d.y > c.y))) parA ^= 1;                       // a inside Q: ray towards +x
-    const bool hitC = oke && kv && ((ay <= c.y) != (by <= c.y)) && ((s_c > 0.f) == (by > ay));           // c inside P
+    parA ^= (okf & ((c.y < ay) != (d.y < ay)) & (pos_a == (fy > 0.f))) ? 1 : 0;               // a inside Q: ray towards +x
+    const bool hitC = oke & use & ((ay <= c.y) != (by <= c.y)) & (pos_c == e_up);              // c inside P
     const unsigned long long hb64 = __ballot(hitC);
     const unsigned int hm = (unsigned int)(half ? (hb64 >> 32) : hb64);
-    if ((__popc(hm) & 1) && l == 0 && okf) accQ += ccd;
+    if ((__popc(hm) & 1) && l == 0) accQ += ccd;
     c = d; o_ec = o_ed;
   }
   const float cab = ax * by - ay * bx;
