@@ -798,6 +798,21 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   EvGuard evguardFJ{evFork, evJoin};
   SD_CHECK(hipEventRecord(evFork, s));
   SD_CHECK(hipStreamWaitEvent(side, evFork, 0));
+  // polygon properties of the decision shortcut (area_bounds.h) first: they also depend on the integer vertices only, and the
+  // decision kernel of the first round needs them before any sweep needs a prepared polygon (evProps / evPrep)
+  const bool areaBounds = R <= 32 && R >= 3 && sd::option(sd::OPT_NMS2D_AREA_BOUNDS) != 0;
+  sdarea::PolyProps* props = nullptr;
+  hipEvent_t evProps = nullptr, evPrep = nullptr;
+  SD_CHECK(hipEventCreateWithFlags(&evProps, hipEventDisableTiming));
+  SD_CHECK(hipEventCreateWithFlags(&evPrep, hipEventDisableTiming));
+  EvGuard evguardP{evProps, evPrep};
+  if (areaBounds) {
+    props = (sdarea::PolyProps*)A.take((size_t)N * sizeof(sdarea::PolyProps));
+    if (!props) return -1;
+    hipLaunchKernelGGL(sdarea::k_poly_props, dim3(sd::div_up(N, 8)), dim3(256), 0, side, vx, vy, N, R, props);
+    SD_LAUNCH_CHECK();
+  }
+  SD_CHECK(hipEventRecord(evProps, side));
   {
     int rc;
     if (R <= 32) rc = BeamPath<32, 64>::prepare(vx, vy, N, R, prep, side);
@@ -806,15 +821,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
     else rc = BeamPath<256, 16>::prepare(vx, vy, N, R, prep, side);
     if (rc) return -1;
   }
-  // polygon properties of the decision shortcut (area_bounds.h), same stream: they also depend on the integer vertices only
-  const bool areaBounds = R <= 32 && R >= 3 && sd::option(sd::OPT_NMS2D_AREA_BOUNDS) != 0;
-  sdarea::PolyProps* props = nullptr;
-  if (areaBounds) {
-    props = (sdarea::PolyProps*)A.take((size_t)N * sizeof(sdarea::PolyProps));
-    if (!props) return -1;
-    hipLaunchKernelGGL(sdarea::k_poly_props, dim3(sd::div_up(N, 8)), dim3(256), 0, side, vx, vy, N, R, props);
-    SD_LAUNCH_CHECK();
-  }
+  SD_CHECK(hipEventRecord(evPrep, side));
   SD_CHECK(hipEventRecord(evJoin, side));
   int gs[8];
   SD_CHECK(hipMemcpyAsync(gs, gstats, sizeof(gs), hipMemcpyDeviceToHost, s));
@@ -883,8 +890,9 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   hipLaunchKernelGGL((k_neighbours<1>), dim3(nbBlocks), dim3(256), 0, s, N, g, f, cellRec, cellStart, nbrCount, nbrLow, (const i64*)nbrStart, nbr, waitOn, W);
   SD_LAUNCH_CHECK();
 
-  // (the prepared polygons are being written on the side stream meanwhile; the pair kernels below are their first readers)
-  SD_CHECK(hipStreamWaitEvent(s, evJoin, 0));
+  // (the prepared polygons are being written on the side stream meanwhile; the sweep kernels are their first readers and wait for
+  // evPrep in run_pairs -- with the shortcut on, the decision kernel of round 1 runs before that and only needs the properties)
+  SD_CHECK(hipStreamWaitEvent(s, evProps, 0));
   if (stats) { SD_CHECK(hipEventRecord(ev1, s)); SD_CHECK(hipEventSynchronize(ev1)); float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns_pre = ms * 1e6; }
 
   // ---- greedy rounds: every kernel of a round takes its work-list length from device memory; ONE host round trip per
@@ -963,17 +971,21 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
         if (decided)
           hipLaunchKernelGGL(k_pairs_decide, dim3(256 * 8), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, vx, vy, R, props, area, threshold, state, suppOut,
                              decided, &d_cnt->nDecided);
+        SD_CHECK(hipStreamWaitEvent(s, evPrep, 0));          // the prepared polygons (side stream; complete long before, except in round 1)
         hipLaunchKernelGGL(k_pair_bucket_count, dim3(512), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, d_points, key, bucketHist, decided);
         hipLaunchKernelGGL(k_pair_bucket_scan, dim3(1), dim3(1024), 0, s, bucketHist, bucketHist + PAIR_BUCKETS, nOrdered);
         hipLaunchKernelGGL(k_pair_bucket_scatter, dim3(512), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, d_points, key, bucketHist + PAIR_BUCKETS,
                            pairOrder, qCap, decided);
         SD_LAUNCH_CHECK();
         rc = BeamPath<32, 64>::tier1(pairs, pairOrder, nOrdered, (const unsigned int*)nullptr, prep, area, threshold, state, suppOut, q1, s);
-      } else
+      } else {
+        SD_CHECK(hipStreamWaitEvent(s, evPrep, 0));
         rc = BeamPath<32, 64>::tier1(pairs, (const unsigned int*)nullptr, &d_cnt->nPairs, first, prep, area, threshold, state, suppOut, q1, s);
+      }
       if (stats) SD_CHECK(hipEventRecord(ev1, s));
       if (!rc) rc = BeamPath<32, 64>::tier2(pairs, spillPairs, &d_cnt->nSpill, (const unsigned int*)nullptr, prep, area, threshold, state, suppOut, q2, s);
     } else {
+      SD_CHECK(hipStreamWaitEvent(s, evPrep, 0));
       if (R <= 64) rc = BeamPath<64, 64>::tier2(pairs, (const unsigned int*)nullptr, &d_cnt->nPairs, first, prep, area, threshold, state, suppOut, q2, s);
       else if (R <= 128) rc = BeamPath<128, 32>::tier2(pairs, (const unsigned int*)nullptr, &d_cnt->nPairs, first, prep, area, threshold, state, suppOut, q2, s);
       else rc = BeamPath<256, 16>::tier2(pairs, (const unsigned int*)nullptr, &d_cnt->nPairs, first, prep, area, threshold, state, suppOut, q2, s);
