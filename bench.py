@@ -494,13 +494,17 @@ def main():
             roof_conv["traffic"] = ct["bytes_per_forward"]
             roof_conv["traffic_source"] = ct["source"]
             roof_conv["kernel_ms_per_forward_rocprof"] = ct["kernel_ms_per_forward"]
-        roof_pair = {"bound": "hbm", "kernel": "k_pairs_beam<32,8,6,4,64> (bound-slot scan-beam polygon intersection, one pair per lane, state in LDS)", "achieved": round(pair_gbs, 3),
+        n_decided = float(s2[9])
+        roof_pair = {"bound": "hbm", "kernel": "pair stage of a greedy round: k_pairs_decide (area enclosure from a boundary integral, 32 lanes per pair, csrc/area_bounds.h) "
+                                               "+ pair bucketing + k_pairs_beam<32,8,6,4,64,REL16> (Clipper-exact scan-beam sweep, one pair per lane, state in LDS) for the pairs "
+                                               "the enclosure leaves undecided", "achieved": round(pair_gbs, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pair_gbs / HBM_PEAK_GBS, 6), "traffic": None,
                      "bytes_per_launch": round(pair_bytes_per_launch), "avg_launch_ms": round(float(pair_ms / pair_launches), 4),
                      "launches_per_step": float(pair_launches), "pairs_per_step": float(n_pairs),
-                     "note": "integer scan-beam sweep, one pair per lane, per-pair state (636 B) lane-interleaved in LDS: LATENCY-bound -- VALU issue 12.5 %, "
-                             "LDS capacity limits a CU to 256 pairs in flight (4 x 64 or 7 x 32 lanes, same time either way: option nms2d_pair_lanes) and a "
-                             "launch costs ceil(pairs / 65536) sweeps of ~0.6 ms; not HBM-bound; algorithmic bytes = 272 B/pair (SURVEY.md 8d)"}
+                     "pairs_decided_by_area_enclosure": n_decided, "pairs_swept_exactly": float(n_pairs) - n_decided,
+                     "note": "not HBM-bound.  The decision kernel is regular VALU work (~1000 instructions per pair, n^2 edge pairs); the sweep is an integer "
+                             "state machine, one pair per lane, per-pair state (420 B) lane-interleaved in LDS: LATENCY-bound under lane divergence, a launch "
+                             "costs at least one sweep's serial latency (~0.7 ms) however few pairs it holds; algorithmic bytes = 272 B/pair (SURVEY.md 8d)"}
         try:
             with open(PAIR_TRAFFIC_JSON) as fh:
                 tj = json.load(fh)
