@@ -43,6 +43,9 @@ int sd_release_workspace(void);           /* free the cached device workspace   
  *                              wave that evaluated the bounds (bit-identical volumes)
  *   "nms2d_area_bounds"   1|0  2D pairs far from the threshold are decided from an enclosure of the intersection area (regular arithmetic,
  *                              area_bounds.h) / every pair runs the Clipper-exact sweep
+ *   "nms2d_defer_undecided" r|0  (with "nms2d_area_bounds") from greedy round r on (default 2), a round that leaves at most 16 384 pairs undecided
+ *                              does not sweep them itself: they are swept by the tail batch's one launch (a sweep launch costs one sweep's
+ *                              latency however few pairs it holds) / 0: every round sweeps its own
  *   "probe_tier"          1|2  capacity tier sd_clip_pairs_device runs first;  "probe_no_general" 1: do not fall back to the general path
  *   "trace"               1    print per-round counters to stdout
  * Nothing in the library reads the process environment.  sd_get_option returns -1 for an unknown name. */
@@ -58,7 +61,7 @@ int sd_get_option(const char* name);
  * stats  optional int64[16] (may be NULL): {0 pairs evaluated, 1 pairs re-run on the exact-join path,
  *        2 greedy rounds, 3 neighbour entries, 4 pair-kernel time ns (HIP events on `stream`),
  *        5 pair-kernel launches, 6 exact-join kernel ns, 7 build+bin+neighbour kernels ns, 8 capacity spills,
- *        9 pairs decided by the area enclosure (counted in 0 as well), 10.. 0}.
+ *        9 pairs decided by the area enclosure (counted in 0 as well), 10 undecided pairs deferred to the tail batch, 11.. 0}.
  */
 int sd_nms2d_host(const float* dist, const float* points, int n_polys, int n_rays,
                   int use_kdtree, int use_bbox, int verbose, float threshold,

@@ -526,6 +526,41 @@ __global__ void k_tail_init(Deferred d, int2* __restrict__ pairs, unsigned int* 
   for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) { pairs[t] = d.pairs[t]; exact[t] = t; }
   if (blockIdx.x == 0 && threadIdx.x == 0) { *nPairs = n; *nExact = n; *firstNew = n; }
 }
+// Deferral of the pairs the area enclosure leaves undecided (option "nms2d_defer_undecided" = first round that defers): a sweep launch
+// costs one sweep's serial latency (~0.65 ms) however few pairs it holds, so from that round on the undecided pairs are not swept in
+// their round but carried to the tail batch like the general-path pairs -- kind[k] = 1 marks them: there they are swept (tier 1 / 2),
+// while the kind-0 pairs go to the general kernel as before.  j is pending until then (can be suppressed, cannot be promoted).
+__global__ void k_defer_undecided(const int2* __restrict__ pairs, const unsigned long long* __restrict__ nPtr, const unsigned int* __restrict__ nDecided,
+                                  unsigned int limit, unsigned char* __restrict__ decided, const unsigned char* __restrict__ state, Deferred d,
+                                  unsigned char* __restrict__ kind) {
+  // only a round whose undecided pairs would make a latency-bound sweep launch defers them (many undecided pairs -- a threshold inside
+  // the overlap range of one object's candidates -- are swept at once more cheaply than they are carried along); a deferred pair gets
+  // decided[t] = 4, so that the bucketing and the sweeps that follow in the stream find nothing to do
+  const unsigned long long n = *nPtr;
+  if (n - (unsigned long long)*nDecided > (unsigned long long)limit) return;
+  for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * blockDim.x) {
+    if (decided[t]) continue;
+    decided[t] = 4;
+    const int2 ij = pairs[t];
+    if (state[ij.y] == ST_SUPPRESSED) continue;            // a decided pair of this round already suppressed j
+    const unsigned int k = atomicAdd(d.count, 1u);
+    if (k < d.cap) { d.pairs[k] = ij; d.pend[ij.y] = 1; d.next[k] = atomicExch(&d.head[ij.y], (int)k); kind[k] = 1; }
+  }
+}
+// tail batch with both kinds of deferred pairs: all become entries 0 .. nDef-1 of the pair list; kind 0 -> general-path queue and
+// decided[t] = 3 (the sweeps skip them), kind 1 -> decided[t] = 0 (bucketed and swept with the tail's own undecided pairs).
+// *nExact must be zero on entry; *nJoin receives the number of kind-0 pairs (the queue's prefix).
+__global__ void k_tail_init2(Deferred d, const unsigned char* __restrict__ kind, int2* __restrict__ pairs, unsigned int* __restrict__ exact,
+                             unsigned long long* nPairs, unsigned int* nExact, unsigned int* firstNew, unsigned char* __restrict__ decided) {
+  unsigned int n = *d.count; if (n > d.cap) n = d.cap;
+  for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    pairs[t] = d.pairs[t];
+    if (kind[t] == 0) { exact[atomicAdd(nExact, 1u)] = t; decided[t] = 3; } else decided[t] = 0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *nPairs = n; *firstNew = n; }
+}
+__global__ void k_copy_u32(unsigned int* dst, const unsigned int* src) { *dst = *src; }
+constexpr unsigned int DEFER_UNDECIDED_MAX = 16384u;      // a sweep launch over fewer pairs than this is pure latency (98 304 pairs are in flight at once)
 // deferred pairs of candidate j: true if one of them suppresses it (their survivors i are KEPT by construction)
 __device__ __forceinline__ bool deferred_suppresses(int j, const int* __restrict__ defHead, const int* __restrict__ defNext,
                                                     const unsigned char* __restrict__ supp) {
@@ -950,6 +985,16 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   bool sideGeneral = false;                   // tail batch: the deferred pairs' general-path launch runs on the helper stream
   unsigned int* nNewExact = A.take_n<unsigned int>(1);
   if (!nNewExact) return -1;
+  // deferral of the enclosure's undecided pairs (see k_defer_undecided): off by default
+  const int deferFrom = (deferOn && decided) ? sd::option(sd::OPT_NMS2D_DEFER_UNDECIDED) : 0;
+  unsigned char* defKind = nullptr; unsigned int* nJoinDef = nullptr;
+  if (deferFrom > 0) {
+    defKind = A.take_n<unsigned char>(qCap); nJoinDef = A.take_n<unsigned int>(1);
+    if (!defKind || !nJoinDef) return -1;
+    SD_CHECK(hipMemsetAsync(defKind, 0, qCap, s));
+  }
+  i64 totalUndecDeferred = 0;
+  i64 nUndecDeferredUpper = 0;               // upper bound of the kind-1 deferred pairs so far (those whose j was suppressed meanwhile are skipped)
   // one beam-path pass over the current pair list (tier 1, tier 2, then the general path -- or its deferral); suppOut == nullptr
   // applies decisions to state (normal round), else records them per pair (tail batch, whose first *firstNew entries are the
   // deferred pairs, already queued for the general path)
@@ -971,10 +1016,14 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
         if (decided)
           hipLaunchKernelGGL(k_pairs_decide, dim3(256 * 8), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, vx, vy, R, props, area, threshold, state, suppOut,
                              decided, &d_cnt->nDecided);
+        if (!suppOut && deferFrom > 0 && rounds >= deferFrom)      // few undecided pairs: they wait for the tail batch's sweep launch
+          hipLaunchKernelGGL(k_defer_undecided, dim3(256), dim3(256), 0, s, pairs, &d_cnt->nPairs, &d_cnt->nDecided, DEFER_UNDECIDED_MAX, decided, state, dfr, defKind);
+        // tail batch with deferred undecided pairs: they sit in the list's prefix with decided[] = 0 and are bucketed with the rest
+        const unsigned int* bfirst = (suppOut && deferFrom > 0) ? nullptr : first;
         SD_CHECK(hipStreamWaitEvent(s, evPrep, 0));          // the prepared polygons (side stream; complete long before, except in round 1)
-        hipLaunchKernelGGL(k_pair_bucket_count, dim3(512), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, d_points, key, bucketHist, decided);
+        hipLaunchKernelGGL(k_pair_bucket_count, dim3(512), dim3(256), 0, s, pairs, &d_cnt->nPairs, bfirst, d_points, key, bucketHist, decided);
         hipLaunchKernelGGL(k_pair_bucket_scan, dim3(1), dim3(1024), 0, s, bucketHist, bucketHist + PAIR_BUCKETS, nOrdered);
-        hipLaunchKernelGGL(k_pair_bucket_scatter, dim3(512), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, d_points, key, bucketHist + PAIR_BUCKETS,
+        hipLaunchKernelGGL(k_pair_bucket_scatter, dim3(512), dim3(256), 0, s, pairs, &d_cnt->nPairs, bfirst, d_points, key, bucketHist + PAIR_BUCKETS,
                            pairOrder, qCap, decided);
         SD_LAUNCH_CHECK();
         rc = BeamPath<32, 64>::tier1(pairs, pairOrder, nOrdered, (const unsigned int*)nullptr, prep, area, threshold, state, suppOut, q1, s);
@@ -999,7 +1048,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
     } else if (suppOut && sideGeneral) {
       // tail batch: the deferred pairs (the first nDeferred queue entries) are being evaluated on the helper stream since the batch
       // began; here only what the two tiers added behind them, then join
-      hipLaunchKernelGGL(k_count_after, dim3(1), dim3(1), 0, s, nNewExact, &d_cnt->nExact, firstNew);
+      hipLaunchKernelGGL(k_count_after, dim3(1), dim3(1), 0, s, nNewExact, &d_cnt->nExact, deferFrom > 0 ? nJoinDef : firstNew);
       SD_LAUNCH_CHECK();
       if (sd::clip_full_pairs(pairs, exactPairs + nDeferred, nNewExact, qCap - (unsigned int)nDeferred, R, vx, vy, area, threshold, state, suppOut, &d_cnt->nErr, s)) return -1;
       SD_CHECK(hipStreamWaitEvent(s, evJoin, 0));
@@ -1030,7 +1079,11 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
       SD_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), s));
       SD_CHECK(hipMemsetAsync(supp, 0, pairCap, s));
       const int wg = sd::div_up(nU, 4) < 2048 ? sd::div_up(nU, 4) : 2048;
-      hipLaunchKernelGGL(k_tail_init, dim3(64), dim3(256), 0, s, dfr, pairs, exactPairs, &d_cnt->nPairs, &d_cnt->nExact, firstNew);
+      if (deferFrom > 0) {
+        hipLaunchKernelGGL(k_tail_init2, dim3(64), dim3(256), 0, s, dfr, defKind, pairs, exactPairs, &d_cnt->nPairs, &d_cnt->nExact, firstNew, decided);
+        hipLaunchKernelGGL(k_copy_u32, dim3(1), dim3(1), 0, s, nJoinDef, &d_cnt->nExact);
+      } else
+        hipLaunchKernelGGL(k_tail_init, dim3(64), dim3(256), 0, s, dfr, pairs, exactPairs, &d_cnt->nPairs, &d_cnt->nExact, firstNew);
       // The deferred pairs all need the general path (a latency-bound launch of ~1 ms over a few thousand pairs, a fraction of the
       // chip): it starts NOW on the helper stream, next to the emission of the remaining pairs and the two bound-slot tiers; decisions
       // are recorded per pair (supp[]), so the two streams write disjoint bytes.  Joined in run_pairs.
@@ -1038,7 +1091,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
       if (sideGeneral) {
         SD_CHECK(hipEventRecord(evFork, s));
         SD_CHECK(hipStreamWaitEvent(side, evFork, 0));
-        if (sd::clip_full_pairs(pairs, exactPairs, firstNew, qCap, R, vx, vy, area, threshold, state, supp, &d_cnt->nErr, side)) return -1;
+        if (sd::clip_full_pairs(pairs, exactPairs, deferFrom > 0 ? nJoinDef : firstNew, qCap, R, vx, vy, area, threshold, state, supp, &d_cnt->nErr, side)) return -1;
         SD_CHECK(hipEventRecord(evJoin, side));
       }
       hipLaunchKernelGGL(k_tail_emit, dim3(wg), dim3(256), 0, s, Ucur, nU, state, nbrStart, nbrLow, nbr, f, d_points, bbox, radius, area, pairs,
@@ -1054,9 +1107,13 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
       SD_LAUNCH_CHECK();
       if (tr) { SD_CHECK(hipEventRecord(evr1, s)); SD_CHECK(hipEventSynchronize(evr1)); float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, evr0, evr1));
                 printf("tail replay (10 steps + resolve loop): %.3f ms\n", ms); (void)hipEventDestroy(evr0); (void)hipEventDestroy(evr1); }
+      unsigned int hDefTotal = (unsigned int)nDeferred;
       SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+      if (deferFrom > 0) SD_CHECK(hipMemcpyAsync(&hDefTotal, dfr.count, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
       SD_CHECK(hipStreamSynchronize(s));
       h.nU = nU; h.nK = 0;
+      if (deferFrom > 0) { totalUndecDeferred = (i64)hDefTotal - nDeferred; if ((unsigned long long)hDefTotal <= h.nPairs) h.nPairs -= hDefTotal; }
+      else
       if ((i64)h.nPairs >= nDeferred) h.nPairs -= (unsigned long long)nDeferred;      // the deferred pairs were counted in their rounds
       if ((i64)h.nExact >= nDeferred) h.nExact -= (unsigned int)nDeferred;
       if (account("tail batch after round")) return -1;
@@ -1075,10 +1132,11 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
     SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
     SD_CHECK(hipStreamSynchronize(s));
     if (h.nK == 0 && h.nU > 0) {
-      if (deferOn && nDeferred > 0 && !forceTail) forceTail = true;      // everything left waits on deferred pairs: run the tail batch now
+      if (deferOn && (nDeferred > 0 || nUndecDeferredUpper > 0) && !forceTail) forceTail = true;      // everything left waits on deferred pairs: run the tail batch now
       else { sd::set_error("sd_nms2d: greedy scan made no progress (internal error)"); return -1; }
     }
     if (deferOn) nDeferred += h.nExact;
+    if (deferFrom > 0 && rounds >= deferFrom && h.nPairs > h.nDecided && h.nPairs - h.nDecided <= DEFER_UNDECIDED_MAX) nUndecDeferredUpper += (i64)(h.nPairs - h.nDecided);
     if (account("round")) return -1;
     nU = h.nU;
     int* t = Ucur; Ucur = Unext; Unext = t;
@@ -1088,7 +1146,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   SD_CHECK(hipStreamSynchronize(s));
   if (stats) { stats[0] = totalPairs; stats[1] = totalExact; stats[2] = rounds; stats[3] = totalNbr;
                stats[4] = (int64_t)ns_pairs; stats[5] = n_pair_launches; stats[6] = (int64_t)ns_full; stats[7] = (int64_t)ns_pre;
-               stats[8] = totalSpill; stats[9] = totalDecided; }
+               stats[8] = totalSpill; stats[9] = totalDecided; stats[10] = totalUndecDeferred; }
   if (verbose) {
     printf("NMS: %lld pair intersections (%lld on the exact-join path), %d greedy rounds, %lld neighbour entries\n",
            (long long)totalPairs, (long long)totalExact, rounds, (long long)totalNbr);

@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # SD_TEST_OPTIONS="name=value,..." (test runs only): start the session with non-default library switches, e.g. to run the whole
+    # parity suite through a formulation that is off by default
+    opts = os.environ.get("SD_TEST_OPTIONS", "")
+    if opts:
+        from stardist_amd.lib import _native
+        for kv in opts.split(","):
+            k, v = kv.split("=")
+            _native.check(_native.lib().sd_set_option(k.strip().encode(), int(v)))
 
 
 @pytest.fixture(scope="session")

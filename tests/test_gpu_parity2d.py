@@ -212,3 +212,20 @@ def test_nms2d_area_bounds_on_off(refmods, thr):
             keep, stats = sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(thr), return_stats=True)
         assert np.array_equal(keep, ref_keep), (on, np.flatnonzero(keep != ref_keep)[:10])
         assert (stats[9] > 0) == bool(on), stats[:10]
+
+
+@pytest.mark.parametrize("shape,R,thr", [((384, 384), 32, 0.4), ((300, 280), 32, 0.7), ((356, 299), 11, 0.5)])
+def test_nms2d_defer_undecided_settings_agree(refmods, shape, R, thr):
+    """the pairs the enclosure leaves undecided swept in their round (0), deferred to the tail batch from round 2 (default) or from round 1:
+    the compiled reference's survivors every time"""
+    from oracle import synth
+    from stardist_amd.lib import _native as N, stardist2d as sd2
+    d, p, s = synth.s2d_uniform(shape[0], shape[1], n_rays=R, prob_thresh=0.85)
+    ref_keep = refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(thr))
+    deferred = {}
+    for opt in (0, 2, 1):
+        with N.option("nms2d_defer_undecided", opt):
+            keep, stats = sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(thr), return_stats=True)
+        assert np.array_equal(keep, ref_keep), (opt, np.flatnonzero(keep != ref_keep)[:10])
+        deferred[opt] = int(stats[10])
+    assert deferred[0] == 0
