@@ -15,4 +15,8 @@ timeout 300 python tools/probe_hand_conv.py --reps 4 > $O/${tag}_conv_layer_prob
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Istardist_amd/csrc tools/conv_f16_phase_profile.hip -o /tmp/cpp16 2>/dev/null && ( /tmp/cpp16 2; /tmp/cpp16 1 ) > $O/${tag}_conv_f16_phases.txt 2>&1
 timeout 300 python -m pytest -s -q tests/test_gpu_unet_parity.py -m gpu > $O/${tag}_unet_parity.log 2>&1
 SD_TRACE=1 timeout 120 python tools/time_nms2d_bench.py 2 > $O/${tag}_nms2d_rounds_trace.txt 2>&1
+SD_TRACE=1 timeout 120 python tools/time_nms3d_bench.py 2 > $O/${tag}_nms3d_rounds_trace.txt 2>&1
+timeout 120 python tools/check_defer.py > $O/${tag}_nms2d_defer_undecided.txt 2>&1
+timeout 200 python -m pytest -s -q tests/test_gpu_parity2d.py -m gpu -k area > $O/${tag}_area_enclosure_validation.txt 2>&1
+timeout 120 python tools/ab_hull.py stardist_amd/csrc/libstardist_hip.so > $O/${tag}_hull_ab.txt 2>&1
 tail -3 $O/${tag}_tests.log; cat $O/${tag}_smoke.log | tail -1; cut -c1-200 $O/${tag}_bench.json
