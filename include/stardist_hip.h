@@ -70,6 +70,19 @@ int sd_nms2d_device(const float* d_dist, const float* d_points, int n_polys, int
                     int use_kdtree, int use_bbox, int verbose, float threshold,
                     uint8_t* d_keep, int64_t* stats, void* stream);
 
+/* replaces stardist.lib.stardist2d.c_non_max_suppression_inds_old
+ *   (stardist/lib/stardist2d.cpp:173-386, "O!O!fiiii"; caller stardist/nms.py:20-74 _non_maximum_suppression_old; the reference keeps
+ *   it as a second statement of the NMS, tests/test_nms2D.py:78-110 "old == new")
+ * polys   (n_polys, 2, n_rays) int32 vertex coordinates (row 0 = y, row 1 = x), sorted by score descending;
+ * mapping (height, width) int32: id of the score-sorted polygon at that pixel of the prediction grid, -1 = none (only read with
+ *         max_bbox_search != 0: polygon i is compared with the polygons j > i found in the window
+ *         [(bbox - max bbox size) / grid, (bbox + max bbox size) / grid) of the map, :285-311; else with every j > i, :337);
+ * keep    (n_polys,) bytes: 1 = survivor. */
+int sd_nms2d_old_host(const int32_t* polys, int n_polys, int n_rays, const int32_t* mapping, int height, int width,
+                      float threshold, int max_bbox_search, int grid_y, int grid_x, int verbose, uint8_t* keep);
+int sd_nms2d_old_device(const int32_t* d_polys, int n_polys, int n_rays, const int32_t* d_mapping, int height, int width,
+                        float threshold, int max_bbox_search, int grid_y, int grid_x, int verbose, uint8_t* d_keep, void* stream);
+
 /* Test probe: Clipper::AddPath (clipper.cpp:1045-1221) once per polygon -- the prepared-polygon records the 2D NMS
  * builds per candidate (stardist_amd/csrc/clip_beam.h, PolyPrep<MAXV>, MAXV = 32/64/128/256 for n_verts). */
 int sd_prepare_polys_device(const int32_t* d_x, const int32_t* d_y, int n_polys, int n_verts, void* d_out,

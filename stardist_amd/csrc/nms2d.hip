@@ -1155,6 +1155,204 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   return 0;
 }
 
+// ---- the legacy variant: c_non_max_suppression_inds_old (stardist2d.cpp:173-386; caller stardist/nms.py:20-74, reference test
+// tests/test_nms2D.py:78-110 "old == new").  Input = integer polygons (n, 2, R) (row 0 = y, row 1 = x) sorted by score descending and,
+// with max_bbox_search, the map pixel -> polygon id: polygon i is only compared with the polygons j > i found in a window of the map
+// around i's bounding box (:285-301); without it, with every j > i (:337).  Not on predict_instances(): kept as the reference keeps it,
+// a second statement of the same NMS.  Every pair the reference could evaluate is evaluated once (Clipper-exact sweep, decisions per
+// pair), then the greedy order is replayed by one workgroup in index order -- exactly the reference's outer loop.
+namespace {
+__global__ void __launch_bounds__(256) k_old_build(const int* __restrict__ polys, int N, int R, int* __restrict__ vx, int* __restrict__ vy,
+                                                   int4* __restrict__ bbox, float* __restrict__ area, int* __restrict__ gmax) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int* py = polys + (size_t)i * 2 * R;
+  const int* px = py + R;
+  int x1 = 0, x2 = 0, y1 = 0, y2 = 0;
+  float a = 0.f;
+  for (int k = 0; k < R; ++k) {
+    const int y = py[k], x = px[k];
+    if (k == 0) { x1 = x2 = x; y1 = y2 = y; }
+    else { x1 = x < x1 ? x : x1; x2 = x > x2 ? x : x2; y1 = y < y1 ? y : y1; y2 = y > y2 ? y : y2; }   // :229-239
+    vx[(size_t)i * R + k] = x; vy[(size_t)i * R + k] = y;
+    const int kn = (k + 1 == R) ? 0 : k + 1;
+    a += (float)((i64)x * py[kn] - (i64)y * px[kn]);                       // area_from_path :128-138
+  }
+  area[i] = (float)(0.5 * (double)fabsf(a));
+  bbox[i] = make_int4(x1, x2, y1, y2);
+  atomicMax(&gmax[0], x2 - x1); atomicMax(&gmax[1], y2 - y1);            // :242-253
+}
+struct OldSearch { int max_bbox_search, grid_y, grid_x, height, width; };
+// wave per polygon i; MODE 0 counts the pairs (i, j) the reference would test, MODE 1 writes them
+template <int MODE>
+__global__ void __launch_bounds__(256) k_old_pairs(int N, OldSearch o, const int* __restrict__ mapping, const int4* __restrict__ bbox,
+                                                   const int* __restrict__ gmax, int* __restrict__ cnt, const i64* __restrict__ start,
+                                                   int2* __restrict__ pairs) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const int4 bi = bbox[i];
+  const i64 base = MODE ? start[i] : 0;
+  int n = 0;
+  auto visit = [&](bool in, int j) {
+    const bool hit = in && j > i && j < N && bbox_intersect(bi, bbox[j]);   // :305-311 (j <= i: higher score or no candidate)
+    const unsigned long long m = __ballot(hit);
+    if (MODE && hit) pairs[base + n + __popcll(m & ((1ull << lane) - 1))] = make_int2(i, j);
+    n += __popcll(m);
+  };
+  if (o.max_bbox_search) {
+    const int mx = gmax[0], my = gmax[1];
+    const int xs = max((bi.x - mx) / o.grid_x, 0), xe = min((bi.y + mx) / o.grid_x, o.width);       // :285-288 (C division, exclusive end)
+    const int ys = max((bi.z - my) / o.grid_y, 0), ye = min((bi.w + my) / o.grid_y, o.height);
+    const int w = xe - xs, h = ye - ys;
+    if (w > 0 && h > 0) {
+      const i64 tot = (i64)w * h;
+      for (i64 t = 0; t < tot; t += 64) {
+        const i64 q = t + lane;
+        const bool in = q < tot;
+        int j = -1;
+        if (in) { const int jj = ys + (int)(q / w), ii = xs + (int)(q % w); j = mapping[(size_t)jj * o.width + ii]; }
+        visit(in, j);
+      }
+    }
+  } else {
+    for (int t = i + 1; t < N; t += 64) visit(t + lane < N, t + lane);   // :337
+  }
+  if (!MODE && lane == 0) cnt[i] = n;
+}
+// the reference's outer loop (:273-323): i ascending; an unsuppressed i suppresses the j of its pairs with overlap > threshold
+__global__ void __launch_bounds__(1024) k_old_replay(int N, const i64* __restrict__ start, const int2* __restrict__ pairs,
+                                                     const unsigned char* __restrict__ supp, volatile unsigned char* state) {
+  for (int i = 0; i < N; ++i) {
+    const i64 beg = start[i], end = start[i + 1];
+    if (beg == end) continue;
+    if (state[i] != ST_SUPPRESSED)
+      for (i64 t = beg + threadIdx.x; t < end; t += blockDim.x) if (supp[t]) state[pairs[t].y] = ST_SUPPRESSED;
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+}  // namespace
+
+extern "C" int sd_nms2d_old_device(const int32_t* d_polys, int n_polys, int n_rays, const int32_t* d_mapping, int height, int width,
+                                   float threshold, int max_bbox_search, int grid_y, int grid_x, int verbose, uint8_t* d_keep,
+                                   void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  const int N = n_polys, R = n_rays;
+  if (N <= 0) return 0;
+  if (R < 1 || R > 256) { sd::set_error("sd_nms2d_old: n_rays=%d unsupported (1..256)", R); return -1; }
+  if (max_bbox_search && (!d_mapping || height <= 0 || width <= 0 || grid_y <= 0 || grid_x <= 0)) {
+    sd::set_error("sd_nms2d_old: max_bbox_search needs a (height, width) mapping and positive grid steps"); return -1;
+  }
+  if (verbose) {
+    printf("Non Maximum Suppression (2D) ++++ \n");
+    printf("NMS: n_polys  = %d \nNMS: n_rays   = %d  \nNMS: thresh   = %.3f \nNMS: max_bbox_search = %d \n", N, R, threshold, max_bbox_search);
+    printf("NMS: using HIP (gfx950), every candidate pair by the scan-beam pair kernel, greedy order replayed on the device\n");
+  }
+  sd::Arena& A = sd::arena();
+  if (A.begin(s)) return -1;
+  int* vx = A.take_n<int>((size_t)N * R);
+  int* vy = A.take_n<int>((size_t)N * R);
+  int4* bbox = A.take_n<int4>(N);
+  float* area = A.take_n<float>(N);
+  int* gmax = A.take_n<int>(2);
+  unsigned char* state = A.take_n<unsigned char>(N);
+  int* cnt = A.take_n<int>(N + 1);
+  i64* start = A.take_n<i64>(N + 1);
+  Counters* d_cnt = (Counters*)A.take(sizeof(Counters));
+  if (!vx || !vy || !bbox || !area || !gmax || !state || !cnt || !start || !d_cnt) return -1;
+  SD_CHECK(hipMemsetAsync(gmax, 0, 2 * sizeof(int), s));
+  SD_CHECK(hipMemsetAsync(state, 0, N, s));
+  SD_CHECK(hipMemsetAsync(cnt, 0, (N + 1) * sizeof(int), s));
+  SD_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), s));
+  hipLaunchKernelGGL(k_old_build, dim3(sd::div_up(N, 256)), dim3(256), 0, s, d_polys, N, R, vx, vy, bbox, area, gmax);
+  SD_LAUNCH_CHECK();
+  const OldSearch o{max_bbox_search, grid_y, grid_x, height, width};
+  hipLaunchKernelGGL((k_old_pairs<0>), dim3(sd::div_up(N, 4)), dim3(256), 0, s, N, o, d_mapping, bbox, gmax, cnt, (const i64*)nullptr, (int2*)nullptr);
+  SD_LAUNCH_CHECK();
+  size_t tmpBytes = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, cnt, start, N + 1, s);
+  void* scanTmp = A.take(tmpBytes + 256);
+  if (!scanTmp) return -1;
+  SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tmpBytes, cnt, start, N + 1, s));
+  i64 total = 0;
+  SD_CHECK(hipMemcpyAsync(&total, start + N, sizeof(i64), hipMemcpyDeviceToHost, s));
+  SD_CHECK(hipStreamSynchronize(s));
+  if (total < 0 || total >= (i64)(1ll << 30)) {
+    sd::set_error("sd_nms2d_old: %lld candidate pairs exceed the capacity of one call (2^30)", (long long)total); return -1;
+  }
+  if (total > 0) {
+    const unsigned int qCap = (unsigned int)total + 64u;
+    int2* pairs = A.take_n<int2>((size_t)total + 64);
+    unsigned char* supp = A.take_n<unsigned char>((size_t)total + 64);
+    unsigned int* spillPairs = A.take_n<unsigned int>(qCap);
+    unsigned int* exactPairs = A.take_n<unsigned int>(qCap);
+    size_t prepStride;
+    if (R <= 32) prepStride = sizeof(sdclip::PolyPrep<32>); else if (R <= 64) prepStride = sizeof(sdclip::PolyPrep<64>);
+    else if (R <= 128) prepStride = sizeof(sdclip::PolyPrep<128>); else prepStride = sizeof(sdclip::PolyPrep<256>);
+    void* prep = A.take((size_t)N * prepStride);
+    if (!pairs || !supp || !spillPairs || !exactPairs || !prep) return -1;
+    SD_CHECK(hipMemsetAsync(supp, 0, (size_t)total + 64, s));
+    hipLaunchKernelGGL((k_old_pairs<1>), dim3(sd::div_up(N, 4)), dim3(256), 0, s, N, o, d_mapping, bbox, gmax, cnt, (const i64*)start, pairs);
+    SD_LAUNCH_CHECK();
+    const unsigned long long nP = (unsigned long long)total;
+    SD_CHECK(hipMemcpyAsync(&d_cnt->nPairs, &nP, sizeof(nP), hipMemcpyHostToDevice, s));
+    PairQueues q1{spillPairs, &d_cnt->nSpill, exactPairs, &d_cnt->nExact, qCap};
+    PairQueues q2{exactPairs, &d_cnt->nExact, exactPairs, &d_cnt->nExact, qCap};
+    int rc;
+    const unsigned int* none = nullptr;
+    if (R <= 32) {
+      rc = BeamPath<32, 64>::prepare(vx, vy, N, R, prep, s);
+      if (!rc) rc = BeamPath<32, 64>::tier1(pairs, none, &d_cnt->nPairs, none, prep, area, threshold, state, supp, q1, s);
+      if (!rc) rc = BeamPath<32, 64>::tier2(pairs, spillPairs, &d_cnt->nSpill, none, prep, area, threshold, state, supp, q2, s);
+    } else if (R <= 64) {
+      rc = BeamPath<64, 64>::prepare(vx, vy, N, R, prep, s);
+      if (!rc) rc = BeamPath<64, 64>::tier2(pairs, none, &d_cnt->nPairs, none, prep, area, threshold, state, supp, q2, s);
+    } else if (R <= 128) {
+      rc = BeamPath<128, 32>::prepare(vx, vy, N, R, prep, s);
+      if (!rc) rc = BeamPath<128, 32>::tier2(pairs, none, &d_cnt->nPairs, none, prep, area, threshold, state, supp, q2, s);
+    } else {
+      rc = BeamPath<256, 16>::prepare(vx, vy, N, R, prep, s);
+      if (!rc) rc = BeamPath<256, 16>::tier2(pairs, none, &d_cnt->nPairs, none, prep, area, threshold, state, supp, q2, s);
+    }
+    if (rc) return -1;
+    if (sd::clip_full_pairs(pairs, exactPairs, &d_cnt->nExact, qCap, R, vx, vy, area, threshold, state, supp, &d_cnt->nErr, s)) return -1;
+    hipLaunchKernelGGL(k_old_replay, dim3(1), dim3(1024), 0, s, N, (const i64*)start, (const int2*)pairs, (const unsigned char*)supp, state);
+    SD_LAUNCH_CHECK();
+    Counters h;
+    SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    SD_CHECK(hipStreamSynchronize(s));
+    if (h.nSpill > qCap || h.nExact > qCap) { sd::set_error("sd_nms2d_old: pair queue overflow (internal error)"); return -1; }
+    if (h.nErr) { sd::set_error("sd_nms2d_old: %u pairs exceeded the general path's fixed capacities", h.nErr); return -1; }
+  }
+  hipLaunchKernelGGL(k_keep, dim3(sd::div_up(N, 256)), dim3(256), 0, s, state, d_keep, N);
+  SD_LAUNCH_CHECK();
+  SD_CHECK(hipStreamSynchronize(s));
+  if (verbose) { printf("NMS: %lld candidate pairs evaluated\n", (long long)total); fflush(stdout); }
+  return 0;
+}
+
+extern "C" int sd_nms2d_old_host(const int32_t* polys, int n_polys, int n_rays, const int32_t* mapping, int height, int width,
+                                 float threshold, int max_bbox_search, int grid_y, int grid_x, int verbose, uint8_t* keep) {
+  if (n_polys <= 0) return 0;
+  int32_t *d_polys = nullptr, *d_map = nullptr;
+  uint8_t* d_keep = nullptr;
+  const size_t pb = (size_t)n_polys * 2 * n_rays * sizeof(int32_t), mb = max_bbox_search ? (size_t)height * width * sizeof(int32_t) : 0;
+  SD_CHECK(hipMalloc(&d_polys, pb));
+  if (mb) SD_CHECK(hipMalloc(&d_map, mb));
+  SD_CHECK(hipMalloc(&d_keep, n_polys));
+  int rc = -1;
+  do {
+    if (hipMemcpy(d_polys, polys, pb, hipMemcpyHostToDevice) != hipSuccess) { sd::set_error("H2D failed"); break; }
+    if (mb && hipMemcpy(d_map, mapping, mb, hipMemcpyHostToDevice) != hipSuccess) { sd::set_error("H2D failed"); break; }
+    if (sd_nms2d_old_device(d_polys, n_polys, n_rays, d_map, height, width, threshold, max_bbox_search, grid_y, grid_x, verbose, d_keep, nullptr)) break;
+    if (hipMemcpy(keep, d_keep, n_polys, hipMemcpyDeviceToHost) != hipSuccess) { sd::set_error("D2H failed"); break; }
+    rc = 0;
+  } while (0);
+  (void)hipFree(d_polys); if (d_map) (void)hipFree(d_map); (void)hipFree(d_keep);
+  return rc;
+}
+
 extern "C" int sd_nms2d_host(const float* dist, const float* points, int n_polys, int n_rays, int use_kdtree, int use_bbox,
                              int verbose, float threshold, uint8_t* keep, int64_t* stats) {
   if (n_polys <= 0) return 0;

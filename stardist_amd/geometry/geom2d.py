@@ -23,6 +23,40 @@ def star_dist(a, n_rays=32, grid=(1, 1), mode="hip"):
     return c_star_dist(a.astype(np.uint16, copy=False), np.int32(n_rays), np.int32(grid[0]), np.int32(grid[1]))
 
 
+def _dist_to_coord_old(rhos, grid=(1, 1)):
+    """geom2d.py:88-109: dense polar -> cartesian for one image (3-D) or several (4-D): coord (..., h, w, 2, n_rays) in the dtype of rhos."""
+    grid = _normalize_grid(grid, 2)
+    rhos = np.asarray(rhos)
+    is_single_image = rhos.ndim == 3
+    if is_single_image:
+        rhos = np.expand_dims(rhos, 0)
+    assert rhos.ndim == 4
+    n_images, h, w, n_rays = rhos.shape
+    coord = np.empty((n_images, h, w, 2, n_rays), dtype=rhos.dtype)
+    start = np.indices((h, w))
+    for i in range(2):
+        coord[..., i, :] = grid[i] * np.broadcast_to(start[i].reshape(1, h, w, 1), (n_images, h, w, n_rays))
+    phis = ray_angles(n_rays).reshape(1, 1, 1, n_rays)
+    coord[..., 0, :] += rhos * np.sin(phis)   # row coordinate
+    coord[..., 1, :] += rhos * np.cos(phis)   # col coordinate
+    return coord[0] if is_single_image else coord
+
+
+def _polygons_to_label_old(coord, prob, points, shape=None, thr=-np.inf):
+    """geom2d.py:112-127: paint the polygons of the dense coordinate map at `points` with increasing probability (ids 1, 2, ... in
+    that order); the per-polygon skimage.draw.polygon loop runs as one call of the HIP rasteriser."""
+    coord = np.asarray(coord); prob = np.asarray(prob); points = np.asarray(points)
+    sh = coord.shape[:2] if shape is None else shape
+    if len(points) == 0:
+        return np.zeros(sh, np.int32)
+    pr = prob[points[:, 0], points[:, 1]]
+    ind = np.argsort(pr)
+    points = points[ind]
+    points = points[prob[points[:, 0], points[:, 1]] >= thr]
+    c = np.ascontiguousarray(coord[points[:, 0], points[:, 1]], np.float32)
+    return polygons_to_label_coord(c, sh, labels=np.arange(len(points)))
+
+
 def dist_to_coord(dist, points, scale_dist=(1, 1)):
     """geom2d.py:130-146: polar -> cartesian, coord (n_polys, 2, n_rays) float32."""
     assert dist.ndim == 2 and points.ndim == 2 and len(dist) == len(points) and points.shape[1] == 2 and len(scale_dist) == 2

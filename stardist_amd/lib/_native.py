@@ -34,6 +34,8 @@ SIGNATURES = {
     "sd_get_option": (_i, [ctypes.c_char_p]),
     "sd_nms2d_host": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "sd_nms2d_device": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "sd_nms2d_old_host": (_i, [_vp, _i, _i, _vp, _i, _i, _f, _i, _i, _i, _i, _vp]),
+    "sd_nms2d_old_device": (_i, [_vp, _i, _i, _vp, _i, _i, _f, _i, _i, _i, _i, _vp, _vp]),
     "sd_clip_pairs_device": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "sd_area_bounds_pairs_device": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sd_prepare_polys_device": (_i, [_vp, _vp, _i, _i, _vp, ctypes.c_int64, _vp]),

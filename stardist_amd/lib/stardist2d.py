@@ -36,6 +36,39 @@ def c_non_max_suppression_inds(dist, points, use_kdtree, use_bbox, verbose, thre
     return (keep, stats) if return_stats else keep
 
 
+def c_non_max_suppression_inds_old(polys, mapping, threshold, max_bbox_search, grid_y, grid_x, verbose):
+    """stardist2d.cpp:173-386 ("O!O!fiiii"). polys (n,2,R) int32 (row 0 = y, row 1 = x) sorted by score desc, mapping (H,W) int32
+    (pixel -> polygon id, -1 = none; an empty array without max_bbox_search, nms.py:56-60) -> bool (n,)."""
+    N.require_device()
+    if N.is_torch(polys):
+        import torch
+        assert polys.dtype == torch.int32 and polys.dim() == 3 and polys.shape[1] == 2
+        polys = polys.contiguous()
+        mapping = mapping.to(torch.int32).contiguous()
+        n, _, R = polys.shape
+        H, W = (int(mapping.shape[0]), int(mapping.shape[1])) if mapping.dim() == 2 else (0, 0)
+        keep = torch.empty(n, dtype=torch.uint8, device=polys.device)
+        if n:
+            N.dcall(polys, "sd_nms2d_old_device", N.tptr(polys), n, R, N.tptr(mapping) if mapping.numel() else None, H, W, float(threshold),
+                    int(max_bbox_search), int(grid_y), int(grid_x), int(verbose), N.tptr(keep))
+        return keep.bool()
+    polys = np.ascontiguousarray(polys)
+    mapping = np.ascontiguousarray(mapping)
+    if polys.dtype != np.int32 or mapping.dtype != np.int32:
+        # the reference reads both buffers as int whatever their dtype (PyArray_GETPTR + cast, :227-228, :303); its caller always
+        # passes int32 (nms.py:56-66) -- refuse anything else instead of reinterpreting bytes
+        raise TypeError("polys and mapping must be int32")
+    if polys.ndim != 3 or polys.shape[1] != 2:
+        raise ValueError("polys must be (n, 2, n_rays)")
+    n, _, R = polys.shape
+    H, W = (mapping.shape[0], mapping.shape[1]) if mapping.ndim == 2 else (0, 0)
+    keep = np.zeros(n, np.uint8)
+    if n:
+        N.check(N.lib().sd_nms2d_old_host(N.ptr(polys), n, R, N.ptr(mapping) if mapping.size else None, int(H), int(W), float(threshold),
+                                          int(max_bbox_search), int(grid_y), int(grid_x), int(verbose), N.ptr(keep)))
+    return keep.astype(bool)
+
+
 def c_star_dist(src, n_rays, grid_y, grid_x):
     """stardist2d.cpp:55-124. src (H,W) uint16 -> (ceil(H/gy), ceil(W/gx), n_rays) f32."""
     N.require_device()

@@ -62,6 +62,35 @@ def non_maximum_suppression_inds(dist, points, scores, thresh=0.5, use_bbox=True
     return c_non_max_suppression_inds(d, p, int(use_kdtree), int(use_bbox), int(verbose), np.float32(thresh))
 
 
+def _non_maximum_suppression_old(coord, prob, grid=(1, 1), b=2, nms_thresh=0.5, prob_thresh=0.5, verbose=False, max_bbox_search=True):
+    """stardist/nms.py:20-74: the legacy NMS on dense polygon coordinates (Ny,Nx,2,n_rays) and prob (Ny,Nx); returns the retained
+    grid points (np.nonzero order).  Kept because the reference keeps it as a second statement of the same NMS (tests/test_nms2D.py:78-110)."""
+    from .lib.stardist2d import c_non_max_suppression_inds_old
+    coord = np.asarray(coord); prob = np.asarray(prob)
+    assert prob.ndim == 2
+    assert coord.ndim == 4
+    grid = _normalize_grid(grid, 2)
+    mask = _ind_prob_thresh(prob, prob_thresh, b)
+    polygons = coord[mask]
+    scores = prob[mask]
+    ind = _argsort_desc(scores)
+    survivors = np.zeros(len(ind), bool)
+    polygons = polygons[ind]
+    scores = scores[ind]
+    if max_bbox_search:
+        # pixel -> id of the score-sorted polygon there, -1: no candidate (nms.py:56-58)
+        mapping = -np.ones(mask.shape, np.int32)
+        mapping.flat[np.flatnonzero(mask)[ind]] = range(len(ind))
+    else:
+        mapping = np.empty((0, 0), np.int32)
+    survivors[ind] = c_non_max_suppression_inds_old(np.ascontiguousarray(polygons.astype(np.int32)), mapping, np.float32(nms_thresh),
+                                                    np.int32(max_bbox_search), np.int32(grid[0]), np.int32(grid[1]), np.int32(verbose))
+    if verbose:
+        print("keeping %s/%s polygons" % (np.count_nonzero(survivors), len(polygons)))
+    points = np.stack([ii[survivors] for ii in np.nonzero(mask)], axis=-1)
+    return points
+
+
 def non_maximum_suppression(dist, prob, grid=(1, 1), b=2, nms_thresh=0.5, prob_thresh=0.5,
                             use_bbox=True, use_kdtree=True, verbose=False):
     """stardist/nms.py:77-132: dense (Ny,Nx,n_rays)/(Ny,Nx) maps -> (points, prob, dist) of survivors."""

@@ -62,3 +62,49 @@ def test_degenerate_configurations(refmods):
                 A, K, ok, _, _ = exact_area(pad(xa), pad(ya), pad(xb), pad(yb))
                 C = refmods.clipper_area(pad(xa)[0], pad(ya)[0], pad(xb)[0], pad(yb)[0])
                 assert ok[0] and abs(A[0] - C) < 1e-9, (xa, ya, xb, yb, A[0], C)
+
+
+ADV = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), "oracle", "_ref", "area_band_adversary")
+
+
+def _adv_available():
+    import os
+    return os.path.exists(ADV)
+
+
+@pytest.mark.skipif(not _adv_available(), reason="oracle/_ref/area_band_adversary not built (make -C oracle ref where /root/reference exists)")
+def test_adversary_restatement_equals_numpy_statement():
+    """the adversarial search tool (oracle/area_band_adversary.cpp) evaluates the SAME enclosure as tests/_area_exact.py (which the GPU probe is
+    pinned to): area, crossings K, near pairs T, the band's main term -- on four families incl. a far offset"""
+    import subprocess
+    rng = np.random.RandomState(5)
+    for R, radius, noise, spread in [(32, 10, 0.1, 12), (16, 25, 0.2, 30), (8, 15, 0.2, 15), (24, 100, 0.15, 150)]:
+        n = 200
+        xa, ya = _star_polys(rng, n, R, radius, noise, spread)
+        xb, yb = _star_polys(rng, n, R, radius * 0.85, noise, spread)
+        A, K, ok, _, _ = exact_area(xa, ya, xb, yb)
+        us = ok & plain(xa, ya) & plain(xb, yb)
+        la, _ = edge_stats(xa, ya); lb, _ = edge_stats(xb, yb)
+        T = near_pairs(xa, ya, xb, yb)
+        inp = "\n".join("%d " % R + " ".join("%d %d" % (xa[i, k], ya[i, k]) for k in range(R)) + " " +
+                        " ".join("%d %d" % (xb[i, k], yb[i, k]) for k in range(R)) for i in range(n))
+        out = subprocess.run([ADV, "--eval"], input=inp, capture_output=True, text=True, check=True).stdout
+        o = np.array([[float(v) for v in l.split()] for l in out.split("\n") if l.strip()])
+        m = o[:, 4] == 1
+        assert m.sum() > 0.9 * n and np.all(us[m])
+        assert np.allclose(o[m, 0], A[m], rtol=1e-7, atol=1e-4)
+        assert np.array_equal(o[m, 2], K[m]) and np.array_equal(o[m, 3], T[m])
+        main = (0.5 * K + 0.125 * T) * (la + lb) + 0.75
+        assert np.all(o[m, 1] >= main[m] - 1e-6) and np.all(o[m, 1] <= main[m] * (1 + 2e-6) + 2.0)
+
+
+@pytest.mark.skipif(not _adv_available(), reason="oracle/_ref/area_band_adversary not built")
+def test_adversarial_search_stays_inside_the_band():
+    """a short run of the annealing search (the committed long runs: profiles/r05_area_band_adversary.txt) -- the worst
+    |A_clipper - A| / band it reaches must stay below 0.6"""
+    import re
+    import subprocess
+    out = subprocess.run([ADV, "11", "160", "1500", "2"], capture_output=True, text=True, check=True).stdout
+    m = re.search(r"(\d+) evaluations \((\d+) usable\), worst \|A_clipper - A\| / band = ([0-9.]+)", out)
+    assert m and int(m.group(2)) > 100000
+    assert float(m.group(3)) < 0.6, out[-2000:]

@@ -229,3 +229,59 @@ def test_nms2d_defer_undecided_settings_agree(refmods, shape, R, thr):
         assert np.array_equal(keep, ref_keep), (opt, np.flatnonzero(keep != ref_keep)[:10])
         deferred[opt] = int(stats[10])
     assert deferred[0] == 0
+
+
+@pytest.mark.parametrize("grid", [(1, 1), (2, 2)])
+@pytest.mark.parametrize("shape,R", [((356, 299), 11), ((114, 217), 32)])
+@pytest.mark.parametrize("max_bbox_search", [1, 0])
+def test_nms2d_old_equals_reference_old_and_new(refmods, shape, R, grid, max_bbox_search):
+    """c_non_max_suppression_inds_old (stardist2d.cpp:173-386) through the C ABI: same keep flags as the compiled reference's _old on the
+    seed-42 candidates of the reference's own old == new test (tests/test_nms2D.py:78-110), and -- that test's statement -- the same
+    survivors as the new NMS (grid (1,1), where both see the same integer polygons)"""
+    from oracle import port, synth
+    from stardist_amd.lib import stardist2d as sd2
+    m = refmods.stardist2d()
+    dist, prob = synth.s2d_uniform(shape[0], shape[1], n_rays=R, dense=True)
+    dist, prob = dist[::grid[0], ::grid[1]], prob[::grid[0], ::grid[1]]
+    mask = port.ind_prob_thresh(prob, 0.9, b=2)
+    pts = np.stack(np.where(mask), 1)
+    d, s = dist[mask], prob[mask]
+    ind = np.argsort(s, kind="stable")[::-1]
+    d, s, pts = d[ind], s[ind], pts[ind]
+    coord = port.dist_to_coord(d, pts * np.array(grid))
+    polys = np.ascontiguousarray(coord.astype(np.int32))
+    if max_bbox_search:
+        mapping = -np.ones(mask.shape, np.int32)
+        mapping.flat[np.flatnonzero(mask)[ind]] = range(len(ind))
+    else:
+        mapping = np.empty((0, 0), np.int32)
+    for thr in (0.3, 0.4):
+        ref_old = m.c_non_max_suppression_inds_old(polys, mapping, np.float32(thr), np.int32(max_bbox_search), np.int32(grid[0]),
+                                                   np.int32(grid[1]), np.int32(0))
+        mine = sd2.c_non_max_suppression_inds_old(polys, mapping, np.float32(thr), np.int32(max_bbox_search), np.int32(grid[0]),
+                                                  np.int32(grid[1]), np.int32(0))
+        assert mine.dtype == bool and np.array_equal(mine, ref_old), np.flatnonzero(mine != ref_old)[:10]
+        if grid == (1, 1):
+            new = sd2.c_non_max_suppression_inds(np.ascontiguousarray(d), np.ascontiguousarray(pts.astype(np.float32)), 1, 1, 0, np.float32(thr))
+            assert np.array_equal(new, mine)
+
+
+def test_nms2d_old_python_path_equals_new(refmods):
+    """tests/test_nms2D.py:78-110 replayed on the mirror's own functions: _dist_to_coord_old -> _non_maximum_suppression_old against
+    non_maximum_suppression, points equal and foreground of the two label images equal"""
+    from oracle import synth
+    from stardist_amd.geometry.geom2d import _dist_to_coord_old, _polygons_to_label_old, polygons_to_label
+    from stardist_amd.nms import _non_maximum_suppression_old, non_maximum_suppression
+    for shape, R, grid in (((356, 299), 11, (1, 1)), ((114, 217), 32, (1, 1))):
+        dist, prob = synth.s2d_uniform(shape[0], shape[1], n_rays=R, dense=True)
+        prob, dist = prob[::grid[0], ::grid[1]], dist[::grid[0], ::grid[1]]
+        coord = _dist_to_coord_old(dist, grid=grid)
+        inds1 = _non_maximum_suppression_old(coord, prob, prob_thresh=0.9, grid=grid, nms_thresh=0.3)
+        points1 = inds1 * np.array(grid)
+        points1 = points1[np.argsort(prob[tuple(inds1.T)], kind="stable")[::-1]]
+        points2, probi2, disti2 = non_maximum_suppression(dist, prob, grid=grid, prob_thresh=0.9, nms_thresh=0.3)
+        img1 = _polygons_to_label_old(coord, prob, inds1, shape=shape)
+        img2 = polygons_to_label(disti2, points2, shape=shape)
+        assert len(points1) == len(points2)
+        assert np.allclose(points1, points2)
+        assert np.allclose(img1 > 0, img2 > 0)
