@@ -266,6 +266,33 @@ def run_leg(model, img, steps, warmup, world, dist_):
     return elapsed, net_ms, res, stats
 
 
+def run_host_legs(model, x_np, steps):
+    """SURVEY.md 8d's definition of the metric -- host array in, (labels, dict) out: `steps` predict_instances on the host array, (a)
+    through predict_instances_iter (models/base.py: the upload of input k + 1 overlaps step k -- helper thread, page-locked staging,
+    copy stream), (b) as a plain loop of predict_instances(host array) calls (each step waits for its own upload first)."""
+    import torch
+    for _ in model.predict_instances_iter([x_np, x_np]):        # warm-up of the staging path
+        pass
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in model.predict_instances_iter(x_np for _ in range(steps)):
+        pass
+    torch.cuda.synchronize(); piped = time.perf_counter() - t0
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        model.predict_instances(x_np)
+    torch.cuda.synchronize(); serial = time.perf_counter() - t0
+    return piped, serial
+
+
+def host_leg_dict(n, steps, piped, serial, unit, ms_device):
+    return {"value": round(n * steps / piped / 1e6, 3), "unit": unit, "ms_per_step": round(1e3 * piped / steps, 3),
+            "gap_to_device_resident_input": round(1e3 * piped / steps / ms_device - 1.0, 4),
+            "serial_loop": {"value": round(n * steps / serial / 1e6, 3), "ms_per_step": round(1e3 * serial / steps, 3)},
+            "note": "SURVEY.md 8d's definition: the same steps with the input handed over as a HOST numpy array, (labels, dict) back on the host; "
+                    "predict_instances_iter overlaps the upload of input k + 1 with step k (`serial_loop`: plain predict_instances(host array) "
+                    "calls, upload in front of every step); this rank only"}
+
+
 def run_mode_leg(model, img, steps, warmup, world, dist_, mode):
     """The same steps with another form of the 3x3 convolutions (models/unet.py conv_mode): 'hand' = the exact-f32 MFMA kernel
     (csrc/conv3x3.hip, one f32 fma chain per output), 'bf16x6' = six bf16 products per f32 product (csrc/conv3x3_bf16.hip, the round-3
@@ -451,10 +478,18 @@ def main():
     # second number (SURVEY.md 8d defines the metric host-array-in): the same steps with the image handed over as a host numpy array,
     # i.e. including the 16.8 MB H2D copy (staged through page-locked memory, stardist_amd/utils.py to_device); `value` stays the
     # HBM-resident figure the bench contract asks for
-    torch.cuda.synchronize(); t0h = time.perf_counter()
-    for _ in range(args.steps):
-        model.predict_instances(img_np)
-    torch.cuda.synchronize(); elapsed_host = time.perf_counter() - t0h
+    elapsed_host, elapsed_host_serial = run_host_legs(model, img_np, args.steps)
+    # the bit-exact-by-construction mode (sd_set_option("nms2d_strict", 1): every pair through the Clipper-exact sweep, no decision from the
+    # area enclosure): same steps, and the instances must be the very same
+    from stardist_amd.lib import _native as _nat
+    strict_steps = max(1, min(args.steps, 10))
+    with _nat.option("nms2d_strict", 1):
+        el_s, _, res_s, _ = run_leg(model, img, strict_steps, 1, world, dist_)
+    strict_leg = {"value": round(world * H * W * strict_steps / el_s / 1e6, 3), "unit": "Mpix/s", "ms_per_step": round(1e3 * el_s / strict_steps, 3),
+                  "instances": len(res_s[1]["prob"]),
+                  "same_result_as_default": bool(np.array_equal(res_s[0], res[0]) and np.array_equal(res_s[1]["points"], res[1]["points"])),
+                  "note": "sd_set_option('nms2d_strict', 1): every 2D pair decided by the Clipper-exact sweep (bit-exact by construction); the default decides "
+                          "pairs far from the threshold from an empirically / adversarially validated band around the exact area (DESIGN.md 3.4)"}
     out = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -531,8 +566,8 @@ def main():
                        "candidates": n_cand, "survivors": len(res[1]["prob"]), "prob_thresh": model.thresholds.prob,
                        "nms_thresh": model.thresholds.nms, "parallelism": "tiles-per-gpu x%d" % world},
             "stages_ms": stages, "roofline": dominant, "roofline_convs": roof_conv, "roofline_pair_kernel": roof_pair,
-            "value_host_input": {"value": round(H * W * args.steps / elapsed_host / 1e6, 3), "unit": "Mpix/s", "ms_per_step": round(1e3 * elapsed_host / args.steps, 3),
-                                 "note": "same steps with the image passed as a host numpy array (H2D of the input inside the timed region), this rank only"},
+            "nms2d_strict": strict_leg,
+            "value_host_input": host_leg_dict(H * W, args.steps, elapsed_host, elapsed_host_serial, "Mpix/s", ms_per_step),
         }
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N=1 only
             try:
@@ -585,6 +620,7 @@ def main():
         macs3 = conv_macs_per_input_pixel(m3.net, m3.config)
         steps3 = max(1, min(args.steps, 5))
         elapsed3, net3_ms, res3, st3 = run_leg(m3, vol, steps3, 2, world, dist_)
+        eh3, eh3s = run_host_legs(m3, vol_np, steps3)
         if rank == 0:
             s3 = st3.get("nms3d", np.zeros(16, np.int64)) / steps3
             ms3 = 1e3 * elapsed3 / steps3
@@ -594,6 +630,7 @@ def main():
                                        "the same step from a host numpy array in to (labels, dict) out, SURVEY.md 8d's definition")
             out["value_3d"] = round(world * S ** 3 * steps3 / elapsed3 / 1e6, 3)
             out["unit_3d"] = "Mvox/s"
+            out["value_host_input_3d"] = host_leg_dict(S ** 3, steps3, eh3, eh3s, "Mvox/s", ms3)
             out["ms_per_step_3d"] = round(ms3, 3)
             out["config_3d"] = {"workload": "StarDist3D Rays_GoldenSpiral(96) U-Net (depth 2), %d^3 synthetic volume per GPU, predict_instances "
                                             "(U-Net + select + 3D NMS cascade + polyhedron raster + relabel)" % S,

@@ -46,6 +46,9 @@ int sd_release_workspace(void);           /* free the cached device workspace   
  *   "nms2d_defer_undecided" r|0  (with "nms2d_area_bounds") from greedy round r on (default 2), a round that leaves at most 16 384 pairs undecided
  *                              does not sweep them itself: they are swept by the tail batch's one launch (a sweep launch costs one sweep's
  *                              latency however few pairs it holds) / 0: every round sweeps its own
+ *   "nms2d_strict"        0|1  1 = bit-exact BY CONSTRUCTION: every 2D pair runs the Clipper-exact sweep (overrides "nms2d_area_bounds"); the
+ *                              default decides the pairs far from the threshold from an enclosure of Clipper's area whose band is validated
+ *                              empirically and adversarially, not proven
  *   "probe_tier"          1|2  capacity tier sd_clip_pairs_device runs first;  "probe_no_general" 1: do not fall back to the general path
  *   "trace"               1    print per-round counters to stdout
  * Nothing in the library reads the process environment.  sd_get_option returns -1 for an unknown name. */
@@ -212,6 +215,14 @@ int sd_select_candidates_device(const float* d_prob, const float* d_dist, int nd
                                 const int* shape, const int* b, int n_rays, float thresh,
                                 int cap, float* d_out_prob, float* d_out_dist,
                                 int32_t* d_out_points, int32_t* d_count, void* stream);
+
+/* Candidates in score order (the argsort of stardist/nms.py:167 applied to the selection above): d_points (n_sel, ndim) int32 grid indices as
+ * written by sd_select_candidates_device, d_order (n,) int64 = index of the k-th best candidate (NULL: identity).  Writes, per k:
+ * d_rows[k] = C-order linear index of (point + origin) in the grid `full_shape` (the row of the channels-last feature matrix the
+ * distance head is evaluated on, sd_head_rows_device), d_points_f32[k] / d_points_i64[k] = point * grid (pixel coordinates: float32 as the
+ * NMS natives take them, int64 as the result dict returns them).  Any output pointer may be NULL. */
+int sd_sorted_rows_device(const int32_t* d_points, const int64_t* d_order, int n, int ndim, const int* full_shape, const int* origin,
+                          const int* grid, int64_t* d_rows, float* d_points_f32, int64_t* d_points_i64, void* stream);
 
 /* ---- reference-style C ABI for the natives that have none in the reference --------------------
  * (stardist/lib/stardist3d_lib.h:52-79 covers only the two 3D functions above).  Same conventions: host pointers, caller

@@ -835,7 +835,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   SD_CHECK(hipStreamWaitEvent(side, evFork, 0));
   // polygon properties of the decision shortcut (area_bounds.h) first: they also depend on the integer vertices only, and the
   // decision kernel of the first round needs them before any sweep needs a prepared polygon (evProps / evPrep)
-  const bool areaBounds = R <= 32 && R >= 3 && sd::option(sd::OPT_NMS2D_AREA_BOUNDS) != 0;
+  const bool areaBounds = R <= 32 && R >= 3 && sd::option(sd::OPT_NMS2D_AREA_BOUNDS) != 0 && sd::option(sd::OPT_NMS2D_STRICT) == 0;
   sdarea::PolyProps* props = nullptr;
   hipEvent_t evProps = nullptr, evPrep = nullptr;
   SD_CHECK(hipEventCreateWithFlags(&evProps, hipEventDisableTiming));
@@ -985,7 +985,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   bool sideGeneral = false;                   // tail batch: the deferred pairs' general-path launch runs on the helper stream
   unsigned int* nNewExact = A.take_n<unsigned int>(1);
   if (!nNewExact) return -1;
-  // deferral of the enclosure's undecided pairs (see k_defer_undecided): off by default
+  // deferral of the enclosure's undecided pairs (see k_defer_undecided): from round 2 on by default (option nms2d_defer_undecided)
   const int deferFrom = (deferOn && decided) ? sd::option(sd::OPT_NMS2D_DEFER_UNDECIDED) : 0;
   unsigned char* defKind = nullptr; unsigned int* nJoinDef = nullptr;
   if (deferFrom > 0) {

@@ -88,7 +88,40 @@ __global__ void __launch_bounds__(BLOCK) k_write(const float* __restrict__ prob,
   }
 }
 
+// candidates in SCORE order: order[k] = index (into the selection's np.where-ordered list) of the k-th best candidate.  One pass writes
+// what the stages behind the sort read -- the row of the feature matrix (distance head on the candidate rows, sd_head_rows_device), the
+// pixel coordinates as float32 (what the NMS natives take, nms.py:217-218) and as int64 (what the result dict returns, base.py:606) --
+// instead of a dozen framework index / multiply / cast launches on (n, ndim) arrays.
+struct RowP { int ndim; int full[3], origin[3], grid[3]; };
+__global__ void __launch_bounds__(256) k_sorted_rows(const int* __restrict__ pts, const long long* __restrict__ order, int n, RowP p,
+                                                     long long* __restrict__ rows, float* __restrict__ pf, long long* __restrict__ pi) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const long long src = order ? order[k] : k;
+  long long row = 0;
+  for (int d = 0; d < p.ndim; ++d) {
+    const int c = pts[src * p.ndim + d];
+    row = row * p.full[d] + (c + p.origin[d]);
+    const long long pix = (long long)c * p.grid[d];
+    if (pf) pf[(size_t)k * p.ndim + d] = (float)pix;
+    if (pi) pi[(size_t)k * p.ndim + d] = pix;
+  }
+  if (rows) rows[k] = row;
+}
+
 }  // namespace
+
+extern "C" int sd_sorted_rows_device(const int32_t* d_points, const int64_t* d_order, int n, int ndim, const int* full_shape, const int* origin,
+                                     const int* grid, int64_t* d_rows, float* d_points_f32, int64_t* d_points_i64, void* stream) {
+  if (n <= 0) return 0;
+  if (ndim < 1 || ndim > 3) { sd::set_error("sd_sorted_rows: ndim must be 1..3"); return -1; }
+  RowP p; p.ndim = ndim;
+  for (int d = 0; d < 3; ++d) { p.full[d] = d < ndim ? full_shape[d] : 1; p.origin[d] = d < ndim && origin ? origin[d] : 0; p.grid[d] = d < ndim && grid ? grid[d] : 1; }
+  hipLaunchKernelGGL(k_sorted_rows, dim3(sd::div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, (const int*)d_points, (const long long*)d_order, n, p,
+                     (long long*)d_rows, d_points_f32, (long long*)d_points_i64);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int sd_select_candidates_device(const float* d_prob, const float* d_dist, int ndim, const int* shape, const int* b,
                                            int n_rays, float thresh, int cap, float* d_out_prob, float* d_out_dist,

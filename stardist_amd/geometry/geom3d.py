@@ -53,15 +53,16 @@ def polyhedron_to_label(dist, points, rays, shape, prob=None, thr=-np.inf, label
         if dist.shape[1] != len(rays): raise ValueError("inconsistent number of rays!")
         if len(prob) != len(points): raise ValueError("len(prob) != len(points)")
         if len(labels) != len(points): raise ValueError("len(labels) != len(points)")
-        ind = torch.where(prob >= thr)[0]
-        if len(ind) == 0:
-            if verbose: print("warning: no points found with probability>= {thr:.4f} (returning background-only image)".format(thr=thr))
-            return _empty()
-        prob, points, dist, labels = prob[ind], points[ind], dist[ind], labels[ind]
+        if thr != -np.inf:                                          # (prob >= -inf holds for every score: no compaction, no read-back)
+            ind = torch.where(prob >= thr)[0]
+            if len(ind) == 0:
+                if verbose: print("warning: no points found with probability>= {thr:.4f} (returning background-only image)".format(thr=thr))
+                return _empty()
+            prob, points, dist, labels = prob[ind], points[ind], dist[ind], labels[ind]
         ind = torch.flip(torch.sort(prob, stable=True)[1], dims=(0,))
-        points, dist, labels = points[ind], dist[ind], labels[ind]
-        verts = torch.as_tensor(np.ascontiguousarray(rays.vertices, np.float32), device=dev)
-        faces = torch.as_tensor(np.ascontiguousarray(rays.faces, np.int32), device=dev)
+        points, dist, labels = points.index_select(0, ind), dist.index_select(0, ind), labels.index_select(0, ind)
+        from ..rays3d import rays_device_tensors
+        verts, faces = rays_device_tensors(rays, dev)
         if window is not None:                                     # polyhedra whose bounding box misses the window are dropped up front
             o = torch.tensor(window[0], device=dev, dtype=torch.float32); e = o + torch.tensor(window[1], device=dev, dtype=torch.float32)
             reach = dist.float().amax(dim=1, keepdim=True) * verts.abs().amax(dim=0, keepdim=True) + 2.0

@@ -5,12 +5,23 @@ import numpy as np
 from .lib import _native as N
 
 
-def relabel_sequential(label_field, offset=1):
+def relabel_sequential(label_field, offset=1, _known_max=None):
     """matching.py:319-408: relabel arbitrary labels to {offset, ..., offset+n_labels-1}; 0 stays background.
-    Returns (relabeled, forward_map, inverse_map)."""
+    Returns (relabeled, forward_map, inverse_map).
+    _known_max (device tensors, internal): the caller guarantees 0 <= labels <= _known_max (the rasteriser's output for M polyhedra
+    without an overlap label); the relabelled volume is then computed without any read-back and the maps are returned as None."""
     offset = int(offset)
     if offset <= 0:
         raise ValueError("Offset must be strictly positive.")
+    if N.is_torch(label_field) and _known_max is not None:
+        import torch
+        li = label_field.reshape(-1).long()
+        present = torch.zeros(int(_known_max) + 1, dtype=torch.bool, device=label_field.device)
+        present[li] = True
+        present[0] = False
+        fwd = torch.cumsum(present, 0, dtype=label_field.dtype) + (offset - 1)
+        fwd = torch.where(present, fwd, torch.zeros_like(fwd))
+        return fwd[li].reshape(label_field.shape), None, None
     if N.is_torch(label_field):
         import torch
         if int(label_field.min()) < 0:

@@ -84,6 +84,16 @@ class StarDistPadAndCropResizer(object):
         return np.where(np.all(points < np.array(bounds), 1))[0]
 
 
+class SortedCandidates(object):
+    """candidates of one (untiled) prediction in SCORE order (descending, `np.argsort(prob)[::-1]` of stardist/nms.py:167 already applied),
+    all on the device: prob (n,), dist (n, R), points (n, nd) int64 pixel coordinates, points_f32 the same as float32 (what the NMS
+    natives take).  What _predict_instances_generator hands from the selection straight to the NMS natives."""
+    __slots__ = ("prob", "dist", "points", "points_f32")
+
+    def __init__(self, prob, dist, points, points_f32):
+        self.prob, self.dist, self.points, self.points_f32 = prob, dist, points, points_f32
+
+
 class StarDistBase(object):
 
     def __init__(self, config, name=None, basedir=".", device=None, seed=0, compute_dtype="float32"):
@@ -531,16 +541,15 @@ class StarDistBase(object):
                 return oprob[:n], odist[:n], opts[:n].to(torch.int64)
             cap = n
 
-    def _select_rows(self, prob, feat, origin, prob_thresh, bs):
-        """_select for the sparse head: threshold + border + ordered compaction on `prob` (a crop, starting at `origin`, of the
-        grid the channels-last feature tensor `feat` (..., C) lives on), then the distance head on the selected rows of feat."""
+    def _select_raw(self, prob, prob_thresh, shape, b):
+        """threshold + border + ordered compaction of `prob` alone (select.hip): (n, prob (cap,), grid indices (cap, nd) int32), the first n
+        entries valid, in np.where order.  The capacity of the first pass is the previous call's count for this grid size + 25 % (a
+        step of a stream of similar images never runs the second pass; the first guess is numel / 64)."""
         import torch
-        prob = prob.contiguous()
         nd = prob.dim()
-        shape = np.asarray(prob.shape, np.int32)
-        b = np.asarray([v for pair in bs for v in pair], np.int32)
+        hints = self.__dict__.setdefault("_sel_cap_hint", {})
+        cap = hints.get(int(prob.numel()), max(1024, int(prob.numel() // 64)))
         cnt = torch.zeros(1, dtype=torch.int32, device=prob.device)
-        cap = max(1024, int(prob.numel() // 64))
         while True:
             oprob = torch.empty(cap, dtype=torch.float32, device=prob.device)
             opts = torch.empty((cap, nd), dtype=torch.int32, device=prob.device)
@@ -550,6 +559,41 @@ class StarDistBase(object):
             if n <= cap:
                 break
             cap = n
+        hints[int(prob.numel())] = max(1024, n + n // 4)
+        return n, oprob, opts
+
+    def _select_sorted(self, prob, feat, prob_thresh, bs):
+        """selection -> score order -> distance head, for the step that goes on to the NMS: candidates of `prob` (the whole grid the
+        channels-last feature tensor `feat` lives on) above the threshold, sorted by score (stable ascending, reversed: nms.py:167 as
+        _argsort_desc states it), with the distance head evaluated on the candidate rows IN THAT ORDER -- the (n, R) distance matrix and
+        the point arrays are written once, sorted, instead of being written in np.where order and gathered again behind the sort."""
+        import torch
+        prob = prob.contiguous()
+        nd = prob.dim()
+        shape = np.asarray(prob.shape, np.int32)
+        b = np.asarray([v for pair in bs for v in pair], np.int32)
+        n, oprob, opts = self._select_raw(prob, prob_thresh, shape, b)
+        sp, order = torch.sort(oprob[:n], stable=True)
+        sp, order = torch.flip(sp, dims=(0,)), torch.flip(order, dims=(0,))
+        rows = torch.empty(n, dtype=torch.int64, device=prob.device)
+        pf = torch.empty((n, nd), dtype=torch.float32, device=prob.device)
+        pi = torch.empty((n, nd), dtype=torch.int64, device=prob.device)
+        if n:
+            full = np.asarray(feat.shape[:-1], np.int32)
+            grid = np.asarray(self.config.grid, np.int32)
+            N.dcall(prob, "sd_sorted_rows_device", N.tptr(opts), N.tptr(order), n, nd, N.ptr(full), None, N.ptr(grid), N.tptr(rows), N.tptr(pf), N.tptr(pi))
+        dist = self.net.dist_rows(feat, rows, 1e-3)           # max(dist, 1e-3): base.py:512-513 / select.hip
+        return SortedCandidates(sp, dist, pi, pf)
+
+    def _select_rows(self, prob, feat, origin, prob_thresh, bs):
+        """_select for the sparse head: threshold + border + ordered compaction on `prob` (a crop, starting at `origin`, of the
+        grid the channels-last feature tensor `feat` (..., C) lives on), then the distance head on the selected rows of feat."""
+        import torch
+        prob = prob.contiguous()
+        nd = prob.dim()
+        shape = np.asarray(prob.shape, np.int32)
+        b = np.asarray([v for pair in bs for v in pair], np.int32)
+        n, oprob, opts = self._select_raw(prob, prob_thresh, shape, b)
         pts = opts[:n].to(torch.int64)
         full = feat.shape[:-1]
         rows = torch.zeros(n, dtype=torch.int64, device=prob.device)
@@ -559,7 +603,7 @@ class StarDistBase(object):
         return oprob[:n], odist, pts
 
     def _predict_sparse_generator(self, img, prob_thresh=None, axes=None, normalizer=None, n_tiles=None,
-                                  show_tile_progress=True, b=2, **predict_kwargs):
+                                  show_tile_progress=True, b=2, _presort=False, **predict_kwargs):
         import torch
         if prob_thresh is None: prob_thresh = self.thresholds.prob
         x, axes, axes_net, axes_net_div_by, resizer, n_tiles, grid, grid_dict, channel = self._predict_setup(img, axes, normalizer, n_tiles)
@@ -591,6 +635,12 @@ class StarDistBase(object):
             if self._is_multiclass(): prob_classa = torch.cat(pcl)
         else:
             res = self._net_forward(x, sparse_head=True)
+            if (_presort and self._head_mode == "sparse" and not self._is_multiclass()
+                    and not any(p[1] for p in resizer.pad.values())):
+                # predict_instances, untiled, nothing padded (filter_points keeps every point): hand the candidates over in score order
+                bs = [(b, b)] * self.config.n_dim if np.isscalar(b) else list(b)
+                yield self._select_sorted(res[0][..., 0], res[1], prob_thresh, bs)
+                return
             yield self._sparse_finish(res, self._head_mode, x, resizer, axes_net, prob_thresh, b)
             return
         idx = resizer.filter_points(x.dim(), pointsa, axes_net)
@@ -667,9 +717,16 @@ class StarDistBase(object):
         res = None
         if sparse:
             for res in self._predict_sparse_generator(img, axes=axes, normalizer=normalizer, n_tiles=n_tiles,
-                                                      prob_thresh=prob_thresh, show_tile_progress=show_tile_progress, **predict_kwargs):
+                                                      prob_thresh=prob_thresh, show_tile_progress=show_tile_progress,
+                                                      _presort=(self.device.type == "cuda"), **predict_kwargs):
                 if res is None:
                     yield "tile"
+            if isinstance(res, SortedCandidates):
+                yield "nms"
+                yield self._instances_from_sorted(_shape_inst, res, nms_thresh=nms_thresh,
+                                                  scale=(None if scale is None else dict(zip(_axes, scale))),
+                                                  return_labels=return_labels, overlap_label=overlap_label, **nms_kwargs)
+                return
         else:
             for res in self._predict_generator(img, axes=axes, normalizer=normalizer, n_tiles=n_tiles,
                                                show_tile_progress=show_tile_progress, **predict_kwargs):
@@ -704,6 +761,90 @@ class StarDistBase(object):
         (SURVEY.md 8e design A); see stardist_amd/big.py::predict_instances_sharded."""
         from ..big import predict_instances_sharded
         return predict_instances_sharded(self, img, axes, block_size, min_overlap, context=context, **kwargs)
+
+    def predict_instances_iter(self, imgs, prefetch=1, **kwargs):
+        """predict_instances over a sequence of HOST arrays, yielding (labels, dict) per image in order, with the upload of image k + 1
+        overlapped with the step on image k (the reference reads block k + 1 while it works on block k only in its big-image loop,
+        stardist/big.py:312-326; a plain loop over predict_instances pays the host -> device copy of every input in front of its step).
+        A helper thread copies the next array into page-locked memory (numpy copy: releases the GIL) and enqueues the device copy on
+        its own stream; the step waits for that copy's event only.  Images that need host-side preparation (a `normalizer`, `scale`)
+        and device tensors are passed through unchanged.  Results are those of predict_instances(img, **kwargs), image by image."""
+        import queue
+        import threading
+        import torch
+        if self.device.type != "cuda" or kwargs.get("normalizer") is not None or kwargs.get("scale") is not None:
+            for img in imgs:
+                yield self.predict_instances(img, **kwargs)
+            return
+        dev = self.device
+        copy_stream = torch.cuda.Stream(device=dev)
+        q = queue.Queue(maxsize=max(1, int(prefetch)))
+        stop = threading.Event()
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def uploader():
+            try:
+                for img in imgs:
+                    if stop.is_set():
+                        return
+                    if N.is_torch(img) or not isinstance(img, np.ndarray) or img.dtype == object:
+                        if not put((img, None)):
+                            return
+                        continue
+                    a = np.ascontiguousarray(img)
+                    # a ring of page-locked staging blocks per (shape, dtype), kept on the model: allocating page-locked memory per image
+                    # costs milliseconds and synchronises the device; a block is re-used once the copy that read it has completed
+                    ring = self.__dict__.setdefault("_upload_ring", {}).setdefault((a.shape, a.dtype.str), [])
+                    slot = None
+                    for cand in ring:
+                        if cand[1] is None or cand[1].query():
+                            slot = cand
+                            break
+                    if slot is None:
+                        if len(ring) >= int(prefetch) + 2:
+                            slot = ring[0]
+                            slot[1].synchronize()
+                        else:
+                            slot = [torch.empty(a.shape, dtype=torch.from_numpy(a[:0].reshape(-1)).dtype, pin_memory=True), None]
+                            ring.append(slot)
+                    ring[:] = [c for c in ring if c is not slot] + [slot]     # least recently used first
+                    np.copyto(slot[0].numpy(), a)
+                    with torch.cuda.device(dev), torch.cuda.stream(copy_stream):
+                        t = slot[0].to(dev, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(copy_stream)
+                    slot[1] = ev
+                    if not put((t, (ev, slot))):
+                        return
+                put((None, "end"))
+            except BaseException as e:                      # noqa: BLE001 -- re-raised in the consumer
+                put((e, "error"))
+
+        th = threading.Thread(target=uploader, name="stardist_amd-upload", daemon=True)
+        th.start()
+        try:
+            while True:
+                item, tag = q.get()
+                if tag == "end":
+                    break
+                if tag == "error":
+                    raise item
+                if tag is not None:
+                    ev, _stage = tag
+                    torch.cuda.current_stream(dev).wait_event(ev)
+                    item.record_stream(torch.cuda.current_stream(dev))
+                yield self.predict_instances(item, **kwargs)
+        finally:
+            stop.set()
+            th.join(timeout=5.0)
 
     def predict_instances(self, *args, **kwargs):
         """Predict instance segmentation: returns (labels, dict) exactly like the reference (base.py:775-790)."""

@@ -41,6 +41,17 @@ class StarDist2D(StarDistBase):
                 prob_class = prob_class[inds]
         return self._instances_from_survivors(img_shape, points, probi, disti, prob_class=prob_class, return_labels=return_labels, scale=scale)
 
+    def _instances_from_sorted(self, img_shape, cand, nms_thresh=None, overlap_label=None, return_labels=True, scale=None, **nms_kwargs):
+        """_instances_from_prediction for candidates the selection already delivers in score order on the device (base.SortedCandidates):
+        the NMS natives take them as they are, the survivors' rows are gathered once"""
+        from ..nms import non_maximum_suppression_sparse_sorted
+        if nms_thresh is None: nms_thresh = self.thresholds.nms
+        if overlap_label is not None:
+            raise NotImplementedError("overlap_label not supported for 2D yet!")
+        idx = non_maximum_suppression_sparse_sorted(cand.dist, cand.prob, cand.points_f32, nms_thresh=nms_thresh, **nms_kwargs)
+        return self._instances_from_survivors(img_shape, cand.points.index_select(0, idx), cand.prob.index_select(0, idx),
+                                              cand.dist.index_select(0, idx), return_labels=return_labels, scale=scale)
+
     def _instances_from_survivors(self, img_shape, points, probi, disti, prob_class=None, return_labels=True, scale=None, window=None):
         """the part of model2d.py:536-563 behind the NMS: label image and result dict of survivors given best score first.
         window = ((y0, x0), (h, w)): only that part of the label image is rendered (block-sharded prediction, stardist_amd/big.py)."""
@@ -55,6 +66,26 @@ class StarDist2D(StarDistBase):
                 points = points * np.array(rescale).reshape(1, 2)
         else:
             rescale = (1, 1)
+        if window is None and N.is_torch(disti) and N.is_torch(points) and N.is_torch(probi) and disti.is_cuda:
+            # device tensors, whole image: the polygons' coordinates are computed ONCE (polygons_to_label would compute them again in
+            # painting order) and everything returns to the host behind one synchronisation
+            import torch
+            from ..geometry.geom2d import polygons_to_label_coord
+            from ..utils import to_host_many
+            coord = dist_to_coord(disti, points, scale_dist=rescale)
+            labels = None
+            if return_labels:
+                # geom2d.py:186-197 with prob given and thr = -inf: `prob > thr` holds for every finite score; paint in ascending
+                # score order (stable), label id = position in the given (NMS) order + 1
+                ind = torch.sort(probi, stable=True)[1]
+                labels = polygons_to_label_coord(coord.index_select(0, ind), shape=img_shape, labels=ind)
+            pc = prob_class if (prob_class is not None and N.is_torch(prob_class)) else None
+            labels, coord_h, points_h, prob_h, pc_h = to_host_many([labels, coord, points, probi, pc])
+            res_dict = dict(coord=coord_h, points=points_h, prob=prob_h)
+            if prob_class is not None:
+                prob_class = np.asarray(pc_h if pc is not None else prob_class)
+                res_dict.update(dict(class_prob=prob_class, class_id=np.argmax(prob_class, axis=-1)))
+            return labels, res_dict
         if return_labels:
             labels = polygons_to_label(disti, points, prob=probi, shape=img_shape, scale_dist=rescale, window=window)
         else:

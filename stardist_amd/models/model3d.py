@@ -48,6 +48,18 @@ class StarDist3D(StarDistBase):
         return self._instances_from_survivors(img_shape, points, probi, disti, prob_class=prob_class, return_labels=return_labels, scale=scale,
                                               overlap_label=overlap_label, verbose=verbose, rays=rays)
 
+    def _instances_from_sorted(self, img_shape, cand, nms_thresh=None, overlap_label=None, return_labels=True, scale=None, **nms_kwargs):
+        """_instances_from_prediction for candidates the selection already delivers in score order on the device (base.SortedCandidates)"""
+        from ..nms import non_maximum_suppression_3d_sparse_sorted
+        if nms_thresh is None: nms_thresh = self.thresholds.nms
+        rays = rays_from_json(self.config.rays_json)
+        idx = non_maximum_suppression_3d_sparse_sorted(cand.dist, cand.prob, cand.points_f32, rays, nms_thresh=nms_thresh, **nms_kwargs)
+        verbose = nms_kwargs.get("verbose", False)
+        verbose and print("render polygons...")
+        return self._instances_from_survivors(img_shape, cand.points.index_select(0, idx), cand.prob.index_select(0, idx),
+                                              cand.dist.index_select(0, idx), return_labels=return_labels, scale=scale,
+                                              overlap_label=overlap_label, verbose=verbose, rays=rays)
+
     def _instances_from_survivors(self, img_shape, points, probi, disti, prob_class=None, return_labels=True, scale=None, overlap_label=None,
                                   verbose=False, rays=None, window=None):
         """the part of model3d.py:616-674 behind the NMS: label volume (polyhedron rasteriser + relabel_sequential) and result dict of
@@ -77,6 +89,8 @@ class StarDist3D(StarDistBase):
                     labels[overlap_mask] = overlap_label2
                     labels, fwd, bwd = relabel_sequential(labels)
                     labels[labels == fwd[overlap_label2]] = overlap_label
+                elif overlap_label is None:
+                    labels, _, _ = relabel_sequential(labels, _known_max=len(points))     # the rasteriser wrote ids 1..M (geom3d.py:141)
                 else:
                     labels, _, _ = relabel_sequential(labels)
                 labels = to_host(labels)
@@ -91,8 +105,14 @@ class StarDist3D(StarDistBase):
                     labels, _, _ = relabel_sequential(labels)
         else:
             labels = None
-        to_np = (lambda t: t.cpu().numpy()) if N.is_torch(disti) else (lambda t: t)
-        res_dict = dict(dist=to_np(disti), points=to_np(points), prob=to_np(probi), rays=rays, rays_vertices=rays.vertices,
+        if N.is_torch(disti) and N.is_torch(points) and N.is_torch(probi):
+            from ..utils import to_host_many
+            dist_h, points_h, prob_h = to_host_many([disti, points, probi])          # one synchronisation for the three
+            to_np = lambda t: t.cpu().numpy()
+        else:
+            to_np = (lambda t: t.cpu().numpy()) if N.is_torch(disti) else (lambda t: t)
+            dist_h, points_h, prob_h = to_np(disti), to_np(points), to_np(probi)
+        res_dict = dict(dist=dist_h, points=points_h, prob=prob_h, rays=rays, rays_vertices=rays.vertices,
                         rays_faces=rays.faces)
         if prob_class is not None:
             prob_class = np.asarray(to_np(prob_class) if N.is_torch(prob_class) else prob_class)

@@ -131,7 +131,36 @@ def non_maximum_suppression_sparse(dist, prob, points, b=2, nms_thresh=0.5, use_
         inds_original = np.arange(len(prob))[_sorted]
     probi, disti, pointsi = prob[_sorted], dist[_sorted], points[_sorted]
     inds = non_maximum_suppression_inds(disti, pointsi, scores=probi, thresh=nms_thresh, use_kdtree=use_kdtree, verbose=verbose)
+    if _is_t(inds):
+        inds = _survivor_positions(inds)          # positions once (one read-back) instead of one boolean-mask indexing per array
     return pointsi[inds], probi[inds], disti[inds], inds_original[inds]
+
+
+def _survivor_positions(keep):
+    """positions of the True entries of a device bool tensor, ascending (what boolean-mask indexing computes internally, once)"""
+    import torch
+    return torch.nonzero(keep).reshape(-1)
+
+
+def non_maximum_suppression_sparse_sorted(dist, prob, points, b=2, nms_thresh=0.5, use_bbox=True, use_kdtree=True, verbose=False):
+    """non_maximum_suppression_sparse (stardist/nms.py:135-183) for candidates that are ALREADY in score order (descending, the order
+    `np.argsort(prob)[::-1]` gives them) as device tensors: positions (int64 tensor) of the survivors, best score first."""
+    assert dist.ndim == 2 and prob.ndim == 1 and points.ndim == 2 and points.shape[-1] == 2 and len(prob) == len(dist) == len(points)
+    keep = non_maximum_suppression_inds(dist, points, scores=prob, thresh=nms_thresh, use_kdtree=use_kdtree, verbose=verbose)
+    return _survivor_positions(keep)
+
+
+def non_maximum_suppression_3d_sparse_sorted(dist, prob, points, rays, b=2, nms_thresh=0.5, use_kdtree=True, verbose=False):
+    """non_maximum_suppression_3d_sparse (stardist/nms.py:285-324) for candidates already in score order (descending) as device tensors:
+    positions (int64 tensor) of the survivors, best score first.  (non_maximum_suppression_3d_inds re-sorts by score, nms.py:352: a
+    stable re-sort of a sorted list is the identity, so it is skipped.)"""
+    from .lib.stardist3d import c_non_max_suppression_inds
+    from .rays3d import rays_device_tensors
+    assert dist.ndim == 2 and prob.ndim == 1 and points.ndim == 2 and dist.shape[-1] == len(rays) and points.shape[-1] == 3 and \
+        len(prob) == len(dist) == len(points)
+    verts, faces = rays_device_tensors(rays, dist.device)
+    keep = c_non_max_suppression_inds(dist, points, verts, faces, prob, 1, int(use_kdtree), int(verbose), np.float32(nms_thresh))
+    return _survivor_positions(keep)
 
 
 # ----------------------------------------------------------------------------- 3D
@@ -146,8 +175,8 @@ def non_maximum_suppression_3d_inds(dist, points, rays, scores, thresh=0.5, use_
             scores = torch.ones(n_poly, device=dist.device)
         ind = _argsort_desc(scores)
         survivors = torch.ones(n_poly, dtype=torch.bool, device=dist.device)
-        verts = torch.as_tensor(np.ascontiguousarray(rays.vertices, np.float32), device=dist.device)
-        faces = torch.as_tensor(np.ascontiguousarray(rays.faces, np.int32), device=dist.device)
+        from .rays3d import rays_device_tensors
+        verts, faces = rays_device_tensors(rays, dist.device)
         survivors[ind] = c_non_max_suppression_inds(dist[ind].float().contiguous(), points[ind].float().contiguous(),
                                                     verts, faces, scores[ind].float().contiguous(),
                                                     int(use_bbox), int(use_kdtree), int(verbose), np.float32(thresh))
@@ -197,4 +226,6 @@ def non_maximum_suppression_3d_sparse(dist, prob, points, rays, b=2, nms_thresh=
         inds_original = np.arange(len(prob))[_sorted]
     probi, disti, pointsi = prob[_sorted], dist[_sorted], points[_sorted]
     inds = non_maximum_suppression_3d_inds(disti, pointsi, rays=rays, scores=probi, thresh=nms_thresh, use_kdtree=use_kdtree, verbose=verbose)
+    if _is_t(inds):
+        inds = _survivor_positions(inds)
     return pointsi[inds], probi[inds], disti[inds], inds_original[inds]

@@ -73,6 +73,22 @@ class Rays_Base(object):
 
 
 _RAYS_CACHE = {}
+_RAYS_DEV_CACHE = {}
+
+
+def rays_device_tensors(rays, device):
+    """(vertices float32 (R, 3), faces int32 (F, 3)) of a ray set as tensors on `device`, uploaded once per distinct ray set (the natives
+    take them on every NMS / rasteriser call: two host -> device copies per call otherwise)"""
+    import torch
+    v = np.ascontiguousarray(rays.vertices, np.float32); f = np.ascontiguousarray(rays.faces, np.int32)
+    key = (str(device), v.tobytes(), f.tobytes())
+    r = _RAYS_DEV_CACHE.get(key)
+    if r is None:
+        if len(_RAYS_DEV_CACHE) >= 16:
+            _RAYS_DEV_CACHE.clear()
+        r = (torch.as_tensor(v, device=device), torch.as_tensor(f, device=device))
+        _RAYS_DEV_CACHE[key] = r
+    return r
 
 
 def rays_from_json(d):

@@ -54,6 +54,24 @@ def to_host(t):
     return h.numpy()
 
 
+def to_host_many(tensors):
+    """several device tensors -> numpy arrays with ONE stream synchronisation: every copy goes through its own page-locked staging
+    tensor (as to_host) and is enqueued non-blocking; None entries and host tensors pass through."""
+    import torch
+    outs, dev = [], None
+    for t in tensors:
+        if t is None or not t.is_cuda:
+            outs.append(None if t is None else t.numpy())
+            continue
+        dev = t.device
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t, non_blocking=True)
+        outs.append(h)
+    if dev is not None:
+        torch.cuda.current_stream(dev).synchronize()
+    return [o.numpy() if (o is not None and not isinstance(o, np.ndarray)) else o for o in outs]
+
+
 def to_device(a, device):
     """host numpy array -> device tensor.  Measured on the MI355X box (tools/probe_h2d.py, 2048^2 float32 = 16.8 MB): the plain
     pageable copy 0.32 ms (52 GB/s), a persistent page-locked staging tensor 0.38 ms -- and filling that staging tensor with torch's

@@ -241,6 +241,7 @@ def test_nms2d_old_equals_reference_old_and_new(refmods, shape, R, grid, max_bbo
     from oracle import port, synth
     from stardist_amd.lib import stardist2d as sd2
     m = refmods.stardist2d()
+    refmods.set_threads(8)           # the reference's _old runs a collapse(2) dynamic OpenMP loop per polygon: 256 host threads oversubscribe it
     dist, prob = synth.s2d_uniform(shape[0], shape[1], n_rays=R, dense=True)
     dist, prob = dist[::grid[0], ::grid[1]], prob[::grid[0], ::grid[1]]
     mask = port.ind_prob_thresh(prob, 0.9, b=2)
