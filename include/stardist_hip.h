@@ -49,6 +49,8 @@ int sd_release_workspace(void);           /* free the cached device workspace   
  *   "nms2d_strict"        0|1  1 = bit-exact BY CONSTRUCTION: every 2D pair runs the Clipper-exact sweep (overrides "nms2d_area_bounds"); the
  *                              default decides the pairs far from the threshold from an enclosure of Clipper's area whose band is validated
  *                              empirically and adversarially, not proven
+ *   "nms2d_neighbours_single_pass" 1|0  neighbour lists of the 2D NMS written in one pass into slots sized from the cell table / counted,
+ *                              scanned and filled in two passes (same lists up to order)
  *   "probe_tier"          1|2  capacity tier sd_clip_pairs_device runs first;  "probe_no_general" 1: do not fall back to the general path
  *   "trace"               1    print per-round counters to stdout
  * Nothing in the library reads the process environment.  sd_get_option returns -1 for an unknown name. */
@@ -335,6 +337,18 @@ int sd_conv3_f16x3_res_ndhwc_device(const float* d_src0, int c0, int stride0, in
                                     int up1, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias,
                                     const float* d_res, int res_stride, int c_out, int act, float* d_out, int* d_range_flag,
                                     void* stream);
+
+/* ... with the ONE-CHANNEL HEAD behind the layer fused into its epilogue (the object-probability head behind the features layer:
+ * Conv 1x1 + sigmoid, stardist/models/model2d.py:338-341, model3d.py:436-439).  Besides d_out the kernel writes, per pixel and per group of
+ * four consecutive output channels, the sum (in channel order) of their products (after bias + activation) with d_dot_w[c_out]:
+ * d_dot_partial[D * H * W][c_out / 4] -- the per-lane term of sd_bias_act_dot_device, taken while the tile is in registers.
+ * sd_dot_combine_device (groups = c_out / 32: 1, 2, 4 or 8) adds a pixel's terms in the order of that function's reduction, then the
+ * head's bias d_wbias[0] (NULL: none), then the logistic function (sigmoid != 0): the result equals sd_bias_act_dot_device on the same
+ * features BIT FOR BIT, without reading the features a second time. */
+int sd_conv3_f16x3_dot_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1,
+                                    int up1, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, int c_out,
+                                    int act, float* d_out, int* d_range_flag, const float* d_dot_w, float* d_dot_partial, void* stream);
+int sd_dot_combine_device(const float* d_partial, int groups, long long n_pix, const float* d_wbias, int sigmoid, float* d_out, void* stream);
 
 /* UpSampling2D/3D (nearest, x2 along the axes of `up`: bit 0 x, 1 y, 2 z) + Concatenate([up-sampled a, b]) of a csbdeep unet_block up
  * level as one channels-last tensor [D][H][W][ca + cb] (a: [D >> z][H >> y][W >> x][ca]).  Only the coverage path needs it -- up

@@ -26,6 +26,7 @@ static const int WINDOW = 2047;
 struct Poly { int n; i64 x[MAXR], y[MAXR]; };
 struct Props { double lmax, perim; bool plain; int orient; i64 xmin, xmax, ymin, ymax; };
 
+static int g_self_rule = 1;
 static int sgn(i64 v) { return v > 0 ? 1 : (v < 0 ? -1 : 0); }
 
 // area_bounds.h k_poly_props
@@ -61,6 +62,23 @@ static Props props(const Poly& p) {
         inter = std::max(std::min(ax, bx), std::min(cx, dx)) <= std::min(std::max(ax, bx), std::max(cx, dx)) &&
                 std::max(std::min(ay, by), std::min(cy, dy)) <= std::min(std::max(ay, by), std::max(cy, dy));
       if (inter) { bad = true; break; }
+    }
+  }
+  // ROBUSTLY simple (rule added in round 5, see area_bounds.h): no vertex within half a lattice step, along its scan line, of an edge of the
+  // same polygon it is not an end point of -- where Clipper's rounded abscissae can tie and re-order the polygon's own edges
+  if (g_self_rule && !bad) {
+    for (int v = 0; v < n && !bad; ++v) {
+      const i64 vx = p.x[v], vy = p.y[v];
+      for (int k = 0; k < n; ++k) {
+        if (deg[k]) continue;
+        const int kn = (k + 1) % n;
+        const i64 ax = p.x[k], ay = p.y[k], bx = p.x[kn], by = p.y[kn];
+        if ((ax == vx && ay == vy) || (bx == vx && by == vy)) continue;          // an end point (or a coincident vertex: caught by `inter` above unless incident)
+        if (vy < std::min(ay, by) || vy > std::max(ay, by)) continue;
+        if (ay == by) { if (vx >= std::min(ax, bx) && vx <= std::max(ax, bx)) { bad = true; break; } continue; }
+        const i64 num = (ax - vx) * (by - ay) + (vy - ay) * (bx - ax);
+        if (2 * std::llabs(num) <= g_self_rule * std::llabs(by - ay)) { bad = true; break; }       // |x_edge(vy) - vx| <= g_self_rule / 2
+      }
     }
   }
   r.lmax *= (1.0 + 1e-6);
@@ -297,6 +315,7 @@ int main(int argc, char** argv) {
   const long restarts = argc > 2 ? atol(argv[2]) : 100;
   const int iters = argc > 3 ? atoi(argv[3]) : 2000;
   const int mode = argc > 4 ? atoi(argv[4]) : 2;
+  if (argc > 5) g_self_rule = atoi(argv[5]);
   init_tables();
   Rng r(seed * 0x9E3779B97F4A7C15ull + 12345);
   double worst = 0, famWorst[NFAM][2]; memset(famWorst, 0, sizeof(famWorst));

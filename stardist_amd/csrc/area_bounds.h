@@ -47,8 +47,9 @@ __device__ __forceinline__ int half_max_i(int v) { for (int o = 16; o; o >>= 1) 
 constexpr int WINDOW = 2047;        // largest |relative coordinate| for which every predicate's products stay below 2^24
 
 // Per polygon (two polygons per wave, lane & 31 = edge): longest edge, L1 perimeter, orientation, integer bounding box and whether the
-// polygon is SIMPLE once zero-length edges are dropped: no two edges share a point except cyclic neighbours at their common vertex,
-// no fold-back between neighbours, at least three edges.  vx / vy: [n][R] (R <= 32).
+// polygon is ROBUSTLY SIMPLE once zero-length edges are dropped: no two edges share a point except cyclic neighbours at their common
+// vertex, no fold-back between neighbours, at least three edges, and no vertex within half a lattice step (along its scan line) of an edge
+// it does not end.  vx / vy: [n][R] (R <= 32).
 static __global__ void __launch_bounds__(256) k_poly_props(const int* __restrict__ vx, const int* __restrict__ vy, int n, int R, PolyProps* __restrict__ out) {
   const int lane = threadIdx.x & 63, half = lane >> 5, l = lane & 31, hb = half << 5;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -74,10 +75,27 @@ static __global__ void __launch_bounds__(256) k_poly_props(const int* __restrict
   if (m32) { const unsigned int above = (l >= 31) ? 0u : (m32 & ~((2u << l) - 1u)); nxt = above ? __ffs((int)above) - 1 : __ffs((int)m32) - 1; }
   const int area2 = half_sum_i(valid ? rx * rby - ry * rbx : 0);                            // exact: |terms| < 2^23, 32 of them
   bool bad = false;
+  // the vertices and the successor table of the half's polygon through LDS: the loop reads them with half-uniform addresses (broadcast
+  // reads) instead of five cross-lane shuffles per iteration
+  __shared__ float2 sv[4][2][32];
+  __shared__ int sn[4][2][32];
+  const int wv = threadIdx.x >> 6;
+  sv[wv][half][l] = make_float2(ax, ay); sn[wv][half][l] = nxt;
+  __builtin_amdgcn_wave_barrier();                  // (a wave's LDS accesses are processed in order)
   for (int k = 0; k < R; ++k) {
-    const float cx = __shfl(ax, hb + k), cy = __shfl(ay, hb + k), dx = __shfl(bx, hb + k), dy = __shfl(by, hb + k);
-    const int nxt_k = __shfl(nxt, hb + k);
+    const int kn = (k + 1 >= R) ? 0 : k + 1;
+    const float2 c2 = sv[wv][half][k], d2 = sv[wv][half][kn];
+    const float cx = c2.x, cy = c2.y, dx = d2.x, dy = d2.y;
+    const int nxt_k = sn[wv][half][k];
     const bool degk = ((m32 >> k) & 1u) == 0u;
+    // ROBUSTLY simple (round 5): my vertex a must not lie, along its scan line, within HALF a lattice step of an edge (c -> d) it is not an
+    // end point of -- there Clipper's rounded abscissae tie and the polygon's OWN edges can be re-ordered, which changes the area it
+    // returns by more than any strip between the two polygons (found by the adversarial search of DESIGN.md 3.4: a polygon of area 80 whose
+    // spike comes within half a step of a vertex is returned with 68.5).  Exact in float: relative coordinates <= WINDOW.
+    if (valid && small && !degk && !((cx == ax && cy == ay) || (dx == ax && dy == ay)) && ay >= fminf(cy, dy) && ay <= fmaxf(cy, dy)) {
+      if (cy == dy) { if (ax >= fminf(cx, dx) && ax <= fmaxf(cx, dx)) bad = true; }
+      else if (2.f * fabsf((cx - ax) * (dy - cy) + (ay - cy) * (dx - cx)) <= fabsf(dy - cy)) bad = true;   // |x_edge(ay) - ax| <= 1/2
+    }
     if (deg || degk || k == l) continue;
     const float fx = dx - cx, fy = dy - cy;
     if (k == nxt || nxt_k == l) {

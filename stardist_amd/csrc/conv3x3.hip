@@ -368,6 +368,7 @@ extern "C" int sd_conv3_res_ndhwc_device(const float* d_src0, int c0, int stride
   P.D = D; P.H = H; P.W = W; P.kz = kz; P.n_units = nc * kz;
   P.zero = d_wpacked + sdconv::packed_floats(c_in, c_out, kz);
   P.res = d_res; P.res_stride = res_stride;
+  P.dotw = nullptr; P.dotp = nullptr;
   P.wp = d_wpacked; P.bias = d_bias; P.out = d_out; P.c_out = c_out; P.act = act;
   P.tiles_x = (W + TW - 1) / TW;
   P.tiles_plane = P.tiles_x * ((H + TH - 1) / TH);

@@ -40,6 +40,9 @@ struct Params {
   int res_stride;      // csbdeep resnet_block, folded into the epilogue (nullptr: none)
   int tiles_x, tiles_plane, n_tiles, groups;
   int* flag;           // conv3x3_f16.hip: OR-ed with 1 when an activation is outside the fp16 range (nullptr: not reported)
+  const float* dotw;   // conv3x3_f16.hip, fused one-channel head (the probability head behind the features layer): weights [c_out] ...
+  float* dotp;         // ... and the partial dot products [groups][D * H * W]: dotp[g][pixel] = sum over the 32 channels of group g of
+                       // out[pixel][c] * dotw[c], taken while the tile is in registers (nullptr: none)
 };
 
 // workgroup -> (output-channel group g, tile slot q): consecutive workgroups go round-robin over the 8 XCDs, so the `groups`

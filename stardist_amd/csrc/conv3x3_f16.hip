@@ -192,7 +192,13 @@ __device__ __forceinline__ void compute_sub(const char* __restrict__ tileH, cons
 // 19 % of the 2D 32 -> 32 layer.  So the tile is transposed through a wave-private 2-KiB LDS scratch in four rounds of 16 pixels
 // (8 ds_write_b32 + 2 ds_read_b128 + 2 buffer_store_dwordx4 each: a lane stores 4 channels of one pixel); LDS operations of one wave
 // execute in order, so the rounds need no barrier and no wait between a round's reads and the next round's writes.
-template <bool RES>
+// DOT: the one-channel head behind this layer (the object probability, model2d.py:338-341 / model3d.py:436-439), first stage: from the four
+// values the lane is about to store, their products with the head's weights summed in channel order -- exactly the per-lane term of
+// sd_bias_act_dot_device (unet_ops.hip) -- written to dotp[pixel][c_out / 4] (4 bytes per lane, 1/4 of the features' bytes).
+// sd_dot_combine_device then adds a pixel's c_out / 4 terms in the order of that kernel's xor butterfly, the bias and the logistic function:
+// the probabilities are BIT-IDENTICAL to the two-pass form, and the 128-channel features are not read a second time for them.
+// The head's 32 weights of this workgroup's channels are staged in LDS (behind the epilogue scratch) at kernel start.
+template <bool RES, bool DOT>
 __device__ __forceinline__ void store_tile(const Params& P, const f32x16 (&acc0)[2], const f32x16 (&acc1)[2], float* __restrict__ scr, int g, int tz,
                                            int ty, int tx, int wave, int lane) {
   const int i = lane & 31, h = lane >> 5;
@@ -211,6 +217,9 @@ __device__ __forceinline__ void store_tile(const Params& P, const f32x16 (&acc0)
     __amdgpu_buffer_rsrc_t rr = ro;
     if (RES && P.res)
       rr = __builtin_amdgcn_make_buffer_rsrc((void*)uniform64((unsigned long long)(P.res + row * P.res_stride)), 0, (int)((unsigned)P.W * res_bytes), 0x00020000);
+    __amdgpu_buffer_rsrc_t rd = ro;
+    if (DOT)
+      rd = __builtin_amdgcn_make_buffer_rsrc((void*)uniform64((unsigned long long)(P.dotp + row * (size_t)(P.c_out >> 2))), 0, (int)((unsigned)P.W * (unsigned)P.c_out), 0x00020000);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {                                      // columns 16 q .. 16 q + 15
 #pragma unroll
@@ -225,7 +234,15 @@ __device__ __forceinline__ void store_tile(const Params& P, const f32x16 (&acc0)
         const unsigned x = (unsigned)(tx + q * 16 + n * 8 + px);
         if (RES && P.res) v += __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(x * res_bytes + chan_off), 0, 0));
         if (P.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, (int)(x * pix_bytes + chan_off), 0, 0);
+        const int so = (int)(x * pix_bytes + chan_off);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, so, 0, 0);
+        if (DOT) {
+          const v4f hw = *(const v4f*)(scr + (4 - wave) * 512 + c4 * 4);    // (LDS, behind the four waves' scratch; held in registers across the unit loop it would be spilled)
+          float d = v.x * hw.x;
+          d += v.y * hw.y; d += v.z * hw.z; d += v.w * hw.w;
+          // dotp[pixel][c_out / 4]: this lane's slot is a quarter of the byte offset of its 16-byte feature store (x >= W: dropped)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d), rd, so >> 2, 0, 0);
+        }
       }
     }
   }
@@ -233,7 +250,7 @@ __device__ __forceinline__ void store_tile(const Params& P, const f32x16 (&acc0)
 
 // TWO workgroups per CU (79.8 KiB of LDS each, <= 256 registers per lane): two waves per SIMD
 // (WPE = 1: the same code compiled for one wave per SIMD -- 512 registers -- as the A/B partner of option conv_f16_workgroups_per_cu = 1)
-template <bool RES, int WPE>
+template <bool RES, int WPE, bool DOT = false>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_conv3_f16(const Params P) {
   extern __shared__ float4 smem4h[];
   // LDS map (bytes): two weight buffers of one sub-unit each | halo tile, 2 fp16 planes | 4 x 2 KiB wave-private epilogue scratch
@@ -245,6 +262,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WP
   int g, q, Q;
   wg_slot(P, g, q, Q);
   if (q >= P.n_tiles) return;
+  if (DOT && tid < 32) ((float*)(tileH + HTILE_BYTES) + 4 * 512)[tid] = P.dotw[g * 32 + tid];    // the head's 32 weights of this group, behind the epilogue scratch (visible behind the prologue's barrier)
   const float bias_r = P.bias ? P.bias[g * 32 + (lane & 31)] : 0.f;
   StageH st;
   stage_init_h(st, tid);
@@ -337,7 +355,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WP
       PROF(10);
       PROF_UNIT();
     }
-    store_tile<RES>(P, acc0, acc1, scr, g, Tc.tz, Tc.ty0 + 1, Tc.tx0 + 1, wave, lane);
+    store_tile<RES, DOT>(P, acc0, acc1, scr, g, Tc.tz, Tc.ty0 + 1, Tc.tx0 + 1, wave, lane);
     PROF(11);
     Tc = Tn;
   }
@@ -368,10 +386,10 @@ extern "C" int sd_conv3_f16x3_pack_weights_host(const float* w, int c_in, int c_
   return 0;
 }
 
-extern "C" int sd_conv3_f16x3_res_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1,
-                                               int up1, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias,
-                                               const float* d_res, int res_stride, int c_out, int act, float* d_out, int* d_range_flag,
-                                               void* stream_) {
+static int conv3_f16x3_launch(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1,
+                              int up1, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias,
+                              const float* d_res, int res_stride, int c_out, int act, float* d_out, int* d_range_flag,
+                              const float* d_dot_w, float* d_dot_partial, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   if (D <= 0 || H <= 0 || W <= 0) return 0;
   const int c_in = c0 + (d_src1 ? c1 : 0);
@@ -407,6 +425,12 @@ extern "C" int sd_conv3_f16x3_res_ndhwc_device(const float* d_src0, int c0, int 
   P.res = d_res; P.res_stride = res_stride;
   P.wp = d_wpacked; P.bias = d_bias; P.out = d_out; P.c_out = c_out; P.act = act;
   P.flag = d_range_flag;
+  if ((d_dot_w != nullptr) != (d_dot_partial != nullptr) || (d_dot_w && d_res) || ((uintptr_t)d_dot_w & 15) || ((uintptr_t)d_dot_partial & 3) ||
+      (d_dot_w && (long long)W * c_out >= 0x7fffffffLL)) {
+    sd::set_error("sd_conv3_f16x3: the fused head needs both its weights (16-byte aligned) and its partial-sum buffer, and no residual");
+    return -1;
+  }
+  P.dotw = d_dot_w; P.dotp = d_dot_partial;
   P.tiles_x = (W + TW - 1) / TW;
   P.tiles_plane = P.tiles_x * ((H + TH - 1) / TH);
   const long long nt_ll = (long long)P.tiles_plane * D;
@@ -424,12 +448,14 @@ extern "C" int sd_conv3_f16x3_res_ndhwc_device(const float* d_src0, int c0, int 
   static int n_cu[16] = {};
   int dev = 0;
   SD_CHECK(hipGetDevice(&dev));
-  const size_t lds = (size_t)2 * HWSUB_BYTES + HTILE_BYTES + 4 * 2048;    // 79.8 KiB: two workgroups per CU
+  const size_t lds = (size_t)2 * HWSUB_BYTES + HTILE_BYTES + 4 * 2048 + 128;    // 79.9 KiB: two workgroups per CU (the last 128 bytes: the fused head's weights)
   if (dev >= 16 || !attr_set[dev]) {
     SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (dev < 16) attr_set[dev] = true;
   }
   int cus = dev < 16 ? n_cu[dev] : 0;
@@ -444,14 +470,32 @@ extern "C" int sd_conv3_f16x3_res_ndhwc_device(const float* d_src0, int c0, int 
   const long long want = (long long)P.n_tiles * P.groups;
   if (blocks > want) blocks = want;
   if (per_cu == 1) {
-    if (d_res) hipLaunchKernelGGL((k_conv3_f16<true, 1>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
+    if (d_dot_w) hipLaunchKernelGGL((k_conv3_f16<false, 1, true>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
+    else if (d_res) hipLaunchKernelGGL((k_conv3_f16<true, 1>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
     else hipLaunchKernelGGL((k_conv3_f16<false, 1>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
   } else {
-    if (d_res) hipLaunchKernelGGL((k_conv3_f16<true, 2>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
+    if (d_dot_w) hipLaunchKernelGGL((k_conv3_f16<false, 2, true>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
+    else if (d_res) hipLaunchKernelGGL((k_conv3_f16<true, 2>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
     else hipLaunchKernelGGL((k_conv3_f16<false, 2>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
   }
   SD_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int sd_conv3_f16x3_res_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1,
+                                               int up1, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias,
+                                               const float* d_res, int res_stride, int c_out, int act, float* d_out, int* d_range_flag,
+                                               void* stream_) {
+  return conv3_f16x3_launch(d_src0, c0, stride0, up0, d_src1, c1, stride1, up1, D, H, W, kz, d_wpacked, d_bias, d_res, res_stride, c_out, act, d_out,
+                            d_range_flag, nullptr, nullptr, stream_);
+}
+
+extern "C" int sd_conv3_f16x3_dot_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1,
+                                               int up1, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, int c_out, int act,
+                                               float* d_out, int* d_range_flag, const float* d_dot_w, float* d_dot_partial, void* stream_) {
+  if (!d_dot_w || !d_dot_partial) { sd::set_error("sd_conv3_f16x3_dot: head weights and partial-sum buffer required"); return -1; }
+  return conv3_f16x3_launch(d_src0, c0, stride0, up0, d_src1, c1, stride1, up1, D, H, W, kz, d_wpacked, d_bias, nullptr, 0, c_out, act, d_out,
+                            d_range_flag, d_dot_w, d_dot_partial, stream_);
 }
 
 extern "C" int sd_conv3_f16x3_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1, int up1,

@@ -124,9 +124,11 @@ __global__ void k_cell_count(const float* __restrict__ pts, int N, GridP g, int*
 // candidates re-packed in cell order: the broad phase streams these 32-byte records (coalesced) instead of gathering
 // bbox / centre / area of every cell item by candidate index
 struct __attribute__((aligned(16))) CellRec { int4 bb; float py, px, area; int j; };
+// slotCap (may be null): upper bound of candidate i's neighbour count = the population of the (2 W + 1)^2 cells its list is built from,
+// minus itself -- the capacity of its slot in the single-pass neighbour lists (k_neighbours<2>)
 __global__ void k_cell_fill(int N, const int* __restrict__ candCell, const int* __restrict__ cellStart,
                             int* __restrict__ cellFill, const float* __restrict__ pts, const int4* __restrict__ bbox,
-                            const float* __restrict__ area, CellRec* __restrict__ rec) {
+                            const float* __restrict__ area, CellRec* __restrict__ rec, GridP g, int W, int* __restrict__ slotCap) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int c = candCell[i];
@@ -134,6 +136,13 @@ __global__ void k_cell_fill(int N, const int* __restrict__ candCell, const int* 
   CellRec r;
   r.bb = bbox[i]; r.py = pts[2 * i]; r.px = pts[2 * i + 1]; r.area = area[i]; r.j = i;
   rec[cellStart[c] + pos] = r;
+  if (slotCap) {
+    const int cy = c / g.nx, cx = c - cy * g.nx;
+    const int x_lo = max(cx - W, 0), x_hi = min(cx + W, g.nx - 1);
+    int u = -1;
+    for (int yy = max(cy - W, 0); yy <= min(cy + W, g.ny - 1); ++yy) u += cellStart[yy * g.nx + x_hi + 1] - cellStart[yy * g.nx + x_lo];
+    slotCap[i] = u;
+  }
 }
 
 __device__ __forceinline__ bool bbox_intersect(const int4 a, const int4 b) {   // stardist2d.cpp:142-148
@@ -147,11 +156,12 @@ __device__ __forceinline__ bool may_interact(const Flags f, const int4 bi, const
                                              float ai, float aj) {
   if (f.thr_nonneg) {
     // disjoint integer bboxes => area 0 => overlap 0 <= thr; more generally area_inter <= area(bbox_i ∩ bbox_j), so a pair
-    // whose bbox-intersection area cannot exceed thr * min(area) can never suppress (same bound as in k_round_emit)
+    // whose bbox-intersection area cannot exceed thr * min(area) can never suppress.  The lists only have to be a SUPERSET of the pairs
+    // the emission kernels accept with the exact form of this bound (k_round_emit / k_tail_emit: the double quotient): here it is the
+    // division-free float form with a relative margin of 1e-5 (every rounding of either form is below 2e-7).
     if (!bbox_intersect(bi, bj)) return false;
-    const double w = (double)(min(bi.y, bj.y) - max(bi.x, bj.x)), hgt = (double)(min(bi.w, bj.w) - max(bi.z, bj.z));
-    const float ub = (float)((w * hgt) / fmin((double)ai + 1.e-10, (double)aj + 1.e-10));
-    return ub > f.thr;
+    const float wh = (float)(min(bi.y, bj.y) - max(bi.x, bj.x)) * (float)(min(bi.w, bj.w) - max(bi.z, bj.z));
+    return wh * 1.00001f >= f.thr * fminf(ai, aj) * 0.99999f;
   }
   bool ok = true;
   if (f.use_bbox) ok = ok && bbox_intersect(bi, bj);
@@ -163,13 +173,16 @@ __device__ __forceinline__ bool may_interact(const Flags f, const int4 bi, const
   return ok;
 }
 
-// MODE 0: count neighbours, MODE 1: fill CSR
+// MODE 0: count neighbours, MODE 1: fill CSR (two passes: exact-size lists);
+// MODE 2: ONE pass into per-candidate slots whose capacity is the population of the cells scanned (k_cell_fill slotCap; nbrStart = slot
+// starts): the better-scored neighbours are written from the slot's front, the others from its back, nbrLow / nbrCount (= the number of
+// the others) tell the consumers where each half ends -- the candidate tests of the counting pass are not repeated
 #define WAIT_NONE (-2)
 #define WAIT_SCAN (-1)
 template <int MODE>
 __global__ void __launch_bounds__(256) k_neighbours(int N, GridP g, Flags f, const CellRec* __restrict__ rec, const int* __restrict__ cellStart,
                                                     int* __restrict__ nbrCount, int* __restrict__ nbrLow, const i64* __restrict__ nbrStart,
-                                                    int* __restrict__ nbr, int* __restrict__ waitOn, int W) {
+                                                    int* __restrict__ nbr, int* __restrict__ waitOn, int W, unsigned long long* __restrict__ total) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // wave w handles the w-th candidate IN CELL ORDER, and consecutive workgroups of one XCD (blockIdx % 8) get consecutive
   // cells: the 5x5 cell neighbourhoods of successive waves overlap almost completely and stay in that XCD's L2
@@ -188,7 +201,7 @@ __global__ void __launch_bounds__(256) k_neighbours(int N, GridP g, Flags f, con
   int nLo = 0, nHi = 0;
   int minj = INT32_MAX;                      // MODE 1: best-scored neighbour above i (first wait target of the greedy scan)
   const i64 baseLo = MODE ? nbrStart[i] : 0;
-  const i64 baseHi = MODE ? baseLo + nbrLow[i] : 0;
+  const i64 baseHi = MODE == 1 ? baseLo + nbrLow[i] : (MODE == 2 ? nbrStart[i + 1] - 1 : 0);      // MODE 2: the slot's last entry, filled downwards
   const int x_lo = max(cx - W, 0), x_hi = min(cx + W, g.nx - 1);
   for (int yy = max(cy - W, 0); yy <= min(cy + W, g.ny - 1); ++yy) {
     const int beg = cellStart[yy * g.nx + x_lo], end = cellStart[yy * g.nx + x_hi + 1];
@@ -205,16 +218,30 @@ __global__ void __launch_bounds__(256) k_neighbours(int N, GridP g, Flags f, con
       if (MODE && hit) {
         const unsigned long long below = (1ull << lane) - 1;
         if (j < i) { nbr[baseLo + nLo + __popcll(mLo & below)] = j; if (j < minj) minj = j; }
-        else nbr[baseHi + nHi + __popcll(mHi & below)] = j;
+        else if (MODE == 1) nbr[baseHi + nHi + __popcll(mHi & below)] = j;
+        else nbr[baseHi - (nHi + __popcll(mHi & below))] = j;
       }
       nLo += __popcll(mLo); nHi += __popcll(mHi);
     }
   }
   if (!MODE && lane == 0) { nbrCount[i] = nLo + nHi; nbrLow[i] = nLo; }
+  if (MODE == 2 && lane == 0) nbrLow[i] = nLo;          // (the total is summed by k_sum_halves: one atomic per candidate on one word serialises at the L2)
+  if (MODE && lane == 0) nbrCount[i] = nHi;            // from here on nbrCount holds the size of the worse-scored half (k_round_emit)
   if (MODE) {
     for (int o = 32; o; o >>= 1) minj = min(minj, __shfl_xor(minj, o));
     if (lane == 0) waitOn[i] = (minj < i) ? minj : WAIT_NONE;
   }
+}
+
+// exact number of list entries of the single-pass form: sum of both halves' sizes, one atomic per workgroup
+__global__ void __launch_bounds__(256) k_sum_halves(const int* __restrict__ nLow, const int* __restrict__ nHigh, int N, unsigned long long* total) {
+  __shared__ unsigned long long ws[4];
+  unsigned long long v = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) v += (unsigned long long)(nLow[i] + nHigh[i]);
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(total, ws[0] + ws[1] + ws[2] + ws[3]);
 }
 
 // Round kernel A1: thread per undecided candidate, O(1): waitOn[i] is the higher-scored neighbour i was last seen waiting
@@ -292,7 +319,7 @@ __global__ void __launch_bounds__(256) k_round_scan(const int* __restrict__ S, c
 
 // Round kernel B: wave per new survivor: mark it, emit the pairs the reference would evaluate.
 __global__ void __launch_bounds__(256) k_round_emit(const int* __restrict__ K, const int* __restrict__ nKPtr, unsigned char* __restrict__ state,
-                                                    const i64* __restrict__ nbrStart, const int* __restrict__ nbrLow, const int* __restrict__ nbr, Flags f,
+                                                    const i64* __restrict__ nbrStart, const int* __restrict__ nbrHigh, const int* __restrict__ nbr, Flags f,
                                                     const float* __restrict__ pts, const int4* __restrict__ bbox,
                                                     const float* __restrict__ radius, const float* __restrict__ area,
                                                     int2* __restrict__ pairs, unsigned long long* pairCount,
@@ -302,7 +329,7 @@ __global__ void __launch_bounds__(256) k_round_emit(const int* __restrict__ K, c
   for (int w = blockIdx.x * (blockDim.x >> 6) + wave; w < nK; w += gridDim.x * (blockDim.x >> 6)) {
   const int i = K[w];
   if (lane == 0) state[i] = ST_KEPT;
-  const i64 beg = nbrStart[i] + nbrLow[i], end = nbrStart[i + 1];      // the neighbours scored below i
+  const i64 end = nbrStart[i + 1], beg = end - nbrHigh[i];             // the neighbours scored below i (the back of i's slot)
   const int4 bi = bbox[i];
   const float pyi = pts[2 * i], pxi = pts[2 * i + 1];
   const float rad = f.max_dist + radius[i];
@@ -896,22 +923,40 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   void* scanTmp = A.take(tmpBytes + 256);
   if (!scanTmp) return -1;
   SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tmpBytes, cellCount, cellStart, nCells + 1, s));
-  hipLaunchKernelGGL(k_cell_fill, dim3(sd::div_up(N, 256)), dim3(256), 0, s, N, candCell, cellStart, cellFill, d_points, bbox, area, cellRec);
+  // Neighbour lists in ONE pass (option "nms2d_neighbours_single_pass", default 1): every candidate gets a slot as large as the population
+  // of the cells its list is built from (known from the cell table: no candidate test needed), the lists are written into the slots --
+  // better-scored neighbours from the front, the others from the back -- and the exact total is counted on the way.  The two-pass form
+  // (count, scan, fill: every candidate test done twice, 1.2 + 0.8 ms at 2048^2) remains for inputs whose slots would exceed 32-bit indices.
+  const bool singlePass = sd::option(sd::OPT_NMS2D_NBR_SINGLE) != 0;
+  SD_CHECK(hipMemsetAsync(nbrCount, 0, (N + 1) * sizeof(int), s));
+  hipLaunchKernelGGL(k_cell_fill, dim3(sd::div_up(N, 256)), dim3(256), 0, s, N, candCell, cellStart, cellFill, d_points, bbox, area, cellRec, g, W,
+                     singlePass ? nbrCount : (int*)nullptr);
   SD_LAUNCH_CHECK();
 
   Flags f;
   f.use_kdtree = use_kdtree; f.use_bbox = use_bbox; f.thr_nonneg = (threshold >= 0.f); f.thr = threshold; f.max_dist = max_dist;
 
   // ---- neighbour CSR
-  SD_CHECK(hipMemsetAsync(nbrCount, 0, (N + 1) * sizeof(int), s));
   const int nbBlocks = (sd::div_up(N, 4) + 7) & ~7;
-  hipLaunchKernelGGL((k_neighbours<0>), dim3(nbBlocks), dim3(256), 0, s, N, g, f, cellRec, cellStart, nbrCount, nbrLow, (const i64*)nullptr, (int*)nullptr,
-                     (int*)nullptr, W);
-  SD_LAUNCH_CHECK();
-  SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tmpBytes, nbrCount, nbrStart, N + 1, s));
-  i64 totalNbr = 0;
-  SD_CHECK(hipMemcpyAsync(&totalNbr, nbrStart + N, sizeof(i64), hipMemcpyDeviceToHost, s));
-  SD_CHECK(hipStreamSynchronize(s));
+  i64 totalNbr = 0, slotTotal = 0;
+  bool slots = false;
+  unsigned long long* d_total = A.take_n<unsigned long long>(1);
+  if (!d_total) return -1;
+  if (singlePass) {
+    SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tmpBytes, nbrCount, nbrStart, N + 1, s));
+    SD_CHECK(hipMemcpyAsync(&slotTotal, nbrStart + N, sizeof(i64), hipMemcpyDeviceToHost, s));
+    SD_CHECK(hipStreamSynchronize(s));
+    slots = slotTotal >= 0 && slotTotal < (i64)0x7fffffff;
+  }
+  if (!slots) {
+    SD_CHECK(hipMemsetAsync(nbrCount, 0, (N + 1) * sizeof(int), s));
+    hipLaunchKernelGGL((k_neighbours<0>), dim3(nbBlocks), dim3(256), 0, s, N, g, f, cellRec, cellStart, nbrCount, nbrLow, (const i64*)nullptr, (int*)nullptr,
+                       (int*)nullptr, W, (unsigned long long*)nullptr);
+    SD_LAUNCH_CHECK();
+    SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tmpBytes, nbrCount, nbrStart, N + 1, s));
+    SD_CHECK(hipMemcpyAsync(&totalNbr, nbrStart + N, sizeof(i64), hipMemcpyDeviceToHost, s));
+    SD_CHECK(hipStreamSynchronize(s));
+  }
   // capacity of one call: neighbour lists and pair queues are indexed with 32 bits.  Beyond it (about 13 M candidates at the density
   // of the 2048^2 bench set) the input has to be sharded -- predict_instances_sharded / predict_instances_big do exactly that.
   if (totalNbr < 0 || totalNbr >= (i64)0x7fffffff) {
@@ -919,11 +964,23 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
                   "(predict_instances_sharded / predict_instances_big)", (long long)totalNbr, N);
     return -1;
   }
-  int* nbr = A.take_n<int>((size_t)totalNbr);
+  int* nbr = A.take_n<int>((size_t)(slots ? slotTotal : totalNbr));
   int* waitOn = A.take_n<int>(N);
   if (!nbr || !waitOn) return -1;
-  hipLaunchKernelGGL((k_neighbours<1>), dim3(nbBlocks), dim3(256), 0, s, N, g, f, cellRec, cellStart, nbrCount, nbrLow, (const i64*)nbrStart, nbr, waitOn, W);
-  SD_LAUNCH_CHECK();
+  if (slots) {
+    SD_CHECK(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL((k_neighbours<2>), dim3(nbBlocks), dim3(256), 0, s, N, g, f, cellRec, cellStart, nbrCount, nbrLow, (const i64*)nbrStart, nbr, waitOn, W, d_total);
+    hipLaunchKernelGGL(k_sum_halves, dim3(sd::div_up(N, 256) < 1024 ? sd::div_up(N, 256) : 1024), dim3(256), 0, s, nbrLow, nbrCount, N, d_total);
+    SD_LAUNCH_CHECK();
+    unsigned long long tot = 0;
+    SD_CHECK(hipMemcpyAsync(&tot, d_total, sizeof(tot), hipMemcpyDeviceToHost, s));
+    SD_CHECK(hipStreamSynchronize(s));
+    totalNbr = (i64)tot;
+  } else {
+    hipLaunchKernelGGL((k_neighbours<1>), dim3(nbBlocks), dim3(256), 0, s, N, g, f, cellRec, cellStart, nbrCount, nbrLow, (const i64*)nbrStart, nbr, waitOn, W,
+                       (unsigned long long*)nullptr);
+    SD_LAUNCH_CHECK();
+  }
 
   // (the prepared polygons are being written on the side stream meanwhile; the sweep kernels are their first readers and wait for
   // evPrep in run_pairs -- with the shortcut on, the decision kernel of round 1 runs before that and only needs the properties)
@@ -1125,7 +1182,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
     hipLaunchKernelGGL(k_round_triage, dim3(sd::div_up(nU, 256)), dim3(256), 0, s, Ucur, nU, state, waitOn, Unext, K, Sl, (int*)d_cnt, dfr.pend);
     const int wgrid = sd::div_up(nU, 4) < 2048 ? sd::div_up(nU, 4) : 2048;
     hipLaunchKernelGGL(k_round_scan, dim3(wgrid), dim3(256), 0, s, Sl, state, nbrStart, nbrLow, nbr, waitOn, Unext, K, (int*)d_cnt, dfr.pend);
-    hipLaunchKernelGGL(k_round_emit, dim3(wgrid), dim3(256), 0, s, K, &d_cnt->nK, state, nbrStart, nbrLow, nbr, f, d_points, bbox,
+    hipLaunchKernelGGL(k_round_emit, dim3(wgrid), dim3(256), 0, s, K, &d_cnt->nK, state, nbrStart, nbrCount, nbr, f, d_points, bbox,
                        radius, area, pairs, &d_cnt->nPairs, pairCap);
     SD_LAUNCH_CHECK();
     if (run_pairs(nullptr)) return -1;

@@ -265,6 +265,53 @@ extern "C" int sd_bias_act_dot_device(const float* d_in, float* d_out, const flo
   return 0;
 }
 
+// second stage of the fused one-channel head (conv3x3_f16.hip store_tile<.., DOT> wrote, per pixel, the LPP = n_channels / 4 per-lane terms
+// of k_bias_act_dot): the terms of a pixel are added in the order of that kernel's xor butterfly -- d[s] += d[s ^ o] for o = LPP / 2 .. 1,
+// i.e. first across the 32-channel groups (o >= 8, in registers: term s = g * 8 + c of lane c), then across the 8 lanes of a group -- then
+// the head's bias and (sigm) the logistic function: bit-identical to k_bias_act_dot on the same features.
+template <int G>
+__global__ void __launch_bounds__(256) k_dot_combine(const float* __restrict__ part, long long n_pix, const float* __restrict__ wb, int sigm,
+                                                     float* __restrict__ out) {
+  const int c = threadIdx.x & 7;
+  const float w0 = wb ? wb[0] : 0.f;
+  const long long per = (long long)gridDim.x * 32;
+  for (long long p0 = (long long)blockIdx.x * 32; p0 < n_pix; p0 += per) {
+    const long long p = p0 + (threadIdx.x >> 3);
+    float v[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v[g] = p < n_pix ? part[(size_t)p * (G * 8) + g * 8 + c] : 0.f;
+#pragma unroll
+    for (int o = G / 2; o >= 1; o >>= 1) {
+      float t[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) t[g] = v[g] + v[g ^ o];
+#pragma unroll
+      for (int g = 0; g < G; ++g) v[g] = t[g];
+    }
+    float d = v[0];
+    d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 1, 64);
+    if (c == 0 && p < n_pix) {
+      d += w0;
+      out[p] = sigm ? 1.f / (1.f + expf(-d)) : d;
+    }
+  }
+}
+
+extern "C" int sd_dot_combine_device(const float* d_partial, int groups, long long n_pix, const float* d_wbias, int sigmoid, float* d_out, void* stream_) {
+  if (n_pix <= 0) return 0;
+  if (!d_partial || !d_out || (groups != 1 && groups != 2 && groups != 4 && groups != 8)) { sd::set_error("sd_dot_combine: groups must be 1, 2, 4 or 8"); return -1; }
+  long long blocks = (n_pix + 31) / 32;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  const dim3 gd((unsigned int)blocks), bd(256);
+  hipStream_t s = (hipStream_t)stream_;
+  if (groups == 1) hipLaunchKernelGGL(k_dot_combine<1>, gd, bd, 0, s, d_partial, n_pix, d_wbias, sigmoid, d_out);
+  else if (groups == 2) hipLaunchKernelGGL(k_dot_combine<2>, gd, bd, 0, s, d_partial, n_pix, d_wbias, sigmoid, d_out);
+  else if (groups == 4) hipLaunchKernelGGL(k_dot_combine<4>, gd, bd, 0, s, d_partial, n_pix, d_wbias, sigmoid, d_out);
+  else hipLaunchKernelGGL(k_dot_combine<8>, gd, bd, 0, s, d_partial, n_pix, d_wbias, sigmoid, d_out);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int sd_head_rows_device(const float* d_feat, int n_channels, const long long* d_rows, long long n_rows, const float* d_w, const float* d_bias,
                                    int n_out, float clamp_min, float* d_out, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;

@@ -77,6 +77,8 @@ SIGNATURES = {
     "sd_conv3_f16x3_pack_weights_host": (_i, [_vp, _i, _i, _i, _vp]),
     "sd_conv3_f16x3_ndhwc_device": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "sd_conv3_f16x3_res_ndhwc_device": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "sd_conv3_f16x3_dot_ndhwc_device": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sd_dot_combine_device": (_i, [_vp, _i, ctypes.c_longlong, _vp, _i, _vp, _vp]),
     "_LIB_non_maximum_suppression_2d": (None, [_vp, _vp, _i, _i, _f, _i, _i, _i, _vp]),
     "_LIB_polygon_to_label": (None, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "_LIB_star_dist": (None, [_vp, _i, _i, _i, _i, _i, _vp]),

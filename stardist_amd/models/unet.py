@@ -220,12 +220,14 @@ def _general_conv(conv, x, kind, res=None, bn=None, tf_same=False):
 _MAX_CHUNK_CHANNELS = 512          # csrc/conv3x3_layout.h MAX_CHUNKS * 32
 
 
-def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False):
+def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False, dot=None):
     """act(conv(cat(srcs, 1)) + bias (+ res)) by a hand-written kernel; srcs = [(tensor (1, C, *spatial) channels-last float32, up)] with
     up = per-axis tuple of 0/1 (or one int for all axes): 1 where the source has half the output resolution and the reference
     up-samples it (nearest, x2) first.  res: residual added before the activation (resnet_block's Add); bn: inference batch-norm layer
     between convolution and activation (folded into kernel and bias).  3x3(x3) stride-1 'same' layers over 32-channel chunks (and the
     one-channel first layer) go to csrc/conv3x3*.hip, everything else with one full-resolution source to csrc/conv_general.hip.
+    dot = (weights (c_out,), holder list): a one-channel head fused into the layer's epilogue when the split-fp16 kernel takes the layer
+    (sd_conv3_f16x3_dot_ndhwc_device) -- holder[0] then receives the per-lane terms (n_pix, c_out / 4); left empty otherwise.
     None when the layer is not covered (the callers raise UnsupportedLayer)."""
     nd = 2 if isinstance(conv, nn.Conv2d) else (3 if isinstance(conv, nn.Conv3d) else 0)
     if not (nd and kind in (0, 1) and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
@@ -279,6 +281,12 @@ def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False):
             co if res is not None else 0, co, kind, ctypes.c_void_p(out.data_ptr())]
     if form == "f16x3":
         args.append(ctypes.c_void_p(range_flag(a.device).data_ptr()))
+        if dot is not None and res is None and dot[0].numel() == co and dot[0].data_ptr() % 16 == 0:
+            part = torch.empty((D * H * W, co // 4), dtype=torch.float32, device=a.device)
+            dargs = args[:14] + args[16:] + [ctypes.c_void_p(dot[0].data_ptr()), ctypes.c_void_p(part.data_ptr())]      # (no residual arguments)
+            N.dcall(a, "sd_conv3_f16x3_dot_ndhwc_device", *dargs)
+            dot[1].append(part)
+            return out
     N.dcall(a, _FORM_PREFIX[form] + "_res_ndhwc_device", *args)
     return out
 
@@ -608,12 +616,20 @@ class StarDistNet(nn.Module):
         wp = self.prob.weight.detach().reshape(-1).contiguous()
         bp = self.prob.bias
         prob = torch.empty((1, 1) + S, dtype=torch.float32, device=base.device)
-        feat = _hand_conv(conv, [(base, 0)], kind)            # features conv with bias + activation fused (64-bit indexing: no slabs)
+        holder = []
+        # features conv with bias + activation fused (64-bit indexing: no slabs); the split-fp16 kernel also takes the probability head's
+        # dot product over each workgroup's 32 channels while the tile is in registers
+        feat = _hand_conv(conv, [(base, 0)], kind, dot=(wp, holder))
         if feat is None:
             raise UnsupportedLayer("features " + _layer_desc(conv, [(base, 0)]))
-        # ... then the probability head alone: one read of the features
-        N.dcall(feat, "sd_bias_act_dot_device", ctypes.c_void_p(feat.data_ptr()), None, None, int(np.prod(S)), C, 0, ctypes.c_void_p(wp.data_ptr()),
-                ctypes.c_void_p(bp.data_ptr() if bp is not None else None), 1, ctypes.c_void_p(prob.data_ptr()))
+        if holder:
+            # ... the per-lane terms -> probabilities, bit-identical to sd_bias_act_dot_device on the same features, which are not re-read
+            N.dcall(feat, "sd_dot_combine_device", ctypes.c_void_p(holder[0].data_ptr()), C // 32, int(np.prod(S)),
+                    ctypes.c_void_p(bp.data_ptr() if bp is not None else None), 1, ctypes.c_void_p(prob.data_ptr()))
+        else:
+            # ... then the probability head alone: one read of the features
+            N.dcall(feat, "sd_bias_act_dot_device", ctypes.c_void_p(feat.data_ptr()), None, None, int(np.prod(S)), C, 0, ctypes.c_void_p(wp.data_ptr()),
+                    ctypes.c_void_p(bp.data_ptr() if bp is not None else None), 1, ctypes.c_void_p(prob.data_ptr()))
         if sparse_head:
             return prob, feat
         R = self.dist.out_channels

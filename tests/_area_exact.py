@@ -91,7 +91,18 @@ def plain(X, Y):
         # neighbours: fold-back
         ex, ey = np.roll(x, -1) - x, np.roll(y, -1) - y
         fx, fy = np.roll(ex, -1), np.roll(ey, -1)
-        if ((ex * fy - ey * fx == 0) & (ex * fx + ey * fy < 0)).any(): out[i] = False
+        if ((ex * fy - ey * fx == 0) & (ex * fx + ey * fy < 0)).any(): out[i] = False; continue
+        # robustly simple (round 5): no vertex (of the ORIGINAL list, duplicates included) within HALF a lattice step, along its scan line, of an
+        # edge it is not an end point of
+        vx, vy = X[i][:, None], Y[i][:, None]                               # vertices on axis 0
+        ax, ay = x[None, :], y[None, :]; bx, by = np.roll(x, -1)[None, :], np.roll(y, -1)[None, :]   # edges (non-degenerate by construction) on axis 1
+        endp = ((ax == vx) & (ay == vy)) | ((bx == vx) & (by == vy))
+        inr = (vy >= np.minimum(ay, by)) & (vy <= np.maximum(ay, by))
+        hor = ay == by
+        risk_h = hor & (vx >= np.minimum(ax, bx)) & (vx <= np.maximum(ax, bx))
+        num = (ax - vx) * (by - ay) + (vy - ay) * (bx - ax)
+        risk_s = (~hor) & (2 * np.abs(num) <= np.abs(by - ay))                       # |x_edge(vy) - vx| <= 1/2: the rounded abscissae tie
+        if (~endp & inr & (risk_h | risk_s)).any(): out[i] = False
     return out
 
 

@@ -137,3 +137,49 @@ def test_model_sparse_head_equals_dense_prediction(dim):
         idx = tuple(want_pts.T)
         assert np.array_equal(ps, prob[idx])
         assert np.array_equal(ds, np.maximum(dist[idx], 1e-3))
+
+
+@pytest.mark.parametrize("nd,shape,co", [(2, (37, 70), 128), (2, (64, 64), 32), (3, (5, 19, 33), 128), (3, (8, 16, 40), 64), (2, (40, 33), 256)])
+def test_fused_probability_head_in_the_features_epilogue(nd, shape, co):
+    """sd_conv3_f16x3_dot_ndhwc_device + sd_dot_combine_device (the probability head's first stage taken from the features layer's tile while
+    it is in registers): the features are bit-identical to the plain layer's, the per-lane terms are the 4-channel dot products of the
+    stored features (float64, <= 1e-5 of the scale), and the combined head equals sd_bias_act_dot_device on those features BIT FOR BIT
+    (and sigmoid(features . w + b) to 2e-6) -- ragged tiles included"""
+    import torch
+    import torch.nn as nn
+    from stardist_amd.lib import _native as N
+    from stardist_amd.models import unet
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(nd * 100 + co)
+    Conv = nn.Conv2d if nd == 2 else nn.Conv3d
+    conv = Conv(32, co, (3,) * nd, padding=1).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_((torch.randn(conv.weight.shape, generator=g) * 0.08).to(dev))
+        conv.bias.copy_((torch.randn(co, generator=g) * 0.1).to(dev))
+    cl = torch.channels_last if nd == 2 else torch.channels_last_3d
+    x = torch.randn((1, 32) + shape, generator=g).to(dev).contiguous(memory_format=cl)
+    w = (torch.randn(co, generator=g) * 0.2).to(dev)
+    wb = torch.randn(1, generator=g).to(dev)
+    with torch.no_grad(), unet.force_conv_mode("f16x3"):
+        plain = unet._hand_conv(conv, [(x, 0)], 1)
+        holder = []
+        feat = unet._hand_conv(conv, [(x, 0)], 1, dot=(w, holder))
+    assert plain is not None and feat is not None and len(holder) == 1
+    assert torch.equal(plain, feat)
+    n_pix = int(np.prod(shape))
+    part = holder[0]
+    assert tuple(part.shape) == (n_pix, co // 4)
+    f32 = feat.permute(*([0] + list(range(2, nd + 2)) + [1])).reshape(n_pix, co).contiguous()
+    f = f32.double()
+    ref_terms = (f * w.double()).reshape(n_pix, co // 4, 4).sum(-1)
+    assert float((part.double() - ref_terms).abs().max()) <= 1e-5 * max(1.0, float(ref_terms.abs().max()))
+    for sigm in (1, 0):
+        prob = torch.full((n_pix,), float("nan"), device=dev)
+        N.dcall(part, "sd_dot_combine_device", _vp(part), co // 32, n_pix, _vp(wb), sigm, _vp(prob))
+        two_pass = torch.full((n_pix,), float("nan"), device=dev)
+        N.dcall(f32, "sd_bias_act_dot_device", _vp(f32), None, None, n_pix, co, 0, _vp(w), _vp(wb), sigm, _vp(two_pass))
+        assert torch.equal(prob, two_pass)
+        ref = f @ w.double() + wb.double()
+        if sigm:
+            ref = torch.sigmoid(ref)
+        assert float((prob.double() - ref).abs().max()) <= (2e-6 if sigm else 2e-5)

@@ -286,3 +286,20 @@ def test_nms2d_old_python_path_equals_new(refmods):
         assert len(points1) == len(points2)
         assert np.allclose(points1, points2)
         assert np.allclose(img1 > 0, img2 > 0)
+
+
+def test_nms2d_neighbour_list_forms_agree(refmods):
+    """the single-pass neighbour lists (slots sized from the cell table, option nms2d_neighbours_single_pass = 1, the default) and the two-pass
+    count / scan / fill form give the reference's survivors -- incl. the all-pairs flags and a set far from the origin"""
+    from oracle import synth
+    from stardist_amd.lib import _native
+    from stardist_amd.lib import stardist2d as sd2
+    for shape, R, thr, off in (((300, 280), 32, 0.4, 0.0), ((200, 231), 17, 0.3, 9000.0)):
+        d, p, s = synth.s2d_uniform(shape[0], shape[1], n_rays=R, prob_thresh=0.85)
+        p = np.ascontiguousarray(p + np.float32(off))
+        for kd, bb in ((1, 1), (0, 1), (1, 0)):
+            ref_keep = refmods.stardist2d().c_non_max_suppression_inds(d, p, kd, bb, 0, np.float32(thr))
+            for form in (1, 0):
+                with _native.option("nms2d_neighbours_single_pass", form):
+                    keep, st = sd2.c_non_max_suppression_inds(d, p, kd, bb, 0, np.float32(thr), return_stats=True)
+                assert np.array_equal(keep, ref_keep), (shape, kd, bb, form, np.flatnonzero(keep != ref_keep)[:8])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, first GPU call: the new legacy-NMS tests, the device timeline of one 2D / 3D step (kernels + copies), a short bench with the host-input and strict legs
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r05a; mkdir -p $O; cd $R; ulimit -c 0
-( time timeout 300 python -m pytest tests/test_gpu_parity2d.py -m gpu -q -x -k "old" 2>&1 | tail -8 ) > $O/tests_old.log 2>&1
+( time timeout 600 python -m pytest tests -m gpu -q -x 2>&1 | tail -15 ) > $O/tests_all.log 2>&1
 cd /tmp; export TMPDIR=/tmp
 for W in 2d 3d; do
   rm -rf /tmp/tl_$W
@@ -10,4 +10,4 @@ for W in 2d 3d; do
 done
 cd $R
 timeout 400 python bench.py --gpus 1 --steps 10 --warmup 3 --no-sharded --no-split-leg --no-cpu-baseline > $O/bench_short.json 2> $O/bench_short.err
-tail -3 $O/tests_old.log; head -3 $O/step_timeline_2d.txt | cut -c1-300; head -3 $O/step_timeline_3d.txt | cut -c1-300; cut -c1-600 $O/bench_short.json; tail -5 $O/bench_short.err
+tail -4 $O/tests_all.log; head -3 $O/step_timeline_2d.txt | cut -c1-300; head -3 $O/step_timeline_3d.txt | cut -c1-300; cut -c1-600 $O/bench_short.json; tail -5 $O/bench_short.err
