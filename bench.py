@@ -385,7 +385,8 @@ def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, di
            "input_shape": list(big.shape), "block_size": block, "min_overlap": overlap, "context": context, "blocks": sum(p["blocks"] for p in per_rank),
            "redundancy": round(sum(p["blocks"] for p in per_rank) * float(block) ** big.dim() / n, 3),
            "instances": r0["instances"], "candidates": sum(p["candidates"] for p in per_rank),
-           "gathered_survivors": r0["gathered"], "gathered_bytes": r0["gathered_bytes"], "band_survivors": r0["band"], "interior_survivors": r0["interior"],
+           "gathered_survivors": r0["gathered"], "gathered_bytes": r0["gathered_bytes"], "exact_record_bytes": r0.get("exact_record_bytes", 0),
+           "band_survivors": r0["band"], "interior_survivors": r0["interior"],
            "t_phase1": max(p["t_phase1"] for p in per_rank),
            "t_predict": max(p["t_predict"] for p in per_rank), "t_local_nms": max(p["t_local_nms"] for p in per_rank), "t_exchange": r0["t_exchange"],
            "t_final": r0["t_final"], "t_final_nms": r0["t_final_nms"], "t_raster": max(p["t_raster"] for p in per_rank),

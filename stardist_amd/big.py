@@ -577,60 +577,93 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
     st["t_phase1"] = st["t_predict"] + st["t_local_nms"]
     rec = torch.cat(recs) if recs else torch.zeros((0, W), dtype=torch.float32, device=dev)
 
-    # ---- phase 2: one gather of the records to rank 0 (counts first; padded to the largest rank)
+    # ---- phase 2: interior / band split ON THE OWNERS, then one exact-size exchange of the records to rank 0.
+    # Two survivors of one block never suppress each other (the local NMS kept both), so a survivor whose bounding box, grown by the
+    # largest bounding radius of ALL survivors (+1), stays inside the part of its block's write region that no other block's write region
+    # covers can neither suppress nor be suppressed, nor be reported twice: it is final ("interior").  The owner decides that from its
+    # own records and ONE scalar all_reduce(MAX) of the bounding radius; only the remaining "band" records are de-duplicated and run
+    # through the NMS again on rank 0.
     t0 = tick()
     cdev = dev
     if multi:
         cdev = dev if dist_.get_backend() == "nccl" else torch.device("cpu")
-        cnt = torch.tensor([rec.shape[0]], dtype=torch.int64, device=cdev)
+    vmax = 1.0
+    if nd == 3:
+        from .rays3d import rays_from_json
+        vmax = float(np.abs(rays_from_json(model.config.rays_json).vertices).max())
+    rad = rec[:, :R].amax(dim=1).double() * vmax + 1.0 if rec.shape[0] else torch.zeros((0,), dtype=torch.float64, device=dev)
+    rmax = torch.tensor([float(rad.max()) if rec.shape[0] else 0.0], dtype=torch.float64, device=cdev)   # (+1 above: integer truncation / rounding of vertices)
+    if multi:
+        dist_.all_reduce(rmax, op=dist_.ReduceOp.MAX)
+    if rec.shape[0]:
+        margin = (rad + float(rmax.item()) + 1.0).reshape(-1, 1)
+        ex = torch.from_numpy(_exclusive_intervals(blocks, axes_out)).to(dev)[rec[:, c_blk].to(torch.int64)]   # (n, nd, 2)
+        c = rec[:, c_pts:c_pts + nd].double()
+        is_int = torch.all((c - margin >= ex[:, :, 0]) & (c + margin < ex[:, :, 1]), dim=1)
+        rec = torch.cat([rec[is_int], rec[~is_int]])                # interior records first
+        n_int = int(is_int.sum())
+    else:
+        n_int = 0
+    n_loc = int(rec.shape[0])
+    ints, bands = [rec[:n_int]], [rec[n_int:]]
+    if multi:
+        cnt = torch.tensor([n_int, n_loc - n_int], dtype=torch.int64, device=cdev)
         cnts = [torch.zeros_like(cnt) for _ in range(world)]
         dist_.all_gather(cnts, cnt)
-        cnts = [int(c.item()) for c in cnts]
-        cap = max(max(cnts), 1)
-        buf = torch.zeros((cap, W), dtype=torch.float32, device=cdev)
-        buf[:rec.shape[0]] = rec.to(cdev)
-        out = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-        dist_.gather(buf, out, dst=0)
+        cnts = [(int(c[0].item()), int(c[1].item())) for c in cnts]
+        # exact sizes, point to point (RCCL over xGMI: the senders use their own links to rank 0 in parallel): no padding to the largest rank
+        ops, bufs = [], {}
         if rank == 0:
-            rec = torch.cat([o[:c] for o, c in zip(out, cnts)]).to(dev)
-        st["gathered_bytes"] = int(sum(cnts)) * W * 4
-        st["gathered"] = int(sum(cnts))
+            for r in range(1, world):
+                if sum(cnts[r]):
+                    bufs[r] = torch.empty((sum(cnts[r]), W), dtype=torch.float32, device=cdev)
+                    ops.append(dist_.P2POp(dist_.irecv, bufs[r], r))
+        elif n_loc:
+            ops.append(dist_.P2POp(dist_.isend, rec.to(cdev).contiguous(), 0))
+        if ops:
+            for q in dist_.batch_isend_irecv(ops):
+                q.wait()
+        if rank == 0:
+            for r in range(1, world):
+                if r in bufs:
+                    b = bufs[r].to(dev)
+                    ints.append(b[:cnts[r][0]]); bands.append(b[cnts[r][0]:])
+        st["gathered"] = int(sum(a + b for a, b in cnts))
+        st["gathered_bytes"] = int(sum((a + b) for r, (a, b) in enumerate(cnts) if r != 0)) * W * 4      # what actually crosses a link
+        st["exact_record_bytes"] = st["gathered"] * W * 4
     else:
-        st["gathered"] = int(rec.shape[0])
+        st["gathered"] = n_loc
     st["t_exchange"] = tick() - t0
 
-    # ---- phase 3 (rank 0): duplicates, interior / band split, cross-tile NMS over the band, global score order
+    # ---- phase 3 (rank 0): duplicates among the band records, cross-tile NMS over the band, global score order
     t0 = tick()
     final = None
     if rank == 0:
-        order = torch.sort(rec[:, c_blk], stable=True)[1]           # canonical order (block index, then the block's score order):
-        rec = rec[order]                                            # the result does not depend on the number of ranks
-        pts = rec[:, c_pts:c_pts + nd].to(torch.int64)
-        if rec.shape[0]:                                            # same pixel reported by two overlapping blocks: keep the first
-            key = pts[:, 0]
+        rint, rband = torch.cat(ints), torch.cat(bands)
+        order = torch.sort(rband[:, c_blk], stable=True)[1]         # canonical order (block index, then the block's score order):
+        rband = rband[order]                                        # the result does not depend on the number of ranks
+
+        def pixel_key(r):
+            p = r[:, c_pts:c_pts + nd].to(torch.int64)
+            key = p[:, 0]
             for d in range(1, nd):
-                key = key * int(shape_out[d]) + pts[:, d]
-            ks, ki = torch.sort(key, stable=True)
+                key = key * int(shape_out[d]) + p[:, d]
+            return key
+        if rband.shape[0]:                                          # same pixel reported by two overlapping blocks: keep the first
+            ks, ki = torch.sort(pixel_key(rband), stable=True)
             first = torch.ones_like(ks, dtype=torch.bool)
             first[1:] = ks[1:] != ks[:-1]
-            # ... and the records in row-major pixel order: candidates of EQUAL score are then taken by every later sort (stable
-            # ascending, reversed: nms._argsort_desc) in the order predict_instances on the whole image takes them, whatever the blocks
-            sel = ki[first]
-            rec, pts = rec[sel], pts[sel]
+            rband = rband[ki[first]]
+        # all unique records in row-major pixel order: candidates of EQUAL score are then taken by every later sort (stable ascending,
+        # reversed: nms._argsort_desc) in the order predict_instances on the whole image takes them, whatever the blocks
+        rec = torch.cat([rint, rband])
+        interior = torch.cat([torch.ones(rint.shape[0], dtype=torch.bool, device=dev), torch.zeros(rband.shape[0], dtype=torch.bool, device=dev)])
+        if rec.shape[0]:
+            ki = torch.sort(pixel_key(rec), stable=True)[1]
+            rec, interior = rec[ki], interior[ki]
+        pts = rec[:, c_pts:c_pts + nd].to(torch.int64)
         nU = int(rec.shape[0])
         st["unique"] = nU
-        if nU:
-            vmax = 1.0
-            if nd == 3:
-                from .rays3d import rays_from_json
-                vmax = float(np.abs(rays_from_json(model.config.rays_json).vertices).max())
-            rad = rec[:, :R].amax(dim=1).double() * vmax + 1.0      # bounding radius per axis (+1: integer truncation / rounding of vertices)
-            margin = (rad + float(rad.max()) + 1.0).reshape(-1, 1)
-            ex = torch.from_numpy(_exclusive_intervals(blocks, axes_out)).to(dev)[rec[:, c_blk].to(torch.int64)]   # (nU, nd, 2)
-            c = pts.double()
-            interior = torch.all((c - margin >= ex[:, :, 0]) & (c + margin < ex[:, :, 1]), dim=1)
-        else:
-            interior = torch.zeros((0,), dtype=torch.bool, device=dev)
         band = torch.nonzero(~interior).reshape(-1)
         st["band"], st["interior"] = int(band.numel()), nU - int(band.numel())
         t1 = tick()

@@ -858,8 +858,6 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   SD_CHECK(hipEventCreateWithFlags(&evFork, hipEventDisableTiming));
   SD_CHECK(hipEventCreateWithFlags(&evJoin, hipEventDisableTiming));
   EvGuard evguardFJ{evFork, evJoin};
-  SD_CHECK(hipEventRecord(evFork, s));
-  SD_CHECK(hipStreamWaitEvent(side, evFork, 0));
   // polygon properties of the decision shortcut (area_bounds.h) first: they also depend on the integer vertices only, and the
   // decision kernel of the first round needs them before any sweep needs a prepared polygon (evProps / evPrep)
   const bool areaBounds = R <= 32 && R >= 3 && sd::option(sd::OPT_NMS2D_AREA_BOUNDS) != 0 && sd::option(sd::OPT_NMS2D_STRICT) == 0;
@@ -871,20 +869,28 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   if (areaBounds) {
     props = (sdarea::PolyProps*)A.take((size_t)N * sizeof(sdarea::PolyProps));
     if (!props) return -1;
-    hipLaunchKernelGGL(sdarea::k_poly_props, dim3(sd::div_up(N, 8)), dim3(256), 0, side, vx, vy, N, R, props);
-    SD_LAUNCH_CHECK();
   }
-  SD_CHECK(hipEventRecord(evProps, side));
-  {
+  // The helper stream's two kernels are enqueued once the LAST read-back of the grid set-up is behind us (launch_side below): k_poly_props
+  // fills every wave slot of the chip, and an 8-byte device -> host copy of the caller's stream issued while it runs waits for a slot
+  // until it drains (measured: 0.69 ms for that copy, the neighbour-list kernel started 0.7 ms late; profiles/r05_step_timeline_2d.txt).
+  auto launch_side = [&]() -> int {
+    SD_CHECK(hipEventRecord(evFork, s));
+    SD_CHECK(hipStreamWaitEvent(side, evFork, 0));
+    if (areaBounds) {
+      hipLaunchKernelGGL(sdarea::k_poly_props, dim3(sd::div_up(N, 8)), dim3(256), 0, side, vx, vy, N, R, props);
+      SD_LAUNCH_CHECK();
+    }
+    SD_CHECK(hipEventRecord(evProps, side));
     int rc;
     if (R <= 32) rc = BeamPath<32, 64>::prepare(vx, vy, N, R, prep, side);
     else if (R <= 64) rc = BeamPath<64, 64>::prepare(vx, vy, N, R, prep, side);
     else if (R <= 128) rc = BeamPath<128, 32>::prepare(vx, vy, N, R, prep, side);
     else rc = BeamPath<256, 16>::prepare(vx, vy, N, R, prep, side);
     if (rc) return -1;
-  }
-  SD_CHECK(hipEventRecord(evPrep, side));
-  SD_CHECK(hipEventRecord(evJoin, side));
+    SD_CHECK(hipEventRecord(evPrep, side));
+    SD_CHECK(hipEventRecord(evJoin, side));
+    return 0;
+  };
   int gs[8];
   SD_CHECK(hipMemcpyAsync(gs, gstats, sizeof(gs), hipMemcpyDeviceToHost, s));
   SD_CHECK(hipStreamSynchronize(s));
@@ -948,6 +954,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
     SD_CHECK(hipStreamSynchronize(s));
     slots = slotTotal >= 0 && slotTotal < (i64)0x7fffffff;
   }
+  if (slots && launch_side()) return -1;
   if (!slots) {
     SD_CHECK(hipMemsetAsync(nbrCount, 0, (N + 1) * sizeof(int), s));
     hipLaunchKernelGGL((k_neighbours<0>), dim3(nbBlocks), dim3(256), 0, s, N, g, f, cellRec, cellStart, nbrCount, nbrLow, (const i64*)nullptr, (int*)nullptr,
@@ -956,6 +963,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
     SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tmpBytes, nbrCount, nbrStart, N + 1, s));
     SD_CHECK(hipMemcpyAsync(&totalNbr, nbrStart + N, sizeof(i64), hipMemcpyDeviceToHost, s));
     SD_CHECK(hipStreamSynchronize(s));
+    if (launch_side()) return -1;
   }
   // capacity of one call: neighbour lists and pair queues are indexed with 32 bits.  Beyond it (about 13 M candidates at the density
   // of the 2048^2 bench set) the input has to be sharded -- predict_instances_sharded / predict_instances_big do exactly that.

@@ -301,28 +301,39 @@ class StarDistBase(object):
         return _permute_axes
 
     def _net_forward(self, x, sparse_head=False):
-        """_net_forward_once under the range guard of the default split-fp16 convolutions (models/unet.py conv_mode): the kernels OR a
-        device flag when an activation lies outside the fp16 range (|x| > 65504 or not finite).  The flag is read back after the pass
-        (one 4-byte copy); when it is set the outputs are discarded, a warning names the cause, and this pass and all later ones of
-        this model run the six-product bf16 form, which has f32 range."""
+        """_net_forward_once under the range guard of the default split-fp16 convolutions (models/unet.py conv_mode): every such layer ORs
+        ITS word of this model's flag tensor when an activation it reads lies outside the fp16 range (|x| > 65504 or infinite).  The words
+        are read back after the pass (one 1-KiB copy); when one is set the outputs are discarded, a warning names the layers and the
+        magnitude limit, exactly those layers are moved to the six-product bf16 form (f32 range) for the rest of the model's life, and the
+        pass is repeated -- the other layers stay on the fp16 form."""
         from . import unet
-        pinned = getattr(self, "_conv_mode_pin", None)
-        if self.device.type != "cuda" or pinned is not None or unet.conv_mode() != "f16x3":
-            if pinned is not None and unet.conv_mode() == "f16x3":
-                with unet.force_conv_mode(pinned):
-                    return self._net_forward_once(x, sparse_head)
+        if self.device.type != "cuda" or unet.conv_mode() != "f16x3":
             return self._net_forward_once(x, sparse_head)
-        flag = unet.range_flag(self.device)
-        flag.zero_()
-        ys = self._net_forward_once(x, sparse_head)
-        if int(flag.item()) == 0:
-            return ys
-        import warnings
-        warnings.warn("an activation of the network lies outside the fp16 range (|x| > 65504 or not finite): re-evaluating with the "
-                      "bf16x6 convolution kernels, which this model uses from now on")
-        self._conv_mode_pin = "bf16x6"
-        with unet.force_conv_mode("bf16x6"):
-            return self._net_forward_once(x, sparse_head)
+        import torch
+        flags = self.__dict__.get("_range_flags")
+        if flags is None:
+            flags = self._range_flags = torch.zeros(unet.N_FLAG_SLOTS, dtype=torch.int32, device=self.device)
+        for _ in range(64):
+            flags.zero_()
+            with unet.use_range_flags(flags):
+                ys = self._net_forward_once(x, sparse_head)
+            h = flags.cpu().numpy()
+            if not h.any():
+                return ys
+            bad = set(int(k) for k in np.flatnonzero(h))
+            names = []
+            for name, mod in self.net.named_modules():
+                if mod.__dict__.get("_sd_flag_slot") in bad and mod.__dict__.get("_sd_force_form") != "bf16x6":
+                    mod.__dict__["_sd_force_form"] = "bf16x6"
+                    names.append(name)
+            if not names:                                    # (a word no layer of this model owns: cannot happen)
+                raise RuntimeError("fp16 range flag set by an unknown layer")
+            self.__dict__.setdefault("_fp16_range_layers", []).extend(names)
+            self.__dict__.pop("_graphs", None)               # the captured passes launch the fp16 form of those layers
+            import warnings
+            warnings.warn("an activation read by layer(s) %s lies outside the fp16 range (|x| > 65504 or not finite): these layers use the "
+                          "bf16x6 convolution kernels from now on (the others keep the fp16 form)" % ", ".join(names))
+        raise RuntimeError("fp16 range fallback did not converge")
 
     def _net_forward_once(self, x, sparse_head=False):
         """x: torch tensor with axes_net semantics (channels last) -> tuple of channels-last outputs (prob, dist[, prob_class]).

@@ -83,11 +83,15 @@ class force_conv_mode(object):
 
 
 _range_flags = {}
+N_FLAG_SLOTS = 256
+_flag_stack = []
+_slot_counter = [0]
 
 
 def range_flag(device):
-    """the device word the split-fp16 convolutions OR with 1 when an activation lies outside the fp16 range (one per device; cleared
-    and read by StarDistBase._net_forward around a forward pass)"""
+    """the device word the split-fp16 convolutions OR with 1 when an activation they READ lies outside the fp16 range (|x| > 65504 or
+    infinite; a NaN simply propagates into the result as it does in any float32 evaluation) -- the default word, used by layers
+    evaluated outside a model's forward pass (one per device)"""
     device = torch.device(device)
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     t = _range_flags.get(key)
@@ -95,6 +99,39 @@ def range_flag(device):
         t = torch.zeros(1, dtype=torch.int32, device=device)
         _range_flags[key] = t
     return t
+
+
+class use_range_flags(object):
+    """context manager: inside it every split-fp16 layer reports into ITS OWN word of `flags` (int32 tensor of N_FLAG_SLOTS words owned by
+    the calling model -- two models on one device do not share state, and the captured HIP graphs keep pointing at their model's words):
+    StarDistBase._net_forward reads the words after a pass and moves exactly the offending layers to the bf16x6 form"""
+
+    def __init__(self, flags):
+        assert flags.dtype == torch.int32 and flags.numel() == N_FLAG_SLOTS
+        self.flags = flags
+
+    def __enter__(self):
+        _flag_stack.append(self.flags)
+        return self
+
+    def __exit__(self, *exc):
+        _flag_stack.pop()
+        return False
+
+
+def flag_slot(conv):
+    """the word (1 .. N_FLAG_SLOTS - 1) a convolution module reports its range flag into; assigned on first use"""
+    s = conv.__dict__.get("_sd_flag_slot")
+    if s is None:
+        _slot_counter[0] = _slot_counter[0] % (N_FLAG_SLOTS - 1) + 1
+        s = conv.__dict__["_sd_flag_slot"] = _slot_counter[0]
+    return s
+
+
+def _flag_ptr(conv, device):
+    if _flag_stack and _flag_stack[-1].device == torch.device(device):
+        return _flag_stack[-1].data_ptr() + 4 * flag_slot(conv)
+    return range_flag(device).data_ptr()
 
 
 def _native_inference(x):
@@ -261,6 +298,8 @@ def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False, dot=None):
     # channels-last operands (a pooling layer may hand over a tensor in the default layout: one copy at its resolution)
     srcs = [(t if t.is_contiguous(memory_format=cl) and t.data_ptr() % 16 == 0 else t.clone(memory_format=cl), up) for t, up in srcs]
     form = "conv3" if (cs == [1] or conv_mode() == "hand") else conv_mode()
+    if form == "f16x3" and conv.__dict__.get("_sd_force_form") == "bf16x6":
+        form = "bf16x6"                                  # this layer has seen an activation beyond the fp16 range (StarDistBase._net_forward)
     if form == "f16x3":
         try:
             wp, bias = _packed_conv_weights(conv, form, bn)
@@ -280,7 +319,7 @@ def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False, dot=None):
             ctypes.c_void_p(bias.data_ptr()) if bias is not None else None, ctypes.c_void_p(res.data_ptr()) if res is not None else None,
             co if res is not None else 0, co, kind, ctypes.c_void_p(out.data_ptr())]
     if form == "f16x3":
-        args.append(ctypes.c_void_p(range_flag(a.device).data_ptr()))
+        args.append(ctypes.c_void_p(_flag_ptr(conv, a.device)))
         if dot is not None and res is None and dot[0].numel() == co and dot[0].data_ptr() % 16 == 0:
             part = torch.empty((D * H * W, co // 4), dtype=torch.float32, device=a.device)
             dargs = args[:14] + args[16:] + [ctypes.c_void_p(dot[0].data_ptr()), ctypes.c_void_p(part.data_ptr())]      # (no residual arguments)

@@ -239,7 +239,9 @@ def test_sharded_cross_tile_nms_equals_whole_image(refmods, tmp_path):
         assert np.array_equal(pts2, ref_res["points"]) and np.allclose(prob2, ref_res["prob"]), rank
         if rank == 0:
             assert np.array_equal(lab, ref_labels)
-            assert st2["gathered"] == st["gathered"] and st2["band"] == st["band"] and st2["gathered_bytes"] == st["gathered"] * (32 + 1 + 2 + 1) * 4
+            # exact-size exchange: what crosses a link is the other rank's records, nothing is padded
+            assert st2["gathered"] == st["gathered"] and st2["band"] == st["band"] and st2["interior"] == st["interior"]
+            assert st2["exact_record_bytes"] == st["gathered"] * (32 + 1 + 2 + 1) * 4 and 0 < st2["gathered_bytes"] < st2["exact_record_bytes"]
         else:
             assert lab is None
         for bi, sl, t in tiles2:                                  # every rank rendered the write regions of ITS blocks, with global ids
@@ -265,10 +267,12 @@ def _sharded_worker4(rank, world, port_, q, block):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("block,n_blocks", [(120, 9), (128, 6)])
-def test_sharded_gloo_world4_uneven_block_counts(refmods, block, n_blocks):
-    """four ranks, block counts that do not divide by four (9 -> 3/2/2/2, 6 -> 2/2/1/1): the form bench.py runs at N > 1 (owner-side
-    tiles, result dict on rank 0 only) equals predict_instances on the whole image, and every block is rendered by exactly its owner"""
+@pytest.mark.parametrize("world,block,n_blocks", [(4, 120, 9), (4, 128, 6), (8, 96, 20)])
+def test_sharded_gloo_uneven_block_counts(refmods, world, block, n_blocks):
+    """four ranks with block counts that do not divide by four (9 -> 3/2/2/2, 6 -> 2/2/1/1) and EIGHT ranks with 20 blocks (3/3/3/3/2/2/2/2, the
+    shape of the driver's 8-GPU run): the form bench.py runs at N > 1 (owner-side tiles, result dict on rank 0 only) equals
+    predict_instances on the whole image, every block is rendered by exactly its owner, and the exchange moves exactly the records of
+    the other ranks (no padding to the largest rank: bytes over the links <= the exact record bytes)"""
     import torch.multiprocessing as mp
     m = _FieldModel()
     x, lbl = _field()
@@ -277,21 +281,27 @@ def test_sharded_gloo_world4_uneven_block_counts(refmods, block, n_blocks):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port_ = 29850 + (os.getpid() + block) % 60
-    procs = [ctx.Process(target=_sharded_worker4, args=(r, 4, port_, q, block)) for r in range(4)]
+    procs = [ctx.Process(target=_sharded_worker4, args=(r, world, port_, q, block)) for r in range(world)]
     for pr in procs: pr.start()
-    out = [q.get(timeout=300) for _ in range(4)]
+    out = [q.get(timeout=600) for _ in range(world)]
     for pr in procs: pr.join(60)
     seen = {}
+    local = 0
     for rank, res, tiles, st in out:
         assert (res is None) == (rank != 0)
+        local += st["local_survivors"]
         if rank == 0:
             assert np.array_equal(res[0], ref_res["points"]) and np.allclose(res[1], ref_res["prob"])
             assert st["instances"] == len(ref_res["prob"]) and st["band"] + st["interior"] == st["unique"]
-        assert st["blocks"] == len([b for b in range(n_blocks) if b % 4 == rank]) == len(tiles)
+            st0 = st
+        assert st["blocks"] == len([b for b in range(n_blocks) if b % world == rank]) == len(tiles)
         for bi, sl, t in tiles:
-            assert bi % 4 == rank and bi not in seen and np.array_equal(t, ref_labels[tuple(slice(a, b) for a, b in sl)])
+            assert bi % world == rank and bi not in seen and np.array_equal(t, ref_labels[tuple(slice(a, b) for a, b in sl)])
             seen[bi] = rank
     assert sorted(seen) == list(range(n_blocks))
+    W = 32 + 1 + 2 + 1
+    assert st0["gathered"] == local and st0["exact_record_bytes"] == local * W * 4
+    assert st0["gathered_bytes"] == (local - st0["local_survivors"]) * W * 4 <= 1.05 * st0["exact_record_bytes"]
 
 
 @pytest.mark.parametrize("name,axes", [("2d", "YX"), ("2dg", "YX"), ("3d", "ZYX")])

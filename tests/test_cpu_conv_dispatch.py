@@ -32,6 +32,7 @@ def recorder(monkeypatch):
         def data_ptr(self):
             return 12345
     ns["range_flag"] = lambda device: _Flag()
+    ns["_flag_ptr"] = lambda conv, device: 12345          # (the layer's word of the model's range-flag tensor)
     exec(gsrc.replace("x.is_cuda and ", ""), ns)
     exec(src.replace("t.is_cuda and ", ""), ns)
     return ns["_hand_conv"], calls

@@ -194,16 +194,54 @@ def test_split_fp16_range_flag_and_fallback():
     img = np.random.RandomState(0).rand(96, 128).astype(np.float32)
     img[40, 50] = 3e7                     # a hot pixel the normaliser is told to keep
     m = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
-    with U.force_conv_mode("bf16x6"):
-        want = m.predict(img)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         got = m.predict(img)
-    if m.__dict__.get("_conv_mode_pin") == "bf16x6":          # the flag tripped (depends on the seeded weights' gain): results must be the bf16 ones
+    forced = m.__dict__.get("_fp16_range_layers") or []
+    if forced:                            # the flag tripped (depends on the seeded weights' gain): the layers are named, the result is finite
         assert any("fp16 range" in str(x.message) for x in w)
-        assert all(np.array_equal(a, b) for a, b in zip(want, got))
-    else:
-        assert all(np.isfinite(a).all() for a in got)
+        assert all(m.net.get_submodule(n).__dict__.get("_sd_force_form") == "bf16x6" for n in forced)
+    assert all(np.isfinite(a).all() for a in got)
+    again = m.predict(img)                # the pinned layers stay pinned: no second warning, same result
+    assert all(np.array_equal(a, b) for a, b in zip(got, again))
+
+
+def test_fp16_range_fallback_pins_only_the_offending_layer():
+    """an activation of ~1e5 produced by ONE mid-level layer: exactly the layer that reads it moves to the bf16x6 form (one warning that
+    names it), every other layer stays on the split-fp16 kernel, and the prediction is within 1e-5 of a float64 evaluation"""
+    import torch
+    import warnings
+    from stardist_amd.models import unet as U
+    from stardist_amd.models import Config2D, StarDist2D
+    from oracle import synth
+    dev = torch.device("cuda:0")
+    m = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
+    blk = m.net.backbone.down[1]                                   # second level: [ConvAct 32 -> 64, ConvAct 64 -> 64]
+    prod, cons = blk[0][0], blk[1][0]
+    gain = 3.0e4
+    with torch.no_grad():
+        prod.weight.mul_(gain); prod.bias.mul_(gain)               # its (ReLU) outputs reach ~1e5 ...
+        cons.weight.mul_(1.0 / gain)                               # ... and the layer that reads them brings the scale back
+    img = synth.s2d_nuclei_image(192, 256, seed=3)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        prob, dist = m.predict(img)
+    forced = m.__dict__.get("_fp16_range_layers")
+    assert forced == ["backbone.down.1.1.0"], forced
+    assert sum("fp16 range" in str(x.message) for x in w) == 1
+    convs = [mod for mod in m.net.modules() if isinstance(mod, torch.nn.Conv2d)]
+    assert [c for c in convs if c.__dict__.get("_sd_force_form") == "bf16x6"] == [cons]
+    mc = StarDist2D(Config2D(n_rays=32), basedir=None, device="cpu", seed=0)
+    mc.net.load_state_dict({k: v.cpu() for k, v in m.net.state_dict().items()})
+    with torch.no_grad():
+        p64, d64 = mc.net.double()(torch.from_numpy(img)[None, None].double())
+    p64 = p64[0, 0].numpy(); d64 = np.moveaxis(d64[0].numpy(), 0, -1)
+    assert float(np.abs(prob - p64).max()) <= 1e-5
+    assert float((np.abs(dist - np.maximum(d64, 1e-3)) / np.maximum(1.0, np.abs(d64))).max()) <= 1e-5
+    # two models on one device keep separate flag words: a clean model next to the pinned one is not disturbed
+    m2 = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
+    m2.predict(img)
+    assert not m2.__dict__.get("_fp16_range_layers")
 
 
 def test_batch_norm_layer_folded_matches_float64():

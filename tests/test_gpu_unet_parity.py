@@ -88,7 +88,7 @@ def test_gpu_forward_matches_cpu_float32_and_is_deterministic(kind, monkeypatch)
     bench.calibrate_heads(m, torch.from_numpy(img).to(dev), **calib)
     out1 = m.predict(img)          # (a layer no hand-written kernel covers raises UnsupportedLayer: there is no library path)
     out2 = m.predict(img)
-    assert m.__dict__.get("_conv_mode_pin") is None, "the fp16 range flag tripped on seeded weights"
+    assert not m.__dict__.get("_fp16_range_layers"), "the fp16 range flag tripped on seeded weights"
     assert all(np.array_equal(a, b) for a, b in zip(out1, out2)), "GPU forward pass is not run-to-run identical"
     p1, d1 = out1[:2]
     mc = make("cpu")
