@@ -49,8 +49,8 @@ int sd_release_workspace(void);           /* free the cached device workspace   
  *   "nms2d_strict"        0|1  1 = bit-exact BY CONSTRUCTION: every 2D pair runs the Clipper-exact sweep (overrides "nms2d_area_bounds"); the
  *                              default decides the pairs far from the threshold from an enclosure of Clipper's area whose band is validated
  *                              empirically and adversarially, not proven
- *   "nms2d_neighbours_single_pass" 1|0  neighbour lists of the 2D NMS written in one pass into slots sized from the cell table / counted,
- *                              scanned and filled in two passes (same lists up to order)
+ *   "nms2d_neighbours_single_pass", "nms3d_neighbours_single_pass" 1|0  neighbour lists of the NMS written in one pass into slots sized
+ *                              from the cell table / counted, scanned and filled in two passes (same lists up to order)
  *   "probe_tier"          1|2  capacity tier sd_clip_pairs_device runs first;  "probe_no_general" 1: do not fall back to the general path
  *   "trace"               1    print per-round counters to stdout
  * Nothing in the library reads the process environment.  sd_get_option returns -1 for an unknown name. */

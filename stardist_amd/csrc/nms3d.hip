@@ -148,11 +148,25 @@ __global__ void k_cell_count3(const float* __restrict__ pts, int N, Grid3 g, int
 // contiguous 40-byte records (mostly L2 hits: neighbouring candidates scan the same rows) instead of gathering 36 bytes per test
 // through an index list
 struct CellRec3 { float p[3]; int idx; int bb[6]; };
+// slotCap (may be null): upper bound of candidate i's neighbour count = the population of the (2 W + 1)^3 cells its list is built from, minus
+// itself: the capacity of its slot in the single-pass neighbour lists (k_neighbours3<2>)
 __global__ void k_cell_fill3(int N, const int* __restrict__ candCell, const int* __restrict__ cellStart, int* __restrict__ cellFill,
-                             const float* __restrict__ pts, const int* __restrict__ bbox, CellRec3* __restrict__ cellRec) {
+                             const float* __restrict__ pts, const int* __restrict__ bbox, CellRec3* __restrict__ cellRec, Grid3 g, int W,
+                             int* __restrict__ slotCap) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int c = candCell[i];
+  if (slotCap) {
+    const int cz = c / (g.ny * g.nx), cy = (c / g.nx) % g.ny, cx = c % g.nx;
+    const int x_lo = max(cx - W, 0), x_hi = min(cx + W, g.nx - 1);
+    int u = -1;
+    for (int zz = max(cz - W, 0); zz <= min(cz + W, g.nz - 1); ++zz)
+      for (int yy = max(cy - W, 0); yy <= min(cy + W, g.ny - 1); ++yy) {
+        const int row = (zz * g.ny + yy) * g.nx;
+        u += cellStart[row + x_hi + 1] - cellStart[row + x_lo];
+      }
+    slotCap[i] = u;
+  }
   CellRec3 r;
   r.p[0] = pts[3 * (size_t)i]; r.p[1] = pts[3 * (size_t)i + 1]; r.p[2] = pts[3 * (size_t)i + 2];
   r.idx = i;
@@ -200,7 +214,9 @@ __global__ void __launch_bounds__(256) k_neighbours3(int N, Grid3 g, Flags3 f, c
   int nLo = 0, nHi = 0;
   int minj = INT_MAX;                      // MODE 1: the best-scored neighbour above i = the first wait target of the greedy scan
   const i64 baseLo = MODE ? nbrStart[i] : 0;
-  const i64 baseHi = MODE ? baseLo + nbrLow[i] : 0;
+  // MODE 2 (one pass into slots sized from the cell table, nms2d.hip k_neighbours<2>): the higher-index half is written downwards from
+  // the slot's last entry
+  const i64 baseHi = MODE == 1 ? baseLo + nbrLow[i] : (MODE == 2 ? nbrStart[i + 1] - 1 : 0);
   const int x_lo = max(cx - W, 0), x_hi = min(cx + W, g.nx - 1);
   for (int zz = max(cz - W, 0); zz <= min(cz + W, g.nz - 1); ++zz)
     for (int yy = max(cy - W, 0); yy <= min(cy + W, g.ny - 1); ++yy) {
@@ -219,16 +235,29 @@ __global__ void __launch_bounds__(256) k_neighbours3(int N, Grid3 g, Flags3 f, c
         const unsigned long long below = (1ull << lane) - 1;
         if (MODE && hit) {
           if (j < i) { nbr[baseLo + nLo + __popcll(mLo & below)] = j; minj = min(minj, j); }
-          else nbr[baseHi + nHi + __popcll(mHi & below)] = j;
+          else if (MODE == 1) nbr[baseHi + nHi + __popcll(mHi & below)] = j;
+          else nbr[baseHi - (nHi + __popcll(mHi & below))] = j;
         }
         nLo += __popcll(mLo); nHi += __popcll(mHi);
       }
     }
   if (!MODE && lane == 0) { nbrCount[i] = nLo + nHi; nbrLow[i] = nLo; }
+  if (MODE == 2 && lane == 0) nbrLow[i] = nLo;
+  if (MODE && lane == 0) nbrCount[i] = nHi;            // from here on nbrCount holds the size of the higher-index half (k_round_emit3)
   if (MODE) {
     for (int o = 32; o; o >>= 1) minj = min(minj, __shfl_xor(minj, o));
     if (lane == 0) waitOn[i] = (minj < i) ? minj : WAIT3_NONE;
   }
+}
+// exact number of list entries of the single-pass form: one atomic per workgroup
+__global__ void __launch_bounds__(256) k_sum_halves3(const int* __restrict__ nLow, const int* __restrict__ nHigh, int N, unsigned long long* total) {
+  __shared__ unsigned long long ws[4];
+  unsigned long long v = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) v += (unsigned long long)(nLow[i] + nHigh[i]);
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(total, ws[0] + ws[1] + ws[2] + ws[3]);
 }
 
 // Greedy round, step 1: one THREAD per undecided candidate, O(1).  waitOn[i] is the better-scored neighbour i was last seen waiting
@@ -336,7 +365,7 @@ __global__ void k_tail3_promote(const int* __restrict__ U, int nU, unsigned char
 // emit: exact neighbour predicate + cascade stages 1 and 2 (:1199-1248).  tail != 0: K is the list of the still undecided candidates,
 // none of which is marked kept; every pair of undecided candidates the sequential loop could still evaluate is emitted.
 __global__ void __launch_bounds__(256) k_round_emit3(const int* __restrict__ K, int nK, SuppSink sink, int tail,
-                                                     const i64* __restrict__ nbrStart, const int* __restrict__ nbrLow, const int* __restrict__ nbr, Flags3 f, Aniso an,
+                                                     const i64* __restrict__ nbrStart, const int* __restrict__ nbrHigh, const int* __restrict__ nbr, Flags3 f, Aniso an,
                                                      const float* __restrict__ pts, const int* __restrict__ bbox,
                                                      const float* __restrict__ volume, const float* __restrict__ r_outer,
                                                      const float* __restrict__ r_outer_iso, const float* __restrict__ r_inner_iso,
@@ -348,7 +377,7 @@ __global__ void __launch_bounds__(256) k_round_emit3(const int* __restrict__ K, 
   unsigned char* state = sink.state;
   if (tail) { if (state[i] != ST_UNDECIDED) return; }
   else if (lane == 0) state[i] = ST_KEPT;
-  const i64 beg = nbrStart[i] + nbrLow[i], end = nbrStart[i + 1];   // the higher-index neighbours
+  const i64 end = nbrStart[i + 1], beg = end - nbrHigh[i];          // the higher-index neighbours (the back of i's slot)
   const float* pi = pts + 3 * (size_t)i;
   const float rad = f.max_dist + r_outer[i];
   const float rad2 = rad * rad;                                                // :1170
@@ -2316,19 +2345,33 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   void* scanTmp = A.take(tb1 + 256);
   if (!scanTmp) return -1;
   SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tb1, cellCount, cellStart, nCells + 1, s));
-  hipLaunchKernelGGL(k_cell_fill3, dim3(sd::div_up(N, 256)), dim3(256), 0, s, N, candCell, cellStart, cellFill, d_points, bbox, cellRec);
+  // neighbour lists in ONE pass (option "nms3d_neighbours_single_pass", default 1; nms2d.hip has the 2D twin): slots sized from the cell
+  // table, better-scored neighbours from the slot's front, the others from its back, the exact total summed afterwards; the two-pass form
+  // (count, scan, fill: every candidate test done twice) remains for inputs whose slots would exceed 32-bit indices
+  const bool singlePass = sd::option(sd::OPT_NMS3D_NBR_SINGLE) != 0;
+  SD_CHECK(hipMemsetAsync(nbrCount, 0, (N + 1) * sizeof(int), s));
+  hipLaunchKernelGGL(k_cell_fill3, dim3(sd::div_up(N, 256)), dim3(256), 0, s, N, candCell, cellStart, cellFill, d_points, bbox, cellRec, gr, W,
+                     singlePass ? nbrCount : (int*)nullptr);
   SD_LAUNCH_CHECK();
   const int nbBlocks = (sd::div_up(N, 4) + 7) & ~7;
   Flags3 f;
   f.use_kdtree = use_kdtree; f.use_bbox = use_bbox; f.thr_nonneg = (threshold >= 0.f); f.thr = threshold; f.max_dist = max_dist;
   Flags3 fs = f;
-  SD_CHECK(hipMemsetAsync(nbrCount, 0, (N + 1) * sizeof(int), s));
-  hipLaunchKernelGGL((k_neighbours3<0>), dim3(nbBlocks), dim3(256), 0, s, N, gr, fs, cellRec, candCell, cellStart,
-                     nbrCount, nbrLow, (const i64*)nullptr, (int*)nullptr, (int*)nullptr, W);
-  SD_LAUNCH_CHECK();
-  SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tb1, nbrCount, nbrStart, N + 1, s));
-  i64 totalNbr = 0;
-  SD_CHECK(hipMemcpyAsync(&totalNbr, nbrStart + N, sizeof(i64), hipMemcpyDeviceToHost, s));
+  i64 totalNbr = 0, slotTotal = 0;
+  if (singlePass) {
+    SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tb1, nbrCount, nbrStart, N + 1, s));
+    SD_CHECK(hipMemcpyAsync(&slotTotal, nbrStart + N, sizeof(i64), hipMemcpyDeviceToHost, s));
+    SD_CHECK(hipStreamSynchronize(s));
+  }
+  const bool slots = singlePass && slotTotal >= 0 && slotTotal < (i64)0x7fffffff;
+  if (!slots) {
+    SD_CHECK(hipMemsetAsync(nbrCount, 0, (N + 1) * sizeof(int), s));
+    hipLaunchKernelGGL((k_neighbours3<0>), dim3(nbBlocks), dim3(256), 0, s, N, gr, fs, cellRec, candCell, cellStart,
+                       nbrCount, nbrLow, (const i64*)nullptr, (int*)nullptr, (int*)nullptr, W);
+    SD_LAUNCH_CHECK();
+    SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tb1, nbrCount, nbrStart, N + 1, s));
+    SD_CHECK(hipMemcpyAsync(&totalNbr, nbrStart + N, sizeof(i64), hipMemcpyDeviceToHost, s));
+  }
   // ray mesh: edge adjacency (seeds of the exact volume routine) and validity (precondition of the volume bounds)
   int* faceAdj = A.take_n<int>((size_t)3 * F);
   int* d_mesh = A.take_n<int>(4);
@@ -2393,12 +2436,26 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
                   "neighbour entries): shard the input (predict_instances_sharded / predict_instances_big)", N, (long long)totalNbr);
     return -1;
   }
-  int* nbr = A.take_n<int>((size_t)totalNbr);
+  int* nbr = A.take_n<int>((size_t)(slots ? slotTotal : totalNbr));
   int* waitOn = A.take_n<int>(N);
   if (!nbr || !waitOn) return -1;
-  hipLaunchKernelGGL((k_neighbours3<1>), dim3(nbBlocks), dim3(256), 0, s, N, gr, fs, cellRec, candCell, cellStart,
-                     nbrCount, nbrLow, (const i64*)nbrStart, nbr, waitOn, W);
-  SD_LAUNCH_CHECK();
+  if (slots) {
+    unsigned long long* d_total = A.take_n<unsigned long long>(1);
+    if (!d_total) return -1;
+    SD_CHECK(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL((k_neighbours3<2>), dim3(nbBlocks), dim3(256), 0, s, N, gr, fs, cellRec, candCell, cellStart,
+                       nbrCount, nbrLow, (const i64*)nbrStart, nbr, waitOn, W);
+    hipLaunchKernelGGL(k_sum_halves3, dim3(sd::div_up(N, 256) < 1024 ? sd::div_up(N, 256) : 1024), dim3(256), 0, s, nbrLow, nbrCount, N, d_total);
+    SD_LAUNCH_CHECK();
+    unsigned long long tot = 0;
+    SD_CHECK(hipMemcpyAsync(&tot, d_total, sizeof(tot), hipMemcpyDeviceToHost, s));
+    SD_CHECK(hipStreamSynchronize(s));
+    totalNbr = (i64)tot;
+  } else {
+    hipLaunchKernelGGL((k_neighbours3<1>), dim3(nbBlocks), dim3(256), 0, s, N, gr, fs, cellRec, candCell, cellStart,
+                       nbrCount, nbrLow, (const i64*)nbrStart, nbr, waitOn, W);
+    SD_LAUNCH_CHECK();
+  }
   if (stats) SD_CHECK(hipEventRecord(evb1, s));
 
   // cone map for the voxel tests of stage 5 (geom3d.h); SD_NMS3D_NO_CONEMAP=1 tests every face as the reference does
@@ -2473,7 +2530,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
     const SuppSink sink = tail ? SuppSink{state, supEdges, supCount, pairCap} : SuppSink{state, nullptr, nullptr, 0u};
     const int nKeep = h.nK, nUndecided = h.nU;
     if (h.nK > 0) {
-      hipLaunchKernelGGL(k_round_emit3, dim3(sd::div_up(nKeep, 4)), dim3(256), 0, s, tail ? Ucur : Kl, nKeep, sink, tail ? 1 : 0, nbrStart, nbrLow, nbr, f, an, d_points, bbox, volume,
+      hipLaunchKernelGGL(k_round_emit3, dim3(sd::div_up(nKeep, 4)), dim3(256), 0, s, tail ? Ucur : Kl, nKeep, sink, tail ? 1 : 0, nbrStart, nbrCount, nbr, f, an, d_points, bbox, volume,
                          r_outer, r_outer_iso, r_inner_iso, pairs3, &d_cnt->nP3, pairCap, d_st);
       SD_LAUNCH_CHECK();
       SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));

@@ -137,6 +137,31 @@ def test_nms3d_tail_batch_does_not_change_survivors(refmods):
     assert st_tail[4] <= st_rounds[4], (st_tail[4], st_rounds[4])       # never more host-driven rounds
 
 
+def test_nms3d_neighbour_list_forms_agree(refmods):
+    """single-pass neighbour lists (slots sized from the cell table, the default) vs count / scan / fill: the reference's survivors, the
+    same number of list entries, with and without the tail batch and in the all-pairs configuration"""
+    import torch
+    from oracle import synth
+    from stardist_amd.lib import _native as N, stardist3d as sd3
+    rays = _rays(96)
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    d, p, s, nobj = synth.s3d_nuclei(96, rays.vertices)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    refmods.stardist3d(); refmods.set_threads(1)
+    for kd in (1, 0):
+        n = len(d) if kd else 3000
+        args = (t(d[:n]), t(p[:n]), t(np.float32(V)), t(F), t(s[:n]), 1, kd, 0, np.float32(0.3))
+        ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d[:n], p[:n], V, F, s[:n], 1, kd, 0, np.float32(0.3))
+        entries = []
+        for form in (1, 0):
+            for tail in (1, 0):
+                with N.option("nms3d_neighbours_single_pass", form), N.option("nms3d_tail_batch", tail):
+                    keep, st = sd3.c_non_max_suppression_inds(*args, return_stats=True)
+                assert np.array_equal(keep.cpu().numpy(), ref_keep), (kd, form, tail)
+                entries.append(int(st[5]))
+        assert len(set(entries)) == 1, entries
+
+
 def test_nms3d_split_exact_does_not_change_survivors_or_volumes(refmods):
     """exact volumes by four waves per pair in a second pass (k_stage3x / k_stage4x) vs by the wave that evaluated the bounds: the
     same survivors as the reference, with and without the bound shortcuts, and bit-identical pair volumes"""
