@@ -537,13 +537,15 @@ __global__ void __launch_bounds__(256) k_tail_emit(const int* __restrict__ U, in
 // but cannot be promoted), and all deferred pairs are evaluated by ONE launch of the general kernel in the tail batch -- instead
 // of one latency-bound launch per round.  Per candidate the deferred pairs form a linked list (defHead / defNext).
 struct Deferred { int2* pairs; int* next; int* head; unsigned char* pend; unsigned int* count; unsigned int cap; };
+// (a deferred list that is full cannot take the pair: counted in *nErr, the call then fails loudly instead of dropping a decision)
 __global__ void k_defer(const int2* __restrict__ pairs, const unsigned int* __restrict__ exact, const unsigned int* __restrict__ nExact, unsigned int qcap,
-                        Deferred d) {
+                        Deferred d, unsigned int* __restrict__ nErr) {
   unsigned int n = *nExact; if (n > qcap) n = qcap;
   for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
     const int2 ij = pairs[exact[t]];
     const unsigned int k = atomicAdd(d.count, 1u);
     if (k < d.cap) { d.pairs[k] = ij; d.pend[ij.y] = 1; d.next[k] = atomicExch(&d.head[ij.y], (int)k); }
+    else atomicAdd(nErr, 1u);
   }
 }
 // tail batch: the deferred pairs become entries 0 .. nDef-1 of the tail's pair list and of its general-path queue
@@ -559,7 +561,7 @@ __global__ void k_tail_init(Deferred d, int2* __restrict__ pairs, unsigned int* 
 // while the kind-0 pairs go to the general kernel as before.  j is pending until then (can be suppressed, cannot be promoted).
 __global__ void k_defer_undecided(const int2* __restrict__ pairs, const unsigned long long* __restrict__ nPtr, const unsigned int* __restrict__ nDecided,
                                   unsigned int limit, unsigned char* __restrict__ decided, const unsigned char* __restrict__ state, Deferred d,
-                                  unsigned char* __restrict__ kind) {
+                                  unsigned char* __restrict__ kind, unsigned int* __restrict__ nErr) {
   // only a round whose undecided pairs would make a latency-bound sweep launch defers them (many undecided pairs -- a threshold inside
   // the overlap range of one object's candidates -- are swept at once more cheaply than they are carried along); a deferred pair gets
   // decided[t] = 4, so that the bucketing and the sweeps that follow in the stream find nothing to do
@@ -572,6 +574,7 @@ __global__ void k_defer_undecided(const int2* __restrict__ pairs, const unsigned
     if (state[ij.y] == ST_SUPPRESSED) continue;            // a decided pair of this round already suppressed j
     const unsigned int k = atomicAdd(d.count, 1u);
     if (k < d.cap) { d.pairs[k] = ij; d.pend[ij.y] = 1; d.next[k] = atomicExch(&d.head[ij.y], (int)k); kind[k] = 1; }
+    else atomicAdd(nErr, 1u);
   }
 }
 // tail batch with both kinds of deferred pairs: all become entries 0 .. nDef-1 of the pair list; kind 0 -> general-path queue and
@@ -1082,7 +1085,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
           hipLaunchKernelGGL(k_pairs_decide, dim3(256 * 8), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, vx, vy, R, props, area, threshold, state, suppOut,
                              decided, &d_cnt->nDecided);
         if (!suppOut && deferFrom > 0 && rounds >= deferFrom)      // few undecided pairs: they wait for the tail batch's sweep launch
-          hipLaunchKernelGGL(k_defer_undecided, dim3(256), dim3(256), 0, s, pairs, &d_cnt->nPairs, &d_cnt->nDecided, DEFER_UNDECIDED_MAX, decided, state, dfr, defKind);
+          hipLaunchKernelGGL(k_defer_undecided, dim3(256), dim3(256), 0, s, pairs, &d_cnt->nPairs, &d_cnt->nDecided, DEFER_UNDECIDED_MAX, decided, state, dfr, defKind, &d_cnt->nErr);
         // tail batch with deferred undecided pairs: they sit in the list's prefix with decided[] = 0 and are bucketed with the rest
         const unsigned int* bfirst = (suppOut && deferFrom > 0) ? nullptr : first;
         SD_CHECK(hipStreamWaitEvent(s, evPrep, 0));          // the prepared polygons (side stream; complete long before, except in round 1)
@@ -1108,7 +1111,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
     if (rc) return -1;
     if (stats) SD_CHECK(hipEventRecord(ev2, s));
     if (!suppOut && deferOn) {
-      hipLaunchKernelGGL(k_defer, dim3(64), dim3(256), 0, s, pairs, exactPairs, &d_cnt->nExact, qCap, dfr);
+      hipLaunchKernelGGL(k_defer, dim3(64), dim3(256), 0, s, pairs, exactPairs, &d_cnt->nExact, qCap, dfr, &d_cnt->nErr);
       SD_LAUNCH_CHECK();
     } else if (suppOut && sideGeneral) {
       // tail batch: the deferred pairs (the first nDeferred queue entries) are being evaluated on the helper stream since the batch
@@ -1123,7 +1126,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   };
   auto account = [&](const char* what) -> int {
     if (h.nPairs > pairCap || h.nSpill > qCap || h.nExact > qCap) { sd::set_error("sd_nms2d: pair queue overflow (internal error)"); return -1; }
-    if (h.nErr) { sd::set_error("sd_nms2d: %u pairs exceeded the general path's fixed capacities", h.nErr); return -1; }
+    if (h.nErr) { sd::set_error("sd_nms2d: %u pairs exceeded the general path's fixed capacities or the deferred-pair list", h.nErr); return -1; }
     totalPairs += (i64)h.nPairs; totalExact += h.nExact; totalSpill += h.nSpill; totalDecided += h.nDecided;
     if (stats) {
       float ms = 0, ms2 = 0;

@@ -63,7 +63,19 @@ __global__ void __launch_bounds__(BLOCK) k_write(const float* __restrict__ prob,
   int off = blockStart[blockIdx.x];
   for (int r = 0; r < ITEMS; ++r) {
     for (int w = 0; w < 4; ++w) {
-      if (w == wave) {
+      if (w == wave && !dist) {
+        // no distance rows to copy (the sparse head evaluates them later, on the selected rows): every selected lane writes its own entry
+        const unsigned long long m = masks[r];
+        if ((m >> lane) & 1ull) {
+          const int o = off + __popcll(m & ((1ull << lane) - 1));
+          if (o < cap) {
+            const long long idx = base + r * BLOCK + threadIdx.x;
+            oprob[o] = prob[idx];
+            long long rem = idx;
+            for (int d = p.ndim - 1; d >= 0; --d) { opts[(size_t)o * p.ndim + d] = (int)(rem % p.shape[d]); rem /= p.shape[d]; }
+          }
+        }
+      } else if (w == wave) {
         // this wave's selected pixels of row r start at `off`; copy them cooperatively
         unsigned long long m = masks[r];
         int rank = 0;

@@ -149,7 +149,7 @@ def test_nms3d_neighbour_list_forms_agree(refmods):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
     refmods.stardist3d(); refmods.set_threads(1)
     for kd in (1, 0):
-        n = len(d) if kd else 3000
+        n = len(d) if kd else 1500
         args = (t(d[:n]), t(p[:n]), t(np.float32(V)), t(F), t(s[:n]), 1, kd, 0, np.float32(0.3))
         ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d[:n], p[:n], V, F, s[:n], 1, kd, 0, np.float32(0.3))
         entries = []

@@ -22,5 +22,5 @@ for r in range(reps):
     dt = time.time() - t
     st = _native.last_stats["nms3d"]
     print(f"rep {r}: N={len(d)} -> {int(keep.sum())}  {dt*1e3:.1f} ms  stage3 {st[8]/1e6:.1f} ms ({st[2]} pairs)  stage4 {st[9]/1e6:.1f} ms ({st[11]} pairs)  "
-          f"stage5 {st[10]/1e6:.1f} ms ({st[3]})  rounds {st[4]}  faces {st[13]} fallback {st[14]}  |  broad phase (precompute + grid + neighbour lists, "
+          f"stage5 {st[10]/1e6:.1f} ms ({st[3]})  rounds {st[4]}  near-threshold exact-volume decisions {st[13]} large-face fallbacks {st[14]}  |  broad phase (precompute + grid + neighbour lists, "
           f"{st[5]} list entries) {st[15]/1e6:.2f} ms = {401.0 * len(d) / max(1, st[15]):.1f} GB/s of the 401 B/candidate the scan must move", flush=True)

@@ -36,4 +36,4 @@ for r in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     torch.cuda.synchronize(); dt = time.time() - t
     st = _native.last_stats["nms3d"]
     print(f"rep {r}: N={len(td)} -> {int(keep.sum())}  {dt*1e3:.1f} ms  stage3 {st[8]/1e6:.1f} ms ({st[2]} pairs)  stage4 {st[9]/1e6:.1f} ms ({st[11]} pairs)  "
-          f"stage5 {st[10]/1e6:.1f} ms ({st[3]})  rounds {st[4]}  faces {st[13]} fallback {st[14]}", flush=True)
+          f"stage5 {st[10]/1e6:.1f} ms ({st[3]})  rounds {st[4]}  near-threshold exact-volume decisions {st[13]} large-face fallbacks {st[14]}", flush=True)
