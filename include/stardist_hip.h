@@ -151,6 +151,13 @@ int sd_polygons_to_label_device(const float* d_coord, const int32_t* d_labels, i
 int sd_polygons_to_label_window_device(const float* d_coord, const int32_t* d_labels, int n_polys, int n_rays, int HI, int WI,
                                        int y0, int x0, int H, int W, int32_t* d_result, void* stream);
 
+/* polar -> cartesian for a list of polygons: replaces stardist.geometry.geom2d.dist_to_coord (geom2d.py:130-146) in numpy's own
+ * arithmetic (products and the final sum in float64, rounded to float32 where numpy rounds): d_dist (n, R) float32, d_points (n, 2)
+ * float64 (y, x), d_sincos (2, R) float64 = (sin, cos) of linspace(0, 2 pi, R, endpoint=False) computed by the caller's libm,
+ * scale (y, x) = `scale_dist`; d_coord (n, 2, R) float32. */
+int sd_dist_to_coord_device(const float* d_dist, const double* d_points, const double* d_sincos, long long n_polys, int n_rays,
+                            double scale_y, double scale_x, float* d_coord, void* stream);
+
 /* ---- 3D non-maximum suppression -------------------------------------------------------------
  * name, signature and semantics of the reference's C ABI
  *   (stardist/lib/stardist3d_lib.h:52-66 -> _COMMON_non_maximum_suppression_sparse,

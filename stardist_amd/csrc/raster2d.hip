@@ -82,6 +82,32 @@ __global__ void k_map_labels(int* __restrict__ img, long long n, const int* __re
 
 }  // namespace
 
+// dist_to_coord (stardist/geometry/geom2d.py:130-146) in numpy's arithmetic, one launch: coord[i][a][k] =
+//   float32( float64( float32( float64(dist[i][k]) * sc[a][k] ) [* scale[a] -> float32] ) + float64(points[i][a]) )
+// sc = (sin, cos)(linspace(0, 2 pi, R, endpoint=False)) in float64 from the HOST's libm (a device table uploaded by the caller):
+// `(dist[:, None] * sc).astype(float32)`, `coord *= scale` (only when scale != 1: float32 * float64 rounded to float32), then
+// `coord += points[..., None]` (added in float64, rounded once).
+__global__ void __launch_bounds__(256) k_dist_to_coord(const float* __restrict__ dist, const double* __restrict__ points, const double* __restrict__ sc,
+                                                       long long n, int R, double sy, double sx, int scaled, float* __restrict__ coord) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * 2 * R) return;
+  const int k = (int)(t % R), a = (int)((t / R) % 2);
+  const long long i = t / (2 * R);
+  float c = (float)((double)dist[i * R + k] * sc[a * R + k]);
+  if (scaled) c = (float)((double)c * (a ? sx : sy));
+  coord[t] = (float)((double)c + points[i * 2 + a]);
+}
+
+extern "C" int sd_dist_to_coord_device(const float* d_dist, const double* d_points, const double* d_sincos, long long n_polys, int n_rays,
+                                       double scale_y, double scale_x, float* d_coord, void* stream) {
+  if (n_polys <= 0 || n_rays <= 0) return 0;
+  const long long tot = n_polys * 2 * n_rays;
+  hipLaunchKernelGGL(k_dist_to_coord, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_dist, d_points, d_sincos, n_polys, n_rays,
+                     scale_y, scale_x, (scale_y != 1.0 || scale_x != 1.0) ? 1 : 0, d_coord);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int sd_polygons_to_label_window_device(const float* d_coord, const int32_t* d_labels, int n_polys, int n_rays, int HI, int WI,
                                                   int y0, int x0, int H, int W, int32_t* d_result, void* stream) {
   hipStream_t s = (hipStream_t)stream;

@@ -5,6 +5,9 @@ from ..lib import _native as N
 from ..utils import _normalize_grid
 
 
+_SC_CACHE = {}
+
+
 def ray_angles(n_rays=32):
     """geom2d.py:214-215"""
     return np.linspace(0, 2 * np.pi, n_rays, endpoint=False)
@@ -63,6 +66,22 @@ def dist_to_coord(dist, points, scale_dist=(1, 1)):
     n_rays = dist.shape[1]
     phis = ray_angles(n_rays)
     sc = np.array([np.sin(phis), np.cos(phis)])           # float64 (2, n_rays)
+    if N.is_torch(dist) and dist.is_cuda and dist.dtype == __import__("torch").float32 and N.is_torch(points):
+        # one launch in numpy's arithmetic (sd_dist_to_coord_device): f32 * f64 products rounded to f32, the centre added in f64 and
+        # rounded once; the (sin, cos) table is the host libm's, uploaded once per (n_rays, device)
+        import torch
+        key = (n_rays, str(dist.device))
+        sct = _SC_CACHE.get(key)
+        if sct is None:
+            sct = _SC_CACHE[key] = torch.as_tensor(np.ascontiguousarray(sc), device=dist.device)
+        d = dist.contiguous()
+        p = points.to(torch.float64).contiguous()
+        coord = torch.empty((d.shape[0], 2, n_rays), dtype=torch.float32, device=dist.device)
+        if d.shape[0]:
+            import ctypes
+            N.dcall(d, "sd_dist_to_coord_device", N.tptr(d), N.tptr(p), N.tptr(sct), int(d.shape[0]), int(n_rays),
+                    ctypes.c_double(float(scale_dist[0])), ctypes.c_double(float(scale_dist[1])), N.tptr(coord))
+        return coord
     if N.is_torch(dist):
         import torch
         sct = torch.as_tensor(sc, device=dist.device)                      # float64

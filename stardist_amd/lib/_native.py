@@ -44,6 +44,7 @@ SIGNATURES = {
     "sd_star_dist3d_host": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sd_star_dist3d_device": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sd_edt_prob_device": (_i, [_vp, _i, _i, _i, ctypes.c_double, ctypes.c_double, ctypes.c_double, _i, _vp, _vp]),
+    "sd_dist_to_coord_device": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, ctypes.c_double, ctypes.c_double, _vp, _vp]),
     "sd_polygons_to_label_host": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sd_polygons_to_label_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sd_polygons_to_label_window_device": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

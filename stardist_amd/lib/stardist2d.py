@@ -9,8 +9,9 @@ import numpy as np
 from . import _native as N
 
 
-def c_non_max_suppression_inds(dist, points, use_kdtree, use_bbox, verbose, threshold, return_stats=False):
-    """stardist2d.cpp:390-615. dist (n,R) f32, points (n,2) f32 sorted by score desc -> bool (n,)."""
+def c_non_max_suppression_inds(dist, points, use_kdtree, use_bbox, verbose, threshold, return_stats=False, _as_uint8=False):
+    """stardist2d.cpp:390-615. dist (n,R) f32, points (n,2) f32 sorted by score desc -> bool (n,).
+    _as_uint8 (device tensors, internal): the flags as the native wrote them (uint8 0 / 1) without the cast to bool."""
     N.require_device()
     stats = np.zeros(16, np.int64)
     if N.is_torch(dist):
@@ -21,7 +22,8 @@ def c_non_max_suppression_inds(dist, points, use_kdtree, use_bbox, verbose, thre
         keep = torch.empty(n, dtype=torch.uint8, device=dist.device)
         N.dcall(dist, "sd_nms2d_device", N.tptr(dist), N.tptr(points), n, R, int(use_kdtree), int(use_bbox),
                                         int(verbose), float(threshold), N.tptr(keep), N.ptr(stats))
-        keep = keep.bool()
+        if not _as_uint8:
+            keep = keep.bool()
     else:
         dist = np.ascontiguousarray(dist, np.float32)
         points = np.ascontiguousarray(points, np.float32)

@@ -12,7 +12,7 @@ import numpy as np
 from . import _native as N
 
 
-def c_non_max_suppression_inds(dist, points, verts, faces, scores, use_bbox, use_kdtree, verbose, threshold, return_stats=False):
+def c_non_max_suppression_inds(dist, points, verts, faces, scores, use_bbox, use_kdtree, verbose, threshold, return_stats=False, _as_uint8=False):
     """stardist3d.cpp:13-62 -> stardist3d_impl.cpp:956-1385. Inputs sorted by score descending. Returns bool (n,)."""
     N.require_device()
     stats = np.zeros(16, np.int64)
@@ -26,7 +26,8 @@ def c_non_max_suppression_inds(dist, points, verts, faces, scores, use_bbox, use
             N.dcall(scores, "sd_nms3d_device", N.tptr(scores), N.tptr(dist), N.tptr(points), n, R, faces.shape[0], N.tptr(verts),
                                             N.tptr(faces), float(threshold), int(use_bbox), int(use_kdtree), int(verbose),
                                             N.tptr(keep), N.ptr(stats))
-        keep = keep.bool()
+        if not _as_uint8:
+            keep = keep.bool()
         N.last_stats["nms3d"] = stats
         return (keep, stats) if return_stats else keep
     dist = np.ascontiguousarray(dist, np.float32); points = np.ascontiguousarray(points, np.float32)

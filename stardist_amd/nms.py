@@ -145,8 +145,11 @@ def _survivor_positions(keep):
 def non_maximum_suppression_sparse_sorted(dist, prob, points, b=2, nms_thresh=0.5, use_bbox=True, use_kdtree=True, verbose=False):
     """non_maximum_suppression_sparse (stardist/nms.py:135-183) for candidates that are ALREADY in score order (descending, the order
     `np.argsort(prob)[::-1]` gives them) as device tensors: positions (int64 tensor) of the survivors, best score first."""
+    from .lib.stardist2d import c_non_max_suppression_inds
+    import torch
     assert dist.ndim == 2 and prob.ndim == 1 and points.ndim == 2 and points.shape[-1] == 2 and len(prob) == len(dist) == len(points)
-    keep = non_maximum_suppression_inds(dist, points, scores=prob, thresh=nms_thresh, use_kdtree=use_kdtree, verbose=verbose)
+    keep = c_non_max_suppression_inds(dist.to(torch.float32).contiguous(), points.to(torch.float32).contiguous(), int(use_kdtree), 1, int(verbose),
+                                      np.float32(nms_thresh), _as_uint8=True)          # (use_bbox: nms.py:175-176 passes its default)
     return _survivor_positions(keep)
 
 
@@ -159,7 +162,7 @@ def non_maximum_suppression_3d_sparse_sorted(dist, prob, points, rays, b=2, nms_
     assert dist.ndim == 2 and prob.ndim == 1 and points.ndim == 2 and dist.shape[-1] == len(rays) and points.shape[-1] == 3 and \
         len(prob) == len(dist) == len(points)
     verts, faces = rays_device_tensors(rays, dist.device)
-    keep = c_non_max_suppression_inds(dist, points, verts, faces, prob, 1, int(use_kdtree), int(verbose), np.float32(nms_thresh))
+    keep = c_non_max_suppression_inds(dist, points, verts, faces, prob, 1, int(use_kdtree), int(verbose), np.float32(nms_thresh), _as_uint8=True)
     return _survivor_positions(keep)
 
 
