@@ -45,7 +45,7 @@ CONV_FORMS = {"f16x3": (3.0, MFMA_BF16_PEAK_TFLOPS, "f16"), "bf16x6": (6.0, MFMA
 # WRITE_SIZE in separate passes) writes them, together with the pair count of the profiled workload, to this json; bench.py
 # reports them as roofline.traffic only when its own pair count matches the profiled one.
 PAIR_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pair_kernel_traffic.json")
-# the same for the convolution kernel, per forward pass (tools/pmc_forward.py + tools/conv_traffic.py, profiles/r04_conv_forward.md)
+# the same for the convolution kernel, per forward pass (tools/pmc_forward.py + tools/conv_traffic.py, profiles/r05_conv_forward.md)
 CONV_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "conv_kernel_traffic.json")
 
 
@@ -340,13 +340,19 @@ def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, di
     and, from the per-block times, the per-rank critical path and strong-scaling efficiency at N = 2, 4, 8 are predicted.
     Returns a dict (rank 0) or None."""
     import torch
-    # warm-up on one block's worth of the input (HIP graph of the block shape, weight packing, arena growth)
+    # warm-up: one block's worth of the input (HIP graph of the block shape, weight packing, arena growth), then ONE untimed pass over the
+    # whole input -- the label image of a pass is returned in page-locked memory (stardist_amd/utils.py to_host), and allocating 1 - 4 GiB of it
+    # costs ~0.1 s the first time; a result is dropped before the next pass starts (as a caller working through slides would), so the timed
+    # passes recycle the block
     warm = big[tuple(slice(0, block) for _ in range(big.dim()))]
     model.predict_instances_sharded(warm, axes, block_size=block, min_overlap=overlap, context=context, distributed=False)
     del warm
     kw = dict(block_size=block, min_overlap=overlap, context=context, broadcast_result=False)
     if world > 1:
         kw["labels_out"] = "local"
+    labels, res = model.predict_instances_sharded(big, axes, **kw)
+    del labels, res
+    if world > 1:
         dist_.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -355,6 +361,8 @@ def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, di
         labels, res = model.predict_instances_sharded(big, axes, **kw)
         for k, v in model._last_sharded_stats.items():
             acc[k] = (acc.get(k, 0) + v) if not isinstance(v, list) else v
+        if _ + 1 < passes:
+            del labels, res
     torch.cuda.synchronize()
     if world > 1:
         dist_.barrier()
@@ -523,7 +531,7 @@ def main():
                      "avg_ms": round(net_ms, 3),
                      "note": "achieved = algorithmic FLOPs of the convolutions (2 x MACs, recomputed from the instantiated module) / HIP-event time of the "
                              "whole forward pass (14 conv launches + pools + head) on the caller's stream; executed_* = x%d matrix products per MAC; "
-                             "for reference the f32-MFMA peak is %.1f TFLOP/s; per-kernel durations and the MFMA-busy counter: profiles/r04_*"
+                             "for reference the f32-MFMA peak is %.1f TFLOP/s; per-kernel durations and the MFMA-busy counter: profiles/r05_*"
                              % (int(mult), MFMA_F32_PEAK_TFLOPS)}
         ct = conv_traffic("2d", mode, H, 2048)
         if ct:

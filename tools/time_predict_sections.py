@@ -54,14 +54,15 @@ def main():
     for _ in range(a.steps):
         model.predict_instances(img)
     torch.cuda.synchronize(); whole = (time.perf_counter() - t0) / a.steps
+    import stardist_amd.lib.stardist2d as L2
+    import stardist_amd.utils as UT
     wrap(model, "_net_forward", "net_forward")
-    wrap(model, "_select_rows", "select+dist_rows")
-    wrap(M2, "non_maximum_suppression_sparse", "nms_sparse(sort+gather+nms+gather)")
-    wrap(NMS, "non_maximum_suppression_inds", "  nms_inds(native)")
-    wrap(NMS, "_argsort_desc", "  argsort")
-    wrap(M2, "polygons_to_label", "raster")
+    wrap(model, "_select_sorted", "select + sort + distance head on the sorted rows")
+    wrap(NMS, "non_maximum_suppression_sparse_sorted", "nms (native + survivor positions)")
+    wrap(L2, "c_non_max_suppression_inds", "  nms_inds(native)")
+    wrap(G2, "polygons_to_label_coord", "raster")
     wrap(M2, "dist_to_coord", "dist_to_coord")
-    wrap(M2, "to_host", "labels_to_host")
+    wrap(UT, "to_host_many", "results_to_host (labels, coord, points, prob)")
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(a.steps):
         model.predict_instances(img)
@@ -88,13 +89,16 @@ def sections_3d(a, dev):
     for _ in range(3):
         m3.predict_instances(vol)
     torch.cuda.synchronize(); whole = (time.perf_counter() - t0) / 3
+    import stardist_amd.lib.stardist3d as L3
+    import stardist_amd.utils as UT
     wrap(m3, "_net_forward", "net_forward")
-    wrap(m3, "_select_rows", "select+dist_rows")
-    wrap(M3, "non_maximum_suppression_3d_sparse", "nms_sparse(sort+gather+nms+gather)")
-    wrap(NMS, "non_maximum_suppression_3d_inds", "  nms_3d_inds(sort+native)")
+    wrap(m3, "_select_sorted", "select + sort + distance head on the sorted rows")
+    wrap(NMS, "non_maximum_suppression_3d_sparse_sorted", "nms (native + survivor positions)")
+    wrap(L3, "c_non_max_suppression_inds", "  nms_3d_inds(native)")
     wrap(M3, "polyhedron_to_label", "raster")
     wrap(M3, "relabel_sequential", "relabel_sequential")
     wrap(M3, "to_host", "labels_to_host")
+    wrap(UT, "to_host_many", "dict_to_host (dist, points, prob)")
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(3):
         m3.predict_instances(vol)
