@@ -82,22 +82,33 @@ static __global__ void __launch_bounds__(256) k_poly_props(const int* __restrict
   const int wv = threadIdx.x >> 6;
   sv[wv][half][l] = make_float2(ax, ay); sn[wv][half][l] = nxt;
   __builtin_amdgcn_wave_barrier();                  // (a wave's LDS accesses are processed in order)
-  for (int k = 0; k < R; ++k) {
+  // every UNORDERED pair of edges {l, k} once: lane l meets k = l + dd (cyclically) for dd = 1 .. R / 2 (the pairs at distance R / 2 of an even
+  // R twice) and evaluates the symmetric edge-against-edge test once and the vertex-against-edge rule in both directions -- half the
+  // iterations of a loop over every k.  A lane's findings are OR-ed over the polygon's lanes below.
+  for (int dd = 1; dd <= (R >> 1); ++dd) {
+    int k = l + dd; if (k >= R) k -= R;
+    if (!valid) k = 0;
     const int kn = (k + 1 >= R) ? 0 : k + 1;
     const float2 c2 = sv[wv][half][k], d2 = sv[wv][half][kn];
     const float cx = c2.x, cy = c2.y, dx = d2.x, dy = d2.y;
     const int nxt_k = sn[wv][half][k];
     const bool degk = ((m32 >> k) & 1u) == 0u;
-    // ROBUSTLY simple (round 5): my vertex a must not lie, along its scan line, within HALF a lattice step of an edge (c -> d) it is not an
-    // end point of -- there Clipper's rounded abscissae tie and the polygon's OWN edges can be re-ordered, which changes the area it
-    // returns by more than any strip between the two polygons (found by the adversarial search of DESIGN.md 3.4: a polygon of area 80 whose
-    // spike comes within half a step of a vertex is returned with 68.5).  Exact in float: relative coordinates <= WINDOW.
-    if (valid && small && !degk && !((cx == ax && cy == ay) || (dx == ax && dy == ay)) && ay >= fminf(cy, dy) && ay <= fmaxf(cy, dy)) {
-      if (cy == dy) { if (ax >= fminf(cx, dx) && ax <= fmaxf(cx, dx)) bad = true; }
-      else if (2.f * fabsf((cx - ax) * (dy - cy) + (ay - cy) * (dx - cx)) <= fabsf(dy - cy)) bad = true;   // |x_edge(ay) - ax| <= 1/2
-    }
-    if (deg || degk || k == l) continue;
     const float fx = dx - cx, fy = dy - cy;
+    // ROBUSTLY simple (round 5): a vertex must not lie, along its scan line, within HALF a lattice step of an edge it is not an end point
+    // of -- there Clipper's rounded abscissae tie and the polygon's OWN edges can be re-ordered, which changes the area it returns by
+    // more than any strip between the two polygons (found by the adversarial search of DESIGN.md 3.4: a polygon of area 80 whose
+    // spike comes within half a step of a vertex is returned with 68.5).  Exact in float: relative coordinates <= WINDOW.
+    //   my vertex a against edge k = (c -> d) ...
+    if (valid && small && !degk && !((cx == ax && cy == ay) || (dx == ax && dy == ay)) && ay >= fminf(cy, dy) && ay <= fmaxf(cy, dy)) {
+      if (fy == 0.f) { if (ax >= fminf(cx, dx) && ax <= fmaxf(cx, dx)) bad = true; }
+      else if (2.f * fabsf((cx - ax) * fy + (ay - cy) * fx) <= fabsf(fy)) bad = true;            // |x_edge(ay) - ax| <= 1/2
+    }
+    //   ... and vertex c (the start of edge k) against my edge (a -> b)
+    if (valid && small && !deg && !((ax == cx && ay == cy) || (bx == cx && by == cy)) && cy >= fminf(ay, by) && cy <= fmaxf(ay, by)) {
+      if (ey == 0.f) { if (cx >= fminf(ax, bx) && cx <= fmaxf(ax, bx)) bad = true; }
+      else if (2.f * fabsf((ax - cx) * ey + (cy - ay) * ex) <= fabsf(ey)) bad = true;
+    }
+    if (deg || degk || !valid) continue;
     if (k == nxt || nxt_k == l) {
       // cyclic neighbours: they share one vertex; anything more is a fold-back (when BOTH hold there are only two edges: count < 3)
       const float cr = ex * fy - ey * fx, dt = ex * fx + ey * fy;

@@ -105,6 +105,71 @@ __global__ void __launch_bounds__(256) k_build(const float* __restrict__ dist, c
   }
 }
 
+// k_build for n_rays <= 32: HALF a wave per candidate (a 32-ray polygon leaves half of a wave idle in k_build: 0.47 -> 0.25 ms for the
+// 418 577 candidates of the 2048^2 bench set, on the critical path of the grid set-up).  Same arithmetic, same order of the float area sum.
+__global__ void __launch_bounds__(256) k_build32(const float* __restrict__ dist, const float* __restrict__ pts,
+                                                 const float2* __restrict__ sincos, int N, int R,
+                                                 int* __restrict__ vx, int* __restrict__ vy, int4* __restrict__ bbox,
+                                                 float* __restrict__ radius, float* __restrict__ area, int* gstats) {
+  __shared__ int sxy[8][2][32];
+  const int l = threadIdx.x & 31, hw = threadIdx.x >> 5;
+  const int i = blockIdx.x * 8 + hw;
+  const bool cv = i < N, lv = cv && l < R;
+  int* sx = sxy[hw][0];
+  int* sy = sxy[hw][1];
+  float py = 0.f, px = 0.f;
+  if (cv) { py = pts[2 * i]; px = pts[2 * i + 1]; }
+  float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY, rmax = 0.f;
+  if (lv) {
+    const float d = dist[(size_t)i * R + l];
+    const float2 sc = sincos[l];
+    const float y = py + d * sc.x;   // stardist2d.cpp:454 (compiled with -ffp-contract=off)
+    const float x = px + d * sc.y;   // stardist2d.cpp:455
+    xmin = xmax = x; ymin = ymax = y;
+    const int X = (int)(long long)x, Y = (int)(long long)y;   // IntPoint(cInt(x), cInt(y)) :471
+    sx[l] = X; sy[l] = Y;
+    vx[(size_t)i * R + l] = X; vy[(size_t)i * R + l] = Y;
+    rmax = fmaxf(0.f, d);
+  }
+  for (int o = 16; o; o >>= 1) {
+    xmin = fminf(xmin, __shfl_xor(xmin, o)); xmax = fmaxf(xmax, __shfl_xor(xmax, o));
+    ymin = fminf(ymin, __shfl_xor(ymin, o)); ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    rmax = fmaxf(rmax, __shfl_xor(rmax, o));
+  }
+  __builtin_amdgcn_wave_barrier();           // (a wave's LDS accesses are processed in order)
+  i64 s = 0, sa = 0;
+  if (lv) {
+    const int kn = (l + 1 == R) ? 0 : l + 1;
+    const i64 c = (i64)sx[l] * sy[kn] - (i64)sy[l] * sx[kn];
+    s = c; sa = (c < 0 ? -c : c);
+  }
+  for (int o = 16; o; o >>= 1) { s += __shfl_xor(s, o); sa += __shfl_xor(sa, o); }
+  if (cv && l == 0) {
+    // area_from_path :128-138: float accumulation of int64 cross products in path order; equals the exact integer sum whenever
+    // sum|term| < 2^24, else the serial order is replayed
+    float a;
+    if (sa < (1ll << 24)) a = (float)s;
+    else {
+      a = 0.f;
+      for (int k = 0; k < R; ++k) {
+        const int kn = (k + 1 == R) ? 0 : k + 1;
+        a += (float)((i64)sx[k] * sy[kn] - (i64)sy[k] * sx[kn]);
+      }
+    }
+    area[i] = (float)(0.5 * (double)fabsf(a));
+    radius[i] = rmax;
+    bbox[i] = make_int4((int)xmin, (int)xmax, (int)ymin, (int)ymax);   // bbox_intersect takes ints :142-148
+    const int rb = __float_as_int(rmax);
+    const int iy = (int)floorf(py), ix = (int)floorf(px);
+    volatile int* gs = gstats;
+    if (rb > gs[0]) atomicMax(&gstats[0], rb);
+    if (iy < gs[1]) atomicMin(&gstats[1], iy);
+    if (iy > gs[2]) atomicMax(&gstats[2], iy);
+    if (ix < gs[3]) atomicMin(&gstats[3], ix);
+    if (ix > gs[4]) atomicMax(&gstats[4], ix);
+  }
+}
+
 struct GridP { float y0, x0, inv_cs; int ny, nx; };
 
 __device__ __forceinline__ int cell_of(const GridP g, float py, float px, int& cy, int& cx) {
@@ -590,7 +655,7 @@ __global__ void k_tail_init2(Deferred d, const unsigned char* __restrict__ kind,
   if (blockIdx.x == 0 && threadIdx.x == 0) { *nPairs = n; *firstNew = n; }
 }
 __global__ void k_copy_u32(unsigned int* dst, const unsigned int* src) { *dst = *src; }
-constexpr unsigned int DEFER_UNDECIDED_MAX = 16384u;      // a sweep launch over fewer pairs than this is pure latency (98 304 pairs are in flight at once)
+// a sweep launch over fewer pairs than this is pure latency (98 304 pairs are in flight at once): option "nms2d_defer_max", default 16 384
 // deferred pairs of candidate j: true if one of them suppresses it (their survivors i are KEPT by construction)
 __device__ __forceinline__ bool deferred_suppresses(int j, const int* __restrict__ defHead, const int* __restrict__ defNext,
                                                     const unsigned char* __restrict__ supp) {
@@ -845,8 +910,11 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   SD_CHECK(hipMemcpyAsync(gstats, gs_init, sizeof(gs_init), hipMemcpyHostToDevice, s));
   SD_CHECK(hipMemsetAsync(state, 0, N, s));
   if (stats) SD_CHECK(hipEventRecord(ev0, s));
-  hipLaunchKernelGGL(k_build, dim3(sd::div_up(N, 4)), dim3(256), 4 * 2 * R * sizeof(int), s, d_dist, d_points, d_sc, N, R,
-                     vx, vy, bbox, radius, area, gstats);
+  if (R <= 32)
+    hipLaunchKernelGGL(k_build32, dim3(sd::div_up(N, 8)), dim3(256), 0, s, d_dist, d_points, d_sc, N, R, vx, vy, bbox, radius, area, gstats);
+  else
+    hipLaunchKernelGGL(k_build, dim3(sd::div_up(N, 4)), dim3(256), 4 * 2 * R * sizeof(int), s, d_dist, d_points, d_sc, N, R,
+                       vx, vy, bbox, radius, area, gstats);
   SD_LAUNCH_CHECK();
   // ---- prepared polygons (Clipper::AddPath once per candidate), on a second stream: they depend on the integer vertices only, the
   // grid and the neighbour lists that follow on the caller's stream do not need them (0.84 ms of independent work at 2048^2)
@@ -1055,6 +1123,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   if (!nNewExact) return -1;
   // deferral of the enclosure's undecided pairs (see k_defer_undecided): from round 2 on by default (option nms2d_defer_undecided)
   const int deferFrom = (deferOn && decided) ? sd::option(sd::OPT_NMS2D_DEFER_UNDECIDED) : 0;
+  const unsigned int deferMax = (unsigned int)(sd::option(sd::OPT_NMS2D_DEFER_MAX) > 0 ? sd::option(sd::OPT_NMS2D_DEFER_MAX) : 0);
   unsigned char* defKind = nullptr; unsigned int* nJoinDef = nullptr;
   if (deferFrom > 0) {
     defKind = A.take_n<unsigned char>(qCap); nJoinDef = A.take_n<unsigned int>(1);
@@ -1085,7 +1154,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
           hipLaunchKernelGGL(k_pairs_decide, dim3(256 * 8), dim3(256), 0, s, pairs, &d_cnt->nPairs, first, vx, vy, R, props, area, threshold, state, suppOut,
                              decided, &d_cnt->nDecided);
         if (!suppOut && deferFrom > 0 && rounds >= deferFrom)      // few undecided pairs: they wait for the tail batch's sweep launch
-          hipLaunchKernelGGL(k_defer_undecided, dim3(256), dim3(256), 0, s, pairs, &d_cnt->nPairs, &d_cnt->nDecided, DEFER_UNDECIDED_MAX, decided, state, dfr, defKind, &d_cnt->nErr);
+          hipLaunchKernelGGL(k_defer_undecided, dim3(256), dim3(256), 0, s, pairs, &d_cnt->nPairs, &d_cnt->nDecided, deferMax, decided, state, dfr, defKind, &d_cnt->nErr);
         // tail batch with deferred undecided pairs: they sit in the list's prefix with decided[] = 0 and are bucketed with the rest
         const unsigned int* bfirst = (suppOut && deferFrom > 0) ? nullptr : first;
         SD_CHECK(hipStreamWaitEvent(s, evPrep, 0));          // the prepared polygons (side stream; complete long before, except in round 1)
@@ -1204,7 +1273,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
       else { sd::set_error("sd_nms2d: greedy scan made no progress (internal error)"); return -1; }
     }
     if (deferOn) nDeferred += h.nExact;
-    if (deferFrom > 0 && rounds >= deferFrom && h.nPairs > h.nDecided && h.nPairs - h.nDecided <= DEFER_UNDECIDED_MAX) nUndecDeferredUpper += (i64)(h.nPairs - h.nDecided);
+    if (deferFrom > 0 && rounds >= deferFrom && h.nPairs > h.nDecided && h.nPairs - h.nDecided <= deferMax) nUndecDeferredUpper += (i64)(h.nPairs - h.nDecided);
     if (account("round")) return -1;
     nU = h.nU;
     int* t = Ucur; Ucur = Unext; Unext = t;

@@ -15,6 +15,9 @@ if os.environ.get("SD_AREA_BOUNDS"):
 if os.environ.get("SD_PAIR_LANES"):
     _native.check(_native.lib().sd_set_option(b"nms2d_pair_lanes", int(os.environ["SD_PAIR_LANES"])))
     print("nms2d_pair_lanes =", _native.lib().sd_get_option(b"nms2d_pair_lanes"))
+for env, opt in (("SD_DEFER_FROM", b"nms2d_defer_undecided"), ("SD_DEFER_MAX", b"nms2d_defer_max")):
+    if os.environ.get(env):
+        _native.check(_native.lib().sd_set_option(opt, int(os.environ[env])))
 if os.environ.get("SD_TRACE"):
     _native.lib().sd_set_option(b"trace", 1)      # per-round counters on stdout
 img = torch.from_numpy(synth.s2d_nuclei_image(2048, 2048, seed=0)).to(dev)
