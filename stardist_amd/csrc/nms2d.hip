@@ -472,7 +472,17 @@ __global__ void __launch_bounds__(S) k_pairs_beam(const int2* __restrict__ pairs
   typedef sdclip::Beam<MAXV, K, MAXIL, MAXREC, Storage> BeamT;
   const unsigned long long n = (unsigned long long)*nPtr;
   const unsigned long long first = firstPtr ? (unsigned long long)*firstPtr : 0ull;      // entries before `first` are already queued for the general path
-  for (unsigned long long t = first + (unsigned long long)blockIdx.x * S + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * S) {
+  // Latency regime (fewer pairs than the launch has lanes: the late rounds, the tail batch): every workgroup takes ONE contiguous chunk of the
+  // (offset-ordered) list with its first `chunk` lanes, the others stay idle -- the sweeps of a wave's lanes share no control flow, so a
+  // launch lasts as long as the busiest wave's lanes take one after the other; spreading 25 000 pairs over all 1 536 waves at 16 lanes each
+  // instead of filling 390 waves halves that.  Otherwise the grid-stride loop over full waves.
+  const unsigned long long total = n > first ? n - first : 0ull;
+  const unsigned long long chunk = (total + gridDim.x - 1) / gridDim.x;
+  const bool spread = chunk <= (unsigned long long)S;
+  unsigned long long t = spread ? first + (unsigned long long)blockIdx.x * chunk + threadIdx.x : first + (unsigned long long)blockIdx.x * S + threadIdx.x;
+  if (spread && (unsigned long long)threadIdx.x >= chunk) t = n;
+  const unsigned long long step = spread ? (1ull << 62) : (unsigned long long)gridDim.x * S;
+  for (; t < n; t += step) {
     const unsigned int p = idx ? idx[t] : (unsigned int)t;
     const int2 ij = pairs[p];
     BeamT bm;

@@ -24,7 +24,9 @@ __global__ void __launch_bounds__(64) k_full_pairs(const int2* __restrict__ pair
                                                    const float* __restrict__ area, float thr, unsigned char* __restrict__ state, unsigned char* __restrict__ supp,
                                                    unsigned int* errCount) {
   unsigned int n = *nPtr; if (n > cap) n = cap;
-  for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+  // pair t -> lane (t / gridDim.x) of workgroup (t % gridDim.x): a short list is spread over the workgroups' FIRST lanes, one sweep per wave
+  // -- the sweeps of different pairs share no control flow, and 62 of them packed into two waves take as long as their sum
+  for (unsigned int t = threadIdx.x * gridDim.x + blockIdx.x; t < n; t += gridDim.x * blockDim.x) {
     const unsigned int p = idx ? idx[t] : t;
     const int2 ij = pairs[p];
     sdclip::SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ> sw;
@@ -48,7 +50,8 @@ __global__ void __launch_bounds__(LDSF_T) k_full_pairs_lds(const int2* __restric
                                                            unsigned int* errCount) {
   typedef sdclip::LdsStorage<LDSF_T> LP;
   unsigned int n = *nPtr; if (n > cap) n = cap;
-  for (unsigned int t = blockIdx.x * LDSF_T + threadIdx.x; t < n; t += gridDim.x * LDSF_T) {
+  // (pair t -> lane t / gridDim.x of workgroup t % gridDim.x: see k_full_pairs -- the tail batch's last launch holds a few dozen pairs)
+  for (unsigned int t = threadIdx.x * gridDim.x + blockIdx.x; t < n; t += gridDim.x * LDSF_T) {
     const unsigned int p = idx ? idx[t] : t;
     const int2 ij = pairs[p];
     sdclip::SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ, LP> sw;

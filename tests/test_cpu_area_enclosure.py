@@ -108,3 +108,22 @@ def test_adversarial_search_stays_inside_the_band():
     m = re.search(r"(\d+) evaluations \((\d+) usable\), worst \|A_clipper - A\| / band = ([0-9.]+)", out)
     assert m and int(m.group(2)) > 100000
     assert float(m.group(3)) < 0.6, out[-2000:]
+
+
+def test_counterexamples_of_the_round4_band_are_excluded_by_the_robustly_simple_rule(refmods):
+    """pairs the adversarial search found against the band as round 4 shipped it (|A_clipper - A| up to 15 bands, some with the polygons
+    nowhere near each other): for each of them Clipper's area really lies outside the band around the exact area, and the rule added in
+    round 5 (no vertex within half a lattice step of a non-incident edge of its own polygon) makes the pair unusable for the shortcut"""
+    import json
+    import os
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "area_band_counterexamples.json")))
+    assert len(G["pairs"]) >= 8
+    for e in G["pairs"]:
+        P, Q = np.array(e["P"], np.int64), np.array(e["Q"], np.int64)
+        xa, ya, xb, yb = P[None, :, 0], P[None, :, 1], Q[None, :, 0], Q[None, :, 1]
+        A, K, ok, _, _ = exact_area(xa, ya, xb, yb)
+        la, pa = edge_stats(xa, ya); lb, pb = edge_stats(xb, yb)
+        B = band(K, near_pairs(xa, ya, xb, yb), la, lb, 64.0, pa, pb)
+        C = float(refmods.clipper_area(xa[0], ya[0], xb[0], yb[0]))
+        assert abs(C - A[0]) > B[0], "not a counter-example any more?"
+        assert not (plain(xa, ya)[0] and plain(xb, yb)[0]), "the robustly-simple rule must exclude this pair"
