@@ -410,6 +410,86 @@ def run_sharded_leg(model, big, axes, block, overlap, context, passes, world, di
     return out
 
 
+class _DryModel(object):
+    """Stand-in of `--dry-collectives` (no GPU, no kernels, no network): the 'image' holds the score of a disc of radius 6 at every
+    point of a 24-pixel lattice, every disc is a candidate and a survivor (they are 12 pixels apart, nothing suppresses anything).
+    What the mode checks is the EXCHANGE of predict_instances_sharded -- how many bytes each rank puts on its link to rank 0 and that
+    every object comes out exactly once although the blocks' write regions overlap -- not any result of the product's kernels."""
+    n_rays = 32
+
+    def __init__(self):
+        from stardist_amd.models.config import Config2D
+        self.config = Config2D(n_rays=self.n_rays, n_channel_in=1)
+        self.device = "cpu"
+
+    def _axes_div_by(self, axes): return tuple(1 for a in axes)
+
+    def _axes_tile_overlap(self, axes): return tuple(0 for a in axes)
+
+    def predict_sparse(self, x, axes=None, prob_thresh=None, **kw):
+        pts = np.argwhere(x > 0)
+        return x[x > 0].astype(np.float32), np.full((len(pts), self.n_rays), 6.0, np.float32), pts
+
+    def _nms_sparse(self, dist, prob, points, nms_thresh=None, **kw):
+        return np.argsort(prob, kind="stable")[::-1].copy()
+
+    def _instances_from_survivors(self, shape, p, pr, d, return_labels=True, window=None, **kw):
+        return None, dict(points=p, prob=pr)
+
+
+def dry_collectives(args):
+    """`bench.py --gpus N --dry-collectives` (under torch.distributed.run, backend gloo, CPU only): the collectives of the block-sharded
+    path on a synthetic survivor set, with the byte count of every rank asserted -- the N > 1 exchange rehearsed where no N-GPU node is
+    at hand.  Prints one JSON line on rank 0 (not a bench line: no metric)."""
+    import torch
+    import torch.distributed as dist_
+    from stardist_amd.big import predict_instances_sharded
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if world > 1:
+        dist_.init_process_group("gloo", rank=rank, world_size=world)
+    size, block, overlap, context = 2048, 576, 64, 32
+    img = np.zeros((size, size), np.float32)
+    g = np.arange(12, size - 12, 24)
+    rs = np.random.RandomState(0)
+    img[np.ix_(g, g)] = rs.uniform(0.5, 1.0, (len(g), len(g))).astype(np.float32)
+    m = _DryModel()
+    _, res = predict_instances_sharded(m, img, "YX", block, overlap, context=context, return_labels=False, broadcast_result=True)
+    st = m._last_sharded_stats
+    W = m.n_rays + 1 + 2 + 1
+    mine = torch.tensor([st.get("sent_bytes", 0), st["local_survivors"], st["blocks"]], dtype=torch.int64)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist_.all_gather(every, mine)
+    else:
+        every = [mine]
+    sent = [int(t[0]) for t in every]
+    kept = [int(t[1]) for t in every]
+    n_obj = len(g) ** 2
+    assert len(res["points"]) == n_obj, (len(res["points"]), n_obj)                       # every object exactly once, on every rank
+    for r in range(world):
+        assert sent[r] == (0 if r == 0 else kept[r] * W * 4), (r, sent[r], kept[r])       # exact sizes: records x record bytes, nothing padded
+    if rank == 0:
+        out = dict(dry_collectives=True, backend="gloo", world=world, blocks_per_rank=[int(t[2]) for t in every],
+                   record_bytes=W * 4, objects=n_obj, records_per_rank=kept, sent_bytes_per_rank=sent)
+        if world > 1:
+            counts = st["rank_counts"]
+            assert [a + b for a, b in counts] == kept, (counts, kept)
+            assert st["gathered_bytes"] == sum(sent) and st["exact_record_bytes"] == sum(kept) * W * 4
+            out.update(gathered_bytes=st["gathered_bytes"], exact_record_bytes=st["exact_record_bytes"],
+                       padded_gather_would_move=world * max(kept) * W * 4, interior=st["interior"], band=st["band"], unique=st["unique"],
+                       duplicates_dropped=sum(kept) - st["unique"],
+                       collectives=["all_reduce(MAX) of 1 float64", "all_gather of 2 int64 per rank", "batch_isend_irecv: one message per rank with records, exact size",
+                                    "broadcast of the instance count", "broadcast of the final records"])
+            assert st["unique"] == n_obj and sum(kept) > n_obj                                # the overlap bands did report objects twice
+        out["ok"] = True
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist_.barrier()
+        dist_.destroy_process_group()
+
+
 def guarded(fn, what):
     """(result, None) or (None, message): an extra leg that fails is reported in the JSON line instead of losing the whole line"""
     try:
@@ -446,7 +526,11 @@ def main():
     ap.add_argument("--skip-sharded-3d", action="store_true")
     ap.add_argument("--no-split-leg", "--no-exact-leg", dest="no_split_leg", action="store_true",
                     help="skip the extra legs with the exact-f32 and the six-product bf16 convolution kernels")
+    ap.add_argument("--dry-collectives", action="store_true",
+                    help="CPU / gloo rehearsal of the sharded path's exchange with asserted byte counts per rank (no GPU, no bench line)")
     args = ap.parse_args()
+    if args.dry_collectives:
+        return dry_collectives(args)
 
     import torch
     import torch.distributed as dist_

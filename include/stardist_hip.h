@@ -41,6 +41,14 @@ int sd_release_workspace(void);           /* free the cached device workspace   
  *   "nms3d_tail_batch"    1|0  late greedy rounds of the 3D NMS as one speculative batch + replay on the device / as plain rounds
  *   "nms3d_split_exact"   1|0  exact volumes of the pairs the bounds leave undecided by four waves per pair in a second pass / by the
  *                              wave that evaluated the bounds (bit-identical volumes)
+ *   "nms3d_bounds_reuse"  1|0  the once-refined direction mesh keeps the ray mesh's vertices in front: their boundary points are taken
+ *                              from the coarse pass that has just run over the same planes (bit for bit what a second cast would store) /
+ *                              every direction of the refined mesh is cast
+ *   "nms3d_defer_exact"   r|0  from greedy round r on, the pairs the bounds of stages 3 / 4 leave undecided are not integrated in their
+ *                              round (a launch of the exact-volume kernel costs one exact volume's latency however few pairs it holds):
+ *                              they are queued, the suppressed-or-not candidate stays undecided, and the tail batch evaluates the queue
+ *                              in its one pass (needs "nms3d_tail_batch" and "nms3d_split_exact"; same survivors) / 0: every round
+ *                              integrates its own
  *   "nms2d_area_bounds"   1|0  2D pairs far from the threshold are decided from an enclosure of the intersection area (regular arithmetic,
  *                              area_bounds.h) / every pair runs the Clipper-exact sweep
  *   "nms2d_defer_undecided" r|0  (with "nms2d_area_bounds") from greedy round r on (default 2), a round that leaves at most 16 384 pairs undecided
@@ -333,7 +341,7 @@ int sd_conv3_bf16x6_res_ndhwc_device(const float* d_src0, int c0, int stride0, i
  * f32-level accuracy (the dropped term is below 2^-22 of a product; networks within 3e-6 of a float64 evaluation like the two forms
  * above) with half the matrix instructions of the bf16 form -- the default network path since round 4.  Same arguments as
  * sd_conv3_bf16x6_*, plus d_range_flag (device int, may be NULL): OR-ed with 1 when an input value lies outside the fp16 range
- * (|x| > 65504 or not finite), in which case the output is not valid and the caller must re-evaluate the layer with the bf16x6 form.
+ * (|x| > 65504, infinities included; a NaN is not flagged -- it propagates into the output as in any f32 evaluation), in which case the output is not valid and the caller must re-evaluate the layer with the bf16x6 form.
  * sd_conv3_f16x3_pack_weights_host returns -2 (weights still packed) when a weight is outside that range.
  * Option "conv_f16_workgroups_per_cu" (sd_set_option): 2 (default) or 1, an A/B probe of the launch geometry; same results. */
 long long sd_conv3_f16x3_packed_floats(int c_in, int c_out, int kz);

@@ -452,13 +452,13 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
     (one process per GPU; RCCL when the backend is "nccl").  Per block, on the owning rank and on the device: network + candidate
     selection (`predict_sparse`) + LOCAL NMS on the block incl. its context; a block keeps the local survivors whose centre lies in its
     write region (= block minus context; neighbouring write regions overlap by >= min_overlap, so an object in an overlap band is
-    seen with full context by both blocks).  Exchange: the kept survivors -- one packed float32 record
-    [dist(R) | prob | centre(nd) | block id | class probabilities] each, 141 B (2D) / 401 B (3D) + 4 -- go to rank 0 with ONE gather
-    (after an all_gather of the counts).  Rank 0 drops exact duplicates (same pixel reported by two blocks) and runs the SAME NMS
-    once more, restricted to the survivors that can meet a survivor of another block: two survivors of one block never suppress
-    each other (the local NMS kept both), so a survivor whose bounding box, grown by the largest bounding radius of all survivors,
-    stays inside the part of its block's write region that no other block covers is final as it is ("interior"); only the
-    "band" survivors enter the cross-tile NMS.  The result equals the NMS over the whole union.  The final instances, in global score
+    seen with full context by both blocks).  Two survivors of one block never suppress each other (the local NMS kept both), so a
+    survivor whose bounding box, grown by the largest bounding radius of all survivors (one scalar all_reduce(MAX)), stays inside the
+    part of its block's write region that no other block covers is final as it is ("interior"); the OWNER decides that.  Exchange: the
+    kept survivors -- one packed float32 record [dist(R) | prob | centre(nd) | block id | class probabilities] each, 141 B (2D) /
+    401 B (3D) + 4, interior records first -- go to rank 0 point to point in their exact sizes (batch_isend_irecv after an all_gather
+    of the two counts; nothing is padded to the largest rank).  Rank 0 drops exact duplicates among the "band" records (same pixel
+    reported by two blocks) and runs the SAME NMS once more over the band only.  The result equals the NMS over the whole union.  The final instances, in global score
     order (= label ids, as predict_instances numbers them), are broadcast, and every rank renders the write regions of ITS blocks
     from that list (windowed rasteriser; pixels in overlapping write regions come out identical on both owners).
 
@@ -628,6 +628,8 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
                 if r in bufs:
                     b = bufs[r].to(dev)
                     ints.append(b[:cnts[r][0]]); bands.append(b[cnts[r][0]:])
+        st["rank_counts"] = cnts                                    # (interior, band) records of every rank
+        st["sent_bytes"] = 0 if rank == 0 else n_loc * W * 4        # this rank's payload on its link to rank 0
         st["gathered"] = int(sum(a + b for a, b in cnts))
         st["gathered_bytes"] = int(sum((a + b) for r, (a, b) in enumerate(cnts) if r != 0)) * W * 4      # what actually crosses a link
         st["exact_record_bytes"] = st["gathered"] * W * 4

@@ -265,7 +265,10 @@ __global__ void __launch_bounds__(256) k_sum_halves3(const int* __restrict__ nLo
 // waiting; only the candidates whose wait target has just been decided go to the list scan (k_round_decide3 over the list S).
 __global__ void __launch_bounds__(256) k_round_triage3(const int* __restrict__ U, int nU, const unsigned char* __restrict__ state,
                                                        const int* __restrict__ waitOn, int* __restrict__ Unext, int* __restrict__ K,
-                                                       int* __restrict__ S, int* counters /* 0: nUnext, 1: nK, 6: nS */) {
+                                                       int* __restrict__ S, int* counters /* 0: nUnext, 1: nK, 6: nS */,
+                                                       const unsigned char* __restrict__ pend) {
+  // pend[i] != 0: a pair (kept, i) of an earlier round is still to be evaluated (its exact volume was carried into the tail batch,
+  // k_defer3): i stays undecided -- and everything that waits for it -- until the tail batch
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   int kind = 0, i = -1;                       // 0 drop, 1 still waiting, 2 becomes a survivor, 3 needs the list scan
@@ -273,7 +276,8 @@ __global__ void __launch_bounds__(256) k_round_triage3(const int* __restrict__ U
     i = U[t];
     if (state[i] != ST_SUPPRESSED) {
       const int wo = waitOn[i];
-      if (wo == WAIT3_NONE) kind = 2;
+      if (pend && pend[i]) kind = 1;
+      else if (wo == WAIT3_NONE) kind = 2;
       else if (wo >= 0 && state[wo] == ST_UNDECIDED) kind = 1;
       else kind = 3;
     }
@@ -330,6 +334,7 @@ __global__ void __launch_bounds__(256) k_round_decide3(const int* __restrict__ U
 struct Stats { unsigned long long upper, lower, kernel, render, kept_pre, sup_pre, sup_kernel, sup_render, convex, kept_convex, overflow, hiv_faces, hiv_fallback, hiv_list, hiv_clips, hiv_rest, lb_decided, ub_decided, near_thr;
                unsigned long long cyc[6]; };   // SD_TRACE: stage-3 wave cycles spent in load+half-spaces / cull / bounds / exact volume / total
 #define SD_PROF_BIT 0x40000000u
+#define SD_NOREUSE_BIT 0x20000000u   // bounds passes: cast every direction of the refined mesh (A/B switch of "nms3d_bounds_reuse")
 
 // Where a cascade stage records "i suppresses j".  Normal round (i is already KEPT): straight into the state array.  Tail batch
 // (i is still undecided, the pair is evaluated speculatively): appended to an edge list; the greedy order is replayed over those
@@ -341,6 +346,27 @@ struct SuppSink {
     else state[j] = ST_SUPPRESSED;
   }
 };
+
+// Exact volumes carried into the tail batch ("nms3d_defer_exact"): a late round's launch of the exact-volume kernel costs the latency
+// of one exact volume (~0.5 ms) for a few dozen pairs.  From round r on, the pairs (i kept, j) the bounds of stage 3 / stage 4 leave
+// undecided are queued instead; j is marked pending (k_round_triage3 keeps it undecided) and the tail batch evaluates the queue in
+// its one pass, in front of its own pairs (k_seed3).  The queue re-enters the cascade at stage 3 (a pair queued by stage 4 passes
+// stage 3's bounds again, with the same outcome).  Same fixed point: the tail replay suppresses j iff a KEPT i has a suppressing edge.
+__global__ void k_defer3(const int2* __restrict__ pairsX, const unsigned int* __restrict__ nX, int2* __restrict__ dfr, unsigned int* dfrCount,
+                         unsigned int cap, unsigned char* __restrict__ pend, unsigned long long* overflow) {
+  const unsigned int n = *nX;
+  for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const int2 ij = pairsX[t];
+    const unsigned int pos = atomicAdd(dfrCount, 1u);
+    if (pos < cap) dfr[pos] = ij; else atomicAdd(overflow, 1ull);           // the host keeps the total below cap: cannot happen
+    pend[ij.y] = 1;
+  }
+}
+__global__ void k_seed3(const int2* __restrict__ dfr, const unsigned int* __restrict__ dfrCount, unsigned int cap, int2* __restrict__ pairs, unsigned int* pairCount) {
+  const unsigned int n = *dfrCount < cap ? *dfrCount : cap;
+  for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) pairs[t] = dfr[t];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *pairCount = n;                  // the tail's emit appends behind the queue
+}
 
 // Tail replay: the fixed point of the sequential loop over the remaining candidates -- j is suppressed iff some KEPT i < j has a
 // suppressing edge (i, j).  One sweep over the edges marks what the decided sources imply, one sweep over the candidates promotes
@@ -832,12 +858,20 @@ __device__ __forceinline__ int hiv_cull_wave(double* hs, int M, const double b1[
 template <int NB>
 __device__ __forceinline__ void hiv_bounds_wave(const double* __restrict__ hs, int M, const float* __restrict__ verts,
                                                 const int* __restrict__ faces, int R, int F, double* wv, unsigned short* hit, int lane,
-                                                double& lb, double& ub) {
+                                                double& lb, double& ub, int kdone = 0, const unsigned short* hitDone = nullptr) {
 #pragma clang fp contract(fast)
+  // kdone != 0: the caller has just evaluated a coarser mesh whose kdone directions are the first kdone of this one (k_refine_mesh
+  // keeps the parent's vertices in front), over the same planes: wv[0 .. 3 kdone) holds their boundary points already (the same
+  // arithmetic on the same operands: bit for bit what this loop would store) and hitDone their planes, which only move to this mesh's
+  // table -- a quarter of the once-refined mesh's directions is not cast twice
+  if (kdone) {
+    for (int k = lane; k < kdone; k += 64) hit[k] = hitDone[k];
+    __syncthreads();                                            // hitDone lies where wv[3 kdone ..) is about to be written
+  }
   // ray cast: the plane loop is the outer one and a lane keeps up to NB directions in registers -- one LDS read of a plane serves
   // NB independent compare chains (a loop over planes per direction is bound by LDS latency + its loop-carried dependency:
   // 358k cycles per pair measured with the refined mesh, 80 % of stage 3)
-  for (int k0 = 0; k0 < R; k0 += 64 * NB) {
+  for (int k0 = kdone; k0 < R; k0 += 64 * NB) {
     double dz[NB], dy[NB], dx[NB], ne_b[NB], q_b[NB];
     int m_b[NB];
 #pragma unroll
@@ -1088,7 +1122,7 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
   double* hs = (double*)smem;                 // 2F * 4
   float* pv1 = (float*)(hs + 8 * F);          // 3R   (dead once hs is built: aliased by the polygon workspace)
   float* pv2 = pv1 + 3 * R;                   // 3R
-  unsigned short* seed = (unsigned short*)(smem + (size_t)8 * F * sizeof(double) + (wsBytes & 0x3FFFFFFFu));   // 2F * 3
+  unsigned short* seed = (unsigned short*)(smem + (size_t)8 * F * sizeof(double) + (wsBytes & 0x1FFFFFFFu));   // 2F * 3
   unsigned short* pos = seed + 6 * F;         // 2F
   unsigned short* orig = pos + 2 * F;         // 2F
   HivLds W;
@@ -1157,7 +1191,8 @@ __global__ void __launch_bounds__(64) k_stage3(const int2* __restrict__ pairs, u
       hiv_bounds_wave<2>(hs, Mc, verts, faces, R, F, W.S, (unsigned short*)(W.S + 3 * R), lane, lb, ub);
       if (bR != R && !(lb * (1.0 - 1e-9) / A_min_d > thr_hi) && !(ub * (1.0 + 1e-9) / A_min_d < thr_lo)) {
         const double lb0 = lb, ub0 = ub;
-        hiv_bounds_wave<6>(hs, Mc, bverts, bfaces, bR, bF, W.S, (unsigned short*)(W.S + 3 * bR), lane, lb, ub);
+        if (wsBytes & SD_NOREUSE_BIT) hiv_bounds_wave<6>(hs, Mc, bverts, bfaces, bR, bF, W.S, (unsigned short*)(W.S + 3 * bR), lane, lb, ub);
+        else hiv_bounds_wave<5>(hs, Mc, bverts, bfaces, bR, bF, W.S, (unsigned short*)(W.S + 3 * bR), lane, lb, ub, R, (const unsigned short*)(W.S + 3 * R));
         lb = fmax(lb, lb0); ub = fmin(ub, ub0);
       }
       if (prof) t3 = clock64();
@@ -1759,7 +1794,7 @@ __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, u
   // the smaller footprint lets six waves share a CU instead of four)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* hs = (double*)smem;                   // 2*cap*4
-  unsigned short* seed = (unsigned short*)(smem + (size_t)8 * cap * sizeof(double) + (wsBytes ? (size_t)wsBytes : hiv_poly_bytes_dev()));   // 2*cap*3
+  unsigned short* seed = (unsigned short*)(smem + (size_t)8 * cap * sizeof(double) + ((wsBytes & 0x1FFFFFFFu) ? (size_t)(wsBytes & 0x1FFFFFFFu) : hiv_poly_bytes_dev()));   // 2*cap*3
   unsigned short* pos = seed + 6 * cap;         // 2*cap
   unsigned short* orig = pos + 2 * cap;         // 2*cap
   HivLds W;
@@ -1817,7 +1852,8 @@ __global__ void __launch_bounds__(64) k_stage4(const int2* __restrict__ pairs, u
       hiv_bounds_wave<2>(hs, Mc, verts, faces, R, F, W.S, (unsigned short*)(W.S + 3 * R), lane, lb, ub);
       if (bR != R && !(lb * (1.0 - 1e-9) / A_min_d > thr_hi) && !(ub * (1.0 + 1e-9) / A_min_d < thr_lo)) {
         const double lb0 = lb, ub0 = ub;
-        hiv_bounds_wave<6>(hs, Mc, bverts, bfaces, bR, bF, W.S, (unsigned short*)(W.S + 3 * bR), lane, lb, ub);
+        if (wsBytes & SD_NOREUSE_BIT) hiv_bounds_wave<6>(hs, Mc, bverts, bfaces, bR, bF, W.S, (unsigned short*)(W.S + 3 * bR), lane, lb, ub);
+        else hiv_bounds_wave<5>(hs, Mc, bverts, bfaces, bR, bF, W.S, (unsigned short*)(W.S + 3 * bR), lane, lb, ub, R, (const unsigned short*)(W.S + 3 * R));
         lb = fmax(lb, lb0); ub = fmin(ub, ub0);
       }
       if (lb * (1.0 - 1e-9) / A_min_d > thr_hi && !no_lb) {
@@ -2506,9 +2542,23 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   const int tailOpt = sd::option(sd::OPT_NMS3D_TAIL_BATCH), tailDiv = tailOpt >= 2 ? tailOpt : 32;       // option value >= 2: the divisor itself (tuning)
   const int tailT = tailOpt ? (N / tailDiv > 512 ? N / tailDiv : 512) : -1;
   int2* supEdges = nullptr; unsigned int* supCount = nullptr; unsigned char* blocked = nullptr; int* d_left = nullptr;
+  // exact volumes of the late rounds carried into the tail batch (k_defer3): from round deferFrom on, while the queue has room for
+  // the round's pairs.  Needs the tail batch and the split exact-volume passes (the bounds passes hand over the undecided pairs).
+  const int deferFrom = (tailOpt && use_bounds && (split3 || split4)) ? sd::option(sd::OPT_NMS3D_DEFER_EXACT) : 0;
+  const unsigned int dfrCap = 65536u;
+  int2* dfr = nullptr; unsigned int* dfrCount = nullptr; unsigned char* pend = nullptr;
+  unsigned int hDef = 0;                                   // pairs queued so far (host mirror: the counters of every round are read anyway)
+  if (deferFrom > 0) {
+    dfr = A.take_n<int2>(dfrCap); dfrCount = A.take_n<unsigned int>(1); pend = A.take_n<unsigned char>(N);
+    if (!dfr || !dfrCount || !pend) return -1;
+    SD_CHECK(hipMemsetAsync(dfrCount, 0, sizeof(unsigned int), s));
+    SD_CHECK(hipMemsetAsync(pend, 0, N, s));
+  }
+  const unsigned int noReuse = sd::option(sd::OPT_NMS3D_BOUNDS_REUSE) ? 0u : SD_NOREUSE_BIT;
+  bool forceTail = false;
   while (nU > 0) {
     ++rounds;
-    const bool tail = rounds > 1 && nU <= tailT;
+    const bool tail = rounds > 1 && (nU <= tailT || forceTail);
     SD_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), s));
     if (tail) {
       if (!supEdges) {
@@ -2517,15 +2567,23 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
       }
       SD_CHECK(hipMemsetAsync(supCount, 0, sizeof(unsigned int), s));
       SD_CHECK(hipMemsetAsync(blocked, 0, N, s));
+      if (hDef) hipLaunchKernelGGL(k_seed3, dim3(sd::div_up(hDef, 256)), dim3(256), 0, s, dfr, dfrCount, dfrCap, pairs3, &d_cnt->nP3);
       h.nK = nU; h.nU = 0;
     } else {
-      hipLaunchKernelGGL(k_round_triage3, dim3(sd::div_up(nU, 256)), dim3(256), 0, s, Ucur, nU, state, waitOn, Unext, Kl, Sl, (int*)d_cnt);
+      hipLaunchKernelGGL(k_round_triage3, dim3(sd::div_up(nU, 256)), dim3(256), 0, s, Ucur, nU, state, waitOn, Unext, Kl, Sl, (int*)d_cnt, (const unsigned char*)pend);
       const int wgrid = sd::div_up(nU, 4) < 2048 ? sd::div_up(nU, 4) : 2048;
       hipLaunchKernelGGL(k_round_decide3, dim3(wgrid), dim3(256), 0, s, Sl, &d_cnt->nS, state, nbrStart, nbrLow, nbr, waitOn, Unext, Kl, (int*)d_cnt);
       SD_LAUNCH_CHECK();
       SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
       SD_CHECK(hipStreamSynchronize(s));
-      if (h.nK == 0 && h.nU > 0) { sd::set_error("sd_nms3d: greedy scan made no progress (internal error)"); return -1; }
+      if (h.nK == 0 && h.nU > 0) {
+        if (!hDef) { sd::set_error("sd_nms3d: greedy scan made no progress (internal error)"); return -1; }
+        // every remaining candidate is pending or waits for a pending one: the tail batch takes over from here
+        forceTail = true;
+        nU = h.nU;
+        int* t = Ucur; Ucur = Unext; Unext = t;
+        continue;
+      }
     }
     const SuppSink sink = tail ? SuppSink{state, supEdges, supCount, pairCap} : SuppSink{state, nullptr, nullptr, 0u};
     const int nKeep = h.nK, nUndecided = h.nU;
@@ -2546,15 +2604,19 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
         const size_t ws3l = small3 ? ws3s : ws3;
         const size_t lds3l = (size_t)8 * F * sizeof(double) + ws3l + (size_t)10 * F * sizeof(unsigned short);
         hipLaunchKernelGGL(k_stage3, dim3(b3), dim3(64), lds3l, s, pairs3, h.nP3, d_dist, d_points, d_verts, d_faces, faceAdj, R, F, volume,
-                           threshold, sink, pairs4, &d_cnt->nP4, d_st, (unsigned int)ws3l | (use_bounds ? 0u : 0x80000000u) | (trace ? SD_PROF_BIT : 0u), bverts, bfaces, bR, bF,
+                           threshold, sink, pairs4, &d_cnt->nP4, d_st, (unsigned int)ws3l | (use_bounds ? 0u : 0x80000000u) | (trace ? SD_PROF_BIT : 0u) | noReuse, bverts, bfaces, bR, bF,
                            (double*)nullptr, sp3 ? pairsX : (int2*)nullptr, &d_cnt->nX3);
-        if (split3 && h.nP3 <= split3Max)
+        const bool defer3 = sp3 && !tail && deferFrom > 0 && rounds >= deferFrom && hDef + h.nP3 <= dfrCap;
+        if (defer3)
+          hipLaunchKernelGGL(k_defer3, dim3(h.nP3 < 16384u ? sd::div_up(h.nP3, 256) : 64), dim3(256), 0, s, pairsX, &d_cnt->nX3, dfr, dfrCount, dfrCap, pend, &d_st->overflow);
+        else if (sp3)
           hipLaunchKernelGGL(k_stage3x<4>, dim3(h.nP3 < 256u ? h.nP3 : 256u), dim3(256), lds3x, s, pairsX, &d_cnt->nX3, 0u, d_dist, d_points, d_verts, d_faces, faceAdj,
                              R, F, volume, threshold, sink, pairs4, &d_cnt->nP4, d_st, (unsigned int)ws3, (double*)nullptr, b3verts, b3faces, b3R, b3F);
         SD_LAUNCH_CHECK();
         if (stats) SD_CHECK(hipEventRecord(ev1, s));
         SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
         SD_CHECK(hipStreamSynchronize(s));
+        if (defer3) hDef += h.nX3;
         if (stats) { float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns3 += ms * 1e6;
                      if (trace) printf("round %d: nU=%d nK=%d stage3 pairs=%u %.3f ms -> stage4 pairs=%u\n", rounds, h.nU, h.nK, h.nP3, ms, h.nP4); }
         if (h.nP4 > 0) {
@@ -2581,14 +2643,18 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
           const size_t lds4l = small4 ? (size_t)16 * R * sizeof(double) + ws4s + (size_t)20 * R * sizeof(unsigned short) : lds4;
           hipLaunchKernelGGL(k_stage4, dim3(b4), dim3(64), lds4l, s, pairs4, h.nP4, d_dist, d_points, d_verts, d_faces, R, F, hullCap, hullPlanes, hullAdj, hullCount,
                              volume, threshold, pairs5, &d_cnt->nP5, d_st, use_bounds ? 0 : 1, bverts, bfaces, bR, bF, (double*)nullptr,
-                             sp4 ? pairsX : (int2*)nullptr, &d_cnt->nX4, small4 ? (unsigned int)ws4s : 0u);
-          if (split4 && h.nP4 <= split4Max)
+                             sp4 ? pairsX : (int2*)nullptr, &d_cnt->nX4, (small4 ? (unsigned int)ws4s : 0u) | noReuse);
+          const bool defer4 = sp4 && !tail && deferFrom > 0 && rounds >= deferFrom && hDef + h.nP4 <= dfrCap;
+          if (defer4)
+            hipLaunchKernelGGL(k_defer3, dim3(h.nP4 < 16384u ? sd::div_up(h.nP4, 256) : 64), dim3(256), 0, s, pairsX, &d_cnt->nX4, dfr, dfrCount, dfrCap, pend, &d_st->overflow);
+          else if (sp4)
             hipLaunchKernelGGL(k_stage4x<4>, dim3(h.nP4 < 256u ? h.nP4 : 256u), dim3(256), lds4x, s, pairsX, &d_cnt->nX4, 0u, d_dist, d_points, R, hullCap, hullPlanes, hullAdj,
                                hullCount, volume, threshold, pairs5, &d_cnt->nP5, d_st, (double*)nullptr, b3verts, b3faces, b3R, b3F);
           SD_LAUNCH_CHECK();
           if (stats) SD_CHECK(hipEventRecord(ev1, s));
           SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
           SD_CHECK(hipStreamSynchronize(s));
+          if (defer4) hDef += h.nX4;
           if (stats) { float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns4 += ms * 1e6;
                        if (trace) printf("         stage4 pairs=%u hulls=%u %.3f ms -> stage5 pairs=%u\n", h.nP4, h.nHull, ms, h.nP5); }
         }
@@ -2607,7 +2673,8 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
       SD_CHECK(hipMemcpyAsync(&nEdges, supCount, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
       SD_CHECK(hipStreamSynchronize(s));
       if (nEdges > pairCap) { sd::set_error("sd_nms3d: tail edge list overflow (internal error)"); return -1; }
-      if (trace) printf("tail batch after round %d: %d undecided candidates, %u suppressing edges\n", rounds - 1, nU, nEdges);
+      if (trace) printf("tail batch after round %d: %d undecided candidates, %u suppressing edges, %u pairs carried over from the rounds%s\n", rounds - 1, nU, nEdges, hDef,
+                        forceTail ? " (started early: every remaining candidate waits for one of them)" : "");
       int left = 1, sweeps = 0;
       while (left) {
         for (int it = 0; it < 8; ++it) {

@@ -92,7 +92,8 @@ def rays_device_tensors(rays, device):
 
 
 def rays_from_json(d):
-    """rays3d.py:156.  The objects are immutable in use (`copy(scale)` returns a new one), so one instance per description is kept:
+    """rays3d.py:156.  The objects are immutable in use (`copy(scale)` returns a new one), so one instance per description is kept
+    and SHARED by its callers (its vertex / face arrays are read-only; `copy()` returns a private, writable instance):
     building Rays_GoldenSpiral(96) runs scipy's ConvexHull (1.4 ms), and the reference's call sites ask for it on every
     predict_instances (model3d.py:600)."""
     import json
@@ -106,6 +107,9 @@ def rays_from_json(d):
         if len(_RAYS_CACHE) >= 16:
             _RAYS_CACHE.clear()
         r = cls[d["name"]](**d["kwargs"])
+        for a in (r._vertices, r._faces):                            # shared between every model with this description: an in-place
+            if isinstance(a, np.ndarray):                            # edit would corrupt them all -- refuse it (copy() gives a private one)
+                a.setflags(write=False)
         _RAYS_CACHE[key] = r
     return r
 

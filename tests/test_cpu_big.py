@@ -328,3 +328,22 @@ def test_cover_crop_filter_objects_equal_reference_golden(name, axes):
         import torch
         lt, pt = block.filter_objects(torch.from_numpy(np.ascontiguousarray(block.crop_context(lab, axes=axes))), dict(points=pts, prob=np.linspace(1, 0.5, len(ids))), axes=axes)
         assert np.array_equal(lt.numpy(), lf) and np.array_equal(pt["points"], pf["points"])
+
+
+def test_bench_dry_collectives_gloo_world2():
+    """`bench.py --gpus 2 --dry-collectives` as the driver would launch it: the sharded path's exchange on gloo with the byte count of
+    every rank asserted inside (exact sizes, nothing padded) and every object of the synthetic set reported once"""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-collectives"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["ok"] and d["world"] == 2 and d["sent_bytes_per_rank"][0] == 0
+    assert d["gathered_bytes"] == d["records_per_rank"][1] * d["record_bytes"] < d["padded_gather_would_move"]
+    assert d["unique"] == d["objects"] and d["duplicates_dropped"] > 0

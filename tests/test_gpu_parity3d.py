@@ -162,6 +162,63 @@ def test_nms3d_neighbour_list_forms_agree(refmods):
         assert len(set(entries)) == 1, entries
 
 
+def test_nms3d_exact_volumes_carried_into_the_tail_batch(refmods, capfd):
+    """"nms3d_defer_exact": the pairs the bounds leave undecided in rounds >= r are queued and evaluated by the tail batch's one pass
+    (k_defer3 / k_seed3, pending candidates stay undecided): the reference's survivors for every r -- r = 1 included, the strongest
+    form (every round defers; the rounds end early once everything left waits for a pending candidate) -- on the noisy random sets of
+    the reference's own test (many pairs near the threshold) and on the nuclei set; the trace tells how many pairs were carried"""
+    import re
+    import torch
+    from oracle import synth
+    from stardist_amd.lib import _native as N, stardist3d as sd3
+    rays = _rays(96)
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    refmods.stardist3d(); refmods.set_threads(1)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    sets = []
+    for thr in (0.3, 0.6):
+        d, p, s = _random_candidates((22, 33, 44), 96, 0.3, seed=96)
+        sets.append(("random %.1f" % thr, d, p, s, thr, _ref_keep_random(refmods, (22, 33, 44), 96, 0.3, thr)))
+    d, p, s, nobj = synth.s3d_nuclei(96, rays.vertices)
+    sets.append(("nuclei", d, p, s, 0.3, refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(0.3))))
+    report = {}
+    for name, d, p, s, thr, ref_keep in sets:
+        args = (t(d), t(p), t(np.float32(V)), t(F), t(s), 1, 1, 0, np.float32(thr))
+        for r in (0, 1, 2, 3):
+            capfd.readouterr()
+            with N.option("nms3d_defer_exact", r), N.option("trace", 1):
+                keep = sd3.c_non_max_suppression_inds(*args)
+                torch.cuda.synchronize()
+            out = capfd.readouterr().out
+            assert np.array_equal(keep.cpu().numpy(), ref_keep), (name, r, int(keep.sum()), int(ref_keep.sum()))
+            m = re.search(r"(\d+) pairs carried over", out)
+            report[(name, r)] = int(m.group(1)) if m else None
+    assert all(report[(name, 0)] in (0, None) for name, *_ in sets), report
+    print("pairs carried into the tail batch:", report)
+
+
+def test_nms3d_bounds_reuse_does_not_change_decisions(refmods):
+    """"nms3d_bounds_reuse": the refined bounds pass takes the ray directions' boundary points from the coarse pass / casts them again:
+    same survivors, same number of pairs decided by each bound and integrated exactly (the bounds are bit-identical)"""
+    import torch
+    from oracle import synth
+    from stardist_amd.lib import _native as N, stardist3d as sd3
+    rays = _rays(96)
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    d, p, s, nobj = synth.s3d_nuclei(96, rays.vertices)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    args = (t(d), t(p), t(np.float32(V)), t(F), t(s), 1, 1, 0, np.float32(0.3))
+    refmods.stardist3d(); refmods.set_threads(1)
+    ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(0.3))
+    res = {}
+    for reuse in (1, 0):
+        with N.option("nms3d_bounds_reuse", reuse):
+            keep, st = sd3.c_non_max_suppression_inds(*args, return_stats=True)
+        assert np.array_equal(keep.cpu().numpy(), ref_keep), reuse
+        res[reuse] = [int(st[k]) for k in (0, 1, 2, 3, 6, 7, 11, 12, 13)]
+    assert res[0] == res[1], res
+
+
 def test_nms3d_split_exact_does_not_change_survivors_or_volumes(refmods):
     """exact volumes by four waves per pair in a second pass (k_stage3x / k_stage4x) vs by the wave that evaluated the bounds: the
     same survivors as the reference, with and without the bound shortcuts, and bit-identical pair volumes"""

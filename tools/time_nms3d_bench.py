@@ -15,6 +15,10 @@ if os.environ.get("SD_SPLIT_EXACT"):
     print("nms3d_split_exact =", _native.lib().sd_get_option(b"nms3d_split_exact"))
 if os.environ.get("SD_TAIL"):
     _native.check(_native.lib().sd_set_option(b"nms3d_tail_batch", int(os.environ["SD_TAIL"])))
+for env, name in (("SD_DEFER3", b"nms3d_defer_exact"), ("SD_REUSE", b"nms3d_bounds_reuse")):
+    if os.environ.get(env):
+        _native.check(_native.lib().sd_set_option(name, int(os.environ[env])))
+        print(name.decode(), "=", _native.lib().sd_get_option(name))
 if os.environ.get("SD_TRACE"):
     _native.lib().sd_set_option(b"trace", 1)      # per-round counters on stdout
 S = int(os.environ.get("SD_SIZE3D", "256"))
