@@ -39,16 +39,19 @@ int sd_release_workspace(void);           /* free the cached device workspace   
  *   "nms3d_refine_mesh"   2|1|0  direction meshes of the volume bounds: the ray mesh only (0); refined once for the pairs it leaves
  *                              undecided (1); refined twice for the pairs that reach the exact-volume kernels (2, default)
  *   "nms3d_tail_batch"    1|0  late greedy rounds of the 3D NMS as one speculative batch + replay on the device / as plain rounds
- *   "nms3d_split_exact"   1|0  exact volumes of the pairs the bounds leave undecided by four waves per pair in a second pass / by the
- *                              wave that evaluated the bounds (bit-identical volumes)
+ *   "nms3d_split_exact"   3|2|1|0  exact volumes of the pairs the bounds leave undecided by four waves per pair in a second pass (3,
+ *                              default: for every launch; 2: stage 4 only up to 16 384 pairs per launch; 1: both stages only for small
+ *                              launches, full-size workspace in the bounds pass) / 0: by the wave that evaluated the bounds
+ *                              (bit-identical volumes)
  *   "nms3d_bounds_reuse"  1|0  the once-refined direction mesh keeps the ray mesh's vertices in front: their boundary points are taken
  *                              from the coarse pass that has just run over the same planes (bit for bit what a second cast would store) /
  *                              every direction of the refined mesh is cast
  *   "nms3d_defer_exact"   r|0  from greedy round r on, the pairs the bounds of stages 3 / 4 leave undecided are not integrated in their
  *                              round (a launch of the exact-volume kernel costs one exact volume's latency however few pairs it holds):
  *                              they are queued, the suppressed-or-not candidate stays undecided, and the tail batch evaluates the queue
- *                              in its one pass (needs "nms3d_tail_batch" and "nms3d_split_exact"; same survivors) / 0: every round
- *                              integrates its own
+ *                              in its one pass (needs "nms3d_tail_batch" and "nms3d_split_exact"; same survivors; default 3: measured
+ *                              on the 256^3 bench set 23.0 -> 21.3 ms, from round 1 or 2 on the pending candidates stall the rounds
+ *                              behind them: 23.2 ms) / 0: every round integrates its own
  *   "nms2d_area_bounds"   1|0  2D pairs far from the threshold are decided from an enclosure of the intersection area (regular arithmetic,
  *                              area_bounds.h) / every pair runs the Clipper-exact sweep
  *   "nms2d_defer_undecided" r|0  (with "nms2d_area_bounds") from greedy round r on (default 2), a round that leaves at most 16 384 pairs undecided

@@ -2545,7 +2545,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   // exact volumes of the late rounds carried into the tail batch (k_defer3): from round deferFrom on, while the queue has room for
   // the round's pairs.  Needs the tail batch and the split exact-volume passes (the bounds passes hand over the undecided pairs).
   const int deferFrom = (tailOpt && use_bounds && (split3 || split4)) ? sd::option(sd::OPT_NMS3D_DEFER_EXACT) : 0;
-  const unsigned int dfrCap = 65536u;
+  const unsigned int dfrCap = 262144u;
   int2* dfr = nullptr; unsigned int* dfrCount = nullptr; unsigned char* pend = nullptr;
   unsigned int hDef = 0;                                   // pairs queued so far (host mirror: the counters of every round are read anyway)
   if (deferFrom > 0) {
@@ -2720,6 +2720,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
     printf("NMS: greedy rounds: %d, neighbour entries: %lld\n", rounds, (long long)totalNbr);
     fflush(stdout);
   }
+  if (trace) fflush(stdout);
   return 0;
 }
 

@@ -53,11 +53,19 @@ def test_nms2d_bench_candidate_set_keep_array_equals_reference(refmods):
     assert np.array_equal(keep, ref_keep), "mismatching candidates: %s (pairs %d, general path %d)" % (np.flatnonzero(keep != ref_keep)[:10], stats[0], stats[1])
 
 
-def test_nms3d_256_keep_array_equals_reference_golden():
+@pytest.mark.parametrize("defer_exact", [None, 0, 1, 3])
+def test_nms3d_256_keep_array_equals_reference_golden(defer_exact):
     """config 3 (S3D-nuclei 256^3, 150 606 candidates, Rays_GoldenSpiral(96)): survivors bit-identical to the compiled reference
-    run with ONE OpenMP thread (minutes of Qhull, hence the committed golden bits)"""
+    run with ONE OpenMP thread (minutes of Qhull, hence the committed golden bits) -- with the library's defaults and with the exact
+    volumes carried into the tail batch from round 1 / round 3 on / never ("nms3d_defer_exact")"""
+    import contextlib
     from oracle import synth
-    from stardist_amd.lib import stardist3d as sd3
+    from stardist_amd.lib import _native as N, stardist3d as sd3
+    with (contextlib.nullcontext() if defer_exact is None else N.option("nms3d_defer_exact", defer_exact)):
+        _nms3d_256_golden(synth, sd3)
+
+
+def _nms3d_256_golden(synth, sd3):
     from stardist_amd.rays3d import Rays_GoldenSpiral
     rays = Rays_GoldenSpiral(96)
     V, F = rays.vertices, rays.faces.astype(np.int32)
