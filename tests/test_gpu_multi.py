@@ -28,7 +28,8 @@ def _worker(rank, world, port, q):
     bench.calibrate_heads(model, img, frac=0.03)
     labels, res = model.predict_instances_sharded(img, "YX", block_size=512, min_overlap=64, context=64)
     st = model._last_sharded_stats
-    q.put((rank, None if labels is None else np.asarray(labels), res["points"], res["prob"], st["gathered"], st["gathered_bytes"]))
+    q.put((rank, None if labels is None else np.asarray(labels), res["points"], res["prob"], st["gathered"], st["gathered_bytes"],
+           st["exact_record_bytes"], [tuple(c) for c in st["rank_counts"]]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,9 +54,12 @@ def test_sharded_two_ranks_rccl_equals_one_rank():
     for p in procs: p.start()
     res = [q.get(timeout=600) for _ in range(2)]
     for p in procs: p.join(120)
-    for rank, labels, pts, prob, gathered, nbytes in res:
+    rec_bytes = (32 + 1 + 2 + 1) * 4
+    for rank, labels, pts, prob, gathered, nbytes, exact, counts in res:
         assert np.array_equal(pts, r1["points"]) and np.array_equal(prob, r1["prob"])
-        assert gathered == model._last_sharded_stats["gathered"] and nbytes == gathered * (32 + 1 + 2 + 1) * 4
+        # exact-size exchange: what crosses a link are the records of the ranks other than 0, nothing padded
+        assert gathered == model._last_sharded_stats["gathered"] == sum(a + b for a, b in counts) and exact == gathered * rec_bytes
+        assert nbytes == sum(a + b for a, b in counts[1:]) * rec_bytes
         if rank == 0:
             assert np.array_equal(labels, l1)
 
