@@ -38,7 +38,8 @@ int sd_release_workspace(void);           /* free the cached device workspace   
  *   "nms3d_cone_map"      1|0  stage-5 voxel tests through the cone map / over every face as the reference does
  *   "nms3d_refine_mesh"   2|1|0  direction meshes of the volume bounds: the ray mesh only (0); refined once for the pairs it leaves
  *                              undecided (1); refined twice for the pairs that reach the exact-volume kernels (2, default)
- *   "nms3d_tail_batch"    1|0  late greedy rounds of the 3D NMS as one speculative batch + replay on the device / as plain rounds
+ *   "nms3d_tail_batch"    1|0  late greedy rounds of the 3D NMS (once at most max(N/32, 512) candidates are undecided) as one speculative
+ *                              batch + replay on the device / as plain rounds; a value d >= 2 sets the threshold to N/d (tuning)
  *   "nms3d_split_exact"   3|2|1|0  exact volumes of the pairs the bounds leave undecided by four waves per pair in a second pass (3,
  *                              default: for every launch; 2: stage 4 only up to 16 384 pairs per launch; 1: both stages only for small
  *                              launches, full-size workspace in the bounds pass) / 0: by the wave that evaluated the bounds
