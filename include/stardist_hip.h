@@ -47,6 +47,9 @@ int sd_release_workspace(void);           /* free the cached device workspace   
  *   "nms3d_bounds_reuse"  1|0  the once-refined direction mesh keeps the ray mesh's vertices in front: their boundary points are taken
  *                              from the coarse pass that has just run over the same planes (bit for bit what a second cast would store) /
  *                              every direction of the refined mesh is cast
+ *   "nms3d_bounds_lean"   1|0  bounds-only launches of stages 3 / 4 (every launch in the two-pass form) are made without the adjacency-seed
+ *                              table, and the cull's index tables lie in the ray-cast workspace: 21.9 instead of 25.6 KB of LDS per wave,
+ *                              seven waves per CU instead of six / the layout of the one-pass kernels
  *   "nms3d_defer_exact"   r|0  from greedy round r on, the pairs the bounds of stages 3 / 4 leave undecided are not integrated in their
  *                              round (a launch of the exact-volume kernel costs one exact volume's latency however few pairs it holds):
  *                              they are queued, the suppressed-or-not candidate stays undecided, and the tail batch evaluates the queue

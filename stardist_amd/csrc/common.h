@@ -49,7 +49,7 @@ static inline int div_up(long long a, long long b) { return (int)((a + b - 1) / 
 
 // Result-preserving switches between equivalent formulations (set through sd_set_option of the C ABI, documented there): the parity
 // suite runs both settings against the reference.  Nothing in a release build reads the process environment.
-enum Option { OPT_NMS3D_VOLUME_BOUNDS, OPT_NMS3D_CONE_MAP, OPT_NMS3D_REFINE_MESH, OPT_PROBE_TIER, OPT_PROBE_NO_GENERAL, OPT_TRACE, OPT_NMS3D_TAIL_BATCH, OPT_NMS3D_SPLIT_EXACT, OPT_CONV_F16_WGS, OPT_NMS2D_PAIR_LANES, OPT_NMS2D_AREA_BOUNDS, OPT_NMS2D_DEFER_UNDECIDED, OPT_NMS2D_STRICT, OPT_NMS2D_NBR_SINGLE, OPT_NMS3D_NBR_SINGLE, OPT_NMS2D_DEFER_MAX, OPT_NMS3D_BOUNDS_REUSE, OPT_NMS3D_DEFER_EXACT, OPT_COUNT };
+enum Option { OPT_NMS3D_VOLUME_BOUNDS, OPT_NMS3D_CONE_MAP, OPT_NMS3D_REFINE_MESH, OPT_PROBE_TIER, OPT_PROBE_NO_GENERAL, OPT_TRACE, OPT_NMS3D_TAIL_BATCH, OPT_NMS3D_SPLIT_EXACT, OPT_CONV_F16_WGS, OPT_NMS2D_PAIR_LANES, OPT_NMS2D_AREA_BOUNDS, OPT_NMS2D_DEFER_UNDECIDED, OPT_NMS2D_STRICT, OPT_NMS2D_NBR_SINGLE, OPT_NMS3D_NBR_SINGLE, OPT_NMS2D_DEFER_MAX, OPT_NMS3D_BOUNDS_REUSE, OPT_NMS3D_DEFER_EXACT, OPT_NMS3D_BOUNDS_LEAN, OPT_COUNT };
 int option(Option o);
 
 // A/B tuning knobs of the probe scripts (pair order, tail-batch thresholds, ...): environment variables in builds made with

@@ -16,8 +16,8 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-static int g_opt[OPT_COUNT] = {1, 1, 2, 1, 0, 0, 1, 3, 2, 64, 1, 2, 0, 1, 1, 16384, 1, 3};
-static const char* const g_opt_name[OPT_COUNT] = {"nms3d_volume_bounds", "nms3d_cone_map", "nms3d_refine_mesh", "probe_tier", "probe_no_general", "trace", "nms3d_tail_batch", "nms3d_split_exact", "conv_f16_workgroups_per_cu", "nms2d_pair_lanes", "nms2d_area_bounds", "nms2d_defer_undecided", "nms2d_strict", "nms2d_neighbours_single_pass", "nms3d_neighbours_single_pass", "nms2d_defer_max", "nms3d_bounds_reuse", "nms3d_defer_exact"};
+static int g_opt[OPT_COUNT] = {1, 1, 2, 1, 0, 0, 1, 3, 2, 64, 1, 2, 0, 1, 1, 16384, 1, 3, 1};
+static const char* const g_opt_name[OPT_COUNT] = {"nms3d_volume_bounds", "nms3d_cone_map", "nms3d_refine_mesh", "probe_tier", "probe_no_general", "trace", "nms3d_tail_batch", "nms3d_split_exact", "conv_f16_workgroups_per_cu", "nms2d_pair_lanes", "nms2d_area_bounds", "nms2d_defer_undecided", "nms2d_strict", "nms2d_neighbours_single_pass", "nms3d_neighbours_single_pass", "nms2d_defer_max", "nms3d_bounds_reuse", "nms3d_defer_exact", "nms3d_bounds_lean"};
 int option(Option o) { return g_opt[o]; }
 #ifdef SD_DEBUG_SWITCHES
 int tuning_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }

@@ -212,12 +212,13 @@ def test_nms3d_bounds_reuse_does_not_change_decisions(refmods):
     refmods.stardist3d(); refmods.set_threads(1)
     ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(0.3))
     res = {}
-    for reuse in (1, 0):
-        with N.option("nms3d_bounds_reuse", reuse):
+    for reuse, lean in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        # "nms3d_bounds_lean": the bounds-only launches without the seed / pos / orig tables behind the workspace (seven waves per CU) / with them
+        with N.option("nms3d_bounds_reuse", reuse), N.option("nms3d_bounds_lean", lean):
             keep, st = sd3.c_non_max_suppression_inds(*args, return_stats=True)
-        assert np.array_equal(keep.cpu().numpy(), ref_keep), reuse
-        res[reuse] = [int(st[k]) for k in (0, 1, 2, 3, 6, 7, 11, 12, 13)]
-    assert res[0] == res[1], res
+        assert np.array_equal(keep.cpu().numpy(), ref_keep), (reuse, lean)
+        res[reuse, lean] = [int(st[k]) for k in (0, 1, 2, 3, 6, 7, 11, 12, 13)]
+    assert len(set(map(tuple, res.values()))) == 1, res
 
 
 def test_nms3d_split_exact_does_not_change_survivors_or_volumes(refmods):
