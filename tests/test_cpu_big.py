@@ -347,3 +347,23 @@ def test_bench_dry_collectives_gloo_world2():
     assert d["ok"] and d["world"] == 2 and d["sent_bytes_per_rank"][0] == 0
     assert d["gathered_bytes"] == d["records_per_rank"][1] * d["record_bytes"] < d["padded_gather_would_move"]
     assert d["unique"] == d["objects"] and d["duplicates_dropped"] > 0
+
+
+def test_bench_sharded_leg_plumbing_gloo_world2():
+    """bench.run_sharded_leg -- the N > 1 headline of bench.py -- under gloo with two ranks and a stand-in model: W untimed passes and exactly K
+    timed ones, the per-rank statistics arrive on rank 0, the blocks of the one input are dealt over both ranks and every object is reported once"""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tests", "_bench_sharded_leg_worker.py")],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["passes"] == 3 and d["warm_passes"] == 2 and d["scaling"] == "strong"
+    assert d["_calls_per_rank_min"] == 1 + 2 + 3                  # one-block warm-up (not distributed) + W + K passes on every rank
+    assert len(d["per_rank"]) == 2 and all(p["blocks"] > 0 for p in d["per_rank"]) and d["blocks"] == sum(p["blocks"] for p in d["per_rank"]) == 16
+    assert d["instances"] == d["_objects"] and d["band_survivors"] + d["interior_survivors"] == d["_objects"]
+    assert d["gathered_bytes"] <= d["exact_record_bytes"] and d["value"] > 0 and "predicted_scaling" not in d
