@@ -1,4 +1,6 @@
-// Decision shortcut of the 2D NMS: an ENCLOSURE of the area the reference's Clipper call returns, from regular arithmetic.
+// Decision shortcut of the 2D NMS: the exact area of P n Q plus / minus a BAND for what the reference's Clipper call can return instead
+// ("area enclosure" in the names below; the band is validated empirically and adversarially, it is NOT a theorem about Clipper -- see the
+// end of this comment and DESIGN.md 3.4; sd_set_option("nms2d_strict", 1) sends every pair to the Clipper-exact sweep instead).
 //
 // The reference decides  area_inter / min(area_i, area_j) > thr  (stardist2d.cpp:580-581) with area_inter from ClipperLib
 // (poly_intersection_area :152-165).  Clipper's result is the intersection of the two integer polygons with every CROSSING
@@ -17,16 +19,21 @@
 //   K  = the number of boundary crossings, T = the number of edge pairs (e of P, f of Q) whose bounding boxes come within one lattice
 //        step of each other, and the band
 //        B = (0.5 K + 0.125 T) (lmax_P + lmax_Q) + 0.75 + (float error term).
-//        Two mechanisms separate Clipper's area from A.  (1) It rounds each of the K crossing points to the lattice: moving one vertex
+//        Three mechanisms separate Clipper's area from A.  (1) It rounds each of the K crossing points to the lattice: moving one vertex
 //        of a polygon by delta changes its area by |delta x (v_next - v_prev)| / 2 <= 0.71 (|e| + |f|) / 2 -- at most 0.36 (lmax_P +
-//        lmax_Q) per crossing.  (2) It orders the active edges by their lattice-ROUNDED abscissae at the scan lines: two edges that run
-//        closer than one step without crossing can tie, be inserted in the wrong order and later be "uncrossed", which moves the strip
-//        between them -- at most one step wide and as long as the shorter edge -- to the wrong side (K = 0 pairs with a deviation of
-//        0.5 exist: tests/test_cpu_area_enclosure.py); along nearly coincident boundaries every edge is near about three edges of the
-//        other polygon, so T counts each such strip about three times.  Measured (tools/area_band_study.py + the GPU test over 3.6 M
-//        pairs of nine families, nearly coincident polygons included): max |A_clipper - A| / B below 0.5.
+//        lmax_Q) per crossing (PROVEN for a crossing that is not clamped to its scan beam; the band carries 0.5).  (2) It orders the
+//        active edges by their lattice-ROUNDED abscissae at the scan lines: two edges that run closer than one step without crossing can
+//        tie, be inserted in the wrong order and later be "uncrossed", which moves the strip between them -- at most one step wide and
+//        as long as the shorter edge -- to the wrong side (K = 0 pairs with a deviation of 0.5 exist: tests/test_cpu_area_enclosure.py);
+//        along nearly coincident boundaries every edge is near about three edges of the other polygon, so T counts each such strip
+//        about three times: the 0.125 is EMPIRICAL.  (3) A polygon whose OWN vertex lies within half a step of one of its own edges
+//        is re-ordered by Clipper on its own (found by the adversarial search of round 5): such polygons are not "robustly simple"
+//        (k_poly_props) and are never decided here.
+//        Evidence for the band: 3.6 M GPU pairs of nine families against the exact sweep (worst 0.28 B), 18 M CPU pairs against the
+//        vendored Clipper (0.27 B), and an annealing ADVERSARY linked to the vendored Clipper (oracle/area_band_adversary.cpp:
+//        > 3 x 10^9 evaluations over NMS-realisable and free integer polygons, worst 0.46 B; profiles/r05_area_band_adversary.txt).
 // A pair is decided when (A -+ B) / min(area) clears the threshold by the margins below; everything else -- and every pair with
-// a polygon that is not SIMPLE (the boundary integral weights regions by winding number, Clipper's NonZero rule does not), with
+// a polygon that is not ROBUSTLY SIMPLE (the boundary integral weights regions by winding number, Clipper's NonZero rule does not), with
 // polygons of opposite orientation, too large for exact float predicates, or whose reference result could be rounded by the
 // float accumulation of area_from_path (:128-138) -- goes to the exact sweep as before.  Decisions, not areas, leave this header.
 #pragma once
