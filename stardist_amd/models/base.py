@@ -803,6 +803,7 @@ class StarDistBase(object):
 
         def uploader():
             try:
+                torch.cuda.set_device(dev)              # HIP's current device is per thread: page-locked blocks belong to THIS model's GPU
                 for img in imgs:
                     if stop.is_set():
                         return
