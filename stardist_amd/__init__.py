@@ -1,21 +1,28 @@
 """stardist_amd: MI355X-native StarDist prediction path.
 
-Public names follow the reference package (`stardist`): StarDist2D, Config2D, nms, geometry.
+Public names follow the reference package (`stardist/__init__.py`): what `from stardist import ...` offers on the prediction path is
+offered here under the same names (models, NMS entry points, geometry, ray sets, `edt_prob`, the ImageJ ROI export).
 """
-import os as _os
-
 __version__ = "0.1.0"
 
-# MIOpen's find mode (torch.backends.cudnn.benchmark, enabled by the models) times EVERY applicable solver once per
-# convolution shape, including its naive reference kernels, which need up to 4.6 s per call on a 256^3 volume (~140 s of
-# warm-up for the 3D network).  They can never win; switching that solver off cuts the first prediction from minutes to
-# seconds and changes nothing else (measured: same solvers chosen, same throughput).  Must be set before MIOpen initialises.
-_os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
+# name -> submodule, resolved lazily so that `import stardist_amd` (and the C-ABI symbol checks) work without torch
+_LAZY = {
+    "StarDist2D": "models", "StarDist3D": "models", "Config2D": "models", "Config3D": "models",
+    "non_maximum_suppression": "nms", "non_maximum_suppression_3d": "nms", "non_maximum_suppression_3d_sparse": "nms",
+    "edt_prob": "utils", "export_imagej_rois": "utils",
+    "star_dist": "geometry", "polygons_to_label": "geometry", "relabel_image_stardist": "geometry", "ray_angles": "geometry",
+    "dist_to_coord": "geometry", "star_dist3D": "geometry", "polyhedron_to_label": "geometry", "relabel_image_stardist3D": "geometry",
+    "rays_from_json": "rays3d", "Rays_Cartesian": "rays3d", "Rays_SubDivide": "rays3d", "Rays_Tetra": "rays3d", "Rays_Octo": "rays3d",
+    "Rays_GoldenSpiral": "rays3d", "Rays_Explicit": "rays3d",
+}
 
 
 def __getattr__(name):
-    # lazy so that `import stardist_amd` (and the C-ABI symbol checks) work without torch
-    if name in ("StarDist2D", "StarDist3D", "Config2D", "Config3D"):
-        from . import models
-        return getattr(models, name)
+    if name in _LAZY:
+        import importlib
+        return getattr(importlib.import_module("." + _LAZY[name], __name__), name)
     raise AttributeError(name)
+
+
+def __dir__():
+    return sorted(list(globals()) + list(_LAZY))

@@ -149,3 +149,46 @@ def polygons_to_label(dist, points, shape, prob=None, thr=-np.inf, scale_dist=(1
     points, dist = points[ind], dist[ind]
     coord = dist_to_coord(dist, points, scale_dist=scale_dist)
     return polygons_to_label_coord(coord, shape=shape, labels=ind)
+
+
+def _region_centroids(lbl):
+    """(labels, centroids): what `skimage.measure.regionprops(lbl)` yields as (r.label, r.centroid) -- the labels present in ascending
+    order, the centroid = the mean of the region's pixel coordinates (skimage: `coords.mean(axis=0)`, a float64 quotient of an exactly
+    representable integer sum and the pixel count; reproduced here as that quotient, so the truncation `astype(int)` the callers apply
+    sees the very same float64).  One bincount per axis instead of one Python object per region."""
+    lbl = np.asarray(lbl)
+    flat = lbl.reshape(-1).astype(np.int64, copy=False)
+    n = np.bincount(flat)
+    labs = np.nonzero(n)[0]
+    labs = labs[labs > 0]
+    cen = np.empty((len(labs), lbl.ndim), np.float64)
+    for d in range(lbl.ndim):
+        shp = [1] * lbl.ndim
+        shp[d] = lbl.shape[d]
+        w = np.broadcast_to(np.arange(lbl.shape[d], dtype=np.float64).reshape(shp), lbl.shape).reshape(-1)
+        cen[:, d] = np.bincount(flat, weights=w, minlength=len(n))[labs] / n[labs]      # sums < 2^53: exact
+    return labs, cen
+
+
+def _check_label_array(y, name=None):
+    """matching.py:23-35 (the non-sequential form the geometry functions use)"""
+    y = np.asarray(y)
+    if not np.issubdtype(y.dtype, np.integer) or (y.size and y.min() < 0):
+        raise ValueError("%s must be an array of non-negative integers." % ("labels" if name is None else name))
+    return True
+
+
+def relabel_image_stardist(lbl, n_rays, **kwargs):
+    """geom2d.py:200-211: relabel each label region in `lbl` with its star representation (star_dist at the truncated region
+    centroid -> polygons_to_label).  Label ids of the result are 1..n in the order of the regions' ids, as in the reference."""
+    lbl = np.asarray(lbl)
+    _check_label_array(lbl, "lbl")
+    if not lbl.ndim == 2:
+        raise ValueError("lbl image should be 2 dimensional")
+    dist = star_dist(lbl, n_rays, **kwargs)
+    points = _region_centroids(lbl)[1].astype(int)
+    if len(points) == 0:
+        dist, points = np.zeros((0, n_rays), np.float32), np.zeros((0, 2), int)
+    else:
+        dist = dist[tuple(points.T)]
+    return polygons_to_label(dist, points, shape=lbl.shape)

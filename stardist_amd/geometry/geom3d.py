@@ -108,6 +108,21 @@ def dist_to_coord3D(dist, points, rays_vertices):
     return points[:, np.newaxis] + dist[..., np.newaxis] * rays_vertices
 
 
+def relabel_image_stardist3D(lbl, rays, verbose=False, **kwargs):
+    """geom3d.py:201-217: relabel each label region in `lbl` with its star representation (star_dist3D at the truncated region
+    centroid, clamped below at 1e-3 -> polyhedron_to_label with the regions' own label ids)."""
+    from .geom2d import _check_label_array, _region_centroids
+    lbl = np.asarray(lbl)
+    _check_label_array(lbl, "lbl")
+    if not lbl.ndim == 3:
+        raise ValueError("lbl image should be 3 dimensional")
+    dist_all = star_dist3D(lbl, rays, **kwargs)
+    labs, cen = _region_centroids(lbl)
+    points = cen.astype(int)
+    dist = np.maximum(np.asarray(dist_all)[tuple(points.T)].reshape(len(points), len(rays)), 1e-3)
+    return polyhedron_to_label(dist, points, rays, shape=lbl.shape, labels=labs, verbose=verbose)
+
+
 def dist_to_volume(dist, rays):
     """volumes of the polyhedra, dist.shape = (nz, ny, nx, n_rays) (geom3d.py:220-235)"""
     from ..lib.stardist3d import c_dist_to_volume
