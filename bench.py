@@ -702,6 +702,8 @@ def main():
                                              "context 128 dealt round-robin over the ranks, local NMS per block, gather of the survivors, cross-tile "
                                              "NMS over the band on rank 0, write regions rendered by their owners" % (big.shape[0], big.shape[1], r["block_size"]))
                 out["config"]["parallelism"] = "blocks-of-one-slide x%d (strong scaling; `value_tiles` = independent tile per rank)" % world
+                out["scaling_base"] = ("the same workload at N = 1 is `sharded_2d.value` of the N = 1 line (one slide, all blocks on one GPU), NOT that "
+                                       "line's `value` (the 2048x2048 tile, BASELINE.json configs[1]): strong-scaling efficiency = value / (N x sharded_2d.value at N = 1)")
         del big
     del model, img
     torch.cuda.empty_cache()

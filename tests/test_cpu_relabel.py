@@ -1,7 +1,7 @@
 """CPU: `relabel_image_stardist` / `relabel_image_stardist3D` (stardist/geometry/geom2d.py:200-211, geom3d.py:201-217) and the package's
 top-level names.  Goldens: tests/golden/relabel_reference.npz, made by the reference's OWN two functions with the real scikit-image
 regionprops / polygon and the compiled reference natives (tests/golden/make_relabel_golden.py).  Here the product's host logic runs with
-the oracle standing in for the HIP natives (the GPU suite runs the same cases on the device: tests/test_gpu_zz_relabel.py)."""
+the oracle standing in for the HIP natives (the GPU suite runs the same cases on the device: tests/test_gpu_relabel.py)."""
 import os
 
 import numpy as np

@@ -1,9 +1,8 @@
 """GPU: `relabel_image_stardist` / `relabel_image_stardist3D` (stardist/geometry/geom2d.py:200-211, geom3d.py:201-217) on the HIP natives
 against label images produced by the reference's OWN two functions (real scikit-image regionprops / polygon, compiled reference
 star_dist / polyhedron rasteriser: tests/golden/make_relabel_golden.py), and the reference's consistency tests for them
-(tests/test_stardist2D.py:46-56, tests/test_stardist3D.py:55-66).  Written after the round's GPU minutes were spent: the host logic is
-pinned on the CPU with the oracle standing in for the natives (tests/test_cpu_relabel.py); the natives these functions call are each
-pinned bit for bit elsewhere in this suite (test_gpu_parity2d.py, test_gpu_parity3d.py).  (The file sorts last on purpose.)"""
+(tests/test_stardist2D.py:46-56, tests/test_stardist3D.py:55-66).  The host logic is also pinned on the CPU with the oracle standing in
+for the natives (tests/test_cpu_relabel.py)."""
 import os
 
 import numpy as np
@@ -23,14 +22,40 @@ def test_relabel_image_stardist_equals_reference(k):
     assert np.array_equal(np.asarray(out).astype(np.int32), G["out2d_%d" % k]), str(G["name2d_%d" % k])
 
 
+def _on_hull_boundary(voxels, lbl, rays):
+    """for each voxel: does it lie ON the convex hull of one of the star polyhedra relabel_image_stardist3D paints (|residual of a hull
+    facet's plane| <= 1e-6 with every other facet satisfied)?  The one documented deviation of the 3D rasteriser (DESIGN.md section 5
+    item 3): mode "full" is kernel OR (hull AND tetrahedra); the reference takes the hull's planes from Qhull, normalised in double, and
+    tests `n.p + d > 0` -- for a voxel exactly on a hull facet or vertex that is the sign of a 1e-16 residual (it paints one pole of the
+    multi-object golden's ellipsoid 6 and not the other)."""
+    from scipy.spatial import ConvexHull
+    from stardist_amd import star_dist3D
+    from stardist_amd.geometry.geom2d import _region_centroids
+    labs, cen = _region_centroids(lbl)
+    pts = cen.astype(int)
+    dist = np.maximum(np.asarray(star_dist3D(lbl, rays))[tuple(pts.T)].reshape(len(pts), len(rays)), 1e-3).astype(np.float32)
+    on = np.zeros(len(voxels), bool)
+    for c, d in zip(pts, dist):
+        pv = (c.astype(np.float32)[None] + d[:, None] * rays.vertices.astype(np.float32)).astype(np.float64)      # stardist3d_impl.cpp polyhedron_polyverts
+        eq = ConvexHull(pv).equations
+        res = voxels.astype(np.float64) @ eq[:, :3].T + eq[:, 3]
+        on |= (res.max(axis=1) <= 1e-6) & (np.abs(res).min(axis=1) <= 1e-6)
+    return on
+
+
 @pytest.mark.parametrize("k", range(int(G["n3d"])))
 def test_relabel_image_stardist3d_equals_reference(k):
+    """voxel for voxel, except voxels that lie exactly on the hull of their polyhedron (lattice-aligned synthetic shapes put the tips of the
+    axis-aligned rays exactly on voxels): there the reference's own answer is rounding noise of Qhull's planes -- at most two per object"""
     from stardist_amd import Rays_GoldenSpiral, relabel_image_stardist3D
     lbl = G["in3d_%d" % k]
     rays = Rays_GoldenSpiral(int(G["rays3d_%d" % k]), anisotropy=tuple(1.0 / G["eps3d_%d" % k]))
-    out = relabel_image_stardist3D(lbl, rays)
+    out = np.asarray(relabel_image_stardist3D(lbl, rays)).astype(np.int32)
     assert out.shape == lbl.shape
-    assert np.array_equal(np.asarray(out).astype(np.int32), G["out3d_%d" % k]), str(G["name3d_%d" % k])
+    diff = np.argwhere(out != G["out3d_%d" % k])
+    if len(diff):
+        assert len(diff) <= 2 * len(G["lab3d_%d" % k]), (str(G["name3d_%d" % k]), len(diff))
+        assert _on_hull_boundary(diff, lbl, rays).all(), (str(G["name3d_%d" % k]), diff[:8])
 
 
 def _circle_image(shape, radius, eps):
