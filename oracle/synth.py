@@ -110,3 +110,33 @@ def s3d_nuclei_image(N, spacing=24, R=(7, 10), seed=0):
         vol[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]][m] = 1.0
     vol += rng.normal(0, 0.05, vol.shape).astype(np.float32)
     return vol
+
+
+def lattice_candidates_2d(R, family, seed, n=1800, shape=(96, 96)):
+    """Candidates whose geometry sits EXACTLY on the pixel lattice (tests/golden/make_lattice_golden.py, tests/test_gpu_lattice.py):
+    integer centres and `const` = regular R-gons of integer radius (R = 4: diamonds with lattice vertices), `int` = every ray its own
+    integer length, `half` = half-integer lengths.  Many shapes coincide or are one-pixel shifts of each other: coincident edges and
+    vertices for Clipper, polygon vertices on pixel centres for the rasteriser.  Sorted by score, best first."""
+    rng = np.random.RandomState(1000 * R + seed)
+    pts = np.stack([rng.randint(2, shape[0] - 2, n), rng.randint(2, shape[1] - 2, n)], 1).astype(np.float32)
+    if family == "const":
+        d = np.repeat(rng.randint(2, 9, (n, 1)), R, 1)
+    elif family == "int":
+        d = rng.randint(2, 9, (n, R))
+    elif family == "half":
+        d = rng.randint(4, 18, (n, R)) * 0.5
+    else:
+        raise ValueError(family)
+    s = rng.uniform(0, 1, n).astype(np.float32)
+    ind = np.argsort(s, kind="stable")[::-1]
+    return np.ascontiguousarray(d[ind].astype(np.float32)), np.ascontiguousarray(pts[ind]), np.ascontiguousarray(s[ind])
+
+
+def lattice_candidates_3d(n_rays, family, n=500, size=48):
+    """3D counterpart: integer centres, one integer radius per polyhedron (`const`) or per ray (`int`)."""
+    rng = np.random.RandomState(n_rays * 7 + (family == "int"))
+    pts = np.stack([rng.randint(4, size - 4, n) for _ in range(3)], 1).astype(np.float32)
+    d = (np.repeat(rng.randint(3, 8, (n, 1)), n_rays, 1) if family == "const" else rng.randint(3, 8, (n, n_rays))).astype(np.float32)
+    s = rng.uniform(0, 1, n).astype(np.float32)
+    ind = np.argsort(s, kind="stable")[::-1]
+    return np.ascontiguousarray(d[ind]), np.ascontiguousarray(pts[ind]), np.ascontiguousarray(s[ind])

@@ -1,0 +1,92 @@
+"""GPU: the natives on LATTICE-ALIGNED inputs -- integer centres, integer / half-integer ray lengths, few rays, many coincident and
+one-pixel-shifted shapes (oracle/synth.py lattice_candidates_*): coincident edges and vertices for the Clipper-exact sweep and the area
+band, voxels exactly on faces for the 3D predicates, polygon vertices on pixel centres for the rasterisers -- the tie cases random float
+inputs never produce.  Goldens: the compiled reference, and the reference's Python rasteriser loop on the real scikit-image
+(tests/golden/make_lattice_golden.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+G = np.load(os.path.join(ROOT, "tests", "golden", "lattice_reference.npz"))
+SHAPE2D, SIZE3D = (96, 96), 48
+CASES2D = [(R, fam, 0) for R in (4, 8, 16, 32) for fam in ("const", "int", "half")]
+# Rays_Cartesian: its pole rays differ by 1e-12 and COINCIDE in float32 (degenerate triangles at both poles; the reference's own Qhull calls
+# print precision warnings on these polyhedra).  How Qhull treats the duplicate vertices is not reproduced: known limit, DESIGN.md section 5 item 3a
+# (measured on these sets: 12 / 54 of 500 keep flags, ~1 % of the painted voxels in mode "full"; mode "kernel" is identical).
+_CART = pytest.param("cartesian_8_5", marks=pytest.mark.xfail(strict=False, reason="ray set with coincident vertices: Qhull's handling of the degenerate mesh is not reproduced (DESIGN.md 5 item 3a)"))
+RAYS3D = ("octo", "golden32", "golden32_aniso")
+
+
+@pytest.mark.parametrize("strict", [0, 1])
+@pytest.mark.parametrize("R,fam,seed", CASES2D)
+def test_nms2d_lattice_polygons(R, fam, seed, strict):
+    """keep flags == compiled reference, with the default pair decisions (area band where a polygon is robustly simple) and with every
+    pair swept (nms2d_strict)"""
+    from oracle import synth
+    from stardist_amd.lib import _native, stardist2d as sd2
+    d, p, s = synth.lattice_candidates_2d(R, fam, seed, shape=SHAPE2D)
+    for thr in (0.3, 0.5):
+        want = np.unpackbits(G["nms2d_%d_%s_%d_%.1f" % (R, fam, seed, thr)])[:len(d)].astype(bool)
+        with _native.option("nms2d_strict", strict):
+            keep = sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(thr))
+        diff = np.flatnonzero(keep != want)
+        assert len(diff) == 0, (R, fam, thr, strict, len(diff), diff[:8])
+
+
+@pytest.mark.parametrize("R,fam,seed", CASES2D)
+def test_raster2d_lattice_polygons(R, fam, seed):
+    """label image == the reference's loop over the real skimage.draw.polygon (vertices and edges through pixel centres)"""
+    from oracle import synth
+    from stardist_amd.geometry import polygons_to_label
+    d, p, s = synth.lattice_candidates_2d(R, fam, seed, shape=SHAPE2D)
+    keep = np.unpackbits(G["nms2d_%d_%s_%d_%.1f" % (R, fam, seed, 0.3)])[:len(d)].astype(bool)
+    lab = np.asarray(polygons_to_label(d[keep], p[keep], SHAPE2D, prob=s[keep]))
+    want = G["raster2d_%d_%s_%d" % (R, fam, seed)].astype(np.int32)
+    assert np.array_equal(lab, want), (R, fam, int((lab != want).sum()))
+
+
+@pytest.mark.parametrize("fam", ["const", "int"])
+@pytest.mark.parametrize("name", RAYS3D + (_CART,))
+def test_nms3d_lattice_polyhedra(name, fam):
+    from make_lattice_golden import rays_of
+    from oracle import synth
+    from stardist_amd.lib import stardist3d as sd3
+    rays = rays_of(name)
+    V, F = rays.vertices.astype(np.float32), rays.faces.astype(np.int32)
+    d, p, s = synth.lattice_candidates_3d(len(V), fam, size=SIZE3D)
+    for thr in (0.2, 0.4):
+        want = np.unpackbits(G["nms3d_%s_%s_%.1f" % (name, fam, thr)])[:len(d)].astype(bool)
+        keep, st = sd3.c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(thr), return_stats=True)
+        diff = np.flatnonzero(keep != want)
+        assert len(diff) == 0, (name, fam, thr, len(diff), diff[:8], st.tolist())
+
+
+@pytest.mark.parametrize("name,fam,mode,mname", [(n, f, m, mn) for n in RAYS3D for f in ("const", "int") for m, mn in ((0, "full"), (1, "kernel"))] +
+                         [("cartesian_8_5", f, 1, "kernel") for f in ("const", "int")] +
+                         [pytest.param("cartesian_8_5", f, 0, "full", marks=_CART.marks) for f in ("const", "int")])
+def test_raster3d_lattice_polyhedra(name, fam, mode, mname):
+    """voxel for voxel; mode "full" except voxels exactly on the hull of a polyhedron that covers them (tests/_hull.py: the reference's answer
+    there is rounding noise of Qhull's planes; measured on these sets: 57 - 173 of 110 592 voxels, every one of them on a hull facet)"""
+    from _hull import on_hull_boundary
+    from make_lattice_golden import rays_of
+    from oracle import synth
+    from stardist_amd.lib import stardist3d as sd3
+    rays = rays_of(name)
+    V, F = rays.vertices.astype(np.float32), rays.faces.astype(np.int32)
+    d, p, s = synth.lattice_candidates_3d(len(V), fam, size=SIZE3D)
+    keep = np.unpackbits(G["nms3d_%s_%s_%.1f" % (name, fam, 0.2)])[:len(d)].astype(bool)
+    lab = np.arange(1, keep.sum() + 1, dtype=np.int32)
+    vol = np.asarray(sd3.c_polyhedron_to_label(d[keep], p[keep], V, F, lab, np.int32(mode), np.int32(0), np.int32(0), np.int32(0), (SIZE3D,) * 3)).astype(np.int32)
+    want = G["raster3d_%s_%s_%s" % (name, fam, mname)].astype(np.int32)
+    diff = np.argwhere(vol != want)
+    print("raster3d %s %s %s: %d of %d voxels differ" % (name, fam, mname, len(diff), vol.size))
+    if mode == 0 and len(diff):
+        assert on_hull_boundary(diff, p[keep], d[keep], V).all(), (name, fam, len(diff), diff[:8])
+        assert len(diff) <= 8 * int(keep.sum())
+    else:
+        assert len(diff) == 0, (name, fam, mname, len(diff), diff[:8])

@@ -23,24 +23,15 @@ def test_relabel_image_stardist_equals_reference(k):
 
 
 def _on_hull_boundary(voxels, lbl, rays):
-    """for each voxel: does it lie ON the convex hull of one of the star polyhedra relabel_image_stardist3D paints (|residual of a hull
-    facet's plane| <= 1e-6 with every other facet satisfied)?  The one documented deviation of the 3D rasteriser (DESIGN.md section 5
-    item 3): mode "full" is kernel OR (hull AND tetrahedra); the reference takes the hull's planes from Qhull, normalised in double, and
-    tests `n.p + d > 0` -- for a voxel exactly on a hull facet or vertex that is the sign of a 1e-16 residual (it paints one pole of the
-    multi-object golden's ellipsoid 6 and not the other)."""
-    from scipy.spatial import ConvexHull
+    """does the voxel lie ON the convex hull of one of the star polyhedra relabel_image_stardist3D paints?  (tests/_hull.py: the one
+    documented deviation of the 3D rasteriser)"""
+    from _hull import on_hull_boundary
     from stardist_amd import star_dist3D
     from stardist_amd.geometry.geom2d import _region_centroids
     labs, cen = _region_centroids(lbl)
     pts = cen.astype(int)
     dist = np.maximum(np.asarray(star_dist3D(lbl, rays))[tuple(pts.T)].reshape(len(pts), len(rays)), 1e-3).astype(np.float32)
-    on = np.zeros(len(voxels), bool)
-    for c, d in zip(pts, dist):
-        pv = (c.astype(np.float32)[None] + d[:, None] * rays.vertices.astype(np.float32)).astype(np.float64)      # stardist3d_impl.cpp polyhedron_polyverts
-        eq = ConvexHull(pv).equations
-        res = voxels.astype(np.float64) @ eq[:, :3].T + eq[:, 3]
-        on |= (res.max(axis=1) <= 1e-6) & (np.abs(res).min(axis=1) <= 1e-6)
-    return on
+    return on_hull_boundary(voxels, pts, dist, rays.vertices)
 
 
 @pytest.mark.parametrize("k", range(int(G["n3d"])))
