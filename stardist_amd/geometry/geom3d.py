@@ -41,6 +41,9 @@ def polyhedron_to_label(dist, points, rays, shape, prob=None, thr=-np.inf, label
     modes = {"full": 0, "kernel": 1, "hull": 2, "bbox": 3, "debug": 4}
     if mode not in modes:
         raise KeyError("Unknown render mode '%s' , allowed:  %s" % (mode, tuple(modes.keys())))
+    if mode in ("full", "hull"):
+        from ..rays3d import warn_if_degenerate
+        warn_if_degenerate(rays)
     if N.is_torch(dist):
         import torch
         if dist.dim() == 1: dist = dist.reshape(1, -1)

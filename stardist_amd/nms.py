@@ -158,9 +158,10 @@ def non_maximum_suppression_3d_sparse_sorted(dist, prob, points, rays, b=2, nms_
     positions (int64 tensor) of the survivors, best score first.  (non_maximum_suppression_3d_inds re-sorts by score, nms.py:352: a
     stable re-sort of a sorted list is the identity, so it is skipped.)"""
     from .lib.stardist3d import c_non_max_suppression_inds
-    from .rays3d import rays_device_tensors
+    from .rays3d import rays_device_tensors, warn_if_degenerate
     assert dist.ndim == 2 and prob.ndim == 1 and points.ndim == 2 and dist.shape[-1] == len(rays) and points.shape[-1] == 3 and \
         len(prob) == len(dist) == len(points)
+    warn_if_degenerate(rays)
     verts, faces = rays_device_tensors(rays, dist.device)
     keep = c_non_max_suppression_inds(dist, points, verts, faces, prob, 1, int(use_kdtree), int(verbose), np.float32(nms_thresh), _as_uint8=True)
     return _survivor_positions(keep)
@@ -170,7 +171,9 @@ def non_maximum_suppression_3d_sparse_sorted(dist, prob, points, rays, b=2, nms_
 def non_maximum_suppression_3d_inds(dist, points, rays, scores, thresh=0.5, use_bbox=True, use_kdtree=True, verbose=1):
     """stardist/nms.py:327-384 (re-sorts by score itself, returns survivors in input order)."""
     from .lib.stardist3d import c_non_max_suppression_inds
+    from .rays3d import warn_if_degenerate
     assert dist.ndim == 2 and points.ndim == 2 and dist.shape[1] == len(rays)
+    warn_if_degenerate(rays)
     n_poly = dist.shape[0]
     if _is_t(dist):
         import torch

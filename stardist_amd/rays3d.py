@@ -69,7 +69,39 @@ class Rays_Base(object):
         assert scale.shape == (3,)
         res = _copy.deepcopy(self)
         res._vertices *= scale[np.newaxis]
+        res.__dict__.pop("_coincident", None)
         return res
+
+    def has_coincident_vertices(self):
+        """True if two rays are closer than 1e-6: their polyhedron vertices `centre + dist * ray`, computed in float32 at image
+        coordinates (stardist3d_impl.cpp polyhedron_polyverts), are the same point (not in the reference; see warn_if_degenerate)."""
+        c = self.__dict__.get("_coincident")
+        if c is None:
+            v = np.round(np.asarray(self._vertices, np.float64), 6) + 0.0
+            c = self.__dict__["_coincident"] = bool(len(np.unique(v, axis=0)) < len(v))
+        return c
+
+
+_WARNED_DEGENERATE = set()
+
+
+def warn_if_degenerate(rays):
+    """One warning per kind of ray set with (nearly) coincident rays.  `Rays_Cartesian` is the case: its pole rays differ by
+    1e-12 (rays3d.py:189-197), so the polyhedron's pole vertices collapse to one float32 point and the mesh has degenerate triangles at both poles -- the reference's
+    own Qhull calls print precision warnings for every such polyhedron.  How Qhull treats the duplicate vertices (hulls, half-space
+    intersections) is NOT reproduced by the 3D NMS / the "full" render mode: survivors and a few voxels can differ from the reference
+    (DESIGN.md section 5 item 3a).  The closed sets (GoldenSpiral, Octo, Tetra, SubDivide) are pinned."""
+    fn = getattr(rays, "has_coincident_vertices", None)
+    if fn is None or not fn():
+        return False
+    key = repr(rays)
+    if key not in _WARNED_DEGENERATE:
+        _WARNED_DEGENERATE.add(key)
+        import warnings
+        warnings.warn("%s: some rays coincide in float32 (degenerate faces). The 3D NMS and polyhedron_to_label(mode='full') do not reproduce "
+                      "Qhull's handling of such meshes: results can differ from the reference (DESIGN.md section 5, item 3a); "
+                      "Rays_GoldenSpiral (the default) is pinned." % key, stacklevel=3)
+    return True
 
 
 _RAYS_CACHE = {}

@@ -241,3 +241,24 @@ def test_unet_batch_norm_matches_keras_semantics_and_round_trips(tmp_path):
     m2.load_weights_npz(path)
     for (n1, p1), (n2, p2) in zip(m.net.state_dict().items(), m2.net.state_dict().items()):
         assert n1 == n2 and (torch.equal(p1, p2) or "num_batches" in n1), n1
+
+
+def test_ray_sets_with_coincident_float32_vertices_are_flagged():
+    """Rays_Cartesian's pole rays differ by 1e-12 and collapse in float32 (degenerate faces): the 3D entry points warn once per set that the
+    reference's (Qhull's) treatment of such meshes is not reproduced; the closed sets are silent"""
+    import warnings
+    from stardist_amd.rays3d import Rays_Cartesian, Rays_GoldenSpiral, Rays_Octo, Rays_Tetra, rays_from_json, warn_if_degenerate
+    assert Rays_Cartesian(8, 5).has_coincident_vertices() and Rays_Cartesian().has_coincident_vertices()
+    for r in (Rays_GoldenSpiral(96), Rays_GoldenSpiral(32, anisotropy=(2, 1, 1)), Rays_Octo(), Rays_Tetra(),
+              rays_from_json(Rays_GoldenSpiral(64).to_json())):
+        assert not r.has_coincident_vertices()
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            assert warn_if_degenerate(r) is False
+    r = Rays_Cartesian(6, 4)
+    with pytest.warns(UserWarning, match="coincide in float32"):
+        assert warn_if_degenerate(r) is True
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert warn_if_degenerate(r) is True                    # once per kind of set
+    assert not Rays_GoldenSpiral(16).copy(scale=(2, 1, 1)).has_coincident_vertices()
