@@ -262,3 +262,66 @@ def test_ray_sets_with_coincident_float32_vertices_are_flagged():
         warnings.simplefilter("error")
         assert warn_if_degenerate(r) is True                    # once per kind of set
     assert not Rays_GoldenSpiral(16).copy(scale=(2, 1, 1)).has_coincident_vertices()
+
+
+def test_instances_from_survivors_undo_scale_like_the_reference():
+    """`predict_instances(scale=...)` (base.py:725-735, model2d.py:538-554, model3d.py:619-627): centres and polygon coordinates are brought
+    back to the input's pixel grid; the numpy path and the tensor path give what the reference's lines give (no rasteriser: return_labels=False)"""
+    import torch
+    from oracle import port
+    from stardist_amd.models import Config2D, Config3D, StarDist2D, StarDist3D
+    from stardist_amd.rays3d import rays_from_json
+    rng = np.random.RandomState(0)
+    m2 = StarDist2D(Config2D(n_rays=8, unet_n_depth=1, unet_n_filter_base=4), basedir=None, device="cpu")
+    pts = rng.randint(0, 90, (17, 2)); prob = np.sort(rng.uniform(0.5, 1, 17).astype(np.float32))[::-1].copy()
+    dist = rng.uniform(2, 9, (17, 8)).astype(np.float32)
+    for scale in (dict(Y=0.5, X=2.0), dict(Y=1.47, X=0.34), dict(Y=1, X=1, C=1)):
+        rescale = (1 / scale["Y"], 1 / scale["X"])
+        want_p = pts * np.array(rescale).reshape(1, 2)
+        want_c = port.dist_to_coord(dist, want_p, scale_dist=rescale)
+        lab, res = m2._instances_from_survivors((100, 100), pts, prob, dist, return_labels=False, scale=scale)
+        assert lab is None and np.array_equal(res["points"], want_p) and np.array_equal(res["coord"], want_c) and res["coord"].dtype == want_c.dtype
+        lab, rt = m2._instances_from_survivors((100, 100), torch.from_numpy(pts), torch.from_numpy(prob), torch.from_numpy(dist), return_labels=False, scale=scale)
+        assert np.array_equal(rt["points"], want_p) and np.array_equal(rt["coord"], want_c) and np.array_equal(rt["prob"], prob)
+    with pytest.raises(ValueError):
+        m2._instances_from_survivors((100, 100), pts, prob, dist, return_labels=False, scale=(0.5, 0.5))
+    m3 = StarDist3D(Config3D(rays=rays_from_json({"name": "Rays_GoldenSpiral", "kwargs": {"n": 12, "anisotropy": None}}), unet_n_depth=1, unet_n_filter_base=4),
+                    basedir=None, device="cpu")
+    p3 = rng.randint(0, 40, (9, 3)); d3 = rng.uniform(2, 6, (9, 12)).astype(np.float32); s3 = np.linspace(0.9, 0.5, 9).astype(np.float32)
+    scale = dict(Z=0.5, Y=2.0, X=1.25)
+    rescale = (1 / 0.5, 1 / 2.0, 1 / 1.25)
+    base = rays_from_json(m3.config.rays_json)
+    for conv in (lambda a: a, torch.from_numpy):
+        lab, res = m3._instances_from_survivors((40, 40, 40), conv(p3), conv(s3), conv(d3), return_labels=False, scale=scale)
+        assert np.array_equal(res["points"], p3 * np.array(rescale).reshape(1, 3)) and np.array_equal(res["dist"], d3)
+        assert np.array_equal(res["rays_vertices"], (base.vertices * np.asarray(rescale)[None]).astype(np.float32)) and np.array_equal(res["rays_faces"], base.faces)   # rays3d.py:139-145 copy(scale)
+    assert np.array_equal(rays_from_json(m3.config.rays_json).vertices, base.vertices)            # the shared instance is untouched
+
+
+def test_predict_instances_scale_zooms_the_input_and_hands_the_scale_on(monkeypatch):
+    """base.py:725-735, 763: the image is resampled with scipy's zoom(order=1) by the per-axis factors (1 for channels), the prediction runs on
+    the resampled image, and the per-axis dict reaches _instances_from_prediction together with the ORIGINAL image shape"""
+    from scipy import ndimage as ndi
+    from stardist_amd.models import Config2D, StarDist2D
+    m = StarDist2D(Config2D(n_rays=8, unet_n_depth=1, unet_n_filter_base=4, n_channel_in=2), basedir=None, device="cpu")
+    img = np.random.RandomState(1).uniform(0, 1, (40, 56, 2)).astype(np.float32)
+    seen = {}
+
+    def fake_sparse(x, **kw):
+        seen["x"] = np.asarray(x)
+        yield (np.zeros(0, np.float32), np.zeros((0, 8), np.float32), np.zeros((0, 2), int))
+
+    def fake_instances(shape, prob, dist, **kw):
+        seen["shape"], seen["scale"] = shape, kw.get("scale")
+        return "labels", {}
+    monkeypatch.setattr(m, "_predict_sparse_generator", fake_sparse)
+    monkeypatch.setattr(m, "_instances_from_prediction", fake_instances)
+    out = m.predict_instances(img, scale=(0.5, 1.5, 1))
+    assert out == ("labels", {})
+    assert np.array_equal(seen["x"], ndi.zoom(img, (0.5, 1.5, 1), order=1)) and seen["shape"] == (40, 56) and seen["scale"] == dict(Y=0.5, X=1.5, C=1)
+    m.predict_instances(img, scale=2)                                  # a number scales the spatial axes only
+    assert seen["x"].shape == (80, 112, 2) and seen["scale"] == dict(Y=2, X=2, C=1)
+    with pytest.raises(ValueError):
+        m.predict_instances(img, scale=(1, 1))
+    with pytest.raises(ValueError):
+        m.predict_instances(img, scale=(0, 1, 1))
