@@ -2,17 +2,15 @@
 tests/test_model3D.py test_predict_with_scale): predicting with `scale` equals predicting the zoomed image, with centres and
 coordinates brought back to the input's grid, and the label image has the INPUT's shape.
 
-Written after the round's GPU minutes were spent: these cases have not run on hardware yet, so they are recorded as non-strict
-expected failures (a pass shows up as XPASS, a failure cannot stop the suite).  The host logic of the option is pinned on the CPU
-(tests/test_cpu_host_logic.py: the zoom, the per-axis dict, the rescaled centres / coordinates / rays on the numpy and the tensor
-path); the natives it calls with rescaled inputs are pinned in tests/test_gpu_glue.py (dist_to_coord with scale_dist) and the raster tests."""
+The host logic of the option is also pinned on the CPU (tests/test_cpu_host_logic.py: the zoom, the per-axis dict, the rescaled centres /
+coordinates / rays on the numpy and the tensor path)."""
 import os
 import sys
 
 import numpy as np
 import pytest
 
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="not yet run on hardware (added after the round's GPU budget was spent)")]
+pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
