@@ -64,6 +64,15 @@ class Rays_Base(object):
         det = np.einsum("...i,...i->...", a, np.cross(b, c))
         return -1. / 6 * det.sum(-1)
 
+    def surface(self, dist=None):
+        """surface area of the polyhedron spanned by dist (last axis = rays): the sum of its triangles' areas (rays3d.py:109-142)"""
+        d = np.asarray(dist)
+        if d.ndim == 0 or d.shape[-1] != len(self):
+            raise ValueError("last dimension of dist should have length len(rays.vertices)")
+        p = d[..., None] * self.vertices                             # (..., R, 3); float32 vertices promote as in the reference
+        a, b, c = (p[..., self._faces[:, k], :] for k in range(3))   # (..., F, 3)
+        return (0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=-1)).sum(-1)
+
     def copy(self, scale=(1, 1, 1)):
         scale = np.asarray(scale)
         assert scale.shape == (3,)

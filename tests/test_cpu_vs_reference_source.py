@@ -1,0 +1,287 @@
+"""CPU: the pure-host functions of the mirror against the REFERENCE'S OWN functions, taken from the reference files at run time
+(nothing is copied into this repo; the goldens under tests/golden pin a handful of cases each for the GPU box, this file sweeps many
+parameter values where the reference sources are at hand -- the build container; skipped elsewhere).
+
+  rays3d.py        loaded as a module (numpy + scipy only): every Rays_* class over parameter sweeps, to_json / rays_from_json,
+                   dist_loss_weights, volume, copy(scale)
+  big.py           loaded as a module with stub packages for what it imports but the block algebra does not use (skimage, csbdeep,
+                   .geometry): Block.cover / BlockND.cover over random sizes -- start, end, read / write / crop slices, context,
+                   responsibility rule incl. its exceptions; _grid_divisible
+  matching.py      relabel_sequential                      (function bodies via ast -> exec)
+  nms.py           _ind_prob_thresh
+  geometry/geom2d  ray_angles, dist_to_coord (numpy path), _dist_to_coord_old
+  geometry/geom3d  dist_to_coord3D, export_to_obj_file3D
+  utils.py         _normalize_grid, _is_power_of_2, polyroi_bytearray, export_imagej_rois (bytes of the zip members)"""
+import ast
+import importlib.util
+import io
+import os
+import sys
+import types
+import zipfile
+
+import numpy as np
+import pytest
+
+REF = "/root/reference/stardist"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference sources (build container only)")
+
+
+def _raise(e):
+    raise e
+
+
+def ref_functions(relpath, names, ns):
+    path = os.path.join(REF, relpath)
+    for node in ast.parse(open(path).read()).body:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in names:
+            exec(compile(ast.Module([node], []), path, "exec"), ns)
+    assert set(names) <= set(ns), sorted(set(names) - set(ns))
+    return ns
+
+
+@pytest.fixture(scope="module")
+def ref_rays():
+    spec = importlib.util.spec_from_file_location("_ref_rays3d", os.path.join(REF, "rays3d.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _same_rays(a, b, tag):
+    assert len(a) == len(b), tag
+    assert a.vertices.dtype == b.vertices.dtype and np.array_equal(a.vertices, b.vertices), tag
+    assert np.array_equal(a.faces, b.faces), tag
+    assert repr(a) == repr(b) and a.to_json() == b.to_json(), tag
+
+
+def test_ray_sets_equal_the_reference_classes(ref_rays):
+    from stardist_amd import rays3d as M
+    for n in (8, 13, 32, 64, 65, 96, 128, 187):
+        for an in (None, (2, 1, 1), (1.0, 0.5, 1.5)):
+            a, b = M.Rays_GoldenSpiral(n, anisotropy=an), ref_rays.Rays_GoldenSpiral(n, anisotropy=an)
+            _same_rays(a, b, ("golden", n, an))
+            d = np.random.RandomState(n).uniform(1, 9, (5, n))
+            assert np.allclose(a.volume(d), b.volume(d), rtol=1e-12, atol=0)      # float64 helpers, other summation order
+            assert np.allclose(a.surface(d), b.surface(d), rtol=1e-12, atol=0) and a.surface(d).shape == b.surface(d).shape      # (volume(None): the reference's default raises for n != 3)
+            assert np.array_equal(a.dist_loss_weights((1, 2, 0.5)), b.dist_loss_weights((1, 2, 0.5)))
+            _same_rays(a.copy(scale=(0.5, 2, 1.25)), b.copy(scale=(0.5, 2, 1.25)), ("golden copy", n, an))
+            _same_rays(M.rays_from_json(a.to_json()), ref_rays.rays_from_json(b.to_json()), ("golden json", n, an))
+    for nx, nz in ((11, 5), (8, 5), (4, 3), (16, 9), (5, 4)):
+        _same_rays(M.Rays_Cartesian(nx, nz), ref_rays.Rays_Cartesian(nx, nz), ("cartesian", nx, nz))
+    for lvl in (1, 2, 3, 4):
+        _same_rays(M.Rays_Tetra(lvl), ref_rays.Rays_Tetra(lvl), ("tetra", lvl))
+        _same_rays(M.Rays_Octo(lvl), ref_rays.Rays_Octo(lvl), ("octo", lvl))
+    g = ref_rays.Rays_GoldenSpiral(10)
+    a, b = M.Rays_Explicit(g.vertices.tolist(), g.faces.tolist()), ref_rays.Rays_Explicit(g.vertices.tolist(), g.faces.tolist())
+    _same_rays(a, b, "explicit")
+    for bad in (dict(n=3),):                                              # refusals
+        with pytest.raises(Exception) as e1:
+            ref_rays.Rays_GoldenSpiral(**bad)
+        with pytest.raises(type(e1.value)):
+            M.Rays_GoldenSpiral(**bad)
+
+
+@pytest.fixture(scope="module")
+def ref_big():
+    """the reference's big.py as a module; the packages it imports for rendering / measuring (not used by the block algebra) are stubs"""
+    saved = {k: sys.modules.get(k) for k in ("skimage", "skimage.measure", "skimage.draw", "csbdeep", "csbdeep.utils", "_ref_sd", "_ref_sd.geometry")}
+
+    def axes_check_and_normalize(axes, length=None, disallowed=None, return_allowed=False):        # csbdeep.utils, restated for the test
+        allowed = "STCZYX"
+        axes = str(axes).upper()
+        assert all(a in allowed for a in axes) and len(set(axes)) == len(axes) and (length is None or len(axes) == length)
+        return (axes, allowed) if return_allowed else axes
+
+    def axes_dict(axes):
+        axes, allowed = axes_check_and_normalize(axes, return_allowed=True)
+        return {a: None if axes.find(a) == -1 else axes.find(a) for a in allowed}
+    mods = {"skimage": types.ModuleType("skimage"), "skimage.measure": types.ModuleType("skimage.measure"), "skimage.draw": types.ModuleType("skimage.draw"),
+            "csbdeep": types.ModuleType("csbdeep"), "csbdeep.utils": types.ModuleType("csbdeep.utils"),
+            "_ref_sd": types.ModuleType("_ref_sd"), "_ref_sd.geometry": types.ModuleType("_ref_sd.geometry")}
+    mods["skimage.measure"].regionprops = None; mods["skimage.draw"].polygon = None
+    mods["csbdeep.utils"]._raise, mods["csbdeep.utils"].axes_check_and_normalize, mods["csbdeep.utils"].axes_dict = _raise, axes_check_and_normalize, axes_dict
+    mods["_ref_sd"].__path__ = []
+    mods["_ref_sd.geometry"].polygons_to_label_coord = mods["_ref_sd.geometry"].polyhedron_to_label = None
+    sys.modules.update(mods)
+    try:
+        m = types.ModuleType("_ref_sd.big")
+        m.__package__ = "_ref_sd"
+        path = os.path.join(REF, "big.py")
+        exec(compile(open(path).read(), path, "exec"), m.__dict__)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return m
+
+
+def _block_row(t):
+    return (t.start, t.end, t.slice_read.start, t.slice_read.stop, t.slice_write.start, t.slice_write.stop, t.slice_crop_context.start,
+            t.slice_crop_context.stop, t.context_start, t.context_end, t.at_begin, t.at_end)
+
+
+def test_block_covers_equal_the_reference_classes(ref_big):
+    from stardist_amd import big as B
+    rng = np.random.RandomState(0)
+    n_ok = n_err = 0
+    for it in range(600):
+        grid = int(rng.choice([1, 1, 2, 4, 8]))
+        size = int(rng.randint(8, 400))
+        bs = int(rng.randint(4, 200)) // grid * grid
+        mo = int(rng.randint(0, 40)) // grid * grid
+        ctx = int(rng.randint(0, 24)) // grid * grid
+        try:
+            want = ref_big.Block.cover(size, bs, mo, ctx, grid, verbose=False)
+        except Exception as e:                                                        # noqa: BLE001 -- the same refusal is expected
+            with pytest.raises(type(e)):
+                B.Block.cover(size, bs, mo, ctx, grid, verbose=False)
+            n_err += 1
+            continue
+        got = B.Block.cover(size, bs, mo, ctx, grid, verbose=False)
+        assert [_block_row(t) for t in got] == [_block_row(t) for t in want], (size, bs, mo, ctx, grid)
+        # the responsibility rule on random intervals, exceptions included (big.py:89-122)
+        for _ in range(12):
+            a = int(rng.randint(0, size)); b = int(rng.randint(a + 1, min(size, a + mo + 6) + 1))
+            for tg, tw in zip(got, want):
+                try:
+                    r = tw.is_responsible((a, b))
+                except Exception as e:                                                # noqa: BLE001
+                    with pytest.raises(Exception) as e2:
+                        tg.is_responsible((a, b))
+                    assert type(e2.value).__name__ == type(e).__name__, (size, bs, mo, ctx, grid, a, b)
+                else:
+                    assert tg.is_responsible((a, b)) == r, (size, bs, mo, ctx, grid, a, b)
+        n_ok += 1
+    assert n_ok > 150 and n_err > 20, (n_ok, n_err)
+    for g, v in ((1, 7), (4, 8), (4, 10), (8, 3), (2, 0)):
+        assert B._grid_divisible(g, v, verbose=False) == ref_big._grid_divisible(g, v, verbose=False)
+
+
+def test_blocknd_covers_equal_the_reference_classes(ref_big):
+    from stardist_amd import big as B
+    rng = np.random.RandomState(1)
+    for it in range(60):
+        nd = int(rng.choice([2, 3]))
+        axes = "YX" if nd == 2 else "ZYX"
+        with_c = bool(rng.randint(0, 2))
+        shape = tuple(int(v) for v in rng.randint(40, 160, nd))
+        grid = tuple(int(v) for v in rng.choice([1, 2, 4], nd))
+        bs = tuple(int(rng.randint(24, 80)) // g * g for g in grid)
+        mo = tuple(int(rng.randint(0, 12)) // g * g for g in grid)
+        ctx = tuple(int(rng.randint(0, 8)) // g * g for g in grid)
+        if with_c:
+            axes, shape, grid, bs, mo, ctx = axes + "C", shape + (3,), grid + (1,), bs + (3,), mo + (0,), ctx + (0,)
+        try:
+            want = ref_big.BlockND.cover(shape, axes, bs, mo, ctx, grid)
+        except Exception as e:                                                        # noqa: BLE001
+            with pytest.raises(type(e)):
+                B.BlockND.cover(shape, axes, bs, mo, ctx, grid)
+            continue
+        got = B.BlockND.cover(shape, axes, bs, mo, ctx, grid)
+        assert len(got) == len(want)
+        x = rng.randint(0, 9, shape)
+        for bg, bw in zip(got, want):
+            assert bg.id == bw.id and bg.slice_read(axes) == bw.slice_read(axes) and bg.slice_write(axes) == bw.slice_write(axes)
+            assert bg.slice_crop_context(axes) == bw.slice_crop_context(axes)
+            assert np.array_equal(bg.read(x, axes=axes), bw.read(x, axes=axes))
+            sub = bw.read(x, axes=axes)
+            assert np.array_equal(bg.crop_context(sub, axes=axes), bw.crop_context(sub, axes=axes))
+            pts = rng.randint(0, 30, (5, nd)).astype(float)
+            ax_sp = axes.replace("C", "")
+            assert np.array_equal(bg.translate_coordinates(pts.copy(), axes=ax_sp), bw.translate_coordinates(pts.copy(), axes=ax_sp))
+
+
+def test_relabel_sequential_equals_the_reference_function():
+    from stardist_amd.matching import relabel_sequential
+    ns = ref_functions("matching.py", {"relabel_sequential"}, {"np": np})
+    rng = np.random.RandomState(2)
+    for it in range(200):
+        dt = rng.choice([np.uint8, np.uint16, np.int32, np.int64, np.float32])
+        shape = tuple(rng.randint(1, 12, rng.randint(1, 4)))
+        a = (rng.randint(0, rng.choice([3, 40, 250]), shape) * rng.choice([1, 1, 7])).astype(dt)
+        off = int(rng.choice([1, 1, 5, 300, 70000]))
+        want = ns["relabel_sequential"](a.copy(), off)
+        got = relabel_sequential(a.copy(), off)
+        for g, w in zip(got, want):
+            assert g.dtype == w.dtype and np.array_equal(g, w), (dt, shape, off)
+    for bad, off in ((np.array([-1, 2]), 1), (np.array([1, 2]), 0)):
+        with pytest.raises(ValueError):
+            ns["relabel_sequential"](bad, off)
+        with pytest.raises(ValueError):
+            relabel_sequential(bad, off)
+
+
+def test_ind_prob_thresh_and_grid_helpers_equal_the_reference_functions():
+    from stardist_amd import nms as NM, utils as U
+    ns = ref_functions("utils.py", {"_normalize_grid", "_is_power_of_2"}, {"np": np, "_raise": _raise})
+    ref_functions("nms.py", {"_ind_prob_thresh"}, ns)
+    rng = np.random.RandomState(3)
+    for it in range(100):
+        nd = int(rng.choice([2, 3]))
+        prob = rng.uniform(0, 1, tuple(rng.randint(1, 14, nd))).astype(np.float32)
+        thr = float(rng.uniform(0, 1))
+        for b in (None, 0, 1, 2, 3, tuple((int(rng.randint(0, 3)), int(rng.randint(0, 3))) for _ in range(nd))):
+            assert np.array_equal(NM._ind_prob_thresh(prob, thr, b=b), ns["_ind_prob_thresh"](prob, thr, b=b)), (prob.shape, b)
+    for grid, n in (((1, 1), 2), ((2, 4), 2), ([1, 2, 8], 3), ((1, 3), 2), ((1, 1), 3), (2, 2), ((0, 1), 2), ((1.0, 2.0), 2), ((-2, 1), 2)):
+        try:
+            want = ns["_normalize_grid"](grid, n)
+        except ValueError:
+            with pytest.raises(ValueError):
+                U._normalize_grid(grid, n)
+        else:
+            assert U._normalize_grid(grid, n) == want
+    for i in (1, 2, 3, 4, 6, 8, 1024, 1000):
+        assert U._is_power_of_2(i) == ns["_is_power_of_2"](i)
+
+
+def test_geometry_host_functions_equal_the_reference_functions(tmp_path):
+    from stardist_amd.geometry import geom2d, geom3d
+    from stardist_amd.rays3d import Rays_GoldenSpiral
+    from stardist_amd.utils import _normalize_grid
+    ns = ref_functions("geometry/geom2d.py", {"ray_angles", "dist_to_coord", "_dist_to_coord_old"}, {"np": np, "_normalize_grid": _normalize_grid})
+    n3 = ref_functions("geometry/geom3d.py", {"dist_to_coord3D", "export_to_obj_file3D"}, {"np": np, "_raise": _raise, "tqdm": lambda x, **k: x})
+    rng = np.random.RandomState(4)
+    for R in (3, 8, 32, 33, 64):
+        assert np.array_equal(geom2d.ray_angles(R), ns["ray_angles"](R))
+        d = rng.uniform(0.5, 30, (50, R)).astype(np.float32)
+        for pts in (rng.randint(0, 500, (50, 2)), rng.uniform(0, 500, (50, 2)).astype(np.float32), rng.uniform(0, 500, (50, 2))):
+            for sc in ((1, 1), (0.5, 2.0), (1 / 1.47, 1 / 0.34)):
+                g, w = geom2d.dist_to_coord(d, pts, scale_dist=sc), ns["dist_to_coord"](d, pts, scale_dist=sc)
+                assert g.dtype == w.dtype and np.array_equal(g, w), (R, pts.dtype, sc)
+        for rhos, grid in ((rng.uniform(0, 9, (5, 7, R)).astype(np.float32), (1, 1)), (rng.uniform(0, 9, (2, 4, 6, R)), (2, 4))):
+            g, w = geom2d._dist_to_coord_old(rhos, grid), ns["_dist_to_coord_old"](rhos, grid)
+            assert g.dtype == w.dtype and g.shape == w.shape and np.array_equal(g, w)
+    rays = Rays_GoldenSpiral(24, anisotropy=(2, 1, 1))
+    d3 = rng.uniform(2, 7, (6, 24)).astype(np.float32); p3 = rng.uniform(0, 50, (6, 3)).astype(np.float32)
+    assert np.array_equal(geom3d.dist_to_coord3D(d3, p3, rays.vertices), n3["dist_to_coord3D"](d3, p3, rays.vertices))
+    polys = dict(dist=d3, points=p3, rays_vertices=rays.vertices, rays_faces=rays.faces)
+    for kw in (dict(), dict(single_mesh=False, uv_map=True, name="cell"), dict(scale=(0.05, 0.2, 0.2)), dict(scale=2)):
+        assert geom3d.export_to_obj_file3D(polys, fname=None, **kw) == n3["export_to_obj_file3D"](polys, fname=None, **kw), kw
+
+
+def test_imagej_roi_bytes_equal_the_reference_functions(tmp_path):
+    import datetime                                                                  # noqa: F401 -- names the reference functions look up
+    from pathlib import Path
+    from zipfile import ZIP_DEFLATED, ZipFile
+    from stardist_amd import utils as U
+    ns = ref_functions("utils.py", {"polyroi_bytearray", "export_imagej_rois"}, {"np": np, "Path": Path, "ZipFile": ZipFile, "ZIP_DEFLATED": ZIP_DEFLATED, "_raise": _raise})
+    rng = np.random.RandomState(5)
+    for it in range(60):
+        n = int(rng.randint(3, 40))
+        x, y = rng.uniform(0, 300, n), rng.uniform(0, 300, n)
+        if it % 3 == 0:
+            x, y = np.round(x), np.round(y)
+        for pos in (None, 1, 17):
+            for sub in (True, False):
+                assert bytes(U.polyroi_bytearray(x, y, pos=pos, subpixel=sub)) == bytes(ns["polyroi_bytearray"](x, y, pos=pos, subpixel=sub)), (it, pos, sub)
+    groups = [rng.uniform(0, 100, (4, 2, 16)), rng.uniform(0, 100, (2, 2, 16))]
+    for arg, kw in ((groups, dict()), (groups[0], dict(set_position=False, subpixel=False))):
+        a, b = str(tmp_path / "mine"), str(tmp_path / "ref.zip")
+        U.export_imagej_rois(a, arg, **kw); ns["export_imagej_rois"](b, arg, **kw)
+        za, zb = zipfile.ZipFile(a + ".zip"), zipfile.ZipFile(b)
+        assert za.namelist() == zb.namelist()
+        for name in za.namelist():
+            assert za.read(name) == zb.read(name), name
