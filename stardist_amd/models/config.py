@@ -19,6 +19,42 @@ class BaseConfig(object):
         self.axes = axes
         self.n_channel_in = int(max(1, n_channel_in))
         self.n_channel_out = int(max(1, n_channel_out))
+        # csbdeep's BaseConfig keys as every config.json of the reference carries them (models/examples/*/config.json)
+        self.train_checkpoint = "weights_best.h5"
+        self.train_checkpoint_last = "weights_last.h5"
+        self.train_checkpoint_epoch = "weights_now.h5"
+
+    def _training_schema(self, patch_size, batch_size, shape_completion):
+        """The training keys of the reference's schema with its defaults (model2d.py:235-257, model3d.py:274-294): unused by the
+        prediction path, kept so that a configuration built with the reference's keyword arguments is accepted, validated and
+        written to config.json exactly as the reference writes it."""
+        if shape_completion:
+            self.train_shape_completion = False
+            self.train_completion_crop = 32
+        self.train_patch_size = patch_size
+        self.train_background_reg = 1e-4
+        self.train_foreground_only = 0.9
+        self.train_sample_cache = True
+        self.train_dist_loss = "mae"
+        self.train_loss_weights = (1, 0.2) if self.n_classes is None else (1, 0.2, 1)
+        self.train_class_weights = (1, 1) if self.n_classes is None else (1,) * (self.n_classes + 1)
+        self.train_epochs = 400
+        self.train_steps_per_epoch = 100
+        self.train_learning_rate = 0.0003
+        self.train_batch_size = batch_size
+        self.train_n_val_patches = None
+        self.train_tensorboard = True
+        self.train_reduce_lr = {"factor": 0.5, "patience": 40, "min_delta": 0}
+        self.use_gpu = False
+
+    def _check_training_weights(self):
+        """model2d.py:266-270, model3d.py:306-310"""
+        if not len(self.train_loss_weights) == (2 if self.n_classes is None else 3):
+            raise ValueError("train_loss_weights %s not compatible with n_classes (%s): must be 3 weights if n_classes is not None, otherwise 2"
+                             % (self.train_loss_weights, self.n_classes))
+        if not len(self.train_class_weights) == (2 if self.n_classes is None else self.n_classes + 1):
+            raise ValueError("train_class_weights %s not compatible with n_classes (%s): must be 'n_classes + 1' weights if n_classes is not None, otherwise 2"
+                             % (self.train_class_weights, self.n_classes))
 
     def update_parameters(self, allow_new=False, **kwargs):
         if not allow_new:
@@ -84,12 +120,11 @@ class Config2D(BaseConfig):
             raise ValueError("backbone '%s' not supported." % self.backbone)
         self.net_input_shape = None, None, self.n_channel_in
         self.net_mask_shape = None, None, 1
-        self.train_patch_size = 256, 256
-        self.train_batch_size = 4
-        self.use_gpu = False
+        self._training_schema((256, 256), 4, shape_completion=True)
         for k in ("n_dim", "n_channel_out"):
             kwargs.pop(k, None)
         self.update_parameters(False, **kwargs)
+        self._check_training_weights()
 
 
 class Config3D(BaseConfig):
@@ -97,17 +132,23 @@ class Config3D(BaseConfig):
 
     def __init__(self, axes="ZYX", rays=None, n_channel_in=1, grid=(1, 1, 1), n_classes=None, anisotropy=None,
                  backbone="unet", **kwargs):
-        from ..rays3d import Rays_GoldenSpiral, Rays_Base
-        if rays is None:
-            rays = Rays_GoldenSpiral(96, anisotropy=anisotropy)
+        from ..rays3d import Rays_GoldenSpiral, rays_from_json
+        if rays is None:                                  # model3d.py:209-217 (a configuration dictionary read back: Config3D(**config_dict))
+            if "rays_json" in kwargs:
+                rays = rays_from_json(kwargs["rays_json"])
+            elif "n_rays" in kwargs:
+                rays = Rays_GoldenSpiral(kwargs["n_rays"])
+            else:
+                rays = Rays_GoldenSpiral(96)
         elif np.isscalar(rays):
-            rays = Rays_GoldenSpiral(rays, anisotropy=anisotropy)
+            rays = Rays_GoldenSpiral(rays)
         super().__init__(axes=axes, n_channel_in=n_channel_in, n_channel_out=1 + len(rays))
         self.n_rays = len(rays)
         self.grid = _normalize_grid(grid, 3)
         self.anisotropy = anisotropy if anisotropy is None else tuple(anisotropy)
         self.backbone = str(backbone).lower()
-        self.rays_json = rays.to_json()
+        import copy
+        self.rays_json = copy.deepcopy(rays.to_json())            # (to_json hands out the ray set's own kwargs: the edit below must not reach a shared instance)
         self.n_classes = None if n_classes is None else int(n_classes)
         if "anisotropy" in self.rays_json["kwargs"]:
             if self.rays_json["kwargs"]["anisotropy"] is None and self.anisotropy is not None:
@@ -137,9 +178,8 @@ class Config3D(BaseConfig):
             raise ValueError("backbone '%s' not supported." % self.backbone)
         self.net_input_shape = None, None, None, self.n_channel_in
         self.net_mask_shape = None, None, None, 1
-        self.train_patch_size = 128, 128, 128
-        self.train_batch_size = 1
-        self.use_gpu = False
-        for k in ("n_dim", "n_channel_out"):
+        self._training_schema((128, 128, 128), 1, shape_completion=False)
+        for k in ("n_dim", "n_channel_out", "n_rays", "rays_json"):
             kwargs.pop(k, None)
         self.update_parameters(False, **kwargs)
+        self._check_training_weights()

@@ -285,3 +285,117 @@ def test_imagej_roi_bytes_equal_the_reference_functions(tmp_path):
         assert za.namelist() == zb.namelist()
         for name in za.namelist():
             assert za.read(name) == zb.read(name), name
+
+
+def test_pad_and_crop_resizer_equals_the_reference_class():
+    """StarDistPadAndCropResizer (models/base.py:1162-1211): reflect padding at the end of every axis to the network's divisor (incl. pads
+    longer than the axis and length-1 axes), the crop of grid-subsampled outputs, the filter of points that fall into the padding"""
+    import math
+    import torch
+    from stardist_amd.models.base import StarDistPadAndCropResizer as Mine
+
+    def axes_check_and_normalize(axes, length=None, **k):
+        axes = str(axes).upper()
+        assert length is None or len(axes) == length
+        return axes
+    ns = {"np": np, "math": math, "Resizer": object, "axes_check_and_normalize": axes_check_and_normalize}
+    Ref = ref_functions("models/base.py", {"StarDistPadAndCropResizer"}, ns)["StarDistPadAndCropResizer"]
+    rng = np.random.RandomState(6)
+    for it in range(200):
+        nd = int(rng.choice([2, 3]))
+        sp = "YX" if nd == 2 else "ZYX"
+        with_c = bool(rng.randint(0, 2))
+        axes = sp + ("C" if with_c else "")
+        grid = {a: int(rng.choice([1, 2, 4])) for a in sp}
+        div = tuple(int(grid.get(a, 1) * rng.choice([1, 2, 4, 8])) if a != "C" else 1 for a in axes)
+        shape = tuple(int(rng.choice([1, 2, 3, 5, 9, 17, 30, 33])) if a != "C" else int(rng.randint(1, 4)) for a in axes)
+        x = rng.uniform(0, 1, shape).astype(np.float32)
+        a, b = Mine(grid), Ref(grid)
+        xa, xb = a.before(torch.from_numpy(x), axes, div), b.before(x, axes, div)
+        assert np.array_equal(xa.numpy(), xb), (shape, axes, div)
+        assert a.pad == b.pad and a.padded_shape == b.padded_shape
+        # network output on the grid: spatial axes subsampled, channels replaced
+        out_axes = sp + "C"
+        out_shape = tuple(xb.shape[axes.index(c)] // grid[c] for c in sp) + (5,)
+        y = rng.uniform(0, 1, out_shape).astype(np.float32)
+        assert np.array_equal(a.after(torch.from_numpy(y), out_axes).numpy(), b.after(y, out_axes)), (shape, axes, div, grid)
+        pts = np.stack([rng.randint(0, max(1, xb.shape[axes.index(c)]), 40) for c in sp], 1)
+        assert np.array_equal(np.asarray(a.filter_points(nd, pts, sp)), b.filter_points(nd, pts, sp)[0])
+        assert np.array_equal(a.filter_points(nd, torch.from_numpy(pts), sp).numpy(), b.filter_points(nd, pts, sp)[0])
+
+
+def _ref_configs(ref_rays):
+    """the reference's Config2D / Config3D classes (model2d.py:123-269, model3d.py:129-311) on a stand-in for csbdeep's BaseConfig that sets
+    what every config.json of the reference carries (models/examples/*/config.json): n_dim, axes (+ 'C'), channel counts, checkpoint names"""
+    import warnings
+    from packaging.version import Version
+
+    class BaseConfig(object):
+        def __init__(self, axes="YX", n_channel_in=1, n_channel_out=1, **kw):
+            axes = str(axes).upper()
+            axes = axes if "C" in axes else axes + "C"
+            self.n_dim, self.axes = len(axes) - 1, axes
+            self.n_channel_in, self.n_channel_out = int(max(1, n_channel_in)), int(max(1, n_channel_out))
+            self.train_checkpoint, self.train_checkpoint_last, self.train_checkpoint_epoch = "weights_best.h5", "weights_last.h5", "weights_now.h5"
+
+        def update_parameters(self, allow_new=False, **kwargs):
+            if not allow_new:
+                bad = [k for k in kwargs if not hasattr(self, k)]
+                if bad:
+                    raise AttributeError("Not allowed to add new parameters (%s)" % ", ".join(bad))
+            for k, v in kwargs.items():
+                setattr(self, k, v)
+    u = ref_functions("utils.py", {"_normalize_grid", "_is_power_of_2"}, {"np": np, "_raise": _raise})
+    ns = {"np": np, "warnings": warnings, "BaseConfig": BaseConfig, "_normalize_grid": u["_normalize_grid"], "backend_channels_last": lambda: True,
+          "Version": Version, "keras": object(), "_raise": _raise, "Rays_GoldenSpiral": ref_rays.Rays_GoldenSpiral, "rays_from_json": ref_rays.rays_from_json}
+    ref_functions("models/model2d.py", {"Config2D"}, ns)
+    ref_functions("models/model3d.py", {"Config3D"}, ns)
+    return ns["Config2D"], ns["Config3D"]
+
+
+def _norm(v):
+    if isinstance(v, dict):
+        return {k: _norm(x) for k, x in v.items()}
+    if isinstance(v, (tuple, list)):
+        return [_norm(x) for x in v]
+    if isinstance(v, np.generic):
+        return v.item()
+    return v
+
+
+def test_config_classes_equal_the_reference_classes(ref_rays, capsys):
+    import json
+    from stardist_amd.models import Config2D, Config3D
+    R2, R3 = _ref_configs(ref_rays)
+    cases2 = [dict(), dict(n_rays=64, grid=(2, 2), n_channel_in=3), dict(n_classes=2), dict(axes="YXC", n_rays=16, unet_n_depth=4, net_conv_after_unet=64, train_epochs=3),
+              dict(grid=(1, 4), unet_batch_norm=True, train_patch_size=(128, 128), use_gpu=True, train_reduce_lr=None), dict(n_classes=3, train_class_weights=(1, 2, 3, 4))]
+    for kw in cases2:
+        a, b = Config2D(**kw), R2(**kw)
+        assert list(vars(a)) == list(vars(b)), kw                          # same keys in the same order (the order config.json is written in)
+        assert _norm(vars(a)) == _norm(vars(b)), kw
+    cases3 = [dict(), dict(rays=32), dict(anisotropy=(2, 1, 1)), dict(rays=ref_rays.Rays_GoldenSpiral(48, anisotropy=(2, 1, 1)), anisotropy=(2, 1, 1), grid=(1, 2, 2)),
+              dict(backbone="resnet", grid=(1, 2, 2), n_channel_in=2), dict(n_classes=2, rays=16), dict(n_rays=24), dict(unet_n_depth=3, train_batch_size=2)]
+    for kw in cases3:
+        kwm = dict(kw)
+        if "rays" in kw and not np.isscalar(kw["rays"]):                   # each side gets its own ray class
+            from stardist_amd.rays3d import Rays_GoldenSpiral
+            kwm["rays"] = Rays_GoldenSpiral(48, anisotropy=(2, 1, 1))
+        a, b = Config3D(**kwm), R3(**kw)
+        assert list(vars(a)) == list(vars(b)), kw
+        assert _norm(vars(a)) == _norm(vars(b)), kw
+    # a configuration dictionary read back (what csbdeep's loader does with config.json): Config(**dict)
+    for path, cls, rcls in (("models/examples/2D_demo/config.json", Config2D, R2), ("models/examples/3D_demo/config.json", Config3D, R3)):
+        d = json.load(open(os.path.join(os.path.dirname(REF), path)))
+        a, b = cls(**d), rcls(**d)
+        assert _norm(vars(a)) == _norm(vars(b)) and list(vars(a)) == list(vars(b)), path
+        assert json.loads(a.to_json()) == _norm(vars(b))
+        c = cls.from_json(os.path.join(os.path.dirname(REF), path))        # the mirror's loader gives the same object
+        assert _norm(vars(c)) == _norm(vars(a)), path
+    # refusals
+    for cls, rcls in ((Config2D, R2), (Config3D, R3)):
+        for kw, exc in ((dict(no_such_key=1), AttributeError), (dict(backbone="vgg"), ValueError), (dict(grid=(3, 1) if cls is Config2D else (3, 1, 1)), ValueError),
+                        (dict(train_loss_weights=(1, 2, 3)), ValueError), (dict(n_classes=2, train_class_weights=(1, 1)), ValueError)):
+            with pytest.raises(exc):
+                rcls(**kw)
+            with pytest.raises(exc):
+                cls(**kw)
