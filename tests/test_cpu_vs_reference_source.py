@@ -399,3 +399,82 @@ def test_config_classes_equal_the_reference_classes(ref_rays, capsys):
                 rcls(**kw)
             with pytest.raises(exc):
                 cls(**kw)
+
+
+@pytest.fixture()
+def ref_nms():
+    """the reference's nms.py as a module of a stand-in package whose `lib.stardist2d` / `lib.stardist3d` ARE the compiled reference natives
+    (oracle/_ref) and whose `utils` holds the reference's _normalize_grid: the Python glue of the reference, end to end"""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not built")
+    ref.set_threads(1)
+    names = ("_ref_sd", "_ref_sd.lib", "_ref_sd.lib.stardist2d", "_ref_sd.lib.stardist3d", "_ref_sd.utils", "_ref_sd.nms")
+    saved = {k: sys.modules.get(k) for k in names}
+    pkg, lib, utils = types.ModuleType("_ref_sd"), types.ModuleType("_ref_sd.lib"), types.ModuleType("_ref_sd.utils")
+    pkg.__path__, lib.__path__ = [], []
+    u = ref_functions("utils.py", {"_normalize_grid", "_is_power_of_2"}, {"np": np, "_raise": _raise})
+    utils._normalize_grid = u["_normalize_grid"]
+    sys.modules.update({"_ref_sd": pkg, "_ref_sd.lib": lib, "_ref_sd.lib.stardist2d": ref.stardist2d(), "_ref_sd.lib.stardist3d": ref.stardist3d(), "_ref_sd.utils": utils})
+    m = types.ModuleType("_ref_sd.nms")
+    m.__package__ = "_ref_sd"
+    path = os.path.join(REF, "nms.py")
+    exec(compile(open(path).read(), path, "exec"), m.__dict__)
+    sys.modules["_ref_sd.nms"] = m
+    yield m
+    for k, v in saved.items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+
+
+def test_nms_python_glue_equals_the_reference_module(ref_nms, monkeypatch, capsys):
+    """stardist/nms.py end to end (thresholding with a border, score sort, grid scaling, the native call, what is returned and in which
+    order) with the SAME natives under both: the mirror's wrappers are given the compiled reference's functions for this test"""
+    from oracle import ref
+    from stardist_amd import nms as NM
+    from stardist_amd.lib import stardist2d as sd2, stardist3d as sd3
+    from stardist_amd.rays3d import Rays_GoldenSpiral
+    m2, m3 = ref.stardist2d(), ref.stardist3d()
+    monkeypatch.setattr(sd2, "c_non_max_suppression_inds", lambda d, p, a, b, c, t, **k: m2.c_non_max_suppression_inds(
+        np.ascontiguousarray(d, np.float32), np.ascontiguousarray(p, np.float32), int(a), int(b), int(c), np.float32(t)).astype(bool))
+    monkeypatch.setattr(sd3, "c_non_max_suppression_inds", lambda d, p, V, F, s, a, b, c, t, **k: m3.c_non_max_suppression_inds(
+        np.ascontiguousarray(d, np.float32), np.ascontiguousarray(p, np.float32), np.ascontiguousarray(V, np.float32), np.ascontiguousarray(F, np.int32),
+        np.ascontiguousarray(s, np.float32), int(a), int(b), int(c), np.float32(t)).astype(bool))
+    rng = np.random.RandomState(7)
+
+    def same(a, b, tag):
+        assert len(a) == len(b), tag
+        for x, y in zip(a, b):
+            x, y = np.asarray(x), np.asarray(y)
+            assert x.shape == y.shape and x.dtype == y.dtype and np.array_equal(x, y), (tag, x.dtype, y.dtype, x.shape, y.shape)
+    for it in range(12):
+        R = int(rng.choice([8, 32]))
+        grid = tuple(int(v) for v in rng.choice([1, 2, 4], 2))
+        H, W = int(rng.randint(20, 60)), int(rng.randint(20, 60))
+        dist = (6 * (1 + 0.3 * rng.uniform(-1, 1, (H, W, R)))).astype(np.float32)
+        prob = rng.uniform(0, 1, (H, W)).astype(np.float32)
+        kw = dict(grid=grid, b=int(rng.choice([0, 2, 3])), nms_thresh=float(rng.choice([0.3, 0.5])), prob_thresh=float(rng.choice([0.6, 0.8])))
+        same(NM.non_maximum_suppression(dist, prob, **kw), ref_nms.non_maximum_suppression(dist, prob, **kw), ("dense2d", kw))
+        mask = prob > 0.7
+        pts = np.stack(np.where(mask), 1) * np.array(grid).reshape(1, 2)
+        kws = dict(b=kw["b"], nms_thresh=kw["nms_thresh"], use_bbox=bool(it % 2), use_kdtree=bool(it % 3))
+        same(NM.non_maximum_suppression_sparse(dist[mask], prob[mask], pts, **kws), ref_nms.non_maximum_suppression_sparse(dist[mask], prob[mask], pts, **kws), ("sparse2d", kws))
+        sc = prob[mask]
+        same([NM.non_maximum_suppression_inds(dist[mask], pts.astype(np.int32), sc, thresh=0.4, verbose=0)],
+             [ref_nms.non_maximum_suppression_inds(dist[mask], pts.astype(np.int32), sc, thresh=0.4, verbose=0)], "inds2d")
+    for it in range(6):
+        rays = Rays_GoldenSpiral(int(rng.choice([16, 32])), anisotropy=(None if it % 2 else (2, 1, 1)))
+        grid = tuple(int(v) for v in rng.choice([1, 2], 3))
+        shape = tuple(int(v) for v in rng.randint(10, 18, 3))
+        dist = (4 * (1 + 0.2 * rng.uniform(-1, 1, shape + (len(rays),)))).astype(np.float32)
+        prob = rng.uniform(0, 1, shape).astype(np.float32)
+        kw = dict(grid=grid, b=int(rng.choice([0, 2])), nms_thresh=0.3, prob_thresh=0.8)
+        same(NM.non_maximum_suppression_3d(dist, prob, rays, **kw), ref_nms.non_maximum_suppression_3d(dist, prob, rays, **kw), ("dense3d", kw))
+        mask = prob > 0.85
+        pts = np.stack(np.where(mask), 1) * np.array(grid).reshape(1, 3)
+        same(NM.non_maximum_suppression_3d_sparse(dist[mask], prob[mask], pts, rays, b=kw["b"], nms_thresh=0.3),
+             ref_nms.non_maximum_suppression_3d_sparse(dist[mask], prob[mask], pts, rays, b=kw["b"], nms_thresh=0.3), "sparse3d")
+        same([NM.non_maximum_suppression_3d_inds(dist[mask], pts.astype(np.int32), rays, prob[mask], thresh=0.3, verbose=0)],
+             [ref_nms.non_maximum_suppression_3d_inds(dist[mask], pts.astype(np.int32), rays, prob[mask], thresh=0.3, verbose=0)], "inds3d")
