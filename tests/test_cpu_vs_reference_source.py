@@ -478,3 +478,108 @@ def test_nms_python_glue_equals_the_reference_module(ref_nms, monkeypatch, capsy
              ref_nms.non_maximum_suppression_3d_sparse(dist[mask], prob[mask], pts, rays, b=kw["b"], nms_thresh=0.3), "sparse3d")
         same([NM.non_maximum_suppression_3d_inds(dist[mask], pts.astype(np.int32), rays, prob[mask], thresh=0.3, verbose=0)],
              [ref_nms.non_maximum_suppression_3d_inds(dist[mask], pts.astype(np.int32), rays, prob[mask], thresh=0.3, verbose=0)], "inds3d")
+
+
+def _ref_method(relpath, cls, name, ns):
+    path = os.path.join(REF, relpath)
+    for node in ast.parse(open(path).read()).body:
+        if isinstance(node, ast.ClassDef) and node.name == cls:
+            for f in node.body:
+                if isinstance(f, ast.FunctionDef) and f.name == name:
+                    exec(compile(ast.Module([f], []), path, "exec"), ns)
+                    return ns[name]
+    raise KeyError((cls, name))
+
+
+def test_instances_from_prediction_equals_the_reference_methods(ref_nms, ref_rays, monkeypatch):
+    """StarDist2D / StarDist3D._instances_from_prediction (model2d.py:512-563, model3d.py:589-674) -- dense and sparse input, multi-class
+    probabilities, `scale`, the 3D overlap label -- label image and result dict against the reference's own methods.  Both sides run on the same
+    natives: the compiled reference's NMS and polyhedron rasteriser, and for 2D the restatement of skimage.draw.polygon (== the real one on
+    30 000 polygons, profiles/r05_raster2d_oracle_vs_skimage.txt)."""
+    from collections import namedtuple
+    from oracle import port, ref
+    from stardist_amd.lib import stardist2d as sd2, stardist3d as sd3
+    from stardist_amd.models import Config2D, Config3D, StarDist2D, StarDist3D
+    from stardist_amd.rays3d import Rays_GoldenSpiral
+    from stardist_amd.utils import _normalize_grid
+    m2, m3 = ref.stardist2d(), ref.stardist3d()
+    f32, i32 = (lambda a: np.ascontiguousarray(a, np.float32)), (lambda a: np.ascontiguousarray(a, np.int32))
+    monkeypatch.setattr(sd2, "c_non_max_suppression_inds", lambda d, p, a, b, c, t, **k: m2.c_non_max_suppression_inds(f32(d), f32(p), int(a), int(b), int(c), np.float32(t)).astype(bool))
+    monkeypatch.setattr(sd2, "c_polygons_to_label", lambda coord, labels, shape, window=None: port.polygons_to_label_coord(coord, shape, labels=labels))
+    monkeypatch.setattr(sd3, "c_non_max_suppression_inds", lambda d, p, V, F, s, a, b, c, t, **k: m3.c_non_max_suppression_inds(f32(d), f32(p), f32(V), i32(F), f32(s), int(a), int(b), int(c), np.float32(t)).astype(bool))
+    monkeypatch.setattr(sd3, "c_polyhedron_to_label", lambda d, p, V, F, l, mode, vb, uo, ol, shape, window=None: m3.c_polyhedron_to_label(f32(d), f32(p), f32(V), i32(F), i32(l), int(mode), int(vb), int(uo), int(ol), tuple(shape)))
+    Thr = namedtuple("Thresholds", ("prob", "nms"))
+    g2 = ref_functions("geometry/geom2d.py", {"ray_angles", "dist_to_coord", "polygons_to_label_coord", "polygons_to_label"}, {"np": np, "polygon": port.polygon, "_check_label_array": lambda *a, **k: True})
+    r2 = _ref_method("models/model2d.py", "StarDist2D", "_instances_from_prediction",
+                     {"np": np, "non_maximum_suppression": ref_nms.non_maximum_suppression, "non_maximum_suppression_sparse": ref_nms.non_maximum_suppression_sparse,
+                      "polygons_to_label": g2["polygons_to_label"], "dist_to_coord": g2["dist_to_coord"]})
+    g3 = ref_functions("geometry/geom3d.py", {"polyhedron_to_label"}, {"np": np, "c_polyhedron_to_label": m3.c_polyhedron_to_label})
+    rs = ref_functions("matching.py", {"relabel_sequential"}, {"np": np})
+    r3 = _ref_method("models/model3d.py", "StarDist3D", "_instances_from_prediction",
+                     {"np": np, "rays_from_json": ref_rays.rays_from_json, "non_maximum_suppression_3d": ref_nms.non_maximum_suppression_3d,
+                      "non_maximum_suppression_3d_sparse": ref_nms.non_maximum_suppression_3d_sparse, "polyhedron_to_label": g3["polyhedron_to_label"],
+                      "relabel_sequential": rs["relabel_sequential"]})
+    rng = np.random.RandomState(8)
+
+    def same_dict(a, b, tag):
+        assert set(a) == set(b), (tag, sorted(a), sorted(b))
+        for k in a:
+            if k == "rays":
+                assert np.array_equal(a[k].vertices, b[k].vertices) and np.array_equal(a[k].faces, b[k].faces), tag
+                continue
+            x, y = np.asarray(a[k]), np.asarray(b[k])
+            assert x.shape == y.shape and x.dtype == y.dtype and np.array_equal(x, y), (tag, k, x.dtype, y.dtype, x.shape, y.shape)
+
+    for it in range(8):
+        grid = tuple(int(v) for v in rng.choice([1, 2], 2))
+        n_cls = None if it % 2 else 2
+        cfg = Config2D(n_rays=16, grid=grid, unet_n_depth=1, unet_n_filter_base=4, n_classes=n_cls)
+        mine = StarDist2D(cfg, basedir=None, device="cpu")
+        mine.thresholds = dict(prob=0.7, nms=0.4)
+        fake = types.SimpleNamespace(thresholds=Thr(0.7, 0.4), config=types.SimpleNamespace(grid=grid))
+        H, W = 40, 52
+        dist = (5 * (1 + 0.3 * rng.uniform(-1, 1, (H, W, 16)))).astype(np.float32)
+        prob = rng.uniform(0, 1, (H, W)).astype(np.float32)
+        pc = None if n_cls is None else rng.dirichlet(np.ones(3), (H, W)).astype(np.float32)
+        shape = (H * grid[0], W * grid[1])
+        scale = None if it < 4 else dict(Y=0.5, X=2.0)
+        la, da = mine._instances_from_prediction(shape, prob, dist, prob_class=pc, scale=scale)
+        lb, db = r2(fake, shape, prob, dist, prob_class=pc, scale=scale)
+        assert la.dtype == lb.dtype and np.array_equal(la, lb), ("2d dense", it)
+        same_dict(da, db, ("2d dense", it))
+        mask = prob > 0.75
+        pts = np.stack(np.where(mask), 1) * np.array(grid).reshape(1, 2)
+        pcs = None if pc is None else pc[mask]
+        la, da = mine._instances_from_prediction(shape, prob[mask], dist[mask], points=pts, prob_class=pcs, scale=scale, return_labels=bool(it % 3))
+        lb, db = r2(fake, shape, prob[mask], dist[mask], points=pts, prob_class=pcs, scale=scale, return_labels=bool(it % 3))
+        assert (la is None and lb is None) or np.array_equal(la, lb), ("2d sparse", it)
+        same_dict(da, db, ("2d sparse", it))
+    with pytest.raises(NotImplementedError):
+        mine._instances_from_prediction(shape, prob, dist, overlap_label=-1)
+
+    for it in range(6):
+        grid = tuple(int(v) for v in rng.choice([1, 2], 3))
+        n_cls = None if it % 2 else 2
+        an = None if it % 3 else (2, 1, 1)
+        cfg = Config3D(rays=Rays_GoldenSpiral(16, anisotropy=an), grid=grid, anisotropy=an, unet_n_depth=1, unet_n_filter_base=4, n_classes=n_cls)
+        mine = StarDist3D(cfg, basedir=None, device="cpu")
+        mine.thresholds = dict(prob=0.8, nms=0.3)
+        fake = types.SimpleNamespace(thresholds=Thr(0.8, 0.3), config=types.SimpleNamespace(grid=grid, rays_json=cfg.rays_json))
+        S = (10, 12, 14)
+        dist = (3.5 * (1 + 0.2 * rng.uniform(-1, 1, S + (16,)))).astype(np.float32)
+        prob = rng.uniform(0, 1, S).astype(np.float32)
+        pc = None if n_cls is None else rng.dirichlet(np.ones(3), S).astype(np.float32)
+        shape = tuple(s * g for s, g in zip(S, grid))
+        scale = None if it < 3 else dict(Z=0.5, Y=2.0, X=1.0)
+        ol = None if it % 2 else -1
+        la, da = mine._instances_from_prediction(shape, prob, dist, prob_class=pc, scale=scale, overlap_label=ol)
+        lb, db = r3(fake, shape, prob, dist, prob_class=pc, scale=scale, overlap_label=ol)
+        assert la.dtype == lb.dtype and np.array_equal(la, lb), ("3d dense", it, la.dtype, lb.dtype)
+        same_dict(da, db, ("3d dense", it))
+        mask = prob > 0.85
+        pts = np.stack(np.where(mask), 1) * np.array(grid).reshape(1, 3)
+        pcs = None if pc is None else pc[mask]
+        la, da = mine._instances_from_prediction(shape, prob[mask], dist[mask], points=pts, prob_class=pcs, scale=scale, return_labels=bool(it % 3))
+        lb, db = r3(fake, shape, prob[mask], dist[mask], points=pts, prob_class=pcs, scale=scale, return_labels=bool(it % 3))
+        assert (la is None and lb is None) or (la.dtype == lb.dtype and np.array_equal(la, lb)), ("3d sparse", it)
+        same_dict(da, db, ("3d sparse", it))
