@@ -583,3 +583,100 @@ def test_instances_from_prediction_equals_the_reference_methods(ref_nms, ref_ray
         lb, db = r3(fake, shape, prob[mask], dist[mask], points=pts, prob_class=pcs, scale=scale, return_labels=bool(it % 3))
         assert (la is None and lb is None) or (la.dtype == lb.dtype and np.array_equal(la, lb)), ("3d sparse", it)
         same_dict(da, db, ("3d sparse", it))
+
+
+def test_predict_instances_big_loop_equals_the_reference_method(ref_big, monkeypatch):
+    """StarDistBase.predict_instances_big (models/base.py:838-983) end to end -- blocks, context crop, responsibility filter, label offsets,
+    the written label image and the merged object dict -- against the reference's own method, both driven by the same stand-in model whose
+    predict_instances returns the ground-truth objects of a block.  (regionprops' label / bbox / image for the reference's filter come from
+    scipy.ndimage.find_objects here; the real scikit-image pins them in tests/golden/make_big_filter_golden.py.)"""
+    from scipy import ndimage as ndi
+    from stardist_amd import big as B
+    from stardist_amd.models.config import Config2D, Config3D
+
+    class Reg(object):
+        def __init__(self, lab, sl, labels):
+            self.label, self.bbox, self.image = lab, tuple(s.start for s in sl) + tuple(s.stop for s in sl), labels[sl] == lab
+    monkeypatch.setattr(ref_big, "regionprops", lambda labels: [Reg(i + 1, sl, labels) for i, sl in enumerate(ndi.find_objects(labels)) if sl is not None])
+    rs = ref_functions("matching.py", {"relabel_sequential"}, {"np": np})
+    mm = types.ModuleType("_ref_sd.matching"); mm.relabel_sequential = rs["relabel_sequential"]
+    pk, pm = types.ModuleType("_ref_sd"), types.ModuleType("_ref_sd.models")
+    pk.__path__, pm.__path__ = [], []
+    for k, v in {"_ref_sd": pk, "_ref_sd.models": pm, "_ref_sd.big": ref_big, "_ref_sd.matching": mm}.items():
+        monkeypatch.setitem(sys.modules, k, v)
+
+    def axes_check_and_normalize(axes, length=None, **k):
+        axes = str(axes).upper()
+        assert length is None or len(axes) == length
+        return axes
+
+    def axes_dict(axes):
+        return {a: (axes.find(a) if a in axes else None) for a in "STCZYX"}
+    method = _ref_method("models/base.py", "StarDistBase", "predict_instances_big",
+                         {"np": np, "tqdm": lambda it, **k: it, "_raise": _raise, "axes_check_and_normalize": axes_check_and_normalize, "axes_dict": axes_dict,
+                          "__package__": "_ref_sd.models", "__name__": "_ref_sd.models.base"})
+
+    class Model(object):
+        def __init__(self, nd, grid):
+            self.config = Config2D() if nd == 2 else Config3D()
+            self._grid, self._axes_out = grid, self.config.axes
+            self.calls = []
+
+        def _axes_div_by(self, axes): return tuple(self._grid if a != "C" else 1 for a in axes)
+
+        def _axes_tile_overlap(self, axes): return tuple(0 for a in axes)
+
+        def predict_instances(self, x, **kwargs):
+            self.calls.append(sorted(kwargs))
+            x = np.asarray(x)
+            if x.ndim > len(self.config.axes) - 1:
+                x = x[..., 0]
+            ids = np.unique(x); ids = ids[ids > 0]
+            lab = np.zeros(x.shape, np.int32)
+            for j, v in enumerate(ids, 1):
+                lab[x == v] = j
+            objs = ndi.find_objects(lab)
+            pts = np.array([[0.5 * (s.start + s.stop) for s in o] for o in objs]).reshape(len(objs), x.ndim)
+            polys = dict(points=pts, prob=np.linspace(1, 0.5, len(objs)), coord=np.zeros((len(objs), x.ndim, 4)) + pts[:, :, None])
+            if x.ndim == 3:
+                polys.update(dist=np.ones((len(objs), 5)), rays_vertices=np.eye(3))
+            return lab, polys
+    rng = np.random.RandomState(9)
+    done = 0
+    for it in range(90):
+        nd = 2 if it % 2 == 0 else 3
+        shape = tuple(int(v) for v in rng.randint(60, 140, nd)) if nd == 2 else tuple(int(v) for v in rng.randint(36, 60, nd))
+        gt = np.zeros(shape, np.int32)
+        grids = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+        k = 0
+        for _ in range(40 if nd == 2 else 25):
+            c = [rng.uniform(4, s - 4) for s in shape]; r = rng.uniform(2, 4)
+            m = sum((g - ci) ** 2 for g, ci in zip(grids, c)) <= r * r
+            if (gt[m] == 0).all():
+                k += 1; gt[m] = k
+        grid = int(rng.choice([1, 2]))
+        with_c = it % 5 == 0
+        axes = ("YX" if nd == 2 else "ZYX") + ("C" if with_c else "")
+        img = gt[..., None].repeat(2, -1) if with_c else gt
+        bs = int(rng.choice([32, 40, 48])) if nd == 2 else int(rng.choice([24, 32]))
+        mo, ctx = int(rng.choice([12, 16])), int(rng.choice([0, 2, 4]))
+        kw = dict(block_size=bs, min_overlap=mo, context=ctx, show_progress=False)
+        extra = dict(labels_out_dtype=np.int64) if it % 7 == 0 else (dict(labels_out=False) if it % 11 == 0 else {})
+        a_model, b_model = Model(nd, grid), Model(nd, grid)
+        try:
+            lb, pb = method(b_model, img, axes, **kw, **extra)
+        except Exception as e:                                                  # noqa: BLE001 -- the reference's cover refuses many size / block combinations (big.py:186, :270)
+            with pytest.raises(type(e)):
+                B.predict_instances_big(a_model, img, axes, distributed=False, **kw, **extra)
+            continue
+        la, pa = B.predict_instances_big(a_model, img, axes, distributed=False, **kw, **extra)
+        if lb is None:
+            assert la is False or la is None
+        else:
+            assert la.dtype == lb.dtype and np.array_equal(la, lb), (it, shape, axes, kw)
+        assert set(pa) == set(pb)
+        for key in pa:
+            assert np.asarray(pa[key]).shape == np.asarray(pb[key]).shape and np.array_equal(pa[key], pb[key]), (it, key)
+        assert a_model.calls == b_model.calls                                   # the same keyword arguments reach predict_instances
+        done += 1
+    assert done >= 30, done
