@@ -680,3 +680,21 @@ def test_predict_instances_big_loop_equals_the_reference_method(ref_big, monkeyp
         assert a_model.calls == b_model.calls                                   # the same keyword arguments reach predict_instances
         done += 1
     assert done >= 30, done
+
+
+def test_model_registry_equals_the_reference_registrations():
+    """models/__init__.py:19-27: the same keys, URLs, md5 sums and aliases, per model class"""
+    from stardist_amd.models import pretrained as P
+    want_models, want_aliases = {}, {}
+    for node in ast.walk(ast.parse(open(os.path.join(REF, "models", "__init__.py")).read())):
+        if isinstance(node, ast.Call) and getattr(node.func, "id", None) in ("register_model", "register_aliases"):
+            args = [a.id if isinstance(a, ast.Name) else ast.literal_eval(a) for a in node.args]
+            if node.func.id == "register_model":
+                want_models.setdefault(args[0], {})[args[1]] = dict(url=args[2], md5=args[3])
+            else:
+                for alias in args[2:]:
+                    want_aliases.setdefault(args[0], {})[alias] = args[1]
+    assert want_models and want_aliases
+    assert {c: dict(m) for c, m in P._MODELS.items()} == want_models
+    assert {c: list(m) for c, m in P._MODELS.items()} == {c: list(m) for c, m in want_models.items()}         # registration order (what the listing prints)
+    assert P._ALIASES == want_aliases
