@@ -698,3 +698,71 @@ def test_model_registry_equals_the_reference_registrations():
     assert {c: dict(m) for c, m in P._MODELS.items()} == want_models
     assert {c: list(m) for c, m in P._MODELS.items()} == {c: list(m) for c, m in want_models.items()}         # registration order (what the listing prints)
     assert P._ALIASES == want_aliases
+
+
+def test_legacy_nms_and_label_glue_equal_the_reference_functions(ref_nms, ref_rays, monkeypatch):
+    """the remaining Python glue around natives, natives shared: `_non_maximum_suppression_old` (nms.py:20-74: mapping image, score order),
+    `polygons_to_label` / `polygons_to_label_coord` / `_polygons_to_label_old` (geom2d.py:112-197: prob filter, paint order, label ids) and
+    `polyhedron_to_label` (geom3d.py:100-198: filter, order, labels, modes, overlap label, empty inputs and its error messages)"""
+    from oracle import port, ref
+    from stardist_amd import nms as NM
+    from stardist_amd.geometry import geom2d, geom3d
+    from stardist_amd.lib import stardist2d as sd2, stardist3d as sd3
+    from stardist_amd.rays3d import Rays_GoldenSpiral
+    from stardist_amd.utils import _normalize_grid
+    m2, m3 = ref.stardist2d(), ref.stardist3d()
+    f32, i32 = (lambda a: np.ascontiguousarray(a, np.float32)), (lambda a: np.ascontiguousarray(a, np.int32))
+    monkeypatch.setattr(sd2, "c_non_max_suppression_inds_old", lambda polys, mapping, t, mb, gy, gx, v: m2.c_non_max_suppression_inds_old(
+        i32(polys), i32(mapping), np.float32(t), np.int32(mb), np.int32(gy), np.int32(gx), np.int32(v)).astype(bool))
+    monkeypatch.setattr(sd2, "c_polygons_to_label", lambda coord, labels, shape, window=None: port.polygons_to_label_coord(coord, shape, labels=labels))
+    monkeypatch.setattr(sd3, "c_polyhedron_to_label", lambda d, p, V, F, l, mode, vb, uo, ol, shape, window=None: m3.c_polyhedron_to_label(f32(d), f32(p), f32(V), i32(F), i32(l), int(mode), int(vb), int(uo), int(ol), tuple(shape)))
+    g2 = ref_functions("geometry/geom2d.py", {"ray_angles", "dist_to_coord", "polygons_to_label_coord", "polygons_to_label", "_polygons_to_label_old", "_dist_to_coord_old"},
+                       {"np": np, "polygon": port.polygon, "_check_label_array": lambda *a, **k: True, "_normalize_grid": _normalize_grid})
+    g3 = ref_functions("geometry/geom3d.py", {"polyhedron_to_label"}, {"np": np, "c_polyhedron_to_label": m3.c_polyhedron_to_label})
+    rng = np.random.RandomState(10)
+    for it in range(8):
+        R = int(rng.choice([8, 16, 32]))
+        grid = tuple(int(v) for v in rng.choice([1, 2], 2))
+        H, W = int(rng.randint(24, 48)), int(rng.randint(24, 48))
+        rhos = (5 * (1 + 0.3 * rng.uniform(-1, 1, (H, W, R)))).astype(np.float32)
+        prob = rng.uniform(0, 1, (H, W)).astype(np.float32)
+        coord = g2["_dist_to_coord_old"](rhos, grid=grid)
+        for mb in (True, False):
+            kw = dict(grid=grid, b=int(rng.choice([0, 2])), nms_thresh=0.4, prob_thresh=0.7, max_bbox_search=mb)
+            a, b = NM._non_maximum_suppression_old(coord, prob, **kw), ref_nms._non_maximum_suppression_old(coord, prob, **kw)
+            assert a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b), ("old nms", it, kw)
+        pts = a * np.array(grid).reshape(1, 2)
+        shape = (H * grid[0], W * grid[1])
+        d = rhos[tuple(a.T)]
+        pr = prob[tuple(a.T)]
+        for kw in (dict(), dict(prob=pr), dict(prob=pr, thr=0.8), dict(scale_dist=(0.5, 2.0))):
+            x, y = geom2d.polygons_to_label(d, pts, shape, **kw), g2["polygons_to_label"](d, pts, shape, **kw)
+            assert x.dtype == y.dtype and np.array_equal(x, y), ("polygons_to_label", it, sorted(kw))
+        cc = g2["dist_to_coord"](d, pts)
+        labs = rng.permutation(len(cc))
+        for lab in (None, labs):
+            x, y = geom2d.polygons_to_label_coord(cc, shape, labels=lab), g2["polygons_to_label_coord"](cc, shape, labels=lab)
+            assert x.dtype == y.dtype and np.array_equal(x, y), ("polygons_to_label_coord", it)
+        x, y = geom2d._polygons_to_label_old(coord, prob, a, shape=shape, thr=0.75), g2["_polygons_to_label_old"](coord, prob, a, shape=shape, thr=0.75)
+        assert x.dtype == y.dtype and np.array_equal(x, y), ("_polygons_to_label_old", it)
+    for it in range(6):
+        an = None if it % 2 else (2, 1, 1)
+        rays, rrays = Rays_GoldenSpiral(16, anisotropy=an), ref_rays.Rays_GoldenSpiral(16, anisotropy=an)
+        n = 12
+        pts = rng.randint(4, 26, (n, 3)); d = rng.uniform(2, 5, (n, 16)).astype(np.float32); pr = rng.uniform(0, 1, n)
+        shape = (30, 30, 30)
+        for kw in (dict(verbose=False), dict(prob=pr, verbose=False), dict(prob=pr, thr=0.5, verbose=False), dict(labels=np.arange(7, 7 + n), verbose=False),
+                   dict(mode="kernel", verbose=False), dict(mode="hull", verbose=False), dict(mode="bbox", verbose=False), dict(overlap_label=-1, verbose=False),
+                   dict(prob=pr, thr=2.0, verbose=False)):
+            x, y = geom3d.polyhedron_to_label(d, pts, rays, shape, **kw), g3["polyhedron_to_label"](d, pts, rrays, shape, **kw)
+            assert np.asarray(x).shape == y.shape and np.array_equal(np.asarray(x), y), ("polyhedron_to_label", it, sorted(kw))
+        x, y = geom3d.polyhedron_to_label(d[:0], pts[:0], rays, shape, verbose=False), g3["polyhedron_to_label"](d[:0], pts[:0], rrays, shape, verbose=False)
+        assert x.dtype == y.dtype and np.array_equal(x, y)
+        for bad in (dict(d=-d), dict(d=d[:, :5]), dict(prob=pr[:3]), dict(labels=np.arange(3)), dict(mode="nope")):
+            kw = dict(verbose=False); dd = bad.get("d", d)
+            kw.update({k: v for k, v in bad.items() if k != "d"})
+            with pytest.raises(Exception) as e1:
+                g3["polyhedron_to_label"](dd, pts, rrays, shape, **kw)
+            with pytest.raises(type(e1.value)) as e2:
+                geom3d.polyhedron_to_label(dd, pts, rays, shape, **kw)
+            assert str(e1.value) == str(e2.value), bad
