@@ -15,10 +15,10 @@ from .config import Config3D
 class StarDist3D(StarDistBase):
     """StarDist3D model: `predict_instances(vol)` -> (labels (Z,Y,X), dict(dist, points, prob, rays, ...))."""
 
-    def __init__(self, config=None, name=None, basedir=".", **kwargs):
-        if config is None and (basedir is None):
+    def __init__(self, config=Config3D(), name=None, basedir=".", **kwargs):
+        if config is None and (basedir is None):                 # (nothing to load a configuration from)
             config = Config3D()
-        super().__init__(config if config is not None else None, name=name, basedir=basedir, **kwargs)
+        super().__init__(config, name=name, basedir=basedir, **kwargs)
 
     def _build(self):
         from .unet import StarDistNet

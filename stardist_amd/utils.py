@@ -1,4 +1,6 @@
 """Small host-side helpers mirrored from the reference (stardist/utils.py, csbdeep.utils)."""
+from zipfile import ZIP_DEFLATED
+
 import numpy as np
 
 
@@ -163,7 +165,7 @@ def polyroi_bytearray(x, y, pos=None, subpixel=True):
     return head + body
 
 
-def export_imagej_rois(fname, polygons, set_position=True, subpixel=True, compression=None):
+def export_imagej_rois(fname, polygons, set_position=True, subpixel=True, compression=ZIP_DEFLATED):
     """ImageJ ROI archive of predicted polygons (what stardist/utils.py:254-268 writes): `polygons` is the `coord` array of
     predict_instances' dict -- (n, 2, n_rays), rows (y, x) -- or a sequence of such arrays, one per stack position; entry
     'PPP_III.roi' holds polygon III of position PPP (both 1-based)."""
@@ -172,7 +174,7 @@ def export_imagej_rois(fname, polygons, set_position=True, subpixel=True, compre
     target = str(fname)
     if not target.endswith(".zip"):
         target += ".zip"
-    with zipfile.ZipFile(target, mode="w", compression=zipfile.ZIP_DEFLATED if compression is None else compression) as zf:
+    with zipfile.ZipFile(target, mode="w", compression=ZIP_DEFLATED if compression is None else compression) as zf:
         for pos, group in enumerate(groups, start=1):
             for k, (ys, xs) in enumerate(group, start=1):
                 zf.writestr("%03d_%03d.roi" % (pos, k), bytes(polyroi_bytearray(xs, ys, pos=pos if set_position else None, subpixel=subpixel)))

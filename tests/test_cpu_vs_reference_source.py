@@ -766,3 +766,78 @@ def test_legacy_nms_and_label_glue_equal_the_reference_functions(ref_nms, ref_ra
             with pytest.raises(type(e1.value)) as e2:
                 geom3d.polyhedron_to_label(dd, pts, rays, shape, **kw)
             assert str(e1.value) == str(e2.value), bad
+
+
+def test_public_signatures_follow_the_reference():
+    """every function / method the mirror shares by name with the reference's modules takes the reference's parameters, in its order, with its
+    defaults -- except where this file says otherwise (the deliberate differences)"""
+    import importlib
+    import inspect
+    allowed = {
+        ("geometry/geom2d.py", "star_dist", "mode"): "'hip' replaces 'cpp' / 'opencl' (both still accepted)",
+        ("geometry/geom3d.py", "star_dist3D", "mode"): "same",
+        ("big.py", "Block.__init__", None): "value object instead of a linked chain (same cover, tests above)",
+        ("rays3d.py", "Rays_SubDivide.split", None): "classmethod in both; the reference names its first parameter 'self'",
+        ("models/base.py", "StarDistBase._predict_setup", None): "internal; progress / predict_kwargs handled by the callers here",
+    }
+
+    def ref_sigs(rel):
+        out = {}
+
+        def sig(f):
+            a = f.args
+            names = [x.arg for x in a.posonlyargs + a.args]
+            defaults = [None] * (len(names) - len(a.defaults)) + [ast.unparse(d) for d in a.defaults]
+            return list(zip(names, defaults)), a.kwarg is not None
+        for n in ast.parse(open(os.path.join(REF, rel)).read()).body:
+            if isinstance(n, ast.FunctionDef):
+                out[n.name] = sig(n)
+            if isinstance(n, ast.ClassDef):
+                for f in n.body:
+                    if isinstance(f, ast.FunctionDef):
+                        out[n.name + "." + f.name] = sig(f)
+        return out
+
+    def value(expr):
+        try:
+            return eval(expr, {"np": np, "ZIP_DEFLATED": zipfile.ZIP_DEFLATED})                      # noqa: S307 -- literals of the reference's signatures
+        except Exception:                                                                            # noqa: BLE001 -- e.g. Config2D()
+            return expr
+    checked = 0
+    for rel, modname in (("nms.py", "stardist_amd.nms"), ("geometry/geom2d.py", "stardist_amd.geometry.geom2d"), ("geometry/geom3d.py", "stardist_amd.geometry.geom3d"),
+                         ("utils.py", "stardist_amd.utils"), ("rays3d.py", "stardist_amd.rays3d"), ("big.py", "stardist_amd.big"), ("matching.py", "stardist_amd.matching"),
+                         ("models/base.py", "stardist_amd.models.base"), ("models/model2d.py", "stardist_amd.models.model2d"), ("models/model3d.py", "stardist_amd.models.model3d")):
+        m = importlib.import_module(modname)
+        for name, (params, has_kw) in ref_sigs(rel).items():
+            leaf = name.split(".")[-1]
+            if (leaf.startswith("__") and leaf != "__init__") or (rel, name, None) in allowed:
+                continue
+            obj = m
+            try:
+                for part in name.split("."):
+                    obj = getattr(obj, part)
+            except AttributeError:
+                continue                                                    # not part of the prediction path (see DESIGN.md, out of scope)
+            if not callable(obj):
+                continue
+            mine = inspect.signature(obj).parameters
+            mine_pos = [p for p in mine.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
+            mine_kw = any(p.kind == p.VAR_KEYWORD for p in mine.values())
+            if inspect.ismethod(obj) or (leaf != "__init__" and "." in name and params and params[0][0] in ("self", "cls") and (not mine_pos or mine_pos[0].name not in ("self", "cls"))):
+                params = params[1:]                                         # bound classmethod / staticmethod view
+            names = [p.name for p in mine_pos]
+            ref_names = [n for n, _ in params]
+            assert [n for n in ref_names if n in names] == ref_names or mine_kw, (rel, name, "missing", [n for n in ref_names if n not in names])
+            assert [n for n in names if n in ref_names] == [n for n in ref_names if n in names], (rel, name, "order")
+            for n, d in params:
+                if n not in mine or d is None or (rel, name, n) in allowed:
+                    continue
+                got, want = mine[n].default, value(d)
+                if isinstance(want, str) and want.endswith("()"):           # a default instance (Config2D()): same class name
+                    assert type(got).__name__ == want[:-2], (rel, name, n)
+                    continue
+                same = (got == want) if not isinstance(want, float) else (got == want or (got != got and want != want))
+                assert same or (isinstance(want, tuple) and tuple(got) == want), (rel, name, n, got, want)
+            assert not has_kw or mine_kw or name.endswith("Resizer.__init__"), (rel, name, "**kwargs")
+            checked += 1
+    assert checked > 80, checked
