@@ -9,7 +9,7 @@ __version__ = "0.1.0"
 _LAZY = {
     "StarDist2D": "models", "StarDist3D": "models", "Config2D": "models", "Config3D": "models",
     "non_maximum_suppression": "nms", "non_maximum_suppression_3d": "nms", "non_maximum_suppression_3d_sparse": "nms",
-    "edt_prob": "utils", "export_imagej_rois": "utils",
+    "edt_prob": "utils", "export_imagej_rois": "utils", "gputools_available": "utils",
     "star_dist": "geometry", "polygons_to_label": "geometry", "relabel_image_stardist": "geometry", "ray_angles": "geometry",
     "dist_to_coord": "geometry", "star_dist3D": "geometry", "polyhedron_to_label": "geometry", "relabel_image_stardist3D": "geometry",
     "rays_from_json": "rays3d", "Rays_Cartesian": "rays3d", "Rays_SubDivide": "rays3d", "Rays_Tetra": "rays3d", "Rays_Octo": "rays3d",

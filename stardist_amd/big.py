@@ -148,6 +148,9 @@ class BlockND(object):
         assert len(self.axes) == len(self.blocks)
         self.axis_to_block = dict(zip(self.axes, self.blocks))
 
+    def __iter__(self):
+        return iter(self.blocks)
+
     def blocks_for_axes(self, axes=None):
         axes = self.axes if axes is None else str(axes).upper()
         return tuple(self.axis_to_block[a] for a in axes)

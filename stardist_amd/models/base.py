@@ -271,6 +271,18 @@ class StarDistBase(object):
                     attr.copy_(torch.from_numpy(v))
 
     # ------------------------------------------------------------------ helpers
+    def _guess_n_tiles(self, img):
+        """base.py:1046-1055: tiles of about one training batch of training patches each (1 for a channel axis)"""
+        axes = self._normalize_axes(img, axes=None)
+        shape = list(img.shape)
+        if "C" in axes:
+            del shape[axes_dict(axes)["C"]]
+        b = self.config.train_batch_size ** (1.0 / self.config.n_dim)
+        n_tiles = [int(np.ceil(s / (p * b))) for s, p in zip(shape, self.config.train_patch_size)]
+        if "C" in axes:
+            n_tiles.insert(axes_dict(axes)["C"], 1)
+        return tuple(n_tiles)
+
     def _normalize_axes(self, img, axes):
         if axes is None:
             axes = self.config.axes

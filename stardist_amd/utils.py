@@ -4,6 +4,12 @@ from zipfile import ZIP_DEFLATED
 import numpy as np
 
 
+def gputools_available():
+    """stardist/utils.py:40-45 asks whether the OpenCL helpers can be imported (they serve the reference's mode='opencl' of the training targets).
+    There is no OpenCL path here -- 'hip' is the one device mode -- so the answer is always False."""
+    return False
+
+
 def _normalize_grid(grid, n):
     """stardist/utils.py:60-68"""
     try:

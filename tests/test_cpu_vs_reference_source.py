@@ -841,3 +841,19 @@ def test_public_signatures_follow_the_reference():
             assert not has_kw or mine_kw or name.endswith("Resizer.__init__"), (rel, name, "**kwargs")
             checked += 1
     assert checked > 80, checked
+
+
+def test_guess_n_tiles_equals_the_reference_method():
+    from stardist_amd.models import Config2D, Config3D, StarDist2D, StarDist3D
+    from stardist_amd.models.base import axes_check_and_normalize, axes_dict
+    norm = _ref_method("models/base.py", "StarDistBase", "_normalize_axes", {"np": np, "axes_check_and_normalize": axes_check_and_normalize})
+    ref = _ref_method("models/base.py", "StarDistBase", "_guess_n_tiles", {"np": np, "axes_dict": axes_dict})
+    for cls, cfg, shapes in ((StarDist2D, Config2D(n_rays=8, unet_n_depth=1, unet_n_filter_base=4), [(300, 700), (2048, 2048), (100, 90)]),
+                             (StarDist2D, Config2D(n_rays=8, unet_n_depth=1, unet_n_filter_base=4, n_channel_in=3, train_patch_size=(128, 64), train_batch_size=2), [(500, 400, 3)]),
+                             (StarDist3D, Config3D(rays=8, unet_n_depth=1, unet_n_filter_base=4, train_batch_size=2), [(64, 300, 300), (20, 20, 20)])):
+        m = cls(cfg, basedir=None, device="cpu")
+        fake = types.SimpleNamespace(config=cfg)
+        fake._normalize_axes = lambda img, axes, _f=fake: norm(_f, img, axes)
+        for sh in shapes:
+            x = np.zeros(sh, np.float32)
+            assert m._guess_n_tiles(x) == ref(fake, x), (cls.__name__, sh)
