@@ -184,3 +184,63 @@ def export_imagej_rois(fname, polygons, set_position=True, subpixel=True, compre
         for pos, group in enumerate(groups, start=1):
             for k, (ys, xs) in enumerate(group, start=1):
                 zf.writestr("%03d_%03d.roi" % (pos, k), bytes(polyroi_bytearray(xs, ys, pos=pos if set_position else None, subpixel=subpixel)))
+
+
+# ----------------------------------------------------------------------------- label-image helpers the reference package exports
+# (stardist/__init__.py:13: fill_label_holes, sample_points, calculate_extents).  Host-side preparation / inspection of label images,
+# not part of the prediction path; numpy + scipy like the reference's.
+
+def _object_boxes(lbl_img):
+    """[(label id, bounding-box slices)] of the labels present, ascending (scipy.ndimage.find_objects: entry i - 1 belongs to label i)"""
+    from scipy.ndimage import find_objects
+    return [(i, sl) for i, sl in enumerate(find_objects(lbl_img), 1) if sl is not None]
+
+
+def fill_label_holes(lbl_img, **kwargs):
+    """Fill the holes of every labelled object (stardist/utils.py:137-153): per object, `binary_fill_holes` of its mask on its bounding
+    box grown by one pixel on every side that is not an image border -- a cavity that reaches the image border stays open, as there.
+    **kwargs go to scipy.ndimage.binary_fill_holes."""
+    from scipy.ndimage import binary_fill_holes
+    lbl_img = np.asarray(lbl_img)
+    out = np.zeros_like(lbl_img)
+    for lab, box in _object_boxes(lbl_img):
+        room = [(s.start > 0, s.stop < n) for s, n in zip(box, lbl_img.shape)]
+        grown = tuple(slice(s.start - int(lo), s.stop + int(hi)) for s, (lo, hi) in zip(box, room))
+        inner = tuple(slice(int(lo), -1 if hi else None) for lo, hi in room)
+        filled = binary_fill_holes(lbl_img[grown] == lab, **kwargs)[inner]
+        out[box][filled] = lab
+    return out
+
+
+def sample_points(n_samples, mask, prob=None, b=2):
+    """Draw `n_samples` pixel positions (with replacement) from a 2D mask, at least `b` pixels from the border, uniformly or weighted by
+    `prob` (stardist/utils.py:156-177; numpy's global random state, the same draws as there)."""
+    mask = np.asarray(mask)
+    if b is not None and b > 0:
+        inner = np.zeros_like(mask)
+        inner[b:-b, b:-b] = True
+    else:
+        inner = True
+    rows, cols = np.nonzero(mask & inner)
+    if prob is not None:
+        w = np.asarray(prob)[rows, cols].astype(np.float64)
+        w /= np.sum(w)
+        pick = np.random.choice(len(rows), n_samples, replace=True, p=w)
+    else:
+        pick = np.random.choice(len(rows), n_samples, replace=True)
+    return np.stack((rows[pick], cols[pick]), axis=-1)
+
+
+def calculate_extents(lbl, func=np.median):
+    """Aggregate (median by default) of the objects' bounding-box sizes per axis, for one 2D / 3D label image, or over a sequence / 4D
+    stack of them (stardist/utils.py:180-193)."""
+    from collections.abc import Iterable
+    if (isinstance(lbl, np.ndarray) and lbl.ndim == 4) or (not isinstance(lbl, np.ndarray) and isinstance(lbl, Iterable)):
+        return func(np.stack([calculate_extents(one, func) for one in lbl], axis=0), axis=0)
+    n = lbl.ndim
+    if n not in (2, 3):
+        raise ValueError("label image should be 2- or 3-dimensional (or pass a list of these)")
+    boxes = _object_boxes(lbl)
+    if not boxes:
+        return np.zeros(n)
+    return func(np.array([[s.stop - s.start for s in box] for _, box in boxes]), axis=0)

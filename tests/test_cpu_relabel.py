@@ -72,6 +72,7 @@ def test_top_level_names_follow_the_reference_package():
     """what `from stardist import ...` offers on the prediction path (stardist/__init__.py:12-20) resolves under the same names"""
     import stardist_amd as s
     names = ["non_maximum_suppression", "non_maximum_suppression_3d", "non_maximum_suppression_3d_sparse", "edt_prob", "export_imagej_rois",
+             "fill_label_holes", "sample_points", "calculate_extents", "gputools_available",
              "star_dist", "polygons_to_label", "relabel_image_stardist", "ray_angles", "dist_to_coord", "star_dist3D", "polyhedron_to_label",
              "relabel_image_stardist3D", "rays_from_json", "Rays_Cartesian", "Rays_SubDivide", "Rays_Tetra", "Rays_Octo", "Rays_GoldenSpiral",
              "Rays_Explicit"]

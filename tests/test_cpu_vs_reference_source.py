@@ -857,3 +857,49 @@ def test_guess_n_tiles_equals_the_reference_method():
         for sh in shapes:
             x = np.zeros(sh, np.float32)
             assert m._guess_n_tiles(x) == ref(fake, x), (cls.__name__, sh)
+
+
+def test_label_image_helpers_equal_the_reference_functions():
+    """fill_label_holes, calculate_extents, sample_points (stardist/utils.py:128-193; exported by the reference package's __init__)"""
+    from collections.abc import Iterable
+    from scipy import ndimage as ndi
+    from stardist_amd import utils as U
+
+    class Reg(object):
+        def __init__(self, sl): self.bbox = tuple(s.start for s in sl) + tuple(s.stop for s in sl)
+    ns = ref_functions("utils.py", {"fill_label_holes", "_fill_label_holes", "sample_points", "calculate_extents"},
+                       {"np": np, "find_objects": ndi.find_objects, "binary_fill_holes": ndi.binary_fill_holes, "Iterable": Iterable, "_raise": _raise,
+                        "regionprops": lambda lbl: [Reg(sl) for sl in ndi.find_objects(lbl) if sl is not None]})
+    rng = np.random.RandomState(11)
+    imgs = []
+    for it in range(40):
+        nd = 2 if it % 3 else 3
+        shape = tuple(int(v) for v in (rng.randint(20, 60, nd) if nd == 2 else rng.randint(10, 24, nd)))
+        grids = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+        lbl = np.zeros(shape, np.uint16 if it % 2 else np.int32)
+        for lab in rng.permutation(np.arange(1, 9))[:rng.randint(1, 7)]:
+            c = [rng.uniform(-2, s + 2) for s in shape]; r = rng.uniform(3, 9)
+            d2 = sum((g - ci) ** 2 for g, ci in zip(grids, c))
+            lbl[(d2 <= r * r) & (d2 >= (0.45 * r) ** 2) & (lbl == 0)] = lab            # rings / shells: holes, some cut by the border
+        imgs.append(lbl)
+        a, b = U.fill_label_holes(lbl), ns["fill_label_holes"](lbl)
+        assert a.dtype == b.dtype and np.array_equal(a, b), it
+        for func in (np.median, np.mean, np.max):
+            x, y = U.calculate_extents(lbl, func), ns["calculate_extents"](lbl, func)
+            assert np.array_equal(x, y) and x.dtype == y.dtype, (it, func.__name__)
+    two_d = [im for im in imgs if im.ndim == 2]
+    assert np.array_equal(U.calculate_extents(two_d), ns["calculate_extents"](two_d))
+    stack = np.stack([im[:10, :10, :10] for im in imgs if im.ndim == 3])
+    assert np.array_equal(U.calculate_extents(stack), ns["calculate_extents"](stack))
+    assert np.array_equal(U.calculate_extents(np.zeros((5, 5), np.int32)), ns["calculate_extents"](np.zeros((5, 5), np.int32)))
+    with pytest.raises(ValueError):
+        U.calculate_extents(np.zeros(5, np.int32))
+    hole = np.zeros((12, 12), bool); hole[2:10, 2:10] = True; hole[5:7, 5:7] = False
+    kw = dict(structure=np.ones((3, 3), bool))
+    assert np.array_equal(U.fill_label_holes(hole.astype(np.int32), **kw), ns["fill_label_holes"](hole.astype(np.int32), **kw))
+    mask = rng.uniform(0, 1, (40, 50)) > 0.6
+    prob = rng.uniform(0, 1, (40, 50))
+    for kw in (dict(), dict(prob=prob), dict(b=0), dict(b=None, prob=prob), dict(b=5)):
+        np.random.seed(3); a = U.sample_points(25, mask, **kw)
+        np.random.seed(3); b = ns["sample_points"](25, mask, **kw)
+        assert a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b), sorted(kw)
