@@ -155,18 +155,18 @@ def _region_centroids(lbl):
     """(labels, centroids): what `skimage.measure.regionprops(lbl)` yields as (r.label, r.centroid) -- the labels present in ascending
     order, the centroid = the mean of the region's pixel coordinates (skimage: `coords.mean(axis=0)`, a float64 quotient of an exactly
     representable integer sum and the pixel count; reproduced here as that quotient, so the truncation `astype(int)` the callers apply
-    sees the very same float64).  One bincount per axis instead of one Python object per region."""
+    sees the very same float64).  Per object on its bounding box (scipy.ndimage.find_objects), like regionprops: no image-sized temporaries."""
+    from scipy.ndimage import find_objects
     lbl = np.asarray(lbl)
-    flat = lbl.reshape(-1).astype(np.int64, copy=False)
-    n = np.bincount(flat)
-    labs = np.nonzero(n)[0]
-    labs = labs[labs > 0]
-    cen = np.empty((len(labs), lbl.ndim), np.float64)
-    for d in range(lbl.ndim):
-        shp = [1] * lbl.ndim
-        shp[d] = lbl.shape[d]
-        w = np.broadcast_to(np.arange(lbl.shape[d], dtype=np.float64).reshape(shp), lbl.shape).reshape(-1)
-        cen[:, d] = np.bincount(flat, weights=w, minlength=len(n))[labs] / n[labs]      # sums < 2^53: exact
+    boxes = [(i, sl) for i, sl in enumerate(find_objects(lbl), 1) if sl is not None]
+    labs = np.array([i for i, _ in boxes], np.int64)
+    cen = np.empty((len(boxes), lbl.ndim), np.float64)
+    for k, (lab, sl) in enumerate(boxes):
+        m = lbl[sl] == lab
+        n = int(m.sum())
+        for d in range(lbl.ndim):
+            along = m.sum(axis=tuple(a for a in range(lbl.ndim) if a != d), dtype=np.int64)           # pixels of the object per coordinate
+            cen[k, d] = int((along * np.arange(sl[d].start, sl[d].stop, dtype=np.int64)).sum()) / n    # exact integer sum, one rounding
     return labs, cen
 
 
