@@ -214,7 +214,8 @@ class StarDistBase(object):
         """weights exported from Keras (tools/keras_to_npz.py) as {layer_name/kernel:0, layer_name/bias:0, ...}.
         The output heads and the feature convolutions are matched BY NAME (prob, dist, features, features_class, prob_class:
         Keras orders layers by graph depth, which for a multi-class model differs from this module's order); the backbone
-        convolutions (csbdeep block names vary between versions) are matched in graph order.  Every kernel's shape is checked."""
+        convolutions (csbdeep block names vary between versions) are matched in graph order -- file order for a named backbone, the
+        creation order of Keras' automatic names for an unnamed one (ResNet).  Every kernel's shape is checked."""
         import torch
         import torch.nn as nn
         data = np.load(path)
@@ -236,6 +237,16 @@ class StarDistBase(object):
         if missing:
             raise ValueError("weight file has no kernels for layer(s) %s" % ", ".join(missing))
         rest = [k for k in kernels if lname(k) not in named]
+        # A backbone whose convolutions ALL carry Keras' automatic names (conv3d, conv3d_1, ...: the ResNet backbone -- csbdeep's
+        # resnet_block names nothing, model3d.py:414-428) is matched in CREATION order, which the numeric suffix records and which is
+        # this module's order (stem, then per block: strided convolution, body, shortcut projection).  The FILE order is model.layers'
+        # -- by graph depth, and a block's 1x1 projection and its last body convolution have EQUAL depth: which of the two Keras lists
+        # first depends on the operand order of the residual Add (tests/test_cpu_reference_build.py).  Named backbones (csbdeep's
+        # unet_block: down_level_* / middle_* / up_level_*, after the unnamed grid stem) are chains without ties: file order.
+        import re
+        auto = [re.match(r"^conv\dd(?:_(\d+))?$", lname(k)) for k in rest]
+        if rest and all(auto):
+            rest = [k for _, k in sorted(zip((int(a.group(1) or 0) for a in auto), rest))]
         if len(rest) != len(backbone):
             raise ValueError("weight file has %d backbone conv kernels, network has %d" % (len(rest), len(backbone)))
 

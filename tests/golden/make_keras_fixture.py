@@ -4,7 +4,10 @@ reference's topologies the script
     unnamed layers get Keras' automatic conv2d, conv2d_1, ... / conv3d, conv3d_1, ... in creation order; heads: features, prob, dist
     as in stardist/models/model2d.py:310-349 and model3d.py:400-447) and stores the variables the way Keras' save_weights stores
     them -- "<layer>/kernel:0" in (k..., c_in, c_out) layout, "<layer>/bias:0" -- in model.layers order (by graph depth; layers of
-    equal depth in creation order: a resnet_block's last body convolution precedes its shortcut projection);
+    equal depth here in creation order: a resnet_block's last body convolution precedes its shortcut projection.  Keras itself breaks
+    that tie by its traversal from the outputs, which with csbdeep's Add()([shortcut, body]) lists the projection FIRST: the loader
+    therefore restores the creation order from the automatic names and reads both file orders -- tests/test_cpu_reference_build.py runs
+    the reference's own _build code over a stand-in Keras with Keras' ordering rule and both operand orders);
   * evaluates the network with its own numpy forward pass written from the Keras layer semantics (Conv 'same' = TensorFlow SAME
     padding incl. strides, MaxPooling 'valid', UpSampling nearest, Concatenate([up, skip]), Add, ReLU, sigmoid);
   * writes config.json + weights_best.npz + expected.npz (input, prob, dist) into tests/golden/keras_fixture/<class>/<name>/.

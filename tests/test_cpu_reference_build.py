@@ -1,0 +1,136 @@
+"""CPU: the reference's OWN network-building code -- StarDist2D._build (stardist/models/model2d.py:310-349), StarDist3D._build /
+_build_unet / _build_resnet (model3d.py:349-447), taken from the reference files at run time, nothing copied -- executed over the
+minimal Keras stand-in of tests/_mini_keras.py (float64 numpy; Keras' layer naming and `model.layers` order; csbdeep's unet_block /
+resnet_block restated, the one third-party piece that is not under /root/reference), on the reference's own Config2D / Config3D
+objects.  The variables of the graph it builds are written in the order keras.Model.save_weights writes them, loaded by the mirror's
+weight loader (StarDistBase.load_weights_npz, the back end of load_weights_h5 / from_pretrained), and the mirror's network must then
+compute what the reference's graph computes: heads off the right tensors (prob / dist off `features`, the class head off the backbone
+through `features_class`), activations, the grid stem in front of the U-Net, the linear 7x7x7 / 3x3x3 ResNet stem, filter doubling
+and strides per block, 'same' padding of the strided convolutions.  Build container only (skipped where the reference is absent)."""
+import ast
+import io
+import os
+
+import numpy as np
+import pytest
+
+import _mini_keras as K
+from test_cpu_vs_reference_source import REF, _raise, _ref_configs, ref_rays  # noqa: F401  (ref_rays: fixture)
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference sources (build container only)")
+
+
+def ref_methods(relpath, cls, names, ns):
+    """the named methods of class `cls` in the reference file, compiled where they lie, as plain functions in `ns`"""
+    path = os.path.join(REF, relpath)
+    for node in ast.parse(open(path).read()).body:
+        if isinstance(node, ast.ClassDef) and node.name == cls:
+            for fn in node.body:
+                if isinstance(fn, ast.FunctionDef) and fn.name in names:
+                    exec(compile(ast.Module([fn], []), path, "exec"), ns)
+    assert set(names) <= set(ns), sorted(set(names) - set(ns))
+    return {n: ns[n] for n in names}
+
+
+def reference_graph(nd, cfg, shortcut_first=True, seed=0):
+    """run the reference's _build on `cfg` (a reference Config object) over the mini-Keras; returns the Model"""
+    K.SESSION.reset(seed)
+    if nd == 2:
+        ns = dict(np=np, _raise=_raise, Input=K.Input, Conv2D=K.Conv2D, MaxPooling2D=K.MaxPooling2D, Model=K.Model, unet_block=K.unet_block)
+        meth = ref_methods("models/model2d.py", "StarDist2D", {"_build"}, ns)
+    else:
+        ns = dict(np=np, _raise=_raise, Input=K.Input, Conv3D=K.Conv3D, MaxPooling3D=K.MaxPooling3D, Model=K.Model, unet_block=K.unet_block,
+                  resnet_block=K.make_resnet_block(shortcut_first))
+        meth = ref_methods("models/model3d.py", "StarDist3D", {"_build", "_build_unet", "_build_resnet"}, ns)
+    meth.update(ref_methods("models/base.py", "StarDistBase", {"_is_multiclass"}, dict(np=np)))
+    obj = type("RefModel", (), meth)()
+    obj.config = cfg
+    return obj._build()
+
+
+def mirror_outputs(cls, cfg, weights, x):
+    """the mirror's network with `weights` ({Keras variable name: array}, file order) loaded by its own loader, evaluated in float64"""
+    import torch
+    m = cls(cfg, basedir=None, device="cpu")
+    buf = io.BytesIO()
+    np.savez(buf, **weights)
+    buf.seek(0)
+    m.load_weights_npz(buf)
+    net = m.net.double().eval()
+    nd = x.ndim - 1
+    with torch.no_grad():
+        out = net(torch.from_numpy(np.moveaxis(x, -1, 0)[None].copy()).double())
+    return [np.moveaxis(o[0].numpy(), 0, -1) for o in out]
+
+
+def compare(nd, kw, shape, ref_rays, shortcut_first=True):
+    from stardist_amd.models import Config2D, Config3D, StarDist2D, StarDist3D
+    R2, R3 = _ref_configs(ref_rays)
+    rcfg = (R2 if nd == 2 else R3)(**kw)
+    model = reference_graph(nd, rcfg, shortcut_first)
+    x = np.random.RandomState(5).uniform(-1, 1, shape + (rcfg.n_channel_in,))
+    want = model.predict(x)
+    got = mirror_outputs(StarDist2D if nd == 2 else StarDist3D, (Config2D if nd == 2 else Config3D)(**kw), model.weights_in_file_order(), x)
+    assert len(got) == len(want) == (2 if rcfg.n_classes is None else 3), kw
+    for name, a, b in zip(("prob", "dist", "prob_class"), got, want):
+        assert a.shape == b.shape and b.shape[:-1] == tuple(-(-s // g) for s, g in zip(shape, rcfg.grid)), (kw, name, a.shape, b.shape)
+        assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max()), (kw, name, float(np.abs(a - b).max()))
+    return model
+
+
+SMALL2 = dict(n_rays=8, unet_n_filter_base=4, net_conv_after_unet=8)
+CASES_2D = [
+    (dict(SMALL2), (24, 32)),
+    (dict(SMALL2, grid=(2, 2), n_channel_in=3), (32, 48)),
+    (dict(SMALL2, grid=(4, 2), unet_n_depth=2), (64, 32)),                     # two rounds of the grid stem, the second pools one axis only
+    (dict(SMALL2, n_classes=2), (16, 24)),
+    (dict(SMALL2, n_classes=3, net_conv_after_unet=0), (16, 16)),             # heads straight off the U-Net
+    (dict(SMALL2, unet_batch_norm=True, grid=(2, 1)), (32, 16)),
+    (dict(SMALL2, unet_n_depth=1, unet_n_conv_per_depth=3, unet_kernel_size=(5, 5), unet_pool=(2, 2)), (12, 20)),
+    (dict(SMALL2, unet_last_activation="linear", unet_prefix="u_"), (16, 16)),
+]
+
+
+@pytest.mark.parametrize("kw,shape", CASES_2D)
+def test_reference_build_2d_equals_the_mirror_network(kw, shape, ref_rays):
+    model = compare(2, kw, shape, ref_rays)
+    names = [l.name for l in model.layers]
+    assert {"input", "prob", "dist"} <= set(names)
+    if kw.get("net_conv_after_unet", 1):
+        assert "features" in names
+
+
+SMALL3 = dict(rays=8, unet_n_filter_base=4, net_conv_after_unet=8)
+RES3 = dict(rays=8, backbone="resnet", resnet_n_filter_base=4, net_conv_after_resnet=8, resnet_n_blocks=2)
+CASES_3D = [
+    (dict(SMALL3), (8, 12, 16)),
+    (dict(SMALL3, grid=(1, 2, 2), n_classes=2, n_channel_in=2), (8, 16, 24)),
+    (dict(SMALL3, grid=(2, 2, 2), unet_n_depth=1, anisotropy=(2, 1, 1)), (8, 12, 8)),
+    (dict(RES3), (6, 7, 9)),                                                   # no pooling, equal widths: no projection anywhere
+    (dict(RES3, grid=(1, 2, 2)), (6, 10, 13)),                                 # the 3D_demo shape: block 0 strided (1,2,2) with projection; odd extents
+    (dict(RES3, grid=(2, 2, 2), resnet_n_blocks=3), (7, 8, 10)),
+    (dict(RES3, grid=(4, 2, 2), n_classes=2), (8, 6, 6)),                      # two strided blocks ((2,2,2) then (2,1,1)), widths doubled twice
+    (dict(RES3, grid=(1, 2, 2), net_conv_after_resnet=0, resnet_n_conv_per_block=2, n_channel_in=2), (4, 8, 8)),
+]
+
+
+@pytest.mark.parametrize("shortcut_first", [True, False])
+@pytest.mark.parametrize("kw,shape", CASES_3D)
+def test_reference_build_3d_equals_the_mirror_network(kw, shape, shortcut_first, ref_rays):
+    if kw.get("backbone") != "resnet" and not shortcut_first:
+        pytest.skip("the Add operand order only exists in the ResNet backbone")
+    compare(3, kw, shape, ref_rays, shortcut_first)
+
+
+def test_model_layers_order_of_a_strided_resnet_block(ref_rays):
+    """what the loader has to cope with: with Add()([shortcut, body]) Keras lists a block's 1x1x1 projection BEFORE the block's last body
+    convolution (equal depth, the traversal from the outputs reaches the shortcut first), with the operands swapped AFTER it; the
+    automatic names carry the creation order either way, and that is the order the loader restores"""
+    _, R3 = _ref_configs(ref_rays)
+    for shortcut_first in (True, False):
+        model = reference_graph(3, R3(**dict(RES3, grid=(1, 2, 2))), shortcut_first)
+        convs = [k.split("/")[0] for k in model.weights_in_file_order() if k.endswith("kernel:0")]
+        # creation order: conv3d (7^3), conv3d_1 (3^3), block 0: conv3d_2 (strided), _3, _4 (last body), _5 (projection), block 1: _6, _7, _8
+        assert convs[:4] == ["conv3d", "conv3d_1", "conv3d_2", "conv3d_3"]
+        assert convs[4:6] == (["conv3d_5", "conv3d_4"] if shortcut_first else ["conv3d_4", "conv3d_5"])
+        assert convs[6:] == ["conv3d_6", "conv3d_7", "conv3d_8", "features", "prob", "dist"]
