@@ -479,7 +479,9 @@ class StarDistBase(object):
 
     def _axes_tile_overlap(self, query_axes):
         """base.py:1100-1110 derives this empirically from an impulse response; the analytic receptive field of
-        the conv stack (upper bound of the empirical one) is used instead."""
+        the conv stack (upper bound of the empirical one) is used instead.  tests/test_cpu_reference_predict.py runs the reference's
+        own _compute_receptive_field on the graph its own _build makes and holds this bound to it (never smaller; the comparison
+        found the stem convolutions of anisotropic grids missing from the bound on the axes a stem round does not pool)."""
         rf = self._receptive_field_radius()
         d = dict(zip(self.config.axes.replace("C", ""), rf))
         return tuple(d.get(a, 0) for a in query_axes)
@@ -490,11 +492,16 @@ class StarDistBase(object):
         if cfg.backbone == "unet":
             k = cfg.unet_kernel_size; pool = cfg.unet_pool; depth = cfg.unet_n_depth; ncv = cfg.unet_n_conv_per_depth
             out = []
+            # the grid stem (model2d.py:317-325, model3d.py:367-375) runs log2(max(grid)) rounds; the convolutions of EVERY round act on
+            # every axis, also on the axes a round does not pool (anisotropic grids: (1, 2, 2), (4, 2))
+            rounds = int(np.log2(max(cfg.grid))) if max(cfg.grid) > 1 else 0
             for d in range(nd):
                 r, scale = 0, 1
                 g = cfg.grid[d]
-                while scale < g:                                  # pre-pooling stages
-                    r += ncv * (k[d] // 2) * scale; scale *= 2
+                for _ in range(rounds):                           # pre-pooling stages
+                    r += ncv * (k[d] // 2) * scale
+                    if scale < g:
+                        scale *= 2
                 for n in range(depth):
                     r += ncv * (k[d] // 2) * scale; scale *= pool[d]
                 r += ncv * (k[d] // 2) * scale
