@@ -91,7 +91,7 @@ def same_dict(a, b, tag, tol=2e-5):
         x, y = np.asarray(a[k]), np.asarray(b[k])
         assert x.shape == y.shape, (tag, k, x.shape, y.shape)
         if np.issubdtype(y.dtype, np.floating):
-            assert x.dtype == y.dtype or k in ("prob", "dist", "coord", "class_prob"), (tag, k, x.dtype, y.dtype)
+            assert x.dtype == y.dtype, (tag, k, x.dtype, y.dtype)
             assert x.size == 0 or np.abs(x - y).max() <= tol * max(1.0, float(np.abs(y).max())), (tag, k, float(np.abs(x - y).max()))
         else:
             assert np.array_equal(x, y), (tag, k)
@@ -119,7 +119,7 @@ def test_predict_instances_2d_end_to_end_equals_the_reference(kw, axes, shape, r
     m.thresholds = dict(prob=thr, nms=0.4)
 
     variants = [dict(), dict(sparse=False), dict(return_labels=False), dict(nms_thresh=0.2, prob_thresh=min(0.999, thr + 0.02)),
-                dict(return_predict=True), dict(nms_kwargs=dict(use_kdtree=False))]
+                dict(return_predict=True), dict(nms_kwargs=dict(use_kdtree=False)), dict(scale=2), dict(scale=tuple(1.5 if a == "Y" else (0.8 if a == "X" else 1) for a in axes))]
     for v in variants:
         import warnings
         with warnings.catch_warnings():
@@ -135,6 +135,18 @@ def test_predict_instances_2d_end_to_end_equals_the_reference(kw, axes, shape, r
                 assert a.shape == b.shape and np.abs(a - b).max() <= 2e-5 * max(1.0, float(np.abs(b).max()))
         else:
             (lw, dw), (lg, dg) = want, got
+        if "scale" in v:
+            # the zoomed (interpolated) input makes near-ties among the scores; the mirror's float32 network and the float64 graph order a few
+            # of them differently and the greedy NMS then keeps another polygon of a cluster: compare as sets
+            pw_, pg_ = set(map(tuple, dw["points"].tolist())), set(map(tuple, dg["points"].tolist()))
+            assert len(pw_ & pg_) >= 0.97 * len(pw_ | pg_), (v, len(pw_), len(pg_), len(pw_ & pg_))
+            iw = {tuple(p): i for i, p in enumerate(dw["points"].tolist())}
+            common = [(i, iw[tuple(p)]) for i, p in enumerate(dg["points"].tolist()) if tuple(p) in iw]
+            gi, wi = np.array(common).T
+            assert np.abs(dg["coord"][gi] - dw["coord"][wi]).max() <= 2e-5 * float(np.abs(dw["coord"]).max()), v
+            assert dg["coord"].dtype == dw["coord"].dtype and dg["points"].dtype == dw["points"].dtype and dg["prob"].dtype == dw["prob"].dtype
+            assert lg.shape == lw.shape == tuple(img.shape[axes.index(a)] for a in "YX") and (lg > 0).sum() >= 0.97 * ((lg > 0) | (lw > 0)).sum()
+            continue
         same_dict(dg, dw, v)
         assert len(dw["prob"]) >= 10, (v, len(dw["prob"]))
         if v.get("return_labels", True):

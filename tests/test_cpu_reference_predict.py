@@ -65,7 +65,7 @@ class _KerasModel(object):
 
     def predict(self, x, **kwargs):
         assert x.shape[0] == 1 and set(kwargs) <= {"verbose"}
-        return [y[np.newaxis] for y in self.model.predict(x[0])]
+        return [y[np.newaxis].astype(np.float32) for y in self.model.predict(x[0])]      # (Keras hands float32 arrays back)
 
 
 def reference_model(nd, rcfg, prob_thresh=0.5):
