@@ -533,6 +533,9 @@ def main():
     if args.dry_collectives:
         return dry_collectives(args)
 
+    # dmabuf IPC (the pool's host driver supports no legacy IPC handles): RCCL's buffer registration between the ranks of one node fails
+    # with `hipIpcGetMemHandle: invalid argument` without it; exported by the image, set here as well in case the launcher's env was trimmed
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist_
     rank = int(os.environ.get("RANK", "0"))
@@ -572,18 +575,25 @@ def main():
     # second number (SURVEY.md 8d defines the metric host-array-in): the same steps with the image handed over as a host numpy array,
     # i.e. including the 16.8 MB H2D copy (staged through page-locked memory, stardist_amd/utils.py to_device); `value` stays the
     # HBM-resident figure the bench contract asks for
-    elapsed_host, elapsed_host_serial = run_host_legs(model, img_np, args.steps)
+    host2d, host2d_err = guarded(lambda: run_host_legs(model, img_np, args.steps), "host-input leg (2D)")      # an extra leg must never lose the line
     # the bit-exact-by-construction mode (sd_set_option("nms2d_strict", 1): every pair through the Clipper-exact sweep, no decision from the
     # area enclosure): same steps, and the instances must be the very same
     from stardist_amd.lib import _native as _nat
     strict_steps = max(1, min(args.steps, 10))
-    with _nat.option("nms2d_strict", 1):
-        el_s, _, res_s, _ = run_leg(model, img, strict_steps, 1, world, dist_)
-    strict_leg = {"value": round(world * H * W * strict_steps / el_s / 1e6, 3), "unit": "Mpix/s", "ms_per_step": round(1e3 * el_s / strict_steps, 3),
-                  "instances": len(res_s[1]["prob"]),
-                  "same_result_as_default": bool(np.array_equal(res_s[0], res[0]) and np.array_equal(res_s[1]["points"], res[1]["points"])),
-                  "note": "sd_set_option('nms2d_strict', 1): every 2D pair decided by the Clipper-exact sweep (bit-exact by construction); the default decides "
-                          "pairs far from the threshold from an empirically / adversarially validated band around the exact area (DESIGN.md 3.4)"}
+
+    def strict_run():
+        with _nat.option("nms2d_strict", 1):
+            return run_leg(model, img, strict_steps, 1, world, dist_)
+    strict, strict_err = guarded(strict_run, "nms2d_strict leg")
+    if strict is None:
+        strict_leg = {"value": None, "error": strict_err}
+    else:
+        el_s, _, res_s, _ = strict
+        strict_leg = {"value": round(world * H * W * strict_steps / el_s / 1e6, 3), "unit": "Mpix/s", "ms_per_step": round(1e3 * el_s / strict_steps, 3),
+                      "instances": len(res_s[1]["prob"]),
+                      "same_result_as_default": bool(np.array_equal(res_s[0], res[0]) and np.array_equal(res_s[1]["points"], res[1]["points"])),
+                      "note": "sd_set_option('nms2d_strict', 1): every 2D pair decided by the Clipper-exact sweep (bit-exact by construction); the default decides "
+                              "pairs far from the threshold from an empirically / adversarially validated band around the exact area (DESIGN.md 3.4)"}
     out = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -661,7 +671,8 @@ def main():
                        "nms_thresh": model.thresholds.nms, "parallelism": "tiles-per-gpu x%d" % world},
             "stages_ms": stages, "roofline": dominant, "roofline_convs": roof_conv, "roofline_pair_kernel": roof_pair,
             "nms2d_strict": strict_leg,
-            "value_host_input": host_leg_dict(H * W, args.steps, elapsed_host, elapsed_host_serial, "Mpix/s", ms_per_step),
+            "value_host_input": (host_leg_dict(H * W, args.steps, host2d[0], host2d[1], "Mpix/s", ms_per_step) if host2d is not None
+                                 else {"value": None, "error": host2d_err}),
         }
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N=1 only
             try:
@@ -720,7 +731,7 @@ def main():
         macs3 = conv_macs_per_input_pixel(m3.net, m3.config)
         steps3 = max(1, min(args.steps, 5))
         elapsed3, net3_ms, res3, st3 = run_leg(m3, vol, steps3, 2, world, dist_)
-        eh3, eh3s = run_host_legs(m3, vol_np, steps3)
+        host3d, host3d_err = guarded(lambda: run_host_legs(m3, vol_np, steps3), "host-input leg (3D)")
         if rank == 0:
             s3 = st3.get("nms3d", np.zeros(16, np.int64)) / steps3
             ms3 = 1e3 * elapsed3 / steps3
@@ -730,7 +741,8 @@ def main():
                                        "the same step from a host numpy array in to (labels, dict) out, SURVEY.md 8d's definition")
             out["value_3d"] = round(world * S ** 3 * steps3 / elapsed3 / 1e6, 3)
             out["unit_3d"] = "Mvox/s"
-            out["value_host_input_3d"] = host_leg_dict(S ** 3, steps3, eh3, eh3s, "Mvox/s", ms3)
+            out["value_host_input_3d"] = (host_leg_dict(S ** 3, steps3, host3d[0], host3d[1], "Mvox/s", ms3) if host3d is not None
+                                          else {"value": None, "error": host3d_err})
             out["ms_per_step_3d"] = round(ms3, 3)
             out["config_3d"] = {"workload": "StarDist3D Rays_GoldenSpiral(96) U-Net (depth 2), %d^3 synthetic volume per GPU, predict_instances "
                                             "(U-Net + select + 3D NMS cascade + polyhedron raster + relabel)" % S,
