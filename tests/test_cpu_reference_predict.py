@@ -159,6 +159,21 @@ def test_predict_and_predict_sparse_equal_the_reference_methods(nd, kw, axes, sh
     if axes in ("YX", "ZYX"):
         assert np.array_equal(m.predict(img)[0], got[0])
 
+    # ---- a normaliser object (csbdeep's protocol: .before(x, axes) on the array laid out as the network wants it), and integer input
+    class Affine(object):
+        def before(self, x, axes):
+            assert axes == rcfg.axes
+            return (x.astype(np.float32) - np.float32(0.25)) * np.float32(1.5)
+    wn, gn = ref.predict(img, axes=axes, normalizer=Affine()), m.predict(img, axes=axes, normalizer=Affine())
+    assert all(np.abs(a - b).max() <= 2e-5 * max(1.0, float(np.abs(b).max())) for a, b in zip(gn, wn))
+    assert np.abs(wn[0] - want[0]).max() > 1e-4                                                          # (the normaliser did act)
+    img8 = (127.5 * (img + 1)).astype(np.uint8)
+    with pytest.warns(UserWarning, match="non-float input"):
+        w8 = ref.predict(img8, axes=axes)
+    with pytest.warns(UserWarning, match="non-float input"):
+        g8 = m.predict(img8, axes=axes)
+    assert all(np.abs(a - b).max() <= 1e-4 * max(1.0, float(np.abs(b).max())) for a, b in zip(g8, w8))
+
     # ---- predict_sparse: same candidates, row for row (np.where order), on a threshold no rounding can move a pixel across
     thr = _gap_threshold(want[0])
     m._select = _select_standin
