@@ -10,7 +10,12 @@ What it checks, for a registered 2D model (default `2D_versatile_fluo`, BASELINE
   3. instance parity: same number of instances, same points, labels identical (the NMS / rasteriser natives are pinned offline
      against the compiled reference; this is the end-to-end statement on real weights).
 
-usage:   python tools/verify_with_tf.py [--model 2D_versatile_fluo] [--image path.tif] [--device cuda:0]
+  4. (`--layer-order`, needs no weights) builds the reference's 3D ResNet (`Config3D(backbone="resnet", grid=(1,2,2))`, the 3D_demo
+     topology) in real Keras and prints the convolution layers in `model.layers` order -- the order `save_weights` writes: the offline
+     stand-in (tests/_mini_keras.py) derives that a strided block's 1x1x1 projection precedes the block's last body convolution; the
+     weight loader reads either order, this confirms which one real Keras produces.
+
+usage:   python tools/verify_with_tf.py [--model 2D_versatile_fluo] [--image path.tif] [--device cuda:0] [--layer-order]
 exit code 0 = all checks passed.  Nothing here is imported by the product or by the test suite."""
 import argparse
 import os
@@ -22,13 +27,35 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def layer_order():
+    try:
+        from stardist.models import Config3D, StarDist3D as RefStarDist3D
+    except ImportError as e:
+        print("this needs the reference stack (tensorflow, csbdeep, stardist): %r" % (e,))
+        return 2
+    ref = RefStarDist3D(Config3D(backbone="resnet", grid=(1, 2, 2), resnet_n_blocks=2, rays=16), name=None, basedir=None)
+    convs = [(l.name, tuple(l.kernel_size), tuple(l.strides)) for l in ref.keras_model.layers if hasattr(l, "kernel_size")]
+    for name, k, st in convs:
+        print("  %-16s kernel %s strides %s" % (name, k, st))
+    idx = {n: i for i, (n, _, _) in enumerate(convs)}
+    proj = [n for n, k, st in convs if k == (1, 1, 1) and st != (1, 1, 1)]
+    if proj:
+        body = [n for n, k, st in convs if k != (1, 1, 1) and idx[n] in (idx[proj[0]] - 1, idx[proj[0]] + 1)]
+        print("projection %s is listed %s its neighbour %s (tests/_mini_keras.py derives: BEFORE the block's last body convolution)"
+              % (proj[0], "before" if body and idx[proj[0]] < idx[body[-1]] else "after", body))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="2D_versatile_fluo")
     ap.add_argument("--image", default=None, help="default: the reference's tests/data/img2d.tif (stardist.data.test_image_nuclei_2d)")
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--tol", type=float, default=1e-5)
+    ap.add_argument("--layer-order", action="store_true", help="print model.layers' convolution order of a strided 3D ResNet and exit")
     args = ap.parse_args()
+    if args.layer_order:
+        return layer_order()
 
     try:
         from csbdeep.utils import normalize
