@@ -367,3 +367,67 @@ def test_bench_sharded_leg_plumbing_gloo_world2():
     assert len(d["per_rank"]) == 2 and all(p["blocks"] > 0 for p in d["per_rank"]) and d["blocks"] == sum(p["blocks"] for p in d["per_rank"]) == 16
     assert d["instances"] == d["_objects"] and d["band_survivors"] + d["interior_survivors"] == d["_objects"]
     assert d["gathered_bytes"] <= d["exact_record_bytes"] and d["value"] > 0 and "predicted_scaling" not in d
+
+
+def _sharded_worker_edge(rank, world, port_, q, case):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port_)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stardist_amd.big import predict_instances_sharded
+    from test_cpu_big import _FieldModel, _field
+    x, _ = _field()
+    if case == "background":
+        x = x.copy(); x[..., 0] = 0                                  # nothing above the threshold anywhere: zero candidates on every rank
+    elif case == "one_corner":
+        x = x.copy(); x[96:, :, 0] = 0; x[:, 112:, 0] = 0            # candidates in the first block only: the other ranks send nothing
+    m = _FieldModel()
+    block = 160 if case == "idle_rank" else 96                       # 160 -> 4 blocks for 6 ranks: two ranks own no block at all
+    labels, res = predict_instances_sharded(m, x, "YXC", block, 32, context=16)
+    tiles, _ = predict_instances_sharded(m, x, "YXC", block, 32, context=16, labels_out="local", broadcast_result=False)
+    st = dict(m._last_sharded_stats)
+    q.put((rank, labels, res["points"], [(bi, tuple((s.start, s.stop) for s in sl), t.numpy()) for bi, sl, t in tiles], st))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,world", [("background", 2), ("one_corner", 3), ("idle_rank", 6)])
+def test_sharded_gloo_degenerate_exchanges(refmods, case, world):
+    """the exchange when there is little or nothing to exchange: no candidate at all (every rank sends zero records, the final list is
+    empty, every tile is background), candidates in one block only (all but one rank send nothing; zero-size messages are never posted),
+    more ranks than blocks (ranks that own no block take part in every collective and render nothing)"""
+    import torch.multiprocessing as mp
+    m = _FieldModel()
+    x, lbl = _field()
+    if case == "background":
+        x = x.copy(); x[..., 0] = 0
+    elif case == "one_corner":
+        x = x.copy(); x[96:, :, 0] = 0; x[:, 112:, 0] = 0
+    p, d, pts = m.predict_sparse(x)
+    if len(p):
+        ref_labels, ref_res = m._instances_from_prediction(x.shape[:2], p, d, points=pts)
+    else:
+        ref_labels, ref_res = np.zeros(x.shape[:2], np.int32), dict(points=np.zeros((0, 2), np.int64))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port_ = 29700 + (os.getpid() + 7 * world) % 80
+    procs = [ctx.Process(target=_sharded_worker_edge, args=(r, world, port_, q, case)) for r in range(world)]
+    for pr in procs: pr.start()
+    out = [q.get(timeout=600) for _ in range(world)]
+    for pr in procs: pr.join(60)
+    seen = set()
+    for rank, lab, pts2, tiles, st in out:
+        assert np.array_equal(np.asarray(pts2).reshape(-1, 2), ref_res["points"]), (case, rank)
+        if rank == 0:
+            assert np.array_equal(lab, ref_labels)
+            assert st["instances"] == len(ref_res["points"])
+            if case == "background":
+                assert st["gathered"] == 0 and st["gathered_bytes"] == 0
+        else:
+            assert lab is None
+        if case == "idle_rank" and rank >= 4:
+            assert st["blocks"] == 0 and tiles == []
+        for bi, sl, t in tiles:
+            assert bi % world == rank and np.array_equal(t, ref_labels[tuple(slice(a, b) for a, b in sl)])
+            seen.add(bi)
+    assert len(seen) == (4 if case == "idle_rank" else 20)
