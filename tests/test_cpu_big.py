@@ -431,3 +431,124 @@ def test_sharded_gloo_degenerate_exchanges(refmods, case, world):
             assert bi % world == rank and np.array_equal(t, ref_labels[tuple(slice(a, b) for a, b in sl)])
             seen.add(bi)
     assert len(seen) == (4 if case == "idle_rank" else 20)
+
+
+# ---------------------------------------------------------------- design A in 3D on the CPU (the relabel of the owners' tiles needs a collective)
+class _FieldModel3D(object):
+    """3D twin of _FieldModel: 'network' = identity on a (Z, Y, X, 1 + n_rays) field; NMS and polyhedron rasteriser = the compiled reference
+    natives; the windowed raster hands back the polyhedra's running numbers (as the product's windowed native does) and the whole-volume
+    form closes the label ids up (model3d.py:646 relabel_sequential)"""
+    n_rays = 16
+
+    def __init__(self):
+        from stardist_amd.models.config import Config3D
+        from stardist_amd.rays3d import rays_from_json
+        self.config = Config3D(rays=self.n_rays, n_channel_in=1 + self.n_rays)
+        self.rays = rays_from_json(self.config.rays_json)
+
+        class T: prob, nms = 0.5, 0.3
+        self.thresholds = T()
+
+    def _axes_div_by(self, axes): return tuple(1 for a in axes)
+
+    def _axes_tile_overlap(self, axes): return tuple(0 for a in axes)
+
+    def predict_sparse(self, x, axes=None, prob_thresh=None, **kw):
+        from oracle import port
+        prob, dist = x[..., 0], x[..., 1:]
+        mask = port.ind_prob_thresh(prob, self.thresholds.prob if prob_thresh is None else prob_thresh, b=2)
+        return prob[mask], dist[mask], np.stack(np.where(mask), 1)
+
+    def _nms_sparse(self, dist, prob, points, nms_thresh=None, **kw):
+        from oracle import ref
+        ind = np.argsort(prob, kind="stable")[::-1]
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        keep = ref.stardist3d().c_non_max_suppression_inds(f32(dist[ind]), f32(points[ind]), f32(self.rays.vertices), np.ascontiguousarray(self.rays.faces, np.int32),
+                                                           f32(prob[ind]), 1, 1, 0, np.float32(self.thresholds.nms if nms_thresh is None else nms_thresh))
+        return ind[keep.astype(bool)]
+
+    def _raster(self, shape, p, d):
+        from oracle import ref
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        if len(p) == 0:
+            return np.zeros(shape, np.int32)
+        return ref.stardist3d().c_polyhedron_to_label(f32(d), f32(p), f32(self.rays.vertices), np.ascontiguousarray(self.rays.faces, np.int32),
+                                                      np.arange(1, len(p) + 1, dtype=np.int32), 0, 0, 0, 0, tuple(int(s) for s in shape))
+
+    def _instances_from_prediction(self, shape, prob, dist, points=None, **kw):
+        s = self._nms_sparse(dist, prob, points)
+        return self._instances_from_survivors(shape, points[s], prob[s], dist[s])
+
+    def _instances_from_survivors(self, shape, p, pr, d, return_labels=True, window=None, **kw):
+        from stardist_amd.matching import relabel_sequential
+        labels = self._raster(shape, p, d) if return_labels else None
+        if window is not None:
+            (z0, y0, x0), (nz, ny, nx) = window
+            return labels[z0:z0 + nz, y0:y0 + ny, x0:x0 + nx].copy(), None
+        if labels is not None:
+            labels = relabel_sequential(labels)[0]
+        return labels, dict(dist=d, points=p, prob=pr)
+
+
+def _field3d(n=72, seed=2):
+    from oracle import synth
+    m = _FieldModel3D()
+    d, p, s, _ = synth.s3d_nuclei(n, m.rays.vertices, spacing=24, R=(6, 9), rc=2, seed=seed)
+    x = np.zeros((n, n, n, 1 + m.n_rays), np.float32)
+    pi = p.astype(np.int64)
+    x[pi[:, 0], pi[:, 1], pi[:, 2], 0] = s
+    x[pi[:, 0], pi[:, 1], pi[:, 2], 1:] = d
+    return x
+
+
+def _sharded_worker3d(rank, world, port_, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port_)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stardist_amd.big import predict_instances_sharded
+    from test_cpu_big import _FieldModel3D, _field3d
+    x = _field3d()
+    m = _FieldModel3D()
+    labels, res = predict_instances_sharded(m, x, "ZYXC", 48, 16, context=8)
+    tiles, _ = predict_instances_sharded(m, x, "ZYXC", 48, 16, context=8, labels_out="local", broadcast_result=False)
+    q.put((rank, labels, res["points"], [(bi, tuple((s.start, s.stop) for s in sl), t.numpy()) for bi, sl, t in tiles], dict(m._last_sharded_stats)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_3d_equals_whole_volume_single_process_and_gloo_world2(refmods):
+    """design A in 3D: blocks of a 72^3 field of spheres -> local NMS (compiled reference) -> exchange -> cross-tile NMS -> owner-side windowed
+    rasters whose label ids are closed up over ALL ranks' tiles (one all_reduce(MAX) of the 'id is visible somewhere' table,
+    model3d.py:646 relabel_sequential on the whole volume): == predict_instances on the whole volume, in one process and over two gloo ranks"""
+    import torch.multiprocessing as mp
+    from stardist_amd.big import predict_instances_sharded
+    m = _FieldModel3D()
+    x = _field3d()
+    p, d, pts = m.predict_sparse(x)
+    ref_labels, ref_res = m._instances_from_prediction(x.shape[:3], p, d, points=pts)
+    assert len(ref_res["prob"]) >= 20 and ref_labels.max() <= len(ref_res["prob"])
+    labels, res = predict_instances_sharded(m, x, "ZYXC", 48, 16, context=8)
+    assert np.array_equal(res["points"], ref_res["points"]) and np.array_equal(labels, ref_labels)
+    st = m._last_sharded_stats
+    assert st["blocks"] == 27 and st["band"] > 0 and st["instances"] == len(ref_res["prob"])
+    tiles, _ = predict_instances_sharded(m, x, "ZYXC", 48, 16, context=8, labels_out="local")
+    assert len(tiles) == 27 and all(np.array_equal(t.numpy(), ref_labels[sl]) for _, sl, t in tiles)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port_ = 29800 + os.getpid() % 40
+    procs = [ctx.Process(target=_sharded_worker3d, args=(r, 2, port_, q)) for r in range(2)]
+    for pr in procs: pr.start()
+    out = [q.get(timeout=600) for _ in range(2)]
+    for pr in procs: pr.join(60)
+    seen = set()
+    for rank, lab, pts2, tiles2, st2 in out:
+        assert np.array_equal(pts2, ref_res["points"]), rank
+        assert (lab is None) == (rank != 0)
+        if rank == 0:
+            assert np.array_equal(lab, ref_labels)
+            assert st2["gathered"] == st["gathered"] and st2["band"] == st["band"]
+        for bi, sl, t in tiles2:
+            assert bi % 2 == rank and np.array_equal(t, ref_labels[tuple(slice(a, b) for a, b in sl)]), (rank, bi)
+            seen.add(bi)
+    assert seen == set(range(27))
