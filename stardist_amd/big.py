@@ -283,6 +283,66 @@ class BlockND(object):
         return tuple(BlockND(i, blocks, axes) for i, blocks in enumerate(product(*cover_1d)))
 
 
+def _clipped_box(lo, hi, shape_max):
+    """integer bounding intervals [floor(lo), ceil(hi)) per axis, clipped to [0, shape_max]: ((start, stop), ...)"""
+    lo = np.maximum(0, np.floor(lo)).astype(int)
+    hi = np.minimum(shape_max, np.ceil(hi)).astype(int)
+    return tuple((a, b) for a, b in zip(tuple(lo), tuple(hi)))
+
+
+class Polygon(object):
+    """One predicted polygon on its own bounding box (big.py:452-472): `bbox` ((y0, y1), (x0, x1)), `slice` into the image, `shape` of
+    the box, `coord` relative to the box, `mask` = the pixels the 2D rasteriser paints for it (the package's rasteriser native, pinned
+    to skimage.draw.polygon: DESIGN.md section 5)."""
+
+    def __init__(self, coord, bbox=None, shape_max=None):
+        self.bbox = self.coords_bbox(coord, shape_max=shape_max) if bbox is None else bbox
+        self.coord = coord - np.array([r[0] for r in self.bbox]).reshape(2, 1)
+        self.slice = tuple(slice(*r) for r in self.bbox)
+        self.shape = tuple(r[1] - r[0] for r in self.bbox)
+        from .geometry import polygons_to_label_coord
+        if min(self.shape) > 0:
+            self.mask = np.asarray(polygons_to_label_coord(np.ascontiguousarray(self.coord[np.newaxis]), self.shape)) > 0
+        else:
+            self.mask = np.zeros(self.shape, bool)
+
+    @staticmethod
+    def coords_bbox(*coords, shape_max=None):
+        """common bounding box of polygons given as (2, n) coordinate arrays"""
+        assert all(isinstance(c, np.ndarray) and c.ndim == 2 and c.shape[0] == 2 for c in coords)
+        every = np.concatenate(coords, axis=1)
+        return _clipped_box(every.min(axis=1), every.max(axis=1), (np.inf, np.inf) if shape_max is None else shape_max)
+
+
+class Polyhedron(object):
+    """One predicted polyhedron on its own bounding box (big.py:476-498): as Polygon, the mask by the 3D rasteriser."""
+
+    def __init__(self, dist, origin, rays, bbox=None, shape_max=None):
+        self.bbox = self.coords_bbox((dist, origin), rays=rays, shape_max=shape_max) if bbox is None else bbox
+        self.slice = tuple(slice(*r) for r in self.bbox)
+        self.shape = tuple(r[1] - r[0] for r in self.bbox)
+        from .geometry import polyhedron_to_label
+        local = origin.reshape(1, 3) - np.array([r[0] for r in self.bbox]).reshape(1, 3)
+        self.mask = np.asarray(polyhedron_to_label(dist[np.newaxis], local, rays, shape=self.shape, verbose=False)).astype(bool)
+
+    @staticmethod
+    def coords_bbox(*dist_origin, rays, shape_max=None):
+        """common bounding box of polyhedra given as (dist (n_rays,), origin (3,)) pairs"""
+        dists, points = zip(*dist_origin)
+        assert all(isinstance(d, np.ndarray) and d.ndim == 1 and len(d) == len(rays) for d in dists)
+        assert all(isinstance(p, np.ndarray) and p.ndim == 1 and len(p) == 3 for p in points)
+        verts = np.stack(dists)[..., np.newaxis] * rays.vertices[np.newaxis] + np.stack(points)[:, np.newaxis]      # (m, n_rays, 3)
+        verts = verts.reshape(-1, 3)
+        return _clipped_box(verts.min(axis=0), verts.max(axis=0), (np.inf, np.inf, np.inf) if shape_max is None else shape_max)
+
+
+def predict_big(model, *args, **kwargs):
+    """big.py:596-602: the old entry point only tells where the function went"""
+    from .models import StarDist2D, StarDist3D
+    dst = type(model).__name__ if isinstance(model, (StarDist2D, StarDist3D)) else "{StarDist2D, StarDist3D}"
+    raise RuntimeError("This function has moved to %s.predict_instances_big." % dst)
+
+
 def relabel_with_offset(labels, offset):
     from .matching import relabel_sequential
     return relabel_sequential(labels, offset)[0]

@@ -14,6 +14,14 @@ def _is_t(x):
     return N.is_torch(x)
 
 
+def _as_arrays(*xs):
+    """np.asarray of every argument, as the reference's entry points do first (lists of rows are legal input there: nms.py:156-158,
+    303-305) -- unless the caller works with device tensors, which pass through untouched"""
+    if any(_is_t(x) for x in xs):
+        return xs
+    return tuple(np.asarray(x) for x in xs)
+
+
 def _ind_prob_thresh(prob, prob_thresh, b=2):
     """stardist/nms.py:6-17"""
     if b is not None and np.isscalar(b):
@@ -120,6 +128,7 @@ def non_maximum_suppression(dist, prob, grid=(1, 1), b=2, nms_thresh=0.5, prob_t
 
 def non_maximum_suppression_sparse(dist, prob, points, b=2, nms_thresh=0.5, use_bbox=True, use_kdtree=True, verbose=False):
     """stardist/nms.py:135-183: candidate lists -> (points, prob, dist, inds) of survivors."""
+    dist, prob, points = _as_arrays(dist, prob, points)
     assert dist.ndim == 2 and prob.ndim == 1 and points.ndim == 2 and points.shape[-1] == 2 and \
         len(prob) == len(dist) == len(points)
     _sorted = _argsort_desc(prob)
@@ -221,6 +230,7 @@ def non_maximum_suppression_3d(dist, prob, rays, grid=(1, 1, 1), b=2, nms_thresh
 
 def non_maximum_suppression_3d_sparse(dist, prob, points, rays, b=2, nms_thresh=0.5, use_kdtree=True, verbose=False):
     """stardist/nms.py:285-324"""
+    dist, prob, points = _as_arrays(dist, prob, points)
     assert dist.ndim == 2 and prob.ndim == 1 and points.ndim == 2 and dist.shape[-1] == len(rays) and \
         points.shape[-1] == 3 and len(prob) == len(dist) == len(points)
     _sorted = _argsort_desc(prob)
