@@ -134,3 +134,24 @@ def test_model_layers_order_of_a_strided_resnet_block(ref_rays):
         assert convs[:4] == ["conv3d", "conv3d_1", "conv3d_2", "conv3d_3"]
         assert convs[4:6] == (["conv3d_5", "conv3d_4"] if shortcut_first else ["conv3d_4", "conv3d_5"])
         assert convs[6:] == ["conv3d_6", "conv3d_7", "conv3d_8", "features", "prob", "dist"]
+
+
+@pytest.mark.parametrize("path,nd,shape", [("models/examples/2D_demo/config.json", 2, (32, 48)), ("models/paper/2D_dsb2018/config.json", 2, (32, 32)),
+                                           ("models/examples/3D_demo/config.json", 3, (6, 12, 16))])
+def test_the_reference_s_own_model_configurations_build_the_same_network(path, nd, shape, ref_rays):
+    """the config.json files the reference ships (2D_demo, the paper's 2D_dsb2018, 3D_demo = the ResNet with the strided (1,2,2) block) at
+    their full widths: reference Config(**json) -> reference _build over the stand-in Keras -> variables in save_weights order -> the
+    mirror built from the same file (Config.from_json) -> same outputs"""
+    import json
+    from stardist_amd.models import Config2D, Config3D, StarDist2D, StarDist3D
+    full = os.path.join(os.path.dirname(REF), path)
+    d = json.load(open(full))
+    R2, R3 = _ref_configs(ref_rays)
+    rcfg = (R2 if nd == 2 else R3)(**d)
+    model = reference_graph(nd, rcfg)
+    x = np.random.RandomState(9).uniform(-1, 1, shape + (rcfg.n_channel_in,))
+    want = model.predict(x)
+    got = mirror_outputs(StarDist2D if nd == 2 else StarDist3D, (Config2D if nd == 2 else Config3D).from_json(full), model.weights_in_file_order(), x)
+    assert len(got) == len(want) == 2
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max())
