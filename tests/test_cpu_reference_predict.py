@@ -188,6 +188,18 @@ def test_predict_and_predict_sparse_equal_the_reference_methods(nd, kw, axes, sh
         # every point lies on the grid, inside the un-padded image (resizer.filter_points), off the border by b grid steps
         assert all((ws[-1][:, d] % rcfg.grid[d] == 0).all() for d in range(nd))
 
+    # ---- the mirror's TILED sparse prediction (its own tile iterator; csbdeep's is absent, the reference's tiled branch cannot run here)
+    # against the reference's UNTILED candidates: same points, same values -- tile offsets, the per-tile border rule (base.py:583-584: the
+    # border of b pixels only where a tile touches the image border), the grid and the crop of the padded part
+    nt = tuple(1 if a == "C" else (2 if img.shape[i] >= 24 else 1) for i, a in enumerate(axes))
+    if int(np.prod(nt)) > 1:
+        ws = ref.predict_sparse(img, prob_thresh=thr, axes=axes, b=2)
+        gs = m.predict_sparse(img, prob_thresh=thr, axes=axes, b=2, n_tiles=nt)
+        order_w, order_g = np.lexsort(ws[-1].T[::-1]), np.lexsort(np.asarray(gs[-1]).T[::-1])
+        assert np.array_equal(np.asarray(gs[-1])[order_g], ws[-1][order_w]), (nt, len(gs[-1]), len(ws[-1]))
+        for a, w in zip(gs[:-1], ws[:-1]):
+            assert np.abs(np.asarray(a)[order_g] - w[order_w]).max() <= 2e-5 * max(1.0, float(np.abs(w).max()))
+
     # ---- refusals of _predict_setup (base.py:373-391)
     for bad in (dict(n_tiles=(1,) * (img.ndim + 1)), dict(n_tiles=(0,) * img.ndim), dict(n_tiles=(1.5,) + (1,) * (img.ndim - 1))):
         with pytest.raises(ValueError):
