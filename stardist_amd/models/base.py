@@ -98,21 +98,52 @@ class StarDistBase(object):
 
     def __init__(self, config, name=None, basedir=".", device=None, seed=0, compute_dtype="float32"):
         import torch
-        self.name = name
+        # the model folder, as csbdeep's BaseModel keeps it (csbdeep/models/base_model.py __init__ / _set_logdir; stardist/models/base.py:230-253):
+        #   config given + basedir: <basedir>/<name> is created (a warning if it exists) and config.json written -- no weights are read;
+        #   config None: config.json, thresholds.json and the weights of <basedir>/<name> are loaded; name None: a time stamp;
+        #   basedir None: nothing touches the disk.
+        if not (name is None or (isinstance(name, str) and len(name) > 0)):
+            raise ValueError("No valid name: '%s'" % str(name))
+        from_disk = config is None
+        if name is None and (from_disk or basedir is None):
+            self.name = None
+        else:
+            import datetime
+            self.name = name if name is not None else datetime.datetime.now().strftime("%Y-%m-%d-%H-%M-%S.%f")
         self.basedir = basedir
-        self.logdir = None if basedir is None else os.path.join(str(basedir), name if name is not None else "stardist_amd")
-        if config is None:
+        self.logdir = None if basedir is None else os.path.join(str(basedir), self.name if self.name is not None else "stardist_amd")
+        if from_disk:
             if self.logdir is None or not os.path.exists(os.path.join(self.logdir, "config.json")):
-                raise FileNotFoundError("config file doesn't exist: %s" % (None if self.logdir is None else os.path.join(self.logdir, "config.json")))
+                raise FileNotFoundError("config file doesn't exist: %s" % (None if self.logdir is None else os.path.abspath(os.path.join(self.logdir, "config.json"))))
             config = self._config_class.from_json(os.path.join(self.logdir, "config.json"))
+        elif self.logdir is not None:
+            if os.path.exists(self.logdir):
+                warnings.warn("output path for model already exists, files may be overwritten: %s" % os.path.abspath(self.logdir))
+            os.makedirs(self.logdir, exist_ok=True)
+            with open(os.path.join(self.logdir, "config.json"), "w") as fh:
+                fh.write(config.to_json())
         self.config = config
         threshs = dict(prob=None, nms=None)
-        if self.logdir is not None and os.path.exists(os.path.join(self.logdir, "thresholds.json")):
-            threshs = json.load(open(os.path.join(self.logdir, "thresholds.json")))
-            if threshs.get("prob") is None or not (0 < threshs.get("prob") < 1): threshs["prob"] = None
-            if threshs.get("nms") is None or not (0 < threshs.get("nms") < 1): threshs["nms"] = None
+        if self.logdir is not None:
+            try:
+                with open(os.path.join(self.logdir, "thresholds.json")) as fh:
+                    threshs = json.load(fh)
+                print("Loading thresholds from 'thresholds.json'.")
+                if threshs.get("prob") is None or not (0 < threshs.get("prob") < 1):
+                    print("- Invalid 'prob' threshold (%s), using default value." % str(threshs.get("prob")))
+                    threshs["prob"] = None
+                if threshs.get("nms") is None or not (0 < threshs.get("nms") < 1):
+                    print("- Invalid 'nms' threshold (%s), using default value." % str(threshs.get("nms")))
+                    threshs["nms"] = None
+            except FileNotFoundError:
+                import glob
+                if from_disk and len(glob.glob(os.path.join(self.logdir, "*.h5"))) > 0:
+                    print("Couldn't load thresholds from 'thresholds.json', using default values. "
+                          "(Call 'optimize_thresholds' to change that.)")
         self.thresholds = dict(prob=0.5 if threshs["prob"] is None else threshs["prob"],
                                nms=0.4 if threshs["nms"] is None else threshs["nms"])
+        if self.logdir is not None:      # (the reference prints this line for every model; kept to folder models: bench / library use stays silent)
+            print("Using default values: prob_thresh={prob:g}, nms_thresh={nms:g}.".format(prob=self.thresholds.prob, nms=self.thresholds.nms))
         self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
         if compute_dtype != "float32":
             # (rounds 1-3 offered bfloat16 / float16 autocast through the framework's library kernels; the prediction path is float32
@@ -122,16 +153,8 @@ class StarDistBase(object):
         self.net = self._build()
         from .unet import init_he_normal_
         init_he_normal_(self.net, seed)
-        if self.logdir is not None:
-            # model folder weights, 'best' before 'last' before 'now' as csbdeep's _find_and_load_weights(prefer='best'); per name the
-            # converted .npz (tools/keras_to_npz.py / save_weights_npz) before the Keras .h5 (needs h5py)
-            for stem in ("weights_best", "weights_last", "weights_now", "weights"):
-                if os.path.exists(os.path.join(self.logdir, stem + ".npz")):
-                    self.load_weights_npz(os.path.join(self.logdir, stem + ".npz"))
-                    break
-                if os.path.exists(os.path.join(self.logdir, stem + ".h5")):
-                    self.load_weights_h5(os.path.join(self.logdir, stem + ".h5"))
-                    break
+        if from_disk:
+            self._find_and_load_weights()
         self.net = self.net.to(self.device).eval()
         if self.device.type == "cuda":
             self.net = self.net.to(memory_format=torch.channels_last if config.n_dim == 2 else torch.channels_last_3d)
@@ -172,6 +195,39 @@ class StarDistBase(object):
         folder = pretrained.get_model_folder(cls.__name__, name_or_alias)
         print("Found model '%s' for '%s'." % (os.path.basename(folder), cls.__name__))
         return cls(config=None, name=os.path.basename(folder), basedir=os.path.dirname(folder), **kwargs)
+
+    def _find_and_load_weights(self, prefer="best"):
+        """csbdeep BaseModel._find_and_load_weights: of the weight files in the model folder (*.h5 / *.hdf5 Keras files, and the *.npz this
+        package converts them to: tools/keras_to_npz.py, save_weights_npz) the newest one whose name contains `prefer`, else the newest"""
+        import glob
+        files = [f for ext in ("*.h5", "*.hdf5", "weights*.npz") for f in glob.glob(os.path.join(self.logdir, ext))]
+        # newest first; of two files of one time stamp the converted .npz goes first (it needs no HDF5 reader)
+        files.sort(key=lambda f: (-os.stat(f).st_mtime, not f.endswith(".npz"), f))
+        if not files:
+            warnings.warn("Couldn't find any network weights (*.h5, *.hdf5) to load.")
+            return
+        preferred = [f for f in files if prefer in os.path.basename(f)]
+        # a converted copy stands for its Keras file whatever their time stamps: weights_best.npz next to weights_best.h5
+        chosen = preferred[0] if preferred else files[0]
+        twin = os.path.splitext(chosen)[0] + ".npz"
+        if not chosen.endswith(".npz") and os.path.exists(twin):
+            chosen = twin
+        print("Loading network weights from '%s'." % os.path.basename(chosen))
+        self.load_weights(os.path.basename(chosen))
+
+    def load_weights(self, name="weights_best.h5"):
+        """csbdeep BaseModel.load_weights: the weights file `name` of the model folder -- Keras HDF5 (`weights_best.h5`, ...) or the
+        converted `.npz`.  Without a model folder (basedir=None) a warning is given and nothing happens, as there."""
+        if self.logdir is None:
+            warnings.warn("Suppressing call of 'load_weights' (due to basedir=None).")
+            return
+        path = os.path.join(self.logdir, str(name))
+        if not os.path.exists(path):
+            raise FileNotFoundError("weights file doesn't exist: %s" % os.path.abspath(path))
+        if path.endswith(".npz"):
+            self.load_weights_npz(path)
+        else:
+            self.load_weights_h5(path)
 
     def load_weights_h5(self, path):
         """Keras HDF5 weights of a csbdeep model folder (needs h5py): converted in memory to the .npz layout, then loaded by name"""
@@ -280,6 +336,11 @@ class StarDistBase(object):
                     if tuple(v.shape) != tuple(attr.shape):
                         raise ValueError("%s%s does not fit its layer" % (base, suffix))
                     attr.copy_(torch.from_numpy(v))
+        # captured forward passes hold the packed form of the OLD kernels (the packed tensors are re-made when a parameter changes,
+        # models/unet.py _packed_conv_weights); the layers' range fallbacks were decided on the old weights as well
+        self.__dict__.pop("_graphs", None)
+        for mod in self.net.modules():
+            mod.__dict__.pop("_sd_force_form", None)
 
     # ------------------------------------------------------------------ helpers
     def _guess_n_tiles(self, img):

@@ -108,3 +108,57 @@ def test_keras_h5_weights_read_without_h5py(cls_name, key, tmp_path):
     prob, dist = m.predict(e["x"])[:2]
     assert np.abs(prob - e["prob"]).max() <= 2e-6
     assert np.abs(dist - np.maximum(e["dist"], 1e-3)).max() <= 2e-5 * max(1.0, float(np.abs(e["dist"]).max()))
+
+
+def test_model_folder_semantics_follow_csbdeep_basemodel(tmp_path, capsys):
+    """csbdeep BaseModel.__init__ / _set_logdir / _find_and_load_weights / load_weights + stardist/models/base.py:230-253 (restated: csbdeep is
+    absent): a model built from a configuration creates <basedir>/<name>/config.json and reads no weights; built with config=None it
+    reads config.json, thresholds.json and the preferred ('best', else the newest) weights file; load_weights(name) switches files"""
+    import json
+    import time
+    import warnings
+    import torch
+    from stardist_amd.models import Config2D, StarDist2D
+    cfg = Config2D(n_rays=8, unet_n_depth=1, unet_n_filter_base=4, net_conv_after_unet=8, grid=(2, 2))
+    base = str(tmp_path)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                  # a fresh folder: no warning
+        a = StarDist2D(cfg, name="m", basedir=base, device="cpu", seed=1)
+    assert a.name == "m" and os.path.samefile(a.logdir, os.path.join(base, "m"))
+    assert json.load(open(os.path.join(base, "m", "config.json"))) == json.loads(cfg.to_json())
+    a.save_weights_npz(os.path.join(a.logdir, "weights_now.npz"))
+    time.sleep(0.02)
+    b = StarDist2D(cfg, name=None, basedir=base, device="cpu", seed=2)      # name None: a time stamp (csbdeep), its own folder
+    assert b.name is not None and b.name != "m" and os.path.exists(os.path.join(base, b.name, "config.json"))
+    b.save_weights_npz(os.path.join(a.logdir, "weights_last.npz"))          # the NEWER file of folder m holds b's weights
+    with pytest.warns(UserWarning, match="already exists"):
+        c = StarDist2D(cfg, name="m", basedir=base, device="cpu", seed=3)   # config given: the folder's weights are NOT read
+    wa, wb, wc = (m.net.prob.weight.detach().clone() for m in (a, b, c))
+    assert not torch.equal(wc, wa) and not torch.equal(wc, wb)
+    capsys.readouterr()
+    d = StarDist2D(None, name="m", basedir=base, device="cpu", seed=4)      # no 'best' file: the newest one
+    out = capsys.readouterr().out
+    assert "Loading network weights from 'weights_last.npz'." in out and "Using default values: prob_thresh=0.5, nms_thresh=0.4." in out
+    assert torch.equal(d.net.prob.weight, wb) and tuple(d.config.grid) == (2, 2)
+    d.load_weights("weights_now.npz")
+    assert torch.equal(d.net.prob.weight, wa)
+    with pytest.raises(FileNotFoundError):
+        d.load_weights("weights_best.h5")
+    c.save_weights_npz(os.path.join(a.logdir, "weights_best.npz"))
+    os.utime(os.path.join(a.logdir, "weights_best.npz"), (1, 1))            # the oldest file -- but the preferred name
+    json.dump(dict(prob=0.62, nms=1.5), open(os.path.join(a.logdir, "thresholds.json"), "w"))
+    e = StarDist2D(None, name="m", basedir=base, device="cpu")
+    out = capsys.readouterr().out
+    assert "Loading network weights from 'weights_best.npz'." in out and "Loading thresholds from 'thresholds.json'." in out
+    assert "- Invalid 'nms' threshold (1.5), using default value." in out and "prob_thresh=0.62, nms_thresh=0.4" in out
+    assert torch.equal(e.net.prob.weight, wc) and e.thresholds.prob == 0.62 and e.thresholds.nms == 0.4
+    # no folder: nothing is written, load_weights only warns; no configuration and no folder: an error
+    f = StarDist2D(cfg, basedir=None, device="cpu")
+    assert f.logdir is None
+    with pytest.warns(UserWarning, match="basedir=None"):
+        f.load_weights()
+    with pytest.raises(FileNotFoundError):
+        StarDist2D(None, name="absent", basedir=base, device="cpu")
+    with pytest.raises(ValueError):
+        StarDist2D(cfg, name="", basedir=None, device="cpu")
+    assert sorted(os.listdir(base)) == sorted(["m", b.name])
