@@ -12,9 +12,23 @@ class BaseConfig(object):
     """csbdeep.models.BaseConfig surface used by the reference: attribute bag + update_parameters."""
 
     def __init__(self, axes, n_channel_in, n_channel_out):
+        # csbdeep BaseConfig.__init__: axes out of STCZYX without repeats, X and Y present, Z and T not together, a sample axis first
+        # (and dropped), the channel axis last (channels_last is the one backend layout: models/__init__.py:8-14) and added when absent
         axes = str(axes).upper()
-        if "C" not in axes:
-            axes = axes + "C"                      # channels_last only (models/__init__.py:8-14)
+        if any(a not in "STCZYX" for a in axes) or any(axes.count(a) > 1 for a in axes):
+            raise ValueError("invalid axes '%s': every axis must be one of 'STCZYX' and occur once" % axes)
+        if not ("X" in axes and "Y" in axes):
+            raise ValueError("lateral axes X and Y must be present.")
+        if "Z" in axes and "T" in axes:
+            raise ValueError("using Z and T axes together not supported.")
+        if "S" in axes and not axes.startswith("S"):
+            raise ValueError("sample axis S must be first.")
+        axes = axes.replace("S", "")
+        if "C" in axes:
+            if axes[-1] != "C":
+                raise ValueError("channel axis must be last for backend (channels_last).")
+        else:
+            axes = axes + "C"
         self.n_dim = len(axes) - 1
         self.axes = axes
         self.n_channel_in = int(max(1, n_channel_in))
@@ -55,6 +69,19 @@ class BaseConfig(object):
         if not len(self.train_class_weights) == (2 if self.n_classes is None else self.n_classes + 1):
             raise ValueError("train_class_weights %s not compatible with n_classes (%s): must be 'n_classes + 1' weights if n_classes is not None, otherwise 2"
                              % (self.train_class_weights, self.n_classes))
+
+    def is_valid(self, return_invalid=False):
+        """csbdeep BaseConfig.is_valid: the base schema has nothing to refuse (the constructors above raise instead)"""
+        return (True, tuple()) if return_invalid else True
+
+    def __repr__(self):
+        """argparse.Namespace's, which csbdeep's BaseConfig inherits: ClassName(key=value, ...) in attribute order"""
+        return "%s(%s)" % (type(self).__name__, ", ".join("%s=%r" % kv for kv in vars(self).items()))
+
+    def __eq__(self, other):
+        return isinstance(other, BaseConfig) and vars(self) == vars(other)
+
+    __hash__ = None
 
     def update_parameters(self, allow_new=False, **kwargs):
         if not allow_new:

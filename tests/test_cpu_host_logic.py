@@ -325,3 +325,17 @@ def test_predict_instances_scale_zooms_the_input_and_hands_the_scale_on(monkeypa
         m.predict_instances(img, scale=(1, 1))
     with pytest.raises(ValueError):
         m.predict_instances(img, scale=(0, 1, 1))
+
+
+def test_config_axes_rules_and_namespace_behaviour_of_csbdeep_baseconfig():
+    """csbdeep BaseConfig (restated; absent offline): axes rules, is_valid, the argparse.Namespace repr / equality the reference's
+    configurations inherit"""
+    from stardist_amd.models import Config2D, Config3D
+    for cls, bad in ((Config2D, "CYX"), (Config2D, "YZ"), (Config2D, "XYQ"), (Config3D, "TZYX"), (Config2D, "YXS"), (Config2D, "YYX")):
+        with pytest.raises(ValueError):
+            cls(axes=bad)
+    assert Config2D(axes="SYX").axes == "YXC" and Config2D(axes="yxc").axes == "YXC" and Config3D(axes="ZYX").axes == "ZYXC"
+    a = Config2D(n_rays=8)
+    assert a.is_valid() is True and a.is_valid(return_invalid=True) == (True, ())
+    assert a == Config2D(n_rays=8) and a != Config2D(n_rays=16) and a != object()
+    assert repr(a).startswith("Config2D(n_dim=2, axes='YXC', n_channel_in=1, n_channel_out=9, ")
