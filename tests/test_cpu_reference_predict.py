@@ -212,7 +212,7 @@ def test_predict_and_predict_sparse_equal_the_reference_methods(nd, kw, axes, sh
                                    (2, dict(S2, grid=(4, 2), unet_n_depth=1)), (2, dict(S2, grid=(1, 4), unet_n_depth=1)),
                                    (3, dict(S3, unet_n_depth=1)), (3, dict(S3, unet_n_depth=1, grid=(1, 2, 2))),
                                    (3, dict(rays=8, backbone="resnet", resnet_n_filter_base=4, net_conv_after_resnet=8, resnet_n_blocks=2)),
-                                   (3, dict(rays=8, backbone="resnet", resnet_n_filter_base=4, net_conv_after_resnet=8, resnet_n_blocks=3, grid=(1, 2, 2)))])
+                                   (3, dict(rays=8, backbone="resnet", resnet_n_filter_base=2, net_conv_after_resnet=4, resnet_n_blocks=2, grid=(1, 2, 2)))])
 def test_tile_overlap_covers_the_receptive_field_the_reference_measures(nd, kw, ref_rays):
     """the reference measures the receptive field of the built network by an impulse response (base.py:1068-1098) and tiles with that
     overlap; the mirror uses the analytic radius of the layer stack (an upper bound: DESIGN.md section 4) -- it must never be smaller, and
