@@ -103,8 +103,11 @@ class BaseConfig(object):
 
     @classmethod
     def from_json(cls, path_or_dict):
-        d = path_or_dict if isinstance(path_or_dict, dict) else json.load(open(path_or_dict))
-        d = dict(d)
+        if isinstance(path_or_dict, dict):
+            d = dict(path_or_dict)
+        else:
+            with open(path_or_dict) as fh:
+                d = dict(json.load(fh))
         init_keys = {k: d.pop(k) for k in list(d) if k in ("axes", "n_rays", "n_channel_in", "grid", "n_classes", "backbone", "rays", "anisotropy")}
         if "rays_json" in d and "rays" not in init_keys and cls.__name__ == "Config3D":
             from ..rays3d import rays_from_json
