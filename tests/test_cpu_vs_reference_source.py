@@ -903,3 +903,99 @@ def test_label_image_helpers_equal_the_reference_functions():
         np.random.seed(3); a = U.sample_points(25, mask, **kw)
         np.random.seed(3); b = ns["sample_points"](25, mask, **kw)
         assert a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b), sorted(kw)
+
+
+def test_matching_metrics_equal_the_reference_module(monkeypatch):
+    """stardist/matching.py (metrics: out of the hot path, kept for code written against the module) loaded as a module -- numba's jit
+    stood in for by the identity, skimage / csbdeep by stubs -- against stardist_amd.matching: label_overlap, the three criteria,
+    matching (scalar / several thresholds, report_matches, non-sequential ids, empty images), matching_dataset (summed and by_image)"""
+    import stardist_amd.matching as mine
+    stubs = {"numba": types.ModuleType("numba"), "skimage": types.ModuleType("skimage"), "skimage.measure": types.ModuleType("skimage.measure"),
+             "csbdeep": types.ModuleType("csbdeep"), "csbdeep.utils": types.ModuleType("csbdeep.utils")}
+    stubs["numba"].jit = lambda *a, **k: (lambda f: f)
+    def regionprops(y):                                                # the two attributes the reference reads: .label, .slice (ascending labels)
+        from scipy.ndimage import find_objects
+        return [types.SimpleNamespace(label=i, slice=sl) for i, sl in enumerate(find_objects(y), 1) if sl is not None]
+    stubs["skimage.measure"].regionprops = regionprops
+    stubs["csbdeep.utils"]._raise = _raise
+    for k, v in stubs.items():
+        monkeypatch.setitem(sys.modules, k, v)
+    spec = importlib.util.spec_from_file_location("_ref_matching", os.path.join(REF, "matching.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    rng = np.random.RandomState(17)
+
+    def blobs(shape, n, ids):
+        y = np.zeros(shape, np.int32)
+        for k in range(n):
+            c = [rng.randint(0, s) for s in shape]
+            r = rng.randint(2, 7)
+            sl = tuple(slice(max(0, ci - r), ci + r) for ci in c)
+            y[sl] = ids[k]
+        return y
+
+    def same(a, b, tag):
+        assert type(a).__name__ == type(b).__name__ and a._fields == b._fields, (tag, a._fields, b._fields)
+        for f, x, y in zip(a._fields, a, b):
+            if isinstance(y, tuple):
+                assert len(x) == len(y) and all(np.allclose(u, v) for u, v in zip(x, y)), (tag, f)
+            elif isinstance(y, str) or isinstance(y, bool):
+                assert x == y, (tag, f)
+            else:
+                assert np.isclose(x, y, rtol=1e-6, atol=0) and type(x) == type(y), (tag, f, x, y, type(x), type(y))
+    pairs = []
+    for it in range(12):
+        shape = (40, 48) if it % 3 else (12, 20, 16)
+        nt, npred = rng.randint(0, 9), rng.randint(0, 9)
+        yt = blobs(shape, nt, rng.permutation(np.arange(1, 40))[:nt] if it % 2 else np.arange(1, nt + 1))
+        yp = blobs(shape, npred, rng.permutation(np.arange(1, 40))[:npred])
+        if it % 4 == 1 and nt:
+            yp = np.where(rng.uniform(size=shape) < 0.7, yt, yp).astype(np.int32)      # a prediction that mostly agrees
+        pairs.append((yt, yp))
+        if yt.max() > 0 and yp.max() > 0:
+            a, b = mine.relabel_sequential(yt)[0], mine.relabel_sequential(yp)[0]
+            ov = ref.label_overlap(a, b)
+            assert np.array_equal(mine.label_overlap(a, b), ov) and mine.label_overlap(a, b).dtype == ov.dtype
+            for name in ("intersection_over_union", "intersection_over_true", "intersection_over_pred"):
+                x, y = getattr(mine, name)(ov), getattr(ref, name)(ov)
+                assert x.dtype == y.dtype and np.array_equal(x, y), name
+        for crit in ("iou", "iot", "iop"):
+            for rm in (False, True):
+                same(mine.matching(yt, yp, thresh=0.5, criterion=crit, report_matches=rm), ref.matching(yt, yp, thresh=0.5, criterion=crit, report_matches=rm), (it, crit, rm))
+        for x, y in zip(mine.matching(yt, yp, thresh=(0.1, 0.5, 0.9)), ref.matching(yt, yp, thresh=(0.1, 0.5, 0.9))):
+            same(x, y, (it, "thresholds"))
+    two = [p for p in pairs if p[0].ndim == 2]
+    for by_image in (False, True):
+        for thr in (0.5, (0.3, 0.7)):
+            a = mine.matching_dataset([p[0] for p in two], [p[1] for p in two], thresh=thr, by_image=by_image, show_progress=False)
+            b = ref.matching_dataset([p[0] for p in two], [p[1] for p in two], thresh=thr, by_image=by_image, show_progress=False)
+            for x, y in zip(a if isinstance(thr, tuple) else (a,), b if isinstance(thr, tuple) else (b,)):
+                same(x, y, ("dataset", by_image, thr))
+    for bad in (dict(criterion="dice"),):
+        with pytest.raises(ValueError):
+            mine.matching(pairs[0][0], pairs[0][1], **bad)
+        with pytest.raises(ValueError):
+            ref.matching(pairs[0][0], pairs[0][1], **bad)
+    for fn in (mine.matching, ref.matching):
+        with pytest.raises(ValueError):
+            fn(pairs[0][0].astype(np.float32), pairs[0][1])
+        with pytest.raises(ValueError):
+            fn(pairs[0][0], pairs[0][1][:-1])
+    assert all(mine.label_are_sequential(y) == ref.label_are_sequential(y) for p in pairs for y in p)
+    # group_matching_labels (a moving scene: frame k + 1 = frame k rolled, one object dropped, ids shuffled), _shuffle_labels (same random state)
+    base = blobs((48, 56), 7, np.arange(1, 8))
+    frames = [base]
+    for k in range(3):
+        nxt = np.roll(frames[-1], 2, axis=1).copy()
+        nxt[nxt == (k + 2)] = 0
+        np.random.seed(k); a = mine._shuffle_labels(nxt)
+        np.random.seed(k); b = ref._shuffle_labels(nxt)
+        assert np.array_equal(a, b) and a.dtype == b.dtype
+        frames.append(a)
+    for ys in (frames, np.stack(frames)):
+        ga, gb = mine.group_matching_labels(ys), ref.group_matching_labels(ys)
+        assert ga.dtype == gb.dtype == np.int32 and np.array_equal(ga, gb)
+    with pytest.raises(ValueError):
+        mine.group_matching_labels(frames[:1])
+    for t in ((5, 1, 2), (0, 3, 4), (7, 0, 0)):
+        assert all(getattr(mine, f)(*t) == getattr(ref, f)(*t) for f in ("precision", "recall", "accuracy", "f1"))
