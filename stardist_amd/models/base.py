@@ -196,6 +196,37 @@ class StarDistBase(object):
         print("Found model '%s' for '%s'." % (os.path.basename(folder), cls.__name__))
         return cls(config=None, name=os.path.basename(folder), basedir=os.path.dirname(folder), **kwargs)
 
+    def optimize_thresholds(self, X_val, Y_val, nms_threshs=[0.3, 0.4, 0.5], iou_threshs=[0.3, 0.5, 0.7], predict_kwargs=None, optimize_kwargs=None,
+                            save_to_json=True):
+        """Tune (prob_thresh, nms_thresh) on validation images X_val (normalised) with label images Y_val: for every nms threshold the
+        prob threshold that maximises the matching score (stardist_amd.utils.optimize_threshold), the best pair becomes self.thresholds and
+        is written to the model folder's thresholds.json -- the file later constructions read (base.py:986-1044).  Host-side tool around
+        the prediction natives; returns dict(prob=..., nms=...)."""
+        import sys
+        from ..utils import optimize_threshold
+        predict_kwargs = {} if predict_kwargs is None else predict_kwargs
+        optimize_kwargs = {} if optimize_kwargs is None else optimize_kwargs
+
+        def kwargs_for(x):
+            if "n_tiles" in predict_kwargs:
+                return predict_kwargs
+            return dict(predict_kwargs, n_tiles=self._guess_n_tiles(x), show_tile_progress=False)
+        Yhat_val = [self.predict(x, **kwargs_for(x))[:2] for x in X_val]           # (prob, dist) also of a multi-class model
+        best = (None, -np.inf, None)
+        for nms in nms_threshs:
+            prob, value = optimize_threshold(Y_val, Yhat_val, model=self, nms_thresh=nms, iou_threshs=iou_threshs, **optimize_kwargs)
+            if value > best[1]:
+                best = (prob, value, nms)
+        opt_threshs = dict(prob=best[0], nms=best[2])
+        self.thresholds = opt_threshs
+        print(end="", file=sys.stderr, flush=True)
+        print("Using optimized values: prob_thresh={prob:g}, nms_thresh={nms:g}.".format(prob=self.thresholds.prob, nms=self.thresholds.nms))
+        if save_to_json and self.basedir is not None:
+            print("Saving to 'thresholds.json'.")
+            with open(os.path.join(self.logdir, "thresholds.json"), "w") as fh:
+                json.dump({k: float(v) for k, v in opt_threshs.items()}, fh)      # (numpy 2 keeps the search in float32: not serialisable as it is)
+        return opt_threshs
+
     def _find_and_load_weights(self, prefer="best"):
         """csbdeep BaseModel._find_and_load_weights: of the weight files in the model folder (*.h5 / *.hdf5 Keras files, and the *.npz this
         package converts them to: tools/keras_to_npz.py, save_weights_npz) the newest one whose name contains `prefer`, else the newest"""

@@ -244,3 +244,35 @@ def calculate_extents(lbl, func=np.median):
     if not boxes:
         return np.zeros(n)
     return func(np.array([[s.stop - s.start for s in box] for _, box in boxes]), axis=0)
+
+
+def optimize_threshold(Y, Yhat, model, nms_thresh, measure="accuracy", iou_threshs=[0.3, 0.5, 0.7], bracket=None, tol=1e-2, maxiter=20, verbose=1):
+    """Tune prob_thresh for a fixed nms_thresh so that `measure` of stardist.matching (averaged over iou_threshs) between the label images Y
+    and the instances of the predictions Yhat = [(prob, dist), ...] is largest: golden-section search over [max prob / 2, max prob]
+    (stardist/utils.py:271-307).  Returns (prob_thresh, value).  Host-side tool: every evaluation is one `_instances_from_prediction` per
+    image (NMS + rasteriser natives).  verbose > 1 prints every evaluation; the reference's progress bar is not drawn."""
+    import datetime
+    from scipy.optimize import minimize_scalar
+    from .matching import matching_dataset
+    if not np.isscalar(nms_thresh):
+        raise ValueError("nms_thresh must be a scalar")
+    iou_threshs = [iou_threshs] if np.isscalar(iou_threshs) else iou_threshs
+    if bracket is None:
+        top = max([np.max(prob) for prob, dist in Yhat])
+        bracket = top / 2, top
+    seen = {}
+
+    def negative_score(thr):
+        prob_thresh = np.clip(thr, *bracket)
+        value = seen.get(prob_thresh)
+        if value is None:
+            instances = [model._instances_from_prediction(y.shape, *prob_dist, prob_thresh=prob_thresh, nms_thresh=nms_thresh)[0] for y, prob_dist in zip(Y, Yhat)]
+            stats = matching_dataset(Y, instances, thresh=iou_threshs, show_progress=False, parallel=True)
+            seen[prob_thresh] = value = np.mean([s._asdict()[measure] for s in stats])
+        if verbose > 1:
+            print("%s   thresh: %f   %s: %f" % (datetime.datetime.now().strftime("%H:%M:%S"), prob_thresh, measure, value), flush=True)
+        return -value
+    opt = minimize_scalar(negative_score, method="golden", bracket=bracket, tol=tol, options={"maxiter": maxiter})
+    if verbose > 1:
+        print("\n", opt, flush=True)
+    return opt.x, -opt.fun

@@ -999,3 +999,82 @@ def test_matching_metrics_equal_the_reference_module(monkeypatch):
         mine.group_matching_labels(frames[:1])
     for t in ((5, 1, 2), (0, 3, 4), (7, 0, 0)):
         assert all(getattr(mine, f)(*t) == getattr(ref, f)(*t) for f in ("precision", "recall", "accuracy", "f1"))
+
+
+def test_optimize_thresholds_equal_the_reference_functions(monkeypatch, tmp_path, capsys):
+    """stardist.utils.optimize_threshold (utils.py:271-307) and StarDistBase.optimize_thresholds (base.py:986-1044) -- the producer of the
+    thresholds.json the prediction path reads -- against the reference's own function / method, both driving the same stand-in model
+    (instances = connected components of prob > prob_thresh, thinned by an nms-dependent size rule): the same evaluations, the same optimum,
+    the same file"""
+    import datetime
+    import json
+    import pathlib
+    from collections import namedtuple
+    from scipy import ndimage as ndi
+    from scipy.optimize import minimize_scalar
+    from tqdm import tqdm
+    import stardist_amd.matching as mm
+    from stardist_amd.models.base import StarDistBase
+    from stardist_amd.utils import optimize_threshold
+    ns = ref_functions("utils.py", {"optimize_threshold"}, {"np": np, "_raise": _raise, "tqdm": tqdm, "minimize_scalar": minimize_scalar, "datetime": datetime,
+                                                            "matching_dataset": mm.matching_dataset})
+    ref_opt = ns["optimize_threshold"]
+    rng = np.random.RandomState(5)
+    Y, Yhat = [], []
+    for k in range(3):
+        y = np.zeros((64, 72), np.int32)
+        for i in range(1, 9):
+            c = rng.randint(8, 56, 2)
+            y[c[0] - 4:c[0] + 4, c[1] - 4:c[1] + 4] = i
+        prob = ndi.gaussian_filter((y > 0).astype(np.float32), 2.0) * rng.uniform(0.8, 1.0)
+        Y.append(y); Yhat.append((prob, np.zeros(y.shape + (4,), np.float32)))
+    calls = []
+
+    class Toy(object):
+        basedir = "x"
+
+        def __init__(self, logdir):
+            self.logdir = logdir
+            self._thr = None
+
+        def _instances_from_prediction(self, shape, prob, dist, prob_thresh=None, nms_thresh=None):
+            calls.append((float(prob_thresh), float(nms_thresh)))
+            lab, n = ndi.label(prob > prob_thresh)
+            sizes = ndi.sum(np.ones_like(lab), lab, index=np.arange(1, n + 1)) if n else np.zeros(0)
+            for i, s in enumerate(sizes, 1):
+                if s < 40 * nms_thresh:
+                    lab[lab == i] = 0
+            return lab.astype(np.int32), {}
+
+        def predict(self, x, **kw):
+            assert kw.get("n_tiles") == (1, 1) and kw.get("show_tile_progress") is False
+            return Yhat[int(x[0, 0])] + ("prob_class",)
+
+        def _guess_n_tiles(self, x):
+            return (1, 1)
+        thresholds = property(lambda self: self._thr, lambda self, d: setattr(self, "_thr", namedtuple("Thresholds", d.keys())(*d.values())))
+    for nms in (0.3, 0.5):
+        for kw in (dict(), dict(measure="f1", iou_threshs=0.5, tol=1e-3), dict(bracket=(0.2, 0.7), maxiter=5)):
+            calls.clear(); a = optimize_threshold(Y, Yhat, Toy(None), nms, verbose=0, **kw); ca = list(calls)
+            calls.clear(); b = ref_opt(Y, Yhat, Toy(None), nms, verbose=0, **kw); cb = list(calls)
+            assert ca == cb and len(ca) > 3 and a == b and type(a[0]) == type(b[0]), (nms, kw, a, b)
+    with pytest.raises(ValueError):
+        optimize_threshold(Y, Yhat, Toy(None), (0.3, 0.4))
+    # the method: same optimum, same messages, same thresholds.json
+    X = [np.full((4, 4), k, np.float32) for k in range(3)]
+    da, db = tmp_path / "a", tmp_path / "b"
+    da.mkdir(); db.mkdir()
+    import sys as _sys
+
+    def save_json(data, fpath, **kw):
+        with open(fpath, "w") as f:
+            f.write(json.dumps(data, default=float, **kw))            # (csbdeep's save_json; under numpy 2 the optimum stays float32)
+    rm = _ref_method("models/base.py", "StarDistBase", "optimize_thresholds", {"np": np, "sys": _sys, "optimize_threshold": ref_opt, "save_json": save_json})
+    ta, tb = Toy(str(da)), Toy(pathlib.Path(db))
+    capsys.readouterr()
+    ra = StarDistBase.optimize_thresholds(ta, X, Y, optimize_kwargs=dict(verbose=0))
+    oa = capsys.readouterr().out
+    rb = rm(tb, X, Y, optimize_kwargs=dict(verbose=0))
+    ob = capsys.readouterr().out
+    assert ra == rb and oa == ob and "Using optimized values" in oa and "Saving to 'thresholds.json'." in oa
+    assert ta.thresholds == tb.thresholds and json.load(open(da / "thresholds.json")) == json.load(open(db / "thresholds.json")) == ra
