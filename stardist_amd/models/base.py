@@ -7,7 +7,8 @@ Mirrors stardist/models/base.py for the hot path only:
 Device-resident: the image goes to HBM once; network heads, `max(1e-3, dist)`, threshold +
 border mask + compaction (select.hip), score sort, NMS and rasterisation all stay on the GPU;
 only the label image and the survivor dict return to the host.
-Training, threshold optimisation, export are out of scope.
+Training and export are out of scope; optimize_thresholds (the producer of thresholds.json) is a host-side tool
+around the prediction natives.
 """
 import json
 import math
