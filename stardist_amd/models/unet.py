@@ -566,6 +566,10 @@ class StarDistNet(nn.Module):
             c = self.backbone.out_channels
             n_after, k_after, act_after = cfg.net_conv_after_unet, cfg.unet_kernel_size, cfg.unet_activation
         elif cfg.backbone == "resnet":                                 # model3d.py:402-447
+            if getattr(cfg, "resnet_batch_norm", False):
+                # csbdeep's resnet_block(batch_norm=True) puts a BatchNormalization behind every bias-free convolution: not built here --
+                # refuse loudly instead of predicting with a network that silently lacks those layers
+                raise UnsupportedLayer("resnet_batch_norm=True: the batch-normalised ResNet backbone is not implemented")
             n_filter = cfg.resnet_n_filter_base
             blocks = [_conv(nd, c, n_filter, (7,) * nd, None),        # linear (no activation) model3d.py:416-417
                       _conv(nd, n_filter, n_filter, (3,) * nd, None)]

@@ -339,3 +339,10 @@ def test_config_axes_rules_and_namespace_behaviour_of_csbdeep_baseconfig():
     assert a.is_valid() is True and a.is_valid(return_invalid=True) == (True, ())
     assert a == Config2D(n_rays=8) and a != Config2D(n_rays=16) and a != object()
     assert repr(a).startswith("Config2D(n_dim=2, axes='YXC', n_channel_in=1, n_channel_out=9, ")
+
+
+def test_batch_normalised_resnet_is_refused_loudly():
+    """model3d.py:405-411 hands resnet_batch_norm to csbdeep's resnet_block; that variant is not built here and must not be run without its layers"""
+    from stardist_amd.models import Config3D, StarDist3D
+    with pytest.raises(NotImplementedError, match="resnet_batch_norm"):
+        StarDist3D(Config3D(rays=8, backbone="resnet", resnet_batch_norm=True, resnet_n_filter_base=4), basedir=None, device="cpu")
