@@ -119,7 +119,7 @@ def test_predict_instances_2d_end_to_end_equals_the_reference(kw, axes, shape, r
     m.thresholds = dict(prob=thr, nms=0.4)
 
     variants = [dict(), dict(sparse=False), dict(return_labels=False), dict(nms_thresh=0.2, prob_thresh=min(0.999, thr + 0.02)),
-                dict(return_predict=True), dict(nms_kwargs=dict(use_kdtree=False)), dict(scale=2), dict(scale=tuple(1.5 if a == "Y" else (0.8 if a == "X" else 1) for a in axes))]
+                dict(return_predict=True), dict(nms_kwargs=dict(use_kdtree=False)), dict(prob_thresh=0.99999), dict(prob_thresh=0.99999, sparse=False), dict(scale=2), dict(scale=tuple(1.5 if a == "Y" else (0.8 if a == "X" else 1) for a in axes))]
     for v in variants:
         import warnings
         with warnings.catch_warnings():
@@ -148,12 +148,12 @@ def test_predict_instances_2d_end_to_end_equals_the_reference(kw, axes, shape, r
             assert lg.shape == lw.shape == tuple(img.shape[axes.index(a)] for a in "YX") and (lg > 0).sum() >= 0.97 * ((lg > 0) | (lw > 0)).sum()
             continue
         same_dict(dg, dw, v)
-        assert len(dw["prob"]) >= 10, (v, len(dw["prob"]))
+        assert len(dw["prob"]) >= 10 or v.get("prob_thresh", 0) > 0.9999, (v, len(dw["prob"]))
         if v.get("return_labels", True):
             assert lg.dtype == lw.dtype and lg.shape == lw.shape, (v, lg.dtype, lw.dtype)
             # the float32 network of the mirror and the float64 graph differ in the 6th digit of a vertex: a pixel centre within that of an edge may flip
             assert (lg != lw).mean() <= 2e-4, (v, float((lg != lw).mean()))
-            assert lg.max() == lw.max() == len(dw["prob"])
+            assert lg.max() == lw.max() == len(dw["prob"]) or len(dw["prob"]) == 0
         else:
             assert lg is None and lw is None
 
@@ -173,12 +173,13 @@ def test_predict_instances_3d_end_to_end_equals_the_reference(kw, axes, shape, r
     thr = float(np.nextafter(np.float32(np.sort(prob.ravel())[-max(40, prob.size // 25)]), np.float32(0)))
     ref.thresholds = types.SimpleNamespace(prob=thr, nms=0.3)
     m.thresholds = dict(prob=thr, nms=0.3)
-    for v in (dict(), dict(sparse=False), dict(return_labels=False), dict(overlap_label=-1), dict(nms_thresh=0.1)):
+    for v in (dict(), dict(sparse=False), dict(return_labels=False), dict(overlap_label=-1), dict(nms_thresh=0.1), dict(prob_thresh=0.99999),
+              dict(prob_thresh=0.99999, sparse=False)):
         tw, (lw, dw) = tokens_and_result(ref, img, axes=axes, **v)
         tg, (lg, dg) = tokens_and_result(m, img, axes=axes, **v)
         assert tw == tg == ["predict", "nms"], (v, tw, tg)
         same_dict(dg, dw, v)
-        assert len(dw["prob"]) >= 2, (v, len(dw["prob"]))
+        assert len(dw["prob"]) >= 2 or v.get("prob_thresh", 0) > 0.9999, (v, len(dw["prob"]))
         if v.get("return_labels", True):
             assert lg.dtype == lw.dtype and lg.shape == lw.shape, (v, lg.dtype, lw.dtype)
             assert (lg != lw).mean() <= 5e-4, (v, float((lg != lw).mean()))
