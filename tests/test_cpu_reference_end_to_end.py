@@ -119,7 +119,7 @@ def test_predict_instances_2d_end_to_end_equals_the_reference(kw, axes, shape, r
     m.thresholds = dict(prob=thr, nms=0.4)
 
     variants = [dict(), dict(sparse=False), dict(return_labels=False), dict(nms_thresh=0.2, prob_thresh=min(0.999, thr + 0.02)),
-                dict(return_predict=True), dict(nms_kwargs=dict(use_kdtree=False)), dict(prob_thresh=0.99999), dict(prob_thresh=0.99999, sparse=False), dict(scale=2), dict(scale=tuple(1.5 if a == "Y" else (0.8 if a == "X" else 1) for a in axes))]
+                dict(return_predict=True), dict(nms_kwargs=dict(use_kdtree=False)), dict(nms_kwargs=dict(use_bbox=False)), dict(verbose=True), dict(sparse=False, nms_kwargs=dict(b=4)), dict(prob_thresh=0.99999), dict(prob_thresh=0.99999, sparse=False), dict(scale=2), dict(scale=tuple(1.5 if a == "Y" else (0.8 if a == "X" else 1) for a in axes))]
     for v in variants:
         import warnings
         with warnings.catch_warnings():
