@@ -185,3 +185,34 @@ def test_predict_instances_3d_end_to_end_equals_the_reference(kw, axes, shape, r
             assert (lg != lw).mean() <= 5e-4, (v, float((lg != lw).mean()))
         else:
             assert lg is None and lw is None
+
+
+def test_cli_predict2d_on_a_model_folder_equals_the_api(tmp_path, monkeypatch, capsys):
+    """CPU twin of tests/test_gpu_cli_multiclass.py::test_cli_predict2d_equals_api (natives stood in for as above): the command line script on a
+    csbdeep-style model folder (config.json, thresholds.json, weights_best.npz) -- tiff in, label tiff out -- equals the API call"""
+    import json
+    from stardist_amd.models import Config2D, StarDist2D
+    from stardist_amd.models.base import StarDistBase
+    from stardist_amd.scripts import predict2d
+    from stardist_amd.scripts._io import imread, imwrite
+    from stardist_amd.utils import normalize
+    oracle_natives(monkeypatch)
+    monkeypatch.setattr(StarDistBase, "_select", staticmethod(_select_standin))
+    cfg = Config2D(n_rays=16, unet_n_depth=1, unet_n_filter_base=4, net_conv_after_unet=8)
+    model = StarDist2D(cfg, name="my_model", basedir=str(tmp_path), device="cpu", seed=3)           # writes my_model/config.json
+    import torch
+    with torch.no_grad():
+        model.net.dist.bias.fill_(5.0); model.net.dist.weight.mul_(0.3)
+    model.save_weights_npz(str(tmp_path / "my_model" / "weights_best.npz"))
+    img = np.random.RandomState(2).uniform(0, 255, (72, 88)).astype(np.float32)
+    x = normalize(img, 1, 99.8)
+    thr = float(np.sort(model.predict(x)[0].ravel())[-400])
+    (tmp_path / "my_model" / "thresholds.json").write_text(json.dumps(dict(prob=thr, nms=0.4)))
+    imwrite(str(tmp_path / "in.tif"), img)
+    rc = predict2d.main(["-i", str(tmp_path / "in.tif"), "-m", str(tmp_path / "my_model"), "-o", str(tmp_path / "out"), "--n_tiles", "2", "1", "--device", "cpu"])
+    out = capsys.readouterr().out
+    assert rc == 0 and "Loading network weights from 'weights_best.npz'." in out and "Loading thresholds from 'thresholds.json'." in out
+    got = imread(str(tmp_path / "out" / "in.stardist.tif"))
+    model.thresholds = dict(prob=thr, nms=0.4)
+    want, res = model.predict_instances(normalize(imread(str(tmp_path / "in.tif")), 1, 99.8), n_tiles=(2, 1))
+    assert got.shape == want.shape and np.array_equal(got, want) and want.max() > 5 and len(res["prob"]) == want.max()
