@@ -216,3 +216,43 @@ def test_cli_predict2d_on_a_model_folder_equals_the_api(tmp_path, monkeypatch, c
     model.thresholds = dict(prob=thr, nms=0.4)
     want, res = model.predict_instances(normalize(imread(str(tmp_path / "in.tif")), 1, 99.8), n_tiles=(2, 1))
     assert got.shape == want.shape and np.array_equal(got, want) and want.max() > 5 and len(res["prob"]) == want.max()
+
+
+@pytest.mark.parametrize("use_channel", [False, True])
+def test_big_equals_whole_by_the_reference_s_own_acceptance_test(use_channel, monkeypatch):
+    """tests/test_big.py:86-117 (`test_predict2D`: predict_instances_big == predict_instances by matching(thresh=.99) accuracy 1.0 and
+    lexsorted polygons allclose(atol=1e-2)) on the CPU with a seeded network (weights are absent) and the natives stood in for; the same
+    criteria for the block-sharded design A (predict_instances_sharded, one process), whose instances must be the very same"""
+    import torch
+    from stardist_amd.matching import matching
+    from stardist_amd.models import Config2D, StarDist2D
+    from stardist_amd.models.base import StarDistBase
+    from stardist_amd.utils import normalize
+    oracle_natives(monkeypatch)
+    monkeypatch.setattr(StarDistBase, "_select", staticmethod(_select_standin))
+    model = StarDist2D(Config2D(n_rays=16, unet_n_depth=1, unet_n_filter_base=4, net_conv_after_unet=8, n_channel_in=1), basedir=None, device="cpu", seed=5)
+    with torch.no_grad():
+        model.net.dist.bias.fill_(5.0); model.net.dist.weight.mul_(0.3)
+    rs = np.random.RandomState(7)
+    from scipy.ndimage import gaussian_filter
+    img = normalize(gaussian_filter(rs.uniform(0, 1, (208, 256)), 2.0), 1, 99.8)          # smooth: blobs of candidates, as a real probability map has
+    axes = "YX"
+    if use_channel:
+        img, axes = img[..., np.newaxis], "YXC"
+    thr = float(np.sort(model.predict(img, axes=axes)[0].ravel())[-2500])
+    model.thresholds = dict(prob=thr, nms=0.3)
+    ref_labels, ref_polys = model.predict_instances(img, axes=axes)
+    assert len(ref_polys["prob"]) > 30
+    res_labels, res_polys = model.predict_instances_big(img, axes=axes, block_size=128, min_overlap=32, context=16, show_progress=False)
+    m = matching(ref_labels, res_labels, thresh=0.99)
+    assert (1.0, 1.0) == (m.accuracy, m.mean_true_score), m
+    ri, si = np.lexsort(ref_polys["points"].T), np.lexsort(res_polys["points"].T)
+    for k in ("coord", "points", "prob"):
+        assert np.allclose(ref_polys[k][ri], res_polys[k][si], atol=1e-2), k
+    sh_labels, sh_polys = model.predict_instances_sharded(img, axes, block_size=128, min_overlap=32, context=16)
+    m = matching(ref_labels, np.asarray(sh_labels), thresh=0.99)
+    assert (1.0, 1.0) == (m.accuracy, m.mean_true_score), m
+    hi = np.lexsort(np.asarray(sh_polys["points"]).T)
+    for k in ("coord", "points", "prob"):
+        assert np.allclose(ref_polys[k][ri], np.asarray(sh_polys[k])[hi], atol=1e-2), k
+    assert np.array_equal(np.asarray(sh_labels), ref_labels)                             # design A numbers its instances like predict_instances
