@@ -525,6 +525,11 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
     order (= label ids, as predict_instances numbers them), are broadcast, and every rank renders the write regions of ITS blocks
     from that list (windowed rasteriser; pixels in overlapping write regions come out identical on both owners).
 
+    Requirement for big == whole: `context` >= the network's receptive field (the default, model._axes_tile_overlap, is): a band candidate
+    is taken from the first block that reports it, so every block that holds it in its write region must have predicted it with full
+    context.  (Design B's responsibility rule takes each object from the block it is most central in and forgives a smaller context;
+    tests/test_cpu_reference_end_to_end.py runs the reference's own big == whole acceptance test on both.)
+
     Label image: `labels_out=None` -- the tiles are sent to rank 0, which returns the whole image (ranks != 0 return None);
     a shared `np.memmap` / zarr-like array -- every rank writes its tiles in place (big.py:319-326 block.write), returned on every rank;
     `labels_out="local"` -- nothing is moved: every rank returns [(block index, slices, tile), ...] for its blocks.

@@ -256,3 +256,41 @@ def test_big_equals_whole_by_the_reference_s_own_acceptance_test(use_channel, mo
     for k in ("coord", "points", "prob"):
         assert np.allclose(ref_polys[k][ri], np.asarray(sh_polys[k])[hi], atol=1e-2), k
     assert np.array_equal(np.asarray(sh_labels), ref_labels)                             # design A numbers its instances like predict_instances
+
+
+def test_big_equals_whole_3d_by_the_reference_s_own_acceptance_test(monkeypatch):
+    """tests/test_big.py:123-147 (`test_predict3D`: matching(thresh=.99) accuracy 1.0, mean_true_score > 0.999, lexsorted dist / points / prob
+    allclose(atol=1e-2)) on the CPU, seeded network, natives stood in for; the same for design A"""
+    import torch
+    from scipy.ndimage import gaussian_filter
+    from stardist_amd.matching import matching
+    from stardist_amd.models import Config3D, StarDist3D
+    from stardist_amd.models.base import StarDistBase
+    from stardist_amd.utils import normalize
+    oracle_natives(monkeypatch)
+    monkeypatch.setattr(StarDistBase, "_select", staticmethod(_select_standin))
+    model = StarDist3D(Config3D(rays=16, unet_n_depth=1, unet_n_filter_base=4, net_conv_after_unet=8), basedir=None, device="cpu", seed=6)
+    with torch.no_grad():
+        model.net.dist.bias.fill_(3.0); model.net.dist.weight.mul_(0.2)
+    img = normalize(gaussian_filter(np.random.RandomState(8).uniform(0, 1, (40, 72, 80)), 1.5), 1, 99.8)
+    v = np.sort(model.predict(img)[0].ravel())[-3100:-2900]                   # a threshold inside the widest gap near the 3000th largest value:
+    k = int(np.argmax(np.diff(v)))                                             # the blocks' forward passes differ from the whole volume's in the last
+    thr = float(0.5 * (v[k] + v[k + 1]))                                       # bits (other tile shapes), which must not move a voxel across it
+    model.thresholds = dict(prob=thr, nms=0.3)
+    ref_labels, ref_polys = model.predict_instances(img)
+    assert len(ref_polys["prob"]) > 20
+    # context >= the network's receptive field (10 here), as the default context (_axes_tile_overlap) is: design A takes a band candidate
+    # from the first block that reports it, so both blocks must see it with full context (design B's responsibility rule is more forgiving)
+    assert max(model._axes_tile_overlap("YX")) <= 12
+    kw = dict(block_size=(40, 56, 56), min_overlap=(16, 16, 16), context=(8, 12, 12))        # (Z is one block)
+    res_labels, res_polys = model.predict_instances_big(img, axes="ZYX", show_progress=False, **kw)
+    m = matching(ref_labels, res_labels, thresh=0.99)
+    assert m.accuracy == 1.0 and m.mean_true_score > 0.999, m
+    ri, si = np.lexsort(ref_polys["points"].T), np.lexsort(res_polys["points"].T)
+    for k in ("dist", "points", "prob"):
+        assert np.allclose(ref_polys[k][ri], res_polys[k][si], atol=1e-2), k
+    sh_labels, sh_polys = model.predict_instances_sharded(img, "ZYX", **kw)
+    assert np.array_equal(np.asarray(sh_labels), ref_labels)
+    hi = np.lexsort(np.asarray(sh_polys["points"]).T)
+    for k in ("dist", "points", "prob"):
+        assert np.allclose(ref_polys[k][ri], np.asarray(sh_polys[k])[hi], atol=1e-2), k
