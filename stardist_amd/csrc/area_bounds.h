@@ -31,7 +31,7 @@
 //        (k_poly_props) and are never decided here.
 //        Evidence for the band: 3.6 M GPU pairs of nine families against the exact sweep (worst 0.28 B), 18 M CPU pairs against the
 //        vendored Clipper (0.27 B), and an annealing ADVERSARY linked to the vendored Clipper (test infrastructure, DESIGN.md 3.4:
-//        > 3 x 10^9 evaluations over NMS-realisable and free integer polygons, worst 0.46 B; profiles/r05_area_band_adversary.txt).
+//        4.8 x 10^9 evaluations over NMS-realisable (worst 0.42 B) and free integer polygons (worst 0.53 B); profiles/r05_area_band_adversary.txt).
 // A pair is decided when (A -+ B) / min(area) clears the threshold by the margins below; everything else -- and every pair with
 // a polygon that is not ROBUSTLY SIMPLE (the boundary integral weights regions by winding number, Clipper's NonZero rule does not), with
 // polygons of opposite orientation, too large for exact float predicates, or whose reference result could be rounded by the
