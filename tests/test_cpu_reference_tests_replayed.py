@@ -42,6 +42,25 @@ def _label(img, **kw):
     return ndi.label(img, structure=np.ones((3,) * np.ndim(img)))[0]
 
 
+def _disk(center, radius, shape=None):
+    """skimage.draw.disk: the pixels strictly inside the circle, clipped to `shape`"""
+    r0, c0 = center
+    lo_r, hi_r = int(np.floor(r0 - radius)), int(np.ceil(r0 + radius)) + 1
+    lo_c, hi_c = int(np.floor(c0 - radius)), int(np.ceil(c0 + radius)) + 1
+    if shape is not None:
+        lo_r, lo_c, hi_r, hi_c = max(lo_r, 0), max(lo_c, 0), min(hi_r, shape[0]), min(hi_c, shape[1])
+    rr, cc = np.mgrid[lo_r:hi_r, lo_c:hi_c]
+    inside = ((rr - r0) / radius) ** 2 + ((cc - c0) / radius) ** 2 < 1
+    return rr[inside], cc[inside]
+
+
+def _nuclei_2d(return_mask=False):
+    """stardist.data.test_image_nuclei_2d: the sample image (and mask) the reference package ships, read where it lies"""
+    d = "/root/reference/stardist/data/images"
+    img, mask = _imread(os.path.join(d, "img2d.tif")), _imread(os.path.join(d, "mask2d.tif"))
+    return (img, mask) if return_mask else img
+
+
 @pytest.fixture()
 def as_stardist(monkeypatch, refmods):
     """`import stardist` -> stardist_amd (natives -> compiled reference), the absent third-party helpers, the reference's tests dir on the path"""
@@ -83,7 +102,8 @@ def as_stardist(monkeypatch, refmods):
     installed = {"stardist": stardist_amd, "stardist.matching": stardist_amd.matching, "stardist.geometry": stardist_amd.geometry, "stardist.big": stardist_amd.big,
                  "csbdeep": mod("csbdeep"), "csbdeep.utils": mod("csbdeep.utils", normalize=normalize),
                  "csbdeep.utils.tf": mod("csbdeep.utils.tf", keras_import=lambda *a, **k: object),
-                 "tifffile": mod("tifffile", imread=_imread), "skimage": mod("skimage"), "skimage.measure": mod("skimage.measure", label=_label)}
+                 "tifffile": mod("tifffile", imread=_imread), "skimage": mod("skimage"), "skimage.measure": mod("skimage.measure", label=_label),
+                 "skimage.draw": mod("skimage.draw", disk=_disk), "stardist.data": mod("stardist.data", test_image_nuclei_2d=_nuclei_2d)}
     # every sub-module under its `stardist.` name as the SAME object (a second import under the alias would make copies the stand-ins miss)
     import stardist_amd.nms, stardist_amd.rays3d, stardist_amd.geometry.geom2d, stardist_amd.geometry.geom3d  # noqa: E401,F401
     for k in [k for k in sys.modules if k.startswith("stardist_amd.")]:
@@ -126,8 +146,8 @@ def _replay(module_name, skip=()):
     mod = _load(module_name)
     ran, skipped = {}, {}
     for name, fn in sorted(vars(mod).items()):
-        if not (name.startswith("test_") and callable(fn)):
-            continue
+        if not (name.startswith("test_") and callable(fn) and getattr(fn, "__module__", None) == mod.__name__):
+            continue                                                   # (imported helpers such as stardist.data.test_image_nuclei_2d are no tests)
         if name in skip:
             skipped[name] = skip[name]
             continue
@@ -222,3 +242,10 @@ def test_predict_big_tells_where_the_function_moved():
     m = StarDist2D(Config2D(n_rays=8, unet_n_depth=1, unet_n_filter_base=4), basedir=None, device="cpu")
     with pytest.raises(RuntimeError, match=r"moved to StarDist2D\.predict_instances_big"):
         predict_big(m, None)
+
+
+def test_reference_test_matching_runs_against_this_package(as_stardist):
+    """tests/test_matching.py: matching on shifted discs, _shuffle_labels and group_matching_labels on the package's sample mask with the
+    reference's own expected label maxima [183, 199, 215, 231, 247, 263]"""
+    ran, skipped = _replay("test_matching")
+    assert ran == {"test_matching": 1, "test_grouping": 1} and not skipped, (ran, skipped)
