@@ -373,6 +373,29 @@ int sd_conv3_f16x3_dot_ndhwc_device(const float* d_src0, int c0, int stride0, in
                                     int act, float* d_out, int* d_range_flag, const float* d_dot_w, float* d_dot_partial, void* stream);
 int sd_dot_combine_device(const float* d_partial, int groups, long long n_pix, const float* d_wbias, int sigmoid, float* d_out, void* stream);
 
+/* ---- split16 activation tensors (round 6) ---------------------------------------------------------------------------------------
+ * What the split-fp16 kernel's consumer side derives from every f32 value it reads -- hi = fp16(x), lo' = fp16((x - hi) * 2^11) -- made
+ * ONCE by the producing layer instead of once per consumer workgroup and unit.  A split16 tensor has the shape, strides and addresses
+ * of the channels-last f32 tensor it stands for (C a multiple of 32, dense); per pixel and 32-channel chunk its 128 bytes hold 8
+ * elements of 16 bytes: element p * 4 + o = the fp16 terms of plane p (0: hi, 1: lo') of channels o * 8 .. o * 8 + 7.
+ * Value = hi + lo' * 2^-11 (exact in f32): the 22 bits the f32-tensor entry points keep of x, so every layer's result is bit-identical
+ * whichever form carries the activations between the layers of the reference's U-Net (csbdeep unet_block, model2d.py:310-349,
+ * model3d.py:360-399).
+ *   sd_conv3_f16x3_fmt_ndhwc_device   the layer of sd_conv3_f16x3_ndhwc_device / _dot_ with either side in split16 form
+ *                                     (in_split16: all sources; out_split16: no fused head then).  d_range_flag |= 1: an f32 INPUT was
+ *                                     outside the fp16 range; |= 2: a value of the split16 OUTPUT was (the output is not valid).
+ *   sd_conv3_c1x32_split16_device     the one-channel first layer (1 -> 32, weights packed by sd_conv3_pack_weights_host) writing split16
+ *   sd_maxpool_split16_ndhwc_device   MaxPooling on a split16 tensor: == split16(maxpool(f32 tensor)) bit for bit (x -> (hi, lo') is monotone)
+ *   sd_split16_pack_device / _unpack_device   f32 <-> split16 as their own passes (tests; consumers that only take f32 tensors) */
+int sd_conv3_f16x3_fmt_ndhwc_device(const float* d_src0, int c0, int up0, const float* d_src1, int c1, int up1, int D, int H, int W, int kz,
+                                    const float* d_wpacked, const float* d_bias, int c_out, int act, float* d_out, int in_split16,
+                                    int out_split16, int* d_range_flag, const float* d_dot_w, float* d_dot_partial, void* stream);
+int sd_conv3_c1x32_split16_device(const float* d_src, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, int act,
+                                  float* d_out, int* d_range_flag, void* stream);
+int sd_maxpool_split16_ndhwc_device(const float* d_in, int n_channels, int D, int H, int W, int pz, int py, int px, float* d_out, void* stream);
+int sd_split16_pack_device(const float* d_in, long long n_pix, int n_channels, float* d_out, int* d_range_flag, void* stream);
+int sd_split16_unpack_device(const float* d_in, long long n_pix, int n_channels, float* d_out, void* stream);
+
 /* UpSampling2D/3D (nearest, x2 along the axes of `up`: bit 0 x, 1 y, 2 z) + Concatenate([up-sampled a, b]) of a csbdeep unet_block up
  * level as one channels-last tensor [D][H][W][ca + cb] (a: [D >> z][H >> y][W >> x][ca]).  Only the coverage path needs it -- up
  * levels whose channel counts are not multiples of 32 (e.g. n_filter_base = 48) run this + sd_convg_ndhwc_device; the fused 3x3 kernels

@@ -208,9 +208,23 @@ __global__ void __launch_bounds__(256) k_conv3_c1(const float* __restrict__ x, i
 // loads, SGPR operands of the FMAs), the 9 / 27 input taps are read once per pixel instead of once per channel quad, and the
 // 128 bytes a thread produces are transposed through LDS (row pitch 36 floats) so that a wave writes its 64 pixels as eight
 // fully coalesced 1-KiB stores.  HBM-write bound (128 B/pixel).
-template <int KZ>
+// SPLIT: the output is written as a split16 tensor (conv3x3_layout.h; the form the split-fp16 kernel's consumer side reads without
+// splitting): a lane then takes 8 consecutive channels of one pixel from the transposition and stores their 8 hi terms and 8 lo' terms
+// (16 bytes each, 64 bytes apart); *flag |= 2 when a value is beyond the fp16 range.
+typedef _Float16 c1_f16x2 __attribute__((ext_vector_type(2)));
+typedef float c1_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int c1_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void c1_split2(float a, float b, unsigned& hi, unsigned& lo, float& amax) {      // split2_pair of conv3x3_f16.hip
+  const c1_f32x2 x = {a, b};
+  const c1_f16x2 h = __builtin_convertvector(x, c1_f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  const c1_f32x2 r = (x - __builtin_convertvector(h, c1_f32x2)) * 2048.f;
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, c1_f16x2));
+  amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)));
+}
+template <int KZ, bool SPLIT = false>
 __global__ void __launch_bounds__(256) k_conv3_c1x32(const float* __restrict__ x, int D, int H, int W, const float* __restrict__ w,
-                                                     const float* __restrict__ bias, int act, float* __restrict__ out) {
+                                                     const float* __restrict__ bias, int act, float* __restrict__ out, int* __restrict__ flag = nullptr) {
   __shared__ float rows[4][64 * 36];
   const long long n_pix = (long long)D * H * W;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -248,6 +262,25 @@ __global__ void __launch_bounds__(256) k_conv3_c1x32(const float* __restrict__ x
     *(v4f*)(row + q * 4) = o;
   }
   // (only this wave touches rows[wave]: LDS operations of one wave complete in order)
+  if (SPLIT) {
+    const int pr = lane >> 2, oc = lane & 3;
+    float amax = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float* src = rows[wave] + (k * 16 + pr) * 36 + oc * 8;
+      const v4f va = *(const v4f*)src, vb = *(const v4f*)(src + 4);
+      unsigned hw[4], lw[4];
+      c1_split2(va.x, va.y, hw[0], lw[0], amax); c1_split2(va.z, va.w, hw[1], lw[1], amax);
+      c1_split2(vb.x, vb.y, hw[2], lw[2], amax); c1_split2(vb.z, vb.w, hw[3], lw[3], amax);
+      const long long p2 = wbase + k * 16 + pr;
+      if (p2 < n_pix) {
+        *(c1_u32x4*)(out + p2 * 32 + oc * 4) = c1_u32x4{hw[0], hw[1], hw[2], hw[3]};
+        *(c1_u32x4*)(out + p2 * 32 + 16 + oc * 4) = c1_u32x4{lw[0], lw[1], lw[2], lw[3]};
+      }
+    }
+    if (flag && !(amax <= 65504.f)) atomicOr(flag, 2);
+    return;
+  }
   const int px = lane >> 3, c4 = lane & 7;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -328,8 +361,8 @@ extern "C" int sd_conv3_res_ndhwc_device(const float* d_src0, int c0, int stride
     if (c_out == 32) {
       const long long waves = ((long long)D * H * W + 63) / 64;
       const dim3 g1((unsigned)((waves + 3) / 4));
-      if (kz == 1) hipLaunchKernelGGL(k_conv3_c1x32<1>, g1, dim3(256), 0, s, d_src0, D, H, W, d_wpacked, d_bias, act, d_out);
-      else hipLaunchKernelGGL(k_conv3_c1x32<3>, g1, dim3(256), 0, s, d_src0, D, H, W, d_wpacked, d_bias, act, d_out);
+      if (kz == 1) hipLaunchKernelGGL((k_conv3_c1x32<1, false>), g1, dim3(256), 0, s, d_src0, D, H, W, d_wpacked, d_bias, act, d_out, (int*)nullptr);
+      else hipLaunchKernelGGL((k_conv3_c1x32<3, false>), g1, dim3(256), 0, s, d_src0, D, H, W, d_wpacked, d_bias, act, d_out, (int*)nullptr);
       SD_LAUNCH_CHECK();
       return 0;
     }
@@ -379,6 +412,24 @@ extern "C" int sd_conv3_res_ndhwc_device(const float* d_src0, int c0, int stride
   P.groups = c_out / (32 * nt);
   (void)nt;
   return launch_conv<1>(P, s);
+}
+
+// first layer (one input channel -> 32) with the output written as a split16 tensor: what sd_conv3_f16x3_fmt_ndhwc_device reads with in_split16
+extern "C" int sd_conv3_c1x32_split16_device(const float* d_src, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, int act,
+                                             float* d_out, int* d_range_flag, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (D <= 0 || H <= 0 || W <= 0) return 0;
+  if (!d_src || !d_wpacked || !d_out || (act != 0 && act != 1) || (kz != 1 && kz != 3) || (kz == 1 && D != 1) ||
+      (((uintptr_t)d_wpacked | (uintptr_t)d_out | (uintptr_t)d_bias) & 15) || ((uintptr_t)d_range_flag & 3)) {
+    sd::set_error("sd_conv3_c1x32_split16: kz 1|3, act 0|1, 16-byte aligned pointers");
+    return -1;
+  }
+  const long long waves = ((long long)D * H * W + 63) / 64;
+  const dim3 g1((unsigned)((waves + 3) / 4));
+  if (kz == 1) hipLaunchKernelGGL((k_conv3_c1x32<1, true>), g1, dim3(256), 0, s, d_src, D, H, W, d_wpacked, d_bias, act, d_out, d_range_flag);
+  else hipLaunchKernelGGL((k_conv3_c1x32<3, true>), g1, dim3(256), 0, s, d_src, D, H, W, d_wpacked, d_bias, act, d_out, d_range_flag);
+  SD_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int sd_conv3_ndhwc_device(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1, int up1,

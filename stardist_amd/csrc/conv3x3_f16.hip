@@ -143,6 +143,17 @@ __device__ __forceinline__ void store_planes(const StageH& st, char* __restrict_
     }
 }
 
+// split16 sources (INP): an element is already 8 fp16 values of one plane (conv3x3_layout.h "split16"): the pixel's 128 bytes are copied as they are
+__device__ __forceinline__ void store_copy(const StageH& st, char* __restrict__ tileH, const v4f (&pre)[PRE_F4], int tid) {
+#pragma unroll
+  for (int n = 0; n < PRE_F4; ++n)
+    if (n < PRE_F4 - 1 || tid < TILE_F4 - (PRE_F4 - 1) * THREADS) {
+      unsigned tyx = st.tyx[n];
+      asm volatile("" : "+v"(tyx));
+      *(v4f*)(tileH + ((int)(tyx & 255u) * HALO_W + (int)(tyx >> 8)) * HPIX + (tid & 7) * 16) = pre[n];
+    }
+}
+
 // One sub-unit (row tap dy): 6 operand groups (dx, block); a group = 2 halo rows x 2 planes (A) + 2 planes (B) = 6 ds_read_b128 feeding
 // 6 MFMAs (three plane pairs x two output rows).  The operands of group g+1 are read while the matrix cores work on group g.
 // `extra(gi)`: vector-ALU work / global loads that do not depend on the matrix instructions, interleaved with them.
@@ -248,10 +259,57 @@ __device__ __forceinline__ void store_tile(const Params& P, const f32x16 (&acc0)
   }
 }
 
+// The same tile as a split16 tensor (OUTP): the consumer's two fp16 terms of every value, made ONCE here instead of once per consumer
+// workgroup and unit.  The transposition hands a lane EIGHT consecutive channels of one pixel (two conflict-free ds_read_b128: the
+// scratch holds channels o*8 .. o*8+3 of the round's 16 pixels in its first KiB, o*8+4 .. o*8+7 in the second), which it splits
+// (round to nearest even, exactly split2_pair of the consumer) and stores as the pixel's hi element and lo' element (16 bytes each,
+// 64 bytes apart).  `amax` collects max |x| of what is stored: a value beyond the fp16 range cannot be represented (range flag bit 1).
+__device__ __forceinline__ void store_tile_split(const Params& P, const f32x16 (&acc0)[2], const f32x16 (&acc1)[2], float* __restrict__ scr, int g, int tz,
+                                                 int ty, int tx, int wave, int lane, float& amax) {
+  const int i = lane & 31, h = lane >> 5;
+  const int pr = lane >> 2, o = lane & 3;                       // as a reader: this lane's pixel within the round's 16, its channel octet
+  const unsigned pix_bytes = (unsigned)P.c_out * 4u;
+  const unsigned chan_off = (unsigned)(g * 128 + o * 16);
+  const int wofs = ((i >> 2) & 1) * 256 + (i >> 3) * 4 + (i & 3);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int y = ty + wave * 2 + p;
+    if (y >= P.H) continue;                                            // (wave-uniform)
+    const size_t row = ((size_t)tz * P.H + y) * P.W;
+    const __amdgpu_buffer_rsrc_t ro =
+        __builtin_amdgcn_make_buffer_rsrc((void*)uniform64((unsigned long long)(P.out + row * P.c_out)), 0, (int)((unsigned)P.W * pix_bytes), 0x00020000);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                                      // columns 16 q .. 16 q + 15
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8) {
+        const int r = q * 8 + r8;
+        const int pl = (r8 & 3) + 8 * (r8 >> 2) + 4 * h;               // pixel within the round's 16
+        scr[pl * 16 + wofs] = acc0[p][r] + acc1[p][r] * 4.8828125e-4f;    // 2^-11
+      }
+      v4f va = *(const v4f*)(scr + lane * 4), vb = *(const v4f*)(scr + 256 + lane * 4);
+      if (P.act == 1) {
+        va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
+        vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
+      }
+      unsigned hw[4], lw[4];
+      split2_pair(va.x, va.y, hw[0], lw[0], amax);
+      split2_pair(va.z, va.w, hw[1], lw[1], amax);
+      split2_pair(vb.x, vb.y, hw[2], lw[2], amax);
+      split2_pair(vb.z, vb.w, hw[3], lw[3], amax);
+      const u32x4 hi = {hw[0], hw[1], hw[2], hw[3]}, lo = {lw[0], lw[1], lw[2], lw[3]};
+      const int so = (int)((unsigned)(tx + q * 16 + pr) * pix_bytes + chan_off);     // (x >= W: outside the row's resource, dropped)
+      __builtin_amdgcn_raw_buffer_store_b128(hi, ro, so, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(lo, ro, so + 64, 0, 0);
+    }
+  }
+}
+
 // TWO workgroups per CU (79.8 KiB of LDS each, <= 256 registers per lane): two waves per SIMD
 // (WPE = 1: the same code compiled for one wave per SIMD -- 512 registers -- as the A/B partner of option conv_f16_workgroups_per_cu = 1)
-template <bool RES, int WPE, bool DOT = false>
+// INP: the sources are split16 tensors (no split here, the halo is copied); OUTP: the output is written as a split16 tensor
+template <bool RES, int WPE, bool DOT = false, bool INP = false, bool OUTP = false>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_conv3_f16(const Params P) {
+  static_assert(!(OUTP && (RES || DOT)), "a split16 output has neither residual nor fused head");
   extern __shared__ float4 smem4h[];
   // LDS map (bytes): two weight buffers of one sub-unit each | halo tile, 2 fp16 planes | 4 x 2 KiB wave-private epilogue scratch
   char* W = (char*)smem4h;
@@ -270,10 +328,9 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WP
   TileAddr Tc, Tn;                                      // the tile being computed, the tile whose first unit is fetched next
   tile_addr(P, q, Tc);
   Tn = Tc;
-  float amax = 0.f;
+  float amax = 0.f, amax_out = 0.f;
   {
     v4f pre[PRE_F4], wreg[WREG];
-    u32x2 pk[PRE_F4][2];
     weights_fetch(P, g, 0, 0, wreg, tid);
     {
       const HaloRsrc hs = halo_rsrc(P, halo_base(P, Tc, 0), Tc);
@@ -281,9 +338,13 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WP
       for (int n = 0; n < PRE_F4; ++n) pre[n] = halo_load_one(hs, halo_off_one(hs, st.tyx[n], q4off));
     }
     weights_store(W, wreg, tid);
+    if (INP) store_copy(st, tileH, pre, tid);
+    else {
+      u32x2 pk[PRE_F4][2];
 #pragma unroll
-    for (int n = 0; n < PRE_F4; ++n) split_elem(pre[n], pk[n], amax);
-    store_planes(st, tileH, pk, tid);
+      for (int n = 0; n < PRE_F4; ++n) split_elem(pre[n], pk[n], amax);
+      store_planes(st, tileH, pk, tid);
+    }
   }
   __syncthreads();
   PROF_DECL;
@@ -300,7 +361,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WP
       const bool have = tn < P.n_tiles;
       v4f pre[PRE_F4];
       unsigned addr[PRE_F4];
-      u32x2 pk[PRE_F4][2];
+      u32x2 pk[INP ? 1 : PRE_F4][2];
       HaloRsrc hs;
       // dy 0: its matrix instructions hide the address arithmetic of the next unit's halo; dy 1 issues its weight loads FIRST and the
       // halo loads after them (the wait for the weights leaves the halo in flight); dy 2 splits the halo elements into their fp16
@@ -330,11 +391,13 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WP
             for (int n = gi * 2; n < gi * 2 + 2; ++n)
               if (n < PRE_F4) pre[n] = halo_load_one(hs, addr[n]);
           });
+        } else if (INP) {
+          compute_sub<0, 0>(tileH, wcur, dy, acc0, acc1, wave, lane & 31, lane >> 5, [&](int) {});
         } else {
           compute_sub<6, 0>(tileH, wcur, dy, acc0, acc1, wave, lane & 31, lane >> 5, [&](int gi) {
 #pragma unroll
             for (int n = (gi - 2) * 3; n < (gi - 2) * 3 + 3; ++n)
-              if (gi >= 2 && n < PRE_F4) split_elem(pre[n], pk[n], amax);
+              if (gi >= 2 && n < PRE_F4) split_elem(pre[n], pk[INP ? 0 : n], amax);
           });
         }
         PROF(dy == 0 ? 3 : 11 + dy);
@@ -349,18 +412,24 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WP
         wb ^= 1;
       }
       PROF(8);
-      if (have) store_planes(st, tileH, pk, tid);                  // (every wave is past the barrier behind the last sub-unit)
+      if (have) {                                                  // (every wave is past the barrier behind the last sub-unit)
+        if constexpr (INP) store_copy(st, tileH, pre, tid);
+        else store_planes(st, tileH, pk, tid);
+      }
       PROF(9);
       __syncthreads();
       PROF(10);
       PROF_UNIT();
     }
-    store_tile<RES, DOT>(P, acc0, acc1, scr, g, Tc.tz, Tc.ty0 + 1, Tc.tx0 + 1, wave, lane);
+    if constexpr (OUTP) store_tile_split(P, acc0, acc1, scr, g, Tc.tz, Tc.ty0 + 1, Tc.tx0 + 1, wave, lane, amax_out);
+    else store_tile<RES, DOT>(P, acc0, acc1, scr, g, Tc.tz, Tc.ty0 + 1, Tc.tx0 + 1, wave, lane);
     PROF(11);
     Tc = Tn;
   }
   // an activation outside the fp16 range (or not finite): tell the host (one atomic per offending wave, normally none)
-  if (P.flag && !(amax <= 65504.f)) atomicOr(P.flag, 1);
+  if (!INP && P.flag && !(amax <= 65504.f)) atomicOr(P.flag, 1);
+  // ... or a value this layer was to store as a split16 element (bit 1: the OUTPUT is not valid, whatever reads it)
+  if (OUTP && P.flag && !(amax_out <= 65504.f)) atomicOr(P.flag, 2);
   PROF_END();
 }
 
@@ -389,8 +458,13 @@ extern "C" int sd_conv3_f16x3_pack_weights_host(const float* w, int c_in, int c_
 static int conv3_f16x3_launch(const float* d_src0, int c0, int stride0, int up0, const float* d_src1, int c1, int stride1,
                               int up1, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias,
                               const float* d_res, int res_stride, int c_out, int act, float* d_out, int* d_range_flag,
-                              const float* d_dot_w, float* d_dot_partial, void* stream_) {
+                              const float* d_dot_w, float* d_dot_partial, void* stream_, int in_split = 0, int out_split = 0) {
   hipStream_t s = (hipStream_t)stream_;
+  if ((in_split & ~1) || (out_split & ~1) || (out_split && (d_res || d_dot_w)) || (in_split && d_res) ||
+      (in_split && (stride0 != c0 || (d_src1 && stride1 != c1)))) {
+    sd::set_error("sd_conv3_f16x3: split16 tensors are dense (stride == channels); a split16 output takes neither residual nor fused head, a residual layer no split16 input");
+    return -1;
+  }
   if (D <= 0 || H <= 0 || W <= 0) return 0;
   const int c_in = c0 + (d_src1 ? c1 : 0);
   const long long n_packed = sd_conv3_f16x3_packed_floats(c_in, c_out, kz);
@@ -449,13 +523,19 @@ static int conv3_f16x3_launch(const float* d_src0, int c0, int stride0, int up0,
   int dev = 0;
   SD_CHECK(hipGetDevice(&dev));
   const size_t lds = (size_t)2 * HWSUB_BYTES + HTILE_BYTES + 4 * 2048 + 128;    // 79.9 KiB: two workgroups per CU (the last 128 bytes: the fused head's weights)
+  typedef void (*kern_t)(const Params);
+  // [variant][one workgroup per CU]: plain, residual, fused head; then the split16 forms (in, out, in + out, in + fused head)
+  static const kern_t kern[7][2] = {
+      {k_conv3_f16<false, 2>, k_conv3_f16<false, 1>},
+      {k_conv3_f16<true, 2>, k_conv3_f16<true, 1>},
+      {k_conv3_f16<false, 2, true>, k_conv3_f16<false, 1, true>},
+      {k_conv3_f16<false, 2, false, true, false>, k_conv3_f16<false, 1, false, true, false>},
+      {k_conv3_f16<false, 2, false, false, true>, k_conv3_f16<false, 1, false, false, true>},
+      {k_conv3_f16<false, 2, false, true, true>, k_conv3_f16<false, 1, false, true, true>},
+      {k_conv3_f16<false, 2, true, true, false>, k_conv3_f16<false, 1, true, true, false>}};
   if (dev >= 16 || !attr_set[dev]) {
-    SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SD_CHECK(hipFuncSetAttribute((const void*)k_conv3_f16<false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int v = 0; v < 7; ++v)
+      for (int w = 0; w < 2; ++w) SD_CHECK(hipFuncSetAttribute((const void*)kern[v][w], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (dev < 16) attr_set[dev] = true;
   }
   int cus = dev < 16 ? n_cu[dev] : 0;
@@ -469,15 +549,8 @@ static int conv3_f16x3_launch(const float* d_src0, int c0, int stride0, int up0,
   if (blocks < P.groups) blocks = P.groups;
   const long long want = (long long)P.n_tiles * P.groups;
   if (blocks > want) blocks = want;
-  if (per_cu == 1) {
-    if (d_dot_w) hipLaunchKernelGGL((k_conv3_f16<false, 1, true>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
-    else if (d_res) hipLaunchKernelGGL((k_conv3_f16<true, 1>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
-    else hipLaunchKernelGGL((k_conv3_f16<false, 1>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
-  } else {
-    if (d_dot_w) hipLaunchKernelGGL((k_conv3_f16<false, 2, true>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
-    else if (d_res) hipLaunchKernelGGL((k_conv3_f16<true, 2>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
-    else hipLaunchKernelGGL((k_conv3_f16<false, 2>), dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
-  }
+  const int variant = d_dot_w ? (in_split ? 6 : 2) : d_res ? 1 : (in_split ? (out_split ? 5 : 3) : (out_split ? 4 : 0));
+  hipLaunchKernelGGL(kern[variant][per_cu == 1 ? 1 : 0], dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
   SD_LAUNCH_CHECK();
   return 0;
 }
@@ -503,4 +576,17 @@ extern "C" int sd_conv3_f16x3_ndhwc_device(const float* d_src0, int c0, int stri
                                            float* d_out, int* d_range_flag, void* stream_) {
   return sd_conv3_f16x3_res_ndhwc_device(d_src0, c0, stride0, up0, d_src1, c1, stride1, up1, D, H, W, kz, d_wpacked, d_bias, nullptr, 0,
                                          c_out, act, d_out, d_range_flag, stream_);
+}
+
+// The same layers over split16 tensors (conv3x3_layout.h): in_split16 != 0: every source holds, per pixel and 32-channel chunk, the
+// 32 fp16 hi terms followed by the 32 fp16 lo' terms of its values (the 128 bytes the chunk's 32 floats would take: same strides, same
+// addresses) -- what this kernel's consumer side derives from an f32 tensor anyway, made once by the producer; out_split16 != 0: the
+// output is written in that form (after bias + activation; d_range_flag |= 2 when a value cannot be represented: |x| > 65504).
+// Results are bit-identical to the f32-tensor entry points (the consumer's operands are the same 22 bits either way).
+// d_dot_w / d_dot_partial (both or neither): the fused one-channel head of sd_conv3_f16x3_dot_ndhwc_device (f32 output only).
+extern "C" int sd_conv3_f16x3_fmt_ndhwc_device(const float* d_src0, int c0, int up0, const float* d_src1, int c1, int up1, int D, int H, int W, int kz,
+                                               const float* d_wpacked, const float* d_bias, int c_out, int act, float* d_out, int in_split16,
+                                               int out_split16, int* d_range_flag, const float* d_dot_w, float* d_dot_partial, void* stream_) {
+  return conv3_f16x3_launch(d_src0, c0, c0, up0, d_src1, c1, c1, up1, D, H, W, kz, d_wpacked, d_bias, nullptr, 0, c_out, act, d_out, d_range_flag,
+                            d_dot_w, d_dot_partial, stream_, in_split16 ? 1 : 0, out_split16 ? 1 : 0);
 }

@@ -159,6 +159,79 @@ __global__ void __launch_bounds__(256) k_maxpool_cl4(const float4* __restrict__ 
   }
 }
 
+// ---- split16 tensors (conv3x3_layout.h) -----------------------------------------------------------------------------------------
+// Per pixel and 32-channel chunk: 8 elements of 16 bytes, element p * 4 + o = the 8 fp16 terms of plane p (0: hi, 1: lo') of channels
+// o * 8 .. o * 8 + 7; value = hi + lo' * 2^-11 (exact in f32).
+typedef _Float16 sp_h8 __attribute__((ext_vector_type(8)));
+typedef float sp_f8 __attribute__((ext_vector_type(8)));
+
+// Max pooling of a split16 tensor: the element of the window whose VALUE is largest is copied (both of its terms).  x -> (hi, lo') is
+// monotone, so this is the pair the consumer would derive from max(x): the pooled split16 tensor equals split(maxpool(f32 tensor))
+// bit for bit.  Two pairs with the same value (hi + half a step, hi' - half a step) can only come from x < x': the larger hi wins.
+// Thread per (output pixel, chunk, octet).
+__global__ void __launch_bounds__(256) k_maxpool_split16(const sp_h8* __restrict__ in, sp_h8* __restrict__ out, long long n_out, int C32, int Ho, int Wo,
+                                                         int H, int W, int pz, int py, int px) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int per_pix = C32 * 4;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n_out; idx += stride) {
+    const int q = (int)(idx % per_pix), c = q >> 2, o = q & 3;
+    long long pix = idx / per_pix;
+    const int xo = (int)(pix % Wo); pix /= Wo;
+    const int yo = (int)(pix % Ho);
+    const long long zo = pix / Ho;
+    sp_h8 bh = {}, bl = {};
+    sp_f8 bv = {};
+    bool first = true;
+    for (int dz = 0; dz < pz; ++dz)
+      for (int dy = 0; dy < py; ++dy) {
+        const sp_h8* row = in + ((((zo * pz + dz) * H + ((long long)yo * py + dy)) * W + (long long)xo * px) * C32 + c) * 8 + o;
+        for (int dx = 0; dx < px; ++dx) {
+          const sp_h8 h = row[(long long)dx * C32 * 8], l = row[(long long)dx * C32 * 8 + 4];
+          const sp_f8 v = __builtin_convertvector(h, sp_f8) + __builtin_convertvector(l, sp_f8) * 4.8828125e-4f;
+          if (first) { bh = h; bl = l; bv = v; first = false; continue; }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const bool take = v[k] > bv[k] || (v[k] == bv[k] && (float)h[k] > (float)bh[k]);
+            if (take) { bh[k] = h[k]; bl[k] = l[k]; bv[k] = v[k]; }
+          }
+        }
+      }
+    sp_h8* dst = out + (idx / per_pix * C32 + c) * 8 + o;
+    dst[0] = bh; dst[4] = bl;
+  }
+}
+
+// f32 -> split16 (the producer-side split as its own pass: tests, and a tensor that reaches a split-fp16 layer from an f32 producer);
+// thread per (pixel, chunk, octet)
+__global__ void __launch_bounds__(256) k_split16_pack(const float4* __restrict__ in, sp_h8* __restrict__ out, long long n, int* __restrict__ flag) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  float amax = 0.f;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+    const long long chunk = idx >> 2;
+    const int o = (int)(idx & 3);
+    const float4 a = in[chunk * 8 + o * 2], b = in[chunk * 8 + o * 2 + 1];
+    const sp_f8 x = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const sp_h8 h = __builtin_convertvector(x, sp_h8);
+    const sp_f8 r = (x - __builtin_convertvector(h, sp_f8)) * 2048.f;
+    out[chunk * 8 + o] = h;
+    out[chunk * 8 + 4 + o] = __builtin_convertvector(r, sp_h8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(x[k]));
+  }
+  if (flag && !(amax <= 65504.f)) atomicOr(flag, 2);
+}
+// split16 -> f32: hi + lo' * 2^-11 (the 22 bits a split-fp16 layer reads; for a consumer that takes f32 tensors only)
+__global__ void __launch_bounds__(256) k_split16_unpack(const sp_h8* __restrict__ in, float4* __restrict__ out, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += stride) {
+    const long long chunk = idx >> 2;
+    const int o = (int)(idx & 3);
+    const sp_f8 v = __builtin_convertvector(in[chunk * 8 + o], sp_f8) + __builtin_convertvector(in[chunk * 8 + 4 + o], sp_f8) * 4.8828125e-4f;
+    out[chunk * 8 + o * 2] = make_float4(v[0], v[1], v[2], v[3]);
+    out[chunk * 8 + o * 2 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
 // UpSampling (nearest, x2 along the axes of `up`) + Concatenate([up-sampled a, b]) as ONE channels-last tensor: the coverage path of an
 // up level whose channel counts the fused 3x3 kernels do not take (csbdeep unet_block, e.g. n_filter_base = 48); thread per
 // (output pixel, channel quad)
@@ -209,6 +282,52 @@ extern "C" int sd_maxpool_ndhwc_device(const float* d_in, int n_channels, int D,
   long long blocks = (n4 + 255) / 256;
   if (blocks > 256 * 64) blocks = 256 * 64;
   hipLaunchKernelGGL(k_maxpool_cl4, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)d_in, (float4*)d_out, n4, n_channels / 4, Ho, Wo, H, W, pz, py, px);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sd_maxpool_split16_ndhwc_device(const float* d_in, int n_channels, int D, int H, int W, int pz, int py, int px, float* d_out, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (pz <= 0 || py <= 0 || px <= 0 || n_channels <= 0 || n_channels % 32 || !d_in || !d_out || (((uintptr_t)d_in | (uintptr_t)d_out) & 15)) {
+    sd::set_error("sd_maxpool_split16_ndhwc: channels must be a multiple of 32, pointers 16-byte aligned, pool sizes positive");
+    return -1;
+  }
+  const int Do = D / pz, Ho = H / py, Wo = W / px;
+  if (Do <= 0 || Ho <= 0 || Wo <= 0) return 0;
+  const long long n = (long long)Do * Ho * Wo * (n_channels / 8);
+  long long blocks = (n + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(k_maxpool_split16, dim3((unsigned)blocks), dim3(256), 0, s, (const sp_h8*)d_in, (sp_h8*)d_out, n, n_channels / 32, Ho, Wo, H, W, pz, py, px);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sd_split16_pack_device(const float* d_in, long long n_pix, int n_channels, float* d_out, int* d_range_flag, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (n_pix <= 0) return 0;
+  if (n_channels <= 0 || n_channels % 32 || !d_in || !d_out || d_in == d_out || (((uintptr_t)d_in | (uintptr_t)d_out) & 15) || ((uintptr_t)d_range_flag & 3)) {
+    sd::set_error("sd_split16_pack: channels must be a multiple of 32, pointers 16-byte aligned and distinct");
+    return -1;
+  }
+  const long long n = n_pix * (n_channels / 8);
+  long long blocks = (n + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(k_split16_pack, dim3((unsigned)blocks), dim3(256), 0, s, (const float4*)d_in, (sp_h8*)d_out, n, d_range_flag);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sd_split16_unpack_device(const float* d_in, long long n_pix, int n_channels, float* d_out, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (n_pix <= 0) return 0;
+  if (n_channels <= 0 || n_channels % 32 || !d_in || !d_out || d_in == d_out || (((uintptr_t)d_in | (uintptr_t)d_out) & 15)) {
+    sd::set_error("sd_split16_unpack: channels must be a multiple of 32, pointers 16-byte aligned and distinct");
+    return -1;
+  }
+  const long long n = n_pix * (n_channels / 8);
+  long long blocks = (n + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(k_split16_unpack, dim3((unsigned)blocks), dim3(256), 0, s, (const sp_h8*)d_in, (float4*)d_out, n);
   SD_LAUNCH_CHECK();
   return 0;
 }

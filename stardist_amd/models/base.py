@@ -418,10 +418,11 @@ class StarDistBase(object):
 
     def _net_forward(self, x, sparse_head=False):
         """_net_forward_once under the range guard of the default split-fp16 convolutions (models/unet.py conv_mode): every such layer ORs
-        ITS word of this model's flag tensor when an activation it reads lies outside the fp16 range (|x| > 65504 or infinite).  The words
-        are read back after the pass (one 1-KiB copy); when one is set the outputs are discarded, a warning names the layers and the
-        magnitude limit, exactly those layers are moved to the six-product bf16 form (f32 range) for the rest of the model's life, and the
-        pass is repeated -- the other layers stay on the fp16 form."""
+        ITS word of this model's flag tensor with 1 when an f32 activation it reads lies outside the fp16 range (|x| > 65504 or infinite),
+        with 2 when a value of the split16 tensor it WRITES does (models/unet.py "split16": the producer makes the reader's fp16 terms).
+        The words are read back after the pass (one 1-KiB copy); when one is set the outputs are discarded, a warning names the layers
+        and the magnitude limit, exactly the layers that read the offending activation are moved to the six-product bf16 form (f32 range)
+        for the rest of the model's life (its producer writes f32 again), and the pass is repeated -- the other layers stay on the fp16 form."""
         from . import unet
         if self.device.type != "cuda" or unet.conv_mode() != "f16x3":
             return self._net_forward_once(x, sparse_head)
@@ -431,15 +432,32 @@ class StarDistBase(object):
             flags = self._range_flags = torch.zeros(unet.N_FLAG_SLOTS, dtype=torch.int32, device=self.device)
         for _ in range(64):
             flags.zero_()
+            unet.split16_replan(False)
             with unet.use_range_flags(flags):
                 ys = self._net_forward_once(x, sparse_head)
             h = flags.cpu().numpy()
+            if unet.split16_replan() and not h.any():
+                # a layer met a split16 tensor it cannot read (models/unet.py _unpack_for): its producer writes f32 from now on; the pass is
+                # repeated so that the result does not depend on which form carried the activation
+                self.__dict__.pop("_graphs", None)
+                continue
             if not h.any():
                 return ys
-            bad = set(int(k) for k in np.flatnonzero(h))
-            names = []
+            bad_in = set(int(k) for k in np.flatnonzero(h & 1))          # layers that READ an f32 activation outside the range
+            bad_out = set(int(k) for k in np.flatnonzero(h & 2))         # layers whose split16 OUTPUT could not hold a value
+            names, pinned = [], set()
             for name, mod in self.net.named_modules():
-                if mod.__dict__.get("_sd_flag_slot") in bad and mod.__dict__.get("_sd_force_form") != "bf16x6":
+                slot = mod.__dict__.get("_sd_flag_slot")
+                if slot in bad_in and mod.__dict__.get("_sd_force_form") != "bf16x6":
+                    pinned.add(mod)
+                if slot in bad_out:
+                    # its readers (recorded by _hand_conv) move to the bf16x6 form, and it writes f32 again
+                    mod.__dict__["_sd_split_out"] = False
+                    for c in mod.__dict__.get("_sd_consumers", ()):
+                        if c.__dict__.get("_sd_force_form") != "bf16x6":
+                            pinned.add(c)
+            for name, mod in self.net.named_modules():
+                if mod in pinned:
                     mod.__dict__["_sd_force_form"] = "bf16x6"
                     names.append(name)
             if not names:                                    # (a word no layer of this model owns: cannot happen)
@@ -470,7 +488,8 @@ class StarDistBase(object):
         else:
             from .unet import conv_mode
             # everything the captured kernels depend on besides the weights: shape, head form, convolution kernel family
-            key = (tuple(xc.shape), xc.dtype, bool(sparse_head), conv_mode(), bool(getattr(self.net, "fused_heads", True)))
+            from .unet import split16_enabled
+            key = (tuple(xc.shape), xc.dtype, bool(sparse_head), conv_mode(), bool(getattr(self.net, "fused_heads", True)), split16_enabled())
             cache = self.__dict__.setdefault("_graphs", {})
             if key not in cache:
                 if len(cache) >= 8:                                  # bounded: tiles of a big image share few shapes

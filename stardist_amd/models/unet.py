@@ -12,6 +12,7 @@ Keras layer names are kept as module names so a Keras weight file maps 1:1 (kern
 U-Net parity against TensorFlow is unpinned in this environment (no TF, no weights).
 """
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -84,8 +85,19 @@ class force_conv_mode(object):
 
 _range_flags = {}
 N_FLAG_SLOTS = 256
-_flag_stack = []
 _slot_counter = [0]
+
+
+class _PerThread(threading.local):
+    """state of the forward pass a thread is running: the flag tensor of ITS model (two threads predicting with two models on one
+    device each report into their own words), and whether a layer asked for the pass to be repeated (split16_replan)"""
+
+    def __init__(self):
+        self.flag_stack = []
+        self.replan = False
+
+
+_tls = _PerThread()
 
 
 def range_flag(device):
@@ -111,16 +123,17 @@ class use_range_flags(object):
         self.flags = flags
 
     def __enter__(self):
-        _flag_stack.append(self.flags)
+        _tls.flag_stack.append(self.flags)
         return self
 
     def __exit__(self, *exc):
-        _flag_stack.pop()
+        _tls.flag_stack.pop()
         return False
 
 
 def flag_slot(conv):
-    """the word (1 .. N_FLAG_SLOTS - 1) a convolution module reports its range flag into; assigned on first use"""
+    """the word (1 .. N_FLAG_SLOTS - 1) a convolution module reports its range flag into; assigned on first use.  A model is not
+    re-entrant: one thread at a time per model (its flag words and captured graphs are per model, the stack of active flag tensors per thread)"""
     s = conv.__dict__.get("_sd_flag_slot")
     if s is None:
         _slot_counter[0] = _slot_counter[0] % (N_FLAG_SLOTS - 1) + 1
@@ -129,9 +142,93 @@ def flag_slot(conv):
 
 
 def _flag_ptr(conv, device):
-    if _flag_stack and _flag_stack[-1].device == torch.device(device):
-        return _flag_stack[-1].data_ptr() + 4 * flag_slot(conv)
+    st = _tls.flag_stack
+    if st and st[-1].device == torch.device(device):
+        return st[-1].data_ptr() + 4 * flag_slot(conv)
     return range_flag(device).data_ptr()
+
+
+# ---- split16 activations (include/stardist_hip.h "split16"; csrc/conv3x3_layout.h) -------------------------------------------------
+# Between two split-fp16 layers an activation tensor travels as the two fp16 terms (hi, lo') the consuming kernel multiplies with --
+# made once in the producer's epilogue instead of once per consumer workgroup and unit.  Same shape, strides and bytes per value as
+# the f32 tensor it stands for (torch dtype float32, tagged with `_sd_split16`); results are bit-identical to the f32 form.
+# Which layers write it is planned from the topology (StarDistNet._plan_split16: a layer whose every consumer is a 3x3 layer over
+# 32-channel chunks, directly or through a max-pooling); a consumer that cannot read the form after all (pinned to bf16x6) unpacks it,
+# clears the producer's mark and asks for the pass to be repeated (`split16_replan`), so a result never depends on the form.
+_split16_override = []
+
+
+def split16_replan(value=None):
+    """the calling thread's "repeat the pass" request (set by _unpack_for, read and cleared by StarDistBase._net_forward)"""
+    if value is not None:
+        _tls.replan = bool(value)
+    return _tls.replan
+
+
+def split16_enabled():
+    """split16 activations between split-fp16 layers (STARDIST_AMD_SPLIT16=0 or force_split16(False): f32 tensors everywhere)"""
+    if _split16_override:
+        return _split16_override[-1]
+    import os
+    return os.environ.get("STARDIST_AMD_SPLIT16", "1") != "0"
+
+
+class force_split16(object):
+    """context manager: `with force_split16(False): ...` (takes precedence over the environment variable)"""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        _split16_override.append(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        _split16_override.pop()
+        return False
+
+
+def is_split16(t):
+    return bool(getattr(t, "_sd_split16", False))
+
+
+def _tag_split16(t, producer):
+    t._sd_split16 = True
+    t._sd_producer = producer
+    return t
+
+
+def split16_unpack(t):
+    """the f32 tensor hi + lo' * 2^-11 of a split16 tensor (a consumer that only reads f32); a plain tensor is returned as it is"""
+    if not is_split16(t):
+        return t
+    from ..lib import _native as N
+    out = torch.empty_like(t)
+    C = int(t.shape[1])
+    N.dcall(t, "sd_split16_unpack_device", ctypes.c_void_p(t.data_ptr()), int(t.numel() // C), C, ctypes.c_void_p(out.data_ptr()))
+    return out
+
+
+def split16_pack(t, flag_ptr=None):
+    """split16 form of a channels-last f32 tensor (1, C, *spatial), C a multiple of 32 (tests; sd_split16_pack_device)"""
+    from ..lib import _native as N
+    nd = t.dim() - 2
+    cl = torch.channels_last if nd == 2 else torch.channels_last_3d
+    assert t.dtype == torch.float32 and t.shape[0] == 1 and t.shape[1] % 32 == 0 and t.is_contiguous(memory_format=cl)
+    out = torch.empty_like(t)
+    C = int(t.shape[1])
+    N.dcall(t, "sd_split16_pack_device", ctypes.c_void_p(t.data_ptr()), int(t.numel() // C), C, ctypes.c_void_p(out.data_ptr()),
+            ctypes.c_void_p(flag_ptr) if flag_ptr else None)
+    return _tag_split16(out, None)
+
+
+def _unpack_for(conv, t):
+    """`conv` cannot read the split16 tensor t: f32 copy for this pass; its producer writes f32 from now on and the pass is repeated"""
+    prod = getattr(t, "_sd_producer", None)
+    if prod is not None and prod.__dict__.get("_sd_split_out"):
+        prod.__dict__["_sd_split_out"] = False
+        split16_replan(True)
+    return split16_unpack(t)
 
 
 def _native_inference(x):
@@ -286,9 +383,13 @@ def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False, dot=None):
         ok = is3 and co % 4 == 0 and not any(ups[0]) and res is None
     else:
         ok = is3 and all(c % 32 == 0 and c > 0 for c in cs) and sum(cs) <= _MAX_CHUNK_CHANNELS and co % 32 == 0
+    for t, _ in srcs:                                    # (who reads a layer's output: the range fallback pins the readers of a split16 tensor)
+        prod = getattr(t, "_sd_producer", None)
+        if prod is not None:
+            prod.__dict__.setdefault("_sd_consumers", set()).add(conv)
     if not ok:
         if len(srcs) == 1 and not any(ups[0]):
-            return _general_conv(conv, srcs[0][0], kind, res, bn, tf_same)
+            return _general_conv(conv, _unpack_for(conv, srcs[0][0]), kind, res, bn, tf_same)
         return None
     shape = tuple(int(s) << u for s, u in zip(srcs[0][0].shape[2:], ups[0]))          # output = full resolution
     for (t, _), up in zip(srcs, ups):
@@ -296,7 +397,7 @@ def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False, dot=None):
             return None
     from ..lib import _native as N
     # channels-last operands (a pooling layer may hand over a tensor in the default layout: one copy at its resolution)
-    srcs = [(t if t.is_contiguous(memory_format=cl) and t.data_ptr() % 16 == 0 else t.clone(memory_format=cl), up) for t, up in srcs]
+    srcs = [(t if is_split16(t) or (t.is_contiguous(memory_format=cl) and t.data_ptr() % 16 == 0) else t.clone(memory_format=cl), up) for t, up in srcs]
     form = "conv3" if (cs == [1] or conv_mode() == "hand") else conv_mode()
     if form == "f16x3" and conv.__dict__.get("_sd_force_form") == "bf16x6":
         form = "bf16x6"                                  # this layer has seen an activation beyond the fp16 range (StarDistBase._net_forward)
@@ -307,12 +408,36 @@ def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False, dot=None):
             form = "bf16x6"
     if form != "f16x3":
         wp, bias = _packed_conv_weights(conv, form, bn)
+    # split16 operands: all sources or none (a layer on another kernel form reads f32 only)
+    in_split = form == "f16x3" and res is None and all(is_split16(t) for t, _ in srcs)
+    if not in_split:
+        srcs = [(_unpack_for(conv, t), up) for t, up in srcs]
+    out_split = bool(conv.__dict__.get("_sd_split_out")) and split16_enabled() and res is None and dot is None and conv_mode() == "f16x3" \
+        and (form == "f16x3" or (cs == [1] and co == 32))
     out = torch.empty((1, co) + shape, dtype=torch.float32, device=conv.weight.device, memory_format=cl)
     if res is not None and not (tuple(res.shape) == tuple(out.shape) and res.dtype == torch.float32 and res.is_contiguous(memory_format=cl)):
         return None
     D, H, W = ((1,) + shape) if nd == 2 else shape
     mask = lambda up: sum(b << k for k, b in enumerate(reversed(up)))                     # bit 0: x, 1: y, 2: z
     a, b = srcs[0][0], (srcs[1][0] if len(srcs) == 2 else None)
+    if cs == [1] and out_split:
+        # the one-channel first layer writing the split16 form its reader takes
+        N.dcall(a, "sd_conv3_c1x32_split16_device", ctypes.c_void_p(a.data_ptr()), D, H, W, 1 if nd == 2 else 3, ctypes.c_void_p(wp.data_ptr()),
+                ctypes.c_void_p(bias.data_ptr()) if bias is not None else None, kind, ctypes.c_void_p(out.data_ptr()),
+                ctypes.c_void_p(_flag_ptr(conv, a.device)))
+        return _tag_split16(out, conv)
+    if form == "f16x3" and (in_split or out_split):
+        part = None
+        if dot is not None and dot[0].numel() == co and dot[0].data_ptr() % 16 == 0:
+            part = torch.empty((D * H * W, co // 4), dtype=torch.float32, device=a.device)
+        N.dcall(a, "sd_conv3_f16x3_fmt_ndhwc_device", ctypes.c_void_p(a.data_ptr()), cs[0], mask(ups[0]),
+                ctypes.c_void_p(b.data_ptr()) if b is not None else None, cs[1] if b is not None else 0, mask(ups[1]) if b is not None else 0,
+                D, H, W, 1 if nd == 2 else 3, ctypes.c_void_p(wp.data_ptr()), ctypes.c_void_p(bias.data_ptr()) if bias is not None else None,
+                co, kind, ctypes.c_void_p(out.data_ptr()), int(in_split), int(out_split), ctypes.c_void_p(_flag_ptr(conv, a.device)),
+                ctypes.c_void_p(dot[0].data_ptr()) if part is not None else None, ctypes.c_void_p(part.data_ptr()) if part is not None else None)
+        if part is not None:
+            dot[1].append(part)
+        return _tag_split16(out, conv) if out_split else out
     args = [ctypes.c_void_p(a.data_ptr()), cs[0], cs[0], mask(ups[0]),
             ctypes.c_void_p(b.data_ptr()) if b is not None else None, cs[1] if b is not None else 0, cs[1] if b is not None else 0,
             mask(ups[1]) if b is not None else 0, D, H, W, 1 if nd == 2 else 3, ctypes.c_void_p(wp.data_ptr()),
@@ -341,6 +466,7 @@ def _upcat_general(conv, x, skip, pool, kind, bn=None):
         return None
     from ..lib import _native as N
     cl = torch.channels_last if nd == 2 else torch.channels_last_3d
+    x, skip = _unpack_for(conv, x), _unpack_for(conv, skip)
     a = x if x.is_contiguous(memory_format=cl) and x.data_ptr() % 16 == 0 else x.clone(memory_format=cl)
     b = skip if skip.is_contiguous(memory_format=cl) and skip.data_ptr() % 16 == 0 else skip.clone(memory_format=cl)
     S = (1,) * (3 - nd) + tuple(int(v) for v in skip.shape[2:])
@@ -403,6 +529,15 @@ def max_pool(x, pool):
         cl = torch.channels_last if nd == 2 else torch.channels_last_3d
         if not (nd in (2, 3) and x.shape[0] == 1 and x.dtype == torch.float32 and x.shape[1] % 4 == 0):
             raise UnsupportedLayer("MaxPooling %s on %s %s" % (pool, x.dtype, tuple(x.shape)))
+        if is_split16(x):
+            # the pooled split16 tensor == split16 of the pooled f32 tensor (x -> (hi, lo') is monotone): same readers, same bits
+            from ..lib import _native as N
+            S = (1,) * (3 - nd) + tuple(int(v) for v in x.shape[2:])
+            P = (1,) * (3 - nd) + pool
+            out = torch.empty((1, x.shape[1]) + tuple(s // p for s, p in zip(x.shape[2:], pool)), dtype=torch.float32, device=x.device, memory_format=cl)
+            if out.numel():
+                N.dcall(x, "sd_maxpool_split16_ndhwc_device", ctypes.c_void_p(x.data_ptr()), int(x.shape[1]), *S, *P, ctypes.c_void_p(out.data_ptr()))
+            return _tag_split16(out, getattr(x, "_sd_producer", None))
         if not (x.is_contiguous(memory_format=cl) and x.data_ptr() % 16 == 0):
             x = x.clone(memory_format=cl)
         from ..lib import _native as N
@@ -596,6 +731,63 @@ class StarDistNet(nn.Module):
         if cfg.n_classes is not None:
             self.features_class = _conv(nd, c, n_after, k_after, act_after) if n_after > 0 else nn.Identity()
             self.prob_class = Conv(cf, cfg.n_classes + 1, (1,) * nd)
+        self._plan_split16()
+
+    def _plan_split16(self):
+        """mark (conv.__dict__["_sd_split_out"]) the layers whose output travels as a split16 tensor (see split16_enabled): 3x3(x3)
+        stride-1 layers with relu / linear activation over 32-channel chunks (or the one-channel first layer with 32 outputs) whose EVERY
+        reader is such a layer, directly or through a max-pooling.  U-Net backbones only (a ResNet block's shortcut and strided layers
+        read f32)."""
+        nd = self.nd
+
+        def layer_ok(m, as_producer):
+            if not isinstance(m, ConvAct):
+                return False
+            conv, _, kind = m.parts()
+            Conv = nn.Conv2d if nd == 2 else nn.Conv3d
+            if not (isinstance(conv, Conv) and kind >= 0 and tuple(conv.kernel_size) == (3,) * nd and tuple(conv.stride) == (1,) * nd
+                    and tuple(conv.padding) == (1,) * nd and tuple(conv.dilation) == (1,) * nd and conv.groups == 1):
+                return False
+            ci, co = conv.in_channels, conv.out_channels
+            if as_producer:
+                return co % 32 == 0 and ((ci % 32 == 0 and ci <= _MAX_CHUNK_CHANNELS) or (ci == 1 and co == 32))
+            return ci % 32 == 0 and ci <= _MAX_CHUNK_CHANNELS and co % 32 == 0
+
+        readers = {}
+
+        def feed(prods, reader):
+            for p in prods:
+                readers.setdefault(p, []).append(reader)
+
+        def run(seq, cur):
+            for m in seq:
+                feed(cur, m)
+                cur = [m]
+            return cur
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Conv3d)):
+                m.__dict__["_sd_split_out"] = False
+        if not isinstance(self.backbone, UNetBlock):
+            return
+        cur = []
+        for st in self.pre:
+            cur = run(st["convs"], cur)
+        bb = self.backbone
+        if not all(p in (1, 2) for p in bb.pool):
+            return
+        skips = []
+        for blk in bb.down:
+            cur = run(blk, cur)
+            skips.append(cur)
+        cur = run(bb.middle, cur)
+        for blk, skip in zip(bb.up, reversed(skips)):
+            cur = run(blk, cur + skip)
+        feed(cur, self.features)
+        if self.n_classes is not None:
+            feed(cur, self.features_class)
+        for p, rs in readers.items():
+            if layer_ok(p, True) and all(layer_ok(r, False) for r in rs):
+                p.parts()[0].__dict__["_sd_split_out"] = True
 
     def _heads(self, base):
         """the plain graph: features conv, prob (Conv 1x1 + sigmoid), dist (Conv 1x1)[, class head] -- on the GPU every convolution is
