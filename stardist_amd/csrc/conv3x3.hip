@@ -398,7 +398,7 @@ extern "C" int sd_conv3_res_ndhwc_device(const float* d_src0, int c0, int stride
   for (int k = 0; k < MAX_CHUNKS; ++k) { P.chunk_kind[k] = 0; P.chunk_choff[k] = 0; }
   for (int k = 0; k < c0 / 32; ++k) { P.chunk_kind[nc] = 0; P.chunk_choff[nc++] = k * 32; }
   if (d_src1) for (int k = 0; k < c1 / 32; ++k) { P.chunk_kind[nc] = 1; P.chunk_choff[nc++] = k * 32; }
-  P.D = D; P.H = H; P.W = W; P.kz = kz; P.n_units = nc * kz;
+  P.D = D; P.H = H; P.W = W; P.kz = kz; P.n_units = nc * kz; P.n_chunks0 = c0 / 32;
   P.zero = d_wpacked + sdconv::packed_floats(c_in, c_out, kz);
   P.res = d_res; P.res_stride = res_stride;
   P.dotw = nullptr; P.dotp = nullptr;

@@ -344,7 +344,7 @@ extern "C" int sd_conv3_bf16x6_res_ndhwc_device(const float* d_src0, int c0, int
   for (int k = 0; k < MAX_CHUNKS; ++k) { P.chunk_kind[k] = 0; P.chunk_choff[k] = 0; }
   for (int k = 0; k < c0 / 32; ++k) { P.chunk_kind[nc] = 0; P.chunk_choff[nc++] = k * 32; }
   if (d_src1) for (int k = 0; k < c1 / 32; ++k) { P.chunk_kind[nc] = 1; P.chunk_choff[nc++] = k * 32; }
-  P.D = D; P.H = H; P.W = W; P.kz = kz; P.n_units = nc * kz;
+  P.D = D; P.H = H; P.W = W; P.kz = kz; P.n_units = nc * kz; P.n_chunks0 = c0 / 32;
   P.zero = d_wpacked + (n_packed - 4);
   if (d_res && (res_stride < c_out || (res_stride & 3) || ((uintptr_t)d_res & 15))) {
     sd::set_error("sd_conv3_bf16x6: the residual needs 16-byte alignment and a stride >= c_out");

@@ -39,6 +39,7 @@ struct Params {
   const float* res;    // optional residual [D][H][W][res_stride]: out = act(conv + bias + res) -- the Add + Activation that closes a
   int res_stride;      // csbdeep resnet_block, folded into the epilogue (nullptr: none)
   int tiles_x, tiles_plane, n_tiles, groups;
+  int n_chunks0;       // chunks of kind[0] (the first c0 / 32 chunks; the others come from kind[1]): chunk_kind / chunk_choff in closed form
   int* flag;           // conv3x3_f16.hip: OR-ed with 1 when an activation is outside the fp16 range (nullptr: not reported)
   const float* dotw;   // conv3x3_f16.hip, fused one-channel head (the probability head behind the features layer): weights [c_out] ...
   float* dotp;         // ... and the partial dot products [groups][D * H * W]: dotp[g][pixel] = sum over the 32 channels of group g of
@@ -138,6 +139,48 @@ __device__ __forceinline__ void tile_addr(const Params& P, int t, TileAddr& T) {
     const Src S = P.kind[k];
     T.off[k] = ((long long)src_base(T.ty0, S.shy) * (P.W >> S.shx) + src_base(T.tx0, S.shx)) * S.stride;
   }
+}
+// A persistent workgroup walks the tiles q, q + Q, q + 2Q, ...: the two integer divisions of tile_addr (and their ~150 vector
+// instructions: 7-12 % of a unit in the round-5 phase profile) are paid once per kernel; afterwards the position advances by the
+// step's digits (plane, tile row, tile column) with carries -- a handful of scalar instructions.
+struct TileWalk {
+  int tz, row, col;          // position of the tile whose address record is current
+  int sz, srow, scol;        // digits of the step Q
+  int tiles_y;
+};
+__device__ __forceinline__ void tile_at(const Params& P, const TileWalk& w, TileAddr& T) {
+  T.tz = w.tz;
+  T.ty0 = w.row * TH - 1;
+  T.tx0 = w.col * TW - 1;
+  T.interior = T.ty0 >= 0 && T.ty0 + HALO_H <= P.H && T.tx0 >= 0 && T.tx0 + HALO_W <= P.W;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const Src S = P.kind[k];
+    T.off[k] = ((long long)src_base(T.ty0, S.shy) * (P.W >> S.shx) + src_base(T.tx0, S.shx)) * S.stride;
+  }
+}
+__device__ __forceinline__ void walk_init(const Params& P, int q, int Q, TileWalk& w) {
+  w.tiles_y = P.tiles_plane / P.tiles_x;
+  w.tz = q / P.tiles_plane;
+  int tr = q - w.tz * P.tiles_plane;
+  w.row = tr / P.tiles_x;
+  w.col = tr - w.row * P.tiles_x;
+  w.sz = Q / P.tiles_plane;
+  tr = Q - w.sz * P.tiles_plane;
+  w.srow = tr / P.tiles_x;
+  w.scol = tr - w.srow * P.tiles_x;
+  w.tz = __builtin_amdgcn_readfirstlane(w.tz); w.row = __builtin_amdgcn_readfirstlane(w.row); w.col = __builtin_amdgcn_readfirstlane(w.col);
+  w.sz = __builtin_amdgcn_readfirstlane(w.sz); w.srow = __builtin_amdgcn_readfirstlane(w.srow); w.scol = __builtin_amdgcn_readfirstlane(w.scol);
+  w.tiles_y = __builtin_amdgcn_readfirstlane(w.tiles_y);
+}
+__device__ __forceinline__ void walk_step(const Params& P, TileWalk& w) {
+  w.col += w.scol;
+  int c = w.col >= P.tiles_x;
+  w.col -= c ? P.tiles_x : 0;
+  w.row += w.srow + c;
+  c = w.row >= w.tiles_y;
+  w.row -= c ? w.tiles_y : 0;
+  w.tz += w.sz + c;
 }
 // field-wise choice (a reference picked at run time would put both records into scratch memory)
 __device__ __forceinline__ TileAddr tile_select(bool second, const TileAddr& a, const TileAddr& b) {

@@ -25,17 +25,25 @@
 #include "stardist_hip.h"
 
 #ifdef SD_CONV_PROFILE
-__device__ unsigned long long g_conv_prof[16];   // [0] total, [1..14] phases, [15] units
-#define PROF_DECL unsigned long long pf_t = __builtin_amdgcn_s_memtime(), pf_acc[14] = {}; const unsigned long long pf_t0 = pf_t; unsigned long long pf_units = 0
+__device__ unsigned long long g_conv_prof[20];   // [0] total, [1..16] phases, [19] units
+#define PROF_DECL unsigned long long pf_t = __builtin_amdgcn_s_memtime(), pf_acc[16] = {}; const unsigned long long pf_t0 = pf_t; unsigned long long pf_units = 0
 #define PROF(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pf_acc[k] += n_ - pf_t; pf_t = n_; } while (0)
 #define PROF_UNIT() (++pf_units)
 #define PROF_END() do { if (threadIdx.x == 0) { atomicAdd(&g_conv_prof[0], __builtin_amdgcn_s_memtime() - pf_t0); \
-  for (int k_ = 0; k_ < 14; ++k_) atomicAdd(&g_conv_prof[1 + k_], pf_acc[k_]); atomicAdd(&g_conv_prof[15], pf_units); } } while (0)
+  for (int k_ = 0; k_ < 16; ++k_) atomicAdd(&g_conv_prof[1 + k_], pf_acc[k_]); atomicAdd(&g_conv_prof[19], pf_units); } } while (0)
 #else
 #define PROF_DECL
 #define PROF(k)
 #define PROF_UNIT()
 #define PROF_END()
+#endif
+
+// Build-time experiment switches (tools/build_variant.sh): bit 0 = per-thread halo offsets precomputed per source tensor and an
+// interior-tile fast path (split16 sources only: their staging keeps no split registers, so the 22 offsets fit)
+// bit 1 = matrix instructions issued so that consecutive ones never share an accumulator
+// bits 2, 3 = ENERGY PROBES, wrong results: only the first two operand groups of a sub-unit read their A (bit 2) / B (bit 3) operands from LDS
+#ifndef SD_CONV_EXP
+#define SD_CONV_EXP 3
 #endif
 
 namespace {
@@ -99,6 +107,55 @@ __device__ __forceinline__ v4f halo_load_one(const HaloRsrc& s, unsigned off) {
   return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, (int)off, 0, 0));
 }
 
+// The same descriptor from values held in scalar registers (the two source records are read from the kernel arguments ONCE; the chunk ->
+// source map in closed form): no dependent scalar loads per unit, so the whole computation can sit between matrix instructions.
+struct SrcS {
+  unsigned long long p;        // address of the tensor
+  long long plane;             // floats per z plane
+  int stride, shz, shy, shx, ws;   // ws = W >> shx
+};
+__device__ __forceinline__ SrcS src_scalars(const Params& P, int k) {
+  const Src S = P.kind[k];
+  SrcS r;
+  r.p = uniform64((unsigned long long)S.p);
+  r.plane = (long long)uniform64((unsigned long long)S.plane);
+  r.stride = __builtin_amdgcn_readfirstlane(S.stride); r.shz = __builtin_amdgcn_readfirstlane(S.shz);
+  r.shy = __builtin_amdgcn_readfirstlane(S.shy); r.shx = __builtin_amdgcn_readfirstlane(S.shx);
+  r.ws = __builtin_amdgcn_readfirstlane(P.W >> S.shx);
+  asm volatile("" : "+s"(r.p), "+s"(r.plane), "+s"(r.stride), "+s"(r.shz), "+s"(r.shy), "+s"(r.shx), "+s"(r.ws));
+  return r;
+}
+struct DimS { int D, H, W, kz, n0; };
+__device__ __forceinline__ void tile_at_s(const SrcS& S0, const SrcS& S1, const DimS& d, const TileWalk& w, TileAddr& T) {
+  T.tz = w.tz;
+  T.ty0 = w.row * TH - 1;
+  T.tx0 = w.col * TW - 1;
+  T.interior = T.ty0 >= 0 && T.ty0 + HALO_H <= d.H && T.tx0 >= 0 && T.tx0 + HALO_W <= d.W;
+  // pixels from a plane's first pixel to the source pixel of halo pixel (0, 0): 32-bit (a plane has fewer than 2^31 pixels), times the stride
+  T.off[0] = (long long)(src_base(T.ty0, S0.shy) * S0.ws + src_base(T.tx0, S0.shx)) * S0.stride;
+  T.off[1] = (long long)(src_base(T.ty0, S1.shy) * S1.ws + src_base(T.tx0, S1.shx)) * S1.stride;
+}
+struct UnitS {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int ty0, tx0, H, W;          // H = 0 for a z plane outside the volume
+  int k, in;                   // source tensor; every element of the halo lies inside the image
+};
+__device__ __forceinline__ UnitS unit_scalars(const SrcS& S0, const SrcS& S1, const DimS& d, const TileAddr& T, int u) {
+  const int c = d.kz == 3 ? (u * 21846) >> 16 : u;           // u / 3 (exact for u < 4096)
+  const int dz = d.kz == 3 ? u - c * 3 - 1 : 0;
+  const int k = c >= d.n0;
+  const int choff = (c - (k ? d.n0 : 0)) * 32;
+  const int z = T.tz + dz;
+  const bool zin = z >= 0 && z < d.D;
+  const int zc = min(max(z, 0), d.D - 1) >> (k ? S1.shz : S0.shz);
+  const long long fl = (long long)choff + (long long)zc * (k ? S1.plane : S0.plane) + (k ? T.off[1] : T.off[0]);
+  UnitS r;
+  r.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((k ? S1.p : S0.p) + (unsigned long long)(fl * 4)), 0, (int)HALO_RANGE, 0x00020000);
+  r.ty0 = T.ty0; r.tx0 = T.tx0; r.H = zin ? d.H : 0; r.W = d.W;
+  r.k = k; r.in = (int)(T.interior && zin);
+  return r;
+}
+
 // weights of sub-unit (u, dy) of group g: 12 KiB = 768 x 16 bytes through registers (three per thread), as in conv3x3_bf16.hip
 constexpr int WREG = (HWSUB_BYTES / 16 + THREADS - 1) / THREADS;
 static_assert(WREG * THREADS == HWSUB_BYTES / 16, "a sub-unit's weights are a whole number of 16-byte elements per thread");
@@ -148,9 +205,10 @@ __device__ __forceinline__ void store_copy(const StageH& st, char* __restrict__ 
 #pragma unroll
   for (int n = 0; n < PRE_F4; ++n)
     if (n < PRE_F4 - 1 || tid < TILE_F4 - (PRE_F4 - 1) * THREADS) {
-      unsigned tyx = st.tyx[n];
-      asm volatile("" : "+v"(tyx));
-      *(v4f*)(tileH + ((int)(tyx & 255u) * HALO_W + (int)(tyx >> 8)) * HPIX + (tid & 7) * 16) = pre[n];
+      // element tid + n * THREADS lies in halo pixel 32 n + p(tid) of the staging order (conv3x3_layout.h stage_elem_b; the last, partial
+      // block keeps the plain order), quad tid & 7: one per-thread base, the rest is an immediate offset
+      const int pb = n < (TILE_F4 >> 8) ? 32 * n + ((tid >> 3) & 7) * 4 + ((tid >> 6) & 3) : (tid >> 3) + n * (THREADS / 8);
+      *(v4f*)(tileH + pb * HPIX + (tid & 7) * 16) = pre[n];
     }
 }
 
@@ -165,9 +223,13 @@ __device__ __forceinline__ void compute_sub(const char* __restrict__ tileH, cons
 #define SD_LOAD_GROUP_H(gi, buf)                                                                                        \
   do {                                                                                                                   \
     const int dx_ = (gi) >> 1, b_ = (gi) & 1;                                                                            \
+    if (!(SD_CONV_EXP & 4) || (gi) < 2) {                                                                               \
     _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                        \
       _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) A[buf][p][pl] = *(const u32x4*)(arow + htile_off(p, i + dx_, pl, b_, h)); \
+    }                                                                                                                    \
+    if (!(SD_CONV_EXP & 8) || (gi) < 2) {                                                                               \
     _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) B[buf][pl] = *(const u32x4*)(w + hw_off(dx_, b_, pl, h, i));        \
+    }                                                                                                                    \
   } while (0)
   SD_LOAD_GROUP_H(0, 0);
 #pragma unroll
@@ -177,12 +239,27 @@ __device__ __forceinline__ void compute_sub(const char* __restrict__ tileH, cons
     __builtin_amdgcn_sched_barrier(0);
     extra(gi);
     const f16x8 bh = __builtin_bit_cast(f16x8, B[buf][0]), bl = __builtin_bit_cast(f16x8, B[buf][1]);
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const f16x8 ah = __builtin_bit_cast(f16x8, A[buf][p][0]), al = __builtin_bit_cast(f16x8, A[buf][p][1]);
-      acc1[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[p], 0, 0, 0);
-      acc1[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[p], 0, 0, 0);
-      acc0[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0[p], 0, 0, 0);
+    // Issue order: no two consecutive matrix instructions share an accumulator (every tile's own sequence of additions is unchanged, so
+    // the results are the same bits): a dependent pair issued back to back stalls for the first one's passes whenever anything else
+    // -- a vector instruction of the shadow work, an operand read -- lands between them (MI355X_MICROARCH: +43 cycles per such slot).
+    {
+      const f16x8 a0h = __builtin_bit_cast(f16x8, A[buf][0][0]), a0l = __builtin_bit_cast(f16x8, A[buf][0][1]);
+      const f16x8 a1h = __builtin_bit_cast(f16x8, A[buf][1][0]), a1l = __builtin_bit_cast(f16x8, A[buf][1][1]);
+#if SD_CONV_EXP & 2
+      acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, acc1[0], 0, 0, 0);
+      acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, acc1[1], 0, 0, 0);
+      acc0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, acc0[0], 0, 0, 0);
+      acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, acc1[0], 0, 0, 0);
+      acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, acc1[1], 0, 0, 0);
+      acc0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, acc0[1], 0, 0, 0);
+#else
+      acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, acc1[0], 0, 0, 0);
+      acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, acc1[0], 0, 0, 0);
+      acc0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, acc0[0], 0, 0, 0);
+      acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, acc1[1], 0, 0, 0);
+      acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, acc1[1], 0, 0, 0);
+      acc0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, acc0[1], 0, 0, 0);
+#endif
     }
     if (NV > 0 || NLD > 0) {
 #pragma unroll
@@ -325,8 +402,30 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WP
   StageH st;
   stage_init_h(st, tid);
   const unsigned q4off = (unsigned)(tid & 7) * 16u;
+  // split16 sources: the element offsets relative to the halo's first source pixel depend on the source tensor only (resolution flags,
+  // strides), not on the tile -- kept per thread for both tensors; a tile whose halo lies inside the image then needs one select per element
+  constexpr bool PREOFF = INP && (SD_CONV_EXP & 1);
+  unsigned offk[PREOFF ? 2 : 1][PREOFF ? PRE_F4 : 1];
+  if constexpr (PREOFF) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const Src S = P.kind[k];
+      const unsigned rowb = (unsigned)((P.W >> S.shx) * S.stride * 4), pixb = (unsigned)(S.stride * 4);
+#pragma unroll
+      for (int n = 0; n < PRE_F4; ++n) {
+        const int ty = (int)(st.tyx[n] & 255u), tx = (int)(st.tyx[n] >> 8);
+        offk[k][n] = (unsigned)(((ty - S.shy) >> S.shy) + S.shy) * rowb + ((unsigned)(((tx - S.shx) >> S.shx) + S.shx) * pixb + q4off);
+      }
+    }
+  }
+  const SrcS S0 = src_scalars(P, 0), S1 = src_scalars(P, 1);
+  DimS dim;
+  dim.D = __builtin_amdgcn_readfirstlane(P.D); dim.H = __builtin_amdgcn_readfirstlane(P.H); dim.W = __builtin_amdgcn_readfirstlane(P.W);
+  dim.kz = __builtin_amdgcn_readfirstlane(P.kz); dim.n0 = __builtin_amdgcn_readfirstlane(P.n_chunks0);
   TileAddr Tc, Tn;                                      // the tile being computed, the tile whose first unit is fetched next
-  tile_addr(P, q, Tc);
+  TileWalk walk;
+  walk_init(P, q, Q, walk);
+  tile_at(P, walk, Tc);
   Tn = Tc;
   float amax = 0.f, amax_out = 0.f;
   {
@@ -363,6 +462,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WP
       unsigned addr[PRE_F4];
       u32x2 pk[INP ? 1 : PRE_F4][2];
       HaloRsrc hs;
+      UnitS us;                         // (PREOFF) the next unit's source: resource, tile position, source tensor, "halo inside the image"
       // dy 0: its matrix instructions hide the address arithmetic of the next unit's halo; dy 1 issues its weight loads FIRST and the
       // halo loads after them (the wait for the weights leaves the halo in flight); dy 2 splits the halo elements into their fp16
       // planes (registers) as they arrive; after its barrier only the LDS stores are left.
@@ -373,13 +473,39 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WP
         // (always issued, from a valid address even when there is nothing left to fetch)
         weights_fetch(P, g, lastdy ? (have ? un : u) : u, lastdy ? (have ? 0 : dy) : dy + 1, wreg, tid);      // next sub-unit's weights
         __builtin_amdgcn_sched_barrier(0);
-        if (dy == 0 && last && have) tile_addr(P, tn, Tn);                                     // (once per tile)
-        __builtin_amdgcn_sched_barrier(0);
         PROF(dy);
+        if (!PREOFF && dy == 0 && last && have) { walk_step(P, walk); tile_at(P, walk, Tn); }   // (once per tile; no division)
+        __builtin_amdgcn_sched_barrier(0);
+        if (dy == 0) PROF(14);
         const char* wcur = W + wb * HWSUB_BYTES;
-        if (dy == 0) {
+        if (PREOFF && dy == 1 && !us.in) {
+          // a tile at the image border (wave-uniform): elements outside the image get the offset the hardware answers with zeros
+#pragma unroll
+          for (int n = 0; n < PRE_F4; ++n) {
+            const int ty = (int)(st.tyx[n] & 255u), tx = (int)(st.tyx[n] >> 8);
+            const bool inside = (int)((unsigned)(us.ty0 + ty) < (unsigned)us.H) & (int)((unsigned)(us.tx0 + tx) < (unsigned)us.W);
+            addr[n] = inside ? addr[n] : HALO_OUTSIDE;
+          }
+        }
+        if (dy == 0 && PREOFF) {
+          // the next unit's source (scalar registers only: the next tile's position once per tile, the unit's plane and tensor) and its
+          // element offsets (one select each) -- all of it between this sub-unit's matrix instructions
+          compute_sub<1, 0>(tileH, wcur, dy, acc0, acc1, wave, lane & 31, lane >> 5, [&](int gi) {
+            if (gi == 0) {
+              if (last && have) { walk_step(P, walk); tile_at_s(S0, S1, dim, walk, Tn); }
+              us = unit_scalars(S0, S1, dim, tile_select(last && have, Tc, Tn), have ? un : u);
+            } else {
+              const bool k1 = us.k != 0;
+#pragma unroll
+              for (int n = (gi - 1) * 3; n < (gi - 1) * 3 + 3; ++n)
+                if (n < PRE_F4) { unsigned a = k1 ? offk[1][PREOFF ? n : 0] : offk[0][PREOFF ? n : 0]; asm volatile("" : "+v"(a)); addr[n] = a; }
+            }
+          });
+        } else if (dy == 0) {
           const TileAddr T = tile_select(last && have, Tc, Tn);
-          hs = halo_rsrc(P, halo_base(P, T, have ? un : u), T);
+          const HaloBase hb = halo_base(P, T, have ? un : u);
+          hs = halo_rsrc(P, hb, T);
+          PROF(8);
           compute_sub<5, 0>(tileH, wcur, dy, acc0, acc1, wave, lane & 31, lane >> 5, [&](int gi) {
 #pragma unroll
             for (int n = gi * 2; n < gi * 2 + 2; ++n)
@@ -389,7 +515,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WP
           compute_sub<0, 2>(tileH, wcur, dy, acc0, acc1, wave, lane & 31, lane >> 5, [&](int gi) {      // the next unit's halo loads
 #pragma unroll
             for (int n = gi * 2; n < gi * 2 + 2; ++n)
-              if (n < PRE_F4) pre[n] = halo_load_one(hs, addr[n]);
+              if (n < PRE_F4) pre[n] = PREOFF ? __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(us.rsrc, (int)addr[n], 0, 0)) : halo_load_one(hs, addr[n]);
           });
         } else if (INP) {
           compute_sub<0, 0>(tileH, wcur, dy, acc0, acc1, wave, lane & 31, lane >> 5, [&](int) {});
@@ -490,7 +616,7 @@ static int conv3_f16x3_launch(const float* d_src0, int c0, int stride0, int up0,
   for (int k = 0; k < MAX_CHUNKS; ++k) { P.chunk_kind[k] = 0; P.chunk_choff[k] = 0; }
   for (int k = 0; k < c0 / 32; ++k) { P.chunk_kind[nc] = 0; P.chunk_choff[nc++] = k * 32; }
   if (d_src1) for (int k = 0; k < c1 / 32; ++k) { P.chunk_kind[nc] = 1; P.chunk_choff[nc++] = k * 32; }
-  P.D = D; P.H = H; P.W = W; P.kz = kz; P.n_units = nc * kz;
+  P.D = D; P.H = H; P.W = W; P.kz = kz; P.n_units = nc * kz; P.n_chunks0 = c0 / 32;
   P.zero = d_wpacked + (n_packed - 4);
   if (d_res && (res_stride < c_out || (res_stride & 3) || ((uintptr_t)d_res & 15))) {
     sd::set_error("sd_conv3_f16x3: the residual needs 16-byte alignment and a stride >= c_out");

@@ -167,8 +167,12 @@ typedef float sp_f8 __attribute__((ext_vector_type(8)));
 
 // Max pooling of a split16 tensor: the element of the window whose VALUE is largest is copied (both of its terms).  x -> (hi, lo') is
 // monotone, so this is the pair the consumer would derive from max(x): the pooled split16 tensor equals split(maxpool(f32 tensor))
-// bit for bit.  Two pairs with the same value (hi + half a step, hi' - half a step) can only come from x < x': the larger hi wins.
-// Thread per (output pixel, chunk, octet).
+// bit for bit.  Two pairs with the same value (hi + half a step, hi' - half a step; or -0 and +0) can only come from x < x': the larger
+// hi wins, in the total order that puts -0 below +0 (what v_max_f32 does with the f32 values).  Thread per (output pixel, chunk, octet).
+__device__ __forceinline__ unsigned sp_order_key(_Float16 h) {
+  const unsigned b = __builtin_bit_cast(unsigned short, h);
+  return (b & 0x8000u) ? (~b & 0xFFFFu) : (b | 0x8000u);
+}
 __global__ void __launch_bounds__(256) k_maxpool_split16(const sp_h8* __restrict__ in, sp_h8* __restrict__ out, long long n_out, int C32, int Ho, int Wo,
                                                          int H, int W, int pz, int py, int px) {
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -179,20 +183,25 @@ __global__ void __launch_bounds__(256) k_maxpool_split16(const sp_h8* __restrict
     const int xo = (int)(pix % Wo); pix /= Wo;
     const int yo = (int)(pix % Ho);
     const long long zo = pix / Ho;
+    // per channel: the pair with the largest (value, hi) in the total order of their bit patterns, as ONE 48-bit integer key
     sp_h8 bh = {}, bl = {};
-    sp_f8 bv = {};
-    bool first = true;
+    unsigned long long bk[8] = {};
     for (int dz = 0; dz < pz; ++dz)
       for (int dy = 0; dy < py; ++dy) {
         const sp_h8* row = in + ((((zo * pz + dz) * H + ((long long)yo * py + dy)) * W + (long long)xo * px) * C32 + c) * 8 + o;
         for (int dx = 0; dx < px; ++dx) {
           const sp_h8 h = row[(long long)dx * C32 * 8], l = row[(long long)dx * C32 * 8 + 4];
           const sp_f8 v = __builtin_convertvector(h, sp_f8) + __builtin_convertvector(l, sp_f8) * 4.8828125e-4f;
-          if (first) { bh = h; bl = l; bv = v; first = false; continue; }
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            const bool take = v[k] > bv[k] || (v[k] == bv[k] && (float)h[k] > (float)bh[k]);
-            if (take) { bh[k] = h[k]; bl[k] = l[k]; bv[k] = v[k]; }
+            const float vk = v[k];                          // (a scalar copy: __builtin_bit_cast on the vector ELEMENT compiled to element 0's bits for every k)
+            const unsigned fb = __float_as_uint(vk);
+            const unsigned fk = (fb & 0x80000000u) ? ~fb : (fb | 0x80000000u);
+            const unsigned long long key = (((unsigned long long)fk << 16) | (unsigned long long)sp_order_key(h[k])) + 1ull;      // (> 0: beats the empty slot)
+            const bool take = key > bk[k];
+            bk[k] = take ? key : bk[k];
+            bh[k] = take ? h[k] : bh[k];
+            bl[k] = take ? l[k] : bl[k];
           }
         }
       }

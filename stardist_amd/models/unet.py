@@ -610,25 +610,31 @@ class UNetBlock(nn.Module):
 
 
 class ResNetBlock(nn.Module):
-    """csbdeep resnet_block(n_filter, kernel_size, pool, n_conv_per_block, activation): first conv strided by
-    `pool`, last conv linear, 1x1 strided projection on the shortcut when shape changes, add, activation."""
+    """csbdeep resnet_block(n_filter, kernel_size, pool, n_conv_per_block, batch_norm, activation): first conv strided by
+    `pool`, last conv linear, 1x1 strided projection on the shortcut when shape changes, add, activation.
+    batch_norm=True (model3d.py:402-412 hands resnet_batch_norm through): every convolution of the block is bias-free
+    (use_bias = not batch_norm, the shortcut projection included) and each BODY convolution -- the last one too, i.e. before the
+    Add -- is followed by a BatchNormalization; the projection has none."""
 
-    def __init__(self, nd, cin, n_filter, kernel_size, pool, n_conv_per_block, activation):
+    def __init__(self, nd, cin, n_filter, kernel_size, pool, n_conv_per_block, activation, batch_norm=False):
         super().__init__()
         Conv = nn.Conv2d if nd == 2 else nn.Conv3d
+        BN = nn.BatchNorm2d if nd == 2 else nn.BatchNorm3d
         k = tuple(kernel_size)
         pad = tuple(kk // 2 for kk in k)
         self.pool = tuple(pool)
         self.k = k
-        self.first = Conv(cin, n_filter, k, stride=self.pool, padding=0)   # Keras 'same' + stride pads asymmetrically
-        layers = [_act(activation)]
+        bias = not batch_norm
+        bn = (lambda: [BN(n_filter, eps=1e-3, momentum=0.01)]) if batch_norm else (lambda: [])       # Keras defaults (see _conv)
+        self.first = Conv(cin, n_filter, k, stride=self.pool, padding=0, bias=bias)   # Keras 'same' + stride pads asymmetrically
+        layers = bn() + [_act(activation)]
         for _ in range(n_conv_per_block - 2):
-            layers += [Conv(n_filter, n_filter, k, padding=pad), _act(activation)]
-        layers += [Conv(n_filter, n_filter, k, padding=pad)]
+            layers += [Conv(n_filter, n_filter, k, padding=pad, bias=bias)] + bn() + [_act(activation)]
+        layers += [Conv(n_filter, n_filter, k, padding=pad, bias=bias)] + bn()
         self.body = nn.Sequential(*layers)
         self.proj = None
         if any(p != 1 for p in self.pool) or cin != n_filter:
-            self.proj = Conv(cin, n_filter, (1,) * nd, stride=self.pool)
+            self.proj = Conv(cin, n_filter, (1,) * nd, stride=self.pool, bias=bias)
         self.act = _act(activation)
 
     def _same_pad(self, x):
@@ -640,29 +646,44 @@ class ResNetBlock(nn.Module):
             pads += [total // 2, total - total // 2]
         return F.pad(x, pads)
 
+    def _stages(self):
+        """[(conv, batch-norm or None, activation module or None)] in graph order: the strided first convolution, then the body's"""
+        BNs = (nn.BatchNorm2d, nn.BatchNorm3d)
+        out, cur = [], [self.first, None, None]
+        for m in self.body:
+            if isinstance(m, (nn.Conv2d, nn.Conv3d)):
+                out.append(tuple(cur))
+                cur = [m, None, None]
+            elif isinstance(m, BNs):
+                cur[1] = m
+            else:
+                cur[2] = m
+        out.append(tuple(cur))
+        return out
+
     def _forward_hand(self, x):
         """the block on the hand-written kernels: strided first convolution (TensorFlow 'same' padding) with its activation, body
-        convolutions, the strided 1x1 projection, and Add + Activation folded into the last convolution's epilogue"""
+        convolutions, the strided 1x1 projection, and Add + Activation folded into the last convolution's epilogue; batch-norm layers
+        folded into the (bias-free) kernels and a bias -- the last one before the Add, as the reference's graph has it"""
         kind = lambda a: 0 if isinstance(a, nn.Identity) else (1 if isinstance(a, nn.ReLU) else -1)
-        layers = list(self.body)
-        if not (kind(layers[0]) >= 0 and kind(self.act) >= 0):
+        stages = self._stages()
+        if not (all(kind(a) >= 0 for _, _, a in stages[:-1]) and kind(self.act) >= 0):
             raise UnsupportedLayer("resnet_block activation %s" % type(self.act).__name__)
+        if any(b is not None and b.training for _, b, _ in stages):
+            raise UnsupportedLayer("resnet_block with batch-norm layers in training mode")
 
         def need(y, conv, src):
             if y is None:
                 raise UnsupportedLayer("resnet_block " + _layer_desc(conv, [(src, 0)]))
             return y
-        y = need(_hand_conv(self.first, [(x, 0)], kind(layers[0]), tf_same=True), self.first, x)
+        conv, bn, act = stages[0]
+        y = need(_hand_conv(conv, [(x, 0)], kind(act), bn=bn, tf_same=True), conv, x)
         sc = x
         if self.proj is not None:
             sc = need(_hand_conv(self.proj, [(x, 0)], 0, tf_same=True), self.proj, x)
-        convs = [(layers[k], layers[k + 1] if k + 1 < len(layers) else None) for k in range(1, len(layers), 2)]
-        for conv, act in convs:
+        for conv, bn, act in stages[1:]:
             last = act is None
-            k = kind(self.act) if last else kind(act)
-            if k < 0:
-                raise UnsupportedLayer("resnet_block activation %s" % type(act).__name__)
-            y = need(_hand_conv(conv, [(y, 0)], k, res=sc if last else None), conv, y)
+            y = need(_hand_conv(conv, [(y, 0)], kind(self.act) if last else kind(act), res=sc if last else None, bn=bn), conv, y)
         return y
 
     def forward(self, x):
@@ -701,10 +722,6 @@ class StarDistNet(nn.Module):
             c = self.backbone.out_channels
             n_after, k_after, act_after = cfg.net_conv_after_unet, cfg.unet_kernel_size, cfg.unet_activation
         elif cfg.backbone == "resnet":                                 # model3d.py:402-447
-            if getattr(cfg, "resnet_batch_norm", False):
-                # csbdeep's resnet_block(batch_norm=True) puts a BatchNormalization behind every bias-free convolution: not built here --
-                # refuse loudly instead of predicting with a network that silently lacks those layers
-                raise UnsupportedLayer("resnet_batch_norm=True: the batch-normalised ResNet backbone is not implemented")
             n_filter = cfg.resnet_n_filter_base
             blocks = [_conv(nd, c, n_filter, (7,) * nd, None),        # linear (no activation) model3d.py:416-417
                       _conv(nd, n_filter, n_filter, (3,) * nd, None)]
@@ -716,7 +733,7 @@ class StarDistNet(nn.Module):
                 if any(p > 1 for p in pool):
                     n_filter *= 2
                 blocks.append(ResNetBlock(nd, c, n_filter, cfg.resnet_kernel_size, tuple(int(p) for p in pool),
-                                          cfg.resnet_n_conv_per_block, cfg.resnet_activation))
+                                          cfg.resnet_n_conv_per_block, cfg.resnet_activation, bool(getattr(cfg, "resnet_batch_norm", False))))
                 c = n_filter
             self.backbone = nn.Sequential(*blocks)
             n_after, k_after, act_after = cfg.net_conv_after_resnet, cfg.resnet_kernel_size, cfg.resnet_activation

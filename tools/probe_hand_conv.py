@@ -10,7 +10,8 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _probe_lib  # noqa: E402,F401  (STARDIST_AMD_PROBE_LIB: a variant build of the library)
 import stardist_amd  # noqa: E402,F401
 from stardist_amd.lib import _native as N  # noqa: E402
 from stardist_amd.models import unet as U  # noqa: E402
@@ -27,7 +28,9 @@ def timeit(fn, reps):
     return a.elapsed_time(b) / reps
 
 
-MODES = [("hand", "hand", 2), ("bf16x6", "bf16x6", 2), ("f16x3", "f16x3", 2), ("f16x3/1wg", "f16x3", 1)]
+MODES = [("hand", "hand", 2), ("bf16x6", "bf16x6", 2), ("f16x3", "f16x3", 2), ("f16x3/1wg", "f16x3", 1), ("f16x3/s16", "f16x3", 2)]
+if os.environ.get("PROBE_F16_ONLY") == "1":
+    MODES = [m for m in MODES if m[0] in ("f16x3", "f16x3/s16")]
 
 
 def layer(nd, shape, chans, cout, reps, dev, totals):
@@ -40,12 +43,23 @@ def layer(nd, shape, chans, cout, reps, dev, totals):
     ref = None
     with torch.no_grad():
         for tag, mode, wgs in MODES:
-            if cin < 32 and tag != "hand":
+            if cin < 32 and tag not in ("hand", "f16x3/s16"):
                 continue
             N.check(N.lib().sd_set_option(b"conv_f16_workgroups_per_cu", wgs))
+            use = srcs
+            if tag.endswith("/s16"):
+                # split16 tensors on both sides (the features layer, c_out 128, writes f32 for the heads)
+                if cin < 32:
+                    conv.__dict__["_sd_split_out"] = True
+                else:
+                    use = [(U.split16_pack(t), up) for t, up in srcs]
+                    conv.__dict__["_sd_split_out"] = cout != 128
             with U.force_conv_mode(mode):
-                t = timeit(lambda: U._hand_conv(conv, srcs, 1), reps)
-                y = U._hand_conv(conv, srcs, 1)
+                t = timeit(lambda: U._hand_conv(conv, use, 1), reps)
+                y = U._hand_conv(conv, use, 1)
+            conv.__dict__["_sd_split_out"] = False
+            y = U.split16_unpack(y)
+            del use
             if ref is None:
                 ref, dev_ = y, float("nan")
             else:
