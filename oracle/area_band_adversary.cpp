@@ -9,7 +9,7 @@
 // half-steps, thin spikes, nested K = 0 pairs, long nearly parallel edges), linked against the vendored Clipper where it lies
 // (oracle/Makefile: _ref/area_band_adversary).  The enclosure below is a host restatement of area_bounds.h (same predicates, same K, T,
 // band; predicates in exact integer arithmetic, area in double -- the device's float rounding is a term of B).
-//   usage: area_band_adversary <seed> <restarts> <iterations per restart> [mode: 0 star (NMS-realisable polygons), 1 free integer polygons, 2 both]
+//   usage: area_band_adversary <seed> <restarts> <iterations per restart> [mode: 0 star (NMS-realisable polygons), 1 free integer polygons, 2 both] [self rule 1|0] [near-pair weight, default 0.15] [strip weight, default 0.45]
 // Prints one line per new overall worst (with the vertices, so a counter-example can be replayed) and a summary per start family.
 #include "clipper.hpp"
 #include <cmath>
@@ -27,6 +27,7 @@ struct Poly { int n; i64 x[MAXR], y[MAXR]; };
 struct Props { double lmax, perim; bool plain; int orient; i64 xmin, xmax, ymin, ymax; };
 
 static int g_self_rule = 1;
+static double g_near_w = 0.15, g_strip_w = 0.45;      // band weights of a near edge pair / of a strip (area_bounds.h NEAR_W, STRIP_W; round 5: 0.125 and no strip term)
 static int sgn(i64 v) { return v > 0 ? 1 : (v < 0 ? -1 : 0); }
 
 // area_bounds.h k_poly_props
@@ -102,6 +103,7 @@ static Encl enclosure(const Poly& P, const Poly& Q, const Props& pp, const Props
   const bool sPpos = pp.orient > 0, sQpos = pq.orient > 0;
   double tot = 0;
   int K = 0, T = 0;
+  bool nearP[MAXR] = {}, nearQ[MAXR] = {};      // edges with at least one near partner: the strips
   const int n = P.n, m = Q.n;
   // c inside P, per vertex of Q: parity over the edges of P
   for (int l = 0; l < n; ++l) {
@@ -121,7 +123,7 @@ static Encl enclosure(const Poly& P, const Poly& Q, const Props& pp, const Props
       const bool pos_c = o_ec > 0 || (o_ec == 0 && tie_e_pos), pos_d = o_ed > 0 || (o_ed == 0 && tie_e_pos);
       const bool pos_a = o_fa > 0 || (o_fa == 0 && tie_f_pos), pos_b = o_fb > 0 || (o_fb == 0 && tie_f_pos);
       const bool both = oke && okf;
-      if (both && (cx <= exhi || dx <= exhi) && (cx >= exlo || dx >= exlo) && (cy <= eyhi || dy <= eyhi) && (cy >= eylo || dy >= eylo)) ++T;
+      if (both && (cx <= exhi || dx <= exhi) && (cx >= exlo || dx >= exlo) && (cy <= eyhi || dy <= eyhi) && (cy >= eylo || dy >= eylo)) { ++T; nearP[l] = nearQ[k] = true; }
       if (both && pos_c != pos_d && pos_a != pos_b) {
         const double t = (double)o_fa / (double)(o_fa - o_fb), u = (double)o_ec / (double)(o_ec - o_ed);
         accP += (pos_b == sQpos) ? (1.0 - t) : -(1.0 - t);
@@ -148,7 +150,11 @@ static Encl enclosure(const Poly& P, const Poly& Q, const Props& pp, const Props
     if (par) tot += (double)(cx * dy - cy * dx);
   }
   E.area = 0.5 * std::fabs(tot); E.K = K; E.T = T;
-  E.band = (0.5 * K + 0.125 * T) * (pp.lmax + pq.lmax) + 0.75 + 2e-6 * (double)ext * (pp.perim + pq.perim);
+  int SP = 0, SQ = 0;
+  for (int l = 0; l < n; ++l) SP += nearP[l];
+  for (int k = 0; k < m; ++k) SQ += nearQ[k];
+  const int S = std::max(SP, SQ);
+  E.band = (0.5 * K + std::max(g_near_w * T, g_strip_w * S)) * (pp.lmax + pq.lmax) + 0.75 + 2e-6 * (double)ext * (pp.perim + pq.perim);
   i64 M = 0, My = 0;
   const i64 xs[4] = {pp.xmin, pp.xmax, pq.xmin, pq.xmax}, ys[4] = {pp.ymin, pp.ymax, pq.ymin, pq.ymax};
   for (int k = 0; k < 4; ++k) { M = std::max(M, std::llabs(xs[k])); My = std::max(My, std::llabs(ys[k])); }
@@ -316,6 +322,8 @@ int main(int argc, char** argv) {
   const int iters = argc > 3 ? atoi(argv[3]) : 2000;
   const int mode = argc > 4 ? atoi(argv[4]) : 2;
   if (argc > 5) g_self_rule = atoi(argv[5]);
+  if (argc > 6) g_near_w = atof(argv[6]);
+  if (argc > 7) g_strip_w = atof(argv[7]);
   init_tables();
   Rng r(seed * 0x9E3779B97F4A7C15ull + 12345);
   double worst = 0, famWorst[NFAM][2]; memset(famWorst, 0, sizeof(famWorst));

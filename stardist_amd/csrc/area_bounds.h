@@ -18,7 +18,8 @@
 //        flow: 32 lanes per pair, lane = edge of P, loop over the edges of Q.
 //   K  = the number of boundary crossings, T = the number of edge pairs (e of P, f of Q) whose bounding boxes come within one lattice
 //        step of each other, and the band
-//        B = (0.5 K + 0.125 T) (lmax_P + lmax_Q) + 0.75 + (float error term).
+//        B = (0.5 K + max(NEAR_W T, STRIP_W S)) (lmax_P + lmax_Q) + 0.75 + (float error term),   NEAR_W = 0.15, STRIP_W = 0.45 (round 5:
+//        0.125 T alone), S = the number of STRIPS = edges with at least one near partner (the larger of the two polygons' counts).
 //        Three mechanisms separate Clipper's area from A.  (1) It rounds each of the K crossing points to the lattice: moving one vertex
 //        of a polygon by delta changes its area by |delta x (v_next - v_prev)| / 2 <= 0.71 (|e| + |f|) / 2 -- at most 0.36 (lmax_P +
 //        lmax_Q) per crossing (PROVEN for a crossing that is not clamped to its scan beam; the band carries 0.5).  (2) It orders the
@@ -26,7 +27,11 @@
 //        tie, be inserted in the wrong order and later be "uncrossed", which moves the strip between them -- at most one step wide and
 //        as long as the shorter edge -- to the wrong side (K = 0 pairs with a deviation of 0.5 exist: tests/test_cpu_area_enclosure.py);
 //        along nearly coincident boundaries every edge is near about three edges of the other polygon, so T counts each such strip
-//        about three times: the 0.125 is EMPIRICAL.  (3) A polygon whose OWN vertex lies within half a step of one of its own edges
+//        about three times (measured on bench-like pairs: T / S = 2.7 .. 3.7): NEAR_W T charges a strip about 0.45 there, but charged the
+//        ISOLATED near pairs of polygons with few long edges a third of that -- exactly the regime in which the round-5 adversary found its
+//        smallest margins (0.53 of the band on K = 0, T = 3 pairs).  Round 6 charges every strip STRIP_W = 0.45 whatever the count splits
+//        into, and raised NEAR_W from 0.125 to 0.15: both changes are monotone (the band only grows: pairs only LEAVE the shortcut for
+//        the exact sweep, earlier evidence stays valid); the weights are EMPIRICAL.  (3) A polygon whose OWN vertex lies within half a step of one of its own edges
 //        is re-ordered by Clipper on its own (found by the adversarial search of round 5): such polygons are not "robustly simple"
 //        (k_poly_props) and are never decided here.
 //        Evidence for the band: 3.6 M GPU pairs of nine families against the exact sweep (worst 0.28 B), 18 M CPU pairs against the
@@ -51,6 +56,7 @@ __device__ __forceinline__ int half_sum_i(int v) { for (int o = 16; o; o >>= 1) 
 __device__ __forceinline__ int half_min_i(int v) { for (int o = 16; o; o >>= 1) { const int t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
 __device__ __forceinline__ int half_max_i(int v) { for (int o = 16; o; o >>= 1) { const int t = __shfl_xor(v, o); v = t > v ? t : v; } return v; }
 
+constexpr float NEAR_W = 0.15f, STRIP_W = 0.45f;   // band weights of an edge pair within one lattice step / of a strip (mechanism 2); tests/_area_exact.py and oracle/area_band_adversary.cpp carry the same values
 constexpr int WINDOW = 2047;        // largest |relative coordinate| for which every predicate's products stay below 2^24
 
 // Per polygon (two polygons per wave, lane & 31 = edge): longest edge, L1 perimeter, orientation, integer bounding box and whether the
@@ -181,7 +187,8 @@ __device__ __forceinline__ Enclosure pair_enclosure(const int* __restrict__ px, 
   const bool sPpos = (pp.flags & PP_POS) != 0, sQpos = (pq.flags & PP_POS) != 0;
   const float exlo = fminf(ax, bx) - 1.f, exhi = fmaxf(ax, bx) + 1.f, eylo = fminf(ay, by) - 1.f, eyhi = fmaxf(ay, by) + 1.f;
   float accP = 0.f, accQ = 0.f;
-  int K = 0, T = 0, parA = 0;
+  int K = 0, T = 0, parA = 0, SQ = 0;
+  bool nearP = false;
   float2 c = sq[0];
   float o_ec = ex * (c.y - ay) - ey * (c.x - ax);
   const int Rw = __any(use) ? R : 0;                // (`use` is uniform within a half; the ballot in the loop is wave-wide)
@@ -198,7 +205,13 @@ __device__ __forceinline__ Enclosure pair_enclosure(const int* __restrict__ px, 
     const float ccd = c.x * d.y - c.y * d.x;
     const bool both = oke & okf;
     // edge pairs closer than one lattice step (bounding boxes)
-    T += (both & ((c.x <= exhi) | (d.x <= exhi)) & ((c.x >= exlo) | (d.x >= exlo)) & ((c.y <= eyhi) | (d.y <= eyhi)) & ((c.y >= eylo) | (d.y >= eylo))) ? 1 : 0;
+    const bool nearb = both & ((c.x <= exhi) | (d.x <= exhi)) & ((c.x >= exlo) | (d.x >= exlo)) & ((c.y <= eyhi) | (d.y <= eyhi)) & ((c.y >= eylo) | (d.y >= eylo));
+    T += nearb ? 1 : 0;
+    nearP |= nearb;
+    {                                               // Q's edge f has a near partner among P's edges (the same value in every lane of the half)
+      const unsigned long long nb64 = __ballot(nearb);
+      SQ += ((unsigned int)(half ? (nb64 >> 32) : nb64) != 0u) ? 1 : 0;
+    }
     if (both & (pos_c != pos_d) & (pos_a != pos_b)) {                                         // e and f cross
       const float t = o_fa * __builtin_amdgcn_rcpf(o_fa - o_fb), u = o_ec * __builtin_amdgcn_rcpf(o_ec - o_ed);   // (1 ulp: far inside the band)
       const float wt = 1.f - t, wu = 1.f - u;
@@ -216,11 +229,12 @@ __device__ __forceinline__ Enclosure pair_enclosure(const int* __restrict__ px, 
   const float cab = ax * by - ay * bx;
   const float contrib = lv ? cab * ((float)parA + accP) + accQ : 0.f;
   const float tot = half_sum(contrib);
-  const int Kt = half_sum_i(lv ? K : 0), Tt = half_sum_i(lv ? T : 0);
+  const int Kt = half_sum_i(lv ? K : 0), Tt = half_sum_i(lv ? T : 0), SPt = half_sum_i((lv && nearP) ? 1 : 0);
+  const int St = SPt > SQ ? SPt : SQ;              // strips: edges with at least one near partner, the larger of the two polygons' counts
   E.area = 0.5f * fabsf(tot);
   E.crossings = Kt; E.near = Tt;
   // float error of the sum: <= 64 terms of magnitude <= ext * edge length, each with a few ulps
-  E.band = (0.5f * (float)Kt + 0.125f * (float)Tt) * (pp.lmax + pq.lmax) + 0.75f + 2e-6f * (float)ext * (pp.perim + pq.perim);
+  E.band = (0.5f * (float)Kt + fmaxf(NEAR_W * (float)Tt, STRIP_W * (float)St)) * (pp.lmax + pq.lmax) + 0.75f + 2e-6f * (float)ext * (pp.perim + pq.perim);
   // area_from_path adds integer cross products in float: exact while the sum of their magnitudes stays below 2^24
   // (|p_i x p_{i+1}| <= |p_i| |p_{i+1} - p_i|; the output's edges are parts of the inputs' edges, crossing points moved by < 1.5)
   if (use) {

@@ -4,6 +4,12 @@ polygon by (eps, eps^2); `plain` = the polygon is simple once zero-length edges 
 (sd_area_bounds_pairs_device) is compared with it, and both with Clipper's area (oracle/_ref on the CPU, sd_clip_pairs_device on the GPU)."""
 import numpy as np
 
+# band weights (stardist_amd/csrc/area_bounds.h NEAR_W, STRIP_W): of an edge pair within one lattice step (round 5: 0.125) and of a STRIP
+# = an edge with at least one near partner (round 6: along nearly coincident boundaries every edge is near about three edges of the other
+# polygon, so 0.15 T already charges each strip 0.45; a pair with FEW near pairs -- each its own strip -- was charged a third of that)
+NEAR_W = 0.15
+STRIP_W = 0.45
+
 
 def sgn(v):
     return np.sign(v).astype(np.int8)
@@ -106,9 +112,26 @@ def plain(X, Y):
     return out
 
 
-def band(K, T, lmaxP, lmaxQ, ext, perimP, perimQ):
-    """half-width of the enclosure of Clipper's area around the exact one (area_bounds.h)"""
-    return (0.5 * K + 0.125 * T) * (lmaxP + lmaxQ) + 0.75 + 2e-6 * ext * (perimP + perimQ)
+def band(K, T, lmaxP, lmaxQ, ext, perimP, perimQ, S=None):
+    """half-width of the enclosure of Clipper's area around the exact one (area_bounds.h); T = near edge pairs, S = strips (near_strips;
+    None: the T term alone)"""
+    near = NEAR_W * T if S is None else np.maximum(NEAR_W * T, STRIP_W * S)
+    return (0.5 * K + near) * (lmaxP + lmaxQ) + 0.75 + 2e-6 * ext * (perimP + perimQ)
+
+
+def _near_matrix(PX, PY, QX, QY):
+    ax, ay = PX[:, :, None], PY[:, :, None]; bx, by = np.roll(PX, -1, 1)[:, :, None], np.roll(PY, -1, 1)[:, :, None]
+    cx, cy = QX[:, None, :], QY[:, None, :]; dx, dy = np.roll(QX, -1, 1)[:, None, :], np.roll(QY, -1, 1)[:, None, :]
+    ox = np.maximum(np.minimum(ax, bx), np.minimum(cx, dx)) - np.minimum(np.maximum(ax, bx), np.maximum(cx, dx))
+    oy = np.maximum(np.minimum(ay, by), np.minimum(cy, dy)) - np.minimum(np.maximum(ay, by), np.maximum(cy, dy))
+    ok = ((ax != bx) | (ay != by)) & ((cx != dx) | (cy != dy))
+    return ok & (ox <= 1) & (oy <= 1)
+
+
+def near_strips(PX, PY, QX, QY):
+    """number of strips: max over the two polygons of the number of edges with at least one near partner (near_pairs' criterion)"""
+    m = _near_matrix(PX, PY, QX, QY)
+    return np.maximum(m.any(2).sum(1), m.any(1).sum(1))
 
 
 def near_pairs(PX, PY, QX, QY):

@@ -165,7 +165,7 @@ def test_nms2d_pair_kernel_forms_agree(refmods):
 @pytest.mark.parametrize("R,radius,noise,spread", [(32, 10, 0.1, 12), (32, 10, 0.3, 25), (32, 4, 0.3, 6), (16, 25, 0.2, 30), (32, 10, 0.9, 12), (7, 12, 0.2, 14)])
 def test_area_enclosure_probe_matches_statement(R, radius, noise, spread):
     """the GPU probe against the numpy statement of the same arithmetic (tests/_area_exact.py): area, crossing count, usability"""
-    from _area_exact import exact_area, near_pairs, plain
+    from _area_exact import band as band_np, edge_stats, exact_area, near_pairs, near_strips, plain
     from stardist_amd.lib import stardist2d as sd2
     rng = np.random.RandomState(R * 7 + int(radius))
     n = 3000
@@ -178,6 +178,15 @@ def test_area_enclosure_probe_matches_statement(R, radius, noise, spread):
     assert np.array_equal(K[usable], Ks[usable])
     assert np.array_equal(T[usable], near_pairs(*(v.astype(np.int64) for v in (xa, ya, xb, yb)))[usable])
     assert np.all(np.abs(area[usable] - A[usable]) <= 2e-3 + 1e-6 * A[usable]), np.abs(area[usable] - A[usable]).max()
+    # the band itself: 0.5 K + max(NEAR_W T, STRIP_W S) per unit of (lmax_P + lmax_Q), + 0.75 + the float term of the pair's extent about
+    # the centre of P's box (round 6: the strip term)
+    i64 = [v.astype(np.int64) for v in (xa, ya, xb, yb)]
+    la, pa = edge_stats(i64[0], i64[1]); lb, pb = edge_stats(i64[2], i64[3])
+    ox = (i64[0].min(1) + i64[0].max(1)) >> 1; oy = (i64[1].min(1) + i64[1].max(1)) >> 1
+    ext = np.maximum.reduce([np.abs(i64[0] - ox[:, None]).max(1), np.abs(i64[1] - oy[:, None]).max(1), np.abs(i64[2] - ox[:, None]).max(1),
+                             np.abs(i64[3] - oy[:, None]).max(1)]).astype(np.float64)
+    want_band = band_np(Ks, near_pairs(*i64), la, lb, ext, pa, pb, near_strips(*i64))
+    assert np.allclose(band[usable], want_band[usable], rtol=2e-5, atol=1e-3), np.abs(band[usable] - want_band[usable]).max()
 
 
 @pytest.mark.parametrize("R,radius,noise,spread,scale", [(32, 10, 0.1, 12, 0.8), (32, 10, 0.03, 6, 1.0), (32, 10, 0.03, 3, 0.97), (32, 20, 0.05, 6, 0.95),

@@ -5,7 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
-from _area_exact import band, edge_stats, exact_area, near_pairs, plain
+from _area_exact import band, edge_stats, exact_area, near_pairs, near_strips, plain
 from oracle import ref
 
 FAMILIES = [  # R, radius, noise, spread of the centres, scale of the second polygon, offset of the whole pair from the origin
@@ -40,7 +40,7 @@ def main():
             us = ok & plain(xa, ya) & plain(xb, yb)
             la, pea = edge_stats(xa, ya); lb, peb = edge_stats(xb, yb)
             ext = np.maximum(np.abs(xa - xa.mean(1, keepdims=True)).max(1), np.abs(xb - xa.mean(1, keepdims=True)).max(1)) + radius
-            B = band(K, near_pairs(xa, ya, xb, yb), la, lb, ext, pea, peb)
+            B = band(K, near_pairs(xa, ya, xb, yb), la, lb, ext, pea, peb, near_strips(xa, ya, xb, yb))
             C = np.array([ref.clipper_area(xa[i], ya[i], xb[i], yb[i]) for i in range(m)], np.float64)
             d = np.abs(C - A)
             if us.any():
