@@ -163,6 +163,8 @@ def cpu_baseline_2d(img_np, model, sample, threads):
     ref.set_threads(threads)
     same = bool(np.array_equal(keep.astype(bool), keep_gpu))
     return dict(value=round(x.size / tot / 1e6, 4), unit="Mpix/s", cores=threads, kind="reference",
+                stages_s={"network(torch-CPU, TF-CPU stand-in)": round(t_net, 3), "select_sort": round(t_sel, 3), "nms(compiled reference)": round(t_nms, 3),
+                          "raster(numpy restatement of the reference's Python loop)": round(t_ras, 3)}, sample_elements=int(x.size),
                 parity_checked=same, parity="keep flags of the compiled reference NMS %s the HIP NMS on the %d candidates of the GPU path (%d survivors)"
                                             % ("==" if same else "DIFFER FROM (%d flags)" % int((keep.astype(bool) != keep_gpu).sum()), len(d), int(keep.sum())),
                 nms_only={"threads_%d" % threads: {"candidates": int(len(d)), "seconds": round(t_nms, 3), "cand_per_s": round(len(d) / t_nms)},
@@ -208,6 +210,8 @@ def cpu_baseline_3d(vol_np, model, sample, threads):
     full = sample >= vol_np.shape[0]
     same = bool(np.array_equal(keep.astype(bool), keep_gpu))
     return dict(value=round(x.size / tot / 1e6, 4), unit="Mvox/s", cores=threads, kind="reference", seconds=round(tot, 2), same_size=bool(full),
+                stages_s={"network(torch-CPU, TF-CPU stand-in)": round(t_net, 3), "select_sort": round(t_sel, 3), "nms(compiled reference incl. Qhull)": round(t_nms, 3),
+                          "raster(compiled reference)": round(t_ras, 3)}, sample_elements=int(x.size),
                 parity_checked=same, parity="keep flags of the compiled reference 3D NMS %s the HIP NMS on the %d candidates of the GPU path (%d survivors)"
                                             % ("==" if same else "DIFFER FROM (%d flags)" % int((keep.astype(bool) != keep_gpu).sum()), len(d), int(keep.sum())),
                 note=("the whole bench volume: a same-size comparison with value_3d" if full else
@@ -241,9 +245,27 @@ def run_leg(model, img, steps, warmup, world, dist_):
         pairs.append((a, b))
         return r
     model._net_forward = timed_forward
+    # the native post-processing calls, timed the same way (events on the stream the C-ABI entry points are handed)
+    nat_pairs = {"nms": [], "raster": []}
+    orig_dcall = _native.dcall
+    NAT = {"sd_nms2d_device": "nms", "sd_nms3d_device": "nms", "sd_polygons_to_label_device": "raster", "sd_polygons_to_label_window_device": "raster",
+           "sd_polyhedron_to_label_device": "raster", "sd_polyhedron_to_label_window_device": "raster"}
+
+    def timed_dcall(t, name, *a):
+        k = NAT.get(name)
+        if k is None:
+            return orig_dcall(t, name, *a)
+        with torch.cuda.device(t.device):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); r = orig_dcall(t, name, *a); e1.record()
+        nat_pairs[k].append((e0, e1))
+        return r
+    _native.dcall = timed_dcall
     for _ in range(warmup):
         res = model.predict_instances(img)
     pairs.clear()
+    for v in nat_pairs.values():
+        v.clear()
     if world > 1:
         dist_.barrier()
     torch.cuda.synchronize()
@@ -259,6 +281,9 @@ def run_leg(model, img, steps, warmup, world, dist_):
     elapsed = time.perf_counter() - t0
     net_ms = sum(a.elapsed_time(b) for a, b in pairs) / max(1, len(pairs))
     model._net_forward = orig_forward
+    _native.dcall = orig_dcall
+    for k, v in nat_pairs.items():                 # ms per step of the whole native call (every kernel, copy and host read-back inside it)
+        stats["call_ms_" + k] = sum(a.elapsed_time(b) for a, b in v) / max(1, steps)
     if world > 1:
         tt = torch.tensor([elapsed], device=img.device if dist_.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist_.all_reduce(tt, op=dist_.ReduceOp.MAX)
@@ -315,6 +340,21 @@ def run_mode_leg(model, img, steps, warmup, world, dist_, mode):
         model.__dict__.pop("_graphs", None)
         if graphs is not None:
             model._graphs = graphs
+
+
+def stage_ratios(cpu, gpu_stages, n_elements):
+    """per-stage time ratios reference-CPU / this path, each scaled to the same number of pixels (the CPU sample may be a crop): the whole-step
+    ratio mixes a flagged network stand-in, the compiled reference natives and (2D) a numpy restatement of the reference's Python
+    rasteriser loop -- quote the stages, not the quotient of the totals.  A reported baseline, not a target."""
+    try:
+        st, ne = cpu["stages_s"], float(cpu["sample_elements"])
+        per = lambda sec: sec / ne * n_elements * 1e3                      # CPU ms for the GPU step's number of elements
+        g = {"network": gpu_stages["unet_forward"], "nms": gpu_stages["nms"], "raster": gpu_stages["raster"]}
+        c = {"network": per([v for k, v in st.items() if k.startswith("network")][0]), "nms": per([v for k, v in st.items() if k.startswith("nms")][0]),
+             "raster": per([v for k, v in st.items() if k.startswith("raster")][0])}
+        return {k: {"cpu_ms": round(c[k], 1), "gpu_ms": round(g[k], 3), "ratio": round(c[k] / g[k], 1) if g[k] > 0 else None} for k in g}
+    except Exception as e:       # pragma: no cover
+        return {"error": repr(e)[:120]}
 
 
 def predicted_scaling(per_block, t_exchange, t_final_nms, t_raster_local, s_pass_n1):
@@ -593,7 +633,7 @@ def main():
                       "instances": len(res_s[1]["prob"]),
                       "same_result_as_default": bool(np.array_equal(res_s[0], res[0]) and np.array_equal(res_s[1]["points"], res[1]["points"])),
                       "note": "sd_set_option('nms2d_strict', 1): every 2D pair decided by the Clipper-exact sweep (bit-exact by construction); the default decides "
-                              "pairs far from the threshold from an empirically / adversarially validated band around the exact area (DESIGN.md 3.4)"}
+                              "pairs far from the threshold from an adversarially validated band around the exact area (DESIGN.md 3.4)"}
     out = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -606,9 +646,16 @@ def main():
         # algorithmic bytes of the pair kernel: SURVEY.md 8(d) pair-traffic model B_pair = 2*(4R+4D) = 272 B per pair (R=32, D=2)
         pair_bytes_per_launch = 272.0 * n_pairs / pair_launches
         pair_gbs = pair_bytes_per_launch / max(1e-9, (pair_ms / pair_launches) * 1e-3) / 1e9
-        stages = {"unet_forward": round(net_ms, 3), "nms_pair_kernel": round(float(pair_ms), 3),
-                  "nms_exact_join_kernel": round(float(s2[6] / 1e6), 3), "nms_build_bin_neighbours": round(float(s2[7] / 1e6), 3),
-                  "other(select,sort,greedy-scan,raster,d2h)": round(ms_per_step - net_ms - float(pair_ms + s2[6] / 1e6 + s2[7] / 1e6), 3)}
+        nms_ms, ras_ms = float(st.get("call_ms_nms", 0.0)), float(st.get("call_ms_raster", 0.0))
+        stages = {"unet_forward": round(net_ms, 3),
+                  "nms": round(nms_ms, 3),
+                  "nms_parts": {"build_grid_neighbour_lists": round(float(s2[7] / 1e6), 3), "pair_stage(decide+bucket+sweep)": round(float(pair_ms), 3),
+                                "general_path(joins)": round(float(s2[6] / 1e6), 3),
+                                "rounds_bookkeeping_and_readbacks": round(nms_ms - float(pair_ms + s2[6] / 1e6 + s2[7] / 1e6), 3)},
+                  "raster": round(ras_ms, 3),
+                  "select_sort_head_rows_results_to_host_glue": round(ms_per_step - net_ms - nms_ms - ras_ms, 3),
+                  "note": "nms / raster = HIP events around the whole native call (sd_nms2d_device, sd_polygons_to_label_device) on the caller's stream; "
+                          "nms_parts = the library's own events (the general path overlaps the tail batch, so the parts need not add up exactly)"}
         # Roofline of the convolutions, SURVEY.md 8(d): ALGORITHMIC flops (2 x MACs of the instantiated module) / HIP-event time of the forward
         # pass / dense peak of the pipe the kernel runs on.  A split form executes `mult` matrix products per algorithmic one (f16x3: 3 on
         # the fp16 pipe, bf16x6: 6 on the bf16 pipe, both 2.5 PFLOP/s dense; exact: 1 on the f32 pipe, 157.3 TFLOP/s): `executed_frac` is
@@ -668,7 +715,11 @@ def main():
                                    "(U-Net + select + 2D NMS + polygon raster), seeded random weights, heads calibrated to ~10%% candidates "
                                    "radius 10+-10%%" % (H, W),
                        "candidates": n_cand, "survivors": len(res[1]["prob"]), "prob_thresh": model.thresholds.prob,
-                       "nms_thresh": model.thresholds.nms, "parallelism": "tiles-per-gpu x%d" % world},
+                       "nms_thresh": model.thresholds.nms, "parallelism": "tiles-per-gpu x%d" % world,
+                       "nms2d_mode": "default: pairs far from the threshold decided from the area enclosure (exact intersection area +- a band for Clipper's "
+                                     "lattice rounding: 0.5 per crossing, max(0.15 per near edge pair, 0.45 per strip), in units of lmax_P + lmax_Q; validated "
+                                     "adversarially against the vendored Clipper, DESIGN.md 3.4), the rest by the Clipper-exact sweep; `nms2d_strict` = every "
+                                     "pair swept (bit-exact by construction), same instances"},
             "stages_ms": stages, "roofline": dominant, "roofline_convs": roof_conv, "roofline_pair_kernel": roof_pair,
             "nms2d_strict": strict_leg,
             "value_host_input": (host_leg_dict(H * W, args.steps, host2d[0], host2d[1], "Mpix/s", ms_per_step) if host2d is not None
@@ -677,6 +728,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline_2d(img_np, model, min(args.cpu_sample, H), threads)
+                out["cpu_baseline"]["stage_ratios"] = stage_ratios(out["cpu_baseline"], stages, H * W)
             except Exception as e:   # oracle/_ref must have travelled with the tree
                 out["cpu_baseline"] = {"value": None, "unit": "Mpix/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
     if not args.no_split_leg:
@@ -750,9 +802,13 @@ def main():
                                 "cascade_calls": {"upper": float(s3[0]), "lower": float(s3[1]), "kernel_volume": float(s3[2]),
                                                   "hull_volume": float(s3[11]), "render": float(s3[3])},
                                 "near_threshold_volume_decisions": float(s3[13])}
-            out["stages_ms_3d"] = {"unet_forward": round(net3_ms, 3), "nms_stage3_kernel_volume": round(float(s3[8] / 1e6), 3),
-                                   "nms_stage4_hull_volume": round(float(s3[9] / 1e6), 3), "nms_stage5_render": round(float(s3[10] / 1e6), 3),
-                                   "other": round(ms3 - net3_ms - float((s3[8] + s3[9] + s3[10]) / 1e6), 3)}
+            nms3_ms, ras3_ms = float(st3.get("call_ms_nms", 0.0)), float(st3.get("call_ms_raster", 0.0))
+            out["stages_ms_3d"] = {"unet_forward": round(net3_ms, 3), "nms": round(nms3_ms, 3),
+                                   "nms_parts": {"stage3_kernel_volume": round(float(s3[8] / 1e6), 3), "stage4_hull_volume": round(float(s3[9] / 1e6), 3),
+                                                 "stage5_render": round(float(s3[10] / 1e6), 3),
+                                                 "broad_phase_rounds_readbacks": round(nms3_ms - float((s3[8] + s3[9] + s3[10]) / 1e6), 3)},
+                                   "raster": round(ras3_ms, 3),
+                                   "select_sort_head_rows_results_to_host_glue": round(ms3 - net3_ms - nms3_ms - ras3_ms, 3)}
             out["roofline_convs_3d"] = {"bound": "mfma", "pipe": pipe, "kernel": "network forward (3x3x3 layers as three z-plane units per 32-channel chunk; kernel family as `roofline_convs`)",
                                         "achieved": round(conv3_tf, 3), "peak": cpeak, "unit": "TFLOP/s", "frac": round(conv3_tf / cpeak, 4),
                                         "traffic": None, "flops_per_launch": flops3, "executed_products_per_mac": mult,
@@ -769,6 +825,7 @@ def main():
                         crop = cb
                         cb = cpu_baseline_3d(vol_np, m3, S, threads)
                         cb["crop_run"] = {"sample": crop["sample"], "value": crop["value"]}
+                    cb["stage_ratios"] = stage_ratios(cb, out["stages_ms_3d"], S ** 3)
                     out["cpu_baseline_3d"] = cb
                 except Exception as e:
                     out["cpu_baseline_3d"] = {"value": None, "unit": "Mvox/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}

@@ -341,8 +341,23 @@ def test_config_axes_rules_and_namespace_behaviour_of_csbdeep_baseconfig():
     assert repr(a).startswith("Config2D(n_dim=2, axes='YXC', n_channel_in=1, n_channel_out=9, ")
 
 
-def test_batch_normalised_resnet_is_refused_loudly():
-    """model3d.py:405-411 hands resnet_batch_norm to csbdeep's resnet_block; that variant is not built here and must not be run without its layers"""
+def test_batch_normalised_resnet_has_the_layers_of_the_reference_graph():
+    """model3d.py:405-411 hands resnet_batch_norm to csbdeep's resnet_block: bias-free convolutions (the shortcut projection included), a
+    BatchNormalization behind every body convolution -- the last one before the Add -- and none on the projection"""
+    import torch
     from stardist_amd.models import Config3D, StarDist3D
-    with pytest.raises(NotImplementedError, match="resnet_batch_norm"):
-        StarDist3D(Config3D(rays=8, backbone="resnet", resnet_batch_norm=True, resnet_n_filter_base=4), basedir=None, device="cpu")
+    m = StarDist3D(Config3D(rays=8, backbone="resnet", resnet_batch_norm=True, resnet_n_filter_base=4, grid=(1, 2, 2), resnet_n_blocks=2), basedir=None, device="cpu")
+    blocks = [b for b in m.net.backbone if hasattr(b, "proj")]
+    assert len(blocks) == 2 and blocks[0].proj is not None and blocks[1].proj is None
+    for b in blocks:
+        convs = [c for c in b.modules() if isinstance(c, torch.nn.Conv3d)]
+        assert all(c.bias is None for c in convs)
+        stages = b._stages()
+        assert len(stages) == 3 and all(isinstance(bn, torch.nn.BatchNorm3d) and bn.eps == 1e-3 for _, bn, _ in stages)
+        assert stages[-1][2] is None and isinstance(stages[0][2], torch.nn.ReLU)          # the last convolution has no activation of its own
+    stem = [c for c in list(m.net.backbone)[:2]]
+    assert all(c[0].bias is not None for c in stem)                                       # the 7x7x7 / 3x3x3 stem keeps its biases (model3d.py:416-417)
+    x = torch.randn(1, 1, 4, 8, 8)
+    with torch.no_grad():
+        p, d = m.net(x)
+    assert tuple(p.shape) == (1, 1, 4, 4, 4) and tuple(d.shape) == (1, 8, 4, 4, 4)

@@ -111,6 +111,8 @@ CASES_3D = [
     (dict(RES3, grid=(2, 2, 2), resnet_n_blocks=3), (7, 8, 10)),
     (dict(RES3, grid=(4, 2, 2), n_classes=2), (8, 6, 6)),                      # two strided blocks ((2,2,2) then (2,1,1)), widths doubled twice
     (dict(RES3, grid=(1, 2, 2), net_conv_after_resnet=0, resnet_n_conv_per_block=2, n_channel_in=2), (4, 8, 8)),
+    (dict(RES3, grid=(1, 2, 2), resnet_batch_norm=True), (6, 10, 13)),         # bias-free convolutions + BatchNormalization (the last one before the Add), no BN on the projection
+    (dict(RES3, grid=(2, 2, 2), resnet_n_blocks=3, resnet_batch_norm=True, resnet_n_conv_per_block=2), (7, 8, 10)),
 ]
 
 

@@ -44,6 +44,9 @@ def _models(kind):
             dict(frac=0.02, radius=8.5, noise=0.03)
     if kind == "unet3d":
         return (lambda d: StarDist3D(Config3D(rays=96), basedir=None, device=d, seed=0)), ("3d", 64), dict(frac=0.02, radius=8.5, noise=0.03)
+    if kind == "resnet3d-bn":   # resnet_batch_norm=True (model3d.py:402-412 -> csbdeep resnet_block: bias-free convolutions, BatchNormalization behind every body convolution, the last one before the Add)
+        return (lambda d: _bn_stats_(StarDist3D(Config3D(rays=96, backbone="resnet", grid=(1, 2, 2), resnet_batch_norm=True), basedir=None, device=d, seed=0))), ("3d", 64), \
+            dict(frac=0.02, radius=8.5, noise=0.03)
     if kind == "resnet3d":   # the reference's 3D_demo topology: resnet backbone, grid (1,2,2)
         return (lambda d: StarDist3D(Config3D(rays=96, backbone="resnet", grid=(1, 2, 2)), basedir=None, device=d, seed=0)), ("3d", 64), \
             dict(frac=0.02, radius=8.5, noise=0.03)
@@ -61,7 +64,7 @@ def _image(dim, size):
 
 # every topology with the default convolution kernel (split-fp16 products, f32 accumulation); "-f32exact": the exact-f32 MFMA kernel;
 # "-bf16x6": the six-product bf16 form (the range fallback of the default)
-KINDS = ["unet2d", "unet2d-grid2", "unet2d-he", "unet2d-bn", "unet2d-multiclass", "unet2d-depth4", "unet2d-base48", "unet3d-base48", "unet3d", "resnet3d",
+KINDS = ["unet2d", "unet2d-grid2", "unet2d-he", "unet2d-bn", "unet2d-multiclass", "unet2d-depth4", "unet2d-base48", "unet3d-base48", "unet3d", "resnet3d", "resnet3d-bn",
          "unet2d-f32exact", "unet2d-grid2-f32exact", "unet2d-bn-f32exact", "unet3d-f32exact", "resnet3d-f32exact",
          "unet2d-bf16x6", "unet3d-bf16x6", "resnet3d-bf16x6"]
 
@@ -106,7 +109,11 @@ def test_gpu_forward_matches_cpu_float32_and_is_deterministic(kind, monkeypatch)
     rel = lambda a, b: float((np.abs(a - b) / np.maximum(np.abs(b), 1.0)).max())
     dprob, ddist = float(np.abs(p1 - pc).max()), rel(d1, dc)
     eg = (float(np.abs(p1 - p64).max()), rel(d1, d64)); ec = (float(np.abs(pc - p64).max()), rel(dc, d64))
-    print("%s: GPU vs CPU-f32: max|d prob| = %.3g, max rel |d dist| = %.3g;  vs float64: GPU %.3g / %.3g, CPU-f32 %.3g / %.3g" % ((kind, dprob, ddist) + eg + ec))
+    # the bar on the distances is RELATIVE to max(1, |dist|): float32 itself carries 6e-8 |dist|, so a 30-pixel distance cannot be held to an
+    # ABSOLUTE 1e-5 by any float32 evaluation (the reference's TensorFlow included); both figures are printed, the largest distance beside them
+    ag, ac = float(np.abs(d1 - d64).max()), float(np.abs(dc - d64).max())
+    print("%s: GPU vs CPU-f32: max|d prob| = %.3g, max rel |d dist| = %.3g;  vs float64: GPU %.3g / %.3g, CPU-f32 %.3g / %.3g;  absolute |d dist| vs float64: GPU %.3g, "
+          "CPU-f32 %.3g px (max |dist| %.1f px)" % ((kind, dprob, ddist) + eg + ec + (ag, ac, float(np.abs(d64).max()))))
     # north star: within 1e-5 on probabilities and distances (relative to max(1, |dist|) pixels) -- measured against the exact
     # (float64) value; the float32 CPU evaluation is itself only that accurate, so GPU-vs-CPU may show up to the sum of both errors
     assert eg[0] <= 1e-5 and eg[1] <= 1e-5, eg
