@@ -506,6 +506,91 @@ def _exclusive_intervals(blocks, axes_out):
     return out
 
 
+def sharded_cover(model, shape, axes, block_size, min_overlap, context=None):
+    """the blocks predict_instances_sharded deals to the ranks for an input of `shape` (BlockND.cover after the same normalisation of
+    block_size / min_overlap / context: grid-divisible, the channel axis whole): (blocks, normalised axes, (block_size, min_overlap, context))"""
+    from .models.base import axes_check_and_normalize, axes_dict
+    n = len(shape)
+    axes = axes_check_and_normalize(axes, length=n)
+    grid = model._axes_div_by(axes)
+    if context is None:
+        context = model._axes_tile_overlap(axes)
+    if np.isscalar(block_size): block_size = n * [block_size]
+    if np.isscalar(min_overlap): min_overlap = n * [min_overlap]
+    if np.isscalar(context): context = n * [context]
+    block_size, min_overlap, context = list(block_size), list(min_overlap), list(context)
+    if "C" in axes:
+        i = axes_dict(axes)["C"]
+        block_size[i] = shape[i]
+        min_overlap[i] = context[i] = 0
+    block_size = tuple(_grid_divisible(g, v, name="block_size", verbose=False) for v, g in zip(block_size, grid))
+    min_overlap = tuple(_grid_divisible(g, v, name="min_overlap", verbose=False) for v, g in zip(min_overlap, grid))
+    context = tuple(_grid_divisible(g, v, name="context", verbose=False) for v, g in zip(context, grid))
+    return BlockND.cover(tuple(shape), axes, block_size, min_overlap, context, grid), axes, (block_size, min_overlap, context)
+
+
+class ShardedInput(object):
+    """One rank's view of a large input: the shape of the WHOLE array, but only the read regions (block + context) of the blocks this rank
+    owns are held -- read from a numpy memmap / zarr-like / array `source` (anything with .shape and slicing) and, with `device`, kept
+    resident there.  predict_instances_sharded takes it in place of the array: `block.read` (big.py:164 of the reference: x[slices]) finds
+    the region by its slices.  A rank of an N-rank job so holds ~1/N of the input (plus the blocks' context) instead of all of it
+    (1024^3 float32: 4 GiB on every rank before); a region that was not prefetched is read from the source on demand.
+
+        src = np.load("slide.npy", mmap_mode="r")
+        x = ShardedInput.for_rank(model, src, "YX", block_size, min_overlap, context, rank, world, device=model.device)
+        labels, res = predict_instances_sharded(model, x, "YX", block_size, min_overlap, context)
+    """
+
+    def __init__(self, source, device=None):
+        self.source, self.device = source, device
+        self.shape = tuple(int(v) for v in source.shape)
+        self.ndim = len(self.shape)
+        self.dtype = getattr(source, "dtype", None)
+        self._held = {}
+        self.bytes_held = 0
+
+    @staticmethod
+    def _key(slices):
+        return tuple((int(s.start), int(s.stop)) for s in slices)
+
+    def _load(self, slices):
+        a = self.source[tuple(slices)]
+        if self.device is not None:
+            import torch
+            t = a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+            a = t.to(self.device)
+        elif not isinstance(a, np.ndarray) and not type(a).__module__.startswith("torch"):
+            a = np.asarray(a)
+        return a
+
+    def prefetch(self, slices):
+        k = self._key(slices)
+        if k not in self._held:
+            a = self._load(slices)
+            self._held[k] = a
+            self.bytes_held += int(np.prod(a.shape)) * (a.element_size() if hasattr(a, "element_size") else a.dtype.itemsize)
+        return self._held[k]
+
+    def __getitem__(self, slices):
+        if not isinstance(slices, tuple):
+            slices = (slices,)
+        if len(slices) == self.ndim and all(isinstance(s, slice) and s.step in (None, 1) and s.start is not None and s.stop is not None for s in slices):
+            a = self._held.get(self._key(slices))
+            if a is not None:
+                return a
+        return self._load(slices)
+
+    @classmethod
+    def for_rank(cls, model, source, axes, block_size, min_overlap, context=None, rank=0, world=1, device=None):
+        """the view of rank `rank` of `world`: the read regions of blocks rank, rank + world, ... (the deal of predict_instances_sharded) prefetched"""
+        x = cls(source, device)
+        blocks, axes_n, _ = sharded_cover(model, x.shape, axes, block_size, min_overlap, context)
+        for bi, b in enumerate(blocks):
+            if bi % world == rank:
+                x.prefetch(b.slice_read(axes_n))
+        return x
+
+
 def predict_instances_sharded(model, img, axes, block_size, min_overlap, context=None, prob_thresh=None, nms_thresh=None,
                               return_labels=True, labels_out=None, show_progress=False, distributed=None, predict_kwargs=None,
                               nms_kwargs=None, broadcast_result=True, keep_debug=False):
@@ -525,10 +610,12 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
     order (= label ids, as predict_instances numbers them), are broadcast, and every rank renders the write regions of ITS blocks
     from that list (windowed rasteriser; pixels in overlapping write regions come out identical on both owners).
 
-    Requirement for big == whole: `context` >= the network's receptive field (the default, model._axes_tile_overlap, is): a band candidate
-    is taken from the first block that reports it, so every block that holds it in its write region must have predicted it with full
-    context.  (Design B's responsibility rule takes each object from the block it is most central in and forgives a smaller context;
-    tests/test_cpu_reference_end_to_end.py runs the reference's own big == whole acceptance test on both.)
+    big == whole exactly: `context` >= the network's receptive field (the default, model._axes_tile_overlap, is).  A band candidate that
+    two blocks report is taken from the block it lies deepest in (round 6; design B's responsibility rule -- every object from the block
+    it is most central in -- applied to a point), so a smaller context degrades gracefully instead of depending on the block order.
+    (tests/test_cpu_reference_end_to_end.py runs the reference's own big == whole acceptance test on both designs.)
+
+    `img` may be a ShardedInput (this rank's read regions only, e.g. from a memmap) instead of the whole array.
 
     Label image: `labels_out=None` -- the tiles are sent to rank 0, which returns the whole image (ranks != 0 return None);
     a shared `np.memmap` / zarr-like array -- every rank writes its tiles in place (big.py:319-326 block.write), returned on every rank;
@@ -546,25 +633,10 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
     predict_kwargs = dict(predict_kwargs or {})
     nms_kwargs = dict(nms_kwargs or {})
     n = img.ndim
-    axes = axes_check_and_normalize(axes, length=n)
-    grid = model._axes_div_by(axes)
+    blocks, axes, (block_size, min_overlap, context) = sharded_cover(model, img.shape, axes, block_size, min_overlap, context)
     axes_out = model.config.axes.replace("C", "")
     shape_dict = dict(zip(axes, img.shape))
     shape_out = tuple(shape_dict[a] for a in axes_out)
-    if context is None:
-        context = model._axes_tile_overlap(axes)
-    if np.isscalar(block_size): block_size = n * [block_size]
-    if np.isscalar(min_overlap): min_overlap = n * [min_overlap]
-    if np.isscalar(context): context = n * [context]
-    block_size, min_overlap, context = list(block_size), list(min_overlap), list(context)
-    if "C" in axes:
-        i = axes_dict(axes)["C"]
-        block_size[i] = img.shape[i]
-        min_overlap[i] = context[i] = 0
-    block_size = tuple(_grid_divisible(g, v, name="block_size", verbose=False) for v, g in zip(block_size, grid))
-    min_overlap = tuple(_grid_divisible(g, v, name="min_overlap", verbose=False) for v, g in zip(min_overlap, grid))
-    context = tuple(_grid_divisible(g, v, name="context", verbose=False) for v, g in zip(context, grid))
-    blocks = BlockND.cover(img.shape, axes, block_size, min_overlap, context, grid)
     if show_progress:
         print("sharded: %d blocks, block_size=%s, min_overlap=%s, context=%s" % (len(blocks), block_size, min_overlap, context), flush=True)
 
@@ -719,11 +791,22 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
             for d in range(1, nd):
                 key = key * int(shape_out[d]) + p[:, d]
             return key
-        if rband.shape[0]:                                          # same pixel reported by two overlapping blocks: keep the first
+        raw_band = rband if keep_debug else None                    # (every report of the band, before the duplicates are dropped)
+        if rband.shape[0]:
+            # the same pixel reported by two (or more) overlapping blocks: keep the report of the block the pixel lies DEEPEST in (largest
+            # distance to that block's border, context included; ties: the lower block index) -- the prediction with the most context, what
+            # the reference's responsibility rule (big.py:89-122: every object from the block it is most central in) amounts to for a
+            # point.  With context >= the receptive field all reports of a pixel are identical and the choice does not matter.
+            ext = torch.tensor([[[t.start, t.end] for t in b.blocks_for_axes(axes_out)] for b in blocks], dtype=torch.float32, device=dev)   # (blocks, nd, 2)
+            e = ext[rband[:, c_blk].to(torch.int64)]
+            pc = rband[:, c_pts:c_pts + nd]
+            depth = torch.minimum(pc - e[:, :, 0], e[:, :, 1] - 1.0 - pc).amin(dim=1)
+            rband = rband[torch.sort(-depth, stable=True)[1]]       # (stable: equal depths stay in block order)
             ks, ki = torch.sort(pixel_key(rband), stable=True)
             first = torch.ones_like(ks, dtype=torch.bool)
             first[1:] = ks[1:] != ks[:-1]
             rband = rband[ki[first]]
+            rband = rband[torch.sort(rband[:, c_blk], stable=True)[1]]   # back to the canonical (block, score) order
         # all unique records in row-major pixel order: candidates of EQUAL score are then taken by every later sort (stable ascending,
         # reversed: nms._argsort_desc) in the order predict_instances on the whole image takes them, whatever the blocks
         rec = torch.cat([rint, rband])
@@ -748,7 +831,8 @@ def predict_instances_sharded(model, img, axes, block_size, min_overlap, context
         st["instances"] = int(final.shape[0])
         if keep_debug:                                              # the parity tests' view of the exchange: the unique gathered records
             model._last_sharded_debug = dict(dist=rec[:, :R], prob=rec[:, c_prob], points=pts, block=rec[:, c_blk], interior=interior,
-                                             keep=keep_mask, order=so)
+                                             keep=keep_mask, order=so, raw_band_points=raw_band[:, c_pts:c_pts + nd].to(torch.int64),
+                                             raw_band_block=raw_band[:, c_blk].to(torch.int64))
     if multi and (return_labels or broadcast_result):               # the final instances to every rank (M x record)
         m = torch.tensor([final.shape[0] if rank == 0 else 0], dtype=torch.int64, device=cdev)
         dist_.broadcast(m, src=0)

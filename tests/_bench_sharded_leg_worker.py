@@ -19,6 +19,7 @@ def main():
     import bench
     from stardist_amd.big import predict_instances_sharded
     torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.max_memory_allocated = lambda *a, **k: 0
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist_.init_process_group("gloo", rank=rank, world_size=world)
     calls = []
@@ -40,7 +41,11 @@ def main():
     g = np.arange(12, size - 12, 24)
     img[np.ix_(g, g)] = np.random.RandomState(0).uniform(0.5, 1.0, (len(g), len(g))).astype(np.float32)
     K, Wp = 3, 2
-    out = bench.run_sharded_leg(Model(), torch.from_numpy(img), "YX", block, 64, 32, K, world, dist_, rank, warm_passes=Wp)
+    # the input exactly as bench.py builds it at N > 1: every rank holds the read regions of ITS blocks only (ShardedInput over a source)
+    model = Model()
+    big = bench.sharded_input(model, img, 1, "YX", block, 64, 32, rank, world, torch.device("cpu"))
+    assert type(big).__name__ == "ShardedInput" and big.bytes_held > 0 and len(big._held) == 8       # 16 blocks over 2 ranks
+    out = bench.run_sharded_leg(model, big, "YX", block, 64, 32, K, world, dist_, rank, warm_passes=Wp)
     n_calls = torch.tensor([len(calls)], dtype=torch.int64)
     dist_.all_reduce(n_calls, op=dist_.ReduceOp.MIN)
     if rank == 0:
