@@ -178,6 +178,23 @@ __device__ __forceinline__ int cell_of(const GridP g, float py, float px, int& c
   return cy * g.nx + cx;
 }
 
+// The cells a candidate's neighbours can lie in (cells are indexed by the CENTRE of a candidate).  With the bbox test in force (threshold >= 0
+// or use_bbox: may_interact requires intersecting integer bounding boxes) a neighbour j of i has bbox_j inside [p_j - (r + 1), p_j + (r + 1)],
+// r = the largest distance of ANY candidate (a vertex is centre + d (sin, cos) truncated), so its centre lies within bbox_i grown by r + 1:
+// a window per candidate (round 6; before: the 5 x 5 cells of size r + 1 around its own cell, 1.5 x the area), with half a pixel of slack
+// for the float cell arithmetic.  Without the bbox test (kd-tree radius only) the window is the centre +- (2 r + 1).
+struct Window { int ylo, yhi, xlo, xhi; };
+__device__ __forceinline__ Window cell_window(const GridP g, bool by_bbox, float reach, const int4 bb, float py, float px) {
+  float y0, y1, x0, x1;
+  if (by_bbox) { x0 = (float)bb.x - reach; x1 = (float)bb.y + reach; y0 = (float)bb.z - reach; y1 = (float)bb.w + reach; }
+  else { const float rr = 2.f * reach; x0 = px - rr; x1 = px + rr; y0 = py - rr; y1 = py + rr; }
+  Window w;
+  w.ylo = min(max((int)floorf((y0 - 0.5f - g.y0) * g.inv_cs), 0), g.ny - 1); w.yhi = min(max((int)floorf((y1 + 0.5f - g.y0) * g.inv_cs), 0), g.ny - 1);
+  w.xlo = min(max((int)floorf((x0 - 0.5f - g.x0) * g.inv_cs), 0), g.nx - 1); w.xhi = min(max((int)floorf((x1 + 0.5f - g.x0) * g.inv_cs), 0), g.nx - 1);
+  return w;
+}
+constexpr int MAX_WIN_ROWS = 32;      // rows of a window (<= 10 with cells of half the reach; the host falls back to coarser cells otherwise)
+
 __global__ void k_cell_count(const float* __restrict__ pts, int N, GridP g, int* __restrict__ cellCount, int* __restrict__ candCell) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
@@ -189,11 +206,11 @@ __global__ void k_cell_count(const float* __restrict__ pts, int N, GridP g, int*
 // candidates re-packed in cell order: the broad phase streams these 32-byte records (coalesced) instead of gathering
 // bbox / centre / area of every cell item by candidate index
 struct __attribute__((aligned(16))) CellRec { int4 bb; float py, px, area; int j; };
-// slotCap (may be null): upper bound of candidate i's neighbour count = the population of the (2 W + 1)^2 cells its list is built from,
+// slotCap (may be null): upper bound of candidate i's neighbour count = the population of the cells of its window (cell_window) its list is built from,
 // minus itself -- the capacity of its slot in the single-pass neighbour lists (k_neighbours<2>)
 __global__ void k_cell_fill(int N, const int* __restrict__ candCell, const int* __restrict__ cellStart,
                             int* __restrict__ cellFill, const float* __restrict__ pts, const int4* __restrict__ bbox,
-                            const float* __restrict__ area, CellRec* __restrict__ rec, GridP g, int W, int* __restrict__ slotCap) {
+                            const float* __restrict__ area, CellRec* __restrict__ rec, GridP g, int by_bbox, float reach, int* __restrict__ slotCap) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int c = candCell[i];
@@ -202,10 +219,9 @@ __global__ void k_cell_fill(int N, const int* __restrict__ candCell, const int* 
   r.bb = bbox[i]; r.py = pts[2 * i]; r.px = pts[2 * i + 1]; r.area = area[i]; r.j = i;
   rec[cellStart[c] + pos] = r;
   if (slotCap) {
-    const int cy = c / g.nx, cx = c - cy * g.nx;
-    const int x_lo = max(cx - W, 0), x_hi = min(cx + W, g.nx - 1);
+    const Window w = cell_window(g, by_bbox != 0, reach, r.bb, r.py, r.px);
     int u = -1;
-    for (int yy = max(cy - W, 0); yy <= min(cy + W, g.ny - 1); ++yy) u += cellStart[yy * g.nx + x_hi + 1] - cellStart[yy * g.nx + x_lo];
+    for (int yy = w.ylo; yy <= w.yhi; ++yy) u += cellStart[yy * g.nx + w.xhi + 1] - cellStart[yy * g.nx + w.xlo];
     slotCap[i] = u;
   }
 }
@@ -247,7 +263,7 @@ __device__ __forceinline__ bool may_interact(const Flags f, const int4 bi, const
 template <int MODE>
 __global__ void __launch_bounds__(256) k_neighbours(int N, GridP g, Flags f, const CellRec* __restrict__ rec, const int* __restrict__ cellStart,
                                                     int* __restrict__ nbrCount, int* __restrict__ nbrLow, const i64* __restrict__ nbrStart,
-                                                    int* __restrict__ nbr, int* __restrict__ waitOn, int W, unsigned long long* __restrict__ total) {
+                                                    int* __restrict__ nbr, int* __restrict__ waitOn, int by_bbox, float reach, unsigned long long* __restrict__ total) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // wave w handles the w-th candidate IN CELL ORDER, and consecutive workgroups of one XCD (blockIdx % 8) get consecutive
   // cells: the 5x5 cell neighbourhoods of successive waves overlap almost completely and stay in that XCD's L2
@@ -267,27 +283,41 @@ __global__ void __launch_bounds__(256) k_neighbours(int N, GridP g, Flags f, con
   int minj = INT32_MAX;                      // MODE 1: best-scored neighbour above i (first wait target of the greedy scan)
   const i64 baseLo = MODE ? nbrStart[i] : 0;
   const i64 baseHi = MODE == 1 ? baseLo + nbrLow[i] : (MODE == 2 ? nbrStart[i + 1] - 1 : 0);      // MODE 2: the slot's last entry, filled downwards
-  const int x_lo = max(cx - W, 0), x_hi = min(cx + W, g.nx - 1);
-  for (int yy = max(cy - W, 0); yy <= min(cy + W, g.ny - 1); ++yy) {
-    const int beg = cellStart[yy * g.nx + x_lo], end = cellStart[yy * g.nx + x_hi + 1];
-    for (int t = beg; t < end; t += 64) {
-      const int idx = t + lane;
-      bool hit = false;
-      int j = -1;
-      if (idx < end) {
-        const CellRec r = rec[idx];
+  // The window's rows are contiguous runs of the cell-ordered records; the runs are walked as ONE list (lane r holds row r's start and its
+  // exclusive prefix), 64 records per step whatever the row lengths -- a row of ~35 records no longer costs a step of its own.
+  const Window win = cell_window(g, by_bbox != 0, reach, bi, pyi, pxi);
+  const int nrows = win.yhi - win.ylo + 1;
+  int rbeg = 0, rlen = 0;
+  if (lane < nrows) { rbeg = cellStart[(win.ylo + lane) * g.nx + win.xlo]; rlen = cellStart[(win.ylo + lane) * g.nx + win.xhi + 1] - rbeg; }
+  int incl = rlen;
+  for (int o = 1; o < MAX_WIN_ROWS; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  const int total_recs = __shfl(incl, nrows - 1);
+  const int excl = incl - rlen;
+  for (int t = 0; t < total_recs; t += 64) {
+    const int v = t + lane;
+    bool hit = false;
+    int j = -1;
+    {
+      // the row of virtual index v: the last row whose exclusive prefix is <= v (rows may be empty)
+      int rb = 0, re = 0;
+      for (int r = 0; r < nrows; ++r) {
+        const int e_r = __shfl(excl, r), b_r = __shfl(rbeg, r);
+        if (e_r <= v) { rb = b_r; re = e_r; }
+      }
+      if (v < total_recs) {
+        const CellRec r = rec[rb + (v - re)];
         j = r.j;
         if (j != i) hit = may_interact(f, bi, r.bb, pyi, pxi, r.py, r.px, ai, r.area);
       }
-      const unsigned long long mLo = __ballot(hit && j < i), mHi = __ballot(hit && j > i);
-      if (MODE && hit) {
-        const unsigned long long below = (1ull << lane) - 1;
-        if (j < i) { nbr[baseLo + nLo + __popcll(mLo & below)] = j; if (j < minj) minj = j; }
-        else if (MODE == 1) nbr[baseHi + nHi + __popcll(mHi & below)] = j;
-        else nbr[baseHi - (nHi + __popcll(mHi & below))] = j;
-      }
-      nLo += __popcll(mLo); nHi += __popcll(mHi);
     }
+    const unsigned long long mLo = __ballot(hit && j < i), mHi = __ballot(hit && j > i);
+    if (MODE && hit) {
+      const unsigned long long below = (1ull << lane) - 1;
+      if (j < i) { nbr[baseLo + nLo + __popcll(mLo & below)] = j; if (j < minj) minj = j; }
+      else if (MODE == 1) nbr[baseHi + nHi + __popcll(mHi & below)] = j;
+      else nbr[baseHi - (nHi + __popcll(mHi & below))] = j;
+    }
+    nLo += __popcll(mLo); nHi += __popcll(mHi);
   }
   if (!MODE && lane == 0) { nbrCount[i] = nLo + nHi; nbrLow[i] = nLo; }
   if (MODE == 2 && lane == 0) nbrLow[i] = nLo;          // (the total is summed by k_sum_halves: one atomic per candidate on one word serialises at the L2)
@@ -980,9 +1010,12 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
 
   // ---- uniform grid
   GridP g;
-  float cs = (max_dist + 1.f) * 1.0001f + 1e-3f;
+  // cells of HALF the reach (max_dist + 1): a candidate's window (cell_window: its bounding box grown by the reach) then spans at most
+  // (2 (max_dist + 1) + 2 (max_dist + 1)) / cs + 2 = 10 rows; a grid that would exceed 2^26 cells gets coarser cells (fewer rows still)
+  const float reach = (max_dist + 1.f) * 1.0001f + 1e-3f;
+  const int by_bbox = (threshold >= 0.f || use_bbox) ? 1 : 0;
+  float cs = 0.5f * reach;
   if (!(cs >= 1.f)) cs = 1.f;
-  const int W = 2;
   for (;;) {
     g.ny = (int)(((double)gs[2] - gs[1]) / cs) + 1;
     g.nx = (int)(((double)gs[4] - gs[3]) / cs) + 1;
@@ -1016,7 +1049,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   // (count, scan, fill: every candidate test done twice, 1.2 + 0.8 ms at 2048^2) remains for inputs whose slots would exceed 32-bit indices.
   const bool singlePass = sd::option(sd::OPT_NMS2D_NBR_SINGLE) != 0;
   SD_CHECK(hipMemsetAsync(nbrCount, 0, (N + 1) * sizeof(int), s));
-  hipLaunchKernelGGL(k_cell_fill, dim3(sd::div_up(N, 256)), dim3(256), 0, s, N, candCell, cellStart, cellFill, d_points, bbox, area, cellRec, g, W,
+  hipLaunchKernelGGL(k_cell_fill, dim3(sd::div_up(N, 256)), dim3(256), 0, s, N, candCell, cellStart, cellFill, d_points, bbox, area, cellRec, g, by_bbox, reach,
                      singlePass ? nbrCount : (int*)nullptr);
   SD_LAUNCH_CHECK();
 
@@ -1035,11 +1068,18 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
     SD_CHECK(hipStreamSynchronize(s));
     slots = slotTotal >= 0 && slotTotal < (i64)0x7fffffff;
   }
+  // the slots can be several times the exact list size (every candidate of the window counts): when they do not fit the workspace the
+  // call falls back to the exact-size two-pass form instead of failing
+  int* nbr = nullptr;
+  if (slots) {
+    nbr = A.take_n<int>((size_t)slotTotal);
+    if (!nbr) slots = false;
+  }
   if (slots && launch_side()) return -1;
   if (!slots) {
     SD_CHECK(hipMemsetAsync(nbrCount, 0, (N + 1) * sizeof(int), s));
     hipLaunchKernelGGL((k_neighbours<0>), dim3(nbBlocks), dim3(256), 0, s, N, g, f, cellRec, cellStart, nbrCount, nbrLow, (const i64*)nullptr, (int*)nullptr,
-                       (int*)nullptr, W, (unsigned long long*)nullptr);
+                       (int*)nullptr, by_bbox, reach, (unsigned long long*)nullptr);
     SD_LAUNCH_CHECK();
     SD_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tmpBytes, nbrCount, nbrStart, N + 1, s));
     SD_CHECK(hipMemcpyAsync(&totalNbr, nbrStart + N, sizeof(i64), hipMemcpyDeviceToHost, s));
@@ -1053,12 +1093,12 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
                   "(predict_instances_sharded / predict_instances_big)", (long long)totalNbr, N);
     return -1;
   }
-  int* nbr = A.take_n<int>((size_t)(slots ? slotTotal : totalNbr));
+  if (!slots) nbr = A.take_n<int>((size_t)totalNbr);
   int* waitOn = A.take_n<int>(N);
   if (!nbr || !waitOn) return -1;
   if (slots) {
     SD_CHECK(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL((k_neighbours<2>), dim3(nbBlocks), dim3(256), 0, s, N, g, f, cellRec, cellStart, nbrCount, nbrLow, (const i64*)nbrStart, nbr, waitOn, W, d_total);
+    hipLaunchKernelGGL((k_neighbours<2>), dim3(nbBlocks), dim3(256), 0, s, N, g, f, cellRec, cellStart, nbrCount, nbrLow, (const i64*)nbrStart, nbr, waitOn, by_bbox, reach, d_total);
     hipLaunchKernelGGL(k_sum_halves, dim3(sd::div_up(N, 256) < 1024 ? sd::div_up(N, 256) : 1024), dim3(256), 0, s, nbrLow, nbrCount, N, d_total);
     SD_LAUNCH_CHECK();
     unsigned long long tot = 0;
@@ -1066,7 +1106,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
     SD_CHECK(hipStreamSynchronize(s));
     totalNbr = (i64)tot;
   } else {
-    hipLaunchKernelGGL((k_neighbours<1>), dim3(nbBlocks), dim3(256), 0, s, N, g, f, cellRec, cellStart, nbrCount, nbrLow, (const i64*)nbrStart, nbr, waitOn, W,
+    hipLaunchKernelGGL((k_neighbours<1>), dim3(nbBlocks), dim3(256), 0, s, N, g, f, cellRec, cellStart, nbrCount, nbrLow, (const i64*)nbrStart, nbr, waitOn, by_bbox, reach,
                        (unsigned long long*)nullptr);
     SD_LAUNCH_CHECK();
   }

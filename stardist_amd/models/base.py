@@ -239,11 +239,16 @@ class StarDistBase(object):
             warnings.warn("Couldn't find any network weights (*.h5, *.hdf5) to load.")
             return
         preferred = [f for f in files if prefer in os.path.basename(f)]
-        # a converted copy stands for its Keras file whatever their time stamps: weights_best.npz next to weights_best.h5
+        # a converted copy stands for its Keras file -- weights_best.npz next to weights_best.h5 -- unless the Keras file is NEWER than the copy
+        # (someone dropped fresh weights into the folder): then the Keras file is loaded, as csbdeep would, and the stale copy is named
         chosen = preferred[0] if preferred else files[0]
         twin = os.path.splitext(chosen)[0] + ".npz"
         if not chosen.endswith(".npz") and os.path.exists(twin):
-            chosen = twin
+            if os.stat(twin).st_mtime >= os.stat(chosen).st_mtime:
+                chosen = twin
+            else:
+                warnings.warn("'%s' is older than '%s': loading the Keras file (the converted copy is out of date; tools/keras_to_npz.py renews it)"
+                              % (os.path.basename(twin), os.path.basename(chosen)))
         print("Loading network weights from '%s'." % os.path.basename(chosen))
         self.load_weights(os.path.basename(chosen))
 

@@ -162,3 +162,48 @@ def test_model_folder_semantics_follow_csbdeep_basemodel(tmp_path, capsys):
     with pytest.raises(ValueError):
         StarDist2D(cfg, name="", basedir=None, device="cpu")
     assert sorted(os.listdir(base)) == sorted(["m", b.name])
+
+
+def test_a_converted_npz_stands_for_its_keras_file_only_while_it_is_not_older(tmp_path, monkeypatch):
+    """weights_best.npz next to weights_best.h5 is the converted copy and is loaded in its place -- unless the Keras file is newer
+    (fresh weights dropped into the folder): then the Keras file is loaded, as csbdeep's newest-file rule would, with a warning that names the stale copy"""
+    import warnings
+    from stardist_amd.models import Config2D, StarDist2D
+    cfg = Config2D(n_rays=8, unet_n_depth=1, unet_n_filter_base=4, net_conv_after_unet=8)
+    m = StarDist2D(cfg, name="m", basedir=str(tmp_path), device="cpu", seed=1)
+    npz, h5 = os.path.join(m.logdir, "weights_best.npz"), os.path.join(m.logdir, "weights_best.h5")
+    m.save_weights_npz(npz)
+    open(h5, "wb").write(b"not read in this test")
+    loaded = []
+    monkeypatch.setattr(StarDist2D, "load_weights_h5", lambda self, p: loaded.append(os.path.basename(p)))
+    monkeypatch.setattr(StarDist2D, "load_weights_npz", lambda self, p: loaded.append(os.path.basename(p)))
+    os.utime(npz, (2000, 2000)); os.utime(h5, (1000, 1000))             # the copy is newer than the Keras file: the copy
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m._find_and_load_weights()
+    os.utime(npz, (1000, 1000)); os.utime(h5, (2000, 2000))             # the Keras file is newer: the Keras file, loudly
+    with pytest.warns(UserWarning, match="out of date"):
+        m._find_and_load_weights()
+    assert loaded == ["weights_best.npz", "weights_best.h5"]
+
+
+def test_sample_image_accessors_return_the_reference_images():
+    """stardist/data/__init__.py:7-39: the arrays the reference's accessors read with tifffile / imageio (here: Pillow on the reference's files,
+    build container only) == what stardist_amd.data serves from its images.npz"""
+    from stardist_amd.data import test_image_he_2d, test_image_nuclei_2d, test_image_nuclei_3d
+    img, mask = test_image_nuclei_2d(return_mask=True)
+    assert img.shape == mask.shape == (512, 512) and test_image_nuclei_2d().shape == (512, 512)
+    v, vm = test_image_nuclei_3d(return_mask=True)
+    assert v.shape == vm.shape == (31, 61, 57) and int(vm.max()) > 10
+    assert test_image_he_2d().shape == (300, 500, 3) and test_image_he_2d().dtype == np.uint8
+    src = "/root/reference/stardist/data/images"
+    if os.path.isdir(src):
+        from PIL import Image
+
+        def read(p):
+            im = Image.open(p); pages = []
+            for k in range(getattr(im, "n_frames", 1)):
+                im.seek(k); pages.append(np.array(im))
+            return pages[0] if len(pages) == 1 else np.stack(pages)
+        assert np.array_equal(img, read(os.path.join(src, "img2d.tif"))) and np.array_equal(mask, read(os.path.join(src, "mask2d.tif")))
+        assert np.array_equal(v, read(os.path.join(src, "img3d.tif"))) and np.array_equal(vm, read(os.path.join(src, "mask3d.tif")))
