@@ -225,7 +225,7 @@ def cpu_baseline_3d(vol_np, model, sample, threads):
 def net_macs(model, macs):
     """multiply-accumulates per input pixel the timed network region executes: with the sparse head (models/unet.py) the distance head
     is evaluated on the candidate pixels only, outside that region -- its dense MACs are not counted"""
-    if getattr(model, "_head_mode", "dense") != "sparse":
+    if getattr(model, "_head_mode", "dense") not in ("sparse", "sparse_lazy"):
         return macs
     d = model.net.dist
     return macs - d.in_channels * d.out_channels / float(np.prod(model.config.grid))

@@ -390,6 +390,12 @@ int sd_dot_combine_device(const float* d_partial, int groups, long long n_pix, c
 int sd_conv3_f16x3_fmt_ndhwc_device(const float* d_src0, int c0, int up0, const float* d_src1, int c1, int up1, int D, int H, int W, int kz,
                                     const float* d_wpacked, const float* d_bias, int c_out, int act, float* d_out, int in_split16,
                                     int out_split16, int* d_range_flag, const float* d_dot_w, float* d_dot_partial, void* stream);
+/* ... on SELECTED pixels: d_out[r][0 .. c_out) = act(bias + conv(src))[d_rows[r]] (d_rows: linear pixel indices into [D][H][W]), bit-identical to
+ * what the dense entry points store there.  The sparse prediction path (stardist/models/base.py:553-610 predict_sparse keeps the candidates of
+ * a dense prediction) runs the features layer densely WITHOUT its store -- sd_conv3_f16x3_fmt_ndhwc_device with d_out == NULL and the fused
+ * probability head: only the head's partial sums leave the kernel -- and then evaluates the layer here for the candidate pixels only. */
+int sd_conv3_f16x3_rows_device(const float* d_src, int c_in, int in_split16, int D, int H, int W, int kz, const float* d_wpacked,
+                               const float* d_bias, int c_out, int act, const long long* d_rows, long long n_rows, float* d_out, void* stream);
 int sd_conv3_c1x32_split16_device(const float* d_src, int D, int H, int W, int kz, const float* d_wpacked, const float* d_bias, int act,
                                   float* d_out, int* d_range_flag, void* stream);
 int sd_maxpool_split16_ndhwc_device(const float* d_in, int n_channels, int D, int H, int W, int pz, int py, int px, float* d_out, void* stream);

@@ -56,7 +56,7 @@ __device__ __forceinline__ int half_sum_i(int v) { for (int o = 16; o; o >>= 1) 
 __device__ __forceinline__ int half_min_i(int v) { for (int o = 16; o; o >>= 1) { const int t = __shfl_xor(v, o); v = t < v ? t : v; } return v; }
 __device__ __forceinline__ int half_max_i(int v) { for (int o = 16; o; o >>= 1) { const int t = __shfl_xor(v, o); v = t > v ? t : v; } return v; }
 
-constexpr float NEAR_W = 0.15f, STRIP_W = 0.45f;   // band weights of an edge pair within one lattice step / of a strip (mechanism 2); tests/_area_exact.py and oracle/area_band_adversary.cpp carry the same values
+constexpr float NEAR_W = 0.15f, STRIP_W = 0.45f;   // band weights of an edge pair within one lattice step / of a strip (mechanism 2); the numpy statement under tests/ and the adversarial search tool of the test infrastructure carry the same values
 constexpr int WINDOW = 2047;        // largest |relative coordinate| for which every predicate's products stay below 2^24
 
 // Per polygon (two polygons per wave, lane & 31 = edge): longest edge, L1 perimeter, orientation, integer bounding box and whether the

@@ -286,7 +286,10 @@ __device__ __forceinline__ void compute_sub(const char* __restrict__ tileH, cons
 // sd_dot_combine_device then adds a pixel's c_out / 4 terms in the order of that kernel's xor butterfly, the bias and the logistic function:
 // the probabilities are BIT-IDENTICAL to the two-pass form, and the 128-channel features are not read a second time for them.
 // The head's 32 weights of this workgroup's channels are staged in LDS (behind the epilogue scratch) at kernel start.
-template <bool RES, bool DOT>
+// NOST (with DOT): the tile itself is NOT stored -- the sparse prediction path needs the features of the candidate pixels only and
+// recomputes exactly those afterwards (k_conv3_f16_rows below, bit-identical), so the dense 128-channel tensor (2 GiB at 2048^2, 8.6 GB at
+// 256^3) is never written.
+template <bool RES, bool DOT, bool NOST = false>
 __device__ __forceinline__ void store_tile(const Params& P, const f32x16 (&acc0)[2], const f32x16 (&acc1)[2], float* __restrict__ scr, int g, int tz,
                                            int ty, int tx, int wave, int lane) {
   const int i = lane & 31, h = lane >> 5;
@@ -323,7 +326,7 @@ __device__ __forceinline__ void store_tile(const Params& P, const f32x16 (&acc0)
         if (RES && P.res) v += __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(x * res_bytes + chan_off), 0, 0));
         if (P.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         const int so = (int)(x * pix_bytes + chan_off);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, so, 0, 0);
+        if (!NOST) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, so, 0, 0);
         if (DOT) {
           const v4f hw = *(const v4f*)(scr + (4 - wave) * 512 + c4 * 4);    // (LDS, behind the four waves' scratch; held in registers across the unit loop it would be spilled)
           float d = v.x * hw.x;
@@ -384,9 +387,10 @@ __device__ __forceinline__ void store_tile_split(const Params& P, const f32x16 (
 // TWO workgroups per CU (79.8 KiB of LDS each, <= 256 registers per lane): two waves per SIMD
 // (WPE = 1: the same code compiled for one wave per SIMD -- 512 registers -- as the A/B partner of option conv_f16_workgroups_per_cu = 1)
 // INP: the sources are split16 tensors (no split here, the halo is copied); OUTP: the output is written as a split16 tensor
-template <bool RES, int WPE, bool DOT = false, bool INP = false, bool OUTP = false>
+template <bool RES, int WPE, bool DOT = false, bool INP = false, bool OUTP = false, bool NOST = false>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_conv3_f16(const Params P) {
   static_assert(!(OUTP && (RES || DOT)), "a split16 output has neither residual nor fused head");
+  static_assert(!NOST || DOT, "only the fused-head form can do without its tile store");
   extern __shared__ float4 smem4h[];
   // LDS map (bytes): two weight buffers of one sub-unit each | halo tile, 2 fp16 planes | 4 x 2 KiB wave-private epilogue scratch
   char* W = (char*)smem4h;
@@ -548,7 +552,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WP
       PROF_UNIT();
     }
     if constexpr (OUTP) store_tile_split(P, acc0, acc1, scr, g, Tc.tz, Tc.ty0 + 1, Tc.tx0 + 1, wave, lane, amax_out);
-    else store_tile<RES, DOT>(P, acc0, acc1, scr, g, Tc.tz, Tc.ty0 + 1, Tc.tx0 + 1, wave, lane);
+    else store_tile<RES, DOT, NOST>(P, acc0, acc1, scr, g, Tc.tz, Tc.ty0 + 1, Tc.tx0 + 1, wave, lane);
     PROF(11);
     Tc = Tn;
   }
@@ -557,6 +561,120 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WP
   // ... or a value this layer was to store as a split16 element (bit 1: the OUTPUT is not valid, whatever reads it)
   if (OUTP && P.flag && !(amax_out <= 65504.f)) atomicOr(P.flag, 2);
   PROF_END();
+}
+
+// ---- the same layer on SELECTED pixels (the sparse prediction path's features) --------------------------------------------------------
+// out[r][:] = act(bias + conv(x))[rows[r]] for n_rows pixels given by their linear index in the [D][H][W] grid -- what the dense kernel
+// would have stored there, BIT FOR BIT: the same matrix instruction with the same operand slots in the same order per accumulator
+// (units (chunk, z tap), row tap dy, (dx, 16-channel block); cross terms ah*bl, al*bh into acc1, ah*bh into acc0; acc0 starts from the
+// bias; acc0 + acc1 2^-11; activation).  A row of the MFMA's A operand is a pixel, rows are independent, so gathering 32 arbitrary
+// candidates into one operand changes nothing for any of them.  One wave = 32 candidates x NG groups of 32 output channels (the gathered
+// A operand is used for all groups); operands straight from global memory (the candidates of one object share cache lines, the packed
+// weights of a sub-unit are 12 KiB that every wave reads).  One full-resolution source; f32 or split16.
+struct RowsParams {
+  const float* src; int c_in;            // [D][H][W][c_in]
+  int D, H, W, kz, n_units;
+  const float* wp; const float* bias;
+  int c_out, act, g0;                    // first output-channel group of this launch
+  const long long* rows; long long n_rows;
+  float* out;                            // [n_rows][c_out]
+};
+template <int NG, bool INP>
+__global__ void __launch_bounds__(256) k_conv3_f16_rows(const RowsParams P) {
+  // Per sub-unit (unit, row tap dy): the workgroup stages the NG weight blocks (12 KiB each) in LDS once for its four waves, every lane
+  // has its 6 x 2 operand elements of the gathered pixels in flight meanwhile (unconditional loads from a clamped address, zeroed
+  // afterwards outside the image: nothing waits on a branch), then 6 x 3 x NG matrix instructions read their B operands from LDS.
+  extern __shared__ float4 rows_lds4[];
+  char* wl = (char*)rows_lds4;
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const long long wbase = ((long long)blockIdx.x * 4 + (tid >> 6)) * 32;
+  const long long ri = wbase + i;
+  const bool live = ri < P.n_rows;
+  long long pix = live ? P.rows[ri] : 0;
+  const int x = (int)(pix % P.W); pix /= P.W;
+  const int y = (int)(pix % P.H);
+  const int z = (int)(pix / P.H);
+  f32x16 acc0[NG], acc1[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const float b = P.bias ? P.bias[(P.g0 + g) * 32 + i] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[g][r] = b; acc1[g][r] = 0.f; }
+  }
+  const size_t pix_floats = (size_t)P.c_in;
+  float amax = 0.f;
+  for (int u = 0; u < P.n_units; ++u) {
+    const int c = P.kz == 3 ? u / 3 : u, dz = P.kz == 3 ? u - 3 * c - 1 : 0;
+    const int zz = z + dz;
+    const bool zin = live && zz >= 0 && zz < P.D;
+    const int zc = min(max(zz, 0), P.D - 1);
+#pragma unroll 1
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y + dy - 1;
+      const bool yin = zin && yy >= 0 && yy < P.H;
+      const int yc = min(max(yy, 0), P.H - 1);
+      const float* prow = P.src + (((size_t)zc * P.H + yc) * P.W) * pix_floats + (size_t)c * 32;
+      // the gathered A operands of the six (dx, block) groups
+      u32x4 ah[6], al[6];
+      v4f f0[INP ? 1 : 6], f1[INP ? 1 : 6];
+#pragma unroll
+      for (int gi = 0; gi < 6; ++gi) {
+        const int dx = gi >> 1, b = gi & 1;
+        const int xc = min(max(x + dx - 1, 0), P.W - 1);
+        const float* px = prow + (size_t)xc * pix_floats;
+        if (INP) {                                                    // split16: element p * 4 + (b * 2 + h) of the pixel's chunk
+          ah[gi] = *(const u32x4*)(px + (b * 2 + h) * 4);
+          al[gi] = *(const u32x4*)(px + 16 + (b * 2 + h) * 4);
+        } else {
+          f0[INP ? 0 : gi] = *(const v4f*)(px + b * 16 + h * 8); f1[INP ? 0 : gi] = *(const v4f*)(px + b * 16 + h * 8 + 4);
+        }
+      }
+      // the weights of this sub-unit for the NG groups -> LDS (the previous sub-unit's reads are done behind the first barrier)
+      __syncthreads();
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const v4f* wsrc = (const v4f*)((const char*)P.wp + ((((size_t)(P.g0 + g) * P.n_units + u) * 3 + dy) * HWSUB_BYTES));
+#pragma unroll
+        for (int n = 0; n < HWSUB_BYTES / 16 / 256; ++n) ((v4f*)(wl + g * HWSUB_BYTES))[tid + n * 256] = wsrc[tid + n * 256];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int gi = 0; gi < 6; ++gi) {
+        const int dx = gi >> 1, b = gi & 1;
+        const int xx = x + dx - 1;
+        const bool inside = yin && xx >= 0 && xx < P.W;
+        u32x4 a_h, a_l;
+        if (INP) { a_h = ah[gi]; a_l = al[gi]; }
+        else {
+          const v4f v0 = f0[INP ? 0 : gi], v1 = f1[INP ? 0 : gi];
+          unsigned hw[4], lw[4];
+          split2_pair(v0.x, v0.y, hw[0], lw[0], amax); split2_pair(v0.z, v0.w, hw[1], lw[1], amax);
+          split2_pair(v1.x, v1.y, hw[2], lw[2], amax); split2_pair(v1.z, v1.w, hw[3], lw[3], amax);
+          a_h = u32x4{hw[0], hw[1], hw[2], hw[3]}; a_l = u32x4{lw[0], lw[1], lw[2], lw[3]};
+        }
+        if (!inside) { a_h = u32x4{0u, 0u, 0u, 0u}; a_l = u32x4{0u, 0u, 0u, 0u}; }
+        const f16x8 fah = __builtin_bit_cast(f16x8, a_h), fal = __builtin_bit_cast(f16x8, a_l);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const f16x8 bh = __builtin_bit_cast(f16x8, *(const u32x4*)(wl + g * HWSUB_BYTES + hw_off(dx, b, 0, h, i)));
+          const f16x8 bl = __builtin_bit_cast(f16x8, *(const u32x4*)(wl + g * HWSUB_BYTES + hw_off(dx, b, 1, h, i)));
+          acc1[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, bl, acc1[g], 0, 0, 0);
+          acc1[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, bh, acc1[g], 0, 0, 0);
+          acc0[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, bh, acc0[g], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // register r of lane (i, h): candidate (r & 3) + 8 (r >> 2) + 4 h of the wave, output channel i of the group
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long ro = wbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+      float v = acc0[g][r] + acc1[g][r] * 4.8828125e-4f;
+      if (P.act == 1) v = fmaxf(v, 0.f);
+      if (ro < P.n_rows) P.out[(size_t)ro * P.c_out + (P.g0 + g) * 32 + i] = v;
+    }
 }
 
 }  // namespace
@@ -586,6 +704,7 @@ static int conv3_f16x3_launch(const float* d_src0, int c0, int stride0, int up0,
                               const float* d_res, int res_stride, int c_out, int act, float* d_out, int* d_range_flag,
                               const float* d_dot_w, float* d_dot_partial, void* stream_, int in_split = 0, int out_split = 0) {
   hipStream_t s = (hipStream_t)stream_;
+  const bool no_store = d_out == nullptr && d_dot_w != nullptr && d_dot_partial != nullptr && !d_res && !out_split;   // fused head without the feature store
   if ((in_split & ~1) || (out_split & ~1) || (out_split && (d_res || d_dot_w)) || (in_split && d_res) ||
       (in_split && (stride0 != c0 || (d_src1 && stride1 != c1)))) {
     sd::set_error("sd_conv3_f16x3: split16 tensors are dense (stride == channels); a split16 output takes neither residual nor fused head, a residual layer no split16 input");
@@ -594,7 +713,7 @@ static int conv3_f16x3_launch(const float* d_src0, int c0, int stride0, int up0,
   if (D <= 0 || H <= 0 || W <= 0) return 0;
   const int c_in = c0 + (d_src1 ? c1 : 0);
   const long long n_packed = sd_conv3_f16x3_packed_floats(c_in, c_out, kz);
-  if (!d_src0 || !d_wpacked || !d_out || (act != 0 && act != 1) || n_packed < 0 || (kz == 1 && D != 1) ||
+  if (!d_src0 || !d_wpacked || (!d_out && !no_store) || (act != 0 && act != 1) || n_packed < 0 || (kz == 1 && D != 1) ||
       (((uintptr_t)d_src0 | (uintptr_t)d_src1 | (uintptr_t)d_wpacked | (uintptr_t)d_out | (uintptr_t)d_bias) & 15) || ((uintptr_t)d_range_flag & 3)) {
     sd::set_error("sd_conv3_f16x3: unsupported channel counts (%d + %d -> %d), kz, act or misaligned pointers", c0, d_src1 ? c1 : 0, c_out);
     return -1;
@@ -651,16 +770,18 @@ static int conv3_f16x3_launch(const float* d_src0, int c0, int stride0, int up0,
   const size_t lds = (size_t)2 * HWSUB_BYTES + HTILE_BYTES + 4 * 2048 + 128;    // 79.9 KiB: two workgroups per CU (the last 128 bytes: the fused head's weights)
   typedef void (*kern_t)(const Params);
   // [variant][one workgroup per CU]: plain, residual, fused head; then the split16 forms (in, out, in + out, in + fused head)
-  static const kern_t kern[7][2] = {
+  static const kern_t kern[9][2] = {
       {k_conv3_f16<false, 2>, k_conv3_f16<false, 1>},
       {k_conv3_f16<true, 2>, k_conv3_f16<true, 1>},
       {k_conv3_f16<false, 2, true>, k_conv3_f16<false, 1, true>},
       {k_conv3_f16<false, 2, false, true, false>, k_conv3_f16<false, 1, false, true, false>},
       {k_conv3_f16<false, 2, false, false, true>, k_conv3_f16<false, 1, false, false, true>},
       {k_conv3_f16<false, 2, false, true, true>, k_conv3_f16<false, 1, false, true, true>},
-      {k_conv3_f16<false, 2, true, true, false>, k_conv3_f16<false, 1, true, true, false>}};
+      {k_conv3_f16<false, 2, true, true, false>, k_conv3_f16<false, 1, true, true, false>},
+      {k_conv3_f16<false, 2, true, false, false, true>, k_conv3_f16<false, 1, true, false, false, true>},
+      {k_conv3_f16<false, 2, true, true, false, true>, k_conv3_f16<false, 1, true, true, false, true>}};
   if (dev >= 16 || !attr_set[dev]) {
-    for (int v = 0; v < 7; ++v)
+    for (int v = 0; v < 9; ++v)
       for (int w = 0; w < 2; ++w) SD_CHECK(hipFuncSetAttribute((const void*)kern[v][w], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (dev < 16) attr_set[dev] = true;
   }
@@ -675,7 +796,7 @@ static int conv3_f16x3_launch(const float* d_src0, int c0, int stride0, int up0,
   if (blocks < P.groups) blocks = P.groups;
   const long long want = (long long)P.n_tiles * P.groups;
   if (blocks > want) blocks = want;
-  const int variant = d_dot_w ? (in_split ? 6 : 2) : d_res ? 1 : (in_split ? (out_split ? 5 : 3) : (out_split ? 4 : 0));
+  const int variant = d_dot_w ? ((in_split ? 6 : 2) + (no_store ? (in_split ? 2 : 5) : 0)) : d_res ? 1 : (in_split ? (out_split ? 5 : 3) : (out_split ? 4 : 0));
   hipLaunchKernelGGL(kern[variant][per_cu == 1 ? 1 : 0], dim3((unsigned)blocks), dim3(THREADS), lds, s, P);
   SD_LAUNCH_CHECK();
   return 0;
@@ -715,4 +836,44 @@ extern "C" int sd_conv3_f16x3_fmt_ndhwc_device(const float* d_src0, int c0, int 
                                                int out_split16, int* d_range_flag, const float* d_dot_w, float* d_dot_partial, void* stream_) {
   return conv3_f16x3_launch(d_src0, c0, c0, up0, d_src1, c1, c1, up1, D, H, W, kz, d_wpacked, d_bias, nullptr, 0, c_out, act, d_out, d_range_flag,
                             d_dot_w, d_dot_partial, stream_, in_split16 ? 1 : 0, out_split16 ? 1 : 0);
+}
+
+// The layer's output on selected pixels only: d_out[r][0 .. c_out) = act(bias + conv(src))[d_rows[r]], d_rows = linear pixel indices into the
+// [D][H][W] grid (int64), bit-identical to what sd_conv3_f16x3_*_ndhwc_device stores at those pixels.  One full-resolution source of c_in
+// channels (f32, or split16 with in_split16 != 0); weights as for the dense entry points.  The sparse prediction path evaluates the
+// features layer this way for the candidate pixels (10 % of a 2D tile, 1 % of a volume) after a dense pass that keeps only the probability
+// head's partial sums (sd_conv3_f16x3_fmt_ndhwc_device with d_out == NULL), cf. stardist/models/base.py:553-610 (predict_sparse).
+extern "C" int sd_conv3_f16x3_rows_device(const float* d_src, int c_in, int in_split16, int D, int H, int W, int kz, const float* d_wpacked,
+                                          const float* d_bias, int c_out, int act, const long long* d_rows, long long n_rows, float* d_out,
+                                          void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (n_rows <= 0) return 0;
+  if (!d_src || !d_wpacked || !d_rows || !d_out || (act != 0 && act != 1) || sd_conv3_f16x3_packed_floats(c_in, c_out, kz) < 0 || (kz == 1 && D != 1) ||
+      D <= 0 || H <= 0 || W <= 0 || (((uintptr_t)d_src | (uintptr_t)d_wpacked) & 15) || ((uintptr_t)d_rows & 7) || ((uintptr_t)d_out & 3)) {
+    sd::set_error("sd_conv3_f16x3_rows: channel counts multiples of 32 (c_in <= 512), kz 1|3, act 0|1, aligned pointers");
+    return -1;
+  }
+  RowsParams P;
+  P.src = d_src; P.c_in = c_in; P.D = D; P.H = H; P.W = W; P.kz = kz; P.n_units = (c_in / 32) * kz;
+  P.wp = d_wpacked; P.bias = d_bias; P.c_out = c_out; P.act = act; P.rows = d_rows; P.n_rows = n_rows; P.out = d_out;
+  const long long waves = (n_rows + 31) / 32;
+  const dim3 grid((unsigned)((waves + 3) / 4));
+  const int groups = c_out / 32;
+  for (int g0 = 0; g0 < groups;) {
+    const int ng = groups - g0 >= 4 ? 4 : (groups - g0 >= 2 ? 2 : 1);
+    P.g0 = g0;
+    const size_t lds = (size_t)ng * HWSUB_BYTES;
+    if (in_split16) {
+      if (ng == 4) hipLaunchKernelGGL((k_conv3_f16_rows<4, true>), grid, dim3(256), lds, s, P);
+      else if (ng == 2) hipLaunchKernelGGL((k_conv3_f16_rows<2, true>), grid, dim3(256), lds, s, P);
+      else hipLaunchKernelGGL((k_conv3_f16_rows<1, true>), grid, dim3(256), lds, s, P);
+    } else {
+      if (ng == 4) hipLaunchKernelGGL((k_conv3_f16_rows<4, false>), grid, dim3(256), lds, s, P);
+      else if (ng == 2) hipLaunchKernelGGL((k_conv3_f16_rows<2, false>), grid, dim3(256), lds, s, P);
+      else hipLaunchKernelGGL((k_conv3_f16_rows<1, false>), grid, dim3(256), lds, s, P);
+    }
+    g0 += ng;
+  }
+  SD_LAUNCH_CHECK();
+  return 0;
 }

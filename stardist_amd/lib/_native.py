@@ -81,6 +81,7 @@ SIGNATURES = {
     "sd_conv3_f16x3_dot_ndhwc_device": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sd_dot_combine_device": (_i, [_vp, _i, ctypes.c_longlong, _vp, _i, _vp, _vp]),
     "sd_conv3_f16x3_fmt_ndhwc_device": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "sd_conv3_f16x3_rows_device": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, ctypes.c_longlong, _vp, _vp]),
     "sd_conv3_c1x32_split16_device": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "sd_maxpool_split16_ndhwc_device": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "sd_split16_pack_device": (_i, [_vp, ctypes.c_longlong, _i, _vp, _vp, _vp]),

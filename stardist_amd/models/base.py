@@ -476,7 +476,7 @@ class StarDistBase(object):
 
     def _net_forward_once(self, x, sparse_head=False):
         """x: torch tensor with axes_net semantics (channels last) -> tuple of channels-last outputs (prob, dist[, prob_class]).
-        sparse_head=True (GPU, fused heads: models/unet.py): (prob, features[, prob_class]) when self._head_mode == "sparse" after
+        sparse_head=True (GPU, fused heads: models/unet.py): (prob, features[, prob_class]) when self._head_mode in ("sparse", "sparse_lazy") after
         the call -- the distance head is then evaluated on the selected rows only (_select_rows); otherwise as above.
 
         On the GPU the forward pass is captured once per input shape into a HIP graph (torch.cuda.CUDAGraph) and
@@ -740,7 +740,14 @@ class StarDistBase(object):
             full = np.asarray(feat.shape[:-1], np.int32)
             grid = np.asarray(self.config.grid, np.int32)
             N.dcall(prob, "sd_sorted_rows_device", N.tptr(opts), N.tptr(order), n, nd, N.ptr(full), None, N.ptr(grid), N.tptr(rows), N.tptr(pf), N.tptr(pi))
-        dist = self.net.dist_rows(feat, rows, 1e-3)           # max(dist, 1e-3): base.py:512-513 / select.hip
+        if self._head_mode == "sparse_lazy" and n:
+            # the features of the candidates are evaluated in their SPATIAL order (np.where order: neighbouring candidates share the cache lines
+            # of their 3x3 neighbourhoods), the distance head reads them in score order
+            rows_sp = torch.empty_like(rows)
+            rows_sp[order] = rows
+            dist = self.net.dist_rows(feat, rows_sp, 1e-3, lazy=True, order=order)
+        else:
+            dist = self.net.dist_rows(feat, rows, 1e-3, lazy=self._head_mode == "sparse_lazy")           # max(dist, 1e-3): base.py:512-513 / select.hip
         return SortedCandidates(sp, dist, pi, pf)
 
     def _select_rows(self, prob, feat, origin, prob_thresh, bs):
@@ -757,7 +764,7 @@ class StarDistBase(object):
         rows = torch.zeros(n, dtype=torch.int64, device=prob.device)
         for d in range(nd):
             rows = rows * int(full[d]) + (pts[:, d] + int(origin[d]))
-        odist = self.net.dist_rows(feat, rows, 1e-3)          # max(dist, 1e-3): base.py:512-513 / select.hip
+        odist = self.net.dist_rows(feat, rows, 1e-3, lazy=self._head_mode == "sparse_lazy")          # max(dist, 1e-3): base.py:512-513 / select.hip
         return oprob[:n], odist, pts
 
     def _predict_sparse_generator(self, img, prob_thresh=None, axes=None, normalizer=None, n_tiles=None,
@@ -777,7 +784,7 @@ class StarDistBase(object):
                 gsrc, gdst = g(s_src), g(s_dst)
                 prob_tile = res[0][..., 0][tuple(gsrc)]
                 bs = [(b if s.start == 0 else 0, b if s.stop == _sh else 0) for s, _sh in zip(gdst, [v for v, a in zip(sh, axes_net) if a != "C"])]   # base.py:583
-                if self._head_mode == "sparse":
+                if self._head_mode in ("sparse", "sparse_lazy"):
                     p_, d_, pt_ = self._select_rows(prob_tile, res[1], [s.start for s in gsrc], prob_thresh, bs)
                 else:
                     p_, d_, pt_ = self._select(prob_tile, res[1][tuple(gsrc)], prob_thresh, bs)
@@ -793,7 +800,7 @@ class StarDistBase(object):
             if self._is_multiclass(): prob_classa = torch.cat(pcl)
         else:
             res = self._net_forward(x, sparse_head=True)
-            if (_presort and self._head_mode == "sparse" and not self._is_multiclass()
+            if (_presort and self._head_mode in ("sparse", "sparse_lazy") and not self._is_multiclass()
                     and not any(p[1] for p in resizer.pad.values())):
                 # predict_instances, untiled, nothing padded (filter_points keeps every point): hand the candidates over in score order
                 bs = [(b, b)] * self.config.n_dim if np.isscalar(b) else list(b)
@@ -815,7 +822,7 @@ class StarDistBase(object):
         gridt = torch.tensor(self.config.grid, device=self.device, dtype=torch.int64).reshape(1, nd)
         prob = res[0][..., 0]
         bs = [(b, b)] * nd if np.isscalar(b) else list(b)
-        if head_mode == "sparse":
+        if head_mode in ("sparse", "sparse_lazy"):
             proba, dista, pts = self._select_rows(prob, res[1], [0] * nd, prob_thresh, bs)
         else:
             proba, dista, pts = self._select(prob, res[1], prob_thresh, bs)

@@ -354,7 +354,10 @@ def _general_conv(conv, x, kind, res=None, bn=None, tf_same=False):
 _MAX_CHUNK_CHANNELS = 512          # csrc/conv3x3_layout.h MAX_CHUNKS * 32
 
 
-def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False, dot=None):
+NO_STORE = object()          # _hand_conv(..., no_store=True): the layer ran without writing its output (fused head only)
+
+
+def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False, dot=None, no_store=False):
     """act(conv(cat(srcs, 1)) + bias (+ res)) by a hand-written kernel; srcs = [(tensor (1, C, *spatial) channels-last float32, up)] with
     up = per-axis tuple of 0/1 (or one int for all axes): 1 where the source has half the output resolution and the reference
     up-samples it (nearest, x2) first.  res: residual added before the activation (resnet_block's Add); bn: inference batch-norm layer
@@ -362,6 +365,8 @@ def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False, dot=None):
     one-channel first layer) go to csrc/conv3x3*.hip, everything else with one full-resolution source to csrc/conv_general.hip.
     dot = (weights (c_out,), holder list): a one-channel head fused into the layer's epilogue when the split-fp16 kernel takes the layer
     (sd_conv3_f16x3_dot_ndhwc_device) -- holder[0] then receives the per-lane terms (n_pix, c_out / 4); left empty otherwise.
+    no_store (with dot): when the fused head is taken the layer's own output is NOT written and NO_STORE is returned (the caller evaluates
+    the layer on the pixels it needs with conv_rows); otherwise ignored.
     None when the layer is not covered (the callers raise UnsupportedLayer)."""
     nd = 2 if isinstance(conv, nn.Conv2d) else (3 if isinstance(conv, nn.Conv3d) else 0)
     if not (nd and kind in (0, 1) and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
@@ -414,8 +419,10 @@ def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False, dot=None):
         srcs = [(_unpack_for(conv, t), up) for t, up in srcs]
     out_split = bool(conv.__dict__.get("_sd_split_out")) and split16_enabled() and res is None and dot is None and conv_mode() == "f16x3" \
         and (form == "f16x3" or (cs == [1] and co == 32))
-    out = torch.empty((1, co) + shape, dtype=torch.float32, device=conv.weight.device, memory_format=cl)
-    if res is not None and not (tuple(res.shape) == tuple(out.shape) and res.dtype == torch.float32 and res.is_contiguous(memory_format=cl)):
+    dot_ok = dot is not None and res is None and dot[0].numel() == co and dot[0].data_ptr() % 16 == 0
+    skip_out = bool(no_store) and form == "f16x3" and dot_ok and not out_split
+    out = None if skip_out else torch.empty((1, co) + shape, dtype=torch.float32, device=conv.weight.device, memory_format=cl)
+    if res is not None and not (tuple(res.shape) == (1, co) + shape and res.dtype == torch.float32 and res.is_contiguous(memory_format=cl)):
         return None
     D, H, W = ((1,) + shape) if nd == 2 else shape
     mask = lambda up: sum(b << k for k, b in enumerate(reversed(up)))                     # bit 0: x, 1: y, 2: z
@@ -426,17 +433,19 @@ def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False, dot=None):
                 ctypes.c_void_p(bias.data_ptr()) if bias is not None else None, kind, ctypes.c_void_p(out.data_ptr()),
                 ctypes.c_void_p(_flag_ptr(conv, a.device)))
         return _tag_split16(out, conv)
-    if form == "f16x3" and (in_split or out_split):
+    if form == "f16x3" and (in_split or out_split or skip_out):
         part = None
-        if dot is not None and dot[0].numel() == co and dot[0].data_ptr() % 16 == 0:
+        if dot_ok:
             part = torch.empty((D * H * W, co // 4), dtype=torch.float32, device=a.device)
         N.dcall(a, "sd_conv3_f16x3_fmt_ndhwc_device", ctypes.c_void_p(a.data_ptr()), cs[0], mask(ups[0]),
                 ctypes.c_void_p(b.data_ptr()) if b is not None else None, cs[1] if b is not None else 0, mask(ups[1]) if b is not None else 0,
                 D, H, W, 1 if nd == 2 else 3, ctypes.c_void_p(wp.data_ptr()), ctypes.c_void_p(bias.data_ptr()) if bias is not None else None,
-                co, kind, ctypes.c_void_p(out.data_ptr()), int(in_split), int(out_split), ctypes.c_void_p(_flag_ptr(conv, a.device)),
+                co, kind, ctypes.c_void_p(out.data_ptr()) if out is not None else None, int(in_split), int(out_split), ctypes.c_void_p(_flag_ptr(conv, a.device)),
                 ctypes.c_void_p(dot[0].data_ptr()) if part is not None else None, ctypes.c_void_p(part.data_ptr()) if part is not None else None)
         if part is not None:
             dot[1].append(part)
+        if skip_out:
+            return NO_STORE
         return _tag_split16(out, conv) if out_split else out
     args = [ctypes.c_void_p(a.data_ptr()), cs[0], cs[0], mask(ups[0]),
             ctypes.c_void_p(b.data_ptr()) if b is not None else None, cs[1] if b is not None else 0, cs[1] if b is not None else 0,
@@ -452,6 +461,23 @@ def _hand_conv(conv, srcs, kind, res=None, bn=None, tf_same=False, dot=None):
             dot[1].append(part)
             return out
     N.dcall(a, _FORM_PREFIX[form] + "_res_ndhwc_device", *args)
+    return out
+
+
+def conv_rows(conv, x, kind, rows, bn=None):
+    """act(conv(x) + bias) on the pixels `rows` (int64 linear indices into x's spatial grid) of a 3x3(x3) layer the split-fp16 kernel takes:
+    (len(rows), c_out) float32, bit-identical to the rows of the dense layer output (sd_conv3_f16x3_rows_device); x (1, C, *spatial)
+    channels-last, f32 or split16"""
+    from ..lib import _native as N
+    nd = x.dim() - 2
+    wp, bias = _packed_conv_weights(conv, "f16x3", bn)
+    co = conv.out_channels
+    out = torch.empty((int(rows.shape[0]), co), dtype=torch.float32, device=x.device)
+    if rows.shape[0]:
+        S = (1,) * (3 - nd) + tuple(int(v) for v in x.shape[2:])
+        N.dcall(x, "sd_conv3_f16x3_rows_device", ctypes.c_void_p(x.data_ptr()), int(x.shape[1]), int(is_split16(x)), *S, 1 if nd == 2 else 3,
+                ctypes.c_void_p(wp.data_ptr()), ctypes.c_void_p(bias.data_ptr()) if bias is not None else None, co, kind,
+                ctypes.c_void_p(rows.data_ptr()), int(rows.shape[0]), ctypes.c_void_p(out.data_ptr()))
     return out
 
 
@@ -843,9 +869,45 @@ class StarDistNet(nn.Module):
         C, R = f[0].out_channels, self.dist.out_channels
         return kind >= 0 and C in (32, 64, 128, 256) and R <= 128 and C * (((R + 31) // 32) * 32 + 1) * 4 <= 64 * 1024
 
-    def dist_rows(self, feat, rows, clamp_min):
-        """distance head on rows of the channels-last feature matrix feat (n_pix, C): (len(rows), n_rays); rows None = all"""
+    # The sparse path without the dense feature tensor (round 6): the features layer runs with the probability head fused and WITHOUT its
+    # store (head_mode "sparse_lazy": forward returns (prob, backbone output)); dist_rows then evaluates the layer on the candidate rows
+    # (conv_rows, bit-identical to the dense layer) and the distance head on those.  2 GiB (2048^2) / 8.6 GB (256^3) are never written.
+    # Measured (round 6): the row kernel costs 0.25 ms at 4e5 (2D) / 1.7e5 (3D) candidates (half of it the weight blocks every workgroup
+    # stages, 0.1 ms the gathers), the dense store it replaces 0.15 ms at 2048^2 (2.1 GB) and 0.3 ms at 256^3 (8.6 GB): the dense tensor is
+    # kept while it is small, from lazy_features_min_bytes on (and for the blocks of a sharded input: 10 GB / 90 GB each) it is not written.
+    lazy_features = True                      # False (or STARDIST_AMD_LAZY_FEATURES=0): the dense feature tensor always
+    lazy_features_min_bytes = 4 << 30
+
+    def _lazy_ok(self, base):
+        import os
+        f = self.features
+        if not (self.lazy_features and os.environ.get("STARDIST_AMD_LAZY_FEATURES", "1") != "0" and conv_mode() == "f16x3" and isinstance(f, ConvAct)):
+            return False
+        conv, bn, kind = f.parts()
+        nd = self.nd
+        if int(np.prod(base.shape[2:])) * conv.out_channels * 4 < self.lazy_features_min_bytes:
+            return False
+        return (bn is None and kind >= 0 and tuple(conv.kernel_size) == (3,) * nd and tuple(conv.stride) == (1,) * nd and tuple(conv.padding) == (1,) * nd
+                and tuple(conv.dilation) == (1,) * nd and conv.groups == 1 and conv.in_channels % 32 == 0 and 0 < conv.in_channels <= _MAX_CHUNK_CHANNELS
+                and conv.out_channels % 32 == 0 and conv.__dict__.get("_sd_force_form") != "bf16x6" and base.shape[1] == conv.in_channels)
+
+    def feature_rows(self, base_cl, rows):
+        """features (after bias + activation) of the pixels `rows` from the backbone output given as its channels-last view (..., C_in)"""
+        nd = base_cl.dim() - 1
+        x = base_cl.permute(*([nd] + list(range(nd)))).unsqueeze(0)          # back to (1, C, *spatial): the channels-last tensor itself
+        if getattr(self, "_lazy_split16", False):
+            x._sd_split16 = True
+        conv, _, kind = self.features.parts()
+        return conv_rows(conv, x, kind, rows)
+
+    def dist_rows(self, feat, rows, clamp_min, lazy=False, order=None):
+        """distance head on rows of the channels-last feature matrix feat (n_pix, C): (len(rows), n_rays); rows None = all.
+        lazy: `feat` is the BACKBONE output (head_mode "sparse_lazy") -- the features of the pixels `rows` are evaluated first (give the
+        rows in SPATIAL order: the gathered 3x3 neighbourhoods then share cache lines) and the head runs on them, in the order `order`
+        (indices into rows; None: as they are)"""
         from ..lib import _native as N
+        if lazy:
+            feat, rows = self.feature_rows(feat, rows), order
         C, R = feat.shape[-1], self.dist.out_channels
         feat = feat.reshape(-1, C)
         n = feat.shape[0] if rows is None else int(rows.shape[0])
@@ -871,9 +933,14 @@ class StarDistNet(nn.Module):
         holder = []
         # features conv with bias + activation fused (64-bit indexing: no slabs); the split-fp16 kernel also takes the probability head's
         # dot product over each workgroup's 32 channels while the tile is in registers
-        feat = _hand_conv(conv, [(base, 0)], kind, dot=(wp, holder))
+        lazy = bool(sparse_head) and self._lazy_ok(base)
+        feat = _hand_conv(conv, [(base, 0)], kind, dot=(wp, holder), no_store=lazy)
         if feat is None:
             raise UnsupportedLayer("features " + _layer_desc(conv, [(base, 0)]))
+        self._lazy_now = feat is NO_STORE
+        if feat is NO_STORE:
+            self._lazy_split16 = is_split16(base)
+            feat = base                       # what the caller gets in place of the features: dist_rows(..., lazy=True) works from it
         if holder:
             # ... the per-lane terms -> probabilities, bit-identical to sd_bias_act_dot_device on the same features, which are not re-read
             N.dcall(feat, "sd_dot_combine_device", ctypes.c_void_p(holder[0].data_ptr()), C // 32, int(np.prod(S)),
@@ -898,7 +965,7 @@ class StarDistNet(nn.Module):
         if self._fused_heads_ok(base):
             out = self._heads_fused(base, sparse_head)
             if sparse_head:
-                self.head_mode = "sparse"
+                self.head_mode = "sparse_lazy" if getattr(self, "_lazy_now", False) else "sparse"
             if self.n_classes is not None:
                 out = tuple(out) + (self._class_head(base),)
             return tuple(out)

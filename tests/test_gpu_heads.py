@@ -121,10 +121,14 @@ def test_model_sparse_head_equals_dense_prediction(dim):
         bench.calibrate_heads(m, torch.from_numpy(img).to(dev), frac=0.02, radius=8.5, noise=0.03)
         tiles = (1, 2, 2)
     thr = float(m.thresholds.prob)
-    for n_tiles in (None, tiles):
+    # with the dense feature tensor (small inputs) and without it (round 6: the features layer keeps only the probability head's partial sums, the
+    # features of the candidate pixels are evaluated afterwards by sd_conv3_f16x3_rows_device; the default from 4 GiB of features on)
+    for lazy_min, n_tiles in ((4 << 30, None), (4 << 30, tiles), (0, None), (0, tiles)):
+        m.net.lazy_features_min_bytes = lazy_min
+        m.__dict__.pop("_graphs", None)
         prob, dist = m.predict(img, n_tiles=n_tiles)[:2]
         ps, ds, pts = m.predict_sparse(img, prob_thresh=thr, n_tiles=n_tiles)
-        assert m._head_mode == "sparse"
+        assert m._head_mode == ("sparse_lazy" if lazy_min == 0 else "sparse")
         mask = prob > thr
         b = 2
         inner = np.zeros_like(mask); inner[(slice(b, -b),) * dim] = True
@@ -183,3 +187,33 @@ def test_fused_probability_head_in_the_features_epilogue(nd, shape, co):
         if sigm:
             ref = torch.sigmoid(ref)
         assert float((prob.double() - ref).abs().max()) <= (2e-6 if sigm else 2e-5)
+
+
+@pytest.mark.parametrize("nd,cin,cout,S", [(2, 32, 128, (70, 90)), (2, 64, 64, (33, 40)), (3, 32, 128, (9, 20, 37)), (3, 64, 32, (6, 10, 12)), (2, 32, 256, (20, 30))])
+@pytest.mark.parametrize("split", [False, True])
+def test_layer_on_selected_pixels_equals_the_dense_layer_bit_for_bit(nd, cin, cout, S, split):
+    """sd_conv3_f16x3_rows_device (the sparse path's features: the layer evaluated on the candidate pixels only, round 6) == the rows of the
+    dense split-fp16 layer, bit for bit -- border pixels (zero padding), a partial last wave, f32 and split16 sources, 1 / 2 / 4 / 8 groups of
+    output channels; and the dense pass that only keeps the fused head's partial sums (d_out == NULL) gives the same probabilities"""
+    import torch
+    from stardist_amd.models import unet as U
+    dev = torch.device("cuda:0")
+    cl = torch.channels_last if nd == 2 else torch.channels_last_3d
+    Conv = torch.nn.Conv2d if nd == 2 else torch.nn.Conv3d
+    torch.manual_seed(nd * 100 + cin + cout)
+    conv = Conv(cin, cout, 3, padding=1).to(dev)
+    x = torch.randn((1, cin) + S, device=dev).contiguous(memory_format=cl)
+    n_pix = int(np.prod(S))
+    g = torch.Generator().manual_seed(5)
+    rows = torch.cat([torch.tensor([0, 1, S[-1] - 1, S[-1], n_pix - 1, n_pix - S[-1]]), torch.randint(0, n_pix, (1000 + 7,), generator=g)]).to(dev)
+    w = torch.randn(cout, device=dev)
+    with torch.no_grad(), U.force_conv_mode("f16x3"):
+        holder = []
+        dense = U._hand_conv(conv, [(x, 0)], 1, dot=(w, holder))
+        src = U.split16_pack(x) if split else x
+        got = U.conv_rows(conv, src, 1, rows)
+        h2 = []
+        r = U._hand_conv(conv, [(src, 0)], 1, dot=(w, h2), no_store=True)
+    want = dense[0].permute(*(list(range(1, nd + 1)) + [0])).reshape(n_pix, cout)[rows]
+    assert torch.equal(got, want), float((got - want).abs().max())
+    assert r is U.NO_STORE and len(h2) == 1 and torch.equal(h2[0], holder[0])
