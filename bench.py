@@ -45,7 +45,7 @@ CONV_FORMS = {"f16x3": (3.0, MFMA_BF16_PEAK_TFLOPS, "f16"), "bf16x6": (6.0, MFMA
 # WRITE_SIZE in separate passes) writes them, together with the pair count of the profiled workload, to this json; bench.py
 # reports them as roofline.traffic only when its own pair count matches the profiled one.
 PAIR_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pair_kernel_traffic.json")
-# the same for the convolution kernel, per forward pass (tools/pmc_forward.py + tools/conv_traffic.py, profiles/r05_conv_forward.md)
+# the same for the convolution kernel, per forward pass (tools/pmc_forward.py + tools/conv_traffic.py, profiles/r06_conv_forward.md)
 CONV_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "conv_kernel_traffic.json")
 
 
@@ -704,7 +704,9 @@ def main():
                      "avg_ms": round(net_ms, 3),
                      "note": "achieved = algorithmic FLOPs of the convolutions (2 x MACs, recomputed from the instantiated module) / HIP-event time of the "
                              "whole forward pass (14 conv launches + pools + head) on the caller's stream; executed_* = x%d matrix products per MAC; "
-                             "for reference the f32-MFMA peak is %.1f TFLOP/s; per-kernel durations and the MFMA-busy counter: profiles/r05_*"
+                             "for reference the f32-MFMA peak is %.1f TFLOP/s; per-kernel durations and the MFMA-busy counter: profiles/r06_*; the kernel is POWER-limited "
+                             "(same instruction stream on zero data: 31-37 %% faster at a 45 %% higher clock; the matrix pipe alone sustains 1.4-1.6 PFLOP/s on "
+                             "realistic operands: profiles/r06_conv_power_*.txt, r06_mfma_power_roof.txt, DESIGN.md 3f)"
                              % (int(mult), MFMA_F32_PEAK_TFLOPS)}
         ct = conv_traffic("2d", mode, H, 2048)
         if ct:
@@ -740,7 +742,10 @@ def main():
                            {"f16x3": "as three fp16 x fp16 terms of operands split into two fp16 parts (hi + lo * 2^-11)",
                             "bf16x6": "as six bf16 x bf16 terms of operands split into three bf16 parts", "hand": "exact in f32"}[mode] +
                            " (f32-accurate: layers and networks within 3e-6 of a float64 evaluation, tests/test_gpu_conv3x3.py, "
-                           "test_gpu_unet_parity.py; `exact_f32` / `split_bf16x6` = the same step with the other kernel forms)"
+                           "test_gpu_unet_parity.py; the bar on distances is RELATIVE to max(1, |dist|): the absolute error is ~1.2e-5 px at 12 px, the same "
+                           "as the float32 CPU evaluation of the module, profiles/r06_unet_parity_vs_float64.txt; activations travel between the layers as "
+                           "the two fp16 terms the consumer multiplies with (split16, made by the producer: bit-identical); `exact_f32` / `split_bf16x6` = "
+                           "the same step with the other kernel forms, `exact_f32` being the figure for a reader who takes 'f32' literally)"
                            "; NMS / rasteriser in the reference's own int64 / float32 / float64 arithmetic"),
             "config": {"workload": "StarDist2D 32-ray U-Net (depth 3, 32 base filters), %dx%d synthetic fluo tile per GPU, predict_instances "
                                    "(U-Net + select + 2D NMS + polygon raster), seeded random weights, heads calibrated to ~10%% candidates "
