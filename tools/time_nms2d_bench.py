@@ -1,5 +1,5 @@
 """Time the 2D NMS alone on the BENCH's candidate set (calibrated U-Net on the 2048^2 synthetic tile). usage: python tools/time_nms2d_bench.py [reps]"""
-import os, sys, time
+import os, sys, time, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
@@ -18,6 +18,10 @@ if os.environ.get("SD_PAIR_LANES"):
 for env, opt in (("SD_DEFER_FROM", b"nms2d_defer_undecided"), ("SD_DEFER_MAX", b"nms2d_defer_max")):
     if os.environ.get(env):
         _native.check(_native.lib().sd_set_option(opt, int(os.environ[env])))
+for kv in filter(None, os.environ.get("SD_OPTS", "").split(",")):          # SD_OPTS="name=value,name=value": any sd_set_option switch
+    k, v = kv.split("=")
+    _native.check(_native.lib().sd_set_option(k.encode(), int(v)))
+    print(k, "=", _native.lib().sd_get_option(k.encode()))
 if os.environ.get("SD_TRACE"):
     _native.lib().sd_set_option(b"trace", 1)      # per-round counters on stdout
 img = torch.from_numpy(synth.s2d_nuclei_image(2048, 2048, seed=0)).to(dev)
@@ -31,4 +35,5 @@ for r in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     keep = sd2.c_non_max_suppression_inds(td, tp, 1, 1, 0, np.float32(0.4))
     torch.cuda.synchronize(); dt = time.time() - t
     st = _native.last_stats["nms2d"]
-    print(f"rep {r}: N={len(td)} -> {int(keep.sum())}  {dt*1e3:.1f} ms  pair {st[4]/1e6:.2f} ms ({st[0]} pairs, {st[5]} launches)  general {st[6]/1e6:.2f} ms ({st[1]})  build {st[7]/1e6:.2f} ms  rounds {st[2]}", flush=True)
+    crc = zlib.crc32((keep.cpu().numpy() if hasattr(keep, "cpu") else np.asarray(keep)).astype(np.uint8).tobytes())
+    print(f"rep {r}: N={len(td)} -> {int(keep.sum())}  {dt*1e3:.1f} ms  pair {st[4]/1e6:.2f} ms ({st[0]} pairs, {st[5]} launches)  general {st[6]/1e6:.2f} ms ({st[1]})  build {st[7]/1e6:.2f} ms  rounds {st[2]}  keep crc {crc:08x}", flush=True)
