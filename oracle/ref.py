@@ -118,3 +118,21 @@ def pair_volumes(dist, points, verts, faces, pairs, kernel=True, hull=True):
                                   ctypes.c_int(len(pairs)), ctypes.c_int(dist.shape[1]), ctypes.c_int(len(faces)),
                                   vp(vk.ctypes.data) if kernel else None, vp(vh.ctypes.data) if hull else None)
     return vk, vh
+
+
+def pair_cascade(dist, points, verts, faces, pairs, anisotropy=(1.0, 1.0, 1.0)):
+    """every quantity the reference's cascade (stardist3d_impl.cpp:1207-1318) looks at for the given pairs (i, j), by the reference's own
+    functions: rows of (volume i, volume j, upper bound, lower bound, kernel stage, hull stage, rendered overlap -- the full count --, 0)"""
+    if "qh" not in _cache:
+        lib = ctypes.CDLL(os.path.join(_REF, "libqhull_ref.so"))
+        lib.ref_pair_volumes.restype = None
+        _cache["qh"] = lib
+    dist = np.ascontiguousarray(dist, np.float32); points = np.ascontiguousarray(points, np.float32)
+    verts = np.ascontiguousarray(verts, np.float32); faces = np.ascontiguousarray(faces, np.int32)
+    pairs = np.ascontiguousarray(pairs, np.int32); an = np.ascontiguousarray(anisotropy, np.float32)
+    out = np.zeros((len(pairs), 8), np.float32)
+    vp = ctypes.c_void_p
+    _cache["qh"].ref_pair_cascade.restype = None
+    _cache["qh"].ref_pair_cascade(vp(dist.ctypes.data), vp(points.ctypes.data), vp(verts.ctypes.data), vp(faces.ctypes.data), vp(pairs.ctypes.data),
+                                  ctypes.c_int(len(pairs)), ctypes.c_int(dist.shape[1]), ctypes.c_int(len(faces)), vp(an.ctypes.data), vp(out.ctypes.data))
+    return out

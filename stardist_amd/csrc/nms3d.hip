@@ -1633,6 +1633,7 @@ __global__ void __launch_bounds__(64) k_hull(const int* __restrict__ hullList, u
   __shared__ int s_probe[8];
   __shared__ int s_n;
   __shared__ int s_cnt[3];
+  __shared__ unsigned int s_dup[32];      // exhaustive search: bit k = vertex k coincides with a lower-indexed vertex (R <= 800 < 1024)
   const int lane = threadIdx.x;
   for (unsigned int it = blockIdx.x; it < nList; it += gridDim.x) {
     const int cand = hullList[it];
@@ -1674,14 +1675,28 @@ __global__ void __launch_bounds__(64) k_hull(const int* __restrict__ hullList, u
       if (lane == 0) s_n = nfast;
     } else {
     hull_probes(pv, R, lane, s_probe, 0, 8);
+    // Degenerate vertex sets (round 6; Rays_Cartesian: its eight pole rays end in ONE float32 point).  One triple stands for a facet plane:
+    // the lexicographically first NON-DEGENERATE one among the plane's points -- a point that coincides with a lower-indexed point is
+    // left out altogether (s_dup), and a point on the line through (a, b) cannot complete them.  (Until round 6 the rule was "the three
+    // lowest indices on the plane": a plane whose three lowest points coincide or are collinear lost its facet, the hull was open there and
+    // the intersection volume too large -- found with tools/diag_cartesian.py against the reference's Qhull volumes.)
+    if (lane < 32) s_dup[lane] = 0u;
+    __syncthreads();
+    for (int k = lane; k < R; k += 64) {
+      bool dp = false;
+      for (int j = 0; j < k && !dp; ++j) dp = pv[3 * j] == pv[3 * k] && pv[3 * j + 1] == pv[3 * k + 1] && pv[3 * j + 2] == pv[3 * k + 2];
+      if (dp) atomicOr(&s_dup[k >> 5], 1u << (k & 31));
+    }
     __syncthreads();
     for (int a = 0; a < R - 2; ++a) {
+      if ((s_dup[a >> 5] >> (a & 31)) & 1u) continue;
       const double az = pv[3 * a], ay = pv[3 * a + 1], ax = pv[3 * a + 2];
       for (int b = a + 1; b < R - 1; ++b) {
+        if ((s_dup[b >> 5] >> (b & 31)) & 1u) continue;
         const double ez = pv[3 * b] - az, ey = pv[3 * b + 1] - ay, ex = pv[3 * b + 2] - ax;
         for (int c0 = b + 1; c0 < R; c0 += 64) {
           const int c = c0 + lane;
-          bool ok = c < R;
+          bool ok = c < R && !((s_dup[(c < R ? c : 0) >> 5] >> ((c < R ? c : 0) & 31)) & 1u);
           double nz = 0, ny = 0, nx = 0, eps = 0;
           if (ok) {
             const double fz = pv[3 * c] - az, fy = pv[3 * c + 1] - ay, fx = pv[3 * c + 2] - ax;
@@ -1705,9 +1720,15 @@ __global__ void __launch_bounds__(64) k_hull(const int* __restrict__ hullList, u
             const double tz = __shfl(nz, src), ty = __shfl(ny, src), tx = __shfl(nx, src), te = __shfl(eps, src);
             bool pos = false, neg = false, low = false;
             for (int q = lane; q < R; q += 64) {
-              if (q == a || q == b || q == cc) continue;
-              const double sd_ = tz * (pv[3 * q] - az) + ty * (pv[3 * q + 1] - ay) + tx * (pv[3 * q + 2] - ax);
-              if (sd_ > te) pos = true; else if (sd_ < -te) neg = true; else if (q < cc) low = true;
+              if (q == a || q == b || q == cc || ((s_dup[q >> 5] >> (q & 31)) & 1u)) continue;
+              const double gz = pv[3 * q] - az, gy = pv[3 * q + 1] - ay, gx = pv[3 * q + 2] - ax;
+              const double sd_ = tz * gz + ty * gy + tx * gx;
+              if (sd_ > te) pos = true; else if (sd_ < -te) neg = true;
+              else if (q < b) low = true;                       // (a, b) are not the plane's two lowest points
+              else if (q < cc) {                                // a lower point that completes (a, b) as well -- unless it lies on their line
+                const double kz = ey * gx - ex * gy, ky = ex * gz - ez * gx, kx = ez * gy - ey * gz;
+                if (sqrt(kz * kz + ky * ky + kx * kx) > 1e-12 * ext * ext) low = true;
+              }
             }
             const bool anyp = __any(pos), anyn = __any(neg), anyl = __any(low);
             if (!(anyp && anyn) && !anyl && lane == 0) {
@@ -2003,7 +2024,7 @@ __global__ void __launch_bounds__(256) k_stage5(const int2* __restrict__ pairs, 
                                                 const float* __restrict__ pts, const float* __restrict__ verts,
                                                 const int* __restrict__ faces, int R, int F, const int* __restrict__ bbox,
                                                 const float* __restrict__ volume, float thr, SuppSink sink, Stats* st,
-                                                sd3::ConeMap cm) {
+                                                sd3::ConeMap cm, int whole_box) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* pv1 = (float*)smem;       // 3R
   float* pv2 = pv1 + 3 * R;        // 3R
@@ -2035,12 +2056,15 @@ __global__ void __launch_bounds__(256) k_stage5(const int2* __restrict__ pairs, 
     }
     const bool safe1 = !s_unsafe[0] && fabsf(c1[0]) < 8192.f && fabsf(c1[1]) < 8192.f && fabsf(c1[2]) < 8192.f;
     const bool safe2 = !s_unsafe[1] && fabsf(c2[0]) < 8192.f && fabsf(c2[1]) < 8192.f && fabsf(c2[2]) < 8192.f;
-    // the reference sweeps the whole bbox of i; lattice points outside j's (rounded) bbox cannot be inside j
+    // the reference sweeps the whole bbox of i; lattice points outside j's (rounded) bbox cannot be inside j -- unless the ray mesh has a
+    // DEGENERATE face (whole_box; Rays_Cartesian: pole rays on one line): a tetrahedron (centre, A, B, C) of zero volume passes
+    // inside_tetrahedron's four `det >= 0` tests (:89-150) on its whole PLANE, lattice points far outside j's box included, and the reference
+    // counts those that fall into i's box.  Then the sweep is the reference's (round 6, found with tools/diag_cartesian2.py).
     const int* b1 = bbox + 6 * (size_t)ij.x;
     const int* b2 = bbox + 6 * (size_t)ij.y;
-    const int zlo = max(b1[0], b2[0] - 1), zhi = min(b1[1], b2[1] + 1);
-    const int ylo = max(b1[2], b2[2] - 1), yhi = min(b1[3], b2[3] + 1);
-    const int xlo = max(b1[4], b2[4] - 1), xhi = min(b1[5], b2[5] + 1);
+    const int zlo = whole_box ? b1[0] : max(b1[0], b2[0] - 1), zhi = whole_box ? b1[1] : min(b1[1], b2[1] + 1);
+    const int ylo = whole_box ? b1[2] : max(b1[2], b2[2] - 1), yhi = whole_box ? b1[3] : min(b1[3], b2[3] + 1);
+    const int xlo = whole_box ? b1[4] : max(b1[4], b2[4] - 1), xhi = whole_box ? b1[5] : min(b1[5], b2[5] + 1);
     unsigned int local = 0;
     if (zhi >= zlo && yhi >= ylo && xhi >= xlo) {
       const i64 bz = zhi - zlo + 1, by = yhi - ylo + 1, bx = xhi - xlo + 1;
@@ -2675,7 +2699,7 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
           const unsigned int b5 = h.nP5 < 16384u ? h.nP5 : 16384u;
           if (stats) SD_CHECK(hipEventRecord(ev0, s));
           hipLaunchKernelGGL(k_stage5, dim3(b5), dim3(256), lds5, s, pairs5, h.nP5, d_dist, d_points, d_verts, d_faces, R, F, bbox, volume,
-                             threshold, sink, d_st, cmap);
+                             threshold, sink, d_st, cmap, mesh_ok ? 0 : 1);
           SD_LAUNCH_CHECK();
           if (stats) { SD_CHECK(hipEventRecord(ev1, s)); SD_CHECK(hipEventSynchronize(ev1)); float ms = 0; SD_CHECK(hipEventElapsedTime(&ms, ev0, ev1)); ns5 += ms * 1e6; }
         }

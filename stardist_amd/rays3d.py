@@ -96,10 +96,14 @@ _WARNED_DEGENERATE = set()
 
 def warn_if_degenerate(rays):
     """One warning per kind of ray set with (nearly) coincident rays.  `Rays_Cartesian` is the case: its pole rays differ by
-    1e-12 (rays3d.py:189-197), so the polyhedron's pole vertices collapse to one float32 point and the mesh has degenerate triangles at both poles -- the reference's
-    own Qhull calls print precision warnings for every such polyhedron.  How Qhull treats the duplicate vertices (hulls, half-space
-    intersections) is NOT reproduced by the 3D NMS / the "full" render mode: survivors and a few voxels can differ from the reference
-    (DESIGN.md section 5 item 3a).  The closed sets (GoldenSpiral, Octo, Tetra, SubDivide) are pinned."""
+    1e-12 (rays3d.py:189-197), so the polyhedron's pole vertices collapse to one float32 point (or lie on one line through the centre)
+    and the mesh has degenerate triangles at both poles -- the reference's own Qhull calls print precision warnings for every such
+    polyhedron and its cascade runs on its error paths (kernel stage: Qhull error for every pair; rendered overlap: a tetrahedron of zero
+    volume passes the inside test on its whole plane).  Since round 6 the 3D NMS follows it there (hulls of point sets with coincident /
+    collinear points, the rendered overlap over the whole box of the first polyhedron; DESIGN.md section 4 item 3a: keep flags identical on
+    the lattice goldens).  What stays open: two such polyhedra in an exactly symmetric position (same distances, centres differing along
+    the pole axis only) -- the hull-stage volume is off there (decisions on the goldens unaffected).  The closed sets (GoldenSpiral, Octo,
+    Tetra, SubDivide) are pinned."""
     fn = getattr(rays, "has_coincident_vertices", None)
     if fn is None or not fn():
         return False
@@ -107,9 +111,10 @@ def warn_if_degenerate(rays):
     if key not in _WARNED_DEGENERATE:
         _WARNED_DEGENERATE.add(key)
         import warnings
-        warnings.warn("%s: some rays coincide in float32 (degenerate faces). The 3D NMS and polyhedron_to_label(mode='full') do not reproduce "
-                      "Qhull's handling of such meshes: results can differ from the reference (DESIGN.md section 5, item 3a); "
-                      "Rays_GoldenSpiral (the default) is pinned." % key, stacklevel=3)
+        warnings.warn("%s: some rays coincide in float32 (degenerate faces): the reference's Qhull stages run on their error paths for such "
+                      "meshes. The 3D NMS follows them (identical keep flags on the lattice goldens, DESIGN.md section 4 item 3a); polyhedra in "
+                      "exactly symmetric positions along the pole axis are a known limit of the hull-stage volume. Rays_GoldenSpiral (the "
+                      "default) is pinned." % key, stacklevel=3)
     return True
 
 

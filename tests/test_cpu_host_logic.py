@@ -244,8 +244,9 @@ def test_unet_batch_norm_matches_keras_semantics_and_round_trips(tmp_path):
 
 
 def test_ray_sets_with_coincident_float32_vertices_are_flagged():
-    """Rays_Cartesian's pole rays differ by 1e-12 and collapse in float32 (degenerate faces): the 3D entry points warn once per set that the
-    reference's (Qhull's) treatment of such meshes is not reproduced; the closed sets are silent"""
+    """Rays_Cartesian's pole rays differ by 1e-12 and collapse in float32 (degenerate faces): the 3D entry points warn once per set (the
+    reference's Qhull stages run on their error paths there; followed since round 6 with one documented limit, DESIGN.md section 4 item 3a);
+    the closed sets are silent"""
     import warnings
     from stardist_amd.rays3d import Rays_Cartesian, Rays_GoldenSpiral, Rays_Octo, Rays_Tetra, rays_from_json, warn_if_degenerate
     assert Rays_Cartesian(8, 5).has_coincident_vertices() and Rays_Cartesian().has_coincident_vertices()

@@ -212,3 +212,35 @@ def test_reference_nms2d_is_not_translation_invariant(refmods):
     k1 = m.c_non_max_suppression_inds(d, (p + np.float32(2048)).astype(np.float32), 1, 1, 0, np.float32(0.4))
     ndiff = int((k0 != k1).sum())
     assert 0 < ndiff < 1e-3 * len(d), ndiff                        # measured: 40 of 104 580
+
+
+def test_reference_cascade_on_rays_cartesian_runs_on_its_error_paths(refmods, capfd):
+    """What the reference does with Rays_Cartesian (pole rays 1e-12 apart: one float32 point, or points on one line through the centre), stage by
+    stage with its own functions (oracle shim `pair_cascade`, stardist3d_impl.cpp:1207-1318) -- the behaviour the device NMS follows since
+    round 6 (tests/test_gpu_lattice.py): the inner-sphere bound is ~0 (a degenerate face has distance 0), the kernel stage returns Qhull's
+    error value for EVERY pair (zero-normal half-spaces), the hull stage returns 1e10 whenever the midpoint of the centres is not inside
+    both hulls, and the rendered overlap counts lattice points far outside a polyhedron (a zero-volume tetrahedron passes the four
+    `det >= 0` tests on its whole plane): more voxels "inside" than the polyhedron has volume."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_lattice_golden import rays_of
+    from oracle import synth
+    rays = rays_of("cartesian_8_5")
+    V, F = rays.vertices.astype(np.float32), rays.faces.astype(np.int32)
+    d, p, s = synth.lattice_candidates_3d(len(V), "int", size=48)
+    P = p.astype(np.float32)
+    pairs = np.array([[3, 8], [3, 15], [22, 27], [22, 29], [2, 21]], np.int32)
+    C = refmods.pair_cascade(d, P, V, F, pairs)
+    capfd.readouterr()                                   # (Qhull's precision warnings)
+    rk, rh = refmods.pair_volumes(d, P, V, F, pairs)
+    capfd.readouterr()
+    assert np.array_equal(C[:, 4], rk) and np.array_equal(C[:, 5], rh)
+    assert (C[:, 4] == 0).all()                          # kernel stage: error value for every pair
+    assert (np.abs(C[:, 3]) < 1e-6).all()                # inner spheres: nothing
+    assert (C[:, 5] > 1e9).sum() >= 3 and (C[:, 5] < 1e9).sum() >= 1
+    assert (C[:, 2] > 0).all() and (C[:, 0] > 200).all() and (C[:, 1] > 200).all()
+    # the rendered overlap of (3, 8) is what suppresses candidate 8 at threshold 0.2 in the lattice golden: 65 voxels of 310.2
+    assert int(C[0, 6]) == 65 and abs(C[0, 0] - 310.2327) < 1e-3
+    G3 = np.load(os.path.join(ROOT, "tests", "golden", "lattice_reference.npz"))
+    keep = np.unpackbits(G3["nms3d_cartesian_8_5_int_0.2"])[:len(d)].astype(bool)
+    assert keep[3] and not keep[8]
