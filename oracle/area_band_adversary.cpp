@@ -353,6 +353,12 @@ int main(int argc, char** argv) {
       temp = 0.02 * (1.0 - (double)it / iters) + 0.002;
     }
     famEvals[fam][free_mode] += g_evals - e0;
+    if ((rs + 1) % 2000 == 0) {          // progress (a run that is cut short still states how far it came)
+      double ws = 0, wf = 0;
+      for (int f = 0; f < NFAM; ++f) { ws = famWorst[f][0] > ws ? famWorst[f][0] : ws; wf = famWorst[f][1] > wf ? famWorst[f][1] : wf; }
+      printf("progress: seed %llu, %ld restarts, %llu evaluations (%llu usable), worst %.4f (star %.4f, free %.4f)\n", seed, rs + 1, g_evals, g_usable, worst, ws, wf);
+      fflush(stdout);
+    }
   }
   printf("seed %llu: %llu evaluations (%llu usable), worst |A_clipper - A| / band = %.4f\n", seed, g_evals, g_usable, worst);
   for (int f = 0; f < NFAM; ++f)

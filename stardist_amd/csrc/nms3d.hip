@@ -516,6 +516,18 @@ __device__ __forceinline__ HivFrame hiv_frame(const double* __restrict__ hs, int
   const double a = mz_ * fr.uz + my_ * fr.uy + mx_ * fr.ux, b = mz_ * fr.vz + my_ * fr.vy + mx_ * fr.vx,     \
                e = mz_ * fr.oz + my_ * fr.oy + mx_ * fr.ox + md_;
 
+// COINCIDENT half-spaces (round 6).  Two polyhedra of the same shape whose centres differ along a direction that lies IN a facet plane have
+// that plane twice, bit for bit (Rays_Cartesian's vertical band under a shift along the pole axis, an octahedron under a shift (1, 1, 0)):
+// each of the twins cuts the other's face with a trace "line" a = b = 0, e = +-1 ulp, so that rounding decided whether a face was counted
+// twice, once or not at all (found with tools/diag_cartesian3.py: 285.8 instead of 321.7).  The twins bound the intersection ONCE: the
+// lower index keeps its face, the higher one drops out.  +1: m is a twin of k and wins (face k is empty); -1: m is a twin and loses (m
+// does not cut k); 0: not a twin.  Unit normals; tol: rounding of an offset at the size of the objects.
+__device__ __forceinline__ int hiv_twin(const double* __restrict__ hs, int k, int m, double a, double b, double e, double L) {
+  if (!(a * a + b * b <= 1e-24) || !(fabs(e) <= 1e-12 * L)) return 0;
+  if (hs[4 * m] * hs[4 * k] + hs[4 * m + 1] * hs[4 * k + 1] + hs[4 * m + 2] * hs[4 * k + 2] <= 0) return 0;      // opposite: a slab of zero width, not a twin
+  return m < k ? 1 : -1;
+}
+
 // Scratch-resident fallback (arbitrary polygons up to HIV_MAXP vertices); only used for the rare faces that exceed
 // the LDS capacities below.  Returns area * height (height from c); NaN on overflow.
 __device__ __noinline__ double hiv_face_term(const double* __restrict__ hs, int M, int k, const double c[3], double L) {
@@ -530,6 +542,7 @@ __device__ __noinline__ double hiv_face_term(const double* __restrict__ hs, int 
   for (int m = 0; m < M; ++m) {
     if (m == k) continue;
     HIV_LINE(fr, hs, m, a, b, e)
+    if (hiv_twin(hs, k, m, a, b, e, L) > 0) return 0;
     const double nrm = sqrt(a * a + b * b);
     if (nrm > 0) dmin = fmin(dmin, fabs(e) / nrm);
   }
@@ -542,6 +555,7 @@ __device__ __noinline__ double hiv_face_term(const double* __restrict__ hs, int 
       const double n2 = a * a + b * b;
       const bool is_near = (n2 > 0) && (e * e <= near_lim * near_lim * n2);
       if (is_near != (pass == 0)) continue;
+      if (hiv_twin(hs, k, m, a, b, e, L) < 0) continue;
       // the origin is inside (e <= 0) and the whole polygon is closer to the origin than the line: nothing to cut
       if (e <= 0 && e * e >= rad2 * n2 * (1.0 + 1e-12)) continue;
       if (!hiv_clip(P, a, b, e)) return NAN;
@@ -701,7 +715,12 @@ __device__ __forceinline__ double hiv_face_term_lds(const double* __restrict__ h
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int m = m0 + q;
-      const bool misses = (e4[q] + radm <= 0) || (e4[q] <= 0 && e4[q] * e4[q] >= rad2 * n4[q] * (1.0 + 1e-12));
+      bool misses = (e4[q] + radm <= 0) || (e4[q] <= 0 && e4[q] * e4[q] >= rad2 * n4[q] * (1.0 + 1e-12));
+      if (m < M && m != k && n4[q] <= 1e-24 && fabs(e4[q]) <= 1e-12 * L) {            // coincident twin (hiv_twin)
+        const int tw = hiv_twin(hs, k, m, 0.0, 0.0, e4[q], L);
+        if (tw > 0) return 0;
+        if (tw < 0) misses = true;
+      }
       const bool cand = (m < M) && !misses && m != k && m != sd[0] && m != sd[1] && m != sd[2];
       if (cand) {
         if (nl < HIV_LCAP) { W.list[nl * 64 + lane] = (unsigned short)m; ++nl; }
@@ -734,6 +753,7 @@ __device__ __forceinline__ double hiv_face_term_lds(const double* __restrict__ h
     HIV_LINE(fr, hs, m, a, b, e)
     const double n2 = a * a + b * b;
     if (e <= 0 && e * e >= rad2 * n2 * (1.0 + 1e-12)) continue;
+    if (hiv_twin(hs, k, m, a, b, e, L) < 0) continue;
     if (!hiv_clip_lds(W, lane, n, a, b, e)) { fallback = true; return 0; }
     rad2 = hiv_rad2(W, lane, n);
   }

@@ -101,8 +101,7 @@ def warn_if_degenerate(rays):
     polyhedron and its cascade runs on its error paths (kernel stage: Qhull error for every pair; rendered overlap: a tetrahedron of zero
     volume passes the inside test on its whole plane).  Since round 6 the 3D NMS follows it there (hulls of point sets with coincident /
     collinear points, the rendered overlap over the whole box of the first polyhedron; DESIGN.md section 4 item 3a: keep flags identical on
-    the lattice goldens).  What stays open: two such polyhedra in an exactly symmetric position (same distances, centres differing along
-    the pole axis only) -- the hull-stage volume is off there (decisions on the goldens unaffected).  The closed sets (GoldenSpiral, Octo,
+    the lattice goldens).  The closed sets (GoldenSpiral, Octo,
     Tetra, SubDivide) are pinned."""
     fn = getattr(rays, "has_coincident_vertices", None)
     if fn is None or not fn():
@@ -112,9 +111,8 @@ def warn_if_degenerate(rays):
         _WARNED_DEGENERATE.add(key)
         import warnings
         warnings.warn("%s: some rays coincide in float32 (degenerate faces): the reference's Qhull stages run on their error paths for such "
-                      "meshes. The 3D NMS follows them (identical keep flags on the lattice goldens, DESIGN.md section 4 item 3a); polyhedra in "
-                      "exactly symmetric positions along the pole axis are a known limit of the hull-stage volume. Rays_GoldenSpiral (the "
-                      "default) is pinned." % key, stacklevel=3)
+                      "meshes. The 3D NMS follows them (identical keep flags on the lattice goldens, DESIGN.md section 4 item 3a). "
+                      "Rays_GoldenSpiral (the default) is pinned on many more inputs." % key, stacklevel=3)
     return True
 
 

@@ -7,7 +7,7 @@ from scipy.spatial import ConvexHull, HalfspaceIntersection
 from make_lattice_golden import rays_of
 from stardist_amd.lib import stardist3d as sd3
 shifts = [(0, 0, 0), (1e-5, 0, 0), (1e-5, 2e-5, 3e-5), (1, 0, 0), (1.00001, 0, 0), (1, 1e-5, 0), (1, 1e-5, 2e-5), (2, 0, 0), (0, 1, 0), (1, 1, 0), (1, 1.00001, 0), (3, 0, 0), (0.5, 0, 0)]
-for name in ("cartesian_8_5", "golden32"):
+for name in ("cartesian_8_5", "octo", "golden32"):
     rays = rays_of(name)
     V, F = rays.vertices.astype(np.float32), rays.faces.astype(np.int32)
     for dist in (5.0,):
