@@ -174,6 +174,18 @@ int sd_polygons_to_label_window_device(const float* d_coord, const int32_t* d_la
 int sd_dist_to_coord_device(const float* d_dist, const double* d_points, const double* d_sincos, long long n_polys, int n_rays,
                             double scale_y, double scale_x, float* d_coord, void* stream);
 
+/* ---- behind the 2D NMS on predict_instances (stardist/models/model2d.py:536-561) --------------
+ * positions of the non-zero keep flags, ascending (the `inds` of non_maximum_suppression_sparse, nms.py:175-183: boolean-mask indexing):
+ * d_positions (n) int64 receives *d_count entries. */
+int sd_survivor_positions_device(const unsigned char* d_keep, long long n, long long* d_positions, int32_t* d_count, void* stream);
+/* for candidates in SCORE order (descending, as the NMS takes them): rows of the m survivors at d_positions -- prob (m), points (m, 2)
+ * int64 -- their polygon coordinates d_out_coord (m, 2, R) = dist_to_coord (geom2d.py:130-146, arithmetic of sd_dist_to_coord_device,
+ * scale 1), and the same coordinates in the order polygons_to_label paints them (ascending score, stable: geom2d.py:186-197) with
+ * their label ids minus one, d_out_labels_paint (m) -- the inputs of sd_polygons_to_label_device.  d_out_coord_paint may be NULL. */
+int sd_survivors2d_device(const long long* d_positions, int m, const float* d_prob, const long long* d_points, const float* d_dist,
+                          int n_rays, const double* d_sincos, float* d_out_prob, long long* d_out_points, float* d_out_coord,
+                          float* d_out_coord_paint, int32_t* d_out_labels_paint, void* stream);
+
 /* ---- 3D non-maximum suppression -------------------------------------------------------------
  * name, signature and semantics of the reference's C ABI
  *   (stardist/lib/stardist3d_lib.h:52-66 -> _COMMON_non_maximum_suppression_sparse,

@@ -121,6 +121,41 @@ def c_polygons_to_label(coord, labels, shape, window=None):
     return out
 
 
+def survivors_of_sorted(keep, prob, points, dist, want_paint=True):
+    """What model2d.py:536-561 does with the keep flags of candidates that are in SCORE order, on the device and in two native calls
+    (csrc/survivors.hip): returns (prob (m,), points (m, 2) int64, coord (m, 2, R) float32, coord_paint, labels_paint) -- coord_paint /
+    labels_paint (int32, label id - 1) are the polygons in the order polygons_to_label paints them (ascending score, stable:
+    geom2d.py:186-197), ready for c_polygons_to_label; None without want_paint.  keep: uint8 / bool device tensor (n,); prob (n,)
+    float32, points (n, 2) int64, dist (n, R) float32, all on keep's device.  One read-back (the survivor count)."""
+    import torch
+    from ..geometry.geom2d import ray_angles, _SC_CACHE
+    N.require_device()
+    assert keep.is_cuda and prob.dtype == torch.float32 and dist.dtype == torch.float32 and points.dtype == torch.int64 and points.shape[1] == 2
+    n, R = int(dist.shape[0]), int(dist.shape[1])
+    assert keep.numel() == n == prob.numel() == points.shape[0]
+    dev = keep.device
+    keep = keep.contiguous().view(torch.uint8) if keep.dtype == torch.bool else keep.contiguous()
+    prob, points, dist = prob.contiguous(), points.contiguous(), dist.contiguous()
+    pos = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    N.dcall(keep, "sd_survivor_positions_device", N.tptr(keep), n, N.tptr(pos), N.tptr(cnt))
+    m = int(cnt.item())
+    key = (R, str(dev))
+    sct = _SC_CACHE.get(key)
+    if sct is None:
+        phis = ray_angles(R)
+        sct = _SC_CACHE[key] = torch.as_tensor(np.ascontiguousarray(np.array([np.sin(phis), np.cos(phis)])), device=dev)
+    oprob = torch.empty(m, dtype=torch.float32, device=dev)
+    opts = torch.empty((m, 2), dtype=torch.int64, device=dev)
+    coord = torch.empty((m, 2, R), dtype=torch.float32, device=dev)
+    cpaint = torch.empty((m, 2, R), dtype=torch.float32, device=dev) if want_paint else None
+    lpaint = torch.empty(m, dtype=torch.int32, device=dev) if want_paint else None
+    if m:
+        N.dcall(keep, "sd_survivors2d_device", N.tptr(pos), m, N.tptr(prob), N.tptr(points), N.tptr(dist), R, N.tptr(sct), N.tptr(oprob), N.tptr(opts),
+                N.tptr(coord), N.tptr(cpaint) if want_paint else None, N.tptr(lpaint) if want_paint else None)
+    return oprob, opts, coord, cpaint, lpaint
+
+
 def clip_pairs(xa, ya, xb, yb):
     """Pair-level probe (tests): 2*area of A∩B per pair as the reference's Clipper call sums it.
     xa..yb int32 (n_pairs, n_verts) numpy arrays. Returns (twice_area int64, flags int32)."""

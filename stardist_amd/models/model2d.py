@@ -48,6 +48,18 @@ class StarDist2D(StarDistBase):
         if nms_thresh is None: nms_thresh = self.thresholds.nms
         if overlap_label is not None:
             raise NotImplementedError("overlap_label not supported for 2D yet!")
+        import torch
+        if scale is None and cand.dist.is_cuda and cand.dist.dtype == torch.float32 and cand.points.dtype == torch.int64 and len(cand.prob):
+            # the keep flags straight into the survivors' rows, coordinates and painting order (csrc/survivors.hip: two native calls and one
+            # read-back where the generic path below issues a dozen framework launches), then the rasteriser and ONE transfer to the host
+            from ..lib.stardist2d import survivors_of_sorted, c_polygons_to_label
+            from ..nms import nms_keep_sorted
+            from ..utils import to_host_many
+            keep = nms_keep_sorted(cand.dist, cand.prob, cand.points_f32, nms_thresh=nms_thresh, **nms_kwargs)
+            probi, points, coord, cpaint, lpaint = survivors_of_sorted(keep, cand.prob, cand.points, cand.dist, want_paint=return_labels)
+            labels = c_polygons_to_label(cpaint, lpaint, img_shape) if return_labels else None
+            labels, coord_h, points_h, prob_h = to_host_many([labels, coord, points, probi])
+            return labels, dict(coord=coord_h, points=points_h, prob=prob_h)
         idx = non_maximum_suppression_sparse_sorted(cand.dist, cand.prob, cand.points_f32, nms_thresh=nms_thresh, **nms_kwargs)
         return self._instances_from_survivors(img_shape, cand.points.index_select(0, idx), cand.prob.index_select(0, idx),
                                               cand.dist.index_select(0, idx), return_labels=return_labels, scale=scale)

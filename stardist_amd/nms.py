@@ -154,12 +154,16 @@ def _survivor_positions(keep):
 def non_maximum_suppression_sparse_sorted(dist, prob, points, b=2, nms_thresh=0.5, use_bbox=True, use_kdtree=True, verbose=False):
     """non_maximum_suppression_sparse (stardist/nms.py:135-183) for candidates that are ALREADY in score order (descending, the order
     `np.argsort(prob)[::-1]` gives them) as device tensors: positions (int64 tensor) of the survivors, best score first."""
+    return _survivor_positions(nms_keep_sorted(dist, prob, points, b=b, nms_thresh=nms_thresh, use_bbox=use_bbox, use_kdtree=use_kdtree, verbose=verbose))
+
+
+def nms_keep_sorted(dist, prob, points, b=2, nms_thresh=0.5, use_bbox=True, use_kdtree=True, verbose=False):
+    """the keep flags (uint8 device tensor) behind non_maximum_suppression_sparse_sorted: same arguments, same candidates in score order"""
     from .lib.stardist2d import c_non_max_suppression_inds
     import torch
     assert dist.ndim == 2 and prob.ndim == 1 and points.ndim == 2 and points.shape[-1] == 2 and len(prob) == len(dist) == len(points)
-    keep = c_non_max_suppression_inds(dist.to(torch.float32).contiguous(), points.to(torch.float32).contiguous(), int(use_kdtree), 1, int(verbose),
+    return c_non_max_suppression_inds(dist.to(torch.float32).contiguous(), points.to(torch.float32).contiguous(), int(use_kdtree), 1, int(verbose),
                                       np.float32(nms_thresh), _as_uint8=True)          # (use_bbox: nms.py:175-176 passes its default)
-    return _survivor_positions(keep)
 
 
 def non_maximum_suppression_3d_sparse_sorted(dist, prob, points, rays, b=2, nms_thresh=0.5, use_kdtree=True, verbose=False):

@@ -95,3 +95,56 @@ def test_to_host_many_one_sync():
     b = torch.rand(7, 3, device=dev)
     out = to_host_many([a, None, b, torch.ones(3)])
     assert np.array_equal(out[0], a.cpu().numpy()) and out[1] is None and np.array_equal(out[2], b.cpu().numpy()) and np.array_equal(out[3], np.ones(3, np.float32))
+
+
+@pytest.mark.parametrize("n,R,frac,ties", [(5000, 32, 0.1, False), (5000, 32, 0.3, True), (3000, 11, 0.02, True), (4097, 64, 0.5, False), (7, 32, 1.0, True), (1500, 32, 0.0, False)])
+def test_survivors_of_sorted_equals_the_reference_lines(n, R, frac, ties):
+    """csrc/survivors.hip against the numpy statement of model2d.py:536-561 + geom2d.py:130-146, 186-197: positions of the keep flags, the
+    survivors' rows, dist_to_coord, and the painting order `np.argsort(prob, kind='stable')` with label ids = position in NMS order (+ 1
+    in the rasteriser) -- with TIES in the scores (groups of equal probabilities keep their NMS order while the groups reverse)"""
+    import torch
+    from stardist_amd.lib.stardist2d import survivors_of_sorted
+    from stardist_amd.geometry.geom2d import ray_angles
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(n + R)
+    prob = np.sort(rng.uniform(0.3, 1, n).astype(np.float32))[::-1].copy()
+    if ties:
+        prob = np.sort(np.round(prob, 2))[::-1].copy()             # long runs of equal scores
+    pts = rng.randint(0, 3000, (n, 2)).astype(np.int64)
+    dist = rng.uniform(0.5, 40, (n, R)).astype(np.float32)
+    keep = rng.uniform(0, 1, n) < frac
+    got = survivors_of_sorted(torch.from_numpy(keep).to(dev), torch.from_numpy(prob).to(dev), torch.from_numpy(pts).to(dev), torch.from_numpy(dist).to(dev))
+    oprob, opts, coord, cpaint, lpaint = [g.cpu().numpy() for g in got]
+    idx = np.flatnonzero(keep)
+    assert np.array_equal(oprob, prob[idx]) and np.array_equal(opts, pts[idx])
+    phis = ray_angles(R)
+    want = (dist[idx][:, np.newaxis] * np.array([np.sin(phis), np.cos(phis)])).astype(np.float32)
+    want += pts[idx][..., np.newaxis]
+    assert coord.dtype == np.float32 and np.array_equal(coord, want)
+    ind = np.argsort(prob[idx], kind="stable")
+    assert np.array_equal(lpaint, ind.astype(np.int32)) and np.array_equal(cpaint, want[ind])
+
+
+def test_predict_instances_2d_fused_survivors_equal_generic_path():
+    """predict_instances through the fused survivors path == the generic chain (positions -> gathers -> dist_to_coord -> stable sort ->
+    rasteriser): labels and every entry of the result dict, on a prediction with a few thousand instances"""
+    import torch
+    import bench
+    from oracle import synth
+    from stardist_amd.models import Config2D, StarDist2D
+    dev = torch.device("cuda:0")
+    img = torch.from_numpy(synth.s2d_nuclei_image(768, 640, seed=3)).to(dev)
+    m = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
+    bench.calibrate_heads(m, img)
+    lab1, res1 = m.predict_instances(img)
+    # the generic chain, called directly on the same candidates
+    from stardist_amd.nms import non_maximum_suppression_sparse_sorted
+    cand = None
+    for r in m._predict_sparse_generator(img, axes=None, _presort=True):
+        cand = r if r is not None else cand
+    idx = non_maximum_suppression_sparse_sorted(cand.dist, cand.prob, cand.points_f32, nms_thresh=m.thresholds.nms)
+    lab2, res2 = m._instances_from_survivors(tuple(img.shape), cand.points.index_select(0, idx), cand.prob.index_select(0, idx), cand.dist.index_select(0, idx))
+    assert len(res1["prob"]) > 300
+    assert np.array_equal(lab1, lab2)
+    for k in ("coord", "points", "prob"):
+        assert res1[k].dtype == res2[k].dtype and np.array_equal(res1[k], res2[k]), k
