@@ -90,6 +90,32 @@ def test_nms3d_random_survivors(refmods, shape, n_rays, noise, thr):
     assert len(diff) == 0, "survivor mismatch at %s of %d (stats %s)" % (diff[:10], len(d), stats.tolist())
 
 
+@pytest.mark.parametrize("nx,nz,shape,noise,thr", [(8, 5, (22, 33, 44), 0.3, 0.3), (11, 5, (22, 33, 44), 0.0, 0.2), (11, 5, (22, 33, 44), 0.5, 0.5),
+                                                     (6, 4, (20, 30, 40), 0.2, 0.4)])
+def test_nms3d_rays_cartesian_random_survivors(refmods, nx, nz, shape, noise, thr):
+    """`Rays_Cartesian` (pole rays 1e-12 apart: degenerate faces, the reference's cascade on its error paths -- DESIGN.md section 4 item 3a) on
+    RANDOM float candidates, as the reference's tests/test_nms3D.py draws them: same survivors (until round 6 only the closed ray sets
+    were pinned; the lattice goldens of tests/test_gpu_lattice.py cover the integer case)"""
+    import warnings
+    from stardist_amd.lib import stardist3d as sd3
+    from stardist_amd.rays3d import Rays_Cartesian
+    rays = Rays_Cartesian(nx, nz)
+    V, F = rays.vertices.astype(np.float32), rays.faces.astype(np.int32)
+    d, p, s = _random_candidates(shape, len(V), noise, seed=len(V))
+    ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(thr))
+    import torch
+    dev = torch.device("cuda:0")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        keep, stats = sd3.c_non_max_suppression_inds(*[torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (d, p, V, F, s)], 1, 1, 0, np.float32(thr), return_stats=True)
+    keep = keep.cpu().numpy()                      # (device tensors in: the stats of the host-array entry point are not filled)
+    diff = np.flatnonzero(keep != ref_keep)
+    print("cartesian(%d, %d) %s noise %.1f thr %.1f: %d candidates -> %d survivors, kernel-stage suppressions %d, rendered pairs %d" %
+          (nx, nz, shape, noise, thr, len(d), int(keep.sum()), int(stats[6]), int(stats[3])))
+    assert int(stats[6]) == 0 and int(stats[2]) > 0 and int(stats[7]) > 0      # the kernel stage runs and never suppresses on such a mesh (Qhull error for every pair): the rendering decides
+    assert len(diff) == 0, "survivor mismatch at %s of %d (stats %s)" % (diff[:10], len(d), stats.tolist())
+
+
 @pytest.mark.parametrize("n,thr,aniso", [(64, 0.3, None), (96, 0.3, None), (64, 0.5, (2, 1, 1))])
 def test_nms3d_nuclei_survivors(refmods, n, thr, aniso):
     from oracle import synth
