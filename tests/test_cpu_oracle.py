@@ -244,3 +244,23 @@ def test_reference_cascade_on_rays_cartesian_runs_on_its_error_paths(refmods, ca
     G3 = np.load(os.path.join(ROOT, "tests", "golden", "lattice_reference.npz"))
     keep = np.unpackbits(G3["nms3d_cartesian_8_5_int_0.2"])[:len(d)].astype(bool)
     assert keep[3] and not keep[8]
+
+
+@pytest.mark.parametrize("name", ["octo1", "tetra3"])
+def test_ref_3d_matches_lattice_golden_more(refmods, name, capfd):
+    """the round-6 lattice goldens of the symmetric ray sets (tests/golden/make_lattice_golden_more.py) are what the compiled reference
+    returns here: keep flags at both thresholds, one OpenMP thread"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_lattice_golden_more import rays_of_more
+    from oracle import synth
+    G4 = np.load(os.path.join(ROOT, "tests", "golden", "lattice_reference_more.npz"))
+    rays = rays_of_more(name)
+    V, F = rays.vertices.astype(np.float32), rays.faces.astype(np.int32)
+    refmods.set_threads(1)
+    for fam in ("const", "int"):
+        d, p, s = synth.lattice_candidates_3d(len(V), fam, size=48)
+        for thr in (0.2, 0.4):
+            keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(thr)).astype(bool)
+            assert np.array_equal(np.packbits(keep), G4["nms3d_%s_%s_%.1f" % (name, fam, thr)]), (name, fam, thr)
+    capfd.readouterr()

@@ -12,7 +12,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-G = np.load(os.path.join(ROOT, "tests", "golden", "lattice_reference.npz"))
+G = dict(np.load(os.path.join(ROOT, "tests", "golden", "lattice_reference.npz")))
+G.update(dict(np.load(os.path.join(ROOT, "tests", "golden", "lattice_reference_more.npz"))))      # round 6: symmetric ray sets (make_lattice_golden_more.py)
 SHAPE2D, SIZE3D = (96, 96), 48
 CASES2D = [(R, fam, 0) for R in (4, 8, 16, 32) for fam in ("const", "int", "half")]
 # Rays_Cartesian: its pole rays differ by 1e-12 and COINCIDE in float32 (degenerate triangles at both poles; the reference's own Qhull calls
@@ -20,7 +21,13 @@ CASES2D = [(R, fam, 0) for R in (4, 8, 16, 32) for fam in ("const", "int", "half
 # (xfail); followed since round 6: the hull of a point set with coincident / collinear points (k_hull's exhaustive search lost the facets
 # whose three lowest-indexed points coincide), the rendered overlap over the WHOLE box of the first polyhedron (a zero-volume tetrahedron is
 # "inside" on its whole plane).
-RAYS3D = ("octo", "golden32", "golden32_aniso", "cartesian_8_5")
+RAYS3D = ("octo", "golden32", "golden32_aniso", "cartesian_8_5", "octo1", "octo2", "tetra3", "cartesian_11_5", "golden96")
+
+
+def _rays_of(name):
+    from make_lattice_golden import rays_of
+    from make_lattice_golden_more import RAYS3D_MORE, rays_of_more
+    return rays_of_more(name) if name in RAYS3D_MORE else rays_of(name)
 
 
 @pytest.mark.parametrize("strict", [0, 1])
@@ -51,20 +58,38 @@ def test_raster2d_lattice_polygons(R, fam, seed):
     assert np.array_equal(lab, want), (R, fam, int((lab != want).sum()))
 
 
+def _decided_at_a_midpoint_on_a_hull_facet(j, want, p, d, V, tol=1e-9):
+    """candidate j meets a better-scored survivor i (reference's flags) such that (c_i + c_j) / 2 lies on the boundary of the hull of i or of j"""
+    from _hull import on_hull_boundary
+    P = np.asarray(p, np.float32)
+    for i in np.flatnonzero(want[:j]):
+        if np.abs(P[i] - P[j]).max() > 2 * float(np.asarray(d).max()) + 2:
+            continue
+        mid = 0.5 * (P[i].astype(np.float64) + P[j])
+        if on_hull_boundary(mid[None], P[[i, j]], np.asarray(d)[[i, j]], V, tol=tol).any():
+            return True
+    return False
+
+
 @pytest.mark.parametrize("fam", ["const", "int"])
 @pytest.mark.parametrize("name", RAYS3D)
 def test_nms3d_lattice_polyhedra(name, fam):
-    from make_lattice_golden import rays_of
     from oracle import synth
     from stardist_amd.lib import stardist3d as sd3
-    rays = rays_of(name)
+    rays = _rays_of(name)
     V, F = rays.vertices.astype(np.float32), rays.faces.astype(np.int32)
     d, p, s = synth.lattice_candidates_3d(len(V), fam, size=SIZE3D)
     for thr in (0.2, 0.4):
         want = np.unpackbits(G["nms3d_%s_%s_%.1f" % (name, fam, thr)])[:len(d)].astype(bool)
         keep, st = sd3.c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(thr), return_stats=True)
         diff = np.flatnonzero(keep != want)
+        # One class of flags is exempt, of the same kind as the hull-facet voxels of the rasteriser (DESIGN.md section 4 items 3 / 3b): the hull
+        # stage asks whether the MIDPOINT of the two centres is strictly inside both hulls (qh_sethalfspace, 1e10 if not); when that midpoint
+        # lies EXACTLY on a hull facet, Qhull's answer is the sign of a 1e-16 residual of its normalised plane (whose bits depend on the order in
+        # which quickhull added the points).  Found on the plain octahedron (octo1 / const / 0.4: one flag of the 10 000 of these sets).
+        diff = np.array([j for j in diff if not _decided_at_a_midpoint_on_a_hull_facet(j, want, p, d, V)], int)
         assert len(diff) == 0, (name, fam, thr, len(diff), diff[:8], st.tolist())
+        assert len(np.flatnonzero(keep != want)) <= 2
 
 
 @pytest.mark.parametrize("name,fam,mode,mname", [(n, f, m, mn) for n in RAYS3D for f in ("const", "int") for m, mn in ((0, "full"), (1, "kernel"))])
@@ -72,10 +97,9 @@ def test_raster3d_lattice_polyhedra(name, fam, mode, mname):
     """voxel for voxel; mode "full" except voxels exactly on the hull of a polyhedron that covers them (tests/_hull.py: the reference's answer
     there is rounding noise of Qhull's planes; measured on these sets: 57 - 173 of 110 592 voxels, every one of them on a hull facet)"""
     from _hull import on_hull_boundary
-    from make_lattice_golden import rays_of
     from oracle import synth
     from stardist_amd.lib import stardist3d as sd3
-    rays = rays_of(name)
+    rays = _rays_of(name)
     V, F = rays.vertices.astype(np.float32), rays.faces.astype(np.int32)
     d, p, s = synth.lattice_candidates_3d(len(V), fam, size=SIZE3D)
     keep = np.unpackbits(G["nms3d_%s_%s_%.1f" % (name, fam, 0.2)])[:len(d)].astype(bool)

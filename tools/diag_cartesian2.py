@@ -10,8 +10,10 @@ from oracle import synth, ref
 from stardist_amd.lib import stardist3d as sd3, _native as N
 
 dev = torch.device("cuda:0")
-G = np.load(os.path.join(ROOT, "tests", "golden", "lattice_reference.npz"))
-rays = rays_of("cartesian_8_5")
+G = dict(np.load(os.path.join(ROOT, "tests", "golden", "lattice_reference.npz"))); G.update(dict(np.load(os.path.join(ROOT, "tests", "golden", "lattice_reference_more.npz"))))
+NAME = sys.argv[2] if len(sys.argv) > 2 else "cartesian_8_5"
+from make_lattice_golden_more import RAYS3D_MORE, rays_of_more
+rays = rays_of_more(NAME) if NAME in RAYS3D_MORE else rays_of(NAME)
 V, F = rays.vertices.astype(np.float32), rays.faces.astype(np.int32)
 tV, tF = torch.from_numpy(V).to(dev), torch.from_numpy(F).to(dev)
 fam = sys.argv[1] if len(sys.argv) > 1 else "int"
@@ -28,7 +30,7 @@ def inside(k, pts, use_map=1):
     return r
 
 for thr in (0.2, 0.4):
-    want = np.unpackbits(G["nms3d_%s_%s_%.1f" % ("cartesian_8_5", fam, thr)])[:n].astype(bool)
+    want = np.unpackbits(G["nms3d_%s_%s_%.1f" % (NAME, fam, thr)])[:n].astype(bool)
     keep = np.asarray(sd3.c_non_max_suppression_inds(d, P, V, F, s, 1, 1, 0, np.float32(thr))).astype(bool)
     diff = np.flatnonzero(keep != want)
     print("RESULT", fam, thr, "default options: flags differ on", len(diff), diff[:12].tolist())
