@@ -116,6 +116,21 @@ def test_nms3d_rays_cartesian_random_survivors(refmods, nx, nz, shape, noise, th
     assert len(diff) == 0, "survivor mismatch at %s of %d (stats %s)" % (diff[:10], len(d), stats.tolist())
 
 
+@pytest.mark.parametrize("use_bbox,use_kdtree,thr", [(0, 1, 0.3), (1, 0, 0.3), (0, 0, 0.3), (0, 0, -0.5), (1, 1, -0.5), (1, 1, 0.0), (0, 1, 0.0)])
+def test_nms3d_flag_combinations(refmods, use_bbox, use_kdtree, thr):
+    """`use_bbox` / `use_kdtree` off and thresholds <= 0 (stardist3d_impl.cpp:1167-1175 every j > i instead of the radius search, :1221 the
+    pretest only with use_bbox; a negative threshold suppresses on the first bound): same survivors as the compiled reference"""
+    from stardist_amd.lib import stardist3d as sd3
+    rays = _rays(32)
+    V, F = rays.vertices, rays.faces.astype(np.int32)
+    d, p, s = _random_candidates((18, 24, 30), 32, 0.3, seed=5, prob_thresh=0.93, radius=6)
+    assert 300 < len(d) < 800
+    ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, use_bbox, use_kdtree, 0, np.float32(thr))
+    keep = sd3.c_non_max_suppression_inds(d, p, V, F, s, use_bbox, use_kdtree, 0, np.float32(thr))
+    diff = np.flatnonzero(keep != ref_keep)
+    assert len(diff) == 0, (use_bbox, use_kdtree, thr, diff[:10], int(ref_keep.sum()), int(keep.sum()))
+
+
 @pytest.mark.parametrize("n,thr,aniso", [(64, 0.3, None), (96, 0.3, None), (64, 0.5, (2, 1, 1))])
 def test_nms3d_nuclei_survivors(refmods, n, thr, aniso):
     from oracle import synth
