@@ -58,10 +58,9 @@ def main():
     import stardist_amd.utils as UT
     wrap(model, "_net_forward", "net_forward")
     wrap(model, "_select_sorted", "select + sort + distance head on the sorted rows")
-    wrap(NMS, "non_maximum_suppression_sparse_sorted", "nms (native + survivor positions)")
-    wrap(L2, "c_non_max_suppression_inds", "  nms_inds(native)")
-    wrap(G2, "polygons_to_label_coord", "raster")
-    wrap(M2, "dist_to_coord", "dist_to_coord")
+    wrap(NMS, "nms_keep_sorted", "nms (sd_nms2d_device)")
+    wrap(L2, "survivors_of_sorted", "survivors: positions, rows, coord, painting order (csrc/survivors.hip)")
+    wrap(L2, "c_polygons_to_label", "raster")
     wrap(UT, "to_host_many", "results_to_host (labels, coord, points, prob)")
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(a.steps):
