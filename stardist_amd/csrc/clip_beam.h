@@ -31,6 +31,13 @@
 // the compiled reference Clipper on millions of pairs) and against the reference Clipper directly.
 #pragma once
 #include "clip_sweep.h"
+// SD_BLK: a large block of the sweep with ONE call site -- part of its caller (no code growth, no call); see the note on calls at add_out_pt_t.
+// -DSD_BEAM_BLOCKS_AS_CALLS restores the round-5 form (every block a real call) for A/B timing.
+#if defined(SD_BEAM_BLOCKS_AS_CALLS)
+#define SD_BLK SD_HDN
+#else
+#define SD_BLK SD_HD
+#endif
 #include <limits.h>
 
 #if defined(BEAM_COUNT) && !defined(__HIP_DEVICE_COMPILE__)
@@ -489,25 +496,40 @@ struct BeamCore {
   }
 
   // ------------------------------------------------------------------ output (delegated to D)
-  SD_HD int add_out_pt(int e, int px, int py) { BEAM_CNT(outpt, 1); return self().out_add_pt(e, px, py); }
-  SD_HDN void add_local_max_poly(int e1, int e2, int px, int py) {           // :1884-1897
-    add_out_pt(e1, px, py);
+  // Calls and the call graph (round 6).  A device function that calls another one has to keep its return address over that call: the
+  // compiler parks it in a lane of a callee-saved VGPR, and that VGPR is stored to SCRATCH in the prologue and re-loaded -- with a full
+  // wait on memory -- in front of every return.  The sweep of one pair returned from ~250 such functions (several per scan-beam), a
+  // round trip to memory each: a large part of the ~0.5 ms a single sweep lasts, which is what bounds the late launches of the NMS.
+  // So: the big blocks with ONE call site (run_sweep, process_horizontal, build_intersect_list, process_edges_at_top_of_scanbeam,
+  // do_maxima, insert_local_minima_into_ael) are part of the kernel body (no code growth), and every real call is a LEAF -- the
+  // blocks with several call sites (intersect_edges, add_local_min_poly, add_local_max_poly, out_add_pt, out_append, ...) have their
+  // own callees inlined (the <true> forms below) and touch no scratch.  The code stays near the size of the instruction cache.
+  template <bool IN> SD_HD int add_out_pt_t(int e, int px, int py) {
+    BEAM_CNT(outpt, 1);
+    if (IN) return self().out_add_pt_i(e, px, py);
+    return self().out_add_pt(e, px, py);
+  }
+  SD_HD int add_out_pt(int e, int px, int py) { return add_out_pt_t<false>(e, px, py); }
+  template <bool IN> SD_HD void add_local_max_poly_t(int e1, int e2, int px, int py) {           // :1884-1897
+    add_out_pt_t<IN>(e1, px, py);
     if (outidx[e1] == outidx[e2]) {
       if (outidx[e1] >= 0) self().out_ring_closed(outidx[e1]);
       outidx[e1] = kUnassigned; outidx[e2] = kUnassigned;
-    } else if (self().out_ring_before(outidx[e1], outidx[e2])) self().out_append(e1, e2);   // OutRec index order (:1893)
-    else self().out_append(e2, e1);
+    } else if (self().out_ring_before(outidx[e1], outidx[e2])) { if (IN) self().out_append_i(e1, e2); else self().out_append(e1, e2); }   // OutRec index order (:1893)
+    else { if (IN) self().out_append_i(e2, e1); else self().out_append(e2, e1); }
   }
-  SD_HDN int add_local_min_poly(int e1, int e2, int px, int py) {            // :1841-1881
+  SD_HDN void add_local_max_poly(int e1, int e2, int px, int py) { add_local_max_poly_t<true>(e1, e2, px, py); }
+  SD_HDN int add_local_min_poly(int e1, int e2, int px, int py) { return add_local_min_poly_t<true>(e1, e2, px, py); }
+  template <bool IN> SD_HD int add_local_min_poly_t(int e1, int e2, int px, int py) {            // :1841-1881
     int e, prevE, result;
     if (is_horz(e2) || dx[e1] > dx[e2]) {
-      result = add_out_pt(e1, px, py);
+      result = add_out_pt_t<IN>(e1, px, py);
       outidx[e2] = outidx[e1];
       side[e1] = kLeft; side[e2] = kRight;
       e = e1;
       prevE = (aprev(e) == e2) ? aprev(e2) : aprev(e);
     } else {
-      result = add_out_pt(e2, px, py);
+      result = add_out_pt_t<IN>(e2, px, py);
       outidx[e1] = outidx[e2];
       side[e1] = kRight; side[e2] = kLeft;
       e = e2;
@@ -517,7 +539,7 @@ struct BeamCore {
       i64 xPrev = top_x(prevE, py), xE = top_x(e, py);
       if (xPrev == xE && wdelta[e] != 0 && wdelta[prevE] != 0 &&
           slopes_equal4(xPrev, py, topx[prevE], topy[prevE], xE, py, topx[e], topy[e])) {
-        const int outPt = add_out_pt(prevE, px, py);
+        const int outPt = add_out_pt_t<IN>(prevE, px, py);
         add_join(result, outPt, topx[e], topy[e]);
       }
     }
@@ -621,37 +643,37 @@ struct BeamCore {
     int e2Wc = wcnt[e2] < 0 ? -wcnt[e2] : wcnt[e2];
     if (c1 && c2) {
       if ((e1Wc != 0 && e1Wc != 1) || (e2Wc != 0 && e2Wc != 1) || (ptyp[e1] != ptyp[e2])) {
-        add_local_max_poly(e1, e2, px, py);
+        add_local_max_poly_t<true>(e1, e2, px, py);
       } else {
-        add_out_pt(e1, px, py);
-        add_out_pt(e2, px, py);
+        add_out_pt_t<true>(e1, px, py);
+        add_out_pt_t<true>(e2, px, py);
         signed char s = side[e1]; side[e1] = side[e2]; side[e2] = s;
         signed char o = outidx[e1]; outidx[e1] = outidx[e2]; outidx[e2] = o;
       }
     } else if (c1) {
       if (e2Wc == 0 || e2Wc == 1) {
-        add_out_pt(e1, px, py);
+        add_out_pt_t<true>(e1, px, py);
         signed char s = side[e1]; side[e1] = side[e2]; side[e2] = s;
         signed char o = outidx[e1]; outidx[e1] = outidx[e2]; outidx[e2] = o;
       }
     } else if (c2) {
       if (e1Wc == 0 || e1Wc == 1) {
-        add_out_pt(e2, px, py);
+        add_out_pt_t<true>(e2, px, py);
         signed char s = side[e1]; side[e1] = side[e2]; side[e2] = s;
         signed char o = outidx[e1]; outidx[e1] = outidx[e2]; outidx[e2] = o;
       }
     } else if ((e1Wc == 0 || e1Wc == 1) && (e2Wc == 0 || e2Wc == 1)) {
       int e1Wc2 = wcnt2[e1] < 0 ? -wcnt2[e1] : wcnt2[e1];
       int e2Wc2 = wcnt2[e2] < 0 ? -wcnt2[e2] : wcnt2[e2];
-      if (ptyp[e1] != ptyp[e2]) add_local_min_poly(e1, e2, px, py);
+      if (ptyp[e1] != ptyp[e2]) add_local_min_poly_t<true>(e1, e2, px, py);
       else if (e1Wc == 1 && e2Wc == 1) {
-        if (e1Wc2 > 0 && e2Wc2 > 0) add_local_min_poly(e1, e2, px, py);
+        if (e1Wc2 > 0 && e2Wc2 > 0) add_local_min_poly_t<true>(e1, e2, px, py);
       } else { signed char s = side[e1]; side[e1] = side[e2]; side[e2] = s; }
     }
   }
 
   // ------------------------------------------------------------------ InsertLocalMinimaIntoAEL  :1978-2077
-  SD_HDN void insert_local_minima_into_ael(int botY) {
+  SD_BLK void insert_local_minima_into_ael(int botY) {
     while (cur_lm < n_lm && next_lm_y == botY) {
       const int m = mlm[cur_lm];
       ++cur_lm;
@@ -744,7 +766,7 @@ struct BeamCore {
     }
     return r;
   }
-  SD_HDN void process_horizontal(int horz) {
+  SD_BLK void process_horizontal(int horz) {
     BEAM_CNT(horz, 1);
     bool l2r; i64 hl, hr;
     if (botx[horz] < topx[horz]) { hl = botx[horz]; hr = topx[horz]; l2r = true; }
@@ -866,7 +888,7 @@ struct BeamCore {
       if (a1 > a2) ipx = top_x(e2, ipy); else ipx = top_x(e1, ipy);
     }
   }
-  SD_HDN void build_intersect_list(int topY) {
+  SD_BLK void build_intersect_list(int topY) {
     const int n = n_ael;
     if (n == 0) return;
     ord_t w = ord;
@@ -944,7 +966,7 @@ struct BeamCore {
   }
 
   // ------------------------------------------------------------------ top of scan-beam  :2957-3113
-  SD_HDN void do_maxima(int e) {
+  SD_BLK void do_maxima(int e) {
     BEAM_CNT(maxima, 1);
     int mp;
     const int mpid = get_maxima_pair_ex(e, mp);
@@ -969,7 +991,7 @@ struct BeamCore {
       delete_from_ael(e); delete_from_ael(mp);
     } else status |= ST_FAIL;   // "DoMaxima error" -> Execute fails, empty solution
   }
-  SD_HDN void process_edges_at_top_of_scanbeam(int topY) {
+  SD_BLK void process_edges_at_top_of_scanbeam(int topY) {
     int e = ael_head();
     int guard = 0;
     while (e >= 0) {
@@ -1035,7 +1057,7 @@ struct BeamCore {
     n_lm = 0; cur_lm = 0; n_il = 0; status = ST_OK; n_joins = 0; n_gj = 0; n_xtra = 0;
   }
   // Runs the sweep.  Returns false if Clipper's Execute would fail (empty solution).
-  SD_HDN bool run_sweep() {
+  SD_BLK bool run_sweep() {
     const Prep* a = prepA; const Prep* b = prepB;
     status |= (a->status | b->status);
     // merged local-minima list: stable by Y descending, polygon A (added first, :157) before B on ties
@@ -1057,10 +1079,10 @@ struct BeamCore {
     cur_lm = 0;
     next_lm_y = lm_y(0);
     int botY = next_lm_y, topY = 0;
-    insert_local_minima_into_ael(botY);
     int guard = 0;
     bool ok = true;
     for (;;) {
+      insert_local_minima_into_ael(botY);              // (in front of the loop and at its end in Clipper: ONE call site here, same sequence)
       if (status & (ST_OVERFLOW_AEL | ST_OVERFLOW_REC | ST_OVERFLOW_IL | ST_ITER)) { ok = false; break; }
       const bool popped = pop_scanbeam(botY, topY);
       if (!popped) break;
@@ -1072,7 +1094,6 @@ struct BeamCore {
       process_edges_at_top_of_scanbeam(topY);
       if (status & ST_FAIL) { ok = false; break; }
       botY = topY;
-      insert_local_minima_into_ael(botY);
     }
     if (!ok || (status & ST_FAIL)) { status |= ST_FAIL; return false; }
     return true;
@@ -1101,7 +1122,9 @@ struct Beam : BeamCore<Beam<MAXV, K, MAXIL, MAXREC, P>, P, MAXV, K, MAXIL> {
   typename P::template Scalar<i64, O_TWICE> twice_area;      // sum over closed rings of |2*area|
   typename P::template Scalar<i64, O_SABS> sum_abs_terms;    // sum of |cross| terms (exactness bound for the float path)
   SD_HD void term(i64 c) { sum_abs_terms += sd_abs64(c); }
-  SD_HDN int out_add_pt(int e, int px, int py) {                             // :2463-2499
+  SD_HDN int out_add_pt(int e, int px, int py) { return out_add_pt_i(e, px, py); }
+  SD_HDN void out_append(int e1, int e2) { out_append_i(e1, e2); }
+  SD_HD int out_add_pt_i(int e, int px, int py) {                            // :2463-2499
     int r = outidx[e];
     if (r < 0) {
       const int f = rfree;
@@ -1138,7 +1161,7 @@ struct Beam : BeamCore<Beam<MAXV, K, MAXIL, MAXREC, P>, P, MAXV, K, MAXIL> {
     if (r1 < 0 || r2 < 0) return r1 < r2;
     return rser[r1] < rser[r2];
   }
-  SD_HDN void out_append(int e1, int e2) {                                   // :2367-2460
+  SD_HD void out_append_i(int e1, int e2) {                                  // :2367-2460
     int r1 = outidx[e1], r2 = outidx[e2];
     if (r1 < 0 || r2 < 0) { status |= ST_OVERFLOW_REC; return; }          // only after a ring-capacity overflow
     i64 c;
