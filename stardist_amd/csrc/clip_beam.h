@@ -31,13 +31,6 @@
 // the compiled reference Clipper on millions of pairs) and against the reference Clipper directly.
 #pragma once
 #include "clip_sweep.h"
-// SD_BLK: a large block of the sweep with ONE call site -- part of its caller (no code growth, no call); see the note on calls at add_out_pt_t.
-// -DSD_BEAM_BLOCKS_AS_CALLS restores the round-5 form (every block a real call) for A/B timing.
-#if defined(SD_BEAM_BLOCKS_AS_CALLS)
-#define SD_BLK SD_HDN
-#else
-#define SD_BLK SD_HD
-#endif
 #include <limits.h>
 
 #if defined(BEAM_COUNT) && !defined(__HIP_DEVICE_COMPILE__)

@@ -53,6 +53,13 @@
 #define SD_HD inline
 #define SD_HDN inline
 #endif
+// SD_BLK: a large block of the sweep with ONE call site -- part of its caller (no code growth, no call, and no scratch round trip for the
+// return address a calling function has to keep: clip_beam.h, note at add_out_pt_t).  -DSD_BEAM_BLOCKS_AS_CALLS: every block a real call.
+#if defined(SD_BEAM_BLOCKS_AS_CALLS)
+#define SD_BLK SD_HDN
+#else
+#define SD_BLK SD_HD
+#endif
 
 namespace sdclip {
 
@@ -709,7 +716,7 @@ struct SweepCore {
   }
 
   // ------------------------------------------------------------------ InsertLocalMinimaIntoAEL  :1978-2077
-  SD_HDN void insert_local_minima_into_ael(int botY) {
+  SD_BLK void insert_local_minima_into_ael(int botY) {
     while (cur_lm < n_lm && lm[cur_lm].y == botY) {
       int lb = lm[cur_lm].left, rb = lm[cur_lm].right;
       ++cur_lm;
@@ -767,7 +774,7 @@ struct SweepCore {
     if (r >= 0 && (anext[r] == aprev[r] && !is_horz(r))) return -1;
     return r;
   }
-  SD_HDN void process_horizontal(int horz) {
+  SD_BLK void process_horizontal(int horz) {
     bool l2r; i64 hl, hr;
     if (botx[horz] < topx[horz]) { hl = botx[horz]; hr = topx[horz]; l2r = true; }
     else { hl = topx[horz]; hr = botx[horz]; l2r = false; }
@@ -875,7 +882,7 @@ struct SweepCore {
       if (a1 > a2) ipx = top_x(e2, ipy); else ipx = top_x(e1, ipy);
     }
   }
-  SD_HDN void build_intersect_list(int topY) {
+  SD_BLK void build_intersect_list(int topY) {
     if (ael < 0) return;
     int e = ael;
     sel = (short)e;
@@ -940,7 +947,7 @@ struct SweepCore {
   }
 
   // ------------------------------------------------------------------ top of scan-beam  :2957-3113
-  SD_HDN void do_maxima(int e) {
+  SD_BLK void do_maxima(int e) {
     int eMaxPair = get_maxima_pair_ex(e);
     if (eMaxPair < 0) {
       if (outidx[e] >= 0) add_out_pt(e, topx[e], topy[e]);
@@ -962,7 +969,7 @@ struct SweepCore {
       delete_from_ael(e); delete_from_ael(eMaxPair);
     } else status |= ST_FAIL;   // "DoMaxima error" -> Execute fails, empty solution
   }
-  SD_HDN void process_edges_at_top_of_scanbeam(int topY) {
+  SD_BLK void process_edges_at_top_of_scanbeam(int topY) {
     int e = ael;
     int guard = 0;
     while (e >= 0) {
@@ -1024,7 +1031,7 @@ struct SweepCore {
   }
   // Runs the sweep (Clipper::ExecuteInternal up to the end of the scan-beam loop). Returns false if
   // Clipper's Execute would fail (empty solution).
-  SD_HDN bool run_sweep() {
+  SD_BLK bool run_sweep() {
     if (n_lm == 0) return true;
     if (!StdSort<LocMin>::sort(lm, n_lm)) status |= ST_SORT_DEPTH;
     for (int i = 0; i < n_lm; ++i) {
@@ -1035,10 +1042,10 @@ struct SweepCore {
     ael = -1; cur_lm = 0;
     int botY, topY = 0;
     if (!pop_scanbeam(botY)) return false;
-    insert_local_minima_into_ael(botY);
     int guard = 0;
     bool ok = true;
     for (;;) {
+      insert_local_minima_into_ael(botY);              // (in front of the loop and at its end in Clipper: ONE call site here, same sequence)
       bool popped = pop_scanbeam(topY);
       if (!popped && !(cur_lm < n_lm)) break;
       if (++guard > 4 * NE) { status |= ST_ITER; break; }
@@ -1048,7 +1055,6 @@ struct SweepCore {
       process_edges_at_top_of_scanbeam(topY);
       if (status & ST_FAIL) { ok = false; break; }
       botY = topY;
-      insert_local_minima_into_ael(botY);
     }
     if (!ok || (status & ST_FAIL)) { status |= ST_FAIL; return false; }
     return true;
