@@ -1245,7 +1245,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   };
   auto account = [&](const char* what) -> int {
     if (h.nPairs > pairCap || h.nSpill > qCap || h.nExact > qCap) { sd::set_error("sd_nms2d: pair queue overflow (internal error)"); return -1; }
-    if (h.nErr) { sd::set_error("sd_nms2d: %u pairs exceeded the general path's fixed capacities or the deferred-pair list", h.nErr); return -1; }
+    if (h.nErr) { sd::set_error("sd_nms2d: %u pairs exceeded the general path's fixed capacities or the deferred-pair list (with more than 64 rays: at least that many; the launch stops at the first)", h.nErr); return -1; }
     totalPairs += (i64)h.nPairs; totalExact += h.nExact; totalSpill += h.nSpill; totalDecided += h.nDecided;
     if (stats) {
       float ms = 0, ms2 = 0;

@@ -27,6 +27,9 @@ __global__ void __launch_bounds__(64) k_full_pairs(const int2* __restrict__ pair
   // pair t -> lane (t / gridDim.x) of workgroup (t % gridDim.x): a short list is spread over the workgroups' FIRST lanes, one sweep per wave
   // -- the sweeps of different pairs share no control flow, and 62 of them packed into two waves take as long as their sum
   for (unsigned int t = threadIdx.x * gridDim.x + blockIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    // the call fails as soon as ONE pair exceeds the fixed capacities (sd_nms2d reports it): nobody needs the other pairs then, and with
+    // 128 / 256 vertices per polygon and every pair overflowing (rays that vary by +-90 %) they would take minutes
+    if (MAXV > 64 && __hip_atomic_load(errCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
     const unsigned int p = idx ? idx[t] : t;
     const int2 ij = pairs[p];
     sdclip::SweepFull<MAXV, MAXIL, MAXREC, MAXPT, MAXJ> sw;
@@ -159,8 +162,11 @@ int clip_full_pairs(const int2* d_pairs, const unsigned int* d_idx, const unsign
     }
     hipLaunchKernelGGL((k_full_pairs_lds<32, 64, 32, 192, 64>), dim3(1024), dim3(LDSF_T), ldsBytes, s, d_pairs, d_idx, d_n, cap, R, d_vx, d_vy, d_area, thr, d_state, d_supp, d_errCount);
   } else if (R <= 64) hipLaunchKernelGGL((k_full_pairs<64, 96, 48, 384, 96>), dim3(2048), dim3(64), 0, s, d_pairs, d_idx, d_n, cap, R, d_vx, d_vy, d_area, thr, d_state, d_supp, d_errCount);
-  else if (R <= 128) hipLaunchKernelGGL((k_full_pairs<128, 128, 64, 768, 128>), dim3(2048), dim3(64), 0, s, d_pairs, d_idx, d_n, cap, R, d_vx, d_vy, d_area, thr, d_state, d_supp, d_errCount);
-  else hipLaunchKernelGGL((k_full_pairs<256, 192, 96, 1536, 192>), dim3(2048), dim3(64), 0, s, d_pairs, d_idx, d_n, cap, R, d_vx, d_vy, d_area, thr, d_state, d_supp, d_errCount);
+  // (the private sweep state of these two is 32 / 62 KB per LANE: 2 / 4 MB of scratch per wave.  With 2048 workgroups the 256-vertex form
+  // faulted -- "memory aperture violation" -- on its first NMS-level run in round 6; the grid is sized so that the launch's scratch
+  // stays near 1 GB.  Pairs are dealt round-robin over whatever grid there is.)
+  else if (R <= 128) hipLaunchKernelGGL((k_full_pairs<128, 128, 64, 768, 128>), dim3(512), dim3(64), 0, s, d_pairs, d_idx, d_n, cap, R, d_vx, d_vy, d_area, thr, d_state, d_supp, d_errCount);
+  else hipLaunchKernelGGL((k_full_pairs<256, 192, 96, 1536, 192>), dim3(256), dim3(64), 0, s, d_pairs, d_idx, d_n, cap, R, d_vx, d_vy, d_area, thr, d_state, d_supp, d_errCount);
   SD_LAUNCH_CHECK();
   return 0;
 }

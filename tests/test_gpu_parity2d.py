@@ -49,6 +49,40 @@ def test_nms2d_survivors_bit_exact(refmods, shape, R, thr):
     assert len(diff) == 0, "survivor mismatch at %s (pairs=%d joins=%d)" % (diff[:10], stats[0], stats[1])
 
 
+@pytest.mark.parametrize("shape,R,radius,noise,thr", [((120, 110), 64, 12, 0.2, 0.4), ((160, 150), 96, 15, 0.5, 0.3), ((150, 140), 128, 20, 0.3, 0.5),
+                                                       ((120, 110), 200, 25, 0.1, 0.4), ((90, 80), 48, 8, 0.1, 0.6), ((100, 100), 256, 18, 0.05, 0.4)])
+def test_nms2d_survivors_bit_exact_many_rays(refmods, shape, R, radius, noise, thr):
+    """more than 32 rays (round 6: until then only the pair-level probe had met them): no decision shortcut, no offset-ordered pair list --
+    every pair goes to the bound-slot sweep of the next vertex capacity (64 / 128 / 256) and, with joins or beyond its capacities, to the
+    general path of that capacity.  Same survivors as the compiled reference."""
+    from oracle import synth
+    from stardist_amd.lib import stardist2d as sd2
+    d, p, s = synth.s2d_uniform(shape[0], shape[1], n_rays=R, radius=radius, noise=noise, seed=R)
+    assert len(d) > 500
+    ref_keep = refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(thr))
+    keep, stats = sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(thr), return_stats=True)
+    diff = np.flatnonzero(keep != ref_keep)
+    assert len(diff) == 0, "survivor mismatch at %s of %d (pairs=%d general path=%d)" % (diff[:10], len(d), stats[0], stats[1])
+
+
+@pytest.mark.parametrize("shape,R,radius,noise", [((80, 80), 256, 18, 0.9), ((120, 110), 200, 25, 0.6)])
+def test_nms2d_many_rays_beyond_the_capacities_fail_loudly_and_fast(shape, R, radius, noise):
+    """polygons of 200 / 256 rays whose neighbouring rays differ by up to +-90 % exceed the fixed capacities of the general path (hundreds of
+    local minima): the call has to say so -- not fault (round 6: 2048 workgroups of the 256-vertex kernel, 4 MB of scratch per wave, ended in a
+    memory aperture violation) and not grind through every other overflowing pair for minutes (the launch stops at the first)"""
+    import time
+    from oracle import synth
+    from stardist_amd.lib import _native, stardist2d as sd2
+    d, p, s = synth.s2d_uniform(shape[0], shape[1], n_rays=R, radius=radius, noise=noise, seed=R)
+    t0 = time.time()
+    with pytest.raises(_native.NativeError, match="exceeded the general path's fixed capacities"):
+        sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(0.4))
+    assert time.time() - t0 < 30
+    # the library is usable afterwards
+    d2, p2, s2 = synth.s2d_uniform(64, 64, n_rays=32)
+    assert sd2.c_non_max_suppression_inds(d2, p2, 1, 1, 0, np.float32(0.4)).sum() > 0
+
+
 @pytest.mark.parametrize("flags", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_nms2d_flags(refmods, flags):
     from oracle import synth
