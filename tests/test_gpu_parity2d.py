@@ -83,6 +83,60 @@ def test_nms2d_many_rays_beyond_the_capacities_fail_loudly_and_fast(shape, R, ra
     assert sd2.c_non_max_suppression_inds(d2, p2, 1, 1, 0, np.float32(0.4)).sum() > 0
 
 
+class _ref_threads(object):
+    """OpenMP threads of the compiled reference for one call (restored to the core count afterwards)"""
+
+    def __init__(self, refmods, n): self.r, self.n = refmods, n
+
+    def __enter__(self): self.r.set_threads(self.n)
+
+    def __exit__(self, *a):
+        import os
+        self.r.set_threads(os.cpu_count() or 1)
+
+
+def _cands2d(rng, n, R, radius, noise, extent):
+    d = (radius * (1 + noise * rng.uniform(-1, 1, (n, R)))).astype(np.float32)
+    p = rng.uniform(0, extent, (n, 2)).astype(np.float32).round()
+    s = rng.uniform(0, 1, n).astype(np.float32)
+    o = np.argsort(s, kind="stable")[::-1]
+    return np.ascontiguousarray(d[o]), np.ascontiguousarray(p[o]), np.ascontiguousarray(s[o])
+
+
+@pytest.mark.parametrize("R,radius,noise,extent,n,thr", [(32, 0.4, 0.5, 12, 600, 0.3), (32, 1.1, 0.8, 20, 800, 0.5), (8, 0.8, 0.3, 10, 400, 0.1),
+                                                          (32, 400, 0.2, 3000, 300, 0.4), (32, 1500, 0.1, 9000, 200, 0.3), (16, 6000, 0.3, 30000, 150, 0.5),
+                                                          (32, 40, 0.3, 60000, 700, 0.4)])
+def test_nms2d_extreme_sizes(refmods, R, radius, noise, extent, n, thr):
+    """polygons far below one pixel (every vertex truncates to the centre or its neighbours: zero areas, the reference divides by
+    area + 1e-10) and far beyond the windows of the fast paths (16-bit relative coordinates of the first sweep tier: +-32 767; exact
+    float predicates of the decision shortcut: +-1 023), and ordinary polygons at coordinates up to 60 000: same survivors"""
+    from stardist_amd.lib import stardist2d as sd2
+    rng = np.random.RandomState(int(radius * 10) + R)
+    d, p, s = _cands2d(rng, n, R, radius, noise, extent)
+    with _ref_threads(refmods, 2):
+        ref_keep = refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(thr))
+    for strict in (0, 1):
+        from stardist_amd.lib import _native
+        with _native.option("nms2d_strict", strict):
+            keep = sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(thr))
+        diff = np.flatnonzero(keep != ref_keep)
+        assert len(diff) == 0, (R, radius, strict, diff[:10], int(ref_keep.sum()), int(keep.sum()))
+    assert 0 < ref_keep.sum() <= n
+
+
+@pytest.mark.parametrize("thr", [0.0, -0.1, 1.0, 1.5, 1e-6, 0.999999])
+def test_nms2d_threshold_edges(refmods, thr):
+    """thresholds at and beyond the ends of [0, 1] (stardist2d.cpp:580-581 `overlap > thr`; a negative one suppresses on any candidate pair
+    the bounding boxes let through, one above 1 never)"""
+    from oracle import synth
+    from stardist_amd.lib import stardist2d as sd2
+    d, p, s = synth.s2d_uniform(64, 56, n_rays=32, radius=7, noise=0.3, seed=11)
+    with _ref_threads(refmods, 2):               # (the reference's OpenMP loop over a few hundred candidates: more threads only spin)
+        ref_keep = refmods.stardist2d().c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(thr))
+    keep = sd2.c_non_max_suppression_inds(d, p, 1, 1, 0, np.float32(thr))
+    assert np.array_equal(keep, ref_keep), (thr, int(keep.sum()), int(ref_keep.sum()), np.flatnonzero(keep != ref_keep)[:10])
+
+
 @pytest.mark.parametrize("flags", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_nms2d_flags(refmods, flags):
     from oracle import synth

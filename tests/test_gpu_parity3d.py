@@ -131,6 +131,24 @@ def test_nms3d_flag_combinations(refmods, use_bbox, use_kdtree, thr):
     assert len(diff) == 0, (use_bbox, use_kdtree, thr, diff[:10], int(ref_keep.sum()), int(keep.sum()))
 
 
+@pytest.mark.parametrize("rays_name,shape,radius,noise,thr,pth", [("tetra1", (20, 24, 28), 5, 0.3, 0.3, 0.93), ("octo1", (20, 24, 28), 5, 0.4, 0.4, 0.93),
+                                                                 ("golden32", (14, 16, 18), 0.7, 0.4, 0.3, 0.8), ("golden32", (16, 18, 20), 1.6, 0.6, 0.2, 0.85),
+                                                                 ("golden32", (40, 44, 48), 16, 0.3, 0.3, 0.9985), ("golden12", (24, 26, 28), 6, 0.9, 0.5, 0.95)])
+def test_nms3d_extreme_shapes(refmods, rays_name, shape, radius, noise, thr, pth):
+    """the smallest ray sets (4 and 6 rays), polyhedra below one voxel (dist < 1: outside the cone map's preconditions) and polyhedra that fill
+    a third of the volume (large rendering boxes), very irregular ones: same survivors as the compiled reference"""
+    from stardist_amd.lib import stardist3d as sd3
+    from stardist_amd.rays3d import Rays_GoldenSpiral, Rays_Octo, Rays_Tetra
+    rays = {"tetra1": lambda: Rays_Tetra(1), "octo1": lambda: Rays_Octo(1), "golden32": lambda: Rays_GoldenSpiral(32), "golden12": lambda: Rays_GoldenSpiral(12)}[rays_name]()
+    V, F = rays.vertices.astype(np.float32), rays.faces.astype(np.int32)
+    d, p, s = _random_candidates(shape, len(V), noise, seed=len(V) + int(radius * 10), prob_thresh=pth, radius=radius)
+    assert 40 < len(d) < 3000, len(d)
+    ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(thr))
+    keep = sd3.c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(thr))
+    diff = np.flatnonzero(keep != ref_keep)
+    assert len(diff) == 0, (rays_name, radius, diff[:10], len(d), int(ref_keep.sum()), int(keep.sum()))
+
+
 @pytest.mark.parametrize("n,thr,aniso", [(64, 0.3, None), (96, 0.3, None), (64, 0.5, (2, 1, 1))])
 def test_nms3d_nuclei_survivors(refmods, n, thr, aniso):
     from oracle import synth
