@@ -76,6 +76,42 @@ def test_polyhedron_to_label_identical(refmods, mode, overlap):
     assert np.array_equal(lbl, ref_lbl), np.count_nonzero(lbl != ref_lbl)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("rays_name,radius,noise,vol", [("tetra1", 6, 0.3, 36), ("octo1", 5, 0.5, 36), ("cartesian", 6, 0.3, 36), ("golden12", 7, 0.9, 40),
+                                                        ("golden32", 0.7, 0.3, 24), ("golden32", 22, 0.2, 40), ("golden96", 9, 0.6, 48)])
+def test_polyhedron_to_label_extreme_shapes(refmods, rays_name, radius, noise, vol, mode):
+    """the rasteriser on what the random nuclei never are: ray sets of 4 / 6 rays, `Rays_Cartesian` (degenerate pole faces), very irregular
+    polyhedra, polyhedra below one voxel, polyhedra larger than the volume (clipped on every side), centres on the border -- modes full,
+    kernel, hull, bbox.  Mode full / hull: voxels exactly on a hull facet are exempt as everywhere."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _hull import on_hull_boundary
+    from stardist_amd.lib import stardist3d as sd3
+    from stardist_amd.rays3d import Rays_Cartesian, Rays_GoldenSpiral, Rays_Octo, Rays_Tetra
+    import warnings
+    rays = {"tetra1": lambda: Rays_Tetra(1), "octo1": lambda: Rays_Octo(1), "cartesian": lambda: Rays_Cartesian(8, 5), "golden12": lambda: Rays_GoldenSpiral(12),
+            "golden32": lambda: Rays_GoldenSpiral(32), "golden96": lambda: Rays_GoldenSpiral(96)}[rays_name]()
+    V, F = rays.vertices.astype(np.float32), rays.faces.astype(np.int32)
+    rng = np.random.RandomState(len(V) * 7 + int(radius * 10))
+    n = 40
+    d = (radius * (1 + noise * rng.uniform(-1, 1, (n, len(V))))).astype(np.float32)
+    p = rng.uniform(0, vol - 1, (n, 3)).astype(np.float32)
+    p[:6] = np.round(p[:6]); p[6] = (0, 0, 0); p[7] = (vol - 1, vol - 1, vol - 1); p[8] = (0, vol / 2, vol - 1)
+    labels = np.arange(1, n + 1, dtype=np.int32)
+    args = (d, p, V, F, labels, mode, 0, 0, 0, (vol, vol, vol))
+    ref_lbl = refmods.stardist3d().c_polyhedron_to_label(*args)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lbl = sd3.c_polyhedron_to_label(*args)
+    diff = np.argwhere(lbl != ref_lbl)
+    if mode in (0, 2) and len(diff):
+        assert on_hull_boundary(diff, p, d, V).all(), (rays_name, radius, mode, len(diff), diff[:6])
+        assert len(diff) <= 8 * n
+    else:
+        assert len(diff) == 0, (rays_name, radius, mode, len(diff), diff[:6])
+    assert (ref_lbl > 0).any() or mode == 1            # (the kernel of a polyhedron with degenerate faces can be empty)
+
+
 @pytest.mark.parametrize("shape,n_rays,noise,thr", [((22, 33, 44), 32, 0.1, 0.2), ((22, 33, 44), 32, 0.5, 0.5),
                                                      ((22, 33, 44), 96, 0.3, 0.3), ((33, 44, 55), 14, 0.0, 0.2),
                                                      ((33, 44, 55), 22, 0.0, 0.4), ((22, 33, 44), 96, 0.3, 0.6)])
