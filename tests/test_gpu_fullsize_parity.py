@@ -124,7 +124,7 @@ def test_predict_instances_3d_end_to_end_equals_oracle_composition(refmods, over
         assert (labels == overlap_label).any()           # the synthetic spheres do overlap: the branch is exercised
 
 
-@pytest.mark.parametrize("case", ["2D_demo-fixture", "default-synthetic"])
+@pytest.mark.parametrize("case", ["2D_demo-fixture", "default-synthetic", "rays64-grid12", "rays128-grid21"])
 def test_predict_instances_2d_end_to_end_equals_oracle_composition(refmods, case, monkeypatch, tmp_path):
     """BASELINE config 1's substitute: the reference's `models/examples/2D_demo` topology (config.json: grid (2,2),
     thresholds.json) with seeded weights on the reference's own fixture image tests/data/img2d.tif (stored in
@@ -149,6 +149,12 @@ def test_predict_instances_2d_end_to_end_equals_oracle_composition(refmods, case
         img = normalize(np.load(os.path.join(ROOT, "tests", "golden", "fixture_images.npz"))["img2d"])
         assert img.shape == (256, 256) and img.dtype == np.float32
         bench.calibrate_heads(model, torch.from_numpy(img).to(dev), frac=0.08, radius=7.0)
+    elif case.startswith("rays"):
+        # (round 6) more than 32 rays and an anisotropic grid: the NMS takes the sweeps of the larger vertex capacities and their general paths
+        R, g = (64, (1, 2)) if case == "rays64-grid12" else (128, (2, 1))
+        model = StarDist2D(Config2D(n_rays=R, grid=g), basedir=None, device=dev, seed=0)
+        img = synth.s2d_nuclei_image(192, 224, seed=5)
+        bench.calibrate_heads(model, torch.from_numpy(img).to(dev))
     else:
         model = StarDist2D(Config2D(n_rays=32), basedir=None, device=dev, seed=0)
         img = synth.s2d_nuclei_image(384, 512, seed=4)
@@ -156,7 +162,7 @@ def test_predict_instances_2d_end_to_end_equals_oracle_composition(refmods, case
     pt, nt, grid = model.thresholds.prob, model.thresholds.nms, tuple(model.config.grid)
     (labels, res), (prob, dist) = model.predict_instances(img, return_predict=True)
     prob = np.asarray(prob); dist = np.asarray(dist)
-    assert prob.shape == tuple(s // g for s, g in zip(img.shape, grid)) and dist.shape == prob.shape + (32,)
+    assert prob.shape == tuple(s // g for s, g in zip(img.shape, grid)) and dist.shape == prob.shape + (model.config.n_rays,)
     # ---- reference composition
     mask = port.ind_prob_thresh(prob, pt, b=2)
     pts = np.stack(np.where(mask), 1)
