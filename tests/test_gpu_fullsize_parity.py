@@ -78,8 +78,8 @@ def _nms3d_256_golden(synth, sd3):
     assert np.array_equal(keep, ref_keep), "mismatching candidates: %s" % np.flatnonzero(keep != ref_keep)[:10]
 
 
-@pytest.mark.parametrize("overlap_label", [None, -1])
-def test_predict_instances_3d_end_to_end_equals_oracle_composition(refmods, overlap_label):
+@pytest.mark.parametrize("overlap_label,variant", [(None, "golden96"), (-1, "golden96"), (None, "golden48-aniso-grid122"), (None, "cartesian-grid211")])
+def test_predict_instances_3d_end_to_end_equals_oracle_composition(refmods, overlap_label, variant):
     """StarDist3D.predict_instances (dense path, so that both sides see ONE forward pass) vs the reference composition on the same
     prob/dist maps: _ind_prob_thresh -> sort -> c_non_max_suppression_inds (1 thread) -> c_polyhedron_to_label -> relabel_sequential
     with the negative-overlap-label remapping of model3d.py:634-645"""
@@ -90,7 +90,17 @@ def test_predict_instances_3d_end_to_end_equals_oracle_composition(refmods, over
     from stardist_amd.models import Config3D, StarDist3D
     dev = torch.device("cuda:0")
     vol = synth.s3d_nuclei_image(64, seed=3)
-    model = StarDist3D(Config3D(rays=96), basedir=None, device=dev, seed=0)
+    import warnings
+    from stardist_amd.rays3d import Rays_Cartesian, Rays_GoldenSpiral
+    if variant == "golden96":
+        cfg = Config3D(rays=96)
+    elif variant == "golden48-aniso-grid122":            # (round 6) anisotropic rays on an anisotropic grid
+        cfg = Config3D(rays=Rays_GoldenSpiral(48, anisotropy=(2, 1, 1)), grid=(1, 2, 2), anisotropy=(2, 1, 1))
+    else:                                                # (round 6) Rays_Cartesian: degenerate pole faces
+        cfg = Config3D(rays=Rays_Cartesian(8, 5), grid=(2, 1, 1))
+    grid3 = tuple(cfg.grid)
+    warnings.filterwarnings("ignore", message=".*coincide in float32.*")
+    model = StarDist3D(cfg, basedir=None, device=dev, seed=0)
     model.thresholds = dict(prob=0.5, nms=0.3)
     bench.calibrate_heads(model, torch.from_numpy(vol).to(dev), frac=0.02, radius=8.5, noise=0.03)
     (labels, res), (prob, dist) = model.predict_instances(vol, return_predict=True, overlap_label=overlap_label)
@@ -103,6 +113,7 @@ def test_predict_instances_3d_end_to_end_equals_oracle_composition(refmods, over
     pr = prob[mask]; di = dist[mask]
     order = nms._argsort_desc(pr)                       # ties: stable order on both sides (DESIGN.md deviation 6)
     pr, di, pts = pr[order], di[order], pts[order]
+    pts = pts * np.array(grid3).reshape(1, 3)
     refmods.stardist3d(); refmods.set_threads(1)
     keep = refmods.stardist3d().c_non_max_suppression_inds(np.ascontiguousarray(di, np.float32), np.ascontiguousarray(pts, np.float32), V, F,
                                                            np.ascontiguousarray(pr, np.float32), 1, 1, 0, np.float32(0.3))
