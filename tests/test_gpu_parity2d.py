@@ -84,7 +84,8 @@ def test_nms2d_many_rays_beyond_the_capacities_fail_loudly_and_fast(shape, R, ra
 
 
 class _ref_threads(object):
-    """OpenMP threads of the compiled reference for one call (restored to the core count afterwards)"""
+    """OpenMP threads of the compiled reference for one call; afterwards 16 at most (the GPU boxes have 256 hardware threads, which
+    oversubscribe the reference's fine-grained OpenMP loops: tests that time out on that set their own count)"""
 
     def __init__(self, refmods, n): self.r, self.n = refmods, n
 
@@ -92,7 +93,7 @@ class _ref_threads(object):
 
     def __exit__(self, *a):
         import os
-        self.r.set_threads(os.cpu_count() or 1)
+        self.r.set_threads(min(os.cpu_count() or 1, 16))
 
 
 def _cands2d(rng, n, R, radius, noise, extent):

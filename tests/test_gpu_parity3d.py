@@ -138,6 +138,7 @@ def test_nms3d_rays_cartesian_random_survivors(refmods, nx, nz, shape, noise, th
     rays = Rays_Cartesian(nx, nz)
     V, F = rays.vertices.astype(np.float32), rays.faces.astype(np.int32)
     d, p, s = _random_candidates(shape, len(V), noise, seed=len(V))
+    refmods.stardist3d(); refmods.set_threads(1)          # (the reference's anisotropy sum is only defined for one thread)
     ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(thr))
     import torch
     dev = torch.device("cuda:0")
@@ -161,6 +162,7 @@ def test_nms3d_flag_combinations(refmods, use_bbox, use_kdtree, thr):
     V, F = rays.vertices, rays.faces.astype(np.int32)
     d, p, s = _random_candidates((18, 24, 30), 32, 0.3, seed=5, prob_thresh=0.93, radius=6)
     assert 300 < len(d) < 800
+    refmods.stardist3d(); refmods.set_threads(1)          # (the reference's anisotropy sum is only defined for one thread)
     ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, use_bbox, use_kdtree, 0, np.float32(thr))
     keep = sd3.c_non_max_suppression_inds(d, p, V, F, s, use_bbox, use_kdtree, 0, np.float32(thr))
     diff = np.flatnonzero(keep != ref_keep)
@@ -179,6 +181,7 @@ def test_nms3d_extreme_shapes(refmods, rays_name, shape, radius, noise, thr, pth
     V, F = rays.vertices.astype(np.float32), rays.faces.astype(np.int32)
     d, p, s = _random_candidates(shape, len(V), noise, seed=len(V) + int(radius * 10), prob_thresh=pth, radius=radius)
     assert 40 < len(d) < 3000, len(d)
+    refmods.stardist3d(); refmods.set_threads(1)          # (the reference's anisotropy sum is only defined for one thread)
     ref_keep = refmods.stardist3d().c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(thr))
     keep = sd3.c_non_max_suppression_inds(d, p, V, F, s, 1, 1, 0, np.float32(thr))
     diff = np.flatnonzero(keep != ref_keep)
