@@ -778,12 +778,13 @@ def main():
     # ---- config 4: one 16384^2 slide (the 2048^2 synthetic tile repeated), blocks 4480 / overlap 128 / context 128, sharded over the ranks
     if not args.no_sharded:
         rep = max(1, args.sharded_size // H)
-        big = sharded_input(model, synth.s2d_nuclei_image(H, W, seed=0), rep, "YX", args.sharded_block, 128, 128, rank, world, dev)
+        big, big_err = guarded(lambda: sharded_input(model, synth.s2d_nuclei_image(H, W, seed=0), rep, "YX", args.sharded_block, 128, 128, rank, world, dev),
+                               "sharded_2d input")
         # N > 1: this leg IS the headline, so it is timed as the contract prescribes -- W untimed passes, then exactly K timed ones
         # (a pass over the slide is one "step"); N = 1: two timed passes next to the tile leg
         sh_passes, sh_warm = (args.steps, max(1, args.warmup)) if world > 1 else (2, 1)
-        r, err = guarded(lambda: run_sharded_leg(model, big, "YX", min(args.sharded_block, big.shape[0]), 128, 128, sh_passes, world, dist_, rank,
-                                                 warm_passes=sh_warm), "sharded_2d")
+        r, err = (None, big_err) if big is None else guarded(
+            lambda: run_sharded_leg(model, big, "YX", min(args.sharded_block, big.shape[0]), 128, 128, sh_passes, world, dist_, rank, warm_passes=sh_warm), "sharded_2d")
         if rank == 0 and err:
             out["sharded_2d"] = {"error": err}                      # the headline stays the tile leg
         elif rank == 0:
@@ -807,8 +808,9 @@ def main():
     del model, img
     torch.cuda.empty_cache()
 
-    # ------------------------------------------------------------------ 3D leg
-    if not args.skip_3d:
+    # ------------------------------------------------------------------ 3D leg (a closure run through guarded(): whatever fails in it, the
+    # line with the 2D figures -- at N > 1 the headline -- is still printed)
+    def legs_3d():
         S = args.size3d
         vol_np = synth.s3d_nuclei_image(S, seed=rank)
         vol = torch.from_numpy(vol_np).to(dev)
@@ -877,16 +879,18 @@ def main():
         if not args.no_sharded and not args.skip_sharded_3d:
             rep = max(1, args.sharded_size3d // S)
             base3 = synth.s3d_nuclei_image(S, seed=0)
-            bigv = sharded_input(m3, base3, rep, "ZYX", args.sharded_block3d, 32, 32, rank, world, dev)
-            r, err = guarded(lambda: run_sharded_leg(m3, bigv, "ZYX", min(args.sharded_block3d, bigv.shape[0]), 32, 32, 1, world, dist_, rank), "sharded_3d")
+            def sharded_3d(block):                                 # (the input is built inside the guarded call too)
+                bigv = sharded_input(m3, base3, rep, "ZYX", block, 32, 32, rank, world, dev)
+                try:
+                    return run_sharded_leg(m3, bigv, "ZYX", min(block, bigv.shape[0]), 32, 32, 1, world, dist_, rank)
+                finally:
+                    del bigv
+            r, err = guarded(lambda: sharded_3d(args.sharded_block3d), "sharded_3d")
             if err and args.sharded_block3d_fallback and args.sharded_block3d_fallback < args.sharded_block3d:      # (every rank fails alike: same shapes)
                 m3.__dict__.pop("_graphs", None)
                 torch.cuda.empty_cache()
                 first_err = err
-                del bigv
-                bigv = sharded_input(m3, base3, rep, "ZYX", args.sharded_block3d_fallback, 32, 32, rank, world, dev)
-                r, err = guarded(lambda: run_sharded_leg(m3, bigv, "ZYX", min(args.sharded_block3d_fallback, bigv.shape[0]), 32, 32, 1, world, dist_, rank),
-                                 "sharded_3d (fallback block)")
+                r, err = guarded(lambda: sharded_3d(args.sharded_block3d_fallback), "sharded_3d (fallback block)")
                 if rank == 0 and r is not None:
                     r["fallback_from"] = {"block_size": args.sharded_block3d, "error": first_err[:300]}
             if rank == 0 and err:
@@ -894,7 +898,10 @@ def main():
             elif rank == 0:
                 r["unit"] = "Mvox/s"
                 out["sharded_3d"] = r
-            del bigv
+    if not args.skip_3d:
+        _, err3 = guarded(legs_3d, "3D legs")
+        if err3 and rank == 0:
+            out["error_3d"] = err3
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -342,12 +342,12 @@ __global__ void __launch_bounds__(256) k_sum_halves(const int* __restrict__ nLow
 // Round kernel A1: thread per undecided candidate, O(1): waitOn[i] is the higher-scored neighbour i was last seen waiting
 // for (k_neighbours seeds it with the best-scored one; WAIT_NONE = there is none, WAIT_SCAN = unknown).  Most waits persist
 // from round to round, so only the candidates whose wait target has just been decided go to the list scan (A2).
-__global__ void __launch_bounds__(256) k_round_triage(const int* __restrict__ U, int nU, const unsigned char* __restrict__ state,
-                                                      const int* __restrict__ waitOn, int* __restrict__ Unext, int* __restrict__ K,
-                                                      int* __restrict__ S, int* counters /*0:nUnext 1:nK 2:nS*/,
-                                                      const unsigned char* __restrict__ pend) {
+__global__ void __launch_bounds__(1024) k_round_triage(const int* __restrict__ U, int nU, const unsigned char* __restrict__ state,
+                                                       const int* __restrict__ waitOn, int* __restrict__ Unext, int* __restrict__ K,
+                                                       int* __restrict__ S, int* counters /*0:nUnext 1:nK 2:nS*/,
+                                                       const unsigned char* __restrict__ pend) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   int kind = 0, i = -1;                       // 0 drop, 1 still waiting, 2 becomes a survivor, 3 needs the list scan
   if (t < nU) {
     i = U[t];
@@ -359,14 +359,26 @@ __global__ void __launch_bounds__(256) k_round_triage(const int* __restrict__ U,
       else kind = 3;
     }
   }
+  // ONE atomic per list and workgroup of 1024 candidates: an atomic per wave (6 500 waves x 3 lists at 2048^2) serialises at the L2 --
+  // measured 138 us for this kernel in round 1, most of it waiting for the three counters
+  __shared__ int wcnt[3][16];
+  __shared__ int bbase[3];
 #pragma unroll
   for (int q = 1; q <= 3; ++q) {
     const unsigned long long m = __ballot(kind == q);
-    if (!m) continue;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&counters[q - 1], __popcll(m));
-    base = __shfl(base, 0);
-    if (kind == q) (q == 1 ? Unext : (q == 2 ? K : S))[base + __popcll(m & ((1ull << lane) - 1))] = i;
+    if (lane == 0) wcnt[q - 1][wave] = __popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    int sum = 0;
+    for (int w = 0; w < nw; ++w) { const int c = wcnt[threadIdx.x][w]; wcnt[threadIdx.x][w] = sum; sum += c; }
+    bbase[threadIdx.x] = sum ? atomicAdd(&counters[threadIdx.x], sum) : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 1; q <= 3; ++q) {
+    const unsigned long long m = __ballot(kind == q);
+    if (kind == q) (q == 1 ? Unext : (q == 2 ? K : S))[bbase[q - 1] + wcnt[q - 1][wave] + __popcll(m & ((1ull << lane) - 1))] = i;
   }
 }
 
@@ -394,25 +406,41 @@ __global__ void __launch_bounds__(256) k_round_scan(const int* __restrict__ S, c
     }
     nbuf = 0;
   };
-  for (int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); w < nS; w += nWaves) {
-    const int i = S[w];
-    const i64 beg = nbrStart[i], end = beg + nbrLow[i];        // the better-scored neighbours
+  // FOUR candidates per wave at a time, 16 lanes each (a list of better-scored neighbours holds ~40 entries): the kernel is a chain of
+  // dependent gathers (list bounds -> neighbour -> its state), so candidates in flight are what counts
+  const int sub = lane >> 4, sl = lane & 15;
+  for (int w0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4; w0 < nS; w0 += nWaves * 4) {
+    const int w = w0 + sub;
+    const bool valid = w < nS;
+    const int i = valid ? S[w] : -1;
+    i64 t = 0, end = 0;
+    if (valid) { t = nbrStart[i]; end = t + nbrLow[i]; }        // the better-scored neighbours
     int found = -1;
-    for (i64 t = beg; t < end && found < 0; t += 64) {
-      const i64 idx = t + lane;
+    while (__any(found < 0 && t < end)) {
+      const i64 idx = t + sl;
       int j = -1;
-      if (idx < end) { j = nbr[idx]; if (!(j < i && state[j] == ST_UNDECIDED)) j = -1; }
+      if (found < 0 && idx < end) { j = nbr[idx]; if (!(j < i && state[j] == ST_UNDECIDED)) j = -1; }
       const unsigned long long m = __ballot(j >= 0);
-      if (m) found = __shfl(j, __ffsll((long long)m) - 1);
+      const unsigned int m16 = (unsigned int)(m >> (sub << 4)) & 0xffffu;
+      const int src = (sub << 4) + (m16 ? __ffs((int)m16) - 1 : 0);
+      const int jf = __shfl(j, src);
+      if (found < 0 && m16) found = jf;
+      t += 16;
     }
-    if (lane == 0) waitOn[i] = found >= 0 ? found : WAIT_NONE;
-    if (lane == nbuf) { myI = i; myKind = (found >= 0 || pend[i]) ? 1 : 2; }
-    if (++nbuf == 64) flush();
+    if (valid && sl == 0) waitOn[i] = found >= 0 ? found : WAIT_NONE;
+    const int kind = (found >= 0 || (valid && pend[i])) ? 1 : 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int vi = __shfl(i, q << 4), vk = __shfl(kind, q << 4);
+      if (vi >= 0) { if (lane == nbuf) { myI = vi; myKind = vk; } ++nbuf; }      // (vi is wave-uniform)
+    }
+    if (nbuf > 60) flush();
   }
   flush();
 }
 
 // Round kernel B: wave per new survivor: mark it, emit the pairs the reference would evaluate.
+constexpr int EMIT_STAGE = 512;
 __global__ void __launch_bounds__(256) k_round_emit(const int* __restrict__ K, const int* __restrict__ nKPtr, unsigned char* __restrict__ state,
                                                     const i64* __restrict__ nbrStart, const int* __restrict__ nbrHigh, const int* __restrict__ nbr, Flags f,
                                                     const float* __restrict__ pts, const int4* __restrict__ bbox,
@@ -421,6 +449,20 @@ __global__ void __launch_bounds__(256) k_round_emit(const int* __restrict__ K, c
                                                     unsigned long long pairCap) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nK = *nKPtr;                               // persistent grid: the survivor count of this round is read on the device
+  // pairs are staged per wave in LDS and appended with ONE atomic per EMIT_STAGE pairs: an atomic per 64-entry chunk of a neighbour list
+  // (1.5 x 10^5 of them on one counter in round 1 at 2048^2) serialises at the L2
+  __shared__ int2 stage[4][EMIT_STAGE];
+  int nst = 0;                                         // (wave-uniform)
+  auto flush = [&]() {
+    if (!nst) return;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(pairCount, (unsigned long long)nst);
+    base = __shfl(base, 0);
+    __builtin_amdgcn_wave_barrier();                   // (a wave's LDS accesses are processed in order)
+    for (int k = lane; k < nst; k += 64) { const unsigned long long pos = base + k; if (pos < pairCap) pairs[pos] = stage[wave][k]; }
+    __builtin_amdgcn_wave_barrier();
+    nst = 0;
+  };
   for (int w = blockIdx.x * (blockDim.x >> 6) + wave; w < nK; w += gridDim.x * (blockDim.x >> 6)) {
   const int i = K[w];
   if (lane == 0) state[i] = ST_KEPT;
@@ -459,16 +501,14 @@ __global__ void __launch_bounds__(256) k_round_emit(const int* __restrict__ K, c
     }
     const unsigned long long m = __ballot(emit);
     if (m) {
-      unsigned long long base = 0;
-      if (lane == 0) base = atomicAdd(pairCount, (unsigned long long)__popcll(m));
-      base = __shfl(base, 0);
-      if (emit) {
-        const unsigned long long pos = base + __popcll(m & ((1ull << lane) - 1));
-        if (pos < pairCap) pairs[pos] = make_int2(i, j);
-      }
+      const int c = __popcll(m);
+      if (nst + c > EMIT_STAGE) flush();
+      if (emit) stage[wave][nst + __popcll(m & ((1ull << lane) - 1))] = make_int2(i, j);
+      nst += c;
     }
   }
   }
+  flush();
 }
 
 // ---- prepared polygons: Clipper::AddPath once per candidate (clip_beam.h), one thread per candidate, working arrays
@@ -1309,7 +1349,7 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
       break;
     }
     SD_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(Counters), s));
-    hipLaunchKernelGGL(k_round_triage, dim3(sd::div_up(nU, 256)), dim3(256), 0, s, Ucur, nU, state, waitOn, Unext, K, Sl, (int*)d_cnt, dfr.pend);
+    hipLaunchKernelGGL(k_round_triage, dim3(sd::div_up(nU, 1024)), dim3(1024), 0, s, Ucur, nU, state, waitOn, Unext, K, Sl, (int*)d_cnt, dfr.pend);
     const int wgrid = sd::div_up(nU, 4) < 2048 ? sd::div_up(nU, 4) : 2048;
     hipLaunchKernelGGL(k_round_scan, dim3(wgrid), dim3(256), 0, s, Sl, state, nbrStart, nbrLow, nbr, waitOn, Unext, K, (int*)d_cnt, dfr.pend);
     hipLaunchKernelGGL(k_round_emit, dim3(wgrid), dim3(256), 0, s, K, &d_cnt->nK, state, nbrStart, nbrCount, nbr, f, d_points, bbox,

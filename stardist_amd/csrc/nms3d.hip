@@ -313,20 +313,35 @@ __global__ void __launch_bounds__(256) k_round_decide3(const int* __restrict__ U
     }
     nbuf = 0;
   };
-  for (int w = blockIdx.x * (blockDim.x >> 6) + wave; w < nU; w += gridDim.x * (blockDim.x >> 6)) {
-    const int i = U[w];
-    const i64 beg = nbrStart[i], end = beg + nbrLow[i];          // the lower-index neighbours
+  // FOUR candidates per wave at a time, 16 lanes each: the kernel is a chain of dependent gathers (list bounds -> neighbour -> its
+  // state), so candidates in flight are what counts (same form as k_round_scan of the 2D NMS)
+  const int sub = lane >> 4, sl = lane & 15;
+  const int nWaves = gridDim.x * (blockDim.x >> 6);
+  for (int w0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 4; w0 < nU; w0 += nWaves * 4) {
+    const int w = w0 + sub;
+    const bool valid = w < nU;
+    const int i = valid ? U[w] : -1;
+    i64 t = 0, end = 0;
+    if (valid) { t = nbrStart[i]; end = t + nbrLow[i]; }          // the lower-index neighbours
     int found = -1;
-    for (i64 t = beg; t < end && found < 0; t += 64) {
-      const i64 idx = t + lane;
+    while (__any(found < 0 && t < end)) {
+      const i64 idx = t + sl;
       int j = -1;
-      if (idx < end) { j = nbr[idx]; if (!(j < i && state[j] == ST_UNDECIDED)) j = -1; }
+      if (found < 0 && idx < end) { j = nbr[idx]; if (!(j < i && state[j] == ST_UNDECIDED)) j = -1; }
       const unsigned long long m = __ballot(j >= 0);
-      if (m) found = __shfl(j, __ffsll((long long)m) - 1);
+      const unsigned int m16 = (unsigned int)(m >> (sub << 4)) & 0xffffu;
+      const int jf = __shfl(j, (sub << 4) + (m16 ? __ffs((int)m16) - 1 : 0));
+      if (found < 0 && m16) found = jf;
+      t += 16;
     }
-    if (lane == 0) waitOn[i] = found >= 0 ? found : WAIT3_NONE;
-    if (lane == nbuf) { myI = i; myKind = found >= 0 ? 1 : 2; }
-    if (++nbuf == 64) flush();
+    if (valid && sl == 0) waitOn[i] = found >= 0 ? found : WAIT3_NONE;
+    const int kind = found >= 0 ? 1 : 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int vi = __shfl(i, q << 4), vk = __shfl(kind, q << 4);
+      if (vi >= 0) { if (lane == nbuf) { myI = vi; myKind = vk; } ++nbuf; }      // (vi is wave-uniform)
+    }
+    if (nbuf > 60) flush();
   }
   flush();
 }
@@ -392,18 +407,19 @@ __global__ void k_tail3_promote(const int* __restrict__ U, int nU, unsigned char
 
 // emit: exact neighbour predicate + cascade stages 1 and 2 (:1199-1248).  tail != 0: K is the list of the still undecided candidates,
 // none of which is marked kept; every pair of undecided candidates the sequential loop could still evaluate is emitted.
-__global__ void __launch_bounds__(256) k_round_emit3(const int* __restrict__ K, int nK, SuppSink sink, int tail,
+__global__ void __launch_bounds__(256) k_round_emit3(const int* __restrict__ K, int nK, const int* __restrict__ nKPtr, SuppSink sink, int tail,
                                                      const i64* __restrict__ nbrStart, const int* __restrict__ nbrHigh, const int* __restrict__ nbr, Flags3 f, Aniso an,
                                                      const float* __restrict__ pts, const int* __restrict__ bbox,
                                                      const float* __restrict__ volume, const float* __restrict__ r_outer,
                                                      const float* __restrict__ r_outer_iso, const float* __restrict__ r_inner_iso,
                                                      int2* __restrict__ pairs, unsigned int* pairCount, unsigned int pairCap, Stats* st) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int w = blockIdx.x * (blockDim.x >> 6) + wave;
-  if (w >= nK) return;
-  const int i = K[w];
+  if (nKPtr) nK = *nKPtr;                            // normal round: the survivor count of this round is read on the device (persistent grid)
   unsigned char* state = sink.state;
-  if (tail) { if (state[i] != ST_UNDECIDED) return; }
+  int n_upper = 0, n_lower = 0, n_keep = 0, n_sup = 0;
+  for (int w = blockIdx.x * (blockDim.x >> 6) + wave; w < nK; w += gridDim.x * (blockDim.x >> 6)) {
+  const int i = K[w];
+  if (tail) { if (state[i] != ST_UNDECIDED) continue; }
   else if (lane == 0) state[i] = ST_KEPT;
   const i64 end = nbrStart[i + 1], beg = end - nbrHigh[i];          // the higher-index neighbours (the back of i's slot)
   const float* pi = pts + 3 * (size_t)i;
@@ -451,13 +467,14 @@ __global__ void __launch_bounds__(256) k_round_emit3(const int* __restrict__ K, 
         if (pos < pairCap) pairs[pos] = make_int2(i, j);
       }
     }
-    const int u = __popcll(__ballot(c_upper)), l = __popcll(__ballot(c_lower)), kp = __popcll(__ballot(c_keep)), sp = __popcll(__ballot(c_sup));
-    if (lane == 0 && (u | l | kp | sp)) {
-      if (u) atomicAdd(&st->upper, (unsigned long long)u);
-      if (l) atomicAdd(&st->lower, (unsigned long long)l);
-      if (kp) atomicAdd(&st->kept_pre, (unsigned long long)kp);
-      if (sp) atomicAdd(&st->sup_pre, (unsigned long long)sp);
-    }
+    n_upper += __popcll(__ballot(c_upper)); n_lower += __popcll(__ballot(c_lower)); n_keep += __popcll(__ballot(c_keep)); n_sup += __popcll(__ballot(c_sup));
+  }
+  }
+  if (lane == 0 && (n_upper | n_lower | n_keep | n_sup)) {          // (once per wave, not once per 64 neighbours)
+    if (n_upper) atomicAdd(&st->upper, (unsigned long long)n_upper);
+    if (n_lower) atomicAdd(&st->lower, (unsigned long long)n_lower);
+    if (n_keep) atomicAdd(&st->kept_pre, (unsigned long long)n_keep);
+    if (n_sup) atomicAdd(&st->sup_pre, (unsigned long long)n_sup);
   }
 }
 
@@ -1643,7 +1660,9 @@ __device__ __forceinline__ void hull_probes(const double* __restrict__ pv, int R
 
 __global__ void __launch_bounds__(64) k_hull(const int* __restrict__ hullList, unsigned int nList, const float* __restrict__ dist,
                                              const float* __restrict__ pts, const float* __restrict__ verts, int R, int cap,
-                                             double* __restrict__ hullPlanes, unsigned short* __restrict__ hullAdj, int* __restrict__ hullCount) {
+                                             double* __restrict__ hullPlanes, unsigned short* __restrict__ hullAdj, int* __restrict__ hullCount,
+                                             const unsigned int* __restrict__ nListPtr = nullptr) {
+  if (nListPtr) nList = *nListPtr;       // the list length read on the device (the grid is sized from an upper bound)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* pv = (double*)smem;            // 3R doubles
   unsigned int* tri = (unsigned int*)(pv + 3 * R);   // cap packed facets a | b << 10 | c << 20
@@ -2629,25 +2648,28 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
       const int wgrid = sd::div_up(nU, 4) < 2048 ? sd::div_up(nU, 4) : 2048;
       hipLaunchKernelGGL(k_round_decide3, dim3(wgrid), dim3(256), 0, s, Sl, &d_cnt->nS, state, nbrStart, nbrLow, nbr, waitOn, Unext, Kl, (int*)d_cnt);
       SD_LAUNCH_CHECK();
-      SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
-      SD_CHECK(hipStreamSynchronize(s));
-      if (h.nK == 0 && h.nU > 0) {
-        if (!hDef) { sd::set_error("sd_nms3d: greedy scan made no progress (internal error)"); return -1; }
-        // every remaining candidate is pending or waits for a pending one: the tail batch takes over from here
-        forceTail = true;
-        nU = h.nU;
-        int* t = Ucur; Ucur = Unext; Unext = t;
-        continue;
-      }
     }
     const SuppSink sink = tail ? SuppSink{state, supEdges, supCount, pairCap} : SuppSink{state, nullptr, nullptr, 0u};
-    const int nKeep = h.nK, nUndecided = h.nU;
-    if (h.nK > 0) {
-      hipLaunchKernelGGL(k_round_emit3, dim3(sd::div_up(nKeep, 4)), dim3(256), 0, s, tail ? Ucur : Kl, nKeep, sink, tail ? 1 : 0, nbrStart, nbrCount, nbr, f, an, d_points, bbox, volume,
-                         r_outer, r_outer_iso, r_inner_iso, pairs3, &d_cnt->nP3, pairCap, d_st);
+    {
+      // ONE read-back for the survivors, the undecided and the stage-3 pairs of the round: the emission takes the survivor count from
+      // device memory (a persistent grid sized from the undecided candidates), as the 2D rounds do
+      const int egrid = sd::div_up(nU, 4) < 2048 ? sd::div_up(nU, 4) : 2048;
+      hipLaunchKernelGGL(k_round_emit3, dim3(egrid), dim3(256), 0, s, tail ? Ucur : Kl, tail ? nU : 0, tail ? (const int*)nullptr : (const int*)&d_cnt->nK, sink, tail ? 1 : 0,
+                         nbrStart, nbrCount, nbr, f, an, d_points, bbox, volume, r_outer, r_outer_iso, r_inner_iso, pairs3, &d_cnt->nP3, pairCap, d_st);
       SD_LAUNCH_CHECK();
       SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
       SD_CHECK(hipStreamSynchronize(s));
+    }
+    if (!tail && h.nK == 0 && h.nU > 0) {
+      if (!hDef) { sd::set_error("sd_nms3d: greedy scan made no progress (internal error)"); return -1; }
+      // every remaining candidate is pending or waits for a pending one: the tail batch takes over from here
+      forceTail = true;
+      nU = h.nU;
+      int* t = Ucur; Ucur = Unext; Unext = t;
+      continue;
+    }
+    const int nUndecided = tail ? 0 : h.nU;
+    {
       if (h.nP3 > pairCap) { sd::set_error("sd_nms3d: pair queue overflow (internal error)"); return -1; }
       if (h.nP3 > 0) {
         const unsigned int b3 = h.nP3 < 16384u ? h.nP3 : 16384u;
@@ -2685,12 +2707,13 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
           }
           SD_CHECK(hipMemsetAsync(&d_cnt->nHull, 0, sizeof(unsigned int), s));
           hipLaunchKernelGGL(k_hull_mark, dim3(sd::div_up(h.nP4, 256)), dim3(256), 0, s, pairs4, h.nP4, hullState, hullList, &d_cnt->nHull);
-          SD_CHECK(hipMemcpyAsync(&h, d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, s));
-          SD_CHECK(hipStreamSynchronize(s));
-          if (h.nHull > 0) {
-            const unsigned int bh = h.nHull < 32768u ? h.nHull : 32768u;
+          {
+            // no read-back of the hull count (~40 us of idle device per round): a pair asks for at most two hulls, the kernel reads the
+            // length of its list on the device; the count reaches the host with the counters behind stage 4
+            const unsigned long long ub = 2ull * h.nP4;
+            const unsigned int bh = ub < 32768ull ? (unsigned int)ub : 32768u;
             hipLaunchKernelGGL(k_hull, dim3(bh), dim3(64), ldsH, s, hullList,
-                               h.nHull, d_dist, d_points, d_verts, R, hullCap, hullPlanes, hullAdj, hullCount);
+                               0u, d_dist, d_points, d_verts, R, hullCap, hullPlanes, hullAdj, hullCount, (const unsigned int*)&d_cnt->nHull);
             SD_LAUNCH_CHECK();
           }
           const bool sp4 = split4 && h.nP4 <= split4Max;
