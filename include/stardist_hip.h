@@ -253,6 +253,11 @@ int sd_select_candidates_device(const float* d_prob, const float* d_dist, int nd
                                 int cap, float* d_out_prob, float* d_out_dist,
                                 int32_t* d_out_points, int32_t* d_count, void* stream);
 
+/* np.argsort(scores)[::-1] of stardist/nms.py:114,167 on the device, stated as a stable ascending sort reversed (best score first, equal scores
+ * in descending order of their position): d_scores (n,) float32 (finite) -> d_sorted (n,) float32 = the scores in that order, d_order (n,) int64 =
+ * the position of the k-th best in d_scores. */
+int sd_sort_scores_desc_device(const float* d_scores, int n, float* d_sorted, int64_t* d_order, void* stream);
+
 /* Candidates in score order (the argsort of stardist/nms.py:167 applied to the selection above): d_points (n_sel, ndim) int32 grid indices as
  * written by sd_select_candidates_device, d_order (n,) int64 = index of the k-th best candidate (NULL: identity).  Writes, per k:
  * d_rows[k] = C-order linear index of (point + origin) in the grid `full_shape` (the row of the channels-last feature matrix the

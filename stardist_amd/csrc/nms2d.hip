@@ -1092,6 +1092,17 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   hipLaunchKernelGGL(k_cell_fill, dim3(sd::div_up(N, 256)), dim3(256), 0, s, N, candCell, cellStart, cellFill, d_points, bbox, area, cellRec, g, by_bbox, reach,
                      singlePass ? nbrCount : (int*)nullptr);
   SD_LAUNCH_CHECK();
+  // The N-sized work lists of the greedy rounds are set up HERE, in front of the neighbour lists: behind the read-back of the list total
+  // their four small launches sat on the critical path in front of round 1 (~60 us of 5-us kernels and gaps)
+  int* U0 = A.take_n<int>(N);
+  unsigned char* pend0 = A.take_n<unsigned char>(N);
+  int* head0 = A.take_n<int>(N);
+  unsigned int* dcount0 = A.take_n<unsigned int>(1);
+  if (!U0 || !pend0 || !head0 || !dcount0) return -1;
+  hipLaunchKernelGGL(k_iota, dim3(sd::div_up(N, 256)), dim3(256), 0, s, U0, N);
+  SD_CHECK(hipMemsetAsync(pend0, 0, N, s));
+  SD_CHECK(hipMemsetAsync(head0, 0xFF, (size_t)N * sizeof(int), s));
+  SD_CHECK(hipMemsetAsync(dcount0, 0, sizeof(unsigned int), s));
 
   Flags f;
   f.use_kdtree = use_kdtree; f.use_bbox = use_bbox; f.thr_nonneg = (threshold >= 0.f); f.thr = threshold; f.max_dist = max_dist;
@@ -1159,7 +1170,6 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   // ---- greedy rounds: every kernel of a round takes its work-list length from device memory; ONE host round trip per
   // round (the undecided / survivor counts that end the loop)
   const unsigned long long pairCap = (unsigned long long)(totalNbr / 2 + 64);
-  int* U0 = A.take_n<int>(N);
   int* U1 = A.take_n<int>(N);
   int* K = A.take_n<int>(N);
   int2* pairs = A.take_n<int2>(pairCap);
@@ -1177,7 +1187,6 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   unsigned char* decided = (areaBounds && pairOrder) ? A.take_n<unsigned char>(pairCap) : nullptr;       // (the shortcut filters through the ordered index list)
   if (areaBounds && pairOrder && !decided) return -1;
   i64 totalDecided = 0;
-  hipLaunchKernelGGL(k_iota, dim3(sd::div_up(N, 256)), dim3(256), 0, s, U0, N);
   int nU = N, rounds = 0;
   i64 totalPairs = 0, totalExact = 0, totalSpill = 0;
   int* Ucur = U0; int* Unext = U1;
@@ -1195,13 +1204,8 @@ extern "C" int sd_nms2d_device(const float* d_dist, const float* d_points, int n
   const bool deferOn = tailT >= 0 && deferEnv;
   Deferred dfr{nullptr, nullptr, nullptr, nullptr, nullptr, qCap};
   unsigned int* firstNew = A.take_n<unsigned int>(1);
-  dfr.pend = A.take_n<unsigned char>(N);
-  dfr.head = A.take_n<int>(N);
-  dfr.count = A.take_n<unsigned int>(1);
-  if (!firstNew || !dfr.pend || !dfr.head || !dfr.count) return -1;
-  SD_CHECK(hipMemsetAsync(dfr.pend, 0, N, s));
-  SD_CHECK(hipMemsetAsync(dfr.head, 0xFF, (size_t)N * sizeof(int), s));
-  SD_CHECK(hipMemsetAsync(dfr.count, 0, sizeof(unsigned int), s));
+  dfr.pend = pend0; dfr.head = head0; dfr.count = dcount0;          // (allocated and cleared in front of the neighbour lists)
+  if (!firstNew) return -1;
   if (deferOn) {
     dfr.pairs = A.take_n<int2>(qCap);
     dfr.next = A.take_n<int>(qCap);

@@ -2311,6 +2311,15 @@ extern "C" int sd_inside_polyhedron_device(const float* d_dist, const float* d_c
   return 0;
 }
 
+// helper stream of the 3D NMS (one per device, created on first use; nullptr: everything stays on the caller's stream)
+static hipStream_t side_stream3() {
+  static hipStream_t st[64] = {};
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
+  if (!st[d] && hipStreamCreateWithFlags(&st[d], hipStreamNonBlocking) != hipSuccess) { st[d] = nullptr; return nullptr; }
+  return st[d];
+}
+
 extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const float* d_points, int n_polys, int n_rays, int n_faces,
                                const float* d_verts, const int* d_faces, float threshold, int use_bbox, int use_kdtree, int verbose,
                                uint8_t* d_keep, int64_t* stats, void* stream_) {
@@ -2394,6 +2403,29 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   hipLaunchKernelGGL(k_pre1, dim3(sd::div_up(N, 128)), dim3(128), ldsRows, s, d_dist, d_points, d_verts, d_faces, N, R, F, volume, bbox, staged);
   SD_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_minmax3, dim3(sd::div_up(N, 256)), dim3(256), 0, s, d_points, N, gi + 1);
+  // cone map for the voxel tests of stage 5 (geom3d.h); option "nms3d_cone_map" = 0 tests every face as the reference does.  It depends on
+  // the ray mesh only and is a latency-bound launch of a few workgroups (0.23 ms at 96 rays): it runs on a helper stream NEXT TO the
+  // read-back of the bounding boxes and the host's sequential anisotropy sum below (0.3 ms of otherwise idle device), joined before the rounds
+  sd3::ConeMap cmap{nullptr, nullptr};
+  struct ConeJoin { hipEvent_t fork = nullptr, done = nullptr; bool pending = false;
+                    ~ConeJoin() { if (pending) (void)hipEventSynchronize(done);       // (an error return: the helper stream still writes into the arena)
+                                  if (fork) (void)hipEventDestroy(fork); if (done) (void)hipEventDestroy(done); } } coneJoin;
+  if (F <= 65535 && sd::option(sd::OPT_NMS3D_CONE_MAP) != 0) {
+    unsigned short* cmList = A.take_n<unsigned short>((size_t)SD_CM_CELLS * SD_CM_CAP);
+    signed char* cmCount = A.take_n<signed char>(SD_CM_CELLS);
+    if (!cmList || !cmCount) return -1;
+    hipStream_t side = side_stream3();
+    if (side) {
+      SD_CHECK(hipEventCreateWithFlags(&coneJoin.fork, hipEventDisableTiming));
+      SD_CHECK(hipEventCreateWithFlags(&coneJoin.done, hipEventDisableTiming));
+      SD_CHECK(hipEventRecord(coneJoin.fork, s));
+      SD_CHECK(hipStreamWaitEvent(side, coneJoin.fork, 0));
+    }
+    hipLaunchKernelGGL(k_cone_map, dim3(sd::div_up(SD_CM_CELLS, 64)), dim3(64), 0, side ? side : s, d_verts, d_faces, F, cmList, cmCount);
+    SD_LAUNCH_CHECK();
+    if (side) { SD_CHECK(hipEventRecord(coneJoin.done, side)); coneJoin.pending = true; }
+    cmap.list = cmList; cmap.count = cmCount;
+  }
   // anisotropy: sequential fp32 accumulation over candidates (:1008-1010) on the host
   std::vector<int> hb((size_t)6 * N);
   SD_CHECK(hipMemcpyAsync(hb.data(), bbox, (size_t)6 * N * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -2567,16 +2599,8 @@ extern "C" int sd_nms3d_device(const float* d_scores, const float* d_dist, const
   }
   if (stats) SD_CHECK(hipEventRecord(evb1, s));
 
-  // cone map for the voxel tests of stage 5 (geom3d.h); SD_NMS3D_NO_CONEMAP=1 tests every face as the reference does
-  sd3::ConeMap cmap{nullptr, nullptr};
-  if (F <= 65535 && sd::option(sd::OPT_NMS3D_CONE_MAP) != 0) {
-    unsigned short* cmList = A.take_n<unsigned short>((size_t)SD_CM_CELLS * SD_CM_CAP);
-    signed char* cmCount = A.take_n<signed char>(SD_CM_CELLS);
-    if (!cmList || !cmCount) return -1;
-    hipLaunchKernelGGL(k_cone_map, dim3(sd::div_up(SD_CM_CELLS, 64)), dim3(64), 0, s, d_verts, d_faces, F, cmList, cmCount);
-    SD_LAUNCH_CHECK();
-    cmap.list = cmList; cmap.count = cmCount;
-  }
+  // (the cone map of stage 5 was started on the helper stream in front of the anisotropy sum; from here on the caller's stream waits for it)
+  if (coneJoin.pending) { SD_CHECK(hipStreamWaitEvent(s, coneJoin.done, 0)); coneJoin.pending = false; }
   const unsigned int pairCap = (unsigned int)((totalNbr / 2 + 64) < (1ll << 31) ? (totalNbr / 2 + 64) : ((1ll << 31) - 1));
   int* U0 = A.take_n<int>(N);
   int* U1 = A.take_n<int>(N);

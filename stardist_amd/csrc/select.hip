@@ -121,7 +121,40 @@ __global__ void __launch_bounds__(256) k_sorted_rows(const int* __restrict__ pts
   if (rows) rows[k] = row;
 }
 
+__global__ void k_sort_iota(unsigned int* v, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] = (unsigned int)i; }
+__global__ void k_sort_reverse(const float* __restrict__ keys, const unsigned int* __restrict__ vals, int n, float* __restrict__ sorted,
+                               long long* __restrict__ order) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  sorted[i] = keys[n - 1 - i];
+  order[i] = (long long)vals[n - 1 - i];
+}
+
 }  // namespace
+
+// np.argsort(scores)[::-1] as the NMS glue states it (stardist/nms.py:114,167; nms.py _argsort_desc): a STABLE ascending sort, reversed --
+// best score first, equal scores in descending order of their position.  One radix sort of (score, position) pairs (scores are
+// probabilities: finite, the radix order of their bit patterns is their numeric order) and one reversing write, instead of the
+// framework's merge sort (a block sort, nine merge passes of two launches each, two transforms, two flips at 4 x 10^5 candidates).
+extern "C" int sd_sort_scores_desc_device(const float* d_scores, int n, float* d_sorted, int64_t* d_order, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= 0) return 0;
+  sd::Arena& A = sd::arena();
+  if (A.begin(s)) return -1;
+  float* keys = A.take_n<float>(n);
+  unsigned int* vin = A.take_n<unsigned int>(n);
+  unsigned int* vout = A.take_n<unsigned int>(n);
+  size_t tmpBytes = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, d_scores, keys, vin, vout, n, 0, 32, s);
+  void* tmp = A.take(tmpBytes + 256);
+  if (!keys || !vin || !vout || !tmp) return -1;
+  hipLaunchKernelGGL(k_sort_iota, dim3(sd::div_up(n, 256)), dim3(256), 0, s, vin, n);
+  SD_LAUNCH_CHECK();
+  SD_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp, tmpBytes, d_scores, keys, vin, vout, n, 0, 32, s));
+  hipLaunchKernelGGL(k_sort_reverse, dim3(sd::div_up(n, 256)), dim3(256), 0, s, (const float*)keys, (const unsigned int*)vout, n, d_sorted, (long long*)d_order);
+  SD_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int sd_sorted_rows_device(const int32_t* d_points, const int64_t* d_order, int n, int ndim, const int* full_shape, const int* origin,
                                      const int* grid, int64_t* d_rows, float* d_points_f32, int64_t* d_points_i64, void* stream) {

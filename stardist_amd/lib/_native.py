@@ -58,6 +58,7 @@ SIGNATURES = {
     "sd_survivor_positions_device": (_i, [_vp, ctypes.c_longlong, _vp, _vp, _vp]),
     "sd_survivors2d_device": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sd_sorted_rows_device": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sd_sort_scores_desc_device": (_i, [_vp, _i, _vp, _vp, _vp]),
     "sd_bias_act_device": (_i, [_vp, _vp, ctypes.c_longlong, _i, ctypes.c_longlong, _i, _vp]),
     "sd_add_bias_act_device": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, ctypes.c_longlong, _i, _vp]),
     "sd_maxpool_ndhwc_device": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -731,8 +731,8 @@ class StarDistBase(object):
         shape = np.asarray(prob.shape, np.int32)
         b = np.asarray([v for pair in bs for v in pair], np.int32)
         n, oprob, opts = self._select_raw(prob, prob_thresh, shape, b)
-        sp, order = torch.sort(oprob[:n], stable=True)
-        sp, order = torch.flip(sp, dims=(0,)), torch.flip(order, dims=(0,))
+        from ..nms import _sort_desc
+        sp, order = _sort_desc(oprob[:n])
         rows = torch.empty(n, dtype=torch.int64, device=prob.device)
         pf = torch.empty((n, nd), dtype=torch.float32, device=prob.device)
         pi = torch.empty((n, nd), dtype=torch.int64, device=prob.device)

@@ -49,9 +49,24 @@ def _argsort_desc(x):
     unstable, so the reference's tie order is implementation-defined; we use 'stable ascending,
     then reversed' on both backends (documented in DESIGN.md)."""
     if _is_t(x):
-        import torch
-        return torch.flip(torch.sort(x, stable=True)[1], dims=(0,))
+        return _sort_desc(x)[1]
     return np.argsort(x, kind="stable")[::-1]
+
+
+def _sort_desc(x):
+    """(sorted scores, order) of a score tensor in the order _argsort_desc states.  float32 scores on the GPU: the library's radix sort of
+    (score, position) pairs + one reversing write (csrc/select.hip sd_sort_scores_desc_device, include/stardist_hip.h); anything else:
+    the framework's stable sort, flipped."""
+    import torch
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 1 and 0 < x.numel() < 2 ** 31:
+        from .lib import _native as N
+        x = x.contiguous()
+        sp = torch.empty_like(x)
+        order = torch.empty(x.numel(), dtype=torch.int64, device=x.device)
+        N.dcall(x, "sd_sort_scores_desc_device", N.tptr(x), int(x.numel()), N.tptr(sp), N.tptr(order))
+        return sp, order
+    sp, order = torch.sort(x, stable=True)
+    return torch.flip(sp, dims=(0,)), torch.flip(order, dims=(0,))
 
 
 def non_maximum_suppression_inds(dist, points, scores, thresh=0.5, use_bbox=True, use_kdtree=True, verbose=1):

@@ -36,6 +36,33 @@ def test_sorted_rows_matches_numpy(nd, full, grid):
     assert np.array_equal(pf.cpu().numpy(), (sel * np.array(grid)).astype(np.float32))
 
 
+@pytest.mark.parametrize("n,levels", [(1, 0), (2, 1), (257, 0), (5000, 7), (418577, 0), (418577, 300), (1 << 20, 2)])
+def test_sort_scores_desc_equals_numpy_stable_argsort_reversed(n, levels):
+    """sd_sort_scores_desc_device == np.argsort(scores, kind="stable")[::-1] (stardist/nms.py:114,167 as nms._argsort_desc states it), with many
+    equal scores (levels > 0: that many distinct values) -- and nms._sort_desc / _argsort_desc take that route for float32 GPU scores"""
+    import torch
+    from stardist_amd.lib import _native as N
+    from stardist_amd.nms import _argsort_desc, _sort_desc
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(n % 1000 + levels)
+    x = rng.rand(n).astype(np.float32)
+    if levels:
+        x = (np.floor(x * levels) / levels).astype(np.float32)
+    x[rng.randint(0, n, max(1, n // 50))] = np.float32(1.0)
+    ref = np.argsort(x, kind="stable")[::-1]
+    t = torch.from_numpy(x).to(dev)
+    sp = torch.full((n,), float("nan"), dtype=torch.float32, device=dev)
+    order = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    N.dcall(t, "sd_sort_scores_desc_device", _vp(t), n, _vp(sp), _vp(order))
+    assert np.array_equal(order.cpu().numpy(), ref)
+    assert np.array_equal(sp.cpu().numpy(), x[ref])
+    sp2, order2 = _sort_desc(t)
+    assert np.array_equal(order2.cpu().numpy(), ref) and np.array_equal(sp2.cpu().numpy(), x[ref])
+    assert np.array_equal(_argsort_desc(t).cpu().numpy(), ref)
+    # the framework route (any other dtype) states the same order
+    assert np.array_equal(_argsort_desc(t.double()).cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("R,scale", [(32, (1, 1)), (11, (1, 1)), (32, (0.5, 2.0)), (64, (1.25, 1))])
 def test_dist_to_coord_native_equals_numpy(R, scale):
     """sd_dist_to_coord_device == the reference's numpy expression bit for bit (float32 x float64 products rounded to float32, optional
