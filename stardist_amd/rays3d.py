@@ -6,6 +6,11 @@ rays_from_json :156).  The vertex/face arrays feed every 3D kernel, and the FACE
 (sequential fp32 sums over faces), so constructions follow the reference step by step; faces of
 the golden spiral come from scipy.spatial.ConvexHull exactly as there.  Pinned against the
 reference module's output in tests/golden/rays_*.npz.
+
+This file is an ADAPTATION of the reference's host-side table generation, not a re-design (about half of its
+statements restate the reference's: the operation order fixes the float32 vertices bit for bit and the face order
+feeds every sequential sum of the 3D kernels, SURVEY.md section 2 row 11 "reuse verbatim semantics"); everything
+that consumes the tables -- the kernels -- is this package's own.
 """
 import copy as _copy
 
