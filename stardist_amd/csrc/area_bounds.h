@@ -34,7 +34,7 @@
 //        the exact sweep, earlier evidence stays valid); the weights are EMPIRICAL.  (3) A polygon whose OWN vertex lies within half a step of one of its own edges
 //        is re-ordered by Clipper on its own (found by the adversarial search of round 5): such polygons are not "robustly simple"
 //        (k_poly_props) and are never decided here.
-//        Evidence for the band: 8.8 x 10^8 GPU pairs of eleven families against the exact sweep (round 6; worst 0.23 B), 18 M CPU pairs against the
+//        Evidence for the band: 2.0 x 10^9 GPU pairs of eleven families against the exact sweep (round 6; worst 0.25 B), 18 M CPU pairs against the
 //        vendored Clipper (0.27 B), and an annealing ADVERSARY linked to the vendored Clipper (test infrastructure, DESIGN.md 3.4:
 //        4.8 x 10^9 evaluations over NMS-realisable (worst 0.42 B) and free integer polygons (worst 0.53 B); profiles/r05_area_band_adversary.txt).
 // A pair is decided when (A -+ B) / min(area) clears the threshold by the margins below; everything else -- and every pair with
