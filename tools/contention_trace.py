@@ -13,6 +13,11 @@ if len(sys.argv) > 1 and sys.argv[1] != "child":
             if l.startswith("round") or l.startswith("tail batch"):
                 l = l.split(" pair_kernel=")[0]
                 tally[l] += 1
+            elif l.startswith("probe"):
+                if ": 0 pairs with a different flag" in l:
+                    tally["probe " + l.split(":")[0].split()[-2] + " " + l.split(":")[0].split()[-1] + ": second evaluation agrees"] += 1
+                else:
+                    print(l[:400])
             elif l.startswith("rep"):
                 tally["keep crc " + l.split("keep crc ")[1]] += 1
     for l, c in sorted(tally.items()):
