@@ -4,7 +4,7 @@ import os, sys, subprocess, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] != "child":
     P, reps = int(sys.argv[1]), int(sys.argv[2])
-    env = dict(os.environ, SD_TRACE="1")
+    env = dict(os.environ, SD_TRACE="1")        # (SD_LIB / SD_OPTS are passed on to tools/time_nms2d_bench.py)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "time_nms2d_bench.py"), str(reps)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(P)]
     tally = collections.Counter()
     for p in procs:
